@@ -1,0 +1,421 @@
+"""ctypes binding of oracle/liboracle.so — the CPU restatement of the reference path.
+
+TEST INFRASTRUCTURE ONLY (see pfhe_oracle.h): imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg, never by the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_u64p = C.POINTER(C.c_uint64)
+_u8p = C.POINTER(C.c_uint8)
+
+
+def build(native: bool = False, out_dir: str | None = None) -> str:
+    """Compile liboracle.so (gcc).  native=True builds a -march=native copy into out_dir."""
+    if not native:
+        subprocess.run(["make", "-s", "-C", _HERE, "liboracle.so"], check=True)
+        return os.path.join(_HERE, "liboracle.so")
+    out_dir = out_dir or _HERE
+    out = os.path.join(out_dir, "liboracle_native.so")
+    subprocess.run(
+        ["gcc", "-O3", "-march=native", "-fPIC", "-std=c11", "-shared", "-o", out,
+         os.path.join(_HERE, "pfhe_oracle.c")],
+        check=True,
+    )
+    return out
+
+
+def _load(path: str | None = None) -> C.CDLL:
+    path = path or os.path.join(_HERE, "liboracle.so")
+    if not os.path.exists(path):
+        build()
+    lib = C.CDLL(path)
+    u64, sz, u32, vp, ci = C.c_uint64, C.c_size_t, C.c_uint32, C.c_void_p, C.c_int
+
+    def sig(name, res, *args):
+        f = getattr(lib, name)
+        f.restype = res
+        f.argtypes = list(args)
+
+    sig("orc_reduce_once", u64, u64, u64)
+    sig("orc_shoup_quotient", u64, u64, u64)
+    sig("orc_mul_mod_lazy", u64, u64, u64, u64, u64)
+    sig("orc_mul_mod_lazy32", u64, u64, u64, u64, u64)
+    sig("orc_shoup_mul", u64, u64, u64, u64, u64)
+    sig("orc_barrett_new", ci, u64, vp)
+    sig("orc_barrett_lazy_reduce_wide", u64, vp, u64, u64)
+    sig("orc_barrett_reduce_wide", u64, vp, u64, u64)
+    sig("orc_barrett_reduce", u64, vp, u64)
+    sig("orc_barrett_mul", u64, vp, u64, u64)
+    sig("orc_barrett_mul_add", u64, vp, u64, u64, u64)
+    sig("orc_reduce_add", u64, u64, u64, u64)
+    sig("orc_reduce_sub", u64, u64, u64, u64)
+    sig("orc_pow_mod", u64, u64, u64, u64)
+    sig("orc_inv_mod", u64, u64, u64)
+    sig("orc_reduce_mul_slice_assign", None, u64, _u64p, _u64p, sz)
+    sig("orc_reduce_add_mul_slice_assign", None, u64, _u64p, _u64p, _u64p, sz)
+    sig("orc_minimal_primitive_root", ci, u32, u64, _u64p)
+
+    sig("orc_u64_ntt_new", ci, u32, u64, C.POINTER(vp))
+    sig("orc_u64_ntt_free", None, vp)
+    for g in ("n",):
+        sig("orc_u64_ntt_" + g, sz, vp)
+    for g in ("modulus", "root", "inv_root", "inv_n", "inv_n_w"):
+        sig("orc_u64_ntt_" + g, u64, vp)
+    for g in ("roots", "roots_precon64", "inv_roots", "inv_roots_precon64", "ordinal_roots"):
+        sig("orc_u64_ntt_" + g, _u64p, vp)
+    sig("orc_u64_ntt_scalar_forward", None, vp, _u64p, u32, u32)
+    sig("orc_u64_ntt_scalar_inverse", None, vp, _u64p, u32, u32)
+    for g in ("transform_slice", "inverse_transform_slice", "lazy_transform_slice",
+              "lazy_inverse_transform_slice"):
+        sig("orc_u64_ntt_" + g, None, vp, _u64p)
+        sig("orc_uint_ntt_" + g, None, vp, _u64p)
+    sig("orc_u64_ntt_transform_monomial", None, vp, u64, sz, _u64p)
+    sig("orc_u64_ntt_transform_coeff_one_monomial", None, vp, sz, _u64p)
+    sig("orc_u64_ntt_transform_coeff_minus_one_monomial", None, vp, sz, _u64p)
+    sig("orc_uint_ntt_new", ci, u32, u64, C.POINTER(vp))
+    sig("orc_uint_ntt_free", None, vp)
+    sig("orc_uint_ntt_transform_monomial", None, vp, u64, sz, _u64p)
+
+    sig("orc_dcrt_new", ci, u32, _u64p, sz, C.POINTER(vp))
+    sig("orc_dcrt_free", None, vp)
+    sig("orc_dcrt_poly_length", sz, vp)
+    sig("orc_dcrt_moduli_count", sz, vp)
+    sig("orc_dcrt_table", vp, vp, sz)
+    sig("orc_dcrt_transform_slice", None, vp, _u64p)
+    sig("orc_dcrt_inverse_transform_slice", None, vp, _u64p)
+    sig("orc_dcrt_poly_mul_assign", None, vp, _u64p, _u64p)
+    sig("orc_dcrt_poly_add_mul_assign", None, vp, _u64p, _u64p, _u64p)
+    sig("orc_naive_negacyclic_mul", None, u64, _u64p, _u64p, _u64p, sz)
+
+    sig("orc_rns_new", ci, _u64p, sz, C.POINTER(vp))
+    sig("orc_rns_free", None, vp)
+    sig("orc_rns_moduli_count", sz, vp)
+    sig("orc_rns_value_len", sz, vp)
+    sig("orc_rns_moduli_product", _u64p, vp)
+    sig("orc_rns_punctured_product", _u64p, vp)
+    sig("orc_rns_compose_to", None, vp, _u64p, _u64p)
+    sig("orc_rns_compose_multiple_values_to", None, vp, _u64p, _u64p, sz)
+    sig("orc_rns_decompose_to", None, vp, _u64p, _u64p)
+    sig("orc_rns_decompose_big_uint_values_to", None, vp, _u64p, _u64p, sz)
+    sig("orc_rns_wrapping_decompose_small_values_to", None, vp, _u64p, _u64p, sz, u64)
+
+    sig("orc_basis_new", ci, vp, u32, sz, C.POINTER(vp))
+    sig("orc_basis_free", None, vp)
+    sig("orc_basis_decompose_length", sz, vp)
+    sig("orc_basis_log_basis", u32, vp)
+    sig("orc_basis_drop_bits", u32, vp)
+    sig("orc_basis_basis_value", u64, vp)
+    sig("orc_basis_init_mode", ci, vp)
+    for g in ("threshold", "adjust_add", "scalars", "scalars_residue"):
+        sig("orc_basis_" + g, _u64p, vp)
+    sig("orc_basis_init_value_carry_slice_inplace", None, vp, _u64p, _u8p, sz)
+    sig("orc_basis_unsigned_decompose_slice_to", None, vp, sz, _u64p, _u64p, _u8p, sz)
+    sig("orc_add_dcrt_glev_mul_crt_poly_assign", None, vp, vp, vp, sz, _u64p, _u64p, _u64p)
+    sig("orc_mul_dcrt_ggsw_to", None, vp, vp, vp, sz, _u64p, _u64p, _u64p)
+    return lib
+
+
+_lib: C.CDLL | None = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def use_library(path: str) -> None:
+    """Switch to another build (e.g. the -march=native copy for the CPU baseline)."""
+    global _lib
+    _lib = _load(path)
+
+
+class OracleError(Exception):
+    def __init__(self, code: int):
+        super().__init__(f"oracle status {code}")
+        self.code = code
+
+
+def _p(a: np.ndarray):
+    assert a.dtype == np.uint64 and a.flags.c_contiguous
+    return a.ctypes.data_as(_u64p)
+
+
+def _arr(ptr, n) -> np.ndarray:
+    return np.ctypeslib.as_array(ptr, shape=(n,)).copy()
+
+
+class Barrett:
+    """BarrettModulus<u64> (primus_modulus/src/barrett/mod.rs)."""
+
+    def __init__(self, q: int):
+        self._buf = (C.c_uint64 * 3)()
+        rc = lib().orc_barrett_new(q, C.addressof(self._buf))
+        if rc:
+            raise OracleError(rc)
+        self.value = q
+        self.ratio = (int(self._buf[1]), int(self._buf[2]))
+
+    def _h(self):
+        return C.addressof(self._buf)
+
+    def lazy_reduce_wide(self, lo, hi): return int(lib().orc_barrett_lazy_reduce_wide(self._h(), lo, hi))
+    def reduce_wide(self, lo, hi): return int(lib().orc_barrett_reduce_wide(self._h(), lo, hi))
+    def reduce(self, v): return int(lib().orc_barrett_reduce(self._h(), v))
+    def reduce_mul(self, a, b): return int(lib().orc_barrett_mul(self._h(), a, b))
+    def reduce_mul_add(self, a, b, c): return int(lib().orc_barrett_mul_add(self._h(), a, b, c))
+
+
+def minimal_primitive_root(log_degree: int, q: int) -> int:
+    r = C.c_uint64(0)
+    rc = lib().orc_minimal_primitive_root(log_degree, q, C.byref(r))
+    if rc:
+        raise OracleError(rc)
+    return int(r.value)
+
+
+class U64NttTable:
+    """primus_ntt::U64NttTable, scalar backend (prime64/table.rs, scalar/transform.rs)."""
+
+    def __init__(self, log_n: int, q: int, _handle=None):
+        self._own = _handle is None
+        if _handle is None:
+            h = C.c_void_p()
+            rc = lib().orc_u64_ntt_new(log_n, q, C.byref(h))
+            if rc:
+                raise OracleError(rc)
+            _handle = h
+        self._h = _handle
+        self.n = int(lib().orc_u64_ntt_n(self._h))
+        self.log_n = log_n
+        self.q = int(lib().orc_u64_ntt_modulus(self._h))
+
+    def __del__(self):
+        if getattr(self, "_own", False) and getattr(self, "_h", None):
+            lib().orc_u64_ntt_free(self._h)
+            self._h = None
+
+    root = property(lambda s: int(lib().orc_u64_ntt_root(s._h)))
+    inv_root = property(lambda s: int(lib().orc_u64_ntt_inv_root(s._h)))
+    inv_n = property(lambda s: int(lib().orc_u64_ntt_inv_n(s._h)))
+    inv_n_w = property(lambda s: int(lib().orc_u64_ntt_inv_n_w(s._h)))
+    roots = property(lambda s: _arr(lib().orc_u64_ntt_roots(s._h), s.n))
+    roots_precon64 = property(lambda s: _arr(lib().orc_u64_ntt_roots_precon64(s._h), s.n))
+    inv_roots = property(lambda s: _arr(lib().orc_u64_ntt_inv_roots(s._h), s.n))
+    inv_roots_precon64 = property(lambda s: _arr(lib().orc_u64_ntt_inv_roots_precon64(s._h), s.n))
+    ordinal_roots = property(lambda s: _arr(lib().orc_u64_ntt_ordinal_roots(s._h), 2 * s.n))
+
+    def _each(self, fn, a: np.ndarray):
+        assert a.size % self.n == 0
+        flat = a.reshape(-1)
+        base = flat.ctypes.data
+        for i in range(flat.size // self.n):
+            fn(self._h, C.cast(base + 8 * self.n * i, _u64p))
+
+    def transform_slice(self, a): self._each(lib().orc_u64_ntt_transform_slice, a)
+    def inverse_transform_slice(self, a): self._each(lib().orc_u64_ntt_inverse_transform_slice, a)
+    def lazy_transform_slice(self, a): self._each(lib().orc_u64_ntt_lazy_transform_slice, a)
+    def lazy_inverse_transform_slice(self, a): self._each(lib().orc_u64_ntt_lazy_inverse_transform_slice, a)
+
+    def scalar_forward(self, a, bit_shift, output_mod_factor):
+        lib().orc_u64_ntt_scalar_forward(self._h, _p(a), bit_shift, output_mod_factor)
+
+    def scalar_inverse(self, a, bit_shift, output_mod_factor):
+        lib().orc_u64_ntt_scalar_inverse(self._h, _p(a), bit_shift, output_mod_factor)
+
+    def transform_monomial(self, coeff, degree):
+        out = np.empty(self.n, np.uint64)
+        lib().orc_u64_ntt_transform_monomial(self._h, coeff, degree, _p(out))
+        return out
+
+    def transform_coeff_one_monomial(self, degree):
+        out = np.empty(self.n, np.uint64)
+        lib().orc_u64_ntt_transform_coeff_one_monomial(self._h, degree, _p(out))
+        return out
+
+    def transform_coeff_minus_one_monomial(self, degree):
+        out = np.empty(self.n, np.uint64)
+        lib().orc_u64_ntt_transform_coeff_minus_one_monomial(self._h, degree, _p(out))
+        return out
+
+
+class UintNttTable:
+    """primus_ntt::UintNttTable<u64> (ntt/primitive.rs) — the reference's own cross-check."""
+
+    def __init__(self, log_n: int, q: int):
+        h = C.c_void_p()
+        rc = lib().orc_uint_ntt_new(log_n, q, C.byref(h))
+        if rc:
+            raise OracleError(rc)
+        self._h = h
+        self.n = 1 << log_n
+        self.q = q
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_uint_ntt_free(self._h)
+            self._h = None
+
+    def transform_slice(self, a): lib().orc_uint_ntt_transform_slice(self._h, _p(a))
+    def inverse_transform_slice(self, a): lib().orc_uint_ntt_inverse_transform_slice(self._h, _p(a))
+    def lazy_transform_slice(self, a): lib().orc_uint_ntt_lazy_transform_slice(self._h, _p(a))
+    def lazy_inverse_transform_slice(self, a): lib().orc_uint_ntt_lazy_inverse_transform_slice(self._h, _p(a))
+
+    def transform_monomial(self, coeff, degree):
+        out = np.empty(self.n, np.uint64)
+        lib().orc_uint_ntt_transform_monomial(self._h, coeff, degree, _p(out))
+        return out
+
+
+class U64DcrtTable:
+    """primus_ntt::U64DcrtTable (dcrt/prime64.rs): modulus-major L x N words per polynomial."""
+
+    def __init__(self, log_n: int, moduli):
+        self.moduli = [int(m) for m in moduli]
+        arr = np.array(self.moduli, np.uint64)
+        h = C.c_void_p()
+        rc = lib().orc_dcrt_new(log_n, _p(arr), len(self.moduli), C.byref(h))
+        if rc:
+            raise OracleError(rc)
+        self._h = h
+        self.log_n = log_n
+        self.n = 1 << log_n
+        self.count = len(self.moduli)
+        self.crt_poly_length = self.n * self.count
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_dcrt_free(self._h)
+            self._h = None
+
+    def table(self, i) -> U64NttTable:
+        return U64NttTable(self.log_n, self.moduli[i], _handle=C.c_void_p(lib().orc_dcrt_table(self._h, i)))
+
+    def _each(self, fn, a):
+        W = self.crt_poly_length
+        assert a.size % W == 0
+        flat = a.reshape(-1)
+        base = flat.ctypes.data
+        for i in range(flat.size // W):
+            fn(self._h, C.cast(base + 8 * W * i, _u64p))
+
+    def transform_slice(self, a): self._each(lib().orc_dcrt_transform_slice, a)
+    def inverse_transform_slice(self, a): self._each(lib().orc_dcrt_inverse_transform_slice, a)
+
+    def mul_assign(self, a, b):
+        lib().orc_dcrt_poly_mul_assign(self._h, _p(a), _p(b))
+
+    def add_mul_assign(self, acc, a, b):
+        lib().orc_dcrt_poly_add_mul_assign(self._h, _p(acc), _p(a), _p(b))
+
+
+def naive_negacyclic_mul(q, a, b):
+    out = np.empty_like(a)
+    lib().orc_naive_negacyclic_mul(q, _p(a), _p(b), _p(out), a.size)
+    return out
+
+
+class RNSBase:
+    """primus_rns::RNSBase<u64, BarrettModulus<u64>> (base.rs)."""
+
+    def __init__(self, moduli):
+        self.moduli = [int(m) for m in moduli]
+        arr = np.array(self.moduli, np.uint64)
+        h = C.c_void_p()
+        rc = lib().orc_rns_new(_p(arr) if len(arr) else None, len(self.moduli), C.byref(h))
+        if rc:
+            raise OracleError(rc)
+        self._h = h
+        self.count = len(self.moduli)
+        self.value_len = int(lib().orc_rns_value_len(h))
+        self.moduli_product = _arr(lib().orc_rns_moduli_product(h), self.value_len)
+        self.punctured_product = _arr(lib().orc_rns_punctured_product(h), self.value_len * self.count)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_rns_free(self._h)
+            self._h = None
+
+    def compose(self, residues):
+        r = np.array(residues, np.uint64)
+        out = np.empty(self.value_len, np.uint64)
+        lib().orc_rns_compose_to(self._h, _p(r), _p(out))
+        return out
+
+    def compose_multiple_values_to(self, multi_residues, value_count):
+        out = np.empty(value_count * self.value_len, np.uint64)
+        lib().orc_rns_compose_multiple_values_to(self._h, _p(multi_residues), _p(out), value_count)
+        return out
+
+    def decompose(self, value):
+        out = np.empty(self.count, np.uint64)
+        lib().orc_rns_decompose_to(self._h, _p(np.ascontiguousarray(value, np.uint64)), _p(out))
+        return out
+
+    def decompose_big_uint_values_to(self, values, value_count):
+        out = np.empty(self.count * value_count, np.uint64)
+        lib().orc_rns_decompose_big_uint_values_to(self._h, _p(values), _p(out), value_count)
+        return out
+
+    def wrapping_decompose_small_values_to(self, small_values, small_value_modulus):
+        sv = np.ascontiguousarray(small_values, np.uint64)
+        out = np.empty(self.count * sv.size, np.uint64)
+        lib().orc_rns_wrapping_decompose_small_values_to(self._h, _p(sv), _p(out), sv.size, small_value_modulus)
+        return out
+
+
+class BigUintApproxSignedBasis:
+    """primus_decompose::big_integer::BigUintApproxSignedBasis<u64> (basis.rs, common.rs)."""
+
+    def __init__(self, rns: RNSBase, log_basis: int, reverse_length: int | None = None):
+        h = C.c_void_p()
+        rc = lib().orc_basis_new(rns._h, log_basis, reverse_length or 0, C.byref(h))
+        if rc:
+            raise OracleError(rc)
+        self._h = h
+        self.rns = rns
+        self.decompose_length = int(lib().orc_basis_decompose_length(h))
+        self.log_basis = int(lib().orc_basis_log_basis(h))
+        self.drop_bits = int(lib().orc_basis_drop_bits(h))
+        self.basis_value = int(lib().orc_basis_basis_value(h))
+        self.init_mode = int(lib().orc_basis_init_mode(h))
+        L = rns.value_len
+        self.threshold = _arr(lib().orc_basis_threshold(h), L)
+        self.adjust_add = _arr(lib().orc_basis_adjust_add(h), L)
+        self.scalars = _arr(lib().orc_basis_scalars(h), L * self.decompose_length)
+        self.scalars_residue = _arr(lib().orc_basis_scalars_residue(h), rns.count * self.decompose_length)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_basis_free(self._h)
+            self._h = None
+
+    def init_value_carry_slice_inplace(self, values, count):
+        carries = np.zeros(count, np.uint8)
+        lib().orc_basis_init_value_carry_slice_inplace(self._h, _p(values), carries.ctypes.data_as(_u8p), count)
+        return carries
+
+    def unsigned_decompose_slice_to(self, level, values, carries, count):
+        digits = np.empty(count, np.uint64)
+        lib().orc_basis_unsigned_decompose_slice_to(self._h, level, _p(values), _p(digits),
+                                                    carries.ctypes.data_as(_u8p), count)
+        return digits
+
+
+def add_dcrt_glev_mul_crt_poly_assign(table: U64DcrtTable, rns: RNSBase, basis, k, acc, glev, crt_poly):
+    lib().orc_add_dcrt_glev_mul_crt_poly_assign(table._h, rns._h, basis._h, k, _p(acc), _p(glev), _p(crt_poly))
+
+
+def mul_dcrt_ggsw_to(table: U64DcrtTable, rns: RNSBase, basis, k, crt_glwe, dcrt_ggsw):
+    """CrtGlwe::mul_dcrt_ggsw_to; returns the DcrtGlwe result ((k+1)*L*N words, NTT form)."""
+    out = np.empty((k + 1) * table.crt_poly_length, np.uint64)
+    lib().orc_mul_dcrt_ggsw_to(table._h, rns._h, basis._h, k, _p(crt_glwe), _p(dcrt_ggsw), _p(out))
+    return out
