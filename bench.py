@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the primus-fhe hot path on MI355X.
+
+Metric (BASELINE.json): NTT/sec (+ RLWE external-products/sec) at N = 2^16, 3-prime RNS, and the
+fraction of the HBM roofline.  One "step" = one forward RNS NTT (U64DcrtTable::transform_slice,
+primus_ntt/src/dcrt/prime64.rs:106) over a batch of 4096 RNS polynomials = 12 288 limb-NTTs of
+2^16 words, in place, inputs resident in HBM (BASELINE.md config 3').  Independent polynomials
+shard across GPUs with no collective: each rank owns its own batch of 4096
+("weak" scaling); torch.distributed is used only for the timing barrier.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  Extra legs on rank 0 at N = 1: per-kernel HIP-event timing for the
+roofline object, the fused NTT->mul->INTT rate (config 3), and a bounded CPU run of the oracle
+(the C restatement of the reference's scalar path) for `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+Q61 = [2305843009211596801, 2305843009210023937, 2305843009208713217]
+LOG_N = 16
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096, help="RNS polynomials per GPU (default: BASELINE config 3')")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(seconds: float):
+    """All-core throughput of the oracle's forward NTT at N=2^16 (one limb-NTT per task).
+
+    kind = "port": the reference is Rust and cannot be built here; this is the C restatement of
+    its scalar path (an AVX-512 host would run the reference's IFMA/DQ kernels faster).
+    """
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import oracle
+
+    try:
+        tmp = tempfile.mkdtemp(prefix="pfhe_oracle_")
+        oracle.use_library(oracle.build(native=True, out_dir=tmp))
+    except Exception:
+        oracle.build()
+    cores = os.cpu_count() or 1
+    n = 1 << LOG_N
+    tabs = [oracle.U64NttTable(LOG_N, q) for q in Q61]
+    rng = np.random.default_rng(1)
+    per_task = 4
+    bufs = [rng.integers(0, Q61[i % 3], n * per_task, dtype=np.uint64) for i in range(cores)]
+
+    def work(i):
+        tabs[i % 3].transform_slice(bufs[i])  # ctypes releases the GIL
+        return per_task
+
+    # single thread first
+    t0 = time.perf_counter()
+    done1 = 0
+    while time.perf_counter() - t0 < min(2.0, seconds / 4):
+        done1 += work(0)
+    single = done1 / (time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    done = 0
+    with ThreadPoolExecutor(cores) as ex:
+        while time.perf_counter() - t0 < seconds * 0.75:
+            done += sum(ex.map(work, range(cores)))
+    dt = time.perf_counter() - t0
+    return {
+        "value": done / dt, "unit": "NTT/s", "cores": cores, "kind": "port",
+        "single_thread_value": single,
+        "sample": f"{done} forward limb-NTTs of N=2^16 (61-bit primes), oracle scalar Harvey path, "
+                  f"{cores} threads, {dt:.1f} s",
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+
+    import primus_fhe_amd as p
+    from primus_fhe_amd._lib import check, u64p
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback); use gpurun")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n, L, batch = 1 << LOG_N, 3, args.batch
+    words = batch * L * n
+    table = p.U64DcrtTable(LOG_N, Q61, device=local_rank)
+    x = torch.empty(words, dtype=torch.int64, device="cuda")
+    mods = np.array(Q61, np.uint64)
+    check(p.lib().pfhe_fill_uniform_dev(local_rank, C.c_void_p(x.data_ptr()), words, mods.ctypes.data_as(u64p), L, n,
+                                        0x5EED000000000003 + rank, None))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        # forward transform of a canonical batch; the output of one step (canonical, bit-reversed
+        # order) is a valid input of the next, so the timed loop needs no re-initialisation
+        table.transform_dev(x)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    limb_ntts = world * batch * L * args.steps
+    value = limb_ntts / dt
+    result = {
+        "metric": "NTT/sec at N=2^16, 3-prime RNS (forward limb-NTTs, batch 4096 RNS polynomials per GPU)",
+        "value": value, "unit": "NTT/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2] shape: N=2^16, 3-prime RNS (61-bit), batch=%d per GPU, "
+                               "forward DCRT NTT in place (config 3')" % batch,
+                   "log_n": LOG_N, "moduli": Q61, "batch_per_gpu": batch, "sharding": "batch, no collectives"},
+        "hbm_roofline_frac": value * 16 * n / world / (HBM_PEAK_GBS * 1e9),
+    }
+
+    if rank == 0 and world == 1:
+        # ---- per-kernel timing (HIP events on the launch stream) for the roofline object ----
+        npass = p.lib().pfhe_dcrt_transform_num_passes(table._h)
+        stream = torch.cuda.current_stream()
+        per_pass = []
+        for i in range(npass):
+            name = p.lib().pfhe_dcrt_transform_pass_name(table._h, 0, i).decode()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = max(3, args.steps)
+            check(p.lib().pfhe_dcrt_transform_pass_dev(table._h, C.c_void_p(x.data_ptr()), words, 0, i, 0,
+                                                       C.c_void_p(stream.cuda_stream)))
+            e0.record(stream)
+            for _ in range(reps):
+                check(p.lib().pfhe_dcrt_transform_pass_dev(table._h, C.c_void_p(x.data_ptr()), words, 0, i, 0,
+                                                           C.c_void_p(stream.cuda_stream)))
+            e1.record(stream)
+            e1.synchronize()
+            per_pass.append((name, e0.elapsed_time(e1) / reps))
+        dom = max(per_pass, key=lambda t: t[1])
+        alg_bytes = 16 * n * batch * L  # each pass reads and writes every coefficient once
+        achieved = alg_bytes / (dom[1] * 1e-3) / 1e9
+        result["roofline"] = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                              "avg_launch_ms": dom[1], "algorithmic_bytes_per_launch": alg_bytes}
+        result["kernels_ms"] = {k: v for k, v in per_pass}
+        # ---- config 3: fused NTT -> pointwise mul (shared multiplicand) -> INTT ----
+        bhat = torch.empty(L * n, dtype=torch.int64, device="cuda")
+        check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(bhat.data_ptr()), L * n, mods.ctypes.data_as(u64p), L, n,
+                                            77, None))
+        table.mul_dcrt_polynomial_dev(x, bhat)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = max(2, args.steps // 2)
+        for _ in range(reps):
+            table.mul_dcrt_polynomial_dev(x, bhat)
+        torch.cuda.synchronize()
+        dtp = (time.perf_counter() - t0) / reps
+        result["polymul"] = {"value": batch / dtp, "unit": "RNS polynomial products/s (NTT+mul+INTT, shared multiplicand)",
+                             "ms_per_batch": dtp * 1e3, "hbm_roofline_frac": batch / dtp * 48 * n / (HBM_PEAK_GBS * 1e9)}
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,127 @@
+"""ctypes loader for libpfhe_hip.so (the C ABI declared in include/pfhe.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libpfhe_hip.so")
+
+u64p = C.POINTER(C.c_uint64)
+
+STATUS = {
+    0: "OK", 1: "NoPrimitiveRoot", 2: "DegreeConversionErr", 3: "DegreeTooLarge", 4: "NttTableErr",
+    5: "ModulusTooLarge", 16: "EmptyBase", 17: "CoPrimeError", 18: "UnrepresentableModulus",
+    32: "BadLength", 33: "BadArgument", 34: "NoDevice", 35: "HipError", 36: "Unsupported",
+}
+
+
+class PfheError(RuntimeError):
+    """A non-zero pfhe_status returned by the C ABI."""
+
+    def __init__(self, code: int, detail: str = ""):
+        self.code = code
+        self.kind = STATUS.get(code, f"status{code}")
+        super().__init__(f"{self.kind} ({code}): {detail}" if detail else f"{self.kind} ({code})")
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def build(jobs: int = 8) -> str:
+    """Compile every HIP source for gfx950 into primus-fhe_amd/libpfhe_hip.so (in-tree)."""
+    subprocess.run(["make", "-s", f"-j{jobs}", "-C", _HERE, "libpfhe_hip.so"], check=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def _declare(lib: C.CDLL) -> None:
+    vp, sz, u32, u64, ci = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64, C.c_int
+
+    def sig(name, res, *args):
+        f = getattr(lib, name)
+        f.restype = res
+        f.argtypes = list(args)
+
+    sig("pfhe_status_string", C.c_char_p, ci)
+    sig("pfhe_last_error", C.c_char_p)
+    sig("pfhe_version", C.c_char_p)
+    sig("pfhe_device_count", ci, C.POINTER(ci))
+    sig("pfhe_device_malloc", ci, ci, sz, C.POINTER(vp))
+    sig("pfhe_device_free", ci, ci, vp)
+    sig("pfhe_memcpy_h2d", ci, ci, vp, vp, sz, vp)
+    sig("pfhe_memcpy_d2h", ci, ci, vp, vp, sz, vp)
+    sig("pfhe_memcpy_d2d", ci, ci, vp, vp, sz, vp)
+    sig("pfhe_memset_dev", ci, ci, vp, ci, sz, vp)
+    sig("pfhe_stream_synchronize", ci, ci, vp)
+    sig("pfhe_fill_uniform_dev", ci, ci, vp, sz, u64p, sz, sz, u64, vp)
+
+    sig("pfhe_ntt_create", ci, u32, u64, ci, C.POINTER(vp))
+    sig("pfhe_ntt_destroy", None, vp)
+    sig("pfhe_ntt_poly_length", sz, vp)
+    sig("pfhe_ntt_log_n", u32, vp)
+    for g in ("modulus", "root", "inv_root", "inv_n"):
+        sig("pfhe_ntt_" + g, u64, vp)
+    sig("pfhe_ntt_device", ci, vp)
+    for g in ("transform_slice", "inverse_transform_slice", "lazy_transform_slice",
+              "lazy_inverse_transform_slice"):
+        sig("pfhe_ntt_" + g, ci, vp, vp, sz)
+        sig("pfhe_dcrt_" + g, ci, vp, vp, sz)
+    sig("pfhe_ntt_transform_monomial", ci, vp, u64, sz, vp, sz)
+    sig("pfhe_ntt_transform_coeff_one_monomial", ci, vp, sz, vp, sz)
+    sig("pfhe_ntt_transform_coeff_minus_one_monomial", ci, vp, sz, vp, sz)
+    sig("pfhe_ntt_transform_dev", ci, vp, vp, sz, ci, vp)
+    sig("pfhe_ntt_inverse_transform_dev", ci, vp, vp, sz, ci, vp)
+    sig("pfhe_ntt_transform_monomial_dev", ci, vp, u64, sz, vp, sz, vp)
+    sig("pfhe_ntt_mul_assign_dev", ci, vp, vp, sz, vp, sz, vp)
+    sig("pfhe_ntt_add_mul_assign_dev", ci, vp, vp, vp, sz, vp, sz, vp)
+
+    sig("pfhe_dcrt_create", ci, u32, u64p, sz, ci, C.POINTER(vp))
+    sig("pfhe_dcrt_destroy", None, vp)
+    for g in ("poly_length", "moduli_count", "crt_poly_length"):
+        sig("pfhe_dcrt_" + g, sz, vp)
+    sig("pfhe_dcrt_device", ci, vp)
+    for g in ("modulus", "root", "inv_n"):
+        sig("pfhe_dcrt_" + g, u64, vp, sz)
+    sig("pfhe_dcrt_transform_monomial", ci, vp, u64, sz, vp, sz)
+    sig("pfhe_dcrt_transform_dev", ci, vp, vp, sz, ci, vp)
+    sig("pfhe_dcrt_inverse_transform_dev", ci, vp, vp, sz, ci, vp)
+    sig("pfhe_dcrt_mul_assign_dev", ci, vp, vp, sz, vp, sz, vp)
+    sig("pfhe_dcrt_add_mul_assign_dev", ci, vp, vp, vp, sz, vp, sz, vp)
+    sig("pfhe_dcrt_mul_dcrt_polynomial_dev", ci, vp, vp, sz, vp, sz, vp)
+    sig("pfhe_dcrt_transform_num_passes", ci, vp)
+    sig("pfhe_dcrt_transform_pass_name", C.c_char_p, vp, ci, ci)
+    sig("pfhe_dcrt_transform_pass_dev", ci, vp, vp, sz, ci, ci, ci, vp)
+
+
+def lib() -> C.CDLL:
+    """Load libpfhe_hip.so.  Fails loudly when it has not been built — there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise ImportError(
+                f"{_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  primus_fhe_amd has no CPU fallback.")
+        try:
+            # torch ships its own libamdhip64.so.7; load it first when torch is importable so
+            # that one HIP runtime serves both torch (device memory, streams) and this library.
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is optional for the C ABI itself
+            pass
+        l = C.CDLL(_LIB_PATH)
+        _declare(l)
+        _lib = l
+    return _lib
+
+
+def status_string(code: int) -> str:
+    return lib().pfhe_status_string(code).decode()
+
+
+def check(code: int) -> None:
+    if code != 0:
+        raise PfheError(code, lib().pfhe_last_error().decode(errors="replace"))

@@ -1,0 +1,564 @@
+// pfhe_capi.hip — extern "C" boundary (include/pfhe.h).  Validates arguments, owns handles,
+// never throws.  There is deliberately no CPU fallback: without a HIP device every create()
+// fails with PFHE_ERR_NO_DEVICE.
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+
+#include "pfhe_common.hpp"
+#include "pfhe_handles.hpp"
+#include "pfhe_ntt_device.hpp"
+#include "pfhe_pointwise.hpp"
+
+namespace pfhe {
+
+static thread_local std::string g_last_error;
+
+void set_last_error(const std::string &msg) { g_last_error = msg; }
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    char buf[512];
+    std::snprintf(buf, sizeof buf, "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    g_last_error = buf;
+    (void)hipGetLastError();  // clear the sticky error
+    return e == hipErrorNoDevice || e == hipErrorInvalidDevice ? PFHE_ERR_NO_DEVICE : PFHE_ERR_HIP;
+}
+
+DeviceGuard::DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) {
+        prev = -1;
+        (void)hipGetLastError();
+    }
+    ok = hipSetDevice(device) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+}
+DeviceGuard::~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+}
+
+static int check_device(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        set_last_error("no HIP device available (libpfhe_hip has no CPU fallback)");
+        return PFHE_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= count) {
+        set_last_error("device index out of range");
+        return PFHE_ERR_NO_DEVICE;
+    }
+    return PFHE_OK;
+}
+
+TableSet::~TableSet() {
+    DeviceGuard g(device);
+    for (void *p : allocations) (void)hipFree(p);
+}
+
+// Builds host tables for every modulus, uploads them, and fills `out`.
+int make_table_set(u32 log_n, const u64 *moduli, size_t count, int device, std::unique_ptr<TableSet> &out) {
+    if (count == 0) {
+        set_last_error("empty modulus list");
+        return PFHE_ERR_BAD_ARGUMENT;
+    }
+    std::vector<HostTable> host(count);
+    for (size_t i = 0; i < count; ++i) PFHE_TRY(build_host_table(log_n, moduli[i], host[i]));
+    PFHE_TRY(check_device(device));
+    DeviceGuard g(device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+
+    auto ts = std::make_unique<TableSet>();
+    ts->device = device;
+    ts->log_n = log_n;
+    ts->n = (size_t)1 << log_n;
+    ts->L = (u32)count;
+    ts->primes.resize(count);
+    const size_t bytes = ts->n * sizeof(ulonglong2);
+    for (size_t i = 0; i < count; ++i) {
+        void *fwd = nullptr, *inv = nullptr;
+        PFHE_HIP(hipMalloc(&fwd, bytes));
+        ts->allocations.push_back(fwd);
+        PFHE_HIP(hipMalloc(&inv, bytes));
+        ts->allocations.push_back(inv);
+        PFHE_HIP(hipMemcpy(fwd, host[i].fwd.data(), bytes, hipMemcpyHostToDevice));
+        PFHE_HIP(hipMemcpy(inv, host[i].inv.data(), bytes, hipMemcpyHostToDevice));
+        NttPrime &P = ts->primes[i];
+        P.q = host[i].q;
+        P.two_q = host[i].q << 1;
+        P.inv_n = host[i].inv_n;
+        P.inv_n_p = (u64)(((unsigned __int128)host[i].inv_n << 64) / host[i].q);
+        P.inv_n_w = host[i].inv_n_w;
+        P.inv_n_w_p = (u64)(((unsigned __int128)host[i].inv_n_w << 64) / host[i].q);
+        P.bar_lo = host[i].bar_lo;
+        P.bar_hi = host[i].bar_hi;
+        P.fwd = static_cast<const ulonglong2 *>(fwd);
+        P.inv = static_cast<const ulonglong2 *>(inv);
+        ts->roots.push_back(host[i].root);
+        ts->inv_roots.push_back(host[i].inv_root);
+    }
+    void *pd = nullptr;
+    PFHE_HIP(hipMalloc(&pd, count * sizeof(NttPrime)));
+    ts->allocations.push_back(pd);
+    PFHE_HIP(hipMemcpy(pd, ts->primes.data(), count * sizeof(NttPrime), hipMemcpyHostToDevice));
+    ts->primes_dev = static_cast<const NttPrime *>(pd);
+    void *md = nullptr;
+    PFHE_HIP(hipMalloc(&md, count * sizeof(u64)));
+    ts->allocations.push_back(md);
+    std::vector<u64> mods(moduli, moduli + count);
+    PFHE_HIP(hipMemcpy(md, mods.data(), count * sizeof(u64), hipMemcpyHostToDevice));
+    ts->moduli_dev = static_cast<const u64 *>(md);
+    out = std::move(ts);
+    return PFHE_OK;
+}
+
+// len must be a positive-or-zero multiple of the unit (L*N words)
+static int check_len(const TableSet &t, size_t len, u64 &units) {
+    const size_t unit = t.n * t.L;
+    if (len % unit != 0) {
+        set_last_error("slice length is not a multiple of the polynomial length");
+        return PFHE_ERR_BAD_LENGTH;
+    }
+    units = len / unit;
+    return PFHE_OK;
+}
+
+int transform_dev(const TableSet &t, u64 *data, size_t len, bool inverse, bool lazy, hipStream_t s) {
+    if (!data && len) return PFHE_ERR_BAD_ARGUMENT;
+    u64 units = 0;
+    PFHE_TRY(check_len(t, len, units));
+    DeviceGuard g(t.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    const u64 npolys = units * t.L;
+    return inverse ? ntt_inverse_dev(t.primes_dev, t.L, t.log_n, data, npolys, lazy, s)
+                   : ntt_forward_dev(t.primes_dev, t.L, t.log_n, data, npolys, lazy, s);
+}
+
+// host-pointer wrapper: stage through a temporary device buffer
+template <class F>
+static int with_staged(const TableSet &t, u64 *host, size_t len, bool copy_in, F &&f) {
+    if (!host && len) return PFHE_ERR_BAD_ARGUMENT;
+    u64 units = 0;
+    PFHE_TRY(check_len(t, len, units));
+    if (len == 0) return PFHE_OK;
+    DeviceGuard g(t.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    void *d = nullptr;
+    PFHE_HIP(hipMalloc(&d, len * sizeof(u64)));
+    int rc = PFHE_OK;
+    hipError_t e = hipSuccess;
+    if (copy_in) e = hipMemcpy(d, host, len * sizeof(u64), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = f(static_cast<u64 *>(d));
+        if (rc == PFHE_OK) e = hipMemcpy(host, d, len * sizeof(u64), hipMemcpyDeviceToHost);  // syncs
+    }
+    (void)hipFree(d);
+    if (e != hipSuccess) return hip_fail(e, "staged copy", __FILE__, __LINE__);
+    return rc;
+}
+
+int transform_host(const TableSet &t, u64 *host, size_t len, bool inverse, bool lazy) {
+    return with_staged(t, host, len, true, [&](u64 *d) { return transform_dev(t, d, len, inverse, lazy, nullptr); });
+}
+
+int pointwise(const TableSet &t, int mode, u64 *acc, const u64 *a, size_t len_a, const u64 *b, size_t len_b,
+              hipStream_t s) {
+    if ((!acc || !b || (mode == 1 && !a)) && len_a) return PFHE_ERR_BAD_ARGUMENT;
+    u64 units = 0;
+    PFHE_TRY(check_len(t, len_a, units));
+    if (len_b != len_a && len_b != t.n * t.L) {
+        set_last_error("multiplicand must have the same length or exactly one polynomial");
+        return PFHE_ERR_BAD_LENGTH;
+    }
+    DeviceGuard g(t.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    return pointwise_dev(mode, acc, a, b, t.primes_dev, t.L, t.log_n, len_a, len_b, s);
+}
+
+int monomial(const TableSet &t, u64 coeff, size_t degree, u64 *values, size_t len, bool host, hipStream_t s) {
+    if (!values) return PFHE_ERR_BAD_ARGUMENT;
+    if (len != t.n * t.L) {
+        set_last_error("monomial output must be exactly one polynomial");
+        return PFHE_ERR_BAD_LENGTH;
+    }
+    std::vector<u64> c(2 * t.L);
+    for (u32 i = 0; i < t.L; ++i) {
+        const u64 q = t.primes[i].q;
+        if (coeff >= q) {
+            set_last_error("monomial coefficient must be reduced modulo every modulus");
+            return PFHE_ERR_BAD_ARGUMENT;
+        }
+        c[i] = coeff;
+        c[t.L + i] = (u64)(((unsigned __int128)coeff << 64) / q);
+    }
+    DeviceGuard g(t.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    void *cd = nullptr;
+    PFHE_HIP(hipMalloc(&cd, c.size() * sizeof(u64)));
+    int rc = PFHE_OK;
+    hipError_t e = hipMemcpyAsync(cd, c.data(), c.size() * sizeof(u64), hipMemcpyHostToDevice, s);
+    void *out_dev = values;
+    if (e == hipSuccess && host) e = hipMalloc(&out_dev, len * sizeof(u64));
+    if (e == hipSuccess) {
+        const u64 deg = (u64)degree & (2 * (u64)t.n - 1);
+        rc = monomial_dev(static_cast<u64 *>(out_dev), t.primes_dev, t.L, t.log_n, deg, static_cast<u64 *>(cd),
+                          static_cast<u64 *>(cd) + t.L, s);
+        if (rc == PFHE_OK && host) e = hipMemcpy(values, out_dev, len * sizeof(u64), hipMemcpyDeviceToHost);
+        if (rc == PFHE_OK && e == hipSuccess) e = hipStreamSynchronize(s);  // c and cd must outlive the kernel
+    }
+    if (host && out_dev != values) (void)hipFree(out_dev);
+    (void)hipFree(cd);
+    if (e != hipSuccess) return hip_fail(e, "monomial transform", __FILE__, __LINE__);
+    return rc;
+}
+
+}  // namespace pfhe
+
+using namespace pfhe;
+
+struct pfhe_ntt {
+    std::unique_ptr<TableSet> t;
+};
+struct pfhe_dcrt {
+    std::unique_ptr<TableSet> t;
+};
+
+#define PFHE_GUARD_BEGIN try {
+#define PFHE_GUARD_END                                   \
+    }                                                    \
+    catch (const std::bad_alloc &) {                     \
+        set_last_error("out of host memory");            \
+        return PFHE_ERR_HIP;                             \
+    }                                                    \
+    catch (...) {                                        \
+        set_last_error("unexpected C++ exception");      \
+        return PFHE_ERR_HIP;                             \
+    }
+
+extern "C" {
+
+const char *pfhe_status_string(int status) {
+    switch (status) {
+        case PFHE_OK: return "ok";
+        case PFHE_ERR_NO_PRIMITIVE_ROOT: return "there is no primitive root with this degree and modulus";
+        case PFHE_ERR_DEGREE_CONVERSION: return "out of range integral type conversion attempted";
+        case PFHE_ERR_DEGREE_TOO_LARGE: return "degree should be less than modulus";
+        case PFHE_ERR_NTT_TABLE: return "failed to generate the desired ntt table";
+        case PFHE_ERR_MODULUS_TOO_LARGE: return "modulus is too large for this NTT table (max 62-bit supported)";
+        case PFHE_ERR_EMPTY_BASE: return "RNS base is empty";
+        case PFHE_ERR_COPRIME: return "RNS moduli are not pairwise coprime";
+        case PFHE_ERR_UNREPRESENTABLE_MODULUS: return "RNS modulus is not representable";
+        case PFHE_ERR_BAD_LENGTH: return "slice length does not match the table";
+        case PFHE_ERR_BAD_ARGUMENT: return "bad argument";
+        case PFHE_ERR_NO_DEVICE: return "no usable HIP device";
+        case PFHE_ERR_HIP: return "HIP runtime error";
+        case PFHE_ERR_UNSUPPORTED: return "unsupported parameter";
+    }
+    return "unknown status";
+}
+
+const char *pfhe_last_error(void) { return g_last_error.c_str(); }
+const char *pfhe_version(void) { return "libpfhe_hip 0.1.0 gfx950"; }
+
+int pfhe_device_count(int *count) {
+    if (!count) return PFHE_ERR_BAD_ARGUMENT;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) {
+        (void)hipGetLastError();
+        c = 0;
+    }
+    *count = c;
+    return PFHE_OK;
+}
+
+int pfhe_device_malloc(int device, size_t bytes, void **out) {
+    if (!out) return PFHE_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    PFHE_TRY(check_device(device));
+    DeviceGuard g(device);
+    if (bytes == 0) return PFHE_OK;
+    PFHE_HIP(hipMalloc(out, bytes));
+    return PFHE_OK;
+}
+
+int pfhe_device_free(int device, void *ptr) {
+    if (!ptr) return PFHE_OK;
+    PFHE_TRY(check_device(device));
+    DeviceGuard g(device);
+    PFHE_HIP(hipFree(ptr));
+    return PFHE_OK;
+}
+
+int pfhe_memcpy_h2d(int device, void *dst, const void *src, size_t bytes, void *stream) {
+    if (bytes == 0) return PFHE_OK;
+    if (!dst || !src) return PFHE_ERR_BAD_ARGUMENT;
+    PFHE_TRY(check_device(device));
+    DeviceGuard g(device);
+    PFHE_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    PFHE_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return PFHE_OK;
+}
+
+int pfhe_memcpy_d2h(int device, void *dst, const void *src, size_t bytes, void *stream) {
+    if (bytes == 0) return PFHE_OK;
+    if (!dst || !src) return PFHE_ERR_BAD_ARGUMENT;
+    PFHE_TRY(check_device(device));
+    DeviceGuard g(device);
+    PFHE_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    PFHE_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return PFHE_OK;
+}
+
+int pfhe_memcpy_d2d(int device, void *dst, const void *src, size_t bytes, void *stream) {
+    if (bytes == 0) return PFHE_OK;
+    if (!dst || !src) return PFHE_ERR_BAD_ARGUMENT;
+    PFHE_TRY(check_device(device));
+    DeviceGuard g(device);
+    PFHE_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return PFHE_OK;
+}
+
+int pfhe_memset_dev(int device, void *dst, int byte, size_t bytes, void *stream) {
+    if (bytes == 0) return PFHE_OK;
+    if (!dst) return PFHE_ERR_BAD_ARGUMENT;
+    PFHE_TRY(check_device(device));
+    DeviceGuard g(device);
+    PFHE_HIP(hipMemsetAsync(dst, byte, bytes, (hipStream_t)stream));
+    return PFHE_OK;
+}
+
+int pfhe_stream_synchronize(int device, void *stream) {
+    PFHE_TRY(check_device(device));
+    DeviceGuard g(device);
+    PFHE_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return PFHE_OK;
+}
+
+int pfhe_fill_uniform_dev(int device, uint64_t *dst, size_t len, const uint64_t *moduli, size_t moduli_count,
+                          size_t poly_len, uint64_t seed, void *stream) {
+    PFHE_GUARD_BEGIN
+    if (len == 0) return PFHE_OK;
+    if (!dst || !moduli || moduli_count == 0 || poly_len == 0) return PFHE_ERR_BAD_ARGUMENT;
+    PFHE_TRY(check_device(device));
+    DeviceGuard g(device);
+    void *md = nullptr;
+    PFHE_HIP(hipMalloc(&md, moduli_count * sizeof(u64)));
+    hipError_t e = hipMemcpy(md, moduli, moduli_count * sizeof(u64), hipMemcpyHostToDevice);
+    int rc = PFHE_OK;
+    if (e == hipSuccess) {
+        rc = fill_uniform_dev((u64 *)dst, len, (const u64 *)md, moduli_count, poly_len, seed, (hipStream_t)stream);
+        e = hipStreamSynchronize((hipStream_t)stream);
+    }
+    (void)hipFree(md);
+    if (e != hipSuccess) return hip_fail(e, "fill_uniform", __FILE__, __LINE__);
+    return rc;
+    PFHE_GUARD_END
+}
+
+/* ---------------------------- U64NttTable ---------------------------- */
+
+int pfhe_ntt_create(uint32_t log_n, uint64_t modulus, int device, pfhe_ntt **out) {
+    PFHE_GUARD_BEGIN
+    if (!out) return PFHE_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    std::unique_ptr<TableSet> t;
+    u64 q = modulus;
+    PFHE_TRY(make_table_set(log_n, &q, 1, device, t));
+    *out = new pfhe_ntt{std::move(t)};
+    return PFHE_OK;
+    PFHE_GUARD_END
+}
+
+void pfhe_ntt_destroy(pfhe_ntt *table) { delete table; }
+size_t pfhe_ntt_poly_length(const pfhe_ntt *t) { return t ? t->t->n : 0; }
+uint32_t pfhe_ntt_log_n(const pfhe_ntt *t) { return t ? t->t->log_n : 0; }
+uint64_t pfhe_ntt_modulus(const pfhe_ntt *t) { return t ? t->t->primes[0].q : 0; }
+uint64_t pfhe_ntt_root(const pfhe_ntt *t) { return t ? t->t->roots[0] : 0; }
+uint64_t pfhe_ntt_inv_root(const pfhe_ntt *t) { return t ? t->t->inv_roots[0] : 0; }
+uint64_t pfhe_ntt_inv_n(const pfhe_ntt *t) { return t ? t->t->primes[0].inv_n : 0; }
+int pfhe_ntt_device(const pfhe_ntt *t) { return t ? t->t->device : -1; }
+
+#define PFHE_NTT_HOST(name, INV, LAZY)                                          \
+    int name(const pfhe_ntt *table, uint64_t *p, size_t len) {                  \
+        PFHE_GUARD_BEGIN                                                        \
+        if (!table) return PFHE_ERR_BAD_ARGUMENT;                               \
+        return transform_host(*table->t, (u64 *)p, len, INV, LAZY);             \
+        PFHE_GUARD_END                                                          \
+    }
+PFHE_NTT_HOST(pfhe_ntt_transform_slice, false, false)
+PFHE_NTT_HOST(pfhe_ntt_inverse_transform_slice, true, false)
+PFHE_NTT_HOST(pfhe_ntt_lazy_transform_slice, false, true)
+PFHE_NTT_HOST(pfhe_ntt_lazy_inverse_transform_slice, true, true)
+#undef PFHE_NTT_HOST
+
+int pfhe_ntt_transform_monomial(const pfhe_ntt *table, uint64_t coeff, size_t degree, uint64_t *values,
+                                size_t len) {
+    PFHE_GUARD_BEGIN
+    if (!table) return PFHE_ERR_BAD_ARGUMENT;
+    return monomial(*table->t, coeff, degree, (u64 *)values, len, true, nullptr);
+    PFHE_GUARD_END
+}
+
+int pfhe_ntt_transform_coeff_one_monomial(const pfhe_ntt *table, size_t degree, uint64_t *values, size_t len) {
+    return pfhe_ntt_transform_monomial(table, 1, degree, values, len);
+}
+
+int pfhe_ntt_transform_coeff_minus_one_monomial(const pfhe_ntt *table, size_t degree, uint64_t *values,
+                                                size_t len) {
+    if (!table) return PFHE_ERR_BAD_ARGUMENT;
+    return pfhe_ntt_transform_monomial(table, table->t->primes[0].q - 1, degree, values, len);
+}
+
+int pfhe_ntt_transform_dev(const pfhe_ntt *table, uint64_t *poly_dev, size_t len, int lazy, void *stream) {
+    PFHE_GUARD_BEGIN
+    if (!table) return PFHE_ERR_BAD_ARGUMENT;
+    return transform_dev(*table->t, (u64 *)poly_dev, len, false, lazy != 0, (hipStream_t)stream);
+    PFHE_GUARD_END
+}
+
+int pfhe_ntt_inverse_transform_dev(const pfhe_ntt *table, uint64_t *values_dev, size_t len, int lazy,
+                                   void *stream) {
+    PFHE_GUARD_BEGIN
+    if (!table) return PFHE_ERR_BAD_ARGUMENT;
+    return transform_dev(*table->t, (u64 *)values_dev, len, true, lazy != 0, (hipStream_t)stream);
+    PFHE_GUARD_END
+}
+
+int pfhe_ntt_transform_monomial_dev(const pfhe_ntt *table, uint64_t coeff, size_t degree, uint64_t *values_dev,
+                                    size_t len, void *stream) {
+    PFHE_GUARD_BEGIN
+    if (!table) return PFHE_ERR_BAD_ARGUMENT;
+    return monomial(*table->t, coeff, degree, (u64 *)values_dev, len, false, (hipStream_t)stream);
+    PFHE_GUARD_END
+}
+
+int pfhe_ntt_mul_assign_dev(const pfhe_ntt *table, uint64_t *a_dev, size_t len_a, const uint64_t *b_dev,
+                            size_t len_b, void *stream) {
+    PFHE_GUARD_BEGIN
+    if (!table) return PFHE_ERR_BAD_ARGUMENT;
+    return pointwise(*table->t, 0, (u64 *)a_dev, nullptr, len_a, (const u64 *)b_dev, len_b, (hipStream_t)stream);
+    PFHE_GUARD_END
+}
+
+int pfhe_ntt_add_mul_assign_dev(const pfhe_ntt *table, uint64_t *acc_dev, const uint64_t *a_dev, size_t len_a,
+                                const uint64_t *b_dev, size_t len_b, void *stream) {
+    PFHE_GUARD_BEGIN
+    if (!table) return PFHE_ERR_BAD_ARGUMENT;
+    return pointwise(*table->t, 1, (u64 *)acc_dev, (const u64 *)a_dev, len_a, (const u64 *)b_dev, len_b,
+                     (hipStream_t)stream);
+    PFHE_GUARD_END
+}
+
+/* ---------------------------- U64DcrtTable ---------------------------- */
+
+int pfhe_dcrt_create(uint32_t log_n, const uint64_t *moduli, size_t moduli_count, int device, pfhe_dcrt **out) {
+    PFHE_GUARD_BEGIN
+    if (!out || (!moduli && moduli_count)) return PFHE_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    std::unique_ptr<TableSet> t;
+    PFHE_TRY(make_table_set(log_n, (const u64 *)moduli, moduli_count, device, t));
+    *out = new pfhe_dcrt{std::move(t)};
+    return PFHE_OK;
+    PFHE_GUARD_END
+}
+
+void pfhe_dcrt_destroy(pfhe_dcrt *table) { delete table; }
+size_t pfhe_dcrt_poly_length(const pfhe_dcrt *t) { return t ? t->t->n : 0; }
+size_t pfhe_dcrt_moduli_count(const pfhe_dcrt *t) { return t ? t->t->L : 0; }
+size_t pfhe_dcrt_crt_poly_length(const pfhe_dcrt *t) { return t ? t->t->n * t->t->L : 0; }
+int pfhe_dcrt_device(const pfhe_dcrt *t) { return t ? t->t->device : -1; }
+uint64_t pfhe_dcrt_modulus(const pfhe_dcrt *t, size_t i) { return (t && i < t->t->L) ? t->t->primes[i].q : 0; }
+uint64_t pfhe_dcrt_root(const pfhe_dcrt *t, size_t i) { return (t && i < t->t->L) ? t->t->roots[i] : 0; }
+uint64_t pfhe_dcrt_inv_n(const pfhe_dcrt *t, size_t i) { return (t && i < t->t->L) ? t->t->primes[i].inv_n : 0; }
+
+#define PFHE_DCRT_HOST(name, INV, LAZY)                                         \
+    int name(const pfhe_dcrt *table, uint64_t *p, size_t len) {                 \
+        PFHE_GUARD_BEGIN                                                        \
+        if (!table) return PFHE_ERR_BAD_ARGUMENT;                               \
+        return transform_host(*table->t, (u64 *)p, len, INV, LAZY);             \
+        PFHE_GUARD_END                                                          \
+    }
+PFHE_DCRT_HOST(pfhe_dcrt_transform_slice, false, false)
+PFHE_DCRT_HOST(pfhe_dcrt_inverse_transform_slice, true, false)
+PFHE_DCRT_HOST(pfhe_dcrt_lazy_transform_slice, false, true)
+PFHE_DCRT_HOST(pfhe_dcrt_lazy_inverse_transform_slice, true, true)
+#undef PFHE_DCRT_HOST
+
+int pfhe_dcrt_transform_monomial(const pfhe_dcrt *table, uint64_t coeff, size_t degree, uint64_t *values,
+                                 size_t len) {
+    PFHE_GUARD_BEGIN
+    if (!table) return PFHE_ERR_BAD_ARGUMENT;
+    return monomial(*table->t, coeff, degree, (u64 *)values, len, true, nullptr);
+    PFHE_GUARD_END
+}
+
+int pfhe_dcrt_transform_dev(const pfhe_dcrt *table, uint64_t *poly_dev, size_t len, int lazy, void *stream) {
+    PFHE_GUARD_BEGIN
+    if (!table) return PFHE_ERR_BAD_ARGUMENT;
+    return transform_dev(*table->t, (u64 *)poly_dev, len, false, lazy != 0, (hipStream_t)stream);
+    PFHE_GUARD_END
+}
+
+int pfhe_dcrt_inverse_transform_dev(const pfhe_dcrt *table, uint64_t *poly_dev, size_t len, int lazy,
+                                    void *stream) {
+    PFHE_GUARD_BEGIN
+    if (!table) return PFHE_ERR_BAD_ARGUMENT;
+    return transform_dev(*table->t, (u64 *)poly_dev, len, true, lazy != 0, (hipStream_t)stream);
+    PFHE_GUARD_END
+}
+
+int pfhe_dcrt_mul_assign_dev(const pfhe_dcrt *table, uint64_t *a_dev, size_t len_a, const uint64_t *b_dev,
+                             size_t len_b, void *stream) {
+    PFHE_GUARD_BEGIN
+    if (!table) return PFHE_ERR_BAD_ARGUMENT;
+    return pointwise(*table->t, 0, (u64 *)a_dev, nullptr, len_a, (const u64 *)b_dev, len_b, (hipStream_t)stream);
+    PFHE_GUARD_END
+}
+
+int pfhe_dcrt_add_mul_assign_dev(const pfhe_dcrt *table, uint64_t *acc_dev, const uint64_t *a_dev, size_t len_a,
+                                 const uint64_t *b_dev, size_t len_b, void *stream) {
+    PFHE_GUARD_BEGIN
+    if (!table) return PFHE_ERR_BAD_ARGUMENT;
+    return pointwise(*table->t, 1, (u64 *)acc_dev, (const u64 *)a_dev, len_a, (const u64 *)b_dev, len_b,
+                     (hipStream_t)stream);
+    PFHE_GUARD_END
+}
+
+int pfhe_dcrt_transform_num_passes(const pfhe_dcrt *table) {
+    return table ? ntt_num_passes(table->t->log_n) : 0;
+}
+
+const char *pfhe_dcrt_transform_pass_name(const pfhe_dcrt *table, int inverse, int index) {
+    static thread_local char buf[96];
+    buf[0] = 0;
+    if (table) ntt_pass_name(table->t->log_n, inverse != 0, index, buf, sizeof buf);
+    return buf;
+}
+
+int pfhe_dcrt_transform_pass_dev(const pfhe_dcrt *table, uint64_t *poly_dev, size_t len, int inverse, int index,
+                                 int lazy, void *stream) {
+    PFHE_GUARD_BEGIN
+    if (!table || (!poly_dev && len)) return PFHE_ERR_BAD_ARGUMENT;
+    const TableSet &t = *table->t;
+    if (len % (t.n * t.L) != 0) return PFHE_ERR_BAD_LENGTH;
+    DeviceGuard g(t.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    return ntt_pass_dev(t.primes_dev, t.L, t.log_n, (u64 *)poly_dev, len / t.n, inverse != 0, index, lazy != 0,
+                        (hipStream_t)stream);
+    PFHE_GUARD_END
+}
+
+int pfhe_dcrt_mul_dcrt_polynomial_dev(const pfhe_dcrt *table, uint64_t *crt_poly_dev, size_t len,
+                                      const uint64_t *dcrt_poly_dev, size_t len_b, void *stream) {
+    PFHE_GUARD_BEGIN
+    if (!table) return PFHE_ERR_BAD_ARGUMENT;
+    const TableSet &t = *table->t;
+    PFHE_TRY(transform_dev(t, (u64 *)crt_poly_dev, len, false, false, (hipStream_t)stream));
+    PFHE_TRY(pointwise(t, 0, (u64 *)crt_poly_dev, nullptr, len, (const u64 *)dcrt_poly_dev, len_b,
+                       (hipStream_t)stream));
+    return transform_dev(t, (u64 *)crt_poly_dev, len, true, false, (hipStream_t)stream);
+    PFHE_GUARD_END
+}
+
+}  // extern "C"

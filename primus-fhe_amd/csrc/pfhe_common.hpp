@@ -1,0 +1,66 @@
+// pfhe_common.hpp — shared declarations of libpfhe_hip (host side).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/pfhe.h"
+
+namespace pfhe {
+
+using u64 = unsigned long long;  // same width as uint64_t; matches HIP's 64-bit intrinsics
+using u32 = unsigned int;
+static_assert(sizeof(u64) == 8 && sizeof(uint64_t) == 8, "64-bit words");
+
+void set_last_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define PFHE_HIP(expr)                                                      \
+    do {                                                                    \
+        hipError_t e_ = (expr);                                             \
+        if (e_ != hipSuccess) return ::pfhe::hip_fail(e_, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+#define PFHE_TRY(expr)            \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != PFHE_OK) return rc_; \
+    } while (0)
+
+// RAII: make `device` current for the scope, restore the previous device afterwards.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int device);
+    ~DeviceGuard();
+};
+
+// Per-prime constants + device twiddle tables of one U64NttTable.
+// Twiddles are stored interleaved {w, floor(w*2^64/q)} so one 16-byte load fetches both.
+//   fwd[i] = roots[i]      (roots[brv(k)] = psi^k,            table.rs:347-351)
+//   inv[i] = inv_roots[i]  (inv_roots[brv(k)+1] = psi^-(k+1), table.rs:354-358)
+struct NttPrime {
+    u64 q, two_q;
+    u64 inv_n, inv_n_p;      // N^-1 mod q and its Shoup quotient
+    u64 inv_n_w, inv_n_w_p;  // N^-1 * inv_roots[N-1] (table.rs:397-400)
+    u64 bar_lo, bar_hi;      // floor(2^128 / q) (BarrettModulus ratio)
+    const ulonglong2 *fwd;   // device, N entries
+    const ulonglong2 *inv;   // device, N entries
+};
+
+struct HostTable {  // host-side result of table construction
+    u32 log_n = 0;
+    u64 q = 0, root = 0, inv_root = 0, inv_n = 0, inv_n_w = 0;
+    u64 bar_lo = 0, bar_hi = 0;
+    std::vector<ulonglong2> fwd, inv;  // N each
+    std::vector<u64> ordinal;          // psi^k, k < 2N (monomial transforms)
+};
+
+// Builds the table; returns a pfhe_status mirroring NttTable::new's errors.
+int build_host_table(u32 log_n, u64 q, HostTable &out);
+
+}  // namespace pfhe

@@ -1,0 +1,401 @@
+// pfhe_ntt.hip — batched negacyclic NTT / INTT kernels for gfx950 (MI355X, CDNA4).
+//
+// What is computed (bit-exact, canonical outputs): U64NttTable::transform_slice /
+// inverse_transform_slice and their lazy variants (primus_ntt/src/ntt/prime64/table.rs:541-563,
+// scalar/transform.rs:13-319) for every N-word chunk of a batch.  Index conventions are the
+// reference's: forward stage with m groups uses roots[m + g]; inverse stage with m groups uses
+// inv_roots[1 + N - 2m + g]; output of the forward transform is in bit-reversed order.
+//
+// How it is computed is NOT the reference's loop nest.  A transform is cut into passes:
+//   * "strided" passes: 2^K coefficients at stride S per thread, K stages entirely in
+//     registers, fully coalesced 16-byte loads/stores, twiddles wave-uniform (scalar loads);
+//   * one "block" pass: a workgroup owns a contiguous block of 2^LOGB coefficients, every
+//     thread keeps 16 of them in registers, runs 4 radix-2 stages per register pass and
+//     re-shuffles through (padded) LDS between register passes.
+// N <= 2^14 is a single block pass (one HBM read + one HBM write); N = 2^15..2^17 is one strided
+// pass + one block pass of 2^12.  In terms of a global element index E (bit p is the butterfly
+// distance 2^p) the twiddle index of a forward butterfly is (N + E) >> (p + 1) and of an inverse
+// butterfly 1 + N - (N >> p) + (E >> (p + 1)).
+#include <cstdio>
+
+#include "pfhe_common.hpp"
+#include "pfhe_modmath.hpp"
+#include "pfhe_ntt_device.hpp"
+
+namespace pfhe {
+
+// ------------------------------------------------------------------------------------------
+// tiny transforms (N <= 8): one thread per polynomial, straight loops.  Only there so that the
+// whole NttTable domain (log_n >= 0) is served by the device path.
+// ------------------------------------------------------------------------------------------
+template <bool INV, bool LAZY>
+__global__ void ntt_tiny_kernel(u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L,
+                                u32 log_n, u64 npolys) {
+    u64 pid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pid >= npolys) return;
+    const NttPrime P = primes[pid % L];
+    const u32 n = 1u << log_n;
+    u64 *x = data + pid * n;
+    const u64 q = P.q, two_q = P.two_q;
+    if (!INV) {
+        for (u32 p = log_n; p-- > 0;) {
+            for (u32 e = 0; e < n; ++e) {
+                if (e & (1u << p)) continue;
+                ulonglong2 w = P.fwd[(n + e) >> (p + 1)];
+                fwd_bfly(x[e], x[e | (1u << p)], w.x, w.y, q, two_q);
+            }
+        }
+        if (!LAZY && log_n > 0)
+            for (u32 e = 0; e < n; ++e) x[e] = reduce_once(reduce_once(x[e], two_q), q);
+    } else {
+        for (u32 p = 0; p + 1 < log_n; ++p) {
+            for (u32 e = 0; e < n; ++e) {
+                if (e & (1u << p)) continue;
+                ulonglong2 w = P.inv[1 + n - (n >> p) + (e >> (p + 1))];
+                inv_bfly(x[e], x[e | (1u << p)], w.x, w.y, q, two_q);
+            }
+        }
+        if (log_n > 0) {
+            const u32 h = n >> 1;
+            for (u32 e = 0; e < h; ++e) inv_final_bfly<LAZY>(x[e], x[e + h], P);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// strided pass: K stages on 2^K coefficients at stride S = 2^LOGS, VEC adjacent columns per
+// thread (16-byte accesses when VEC == 2).
+//   forward: stages with butterfly distance S*2^(K-1) ... S       (register bit j <-> bit LOGS+j)
+//   inverse: stages with butterfly distance S ... S*2^(K-1); FINAL marks that the top stage is
+//            the last stage of the whole transform (fused N^-1 scaling, table.rs:283-318).
+// ------------------------------------------------------------------------------------------
+template <int K, int VEC, bool INV, bool FINAL, bool LAZY>
+__global__ __launch_bounds__(256) void ntt_strided_kernel(u64 *__restrict__ data,
+                                                          const NttPrime *__restrict__ primes,
+                                                          u32 L, u32 log_n, u32 log_s,
+                                                          u64 total_threads) {
+    constexpr int R = 1 << K;
+    u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total_threads) return;
+    // gid -> (pid, hi, col): col indexes VEC-wide column groups inside the stride
+    const u32 log_cols = log_s - (VEC == 2 ? 1 : 0);
+    const u32 log_hi = log_n - log_s - K;  // number of index bits above the register bits
+    const u32 col = (u32)(gid & ((1ull << log_cols) - 1));
+    // hi and pid are identical for all 64 lanes of a wave (2^log_cols >= 64 threads per value)
+    const u32 hi = __builtin_amdgcn_readfirstlane((u32)((gid >> log_cols) & ((1ull << log_hi) - 1)));
+    const u32 pid_lo = __builtin_amdgcn_readfirstlane((u32)(gid >> (log_cols + log_hi)));
+    const u32 limb = pid_lo % L;
+    const NttPrime *__restrict__ P = primes + limb;
+    const u64 q = P->q, two_q = P->two_q;
+    const u32 n = 1u << log_n;
+    const u32 ebase = hi << (log_s + K);  // element index of register 0, column 0
+    u64 *__restrict__ ptr = data + (u64)pid_lo * n + ebase + (u64)col * VEC;
+
+    u64 x[R][VEC];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        if constexpr (VEC == 2) {
+            ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(ptr + ((u64)k << log_s));
+            x[k][0] = v.x;
+            x[k][1] = v.y;
+        } else {
+            x[k][0] = ptr[(u64)k << log_s];
+        }
+    }
+
+    if constexpr (!INV) {
+        const ulonglong2 *__restrict__ tw = P->fwd;
+#pragma unroll
+        for (int j = K - 1; j >= 0; --j) {
+            const u32 base = (n + ebase) >> (log_s + j + 1);
+#pragma unroll
+            for (int u = 0; u < (R >> (j + 1)); ++u) {
+                const ulonglong2 w = tw[base + u];
+#pragma unroll
+                for (int v = 0; v < (1 << j); ++v) {
+                    const int k0 = (u << (j + 1)) | v, k1 = k0 | (1 << j);
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) fwd_bfly(x[k0][c], x[k1][c], w.x, w.y, q, two_q);
+                }
+            }
+        }
+    } else {
+        const ulonglong2 *__restrict__ tw = P->inv;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const u32 p = log_s + j;
+            if (FINAL && j == K - 1) {
+                const NttPrime PP = *P;
+#pragma unroll
+                for (int v = 0; v < (1 << j); ++v)
+#pragma unroll
+                    for (int c = 0; c < VEC; ++c) inv_final_bfly<LAZY>(x[v][c], x[v | (1 << j)][c], PP);
+            } else {
+                const u32 base = 1 + n - (n >> p) + (ebase >> (p + 1));
+#pragma unroll
+                for (int u = 0; u < (R >> (j + 1)); ++u) {
+                    const ulonglong2 w = tw[base + u];
+#pragma unroll
+                    for (int v = 0; v < (1 << j); ++v) {
+                        const int k0 = (u << (j + 1)) | v, k1 = k0 | (1 << j);
+#pragma unroll
+                        for (int c = 0; c < VEC; ++c) inv_bfly(x[k0][c], x[k1][c], w.x, w.y, q, two_q);
+                    }
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        if constexpr (VEC == 2) {
+            *reinterpret_cast<ulonglong2 *>(ptr + ((u64)k << log_s)) = ulonglong2{x[k][0], x[k][1]};
+        } else {
+            ptr[(u64)k << log_s] = x[k][0];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// block pass: a workgroup owns BPW contiguous blocks of B = 2^LOGB coefficients (BPW > 1 only
+// for B < 4096 so that a workgroup always has 256+ threads).
+//   forward: the LAST LOGB stages of the transform (distances B/2 ... 1), canonical reduction
+//            fused into the final stage (scalar/transform.rs:104-116) unless LAZY.
+//   inverse: the FIRST LOGB stages (distances 1 ... B/2); when B == N the final stage carries
+//            the fused N^-1 / N^-1*w scaling (scalar/transform.rs:283-318).
+// ------------------------------------------------------------------------------------------
+template <int LOGB, bool INV, bool LAZY>
+__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) void ntt_block_kernel(
+    u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L, u32 log_n, u64 total_blocks) {
+    using Cfg = BlockCfg<LOGB>;
+    extern __shared__ __attribute__((aligned(16))) u64 lds_raw[];
+
+    const u32 tid = threadIdx.x;
+    const u32 sub = Cfg::BPW == 1 ? 0u : tid / Cfg::TPB;
+    const u32 lt = Cfg::BPW == 1 ? tid : tid % Cfg::TPB;
+    u64 blk = (u64)blockIdx.x * Cfg::BPW + sub;
+    const bool valid = blk < total_blocks;
+    if (!valid) blk = 0;
+    const u32 log_nb = log_n - LOGB;  // blocks per polynomial
+    const u64 pid = blk >> log_nb;
+    const u32 bi = (u32)(blk & ((1ull << log_nb) - 1));
+    const u32 limb = (u32)(pid % L);
+    const NttPrime *__restrict__ P = primes + limb;
+    const u32 n = 1u << log_n;
+    const u32 eblk = bi << LOGB;
+    u64 *__restrict__ gptr = data + pid * n + eblk;
+    u64 *__restrict__ lds = lds_raw + (size_t)sub * Cfg::LDS_WORDS;
+
+    u64 x[16];
+    if constexpr (!INV) {
+        block_forward<LOGB, LAZY>(x, gptr, lds, P, n, eblk, lt, valid);
+    } else {
+        block_inverse<LOGB, LAZY>(x, gptr, lds, P, n, eblk, lt, valid, log_n == LOGB);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side planner / launchers
+// ------------------------------------------------------------------------------------------
+namespace {
+
+template <int LOGB, bool INV, bool LAZY>
+int launch_block(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys, hipStream_t s) {
+    using Cfg = BlockCfg<LOGB>;
+    const u64 total_blocks = npolys << (log_n - LOGB);
+    const u64 grid = (total_blocks + Cfg::BPW - 1) / Cfg::BPW;
+    if (grid == 0) return PFHE_OK;
+    if (grid > 0x7fffffffull) {
+        set_last_error("batch too large for one launch");
+        return PFHE_ERR_BAD_LENGTH;
+    }
+    constexpr size_t lds_bytes = (size_t)Cfg::BPW * Cfg::LDS_WORDS * sizeof(u64);
+    auto kern = ntt_block_kernel<LOGB, INV, LAZY>;
+    if (lds_bytes > 64 * 1024) {
+        static thread_local bool configured[64] = {};
+        int dev = 0;
+        PFHE_HIP(hipGetDevice(&dev));
+        if (dev < 64 && !configured[dev]) {
+            PFHE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            configured[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((u32)grid), dim3(Cfg::THREADS), lds_bytes, s, data, primes, L, log_n,
+                       total_blocks);
+    PFHE_HIP(hipGetLastError());
+    return PFHE_OK;
+}
+
+template <bool INV, bool LAZY>
+int dispatch_block(int logb, u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys,
+                   hipStream_t s) {
+    switch (logb) {
+#define PFHE_CASE(B) \
+    case B:          \
+        return launch_block<B, INV, LAZY>(data, primes, L, log_n, npolys, s);
+        PFHE_CASE(4) PFHE_CASE(5) PFHE_CASE(6) PFHE_CASE(7) PFHE_CASE(8) PFHE_CASE(9) PFHE_CASE(10)
+        PFHE_CASE(11) PFHE_CASE(12) PFHE_CASE(13) PFHE_CASE(14)
+#undef PFHE_CASE
+    }
+    set_last_error("unsupported block size");
+    return PFHE_ERR_UNSUPPORTED;
+}
+
+template <int K, int VEC, bool INV, bool FINAL, bool LAZY>
+int launch_strided(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u32 log_s, u64 npolys,
+                   hipStream_t s) {
+    const u64 total = (npolys << (log_n - K)) >> (VEC == 2 ? 1 : 0);
+    const u64 grid = (total + 255) / 256;
+    if (grid == 0) return PFHE_OK;
+    if (grid > 0x7fffffffull) {
+        set_last_error("batch too large for one launch");
+        return PFHE_ERR_BAD_LENGTH;
+    }
+    hipLaunchKernelGGL((ntt_strided_kernel<K, VEC, INV, FINAL, LAZY>), dim3((u32)grid), dim3(256), 0, s,
+                       data, primes, L, log_n, log_s, total);
+    PFHE_HIP(hipGetLastError());
+    return PFHE_OK;
+}
+
+template <bool INV, bool FINAL, bool LAZY>
+int dispatch_strided(int k, u64 *data, const NttPrime *primes, u32 L, u32 log_n, u32 log_s, u64 npolys,
+                     hipStream_t s) {
+    switch (k) {
+        case 1: return launch_strided<1, 2, INV, FINAL, LAZY>(data, primes, L, log_n, log_s, npolys, s);
+        case 2: return launch_strided<2, 2, INV, FINAL, LAZY>(data, primes, L, log_n, log_s, npolys, s);
+        case 3: return launch_strided<3, 2, INV, FINAL, LAZY>(data, primes, L, log_n, log_s, npolys, s);
+        case 4: return launch_strided<4, 2, INV, FINAL, LAZY>(data, primes, L, log_n, log_s, npolys, s);
+        case 5: return launch_strided<5, 1, INV, FINAL, LAZY>(data, primes, L, log_n, log_s, npolys, s);
+    }
+    set_last_error("unsupported strided radix");
+    return PFHE_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+NttPlan make_ntt_plan(u32 log_n) {
+    NttPlan p;
+    if (log_n <= 3) {
+        p.tiny = true;
+        return p;
+    }
+    if (log_n <= kMaxSinglePassLog) {
+        p.block_log = (int)log_n;
+        return p;
+    }
+    p.block_log = kTwoPassBlockLog;
+    int rest = (int)log_n - p.block_log;
+    // fewest strided passes with at most 5 stages each, balanced
+    int passes = (rest + 4) / 5;
+    for (int i = 0; i < passes; ++i) {
+        int k = (rest + (passes - i) - 1) / (passes - i);
+        p.strided[p.n_strided++] = k;
+        rest -= k;
+    }
+    return p;
+}
+
+template <bool LAZY>
+static int forward_impl(const NttPrime *primes, u32 L, u32 log_n, u64 *data, u64 npolys, hipStream_t s) {
+    const NttPlan plan = make_ntt_plan(log_n);
+    if (plan.tiny) {
+        if (log_n == 0 || npolys == 0) return PFHE_OK;
+        hipLaunchKernelGGL((ntt_tiny_kernel<false, LAZY>), dim3((u32)((npolys + 255) / 256)), dim3(256), 0, s,
+                           data, primes, L, log_n, npolys);
+        PFHE_HIP(hipGetLastError());
+        return PFHE_OK;
+    }
+    // forward: strided passes first (largest distances), block pass last
+    u32 top = log_n;  // bits [top-1 ...] still to be processed
+    for (int i = 0; i < plan.n_strided; ++i) {
+        const int k = plan.strided[i];
+        const u32 log_s = top - k;
+        PFHE_TRY((dispatch_strided<false, false, false>(k, data, primes, L, log_n, log_s, npolys, s)));
+        top = log_s;
+    }
+    return dispatch_block<false, LAZY>(plan.block_log, data, primes, L, log_n, npolys, s);
+}
+
+template <bool LAZY>
+static int inverse_impl(const NttPrime *primes, u32 L, u32 log_n, u64 *data, u64 npolys, hipStream_t s) {
+    const NttPlan plan = make_ntt_plan(log_n);
+    if (plan.tiny) {
+        if (log_n == 0 || npolys == 0) return PFHE_OK;
+        hipLaunchKernelGGL((ntt_tiny_kernel<true, LAZY>), dim3((u32)((npolys + 255) / 256)), dim3(256), 0, s,
+                           data, primes, L, log_n, npolys);
+        PFHE_HIP(hipGetLastError());
+        return PFHE_OK;
+    }
+    PFHE_TRY((dispatch_block<true, LAZY>(plan.block_log, data, primes, L, log_n, npolys, s)));
+    u32 log_s = (u32)plan.block_log;
+    for (int i = plan.n_strided - 1; i >= 0; --i) {
+        const int k = plan.strided[i];
+        const bool final_pass = (i == 0);
+        if (final_pass) {
+            PFHE_TRY((dispatch_strided<true, true, LAZY>(k, data, primes, L, log_n, log_s, npolys, s)));
+        } else {
+            PFHE_TRY((dispatch_strided<true, false, false>(k, data, primes, L, log_n, log_s, npolys, s)));
+        }
+        log_s += k;
+    }
+    return PFHE_OK;
+}
+
+// Profiling hooks: run / name ONE pass of the plan (pass order is execution order).
+int ntt_num_passes(u32 log_n) {
+    const NttPlan plan = make_ntt_plan(log_n);
+    return plan.tiny ? 1 : plan.n_strided + 1;
+}
+
+void ntt_pass_name(u32 log_n, bool inverse, int index, char *buf, size_t cap) {
+    const NttPlan plan = make_ntt_plan(log_n);
+    if (plan.tiny) {
+        std::snprintf(buf, cap, "ntt_tiny_kernel");
+        return;
+    }
+    const int block_at = inverse ? 0 : plan.n_strided;
+    if (index == block_at) {
+        std::snprintf(buf, cap, "ntt_block_kernel<%d,%s>", plan.block_log, inverse ? "inv" : "fwd");
+    } else {
+        const int i = inverse ? plan.n_strided - index : index;
+        std::snprintf(buf, cap, "ntt_strided_kernel<K=%d,%s>", plan.strided[i], inverse ? "inv" : "fwd");
+    }
+}
+
+int ntt_pass_dev(const NttPrime *primes, u32 L, u32 log_n, u64 *data, u64 npolys, bool inverse, int index,
+                 bool lazy, hipStream_t s) {
+    const NttPlan plan = make_ntt_plan(log_n);
+    if (index < 0 || index >= ntt_num_passes(log_n)) return PFHE_ERR_BAD_ARGUMENT;
+    if (plan.tiny) return inverse ? ntt_inverse_dev(primes, L, log_n, data, npolys, lazy, s)
+                                  : ntt_forward_dev(primes, L, log_n, data, npolys, lazy, s);
+    const int block_at = inverse ? 0 : plan.n_strided;
+    if (index == block_at) {
+        if (inverse) return lazy ? dispatch_block<true, true>(plan.block_log, data, primes, L, log_n, npolys, s)
+                                 : dispatch_block<true, false>(plan.block_log, data, primes, L, log_n, npolys, s);
+        return lazy ? dispatch_block<false, true>(plan.block_log, data, primes, L, log_n, npolys, s)
+                    : dispatch_block<false, false>(plan.block_log, data, primes, L, log_n, npolys, s);
+    }
+    const int i = inverse ? plan.n_strided - index : index;  // index into plan.strided (forward order)
+    u32 log_s = log_n;
+    for (int j = 0; j <= i; ++j) log_s -= plan.strided[j];
+    const int k = plan.strided[i];
+    if (!inverse) return dispatch_strided<false, false, false>(k, data, primes, L, log_n, log_s, npolys, s);
+    if (i == 0) return lazy ? dispatch_strided<true, true, true>(k, data, primes, L, log_n, log_s, npolys, s)
+                            : dispatch_strided<true, true, false>(k, data, primes, L, log_n, log_s, npolys, s);
+    return dispatch_strided<true, false, false>(k, data, primes, L, log_n, log_s, npolys, s);
+}
+
+int ntt_forward_dev(const NttPrime *primes, u32 L, u32 log_n, u64 *data, u64 npolys, bool lazy,
+                    hipStream_t s) {
+    return lazy ? forward_impl<true>(primes, L, log_n, data, npolys, s)
+                : forward_impl<false>(primes, L, log_n, data, npolys, s);
+}
+
+int ntt_inverse_dev(const NttPrime *primes, u32 L, u32 log_n, u64 *data, u64 npolys, bool lazy,
+                    hipStream_t s) {
+    return lazy ? inverse_impl<true>(primes, L, log_n, data, npolys, s)
+                : inverse_impl<false>(primes, L, log_n, data, npolys, s);
+}
+
+}  // namespace pfhe

@@ -1,0 +1,145 @@
+// pfhe_pointwise.hip — streaming modular kernels: Barrett multiply / multiply-accumulate,
+// monomial transforms, synthetic fill.  All HBM-bound: 16-byte accesses, grid-stride.
+//
+//   mul_assign      a[i] = a[i]*b[i] mod q_r        DcrtPolynomial::mul_assign, dcrt/mul.rs:176-187
+//   add_mul_assign  acc[i] = a[i]*b[i] + acc[i]     DcrtPolynomial::add_mul_assign, dcrt/mod.rs:105-123
+// (per limb: BarrettModulus::reduce_mul / reduce_mul_add, primus_modulus/src/barrett/ops.rs:276-315)
+#include "pfhe_common.hpp"
+#include "pfhe_modmath.hpp"
+#include "pfhe_pointwise.hpp"
+
+namespace pfhe {
+
+namespace {
+
+constexpr int kPwThreads = 256;
+
+struct Bar {
+    u64 q, lo, hi;
+};
+
+__device__ __forceinline__ Bar load_bar(const NttPrime *__restrict__ primes, u32 limb) {
+    const NttPrime *P = primes + limb;
+    return Bar{P->q, P->bar_lo, P->bar_hi};
+}
+
+// MODE 0: a = a*b ; MODE 1: acc = a*b + acc
+template <int MODE, bool PAIR>
+__global__ __launch_bounds__(kPwThreads) void pointwise_kernel(u64 *acc, const u64 *a,
+                                                               const u64 *__restrict__ b,
+                                                               const NttPrime *__restrict__ primes, u32 L,
+                                                               u32 log_n, u64 len, u64 len_b) {
+    constexpr u64 V = PAIR ? 2 : 1;
+    const u64 nvec = len / V;
+    const bool shared_b = len_b != len;
+    for (u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (u64)gridDim.x * blockDim.x) {
+        const u64 i = v * V;
+        const u32 limb = (u32)((i >> log_n) % L);
+        const Bar m = load_bar(primes, limb);
+        const u64 ib = shared_b ? (i % len_b) : i;
+        if constexpr (PAIR) {
+            const ulonglong2 av = *reinterpret_cast<const ulonglong2 *>((MODE == 0 ? acc : a) + i);
+            const ulonglong2 bv = *reinterpret_cast<const ulonglong2 *>(b + ib);
+            ulonglong2 r;
+            if constexpr (MODE == 0) {
+                r.x = mul_mod_barrett(av.x, bv.x, m.q, m.lo, m.hi);
+                r.y = mul_mod_barrett(av.y, bv.y, m.q, m.lo, m.hi);
+            } else {
+                const ulonglong2 cv = *reinterpret_cast<const ulonglong2 *>(acc + i);
+                r.x = mul_add_mod_barrett(av.x, bv.x, cv.x, m.q, m.lo, m.hi);
+                r.y = mul_add_mod_barrett(av.y, bv.y, cv.y, m.q, m.lo, m.hi);
+            }
+            *reinterpret_cast<ulonglong2 *>(acc + i) = r;
+        } else {
+            if constexpr (MODE == 0) {
+                acc[i] = mul_mod_barrett(acc[i], b[ib], m.q, m.lo, m.hi);
+            } else {
+                acc[i] = mul_add_mod_barrett(a[i], b[ib], acc[i], m.q, m.lo, m.hi);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ u64 splitmix64(u64 seed, u64 i) {
+    u64 z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(kPwThreads) void fill_uniform_kernel(u64 *__restrict__ dst, u64 len,
+                                                                  const u64 *__restrict__ moduli, u64 count,
+                                                                  u64 poly_len, u64 seed) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (u64)gridDim.x * blockDim.x) {
+        const u64 q = moduli[(i / poly_len) % count];
+        dst[i] = mulhi64(splitmix64(seed, i), q);
+    }
+}
+
+// NTT of coeff * X^degree: out[i] = coeff * psi^((2*brv(i)+1)*degree mod 2N)  (table.rs:565-609)
+__global__ __launch_bounds__(kPwThreads) void monomial_kernel(u64 *__restrict__ out,
+                                                              const NttPrime *__restrict__ primes, u32 L,
+                                                              u32 log_n, u64 degree, const u64 *__restrict__ coeff,
+                                                              const u64 *__restrict__ coeff_p) {
+    const u64 n = 1ull << log_n;
+    const u64 total = n * L;
+    for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (u64)gridDim.x * blockDim.x) {
+        const u32 limb = (u32)(t >> log_n);
+        const u32 i = (u32)(t & (n - 1));
+        const NttPrime *P = primes + limb;
+        const u32 r = log_n == 0 ? 0u : (__brev(i) >> (32 - log_n));
+        const u64 idx = ((2ull * r + 1) * degree) & (2 * n - 1);
+        const u32 k = (u32)(idx & (n - 1));
+        const u32 kb = log_n == 0 ? 0u : (__brev(k) >> (32 - log_n));
+        u64 w = P->fwd[kb].x;         // psi^k
+        if (idx >= n) w = P->q - w;   // psi^(k+N) = -psi^k
+        out[t] = mul_shoup(w, coeff[limb], coeff_p[limb], P->q);
+    }
+}
+
+u32 grid_for(u64 work_items) {
+    u64 g = (work_items + kPwThreads - 1) / kPwThreads;
+    const u64 cap = 256ull * 8;  // 256 CUs x 8 workgroups, grid-stride beyond that
+    if (g > cap) g = cap;
+    if (g == 0) g = 1;
+    return (u32)g;
+}
+
+}  // namespace
+
+int pointwise_dev(int mode, u64 *acc, const u64 *a, const u64 *b, const NttPrime *primes, u32 L, u32 log_n,
+                  u64 len, u64 len_b, hipStream_t s) {
+    if (len == 0) return PFHE_OK;
+    const bool pair = log_n >= 1 && (len % 2 == 0) && (len_b % 2 == 0);
+    const u64 items = pair ? len / 2 : len;
+    const dim3 g(grid_for(items)), t(kPwThreads);
+    if (mode == 0) {
+        if (pair) hipLaunchKernelGGL((pointwise_kernel<0, true>), g, t, 0, s, acc, a, b, primes, L, log_n, len, len_b);
+        else hipLaunchKernelGGL((pointwise_kernel<0, false>), g, t, 0, s, acc, a, b, primes, L, log_n, len, len_b);
+    } else {
+        if (pair) hipLaunchKernelGGL((pointwise_kernel<1, true>), g, t, 0, s, acc, a, b, primes, L, log_n, len, len_b);
+        else hipLaunchKernelGGL((pointwise_kernel<1, false>), g, t, 0, s, acc, a, b, primes, L, log_n, len, len_b);
+    }
+    PFHE_HIP(hipGetLastError());
+    return PFHE_OK;
+}
+
+int fill_uniform_dev(u64 *dst, u64 len, const u64 *moduli_dev, u64 count, u64 poly_len, u64 seed,
+                     hipStream_t s) {
+    if (len == 0) return PFHE_OK;
+    hipLaunchKernelGGL(fill_uniform_kernel, dim3(grid_for(len)), dim3(kPwThreads), 0, s, dst, len, moduli_dev,
+                       count, poly_len, seed);
+    PFHE_HIP(hipGetLastError());
+    return PFHE_OK;
+}
+
+int monomial_dev(u64 *out, const NttPrime *primes, u32 L, u32 log_n, u64 degree, const u64 *coeff_dev,
+                 const u64 *coeff_p_dev, hipStream_t s) {
+    const u64 total = ((u64)L) << log_n;
+    hipLaunchKernelGGL(monomial_kernel, dim3(grid_for(total)), dim3(kPwThreads), 0, s, out, primes, L, log_n,
+                       degree, coeff_dev, coeff_p_dev);
+    PFHE_HIP(hipGetLastError());
+    return PFHE_OK;
+}
+
+}  // namespace pfhe

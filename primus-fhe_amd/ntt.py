@@ -1,0 +1,177 @@
+"""U64NttTable / U64DcrtTable — the reference's `NttTable` / `DcrtTable` operator surface.
+
+Reference: primus_ntt/src/ntt/mod.rs:16-113 (trait NttTable), ntt/prime64/table.rs:41 (U64NttTable),
+primus_ntt/src/dcrt/mod.rs:19-135 (trait DcrtTable), dcrt/prime64.rs:11 (U64DcrtTable).
+
+`*_slice` methods take numpy uint64 arrays on the host and transform them in place, like the
+reference's `&mut [u64]`.  `*_dev` methods take a device pointer (int) or a torch CUDA tensor and
+an optional stream and are asynchronous; the batch is len / unit polynomials.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import PfheError, check, lib, u64p
+
+NttError = PfheError  # primus_ntt::NttError variants are carried in PfheError.kind
+
+
+def _host(a: np.ndarray):
+    if not isinstance(a, np.ndarray) or a.dtype != np.uint64 or not a.flags.c_contiguous:
+        raise TypeError("expected a C-contiguous numpy uint64 array")
+    return a.ctypes.data_as(C.c_void_p), a.size
+
+
+def _dev(x):
+    """(device pointer, number of 64-bit words) of a torch CUDA tensor or a (ptr, words) pair."""
+    if isinstance(x, tuple):
+        return C.c_void_p(int(x[0])), int(x[1])
+    if hasattr(x, "data_ptr"):
+        if x.element_size() != 8 or not x.is_contiguous() or not x.is_cuda:
+            raise TypeError("expected a contiguous 64-bit CUDA tensor")
+        return C.c_void_p(x.data_ptr()), x.numel()
+    raise TypeError("expected a torch CUDA tensor or a (device_ptr, words) tuple")
+
+
+def _stream(stream):
+    if stream is None:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        except Exception:
+            pass
+        return C.c_void_p(0)
+    return C.c_void_p(int(getattr(stream, "cuda_stream", stream)))
+
+
+class U64NttTable:
+    """primus_ntt::U64NttTable — negacyclic NTT over one prime q < 2^62 (table.rs:41-516)."""
+
+    def __init__(self, log_n: int, modulus: int, device: int = 0):
+        h = C.c_void_p()
+        check(lib().pfhe_ntt_create(log_n, modulus, device, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().pfhe_ntt_destroy(h)
+            self._h = None
+
+    # getters (table.rs:127-161)
+    def poly_length(self) -> int: return int(lib().pfhe_ntt_poly_length(self._h))
+    def n(self) -> int: return self.poly_length()
+    def log_n(self) -> int: return int(lib().pfhe_ntt_log_n(self._h))
+    def modulus(self) -> int: return int(lib().pfhe_ntt_modulus(self._h))
+    def root(self) -> int: return int(lib().pfhe_ntt_root(self._h))
+    def inv_root(self) -> int: return int(lib().pfhe_ntt_inv_root(self._h))
+    def inv_n(self) -> int: return int(lib().pfhe_ntt_inv_n(self._h))
+    def device(self) -> int: return int(lib().pfhe_ntt_device(self._h))
+
+    # host slices, in place (table.rs:541-563)
+    def transform_slice(self, poly): check(lib().pfhe_ntt_transform_slice(self._h, *_host(poly)))
+    def inverse_transform_slice(self, values): check(lib().pfhe_ntt_inverse_transform_slice(self._h, *_host(values)))
+    def lazy_transform_slice(self, poly): check(lib().pfhe_ntt_lazy_transform_slice(self._h, *_host(poly)))
+    def lazy_inverse_transform_slice(self, values): check(lib().pfhe_ntt_lazy_inverse_transform_slice(self._h, *_host(values)))
+    transform_inplace = transform_slice                  # table.rs:523-530
+    inverse_transform_inplace = inverse_transform_slice  # table.rs:532-539
+
+    # monomial shortcuts (table.rs:565-651)
+    def transform_monomial(self, coeff: int, degree: int, values):
+        check(lib().pfhe_ntt_transform_monomial(self._h, coeff, degree, *_host(values)))
+
+    def transform_coeff_one_monomial(self, degree: int, values):
+        check(lib().pfhe_ntt_transform_coeff_one_monomial(self._h, degree, *_host(values)))
+
+    def transform_coeff_minus_one_monomial(self, degree: int, values):
+        check(lib().pfhe_ntt_transform_coeff_minus_one_monomial(self._h, degree, *_host(values)))
+
+    # device path
+    def transform_dev(self, poly, lazy: bool = False, stream=None):
+        p, n = _dev(poly)
+        check(lib().pfhe_ntt_transform_dev(self._h, p, n, int(lazy), _stream(stream)))
+
+    def inverse_transform_dev(self, values, lazy: bool = False, stream=None):
+        p, n = _dev(values)
+        check(lib().pfhe_ntt_inverse_transform_dev(self._h, p, n, int(lazy), _stream(stream)))
+
+    def transform_monomial_dev(self, coeff: int, degree: int, values, stream=None):
+        p, n = _dev(values)
+        check(lib().pfhe_ntt_transform_monomial_dev(self._h, coeff, degree, p, n, _stream(stream)))
+
+    def mul_assign_dev(self, a, b, stream=None):
+        """NttPolynomial::mul_assign (primus_poly/src/ntt/mul.rs:84-90)."""
+        (pa, na), (pb, nb) = _dev(a), _dev(b)
+        check(lib().pfhe_ntt_mul_assign_dev(self._h, pa, na, pb, nb, _stream(stream)))
+
+    def add_mul_assign_dev(self, acc, a, b, stream=None):
+        """NttPolynomial::add_mul_assign (primus_poly/src/ntt/mod.rs:101-112)."""
+        (pc, nc), (pa, na), (pb, nb) = _dev(acc), _dev(a), _dev(b)
+        if nc != na:
+            raise PfheError(32, "acc and a differ in length")
+        check(lib().pfhe_ntt_add_mul_assign_dev(self._h, pc, pa, na, pb, nb, _stream(stream)))
+
+
+class U64DcrtTable:
+    """primus_ntt::U64DcrtTable — one U64NttTable per RNS limb, modulus-major data (dcrt/prime64.rs)."""
+
+    def __init__(self, log_n: int, moduli, device: int = 0):
+        arr = np.ascontiguousarray(np.array([int(m) for m in moduli], dtype=np.uint64))
+        h = C.c_void_p()
+        check(lib().pfhe_dcrt_create(log_n, arr.ctypes.data_as(u64p), arr.size, device, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().pfhe_dcrt_destroy(h)
+            self._h = None
+
+    def poly_length(self) -> int: return int(lib().pfhe_dcrt_poly_length(self._h))
+    def moduli_count(self) -> int: return int(lib().pfhe_dcrt_moduli_count(self._h))
+    def crt_poly_length(self) -> int: return int(lib().pfhe_dcrt_crt_poly_length(self._h))
+    def device(self) -> int: return int(lib().pfhe_dcrt_device(self._h))
+    def moduli(self): return [int(lib().pfhe_dcrt_modulus(self._h, i)) for i in range(self.moduli_count())]
+    def roots(self): return [int(lib().pfhe_dcrt_root(self._h, i)) for i in range(self.moduli_count())]
+
+    def transform_slice(self, poly): check(lib().pfhe_dcrt_transform_slice(self._h, *_host(poly)))
+    def inverse_transform_slice(self, poly): check(lib().pfhe_dcrt_inverse_transform_slice(self._h, *_host(poly)))
+    def lazy_transform_slice(self, poly): check(lib().pfhe_dcrt_lazy_transform_slice(self._h, *_host(poly)))
+    def lazy_inverse_transform_slice(self, poly): check(lib().pfhe_dcrt_lazy_inverse_transform_slice(self._h, *_host(poly)))
+    transform_inplace = transform_slice
+    inverse_transform_inplace = inverse_transform_slice
+
+    def transform_monomial(self, coeff: int, degree: int, values):
+        check(lib().pfhe_dcrt_transform_monomial(self._h, coeff, degree, *_host(values)))
+
+    def transform_coeff_one_monomial(self, degree: int, values):
+        self.transform_monomial(1, degree, values)
+
+    def transform_dev(self, poly, lazy: bool = False, stream=None):
+        p, n = _dev(poly)
+        check(lib().pfhe_dcrt_transform_dev(self._h, p, n, int(lazy), _stream(stream)))
+
+    def inverse_transform_dev(self, poly, lazy: bool = False, stream=None):
+        p, n = _dev(poly)
+        check(lib().pfhe_dcrt_inverse_transform_dev(self._h, p, n, int(lazy), _stream(stream)))
+
+    def mul_assign_dev(self, a, b, stream=None):
+        """DcrtPolynomial::mul_assign (primus_poly/src/dcrt/mul.rs:176-187); b may be one shared polynomial."""
+        (pa, na), (pb, nb) = _dev(a), _dev(b)
+        check(lib().pfhe_dcrt_mul_assign_dev(self._h, pa, na, pb, nb, _stream(stream)))
+
+    def add_mul_assign_dev(self, acc, a, b, stream=None):
+        """DcrtPolynomial::add_mul_assign (primus_poly/src/dcrt/mod.rs:105-123)."""
+        (pc, nc), (pa, na), (pb, nb) = _dev(acc), _dev(a), _dev(b)
+        if nc != na:
+            raise PfheError(32, "acc and a differ in length")
+        check(lib().pfhe_dcrt_add_mul_assign_dev(self._h, pc, pa, na, pb, nb, _stream(stream)))
+
+    def mul_dcrt_polynomial_dev(self, crt_poly, dcrt_poly, stream=None):
+        """CrtRlwe::mul_dcrt_polynomial_to + into_coeff_form (primus_lattice/src/rlwe/crt.rs:42-65,
+        macros/mod.rs:901-911): NTT -> pointwise multiply -> INTT, in place."""
+        (pa, na), (pb, nb) = _dev(crt_poly), _dev(dcrt_poly)
+        check(lib().pfhe_dcrt_mul_dcrt_polynomial_dev(self._h, pa, na, pb, nb, _stream(stream)))

@@ -1,0 +1,56 @@
+"""CPU-side boundary checks: libpfhe_hip.so builds for gfx950, loads without a GPU, exports every
+symbol include/pfhe.h declares, and fails loudly (no CPU fallback) when no device is present."""
+import ctypes
+import os
+import re
+import shutil
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pfhe():
+    import primus_fhe_amd as p
+    if not os.path.exists(p.library_path()):
+        if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+            pytest.skip("hipcc not available to build libpfhe_hip.so")
+        p.build()
+    return p
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "pfhe.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pfhe_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(pfhe):
+    lib = ctypes.CDLL(pfhe.library_path())
+    names = declared_functions()
+    assert len(names) > 40
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, f"declared in pfhe.h but not exported: {missing}"
+
+
+def test_status_strings(pfhe):
+    assert pfhe.status_string(0) == "ok"
+    assert "primitive root" in pfhe.status_string(1)
+    assert b"gfx950" in pfhe.lib().pfhe_version()
+
+
+def test_no_cpu_fallback_without_device(pfhe):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pfhe.PfheError) as e:
+        pfhe.U64NttTable(10, 4611686018425815041)
+    assert e.value.kind == "NoDevice"
+    # argument errors are reported before the device is touched, mirroring NttTable::new
+    with pytest.raises(pfhe.PfheError) as e:
+        pfhe.U64NttTable(20, 1125899906826241)   # 2N does not divide q-1
+    assert e.value.kind == "NoPrimitiveRoot"
+    with pytest.raises(pfhe.PfheError) as e:
+        pfhe.U64DcrtTable(4, [])
+    assert e.value.kind == "BadArgument"

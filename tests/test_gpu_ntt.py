@@ -1,0 +1,217 @@
+"""GPU parity (bit-exact) of the HIP NTT path against the CPU oracle, through the C ABI.
+
+Mirrors primus_ntt/src/ntt/prime64/tests.rs and primus_ntt/tests/ntt.rs, with the oracle
+(oracle/pfhe_oracle.c) standing where the reference's UintNttTable stands.
+"""
+import numpy as np
+import pytest
+
+import pyref
+from gpu_util import rand_mod, rand_rns, to_dev, to_host
+from pyref import Q61, Q62
+
+pytestmark = pytest.mark.gpu
+
+PRIMES = [Q62, Q61[0], 132120577, 1125899906826241]
+
+
+@pytest.fixture(scope="module")
+def pf():
+    import primus_fhe_amd as p
+    return p
+
+
+def max_log(q):
+    k = 0
+    while (q - 1) % (1 << (k + 2)) == 0:
+        k += 1
+    return k
+
+
+@pytest.mark.parametrize("q", PRIMES)
+@pytest.mark.parametrize("log_n", list(range(0, 18)))
+def test_forward_inverse_match_oracle(pf, orc, q, log_n):
+    if log_n > max_log(q):
+        pytest.skip("modulus has no 2N-th root")
+    rng = np.random.default_rng(1000 * log_n + q % 997)
+    n = 1 << log_n
+    batch = 5 if log_n <= 12 else 2
+    t, o = pf.U64NttTable(log_n, q), orc.U64NttTable(log_n, q)
+    assert (t.poly_length(), t.modulus(), t.root(), t.inv_root(), t.inv_n()) == (n, q, o.root, o.inv_root, o.inv_n)
+    a = rand_mod(rng, q, n * batch)
+    a[:min(n, 4)] = [0, q - 1, 1, q // 2][:min(n, 4)]
+    ref = a.copy(); o.transform_slice(ref)
+    got = a.copy(); t.transform_slice(got)
+    assert np.array_equal(got, ref)
+    t.inverse_transform_slice(got)
+    assert np.array_equal(got, a)
+    # lazy variants: documented ranges, equal mod q (prime64/tests.rs:15-47,100-106)
+    lz = a.copy(); t.lazy_transform_slice(lz)
+    assert lz.max() < 4 * q and np.array_equal(lz % np.uint64(q), ref)
+    lzi = ref.copy(); t.lazy_inverse_transform_slice(lzi)
+    assert lzi.max() < 2 * q and np.array_equal(lzi % np.uint64(q), a)
+
+
+@pytest.mark.parametrize("log_n", [4, 9, 12, 14, 16])
+def test_lazy_forward_accepts_4q_inputs(pf, orc, log_n):
+    q = Q62
+    rng = np.random.default_rng(log_n)
+    t, o = pf.U64NttTable(log_n, q), orc.U64NttTable(log_n, q)
+    a = rng.integers(0, 4 * q, 1 << log_n, dtype=np.uint64)
+    ref = (a % np.uint64(q)).copy(); o.transform_slice(ref)
+    got = a.copy(); t.lazy_transform_slice(got)
+    assert got.max() < 4 * q and np.array_equal(got % np.uint64(q), ref)
+
+
+@pytest.mark.parametrize("batch", [1, 2, 3, 7, 33, 257])
+@pytest.mark.parametrize("log_n", [3, 5, 8, 11])
+def test_ragged_batches(pf, orc, log_n, batch):
+    """batch sizes that do not fill a workgroup (several small polynomials share one)."""
+    q = Q61[1]
+    rng = np.random.default_rng(batch * 31 + log_n)
+    t, o = pf.U64NttTable(log_n, q), orc.U64NttTable(log_n, q)
+    a = rand_mod(rng, q, batch << log_n)
+    ref = a.copy(); o.transform_slice(ref)
+    got = a.copy(); t.transform_slice(got)
+    assert np.array_equal(got, ref)
+    t.inverse_transform_slice(got)
+    assert np.array_equal(got, a)
+
+
+def test_empty_and_bad_lengths(pf):
+    t = pf.U64NttTable(6, Q61[0])
+    t.transform_slice(np.empty(0, np.uint64))  # empty batch is a no-op
+    for bad in (1, 63, 65, 100):
+        with pytest.raises(pf.PfheError) as e:
+            t.transform_slice(np.zeros(bad, np.uint64))
+        assert e.value.kind == "BadLength"
+    d = pf.U64DcrtTable(6, Q61)
+    with pytest.raises(pf.PfheError) as e:
+        d.transform_slice(np.zeros(64 * 2, np.uint64))  # needs a multiple of L*N
+    assert e.value.kind == "BadLength"
+
+
+def test_create_errors(pf):
+    with pytest.raises(pf.PfheError) as e:
+        pf.U64NttTable(20, 1125899906826241)
+    assert e.value.kind == "NoPrimitiveRoot"
+    with pytest.raises(pf.PfheError) as e:
+        pf.U64DcrtTable(16, [Q61[0], 132120577 * 0 + 1125899906826241])
+    assert e.value.kind == "NoPrimitiveRoot"
+
+
+@pytest.mark.parametrize("q,log_n", [(132120577, 10), (Q61[2], 6), (Q62, 13), (Q61[0], 16), (Q61[0], 2), (Q61[0], 0)])
+def test_monomial_transforms(pf, orc, q, log_n):
+    t, o = pf.U64NttTable(log_n, q), orc.U64NttTable(log_n, q)
+    n = 1 << log_n
+    rng = np.random.default_rng(9)
+    out = np.empty(n, np.uint64)
+    for degree in sorted({0, 1, 2, n // 2, n - 1, n, n + 3, 2 * n - 1}):
+        for coeff in [0, 1, q - 1, int(rng.integers(2, q - 1))]:
+            t.transform_monomial(coeff, degree, out)
+            assert np.array_equal(out, o.transform_monomial(coeff, degree)), (degree, coeff)
+        t.transform_coeff_one_monomial(degree, out)
+        assert np.array_equal(out, o.transform_coeff_one_monomial(degree))
+        t.transform_coeff_minus_one_monomial(degree, out)
+        assert np.array_equal(out, o.transform_coeff_minus_one_monomial(degree))
+
+
+@pytest.mark.parametrize("log_n,batch", [(3, 4), (10, 3), (14, 2), (16, 2)])
+def test_dcrt_table(pf, orc, log_n, batch):
+    """U64DcrtTable: modulus-major limbs, each with its own table (dcrt/prime64.rs:98-127)."""
+    rng = np.random.default_rng(log_n)
+    d, o = pf.U64DcrtTable(log_n, Q61), orc.U64DcrtTable(log_n, Q61)
+    assert (d.poly_length(), d.moduli_count(), d.crt_poly_length()) == (1 << log_n, 3, 3 << log_n)
+    assert d.moduli() == Q61 and d.roots() == [o.table(i).root for i in range(3)]
+    a = rand_rns(rng, Q61, 1 << log_n, batch)
+    ref = a.copy(); o.transform_slice(ref)
+    got = a.copy(); d.transform_slice(got)
+    assert np.array_equal(got, ref)
+    d.inverse_transform_slice(got)
+    assert np.array_equal(got, a)
+    mono = np.empty(3 << log_n, np.uint64)
+    d.transform_monomial(5, 3, mono)
+    exp = np.concatenate([o.table(i).transform_monomial(5, 3) for i in range(3)])
+    assert np.array_equal(mono, exp)
+
+
+@pytest.mark.parametrize("log_n,batch", [(4, 3), (11, 5), (13, 2)])
+def test_pointwise_device_ops(pf, orc, log_n, batch):
+    """DcrtPolynomial::mul_assign / add_mul_assign, elementwise and shared multiplicand."""
+    rng = np.random.default_rng(7 + log_n)
+    n = 1 << log_n
+    d, o = pf.U64DcrtTable(log_n, Q61), orc.U64DcrtTable(log_n, Q61)
+    W = 3 * n
+    a, b, acc = (rand_rns(rng, Q61, n, batch) for _ in range(3))
+    bs = b[:W].copy()
+    for shared in (False, True):
+        bb = bs if shared else b
+        exp_mul, exp_fma = a.copy(), acc.copy()
+        for i in range(batch):
+            bi = bb if shared else bb[i * W:(i + 1) * W]
+            x = exp_mul[i * W:(i + 1) * W]; o.mul_assign(x, np.ascontiguousarray(bi))
+            y = exp_fma[i * W:(i + 1) * W]; o.add_mul_assign(y, np.ascontiguousarray(a[i * W:(i + 1) * W]), np.ascontiguousarray(bi))
+        da, db, dacc = to_dev(a), to_dev(bb), to_dev(acc)
+        d.add_mul_assign_dev(dacc, da, db)
+        d.mul_assign_dev(da, db)
+        assert np.array_equal(to_host(da), exp_mul)
+        assert np.array_equal(to_host(dacc), exp_fma)
+
+
+@pytest.mark.parametrize("log_n", [3, 5])
+def test_polymul_equals_schoolbook(pf, log_n):
+    """NTT -> pointwise -> INTT == schoolbook product mod (X^N+1, q) on Python integers."""
+    rng = np.random.default_rng(log_n)
+    n = 1 << log_n
+    d = pf.U64DcrtTable(log_n, Q61)
+    a, b = rand_rns(rng, Q61, n, 2), rand_rns(rng, Q61, n, 1)
+    bh = b.copy(); d.transform_slice(bh)
+    da = to_dev(a)
+    d.mul_dcrt_polynomial_dev(da, to_dev(bh))
+    got = to_host(da)
+    for e in range(2):
+        for r, q in enumerate(Q61):
+            exp = pyref.negacyclic_mul(a[(e * 3 + r) * n:(e * 3 + r + 1) * n], b[r * n:(r + 1) * n], q)
+            assert got[(e * 3 + r) * n:(e * 3 + r + 1) * n].tolist() == exp
+
+
+def test_config3_shape_vs_oracle(pf, orc):
+    """BASELINE config 3 shape (N=2^16, 3 primes) on a small batch: fused polymul == oracle."""
+    log_n, batch = 16, 3
+    rng = np.random.default_rng(3)
+    n = 1 << log_n
+    d, o = pf.U64DcrtTable(log_n, Q61), orc.U64DcrtTable(log_n, Q61)
+    a, bh = rand_rns(rng, Q61, n, batch), rand_rns(rng, Q61, n, 1)
+    exp = a.copy(); o.transform_slice(exp)
+    for i in range(batch):
+        o.mul_assign(exp[i * 3 * n:(i + 1) * 3 * n], bh)
+    o.inverse_transform_slice(exp)
+    da = to_dev(a)
+    d.mul_dcrt_polynomial_dev(da, to_dev(bh))
+    assert np.array_equal(to_host(da), exp)
+
+
+def test_full_size_roundtrip_and_spot_checks(pf, orc):
+    """BASELINE config 3' at its full batch (4096 x 3 x 2^16 words = 6 GiB): device-generated
+    inputs, forward + inverse round trip over the whole batch, oracle spot checks."""
+    import ctypes as C
+    import torch
+    log_n, batch = 16, 4096
+    n, L = 1 << log_n, 3
+    d, o = pf.U64DcrtTable(log_n, Q61), orc.U64DcrtTable(log_n, Q61)
+    words = batch * L * n
+    x = torch.empty(words, dtype=torch.int64, device="cuda")
+    mod = np.array(Q61, np.uint64)
+    from primus_fhe_amd._lib import check, u64p
+    check(pf.lib().pfhe_fill_uniform_dev(0, C.c_void_p(x.data_ptr()), words, mod.ctypes.data_as(u64p), 3, n,
+                                         0x5EED000000000003, None))
+    orig = x.clone()
+    d.transform_dev(x)
+    torch.cuda.synchronize()
+    for e in (0, 1777, batch - 1):
+        ref = to_host(orig[e * L * n:(e + 1) * L * n]).copy()
+        assert all(int(ref[r * n:(r + 1) * n].max()) < Q61[r] for r in range(3))
+        o.transform_slice(ref)
+        assert np.array_equal(to_host(x[e * L * n:(e + 1) * L * n]), ref)
+    d.inverse_transform_dev(x)
+    assert torch.equal(x, orig)
