@@ -173,6 +173,103 @@ int pfhe_dcrt_mul_dcrt_polynomial_dev(const pfhe_dcrt *table, uint64_t *crt_poly
                                       size_t len, const uint64_t *dcrt_poly_dev, size_t len_b,
                                       void *stream);
 
+/* =====================================================================================
+ * RNSBase<u64, BarrettModulus<u64>> — primus_rns/src/base.rs:26
+ * ===================================================================================== */
+typedef struct pfhe_rns pfhe_rns;
+
+/* RNSBase::new(moduli) — base.rs:79-117.  Errors: EMPTY_BASE (:47-49), COPRIME (:83-89),
+ * UNREPRESENTABLE_MODULUS when a modulus is not in (1, 2^62) (BarrettModulus::new,
+ * primus_modulus/src/barrett/mod.rs:39-44), UNSUPPORTED for more than 8 moduli. */
+int pfhe_rns_create(const uint64_t *moduli, size_t count, int device, pfhe_rns **out);
+void pfhe_rns_destroy(pfhe_rns *base);
+size_t pfhe_rns_moduli_count(const pfhe_rns *base);        /* base.rs:124 */
+size_t pfhe_rns_big_uint_value_len(const pfhe_rns *base);  /* base.rs:139 */
+int pfhe_rns_moduli_product(const pfhe_rns *base, uint64_t *out, size_t len); /* base.rs:133 */
+/* compose_multiple_values_to — base.rs:648-675 (-> compose_to :609-633): residue i of value c is
+ * multi_residues[i*value_count + c] (modulus-major); value c is written as big_uint_value_len
+ * little-endian limbs at big_uint_values[c*big_uint_value_len], canonical in [0, Q). */
+int pfhe_rns_compose_multiple_values_to(const pfhe_rns *base, const uint64_t *multi_residues,
+                                        size_t len_in, uint64_t *big_uint_values, size_t len_out,
+                                        size_t value_count);
+int pfhe_rns_compose_multiple_values_to_dev(const pfhe_rns *base, const uint64_t *multi_residues_dev,
+                                            size_t len_in, uint64_t *big_uint_values_dev,
+                                            size_t len_out, size_t value_count, void *stream);
+/* wrapping_decompose_small_values_to — base.rs:279-312 (+ :721-730): centred lift of u in
+ * [0, small_value_modulus): u < ceil(m/2) ? u : q_i - m + u ; m == 2 copies. */
+int pfhe_rns_wrapping_decompose_small_values_to(const pfhe_rns *base, const uint64_t *small_values,
+                                                size_t value_count, uint64_t *multi_residues,
+                                                size_t len_out, uint64_t small_value_modulus);
+int pfhe_rns_wrapping_decompose_small_values_to_dev(const pfhe_rns *base,
+                                                    const uint64_t *small_values_dev,
+                                                    size_t value_count, uint64_t *multi_residues_dev,
+                                                    size_t len_out, uint64_t small_value_modulus,
+                                                    void *stream);
+
+/* =====================================================================================
+ * BigUintApproxSignedBasis<u64> — primus_decompose/src/big_integer/basis.rs:17
+ * ===================================================================================== */
+typedef struct pfhe_basis pfhe_basis;
+
+/* BigUintApproxSignedBasis::new(Q, log_basis, reverse_length, rns_base) — basis.rs:40-211.
+ * reverse_length == 0 means None (full chain).  The reference asserts; we return BAD_ARGUMENT. */
+int pfhe_basis_create(const pfhe_rns *base, uint32_t log_basis, size_t reverse_length,
+                      pfhe_basis **out);
+void pfhe_basis_destroy(pfhe_basis *basis);
+size_t pfhe_basis_decompose_length(const pfhe_basis *basis); /* basis.rs:236 */
+uint32_t pfhe_basis_log_basis(const pfhe_basis *basis);      /* :242 */
+uint32_t pfhe_basis_drop_bits(const pfhe_basis *basis);      /* :248 */
+uint64_t pfhe_basis_basis_value(const pfhe_basis *basis);    /* :224 */
+/* scalar_iter (:283) = 2^(drop + j*log_basis) as big_uint_value_len limbs per level;
+ * iter_scalar_residues (:266) = the same reduced modulo every RNS modulus. */
+int pfhe_basis_scalars(const pfhe_basis *basis, uint64_t *out, size_t len);
+int pfhe_basis_scalars_residue(const pfhe_basis *basis, uint64_t *out, size_t len);
+/* init_value_carry_slice_inplace — basis.rs:326-367.  carries are one byte (0/1) per value. */
+int pfhe_basis_init_value_carry_slice_inplace(const pfhe_basis *basis, uint64_t *values, size_t len,
+                                              uint8_t *carries, size_t count);
+int pfhe_basis_init_value_carry_slice_inplace_dev(const pfhe_basis *basis, uint64_t *values_dev,
+                                                  size_t len, uint8_t *carries_dev, size_t count,
+                                                  void *stream);
+/* decomposer_iter().nth(level).unsigned_decompose_slice_to — big_integer/common.rs:309-325
+ * (-> unsigned_decompose_to :275-285); level 0 is the least significant digit. */
+int pfhe_basis_unsigned_decompose_slice_to(const pfhe_basis *basis, size_t level,
+                                           const uint64_t *values, size_t len, uint64_t *digits,
+                                           uint8_t *carries, size_t count);
+int pfhe_basis_unsigned_decompose_slice_to_dev(const pfhe_basis *basis, size_t level,
+                                               const uint64_t *values_dev, size_t len,
+                                               uint64_t *digits_dev, uint8_t *carries_dev,
+                                               size_t count, void *stream);
+
+/* =====================================================================================
+ * RNS gadget external product — primus_lattice
+ * ===================================================================================== */
+typedef struct pfhe_extprod_plan pfhe_extprod_plan;
+
+/* Bundles what the reference passes as (&BigUintApproxSignedBasis, &Table, &RNSBase,
+ * &mut DcrtGlevContext) — glwe/crt.rs:200-212, context/glev.rs:4-68.  The plan borrows `table`
+ * (which must outlive it) and owns device scratch for `chunk` ciphertexts (0 = default 8):
+ * chunk*(k+1)*ell*L*N words.  Like `&mut DcrtGlevContext` it must not be used concurrently. */
+int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *base, const pfhe_basis *basis,
+                             size_t glwe_dimension, size_t chunk, pfhe_extprod_plan **out);
+void pfhe_extprod_plan_destroy(pfhe_extprod_plan *plan);
+size_t pfhe_extprod_plan_scratch_bytes(const pfhe_extprod_plan *plan);
+/* CrtGlwe::mul_dcrt_ggsw_to — glwe/crt.rs:200-227.  crt_glwe: batch x (k+1) CRT polynomials
+ * |a1|..|ak|b|; dcrt_ggsw: ONE GGSW shared by the batch or batch GGSWs, each
+ * (k+1) rows x ell levels x (k+1) components x L x N words; result: batch DcrtGlwe (NTT form), or
+ * coefficient form when into_coeff_form != 0 (DcrtGlwe::into_coeff_form, macros/mod.rs:901-911). */
+int pfhe_extprod_mul_dcrt_ggsw_to(pfhe_extprod_plan *plan, const uint64_t *crt_glwe, size_t len_glwe,
+                                  const uint64_t *dcrt_ggsw, size_t len_ggsw, uint64_t *result,
+                                  size_t len_result, int into_coeff_form);
+int pfhe_extprod_mul_dcrt_ggsw_to_dev(pfhe_extprod_plan *plan, const uint64_t *crt_glwe_dev,
+                                      size_t len_glwe, const uint64_t *dcrt_ggsw_dev, size_t len_ggsw,
+                                      uint64_t *result_dev, size_t len_result, int into_coeff_form,
+                                      void *stream);
+/* DcrtGlwe::add_dcrt_glev_mul_crt_poly_assign — glwe/dcrt.rs:178-255: acc += glev (x) crt_poly. */
+int pfhe_extprod_add_dcrt_glev_mul_crt_poly_assign_dev(pfhe_extprod_plan *plan, uint64_t *acc_dev,
+                                                       size_t len_acc, const uint64_t *dcrt_glev_dev,
+                                                       size_t len_glev, const uint64_t *crt_poly_dev,
+                                                       size_t len_poly, void *stream);
+
 /* Profiling hooks (bench.py / rocprofv3): a transform is executed as a short sequence of kernel
  * passes (DESIGN.md "Kernels"); these run or name ONE pass so that each kernel can be timed with
  * HIP events in isolation.  The data is only meaningful after all passes have run in order. */

@@ -93,6 +93,34 @@ def _declare(lib: C.CDLL) -> None:
     sig("pfhe_dcrt_mul_assign_dev", ci, vp, vp, sz, vp, sz, vp)
     sig("pfhe_dcrt_add_mul_assign_dev", ci, vp, vp, vp, sz, vp, sz, vp)
     sig("pfhe_dcrt_mul_dcrt_polynomial_dev", ci, vp, vp, sz, vp, sz, vp)
+    u8p = C.POINTER(C.c_uint8)
+    sig("pfhe_rns_create", ci, u64p, sz, ci, C.POINTER(vp))
+    sig("pfhe_rns_destroy", None, vp)
+    sig("pfhe_rns_moduli_count", sz, vp)
+    sig("pfhe_rns_big_uint_value_len", sz, vp)
+    sig("pfhe_rns_moduli_product", ci, vp, vp, sz)
+    sig("pfhe_rns_compose_multiple_values_to", ci, vp, vp, sz, vp, sz, sz)
+    sig("pfhe_rns_compose_multiple_values_to_dev", ci, vp, vp, sz, vp, sz, sz, vp)
+    sig("pfhe_rns_wrapping_decompose_small_values_to", ci, vp, vp, sz, vp, sz, u64)
+    sig("pfhe_rns_wrapping_decompose_small_values_to_dev", ci, vp, vp, sz, vp, sz, u64, vp)
+    sig("pfhe_basis_create", ci, vp, u32, sz, C.POINTER(vp))
+    sig("pfhe_basis_destroy", None, vp)
+    sig("pfhe_basis_decompose_length", sz, vp)
+    sig("pfhe_basis_log_basis", u32, vp)
+    sig("pfhe_basis_drop_bits", u32, vp)
+    sig("pfhe_basis_basis_value", u64, vp)
+    sig("pfhe_basis_scalars", ci, vp, vp, sz)
+    sig("pfhe_basis_scalars_residue", ci, vp, vp, sz)
+    sig("pfhe_basis_init_value_carry_slice_inplace", ci, vp, vp, sz, vp, sz)
+    sig("pfhe_basis_init_value_carry_slice_inplace_dev", ci, vp, vp, sz, vp, sz, vp)
+    sig("pfhe_basis_unsigned_decompose_slice_to", ci, vp, sz, vp, sz, vp, vp, sz)
+    sig("pfhe_basis_unsigned_decompose_slice_to_dev", ci, vp, sz, vp, sz, vp, vp, sz, vp)
+    sig("pfhe_extprod_plan_create", ci, vp, vp, vp, sz, sz, C.POINTER(vp))
+    sig("pfhe_extprod_plan_destroy", None, vp)
+    sig("pfhe_extprod_plan_scratch_bytes", sz, vp)
+    sig("pfhe_extprod_mul_dcrt_ggsw_to", ci, vp, vp, sz, vp, sz, vp, sz, ci)
+    sig("pfhe_extprod_mul_dcrt_ggsw_to_dev", ci, vp, vp, sz, vp, sz, vp, sz, ci, vp)
+    sig("pfhe_extprod_add_dcrt_glev_mul_crt_poly_assign_dev", ci, vp, vp, sz, vp, sz, vp, sz, vp)
     sig("pfhe_dcrt_transform_num_passes", ci, vp)
     sig("pfhe_dcrt_transform_pass_name", C.c_char_p, vp, ci, ci)
     sig("pfhe_dcrt_transform_pass_dev", ci, vp, vp, sz, ci, ci, ci, vp)

@@ -6,6 +6,7 @@
 #include <memory>
 #include <new>
 
+#include "pfhe_capi_internal.hpp"
 #include "pfhe_common.hpp"
 #include "pfhe_handles.hpp"
 #include "pfhe_ntt_device.hpp"
@@ -224,17 +225,11 @@ struct pfhe_dcrt {
     std::unique_ptr<TableSet> t;
 };
 
-#define PFHE_GUARD_BEGIN try {
-#define PFHE_GUARD_END                                   \
-    }                                                    \
-    catch (const std::bad_alloc &) {                     \
-        set_last_error("out of host memory");            \
-        return PFHE_ERR_HIP;                             \
-    }                                                    \
-    catch (...) {                                        \
-        set_last_error("unexpected C++ exception");      \
-        return PFHE_ERR_HIP;                             \
-    }
+namespace pfhe {
+int capi_check_device(int device) { return check_device(device); }
+const TableSet *capi_table_of(const pfhe_dcrt *t) { return t->t.get(); }
+}  // namespace pfhe
+
 
 extern "C" {
 

@@ -1,0 +1,396 @@
+// pfhe_capi_rns.hip — extern "C" boundary for RNSBase, BigUintApproxSignedBasis and the RNS gadget
+// external product (include/pfhe.h, second half).
+#include <memory>
+#include <new>
+
+#include "pfhe_capi_internal.hpp"
+#include "pfhe_ntt_device.hpp"
+#include "pfhe_rns.hpp"
+
+using namespace pfhe;
+
+struct pfhe_rns {
+    RnsHost h;
+};
+struct pfhe_basis {
+    BasisHost h;
+};
+struct pfhe_extprod_plan {
+    const TableSet *table = nullptr;  // borrowed from the pfhe_dcrt (must outlive the plan)
+    RnsDev rns{};
+    BasisDev basis{};
+    u32 k = 1;
+    size_t chunk = 1;
+    u64 *digits = nullptr;  // chunk * (k+1) * ell * L * N words of device scratch
+    size_t digits_words = 0;
+    ~pfhe_extprod_plan() {
+        if (digits && table) {
+            DeviceGuard g(table->device);
+            (void)hipFree(digits);
+        }
+    }
+};
+
+namespace {
+
+// temporary device buffers for the host-pointer convenience entry points
+struct Staging {
+    std::vector<void *> bufs;
+    ~Staging() {
+        for (void *p : bufs) (void)hipFree(p);
+    }
+    int alloc(size_t bytes, void **out) {
+        *out = nullptr;
+        if (bytes == 0) bytes = 8;
+        PFHE_HIP(hipMalloc(out, bytes));
+        bufs.push_back(*out);
+        return PFHE_OK;
+    }
+    int upload(const void *host, size_t bytes, void **out) {
+        PFHE_TRY(alloc(bytes, out));
+        if (bytes) PFHE_HIP(hipMemcpy(*out, host, bytes, hipMemcpyHostToDevice));
+        return PFHE_OK;
+    }
+};
+
+int plan_check(const pfhe_extprod_plan *p) {
+    if (!p || !p->table) return PFHE_ERR_BAD_ARGUMENT;
+    return PFHE_OK;
+}
+
+// one row of the product: acc[e] += glev[e or shared] (x) crt_poly[e]   (glwe/dcrt.rs:178-255)
+// rows == k+1 with `zero_first` gives CrtGlwe::mul_dcrt_ggsw_to (glwe/crt.rs:200-227).
+int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 *keys, bool keys_shared, u64 *result,
+                u64 batch, bool accumulate, hipStream_t s) {
+    const TableSet &t = *p->table;
+    const u64 W = (u64)t.L * t.n;
+    const u32 ell = p->basis.ell;
+    const u64 key_words = (u64)rows * ell * (p->k + 1) * W;
+    for (u64 done = 0; done < batch; done += p->chunk) {
+        const u64 cur = std::min<u64>(p->chunk, batch - done);
+        const u64 *in = crt_polys + done * rows * W;
+        PFHE_TRY(gadget_decompose_dev(p->rns, p->basis, t.log_n, in, p->digits, cur * rows, s));
+        PFHE_TRY(ntt_forward_dev(t.primes_dev, t.L, t.log_n, p->digits, cur * rows * ell * t.L, false, s));
+        PFHE_TRY(gadget_mulacc_dev(t.primes_dev, t.L, t.log_n, p->k, rows, ell, p->digits,
+                                   keys + (keys_shared ? 0 : done * key_words), keys_shared,
+                                   result + done * (p->k + 1) * W, cur, accumulate, s));
+    }
+    return PFHE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* ------------------------------ RNSBase ------------------------------ */
+
+int pfhe_rns_create(const uint64_t *moduli, size_t count, int device, pfhe_rns **out) {
+    PFHE_GUARD_BEGIN
+    if (!out || (!moduli && count)) return PFHE_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    auto r = std::make_unique<pfhe_rns>();
+    PFHE_TRY(build_rns((const u64 *)moduli, count, r->h));
+    PFHE_TRY(capi_check_device(device));
+    r->h.device = device;
+    *out = r.release();
+    return PFHE_OK;
+    PFHE_GUARD_END
+}
+
+void pfhe_rns_destroy(pfhe_rns *r) { delete r; }
+size_t pfhe_rns_moduli_count(const pfhe_rns *r) { return r ? r->h.dev.L : 0; }
+size_t pfhe_rns_big_uint_value_len(const pfhe_rns *r) { return r ? r->h.dev.value_len : 0; }
+
+int pfhe_rns_moduli_product(const pfhe_rns *r, uint64_t *out, size_t len) {
+    if (!r || !out) return PFHE_ERR_BAD_ARGUMENT;
+    if (len != r->h.dev.value_len) return PFHE_ERR_BAD_LENGTH;
+    for (size_t j = 0; j < len; ++j) out[j] = r->h.dev.Q[j];
+    return PFHE_OK;
+}
+
+int pfhe_rns_compose_multiple_values_to_dev(const pfhe_rns *r, const uint64_t *multi_residues_dev, size_t len_in,
+                                            uint64_t *big_uint_values_dev, size_t len_out, size_t value_count,
+                                            void *stream) {
+    PFHE_GUARD_BEGIN
+    if (!r || ((!multi_residues_dev || !big_uint_values_dev) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
+    if (len_in != value_count * r->h.dev.L || len_out != value_count * r->h.dev.value_len) {
+        set_last_error("compose: multi_residues must hold moduli_count*value_count words and the output "
+                       "value_count*big_uint_value_len words");
+        return PFHE_ERR_BAD_LENGTH;
+    }
+    DeviceGuard g(r->h.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    return rns_compose_dev(r->h.dev, (const u64 *)multi_residues_dev, (u64 *)big_uint_values_dev, value_count,
+                           (hipStream_t)stream);
+    PFHE_GUARD_END
+}
+
+int pfhe_rns_compose_multiple_values_to(const pfhe_rns *r, const uint64_t *multi_residues, size_t len_in,
+                                        uint64_t *big_uint_values, size_t len_out, size_t value_count) {
+    PFHE_GUARD_BEGIN
+    if (!r || ((!multi_residues || !big_uint_values) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
+    if (len_in != value_count * r->h.dev.L || len_out != value_count * r->h.dev.value_len) return PFHE_ERR_BAD_LENGTH;
+    if (value_count == 0) return PFHE_OK;
+    DeviceGuard g(r->h.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    Staging st;
+    void *in = nullptr, *o = nullptr;
+    PFHE_TRY(st.upload(multi_residues, len_in * 8, &in));
+    PFHE_TRY(st.alloc(len_out * 8, &o));
+    PFHE_TRY(rns_compose_dev(r->h.dev, (const u64 *)in, (u64 *)o, value_count, nullptr));
+    PFHE_HIP(hipMemcpy(big_uint_values, o, len_out * 8, hipMemcpyDeviceToHost));
+    return PFHE_OK;
+    PFHE_GUARD_END
+}
+
+int pfhe_rns_wrapping_decompose_small_values_to_dev(const pfhe_rns *r, const uint64_t *small_values_dev,
+                                                    size_t value_count, uint64_t *multi_residues_dev, size_t len_out,
+                                                    uint64_t small_value_modulus, void *stream) {
+    PFHE_GUARD_BEGIN
+    if (!r || ((!small_values_dev || !multi_residues_dev) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
+    if (len_out != value_count * r->h.dev.L) return PFHE_ERR_BAD_LENGTH;
+    for (u32 i = 0; i < r->h.dev.L; ++i) {
+        if (small_value_modulus >= r->h.dev.q[i] || small_value_modulus < 2) {  // base.rs:288-292
+            set_last_error("small_value_modulus must be >= 2 and smaller than every RNS modulus");
+            return PFHE_ERR_BAD_ARGUMENT;
+        }
+    }
+    DeviceGuard g(r->h.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    return rns_wrapping_decompose_dev(r->h.dev, (const u64 *)small_values_dev, (u64 *)multi_residues_dev, value_count,
+                                      small_value_modulus, (hipStream_t)stream);
+    PFHE_GUARD_END
+}
+
+int pfhe_rns_wrapping_decompose_small_values_to(const pfhe_rns *r, const uint64_t *small_values, size_t value_count,
+                                                uint64_t *multi_residues, size_t len_out,
+                                                uint64_t small_value_modulus) {
+    PFHE_GUARD_BEGIN
+    if (!r || ((!small_values || !multi_residues) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
+    if (len_out != value_count * r->h.dev.L) return PFHE_ERR_BAD_LENGTH;
+    if (value_count == 0) return PFHE_OK;
+    DeviceGuard g(r->h.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    Staging st;
+    void *in = nullptr, *o = nullptr;
+    PFHE_TRY(st.upload(small_values, value_count * 8, &in));
+    PFHE_TRY(st.alloc(len_out * 8, &o));
+    PFHE_TRY(pfhe_rns_wrapping_decompose_small_values_to_dev(r, (const uint64_t *)in, value_count, (uint64_t *)o,
+                                                             len_out, small_value_modulus, nullptr));
+    PFHE_HIP(hipMemcpy(multi_residues, o, len_out * 8, hipMemcpyDeviceToHost));
+    return PFHE_OK;
+    PFHE_GUARD_END
+}
+
+/* ------------------------------ BigUintApproxSignedBasis ------------------------------ */
+
+int pfhe_basis_create(const pfhe_rns *rns, uint32_t log_basis, size_t reverse_length, pfhe_basis **out) {
+    PFHE_GUARD_BEGIN
+    if (!out || !rns) return PFHE_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    auto b = std::make_unique<pfhe_basis>();
+    PFHE_TRY(build_basis(rns->h, log_basis, reverse_length, b->h));
+    *out = b.release();
+    return PFHE_OK;
+    PFHE_GUARD_END
+}
+
+void pfhe_basis_destroy(pfhe_basis *b) { delete b; }
+size_t pfhe_basis_decompose_length(const pfhe_basis *b) { return b ? b->h.dev.ell : 0; }
+uint32_t pfhe_basis_log_basis(const pfhe_basis *b) { return b ? b->h.dev.log_basis : 0; }
+uint32_t pfhe_basis_drop_bits(const pfhe_basis *b) { return b ? b->h.dev.drop_bits : 0; }
+uint64_t pfhe_basis_basis_value(const pfhe_basis *b) { return b ? b->h.dev.basis : 0; }
+
+int pfhe_basis_scalars(const pfhe_basis *b, uint64_t *out, size_t len) {
+    if (!b || !out) return PFHE_ERR_BAD_ARGUMENT;
+    if (len != b->h.scalars.size()) return PFHE_ERR_BAD_LENGTH;
+    std::copy(b->h.scalars.begin(), b->h.scalars.end(), out);
+    return PFHE_OK;
+}
+
+int pfhe_basis_scalars_residue(const pfhe_basis *b, uint64_t *out, size_t len) {
+    if (!b || !out) return PFHE_ERR_BAD_ARGUMENT;
+    if (len != b->h.scalars_residue.size()) return PFHE_ERR_BAD_LENGTH;
+    std::copy(b->h.scalars_residue.begin(), b->h.scalars_residue.end(), out);
+    return PFHE_OK;
+}
+
+int pfhe_basis_init_value_carry_slice_inplace_dev(const pfhe_basis *b, uint64_t *values_dev, size_t len,
+                                                  uint8_t *carries_dev, size_t count, void *stream) {
+    PFHE_GUARD_BEGIN
+    if (!b || ((!values_dev || !carries_dev) && count)) return PFHE_ERR_BAD_ARGUMENT;
+    if (len != count * b->h.dev.value_len) return PFHE_ERR_BAD_LENGTH;  // basis.rs:332
+    DeviceGuard g(b->h.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    return basis_init_value_carry_dev(b->h.dev, (u64 *)values_dev, carries_dev, count, (hipStream_t)stream);
+    PFHE_GUARD_END
+}
+
+int pfhe_basis_init_value_carry_slice_inplace(const pfhe_basis *b, uint64_t *values, size_t len, uint8_t *carries,
+                                              size_t count) {
+    PFHE_GUARD_BEGIN
+    if (!b || ((!values || !carries) && count)) return PFHE_ERR_BAD_ARGUMENT;
+    if (len != count * b->h.dev.value_len) return PFHE_ERR_BAD_LENGTH;
+    if (count == 0) return PFHE_OK;
+    DeviceGuard g(b->h.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    Staging st;
+    void *v = nullptr, *c = nullptr;
+    PFHE_TRY(st.upload(values, len * 8, &v));
+    PFHE_TRY(st.alloc(count, &c));
+    PFHE_TRY(basis_init_value_carry_dev(b->h.dev, (u64 *)v, (unsigned char *)c, count, nullptr));
+    PFHE_HIP(hipMemcpy(values, v, len * 8, hipMemcpyDeviceToHost));
+    PFHE_HIP(hipMemcpy(carries, c, count, hipMemcpyDeviceToHost));
+    return PFHE_OK;
+    PFHE_GUARD_END
+}
+
+int pfhe_basis_unsigned_decompose_slice_to_dev(const pfhe_basis *b, size_t level, const uint64_t *values_dev,
+                                               size_t len, uint64_t *digits_dev, uint8_t *carries_dev, size_t count,
+                                               void *stream) {
+    PFHE_GUARD_BEGIN
+    if (!b || ((!values_dev || !digits_dev || !carries_dev) && count)) return PFHE_ERR_BAD_ARGUMENT;
+    if (level >= b->h.dev.ell) return PFHE_ERR_BAD_ARGUMENT;
+    if (len != count * b->h.dev.value_len) return PFHE_ERR_BAD_LENGTH;  // common.rs:316-317
+    DeviceGuard g(b->h.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    return basis_unsigned_decompose_dev(b->h.dev, (u32)level, (const u64 *)values_dev, (u64 *)digits_dev, carries_dev,
+                                        count, (hipStream_t)stream);
+    PFHE_GUARD_END
+}
+
+int pfhe_basis_unsigned_decompose_slice_to(const pfhe_basis *b, size_t level, const uint64_t *values, size_t len,
+                                           uint64_t *digits, uint8_t *carries, size_t count) {
+    PFHE_GUARD_BEGIN
+    if (!b || ((!values || !digits || !carries) && count)) return PFHE_ERR_BAD_ARGUMENT;
+    if (level >= b->h.dev.ell) return PFHE_ERR_BAD_ARGUMENT;
+    if (len != count * b->h.dev.value_len) return PFHE_ERR_BAD_LENGTH;
+    if (count == 0) return PFHE_OK;
+    DeviceGuard g(b->h.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    Staging st;
+    void *v = nullptr, *d = nullptr, *c = nullptr;
+    PFHE_TRY(st.upload(values, len * 8, &v));
+    PFHE_TRY(st.alloc(count * 8, &d));
+    PFHE_TRY(st.upload(carries, count, &c));
+    PFHE_TRY(basis_unsigned_decompose_dev(b->h.dev, (u32)level, (const u64 *)v, (u64 *)d, (unsigned char *)c, count,
+                                          nullptr));
+    PFHE_HIP(hipMemcpy(digits, d, count * 8, hipMemcpyDeviceToHost));
+    PFHE_HIP(hipMemcpy(carries, c, count, hipMemcpyDeviceToHost));
+    return PFHE_OK;
+    PFHE_GUARD_END
+}
+
+/* ------------------------------ external product ------------------------------ */
+
+int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *rns, const pfhe_basis *basis,
+                             size_t glwe_dimension, size_t chunk, pfhe_extprod_plan **out) {
+    PFHE_GUARD_BEGIN
+    if (!out || !table || !rns || !basis || glwe_dimension == 0 || glwe_dimension > 64) return PFHE_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    const TableSet *t = capi_table_of(table);
+    if (t->L != rns->h.dev.L) {
+        set_last_error("DCRT table and RNS base have different moduli counts");
+        return PFHE_ERR_BAD_ARGUMENT;
+    }
+    for (u32 i = 0; i < t->L; ++i) {
+        if (t->primes[i].q != rns->h.dev.q[i]) {
+            set_last_error("DCRT table and RNS base must use the same moduli in the same order");
+            return PFHE_ERR_BAD_ARGUMENT;
+        }
+    }
+    if (basis->h.rns.value_len != rns->h.dev.value_len || basis->h.rns.L != rns->h.dev.L) return PFHE_ERR_BAD_ARGUMENT;
+    for (u32 j = 0; j < rns->h.dev.value_len; ++j)
+        if (basis->h.rns.Q[j] != rns->h.dev.Q[j]) return PFHE_ERR_BAD_ARGUMENT;  // basis.rs:52
+    auto p = std::make_unique<pfhe_extprod_plan>();
+    p->table = t;
+    p->rns = rns->h.dev;
+    p->basis = basis->h.dev;
+    p->k = (u32)glwe_dimension;
+    p->chunk = chunk ? chunk : 8;
+    p->digits_words = p->chunk * (p->k + 1) * p->basis.ell * t->L * t->n;
+    DeviceGuard g(t->device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    void *d = nullptr;
+    PFHE_HIP(hipMalloc(&d, p->digits_words * sizeof(u64)));
+    p->digits = (u64 *)d;
+    *out = p.release();
+    return PFHE_OK;
+    PFHE_GUARD_END
+}
+
+void pfhe_extprod_plan_destroy(pfhe_extprod_plan *p) { delete p; }
+size_t pfhe_extprod_plan_scratch_bytes(const pfhe_extprod_plan *p) { return p ? p->digits_words * 8 : 0; }
+
+int pfhe_extprod_mul_dcrt_ggsw_to_dev(pfhe_extprod_plan *plan, const uint64_t *crt_glwe_dev, size_t len_glwe,
+                                      const uint64_t *dcrt_ggsw_dev, size_t len_ggsw, uint64_t *result_dev,
+                                      size_t len_result, int into_coeff_form, void *stream) {
+    PFHE_GUARD_BEGIN
+    PFHE_TRY(plan_check(plan));
+    const TableSet &t = *plan->table;
+    const size_t W = (size_t)t.L * t.n, glwe = (plan->k + 1) * W;
+    const size_t ggsw = (size_t)(plan->k + 1) * plan->basis.ell * glwe;
+    if (len_glwe % glwe != 0 || len_result != len_glwe || (len_ggsw != ggsw && len_ggsw != len_glwe / glwe * ggsw)) {
+        set_last_error("external product: glwe/result must be batch*(k+1)*L*N words and the GGSW one or batch "
+                       "ciphertexts of (k+1)*ell*(k+1)*L*N words");
+        return PFHE_ERR_BAD_LENGTH;
+    }
+    const u64 batch = len_glwe / glwe;
+    if (batch == 0) return PFHE_OK;
+    if (!crt_glwe_dev || !dcrt_ggsw_dev || !result_dev) return PFHE_ERR_BAD_ARGUMENT;
+    DeviceGuard g(t.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    const bool shared = len_ggsw == ggsw && batch > 1 ? true : (len_ggsw == ggsw);
+    // result.set_zero() (glwe/crt.rs:217) is implied: the first accumulation overwrites
+    PFHE_TRY(run_product(plan, (const u64 *)crt_glwe_dev, plan->k + 1, (const u64 *)dcrt_ggsw_dev, shared,
+                         (u64 *)result_dev, batch, false, (hipStream_t)stream));
+    if (into_coeff_form)  // DcrtGlwe::into_coeff_form, macros/mod.rs:901-911
+        PFHE_TRY(ntt_inverse_dev(t.primes_dev, t.L, t.log_n, (u64 *)result_dev, batch * (plan->k + 1) * t.L, false,
+                                 (hipStream_t)stream));
+    return PFHE_OK;
+    PFHE_GUARD_END
+}
+
+int pfhe_extprod_add_dcrt_glev_mul_crt_poly_assign_dev(pfhe_extprod_plan *plan, uint64_t *acc_dev, size_t len_acc,
+                                                       const uint64_t *dcrt_glev_dev, size_t len_glev,
+                                                       const uint64_t *crt_poly_dev, size_t len_poly, void *stream) {
+    PFHE_GUARD_BEGIN
+    PFHE_TRY(plan_check(plan));
+    const TableSet &t = *plan->table;
+    const size_t W = (size_t)t.L * t.n, glwe = (plan->k + 1) * W, glev = plan->basis.ell * glwe;
+    if (len_poly % W != 0) return PFHE_ERR_BAD_LENGTH;
+    const u64 batch = len_poly / W;
+    if (len_acc != batch * glwe || (len_glev != glev && len_glev != batch * glev)) {
+        set_last_error("glev product: acc must be batch*(k+1)*L*N words and the GLev one or batch of ell*(k+1)*L*N");
+        return PFHE_ERR_BAD_LENGTH;
+    }
+    if (batch == 0) return PFHE_OK;
+    if (!acc_dev || !dcrt_glev_dev || !crt_poly_dev) return PFHE_ERR_BAD_ARGUMENT;
+    DeviceGuard g(t.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    return run_product(plan, (const u64 *)crt_poly_dev, 1, (const u64 *)dcrt_glev_dev, len_glev == glev,
+                       (u64 *)acc_dev, batch, true, (hipStream_t)stream);
+    PFHE_GUARD_END
+}
+
+int pfhe_extprod_mul_dcrt_ggsw_to(pfhe_extprod_plan *plan, const uint64_t *crt_glwe, size_t len_glwe,
+                                  const uint64_t *dcrt_ggsw, size_t len_ggsw, uint64_t *result, size_t len_result,
+                                  int into_coeff_form) {
+    PFHE_GUARD_BEGIN
+    PFHE_TRY(plan_check(plan));
+    if ((!crt_glwe || !dcrt_ggsw || !result) && len_glwe) return PFHE_ERR_BAD_ARGUMENT;
+    DeviceGuard g(plan->table->device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    Staging st;
+    void *a = nullptr, *k = nullptr, *r = nullptr;
+    PFHE_TRY(st.upload(crt_glwe, len_glwe * 8, &a));
+    PFHE_TRY(st.upload(dcrt_ggsw, len_ggsw * 8, &k));
+    PFHE_TRY(st.alloc(len_result * 8, &r));
+    PFHE_TRY(pfhe_extprod_mul_dcrt_ggsw_to_dev(plan, (const uint64_t *)a, len_glwe, (const uint64_t *)k, len_ggsw,
+                                               (uint64_t *)r, len_result, into_coeff_form, nullptr));
+    if (len_result) PFHE_HIP(hipMemcpy(result, r, len_result * 8, hipMemcpyDeviceToHost));
+    return PFHE_OK;
+    PFHE_GUARD_END
+}
+
+}  // extern "C"

@@ -1,0 +1,357 @@
+// pfhe_rns.hip — RNS composition, gadget decomposition and the digit x key multiply-accumulate.
+//
+// Reference steps (primus_lattice/src/glwe/dcrt.rs:178-255), per input CRT polynomial:
+//   (1) RNSBase::compose_multiple_values_to          primus_rns/src/base.rs:648-675 (-> :609-633)
+//   (2) BigUintApproxSignedBasis::init_value_carry_slice_inplace
+//                                                     primus_decompose/src/big_integer/basis.rs:326-367
+//   (3) OnceBigUintSignedDecomposer::unsigned_decompose_slice_to   big_integer/common.rs:275-325
+//   (4) RNSBase::wrapping_decompose_small_values_to   primus_rns/src/base.rs:279-312,721-730
+//   (5) DcrtTable::transform_slice                    (pfhe_ntt.hip)
+//   (6) DcrtGlwe::add_dcrt_glwe_mul_dcrt_polynomial_assign         glwe/dcrt.rs:108-126
+// Each step exists as its own kernel (parity with the reference's slice functions), and steps
+// (1)-(4) additionally as ONE fused kernel that keeps the composed big integer in registers and
+// never writes it (the reference writes N*value_len words of scratch and re-reads them ell times).
+// All values are exact integers; every output is canonical.
+#include "pfhe_modmath.hpp"
+#include "pfhe_rns.hpp"
+
+namespace pfhe {
+
+namespace {
+
+constexpr int kThreads = 256;
+
+u32 grid_for(u64 items) {
+    u64 g = (items + kThreads - 1) / kThreads;
+    if (g == 0) g = 1;
+    if (g > 0x7fffffffull) g = 0x7fffffffull;
+    return (u32)g;
+}
+
+// v (LEN limbs, canonical in [0,Q)) = CRT lift of residues r[0..L)  — base.rs:609-633.
+template <int LEN>
+__device__ __forceinline__ void compose(const RnsDev &R, const u64 *r, u64 (&v)[LEN]) {
+#pragma unroll
+    for (int j = 0; j < LEN; ++j) v[j] = 0;
+    for (u32 i = 0; i < R.L; ++i) {
+        const u64 t = mul_shoup(r[i], R.inv_punct[i], R.inv_punct_p[i], R.q[i]);
+        // v += P_i * t  (LEN limbs + carry word)
+        u64 carry = 0;
+#pragma unroll
+        for (int j = 0; j < LEN; ++j) {
+            const u64 lo = R.punct[i][j] * t;
+            const u64 hi = mulhi64(R.punct[i][j], t);
+            u64 s = v[j] + lo;
+            u64 c1 = s < lo;
+            u64 s2 = s + carry;
+            c1 += s2 < carry;
+            v[j] = s2;
+            carry = hi + c1;
+        }
+        // if carry != 0 or v >= Q: v -= Q
+        bool ge = carry != 0;
+        if (!ge) {
+            ge = true;  // equal counts as >=
+#pragma unroll
+            for (int j = LEN - 1; j >= 0; --j) {
+                if (v[j] != R.Q[j]) {
+                    ge = v[j] > R.Q[j];
+                    break;
+                }
+            }
+        }
+        if (ge) {
+            u64 borrow = 0;
+#pragma unroll
+            for (int j = 0; j < LEN; ++j) {
+                const u64 d = v[j] - R.Q[j];
+                const u64 b1 = v[j] < R.Q[j];
+                const u64 d2 = d - borrow;
+                const u64 b2 = d < borrow;
+                v[j] = d2;
+                borrow = b1 | b2;
+            }
+        }
+    }
+}
+
+// basis.rs:334-349: if v >= threshold: v += add ; returns the initial carry bit
+template <int LEN>
+__device__ __forceinline__ u32 init_value_carry(const BasisDev &B, u64 (&v)[LEN]) {
+    if (B.mode & 2u) {
+        bool ge = true;
+#pragma unroll
+        for (int j = LEN - 1; j >= 0; --j) {
+            if (v[j] != B.threshold[j]) {
+                ge = v[j] > B.threshold[j];
+                break;
+            }
+        }
+        if (ge) {
+            u64 carry = 0;
+#pragma unroll
+            for (int j = 0; j < LEN; ++j) {
+                const u64 s = v[j] + B.add[j];
+                const u64 c1 = s < v[j];
+                const u64 s2 = s + carry;
+                const u64 c2 = s2 < s;
+                v[j] = s2;
+                carry = c1 | c2;
+            }
+        }
+    }
+    u32 carry = 0;
+    if (B.mode & 1u) {
+        u64 limb = 0;
+#pragma unroll
+        for (int j = 0; j < LEN; ++j)
+            if ((u32)j == B.carry_index) limb = v[j];
+        carry = (limb & B.carry_bit_mask) != 0;
+    }
+    return carry;
+}
+
+// window of log_basis bits starting at bit `start` of the LEN-limb value — common.rs:132-140
+template <int LEN>
+__device__ __forceinline__ u64 window(const u64 (&v)[LEN], u32 start, u64 mask, u32 log_basis) {
+    const u32 idx = start >> 6, shr = start & 63;
+    u64 lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 0; j < LEN; ++j) {
+        if ((u32)j == idx) lo = v[j];
+        if ((u32)j == idx + 1) hi = v[j];
+    }
+    u64 w = lo >> shr;
+    if (shr + log_basis > 64) w |= hi << (64 - shr);
+    return w & mask;
+}
+
+__device__ __forceinline__ u64 window_dyn(const u64 *v, u32 start, u64 mask, u32 log_basis) {
+    const u32 idx = start >> 6, shr = start & 63;
+    u64 w = v[idx] >> shr;
+    if (shr + log_basis > 64) w |= v[idx + 1] << (64 - shr);
+    return w & mask;
+}
+
+// ---- unfused kernels: one reference slice function each ----
+
+template <int LEN>
+__global__ __launch_bounds__(kThreads) void compose_kernel(RnsDev R, const u64 *__restrict__ multi,
+                                                           u64 *__restrict__ out, u64 count) {
+    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= count) return;
+    u64 r[kMaxLimbs];
+    for (u32 i = 0; i < R.L; ++i) r[i] = multi[(u64)i * count + c];
+    u64 v[LEN];
+    compose<LEN>(R, r, v);
+#pragma unroll
+    for (int j = 0; j < LEN; ++j) out[c * LEN + j] = v[j];
+}
+
+__global__ __launch_bounds__(kThreads) void wrapping_decompose_kernel(RnsDev R, const u64 *__restrict__ small,
+                                                                     u64 *__restrict__ multi, u64 count,
+                                                                     u64 small_modulus) {
+    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= count) return;
+    const u64 v = small[c];
+    const u64 half = (small_modulus + 1) / 2;
+    for (u32 i = 0; i < R.L; ++i) {
+        u64 o = v;
+        if (small_modulus != 2 && v >= half) o = R.q[i] - small_modulus + v;
+        multi[(u64)i * count + c] = o;
+    }
+}
+
+template <int LEN>
+__global__ __launch_bounds__(kThreads) void init_value_carry_kernel(BasisDev B, u64 *__restrict__ values,
+                                                                    unsigned char *__restrict__ carries, u64 count) {
+    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= count) return;
+    u64 v[LEN];
+#pragma unroll
+    for (int j = 0; j < LEN; ++j) v[j] = values[c * LEN + j];
+    const u32 carry = init_value_carry<LEN>(B, v);
+#pragma unroll
+    for (int j = 0; j < LEN; ++j) values[c * LEN + j] = v[j];
+    carries[c] = (unsigned char)carry;
+}
+
+__global__ __launch_bounds__(kThreads) void unsigned_decompose_kernel(BasisDev B, u32 level,
+                                                                     const u64 *__restrict__ values,
+                                                                     u64 *__restrict__ digits,
+                                                                     unsigned char *__restrict__ carries, u64 count) {
+    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= count) return;
+    const u32 start = B.drop_bits + level * B.log_basis;
+    const u64 temp = window_dyn(values + c * B.value_len, start, B.basis_minus_one, B.log_basis) + carries[c];
+    carries[c] = (temp & B.carry_mask) != 0;  // common.rs:275-285
+    digits[c] = temp & B.basis_minus_one;
+}
+
+// ---- fused steps (1)-(4): one thread per coefficient, big integer kept in registers ----
+template <int LEN>
+__global__ __launch_bounds__(kThreads) void gadget_decompose_kernel(RnsDev R, BasisDev B, u32 log_n,
+                                                                   const u64 *__restrict__ crt, u64 *__restrict__ out,
+                                                                   u64 total) {
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const u64 n = 1ull << log_n;
+    const u64 poly = gid >> log_n, t = gid & (n - 1);
+    const u64 *__restrict__ in = crt + poly * R.L * n + t;
+    u64 r[kMaxLimbs];
+    for (u32 i = 0; i < R.L; ++i) r[i] = in[(u64)i * n];
+    u64 v[LEN];
+    compose<LEN>(R, r, v);
+    u32 carry = init_value_carry<LEN>(B, v);
+    const u64 half = (B.basis + 1) / 2;
+    u64 *__restrict__ o = out + poly * B.ell * R.L * n + t;
+    for (u32 j = 0; j < B.ell; ++j) {
+        const u64 temp = window<LEN>(v, B.drop_bits + j * B.log_basis, B.basis_minus_one, B.log_basis) + carry;
+        carry = (temp & B.carry_mask) != 0;
+        const u64 u = temp & B.basis_minus_one;
+        for (u32 i = 0; i < R.L; ++i) {
+            u64 res = u;
+            if (B.basis != 2 && u >= half) res = R.q[i] - B.basis + u;  // centred lift, base.rs:721-730
+            o[((u64)j * R.L + i) * n] = res;
+        }
+    }
+}
+
+// ---- step (6) summed over rows and levels with ONE Barrett reduction per output word ----
+// Products of canonical residues (< 2^124) are summed lazily in 128 bits and folded every 8 terms,
+// so the final canonical value equals what the reference reaches with rows*ell sequential
+// reduce_mul_add calls (exact integer arithmetic; the order of reductions cannot change it).
+__global__ __launch_bounds__(kThreads) void gadget_mulacc_kernel(const NttPrime *__restrict__ primes, u32 L, u32 log_n,
+                                                                 u32 k, u32 rows, u32 ell, const u64 *__restrict__ digits,
+                                                                 const u64 *__restrict__ ggsw, u64 ggsw_stride,
+                                                                 u64 *__restrict__ result, u64 total, u32 accumulate) {
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const u64 n = 1ull << log_n;
+    const u64 W = (u64)L * n;
+    const u64 t = gid & (n - 1);
+    u64 rest = gid >> log_n;
+    const u32 limb = (u32)(rest % L);
+    rest /= L;
+    const u32 c = (u32)(rest % (k + 1));
+    const u64 e = rest / (k + 1);
+    const NttPrime *P = primes + limb;
+    const u64 *__restrict__ dg = digits + e * rows * ell * W + (u64)limb * n + t;
+    const u64 *__restrict__ key = ggsw + e * ggsw_stride + ((u64)c * L + limb) * n + t;
+    u64 lo = 0, hi = 0;
+    const u32 terms = rows * ell;
+    for (u32 ij = 0; ij < terms; ++ij) {
+        const u64 d = dg[(u64)ij * W];
+        const u64 g = key[(u64)ij * (k + 1) * W];
+        const u64 pl = d * g, ph = mulhi64(d, g);
+        lo += pl;
+        hi += ph + (lo < pl);
+        if ((ij & 7u) == 7u) {  // 8 products of residues < 2^62 stay below 2^127: fold before the next 8
+            lo = barrett_reduce128(lo, hi, P->q, P->bar_lo, P->bar_hi);
+            hi = 0;
+        }
+    }
+    u64 *__restrict__ out = result + (e * (k + 1) + c) * W + (u64)limb * n + t;
+    if (accumulate) {
+        const u64 a = *out;
+        lo += a;
+        hi += lo < a;
+    }
+    *out = barrett_reduce128(lo, hi, P->q, P->bar_lo, P->bar_hi);
+}
+
+template <template <int> class F, class... A>
+int dispatch_len(u32 len, A &&...a) {
+    switch (len) {
+        case 1: return F<1>::run(a...);
+        case 2: return F<2>::run(a...);
+        case 3: return F<3>::run(a...);
+        case 4: return F<4>::run(a...);
+        case 5: return F<5>::run(a...);
+        case 6: return F<6>::run(a...);
+        case 7: return F<7>::run(a...);
+        case 8: return F<8>::run(a...);
+    }
+    set_last_error("unsupported big-integer length");
+    return PFHE_ERR_UNSUPPORTED;
+}
+
+template <int LEN>
+struct ComposeLaunch {
+    static int run(const RnsDev &r, const u64 *multi, u64 *out, u64 count, hipStream_t s) {
+        hipLaunchKernelGGL(compose_kernel<LEN>, dim3(grid_for(count)), dim3(kThreads), 0, s, r, multi, out, count);
+        return PFHE_OK;
+    }
+};
+template <int LEN>
+struct InitLaunch {
+    static int run(const BasisDev &b, u64 *values, unsigned char *carries, u64 count, hipStream_t s) {
+        hipLaunchKernelGGL(init_value_carry_kernel<LEN>, dim3(grid_for(count)), dim3(kThreads), 0, s, b, values,
+                           carries, count);
+        return PFHE_OK;
+    }
+};
+template <int LEN>
+struct FusedLaunch {
+    static int run(const RnsDev &r, const BasisDev &b, u32 log_n, const u64 *crt, u64 *out, u64 total, hipStream_t s) {
+        hipLaunchKernelGGL(gadget_decompose_kernel<LEN>, dim3(grid_for(total)), dim3(kThreads), 0, s, r, b, log_n, crt,
+                           out, total);
+        return PFHE_OK;
+    }
+};
+
+}  // namespace
+
+int rns_compose_dev(const RnsDev &r, const u64 *multi, u64 *out, u64 count, hipStream_t s) {
+    if (count == 0) return PFHE_OK;
+    PFHE_TRY((dispatch_len<ComposeLaunch>(r.value_len, r, multi, out, count, s)));
+    PFHE_HIP(hipGetLastError());
+    return PFHE_OK;
+}
+
+int rns_wrapping_decompose_dev(const RnsDev &r, const u64 *small, u64 *multi, u64 count, u64 small_modulus,
+                               hipStream_t s) {
+    if (count == 0) return PFHE_OK;
+    hipLaunchKernelGGL(wrapping_decompose_kernel, dim3(grid_for(count)), dim3(kThreads), 0, s, r, small, multi, count,
+                       small_modulus);
+    PFHE_HIP(hipGetLastError());
+    return PFHE_OK;
+}
+
+int basis_init_value_carry_dev(const BasisDev &b, u64 *values, unsigned char *carries, u64 count, hipStream_t s) {
+    if (count == 0) return PFHE_OK;
+    PFHE_TRY((dispatch_len<InitLaunch>(b.value_len, b, values, carries, count, s)));
+    PFHE_HIP(hipGetLastError());
+    return PFHE_OK;
+}
+
+int basis_unsigned_decompose_dev(const BasisDev &b, u32 level, const u64 *values, u64 *digits,
+                                 unsigned char *carries, u64 count, hipStream_t s) {
+    if (count == 0) return PFHE_OK;
+    hipLaunchKernelGGL(unsigned_decompose_kernel, dim3(grid_for(count)), dim3(kThreads), 0, s, b, level, values, digits,
+                       carries, count);
+    PFHE_HIP(hipGetLastError());
+    return PFHE_OK;
+}
+
+int gadget_decompose_dev(const RnsDev &r, const BasisDev &b, u32 log_n, const u64 *crt, u64 *digits, u64 npolys,
+                         hipStream_t s) {
+    const u64 total = npolys << log_n;
+    if (total == 0) return PFHE_OK;
+    PFHE_TRY((dispatch_len<FusedLaunch>(r.value_len, r, b, log_n, crt, digits, total, s)));
+    PFHE_HIP(hipGetLastError());
+    return PFHE_OK;
+}
+
+int gadget_mulacc_dev(const NttPrime *primes, u32 L, u32 log_n, u32 k, u32 rows, u32 ell, const u64 *digits,
+                      const u64 *ggsw, bool ggsw_shared, u64 *result, u64 batch, bool accumulate, hipStream_t s) {
+    const u64 total = (batch * (k + 1) * L) << log_n;
+    if (total == 0) return PFHE_OK;
+    const u64 ggsw_words = ((u64)rows * ell * (k + 1) * L) << log_n;
+    hipLaunchKernelGGL(gadget_mulacc_kernel, dim3(grid_for(total)), dim3(kThreads), 0, s, primes, L, log_n, k, rows, ell,
+                       digits, ggsw, ggsw_shared ? 0ull : ggsw_words, result, total, accumulate ? 1u : 0u);
+    PFHE_HIP(hipGetLastError());
+    return PFHE_OK;
+}
+
+}  // namespace pfhe

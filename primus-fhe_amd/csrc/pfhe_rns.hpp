@@ -1,0 +1,68 @@
+// pfhe_rns.hpp — RNS base, gadget basis and external-product plan (host structs + launchers).
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "pfhe_common.hpp"
+#include "pfhe_handles.hpp"
+
+namespace pfhe {
+
+constexpr int kMaxLimbs = 8;  // RNS moduli / big-integer limbs supported by the device kernels
+
+// RNSBase<u64, BarrettModulus<u64>> constants (primus_rns/src/base.rs:26-117), passed by value.
+struct RnsDev {
+    u32 L, value_len;
+    u64 q[kMaxLimbs];
+    u64 inv_punct[kMaxLimbs], inv_punct_p[kMaxLimbs];  // (Q/q_i)^-1 mod q_i and its Shoup quotient
+    u64 punct[kMaxLimbs][kMaxLimbs];                    // Q/q_i, little-endian limbs
+    u64 Q[kMaxLimbs];                                   // product of all moduli
+};
+
+// BigUintApproxSignedBasis<u64> constants (primus_decompose/src/big_integer/basis.rs:17-211).
+struct BasisDev {
+    u32 value_len, ell, log_basis, drop_bits;
+    u32 mode;  // bit0: extract initial carry, bit1: adjust values >= threshold
+    u32 carry_index;
+    u64 carry_bit_mask;
+    u64 basis, basis_minus_one, carry_mask;
+    u64 threshold[kMaxLimbs], add[kMaxLimbs];
+};
+
+struct RnsHost {
+    int device = 0;
+    RnsDev dev{};
+    std::vector<u64> moduli;
+};
+
+struct BasisHost {
+    int device = 0;
+    BasisDev dev{};
+    RnsDev rns{};
+    std::vector<u64> scalars;          // ell * value_len : 2^(drop + j*log_basis)
+    std::vector<u64> scalars_residue;  // ell * L
+};
+
+int build_rns(const u64 *moduli, size_t count, RnsHost &out);
+int build_basis(const RnsHost &rns, u32 log_basis, size_t reverse_length, BasisHost &out);
+
+// --- device launchers (pfhe_rns.hip); all pointers are device pointers ---
+int rns_compose_dev(const RnsDev &r, const u64 *multi_residues, u64 *big_uint_values, u64 value_count,
+                    hipStream_t s);
+int rns_wrapping_decompose_dev(const RnsDev &r, const u64 *small_values, u64 *multi_residues, u64 value_count,
+                               u64 small_value_modulus, hipStream_t s);
+int basis_init_value_carry_dev(const BasisDev &b, u64 *values, unsigned char *carries, u64 count, hipStream_t s);
+int basis_unsigned_decompose_dev(const BasisDev &b, u32 level, const u64 *values, u64 *digits,
+                                 unsigned char *carries, u64 count, hipStream_t s);
+// Fused steps (1)-(4) of add_dcrt_glev_mul_crt_poly_assign (glwe/dcrt.rs:219-244) for `npolys` CRT
+// polynomials of L*N words: writes, per input polynomial, ell digit polynomials in CRT form
+// (centred lift), laid out [poly][level][limb][N].
+int gadget_decompose_dev(const RnsDev &r, const BasisDev &b, u32 log_n, const u64 *crt_polys, u64 *digits,
+                         u64 npolys, hipStream_t s);
+// result[e][c][r][t] = sum_{i,j} ggsw[(e)][i][j][c][r][t] * digits[e][i][j][r][t]  (mod q_r)
+// (steps (6) of glwe/dcrt.rs:248 summed over rows and levels, glwe/crt.rs:219-226).
+// accumulate != 0 adds into the existing result instead of overwriting it.
+int gadget_mulacc_dev(const NttPrime *primes, u32 L, u32 log_n, u32 k, u32 rows, u32 ell, const u64 *digits,
+                      const u64 *ggsw, bool ggsw_shared, u64 *result, u64 batch, bool accumulate, hipStream_t s);
+
+}  // namespace pfhe

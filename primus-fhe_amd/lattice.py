@@ -1,0 +1,66 @@
+"""RNS gadget external product — host-side mirror of the primus_lattice entry points.
+
+Reference: CrtGlwe::mul_dcrt_ggsw_to (primus_lattice/src/glwe/crt.rs:200-227),
+DcrtGlwe::add_dcrt_glev_mul_crt_poly_assign (glwe/dcrt.rs:178-255),
+DcrtGlevContext (context/glev.rs:4-68), DcrtGlwe::into_coeff_form (macros/mod.rs:901-911).
+
+Layouts (flat uint64, exactly the reference's nesting): CrtGlwe / DcrtGlwe = (k+1) x L x N;
+DcrtGlev = ell x DcrtGlwe; DcrtGgsw = (k+1) x DcrtGlev.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib
+from .ntt import U64DcrtTable, _dev, _host, _stream
+from .rns import BigUintApproxSignedBasis, RNSBase
+
+
+class DcrtGlevContext:
+    """Working context of the external product (context/glev.rs:4-68): bundles basis, table and
+    RNS base and owns the device scratch; use one per stream/thread (it is `&mut` in the reference)."""
+
+    def __init__(self, table: U64DcrtTable, rns_base: RNSBase, basis: BigUintApproxSignedBasis,
+                 glwe_dimension: int = 1, chunk: int = 0):
+        h = C.c_void_p()
+        check(lib().pfhe_extprod_plan_create(table._h, rns_base._h, basis._h, glwe_dimension, chunk, C.byref(h)))
+        self._h = h
+        self.table, self.rns_base, self.basis, self.glwe_dimension = table, rns_base, basis, glwe_dimension
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().pfhe_extprod_plan_destroy(h)
+            self._h = None
+
+    def scratch_bytes(self) -> int:
+        return int(lib().pfhe_extprod_plan_scratch_bytes(self._h))
+
+    def glwe_len(self) -> int:
+        return (self.glwe_dimension + 1) * self.table.crt_poly_length()
+
+    def ggsw_len(self) -> int:
+        return (self.glwe_dimension + 1) * self.basis.decompose_length() * self.glwe_len()
+
+
+def mul_dcrt_ggsw_to(crt_glwe, dcrt_ggsw, result, context: DcrtGlevContext, into_coeff_form: bool = False):
+    """CrtGlwe::mul_dcrt_ggsw_to on host numpy arrays (batched: concatenated ciphertexts)."""
+    (pa, na), (pk, nk), (pr, nr) = _host(crt_glwe), _host(dcrt_ggsw), _host(result)
+    check(lib().pfhe_extprod_mul_dcrt_ggsw_to(context._h, pa, na, pk, nk, pr, nr, int(into_coeff_form)))
+
+
+def mul_dcrt_ggsw_to_dev(crt_glwe, dcrt_ggsw, result, context: DcrtGlevContext, into_coeff_form: bool = False,
+                         stream=None):
+    """Device-pointer variant (torch CUDA tensors or (ptr, words) tuples), asynchronous."""
+    (pa, na), (pk, nk), (pr, nr) = _dev(crt_glwe), _dev(dcrt_ggsw), _dev(result)
+    check(lib().pfhe_extprod_mul_dcrt_ggsw_to_dev(context._h, pa, na, pk, nk, pr, nr, int(into_coeff_form),
+                                                  _stream(stream)))
+
+
+def add_dcrt_glev_mul_crt_poly_assign_dev(acc, dcrt_glev, crt_poly, context: DcrtGlevContext, stream=None):
+    """DcrtGlwe::add_dcrt_glev_mul_crt_poly_assign (glwe/dcrt.rs:178-255): acc += glev (x) crt_poly."""
+    (pc, nc), (pg, ng), (pp, np_) = _dev(acc), _dev(dcrt_glev), _dev(crt_poly)
+    check(lib().pfhe_extprod_add_dcrt_glev_mul_crt_poly_assign_dev(context._h, pc, nc, pg, ng, pp, np_,
+                                                                   _stream(stream)))

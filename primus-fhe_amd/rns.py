@@ -1,0 +1,119 @@
+"""RNSBase and BigUintApproxSignedBasis — host-side mirror of primus_rns / primus_decompose.
+
+Reference: primus_rns/src/base.rs:26 (RNSBase<u64, BarrettModulus<u64>>),
+primus_decompose/src/big_integer/basis.rs:17 (BigUintApproxSignedBasis<u64>),
+primus_decompose/src/big_integer/common.rs:242 (OnceBigUintSignedDecomposer).
+Every method runs a HIP kernel through the C ABI; `*_to` names keep the reference's meaning.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import PfheError, check, lib, u64p
+from .ntt import _dev, _host, _stream
+
+RNSError = PfheError
+
+
+class RNSBase:
+    """primus_rns::RNSBase — pairwise-coprime basis with CRT precomputations (base.rs:26-117)."""
+
+    def __init__(self, moduli, device: int = 0):
+        arr = np.ascontiguousarray(np.array([int(m) for m in moduli], dtype=np.uint64))
+        h = C.c_void_p()
+        check(lib().pfhe_rns_create(arr.ctypes.data_as(u64p) if arr.size else None, arr.size, device, C.byref(h)))
+        self._h = h
+        self._moduli = [int(m) for m in moduli]
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().pfhe_rns_destroy(h)
+            self._h = None
+
+    def moduli(self): return list(self._moduli)
+    def moduli_count(self) -> int: return int(lib().pfhe_rns_moduli_count(self._h))
+    def big_uint_value_len(self) -> int: return int(lib().pfhe_rns_big_uint_value_len(self._h))
+
+    def moduli_product(self) -> np.ndarray:
+        out = np.empty(self.big_uint_value_len(), np.uint64)
+        check(lib().pfhe_rns_moduli_product(self._h, *_host(out)))
+        return out
+
+    def compose_multiple_values_to(self, multi_residues, big_uint_values, value_count: int):
+        """base.rs:648-675; `scratch` of the reference is owned by the kernel (registers)."""
+        pi, ni = _host(multi_residues)
+        po, no = _host(big_uint_values)
+        check(lib().pfhe_rns_compose_multiple_values_to(self._h, pi, ni, po, no, value_count))
+
+    compose_polynomial_to = compose_multiple_values_to  # base.rs:690-706
+
+    def wrapping_decompose_small_values_to(self, small_values, multi_residues, value_count: int,
+                                           small_value_modulus: int):
+        """base.rs:279-312."""
+        pi, ni = _host(small_values)
+        po, no = _host(multi_residues)
+        if ni != value_count:
+            raise PfheError(32, "small_values.len() must equal value_count")
+        check(lib().pfhe_rns_wrapping_decompose_small_values_to(self._h, pi, value_count, po, no, small_value_modulus))
+
+    def compose_multiple_values_to_dev(self, multi_residues, big_uint_values, value_count: int, stream=None):
+        (pi, ni), (po, no) = _dev(multi_residues), _dev(big_uint_values)
+        check(lib().pfhe_rns_compose_multiple_values_to_dev(self._h, pi, ni, po, no, value_count, _stream(stream)))
+
+    def wrapping_decompose_small_values_to_dev(self, small_values, multi_residues, value_count: int,
+                                               small_value_modulus: int, stream=None):
+        (pi, ni), (po, no) = _dev(small_values), _dev(multi_residues)
+        if ni != value_count:
+            raise PfheError(32, "small_values.len() must equal value_count")
+        check(lib().pfhe_rns_wrapping_decompose_small_values_to_dev(self._h, pi, value_count, po, no,
+                                                                    small_value_modulus, _stream(stream)))
+
+
+class BigUintApproxSignedBasis:
+    """primus_decompose::big_integer::BigUintApproxSignedBasis<u64> (basis.rs:17-211)."""
+
+    def __init__(self, rns_base: RNSBase, log_basis: int, reverse_length: int | None = None):
+        h = C.c_void_p()
+        check(lib().pfhe_basis_create(rns_base._h, log_basis, reverse_length or 0, C.byref(h)))
+        self._h = h
+        self.rns_base = rns_base
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().pfhe_basis_destroy(h)
+            self._h = None
+
+    def decompose_length(self) -> int: return int(lib().pfhe_basis_decompose_length(self._h))
+    def log_basis(self) -> int: return int(lib().pfhe_basis_log_basis(self._h))
+    def drop_bits(self) -> int: return int(lib().pfhe_basis_drop_bits(self._h))
+    def basis_value(self) -> int: return int(lib().pfhe_basis_basis_value(self._h))
+
+    def scalars(self) -> np.ndarray:
+        out = np.empty(self.decompose_length() * self.rns_base.big_uint_value_len(), np.uint64)
+        check(lib().pfhe_basis_scalars(self._h, *_host(out)))
+        return out
+
+    def scalars_residue(self) -> np.ndarray:
+        out = np.empty(self.decompose_length() * self.rns_base.moduli_count(), np.uint64)
+        check(lib().pfhe_basis_scalars_residue(self._h, *_host(out)))
+        return out
+
+    def init_value_carry_slice_inplace(self, values, carries, big_uint_value_len: int | None = None):
+        """basis.rs:326-367; carries is a numpy uint8 (bool) array, one entry per value."""
+        pv, nv = _host(values)
+        assert carries.dtype in (np.uint8, np.bool_) and carries.flags.c_contiguous
+        check(lib().pfhe_basis_init_value_carry_slice_inplace(self._h, pv, nv, carries.ctypes.data_as(C.c_void_p),
+                                                              carries.size))
+
+    def unsigned_decompose_slice_to(self, level: int, big_uint_values, decomposed_unsigned_values, carries):
+        """decomposer_iter().nth(level).unsigned_decompose_slice_to(...) — common.rs:309-325."""
+        pv, nv = _host(big_uint_values)
+        pd, nd = _host(decomposed_unsigned_values)
+        if nd != carries.size:
+            raise PfheError(32, "carries and digits differ in length")
+        check(lib().pfhe_basis_unsigned_decompose_slice_to(self._h, level, pv, nv, pd,
+                                                           carries.ctypes.data_as(C.c_void_p), carries.size))

@@ -1,0 +1,220 @@
+"""GPU parity of RNSBase / BigUintApproxSignedBasis / external product against the oracle.
+
+Mirrors primus_rns/tests/rns.rs and primus_decompose/tests/big_uint.rs through the C ABI, and
+adds the end-to-end external product the reference never tests.
+"""
+import numpy as np
+import pytest
+
+import pyref
+from gpu_util import rand_rns, to_dev, to_host
+from pyref import Q61, crt_compose, int_to_limbs, limbs_to_int
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pf():
+    import primus_fhe_amd as p
+    return p
+
+
+def test_rns_errors(pf):
+    with pytest.raises(pf.PfheError) as e:
+        pf.RNSBase([])
+    assert e.value.kind == "EmptyBase"
+    with pytest.raises(pf.PfheError) as e:
+        pf.RNSBase([21, 35])
+    assert e.value.kind == "CoPrimeError"
+    with pytest.raises(pf.PfheError) as e:
+        pf.RNSBase([1 << 62, 97])
+    assert e.value.kind == "UnrepresentableModulus"
+
+
+def test_rns_reference_closed_forms(pf):
+    """rns.rs:77-98 ((3,5,7), residues (2,3,2) -> 23) and rns.rs:105-147 (modulus-major layout)."""
+    base = pf.RNSBase([3, 5, 7])
+    out = np.empty(1, np.uint64)
+    base.compose_multiple_values_to(np.array([2, 3, 2], np.uint64), out, 1)
+    assert int(out[0]) == 23
+    moduli = [1_125_899_906_826_241, 1_125_899_906_629_633]
+    base = pf.RNSBase(moduli)
+    rows = [[0, 0], [1, 2], [97, 131], [moduli[0] - 1, moduli[1] - 2], [123_456_789, 987_654_321]]
+    packed = np.array([r[i] for i in range(2) for r in rows], np.uint64)
+    vals = np.empty(len(rows) * base.big_uint_value_len(), np.uint64)
+    base.compose_multiple_values_to(packed, vals, len(rows))
+    L = base.big_uint_value_len()
+    for c, r in enumerate(rows):
+        assert limbs_to_int(vals[c * L:(c + 1) * L]) == crt_compose(r, moduli)
+
+
+def test_wrapping_decompose_reference_case(pf):
+    """rns.rs:154-194."""
+    moduli = [97, 101, 103]
+    base = pf.RNSBase(moduli)
+    for sm in (2, 7, 16):
+        small = np.array([(i * 5 + 3) % sm for i in range(17)], np.uint64)
+        got = np.empty(3 * 17, np.uint64)
+        base.wrapping_decompose_small_values_to(small, got, 17, sm)
+        exp = [v if (sm == 2 or v < -(-sm // 2)) else m - sm + v for m in moduli for v in map(int, small)]
+        assert got.tolist() == exp
+
+
+@pytest.mark.parametrize("moduli", [Q61, [137438822401, 137438814209, 137438773249], [Q61[0]], Q61[:2]])
+@pytest.mark.parametrize("count", [1, 64, 1000])
+def test_compose_matches_oracle(pf, orc, moduli, count):
+    rng = np.random.default_rng(count)
+    base, obase = pf.RNSBase(moduli), orc.RNSBase(moduli)
+    assert base.big_uint_value_len() == obase.value_len
+    assert np.array_equal(base.moduli_product(), obase.moduli_product)
+    res = np.concatenate([rng.integers(0, m, count, dtype=np.uint64) for m in moduli])
+    res[0] = 0
+    for i, m in enumerate(moduli):
+        res[i * count + count - 1] = m - 1
+    out = np.empty(count * base.big_uint_value_len(), np.uint64)
+    base.compose_multiple_values_to(res, out, count)
+    assert np.array_equal(out, obase.compose_multiple_values_to(res, count))
+    with pytest.raises(pf.PfheError) as e:
+        base.compose_multiple_values_to(res[:-1].copy(), out, count)
+    assert e.value.kind == "BadLength"
+
+
+@pytest.mark.parametrize("moduli,log_basis,rev", [
+    (Q61, 30, None), (Q61, 30, 4), (Q61, 61, None), (Q61, 1, None), (Q61, 7, None),
+    ([134215681, 134176769], 7, None), ([134215681, 134176769], 6, None), (Q61[:2], 13, 5),
+    ([137438822401, 137438814209, 137438773249], 15, None), (Q61[:1], 20, None),
+])
+def test_gadget_steps_match_oracle(pf, orc, moduli, log_basis, rev):
+    """Steps (2)-(4) of glwe/dcrt.rs:226-244, slice by slice, + the recomposition bound."""
+    rng = np.random.default_rng(log_basis)
+    base, obase = pf.RNSBase(moduli), orc.RNSBase(moduli)
+    basis, obasis = pf.BigUintApproxSignedBasis(base, log_basis, rev), orc.BigUintApproxSignedBasis(obase, log_basis, rev)
+    assert (basis.decompose_length(), basis.log_basis(), basis.drop_bits(), basis.basis_value()) == \
+        (obasis.decompose_length, obasis.log_basis, obasis.drop_bits, obasis.basis_value)
+    assert np.array_equal(basis.scalars(), obasis.scalars)
+    assert np.array_equal(basis.scalars_residue(), obasis.scalars_residue)
+    g = pyref.Gadget(moduli, log_basis, rev)
+    L, n = base.big_uint_value_len(), 515
+    vals_int = [int.from_bytes(rng.bytes(40), "little") % g.Q for _ in range(n)]
+    vals_int[:6] = [0, 1, g.Q - 1, g.Q // 2, (g.threshold or 1) - 1, g.threshold or 1]
+    values = np.concatenate([int_to_limbs(v, L) for v in vals_int])
+    ov = values.copy()
+    oc = obasis.init_value_carry_slice_inplace(ov, n)
+    gv, gc = values.copy(), np.zeros(n, np.uint8)
+    basis.init_value_carry_slice_inplace(gv, gc)
+    assert np.array_equal(gv, ov) and np.array_equal(gc, oc)
+    for j in range(basis.decompose_length()):
+        od = obasis.unsigned_decompose_slice_to(j, ov, oc, n)
+        gd = np.empty(n, np.uint64)
+        basis.unsigned_decompose_slice_to(j, gv, gd, gc)
+        assert np.array_equal(gd, od) and np.array_equal(gc, oc), j
+        lifted = np.empty(len(moduli) * n, np.uint64)
+        base.wrapping_decompose_small_values_to(gd, lifted, n, basis.basis_value())
+        assert np.array_equal(lifted, obase.wrapping_decompose_small_values_to(od, obasis.basis_value))
+
+
+def test_basis_errors(pf):
+    base = pf.RNSBase(Q61)
+    for lb in (0, 64, 62):  # 2^62 is not smaller than the moduli
+        with pytest.raises(pf.PfheError) as e:
+            pf.BigUintApproxSignedBasis(base, lb)
+        assert e.value.kind == "BadArgument"
+    with pytest.raises(pf.PfheError):
+        pf.BigUintApproxSignedBasis(base, 30, 7)  # reverse_length > full length
+
+
+def make_case(orc, rng, log_n, k, moduli, log_basis, rev, batch, shared):
+    n, Lm = 1 << log_n, len(moduli)
+    otable, obase = orc.U64DcrtTable(log_n, moduli), orc.RNSBase(moduli)
+    obasis = orc.BigUintApproxSignedBasis(obase, log_basis, rev)
+    ell = obasis.decompose_length
+    glwe = rand_rns(rng, moduli, n, batch * (k + 1))
+    nkeys = 1 if shared else batch
+    ggsw = rand_rns(rng, moduli, n, nkeys * (k + 1) * ell * (k + 1))  # already "in NTT form": any residues
+    W, glwe_len, ggsw_len = Lm * n, (k + 1) * Lm * n, (k + 1) * ell * (k + 1) * Lm * n
+    exp = np.concatenate([
+        orc.mul_dcrt_ggsw_to(otable, obase, obasis, k, glwe[e * glwe_len:(e + 1) * glwe_len].copy(),
+                             ggsw[(0 if shared else e) * ggsw_len:((0 if shared else e) + 1) * ggsw_len].copy())
+        for e in range(batch)])
+    return otable, glwe, ggsw, exp
+
+
+@pytest.mark.parametrize("log_n,k,moduli,log_basis,rev,batch,shared,chunk", [
+    (3, 1, Q61, 30, None, 1, True, 0), (4, 1, Q61, 30, None, 5, True, 2), (4, 1, Q61, 30, None, 5, False, 3),
+    (6, 2, Q61[:2], 20, 3, 3, True, 1), (10, 1, [134215681, 134176769], 7, None, 2, False, 0),
+    (12, 1, Q61, 30, None, 3, True, 2), (13, 1, Q61, 13, None, 1, True, 0),
+])
+def test_external_product_matches_oracle(pf, orc, log_n, k, moduli, log_basis, rev, batch, shared, chunk):
+    """CrtGlwe::mul_dcrt_ggsw_to (glwe/crt.rs:200-227), batched, shared or per-ciphertext GGSW."""
+    rng = np.random.default_rng(log_n * 7 + batch)
+    otable, glwe, ggsw, exp = make_case(orc, rng, log_n, k, moduli, log_basis, rev, batch, shared)
+    table, base = pf.U64DcrtTable(log_n, moduli), pf.RNSBase(moduli)
+    basis = pf.BigUintApproxSignedBasis(base, log_basis, rev)
+    ctx = pf.DcrtGlevContext(table, base, basis, k, chunk)
+    out = np.empty_like(glwe)
+    pf.mul_dcrt_ggsw_to(glwe, ggsw, out, ctx)
+    assert np.array_equal(out, exp)
+    # coefficient-form output == oracle result after DcrtGlwe::into_coeff_form
+    pf.mul_dcrt_ggsw_to(glwe, ggsw, out, ctx, into_coeff_form=True)
+    otable.inverse_transform_slice(exp)
+    assert np.array_equal(out, exp)
+    with pytest.raises(pf.PfheError) as e:
+        pf.mul_dcrt_ggsw_to(glwe, ggsw[:-1].copy(), out, ctx)
+    assert e.value.kind == "BadLength"
+
+
+def test_external_product_equals_schoolbook(pf, orc):
+    """End-to-end ground truth on Python integers: sum_i sum_j digit_ij (*) key_ij mod (X^N+1, q_r)."""
+    log_n, k, moduli, log_basis = 3, 1, Q61, 30
+    rng = np.random.default_rng(42)
+    n, Lm = 1 << log_n, 3
+    table, base = pf.U64DcrtTable(log_n, moduli), pf.RNSBase(moduli)
+    basis = pf.BigUintApproxSignedBasis(base, log_basis)
+    g = pyref.Gadget(moduli, log_basis)
+    ell = g.ell
+    glwe = rand_rns(rng, moduli, n, k + 1)
+    key_coeff = rand_rns(rng, moduli, n, (k + 1) * ell * (k + 1))
+    ggsw = key_coeff.copy()
+    table.transform_slice(ggsw)
+    ctx = pf.DcrtGlevContext(table, base, basis, k)
+    out = np.empty_like(glwe)
+    pf.mul_dcrt_ggsw_to(glwe, ggsw, out, ctx, into_coeff_form=True)
+    exp = pyref.external_product_coeff(moduli, n, k, g, glwe.reshape(k + 1, Lm, n).tolist(),
+                                       key_coeff.reshape(k + 1, ell, k + 1, Lm, n).tolist())
+    assert out.reshape(k + 1, Lm, n).tolist() == exp
+
+
+def test_add_dcrt_glev_mul_crt_poly_assign(pf, orc):
+    """glwe/dcrt.rs:178-255: accumulate one GLev row into an existing DcrtGlwe."""
+    log_n, k, moduli, log_basis, batch = 8, 1, Q61, 30, 3
+    rng = np.random.default_rng(8)
+    n, Lm = 1 << log_n, 3
+    otable, obase = orc.U64DcrtTable(log_n, moduli), orc.RNSBase(moduli)
+    obasis = orc.BigUintApproxSignedBasis(obase, log_basis)
+    ell, W = obasis.decompose_length, Lm * n
+    acc = rand_rns(rng, moduli, n, batch * (k + 1))
+    glev = rand_rns(rng, moduli, n, ell * (k + 1))
+    poly = rand_rns(rng, moduli, n, batch)
+    exp = acc.copy()
+    for e in range(batch):
+        a = exp[e * (k + 1) * W:(e + 1) * (k + 1) * W]
+        orc.add_dcrt_glev_mul_crt_poly_assign(otable, obase, obasis, k, a, glev, poly[e * W:(e + 1) * W].copy())
+    table, base = pf.U64DcrtTable(log_n, moduli), pf.RNSBase(moduli)
+    ctx = pf.DcrtGlevContext(table, base, pf.BigUintApproxSignedBasis(base, log_basis), k)
+    dacc = to_dev(acc)
+    pf.add_dcrt_glev_mul_crt_poly_assign_dev(dacc, to_dev(glev), to_dev(poly), ctx)
+    assert np.array_equal(to_host(dacc), exp)
+
+
+def test_config4_shape_vs_oracle(pf, orc):
+    """BASELINE config 4 shape (N=2^16, 3 primes, k=1, logB=30 -> ell=6), small batch, shared GGSW."""
+    log_n, k, batch = 16, 1, 2
+    rng = np.random.default_rng(4)
+    otable, glwe, ggsw, exp = make_case(orc, rng, log_n, k, Q61, 30, None, batch, True)
+    table, base = pf.U64DcrtTable(log_n, Q61), pf.RNSBase(Q61)
+    basis = pf.BigUintApproxSignedBasis(base, 30)
+    assert (basis.decompose_length(), basis.drop_bits()) == (6, 3)
+    ctx = pf.DcrtGlevContext(table, base, basis, k, 1)
+    dout = to_dev(np.zeros_like(glwe))
+    pf.mul_dcrt_ggsw_to_dev(to_dev(glwe), to_dev(ggsw), dout, ctx)
+    assert np.array_equal(to_host(dout), exp)
