@@ -302,6 +302,12 @@ int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *rns, const 
     if (basis->h.rns.value_len != rns->h.dev.value_len || basis->h.rns.L != rns->h.dev.L) return PFHE_ERR_BAD_ARGUMENT;
     for (u32 j = 0; j < rns->h.dev.value_len; ++j)
         if (basis->h.rns.Q[j] != rns->h.dev.Q[j]) return PFHE_ERR_BAD_ARGUMENT;  // basis.rs:52
+    for (u32 i = 0; i < t->L; ++i) {
+        if (basis->h.dev.basis >= t->primes[i].q) {  // wrapping_decompose needs B < q_i (base.rs:288-292)
+            set_last_error("gadget basis must be smaller than every RNS modulus");
+            return PFHE_ERR_BAD_ARGUMENT;
+        }
+    }
     auto p = std::make_unique<pfhe_extprod_plan>();
     p->table = t;
     p->rns = rns->h.dev;

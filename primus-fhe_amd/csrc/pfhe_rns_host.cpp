@@ -155,12 +155,6 @@ int build_basis(const RnsHost &rns, u32 log_basis, size_t reverse_length, BasisH
         return PFHE_ERR_BAD_ARGUMENT;
     }
     const u64 B = 1ull << log_basis, bm1 = B - 1;
-    for (u32 i = 0; i < r.L; ++i) {
-        if (B >= r.q[i]) {  // wrapping_decompose needs B < every modulus (base.rs:288-292)
-            set_last_error("gadget basis must be smaller than every RNS modulus");
-            return PFHE_ERR_BAD_ARGUMENT;
-        }
-    }
     BasisDev d{};
     d.value_len = len;
     d.ell = (u32)ell;

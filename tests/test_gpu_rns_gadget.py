@@ -108,19 +108,26 @@ def test_gadget_steps_match_oracle(pf, orc, moduli, log_basis, rev):
         gd = np.empty(n, np.uint64)
         basis.unsigned_decompose_slice_to(j, gv, gd, gc)
         assert np.array_equal(gd, od) and np.array_equal(gc, oc), j
-        lifted = np.empty(len(moduli) * n, np.uint64)
-        base.wrapping_decompose_small_values_to(gd, lifted, n, basis.basis_value())
-        assert np.array_equal(lifted, obase.wrapping_decompose_small_values_to(od, obasis.basis_value))
+        if basis.basis_value() < min(moduli):  # the centred lift needs B < q_i (base.rs:288-292)
+            lifted = np.empty(len(moduli) * n, np.uint64)
+            base.wrapping_decompose_small_values_to(gd, lifted, n, basis.basis_value())
+            assert np.array_equal(lifted, obase.wrapping_decompose_small_values_to(od, obasis.basis_value))
 
 
 def test_basis_errors(pf):
     base = pf.RNSBase(Q61)
-    for lb in (0, 64, 62):  # 2^62 is not smaller than the moduli
+    for lb in (0, 64):  # basis.rs:51
         with pytest.raises(pf.PfheError) as e:
             pf.BigUintApproxSignedBasis(base, lb)
         assert e.value.kind == "BadArgument"
     with pytest.raises(pf.PfheError):
-        pf.BigUintApproxSignedBasis(base, 30, 7)  # reverse_length > full length
+        pf.BigUintApproxSignedBasis(base, 30, 7)  # reverse_length > full length (basis.rs:64)
+    # B = 2^61 exceeds the 61-bit moduli: fine for the basis itself, rejected where the centred
+    # lift would need B < q_i (primus_rns/src/base.rs:288-292)
+    big = pf.BigUintApproxSignedBasis(base, 61)
+    with pytest.raises(pf.PfheError) as e:
+        pf.DcrtGlevContext(pf.U64DcrtTable(4, Q61), base, big, 1)
+    assert e.value.kind == "BadArgument"
 
 
 def make_case(orc, rng, log_n, k, moduli, log_basis, rev, batch, shared):
