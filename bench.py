@@ -42,6 +42,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="RNS polynomials per GPU (default: BASELINE config 3')")
+    ap.add_argument("--ext-batch", type=int, default=1024, help="ciphertexts in the external-product leg (config 4)")
+    ap.add_argument("--ext-chunk", type=int, default=0, help="ciphertexts per internal pass of the external product")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -66,7 +68,7 @@ def cpu_baseline(seconds: float):
     n = 1 << LOG_N
     tabs = [oracle.U64NttTable(LOG_N, q) for q in Q61]
     rng = np.random.default_rng(1)
-    per_task = 4
+    per_task = 32  # ~40 ms of work per task keeps the Python dispatch overhead negligible
     bufs = [rng.integers(0, Q61[i % 3], n * per_task, dtype=np.uint64) for i in range(cores)]
 
     def work(i):
@@ -121,29 +123,14 @@ def main():
     check(p.lib().pfhe_fill_uniform_dev(local_rank, C.c_void_p(x.data_ptr()), words, mods.ctypes.data_as(u64p), L, n,
                                         0x5EED000000000003 + rank, None))
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    from primus_fhe_amd.shard import timed_steps
 
     def step():
         # forward transform of a canonical batch; the output of one step (canonical, bit-reversed
         # order) is a valid input of the next, so the timed loop needs no re-initialisation
         table.transform_dev(x)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, dist, "cuda")
 
     limb_ntts = world * batch * L * args.steps
     value = limb_ntts / dt
@@ -183,6 +170,8 @@ def main():
                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                               "avg_launch_ms": dom[1], "algorithmic_bytes_per_launch": alg_bytes}
         result["kernels_ms"] = {k: v for k, v in per_pass}
+        # the single-pass loops above left x in an arbitrary state: restore canonical residues
+        check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(x.data_ptr()), words, mods.ctypes.data_as(u64p), L, n, 5, None))
         # ---- config 3: fused NTT -> pointwise mul (shared multiplicand) -> INTT ----
         bhat = torch.empty(L * n, dtype=torch.int64, device="cuda")
         check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(bhat.data_ptr()), L * n, mods.ctypes.data_as(u64p), L, n,
@@ -197,6 +186,33 @@ def main():
         dtp = (time.perf_counter() - t0) / reps
         result["polymul"] = {"value": batch / dtp, "unit": "RNS polynomial products/s (NTT+mul+INTT, shared multiplicand)",
                              "ms_per_batch": dtp * 1e3, "hbm_roofline_frac": batch / dtp * 48 * n / (HBM_PEAK_GBS * 1e9)}
+        # ---- config 4: RNS gadget external product, k=1, logB=30 (ell=6), batch 1024, one shared GGSW ----
+        del bhat
+        ep_batch = min(args.ext_batch, batch)
+        base = p.RNSBase(Q61, device=local_rank)
+        basis = p.BigUintApproxSignedBasis(base, 30)
+        ctx = p.DcrtGlevContext(table, base, basis, 1, args.ext_chunk)
+        glwe_words, ggsw_words = ep_batch * 2 * L * n, ctx.ggsw_len()
+        glwe = x[:glwe_words]                       # canonical residues: a valid CrtGlwe batch
+        ggsw = torch.empty(ggsw_words, dtype=torch.int64, device="cuda")
+        check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(ggsw.data_ptr()), ggsw_words, mods.ctypes.data_as(u64p), L, n,
+                                            99, None))
+        out = torch.empty(glwe_words, dtype=torch.int64, device="cuda")
+        p.mul_dcrt_ggsw_to_dev(glwe, ggsw, out, ctx, into_coeff_form=True)
+        torch.cuda.synchronize()
+        reps = max(2, args.steps // 3)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            p.mul_dcrt_ggsw_to_dev(glwe, ggsw, out, ctx, into_coeff_form=True)
+        torch.cuda.synchronize()
+        dte = (time.perf_counter() - t0) / reps
+        result["external_product"] = {
+            "value": ep_batch / dte, "unit": "RLWE external products/s (CrtGlwe x DcrtGgsw -> coefficient form)",
+            "batch": ep_batch, "ms_per_batch": dte * 1e3, "gadget": {"log_basis": 30, "ell": 6, "k": 1},
+            "ggsw": "one shared 36 MiB DcrtGgsw", "chunk": args.ext_chunk or 8,
+            "hbm_roofline_frac": ep_batch / dte * 96 * n / (HBM_PEAK_GBS * 1e9),
+            "limb_ntts_per_product": 42}
+        del ggsw, out, ctx
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
 

@@ -1,0 +1,88 @@
+"""N > 1 path on CPU: two gloo ranks shard a batch (no data-path collective), and the union of the
+per-rank results equals the unsharded result.  The per-rank "device work" here is the oracle —
+tests may use it; the point is the sharding / barrier / max-reduce logic bench.py relies on."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+
+    from oracle import oracle
+    from primus_fhe_amd.shard import shard_range, timed_steps
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    moduli = [2305843009211596801, 2305843009210023937, 2305843009208713217]
+    log_n, batch = 6, 7  # 7 does not divide evenly: ragged shards
+    n = 1 << log_n
+    rng = np.random.default_rng(0)  # same seed on every rank -> same global batch
+    data = np.concatenate([rng.integers(0, m, n, dtype=np.uint64) for _ in range(batch) for m in moduli])
+    table = oracle.U64DcrtTable(log_n, moduli)
+    b, e = shard_range(batch, world, rank)
+    mine = data[b * 3 * n:e * 3 * n].copy()
+    calls = []
+
+    def step():
+        calls.append(1)
+        if len(calls) == 1:
+            table.transform_slice(mine)
+
+    dt = timed_steps(step, steps=2, warmup=1, sync=lambda: None, dist=dist, device="cpu")
+    # gather the shards (test-only collective) and compare with the unsharded transform
+    parts = [None] * world
+    dist.all_gather_object(parts, (b, e, mine))
+    dist.destroy_process_group()
+    if rank == 0:
+        full = data.copy()
+        table.transform_slice(full)
+        got = np.concatenate([p[2] for p in sorted(parts, key=lambda t: t[0])])
+        q.put((np.array_equal(got, full), [(p[0], p[1]) for p in parts], dt, len(calls)))
+
+
+def test_shard_range_properties():
+    from primus_fhe_amd.shard import shard_range
+    for total in (0, 1, 7, 8, 4096, 8191):
+        for world in (1, 2, 3, 8):
+            rs = [shard_range(total, world, r) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == total
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+            sizes = [e - b for b, e in rs]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(4, 2, 2)
+
+
+def test_two_rank_gloo_sharding_matches_unsharded():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok, ranges, dt, ncalls = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok
+    assert sorted(ranges) == [(0, 4), (4, 7)]
+    assert dt > 0 and ncalls == 3  # 1 warm-up + exactly 2 timed steps

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 outputs into profiles/: per-kernel durations (kernel trace) and HBM traffic
+(FETCH_SIZE / WRITE_SIZE from two separate --pmc passes), corrected as MI355X_MICROARCH.md §HBM
+prescribes: on gfx950 FETCH_SIZE reports half of the bytes of a coalesced streaming read, so
+read bytes = 2 x FETCH_SIZE; WRITE_SIZE is exact.  Units in the CSVs are KiB.
+
+usage: pmc_summary.py TRACE_DIR FETCH_DIR WRITE_DIR OUT_PREFIX
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def one(pattern):
+    files = glob.glob(pattern, recursive=True)
+    if not files:
+        raise SystemExit(f"no file matches {pattern}")
+    return files[0]
+
+
+def short(name):
+    name = name.replace("void ", "").replace("pfhe::(anonymous namespace)::", "").replace("pfhe::", "")
+    return name.split("(")[0]
+
+
+def main():
+    trace_dir, fetch_dir, write_dir, out = sys.argv[1:5]
+    stats = list(csv.DictReader(open(one(f"{trace_dir}/**/*kernel_stats.csv"))))
+    trace = list(csv.DictReader(open(one(f"{trace_dir}/**/*kernel_trace.csv"))))
+    fetch = list(csv.DictReader(open(one(f"{fetch_dir}/**/*counter_collection.csv"))))
+    write = list(csv.DictReader(open(one(f"{write_dir}/**/*counter_collection.csv"))))
+    # group dispatches by (kernel, grid size): the same kernel runs at several problem sizes
+    dur = collections.defaultdict(list)
+    for r in trace:
+        key = (short(r["Kernel_Name"]), int(r["Grid_Size"]) if "Grid_Size" in r else int(r.get("Grid_Size_X", 0)))
+        dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    traffic = collections.defaultdict(lambda: {"fetch_kib": [], "write_kib": []})
+    for r in fetch:
+        traffic[(short(r["Kernel_Name"]), int(r["Grid_Size"]))]["fetch_kib"].append(float(r["Counter_Value"]))
+    for r in write:
+        traffic[(short(r["Kernel_Name"]), int(r["Grid_Size"]))]["write_kib"].append(float(r["Counter_Value"]))
+    rows = []
+    for key in sorted(set(dur) | set(traffic), key=lambda k: (k[0], -k[1])):
+        d, t = dur.get(key, []), traffic.get(key, {"fetch_kib": [], "write_kib": []})
+        if key[0].startswith("__amd"):
+            continue
+        f = sum(t["fetch_kib"]) / len(t["fetch_kib"]) if t["fetch_kib"] else None
+        w = sum(t["write_kib"]) / len(t["write_kib"]) if t["write_kib"] else None
+        row = {"kernel": key[0], "grid_size": key[1], "launches": len(d),
+               "avg_ms": sum(d) / len(d) / 1e6 if d else None,
+               "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
+               "read_bytes_corrected": None if f is None else 2 * f * 1024,
+               "write_bytes": None if w is None else w * 1024}
+        if f is not None and w is not None:
+            row["hbm_bytes_per_launch"] = row["read_bytes_corrected"] + row["write_bytes"]
+            if row["avg_ms"]:
+                row["traffic_GBps"] = row["hbm_bytes_per_launch"] / (row["avg_ms"] * 1e-3) / 1e9
+        rows.append(row)
+    json.dump({"note": "read bytes = 2 x FETCH_SIZE (gfx950 correction), WRITE_SIZE exact; separate --pmc passes",
+               "kernels": rows, "kernel_stats": stats}, open(out + ".json", "w"), indent=1)
+    with open(out + ".txt", "w") as fh:
+        fh.write(f"{'kernel':58s} {'grid':>10s} {'n':>3s} {'avg ms':>9s} {'read GiB':>9s} {'write GiB':>9s} {'GB/s':>8s}\n")
+        for r in rows:
+            g = lambda v, s=1.0: "-" if v is None else f"{v / s:.3f}"
+            fh.write(f"{r['kernel'][:58]:58s} {r['grid_size']:10d} {r['launches']:3d} {g(r['avg_ms']):>9s} "
+                     f"{g(r['read_bytes_corrected'], 2**30):>9s} {g(r['write_bytes'], 2**30):>9s} "
+                     f"{g(r.get('traffic_GBps')):>8s}\n")
+    print(open(out + ".txt").read())
+
+
+if __name__ == "__main__":
+    main()

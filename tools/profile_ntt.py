@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Small fixed workload for rocprofv3 (kernel trace or one --pmc pass at a time).
+
+    rocprofv3 --kernel-trace --stats --output-format csv -d OUT -- python3 tools/profile_ntt.py
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d OUT -- python3 tools/profile_ntt.py
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d OUT -- python3 tools/profile_ntt.py
+
+Runs, at the bench's shape (N=2^16, 3 primes, batch 4096 = 6 GiB, far beyond the 256 MiB Infinity
+Cache): 3 forward + 1 inverse RNS NTTs, one pointwise multiply, and the external product on 64
+ciphertexts.  Every kernel's algorithmic byte count is known, so FETCH_SIZE/WRITE_SIZE can be
+calibrated per access pattern (MI355X_MICROARCH.md §HBM)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import primus_fhe_amd as p  # noqa: E402
+from primus_fhe_amd._lib import check, u64p  # noqa: E402
+
+Q61 = [2305843009211596801, 2305843009210023937, 2305843009208713217]
+batch = int(os.environ.get("PFHE_PROFILE_BATCH", "4096"))
+n, L = 1 << 16, 3
+t = p.U64DcrtTable(16, Q61)
+words = batch * L * n
+x = torch.empty(words, dtype=torch.int64, device="cuda")
+mods = np.array(Q61, np.uint64)
+check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(x.data_ptr()), words, mods.ctypes.data_as(u64p), L, n, 1, None))
+b = x[:L * n].clone()
+for _ in range(3):
+    t.transform_dev(x)
+t.mul_assign_dev(x, b)
+t.inverse_transform_dev(x)
+base = p.RNSBase(Q61)
+ctx = p.DcrtGlevContext(t, base, p.BigUintApproxSignedBasis(base, 30), 1, 8)
+ep = min(64, batch // 2)
+ggsw = torch.empty(ctx.ggsw_len(), dtype=torch.int64, device="cuda")
+check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(ggsw.data_ptr()), ggsw.numel(), mods.ctypes.data_as(u64p), L, n, 2, None))
+out = torch.empty(ep * 2 * L * n, dtype=torch.int64, device="cuda")
+p.mul_dcrt_ggsw_to_dev(x[:ep * 2 * L * n], ggsw, out, ctx, into_coeff_form=True)
+torch.cuda.synchronize()
+print("profile workload done")
