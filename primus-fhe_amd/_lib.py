@@ -6,7 +6,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libpfhe_hip.so")
+# PFHE_LIB_PATH selects another build of the same library (tuning / ablation builds); default in-tree
+_LIB_PATH = os.environ.get("PFHE_LIB_PATH") or os.path.join(_HERE, "libpfhe_hip.so")
 
 u64p = C.POINTER(C.c_uint64)
 

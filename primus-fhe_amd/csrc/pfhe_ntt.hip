@@ -16,6 +16,7 @@
 // pass + one block pass of 2^12.  In terms of a global element index E (bit p is the butterfly
 // distance 2^p) the twiddle index of a forward butterfly is (N + E) >> (p + 1) and of an inverse
 // butterfly 1 + N - (N >> p) + (E >> (p + 1)).
+#include <algorithm>
 #include <cstdio>
 
 #include "pfhe_common.hpp"
@@ -41,7 +42,7 @@ __global__ void ntt_tiny_kernel(u64 *__restrict__ data, const NttPrime *__restri
         for (u32 p = log_n; p-- > 0;) {
             for (u32 e = 0; e < n; ++e) {
                 if (e & (1u << p)) continue;
-                ulonglong2 w = P.fwd[(n + e) >> (p + 1)];
+                const u64x2 w = tw_global(P.fwd)[(n + e) >> (p + 1)];
                 fwd_bfly(x[e], x[e | (1u << p)], w.x, w.y, q, two_q);
             }
         }
@@ -51,7 +52,7 @@ __global__ void ntt_tiny_kernel(u64 *__restrict__ data, const NttPrime *__restri
         for (u32 p = 0; p + 1 < log_n; ++p) {
             for (u32 e = 0; e < n; ++e) {
                 if (e & (1u << p)) continue;
-                ulonglong2 w = P.inv[1 + n - (n >> p) + (e >> (p + 1))];
+                const u64x2 w = tw_global(P.inv)[1 + n - (n >> p) + (e >> (p + 1))];
                 inv_bfly(x[e], x[e | (1u << p)], w.x, w.y, q, two_q);
             }
         }
@@ -104,13 +105,13 @@ __global__ __launch_bounds__(256) void ntt_strided_kernel(u64 *__restrict__ data
     }
 
     if constexpr (!INV) {
-        const ulonglong2 *__restrict__ tw = P->fwd;
+        const TwPtr tw = tw_global(P->fwd);
 #pragma unroll
         for (int j = K - 1; j >= 0; --j) {
             const u32 base = (n + ebase) >> (log_s + j + 1);
 #pragma unroll
             for (int u = 0; u < (R >> (j + 1)); ++u) {
-                const ulonglong2 w = tw[base + u];
+                const u64x2 w = tw[base + u];
 #pragma unroll
                 for (int v = 0; v < (1 << j); ++v) {
                     const int k0 = (u << (j + 1)) | v, k1 = k0 | (1 << j);
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void ntt_strided_kernel(u64 *__restrict__ data
             }
         }
     } else {
-        const ulonglong2 *__restrict__ tw = P->inv;
+        const TwPtr tw = tw_global(P->inv);
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             const u32 p = log_s + j;
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void ntt_strided_kernel(u64 *__restrict__ data
                 const u32 base = 1 + n - (n >> p) + (ebase >> (p + 1));
 #pragma unroll
                 for (int u = 0; u < (R >> (j + 1)); ++u) {
-                    const ulonglong2 w = tw[base + u];
+                    const u64x2 w = tw[base + u];
 #pragma unroll
                     for (int v = 0; v < (1 << j); ++v) {
                         const int k0 = (u << (j + 1)) | v, k1 = k0 | (1 << j);
@@ -187,10 +188,82 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) void ntt_block_kernel(
     u64 *__restrict__ lds = lds_raw + (size_t)sub * Cfg::LDS_WORDS;
 
     u64 x[16];
+#if defined(PFHE_DIRECT_IO)
     if constexpr (!INV) {
         block_forward<LOGB, LAZY>(x, gptr, lds, P, n, eblk, lt, valid);
     } else {
         block_inverse<LOGB, LAZY>(x, gptr, lds, P, n, eblk, lt, valid, log_n == LOGB);
+    }
+#else
+    // all global traffic as 16-byte vectors in natural order (1 KiB per wave instruction), staged
+    // through LDS into / out of the register layouts of the first / last register pass
+    u64x2 io[8];
+    if (valid) load_block_vectors<LOGB>(io, gptr, lt);
+    lds_put_vectors<LOGB>(io, lds, lt);
+    __syncthreads();
+    if constexpr (!INV) {
+        lds_get_layout<LOGB - 4>(x, lds, lt);
+        block_forward_core<LOGB, LAZY, true>(x, lds, P, n, eblk, lt);
+        __syncthreads();
+        lds_put_layout<0>(x, lds, lt);
+    } else {
+        lds_get_layout<0>(x, lds, lt);
+        block_inverse_core<LOGB, LAZY, true>(x, lds, P, n, eblk, lt, log_n == LOGB);
+        __syncthreads();
+        lds_put_layout<LOGB - 4>(x, lds, lt);
+    }
+    __syncthreads();
+    lds_get_vectors<LOGB>(io, lds, lt);
+    if (valid) store_block_vectors<LOGB>(io, gptr, lt);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
+// persistent block pass (LOGB >= 12): a workgroup loops over blocks; all global traffic is
+// 16-byte coalesced (staged through LDS in natural order) and the NEXT block's input is
+// prefetched into registers while the current block is transformed, so HBM latency overlaps
+// the butterfly arithmetic instead of being exposed once per workgroup.
+// ------------------------------------------------------------------------------------------
+template <int LOGB, bool INV, bool LAZY>
+__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS, (LOGB == 12 ? 3 : 1)) void ntt_block_persistent_kernel(
+    u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L, u32 log_n, u64 total_blocks) {
+    using Cfg = BlockCfg<LOGB>;
+    static_assert(Cfg::BPW == 1, "persistent variant is for one block per workgroup");
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const u32 lt = threadIdx.x;
+    const u32 log_nb = log_n - LOGB;
+    const u32 n = 1u << log_n;
+    u64 blk = blockIdx.x;
+    if (blk >= total_blocks) return;
+    u64x2 io[8];
+    load_block_vectors<LOGB>(io, data + (blk << LOGB), lt);
+    for (; blk < total_blocks; blk += gridDim.x) {
+        const u64 pid = blk >> log_nb;
+        const u32 eblk = (u32)(blk & ((1ull << log_nb) - 1)) << LOGB;
+        const NttPrime *__restrict__ P = primes + (u32)(pid % L);
+        u64 *__restrict__ gptr = data + (blk << LOGB);
+        __syncthreads();  // previous iteration's LDS readers are done
+        lds_put_vectors<LOGB>(io, lds, lt);
+        __syncthreads();
+        u64 next = blk + gridDim.x;
+        if (next >= total_blocks) next = blk;  // last iteration: harmless re-read, keeps the prefetch unconditional
+        load_block_vectors<LOGB>(io, data + (next << LOGB), lt);
+        u64 x[16];
+        if constexpr (!INV) {
+            lds_get_layout<LOGB - 4>(x, lds, lt);
+            block_forward_core<LOGB, LAZY, true>(x, lds, P, n, eblk, lt);
+            __syncthreads();
+            lds_put_layout<0>(x, lds, lt);
+        } else {
+            lds_get_layout<0>(x, lds, lt);
+            block_inverse_core<LOGB, LAZY, true>(x, lds, P, n, eblk, lt, log_n == LOGB);
+            __syncthreads();
+            lds_put_layout<LOGB - 4>(x, lds, lt);
+        }
+        __syncthreads();
+        u64x2 out[8];
+        lds_get_vectors<LOGB>(out, lds, lt);
+        store_block_vectors<LOGB>(out, gptr, lt);
     }
 }
 
@@ -199,18 +272,41 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) void ntt_block_kernel(
 // ------------------------------------------------------------------------------------------
 namespace {
 
+int device_cu_count() {
+    static thread_local int cached[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cached[dev] = cus;
+    }
+    return cached[dev];
+}
+
 template <int LOGB, bool INV, bool LAZY>
 int launch_block(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys, hipStream_t s) {
     using Cfg = BlockCfg<LOGB>;
     const u64 total_blocks = npolys << (log_n - LOGB);
-    const u64 grid = (total_blocks + Cfg::BPW - 1) / Cfg::BPW;
+    u64 grid = (total_blocks + Cfg::BPW - 1) / Cfg::BPW;
     if (grid == 0) return PFHE_OK;
+    constexpr size_t lds_bytes = (size_t)Cfg::BPW * Cfg::LDS_WORDS * sizeof(u64);
+#if defined(PFHE_NO_PERSISTENT)
+    constexpr bool kPersistent = false;
+#else
+    constexpr bool kPersistent = LOGB >= 12;
+#endif
+    if constexpr (kPersistent) {
+        // resident workgroups per CU are bounded by LDS (160 KiB); loop over the rest
+        const u64 per_cu = std::max<u64>(1, (160 * 1024) / lds_bytes);
+        grid = std::min<u64>(grid, (u64)device_cu_count() * per_cu);
+    }
     if (grid > 0x7fffffffull) {
         set_last_error("batch too large for one launch");
         return PFHE_ERR_BAD_LENGTH;
     }
-    constexpr size_t lds_bytes = (size_t)Cfg::BPW * Cfg::LDS_WORDS * sizeof(u64);
-    auto kern = ntt_block_kernel<LOGB, INV, LAZY>;
+    auto kern = kPersistent ? ntt_block_persistent_kernel<LOGB < 12 ? 12 : LOGB, INV, LAZY>
+                            : ntt_block_kernel<LOGB, INV, LAZY>;
     if (lds_bytes > 64 * 1024) {
         static thread_local bool configured[64] = {};
         int dev = 0;

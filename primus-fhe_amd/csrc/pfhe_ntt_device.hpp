@@ -29,6 +29,14 @@ int ntt_pass_dev(const NttPrime *primes, u32 L, u32 log_n, u64 *data, u64 npolys
 
 #if defined(__HIPCC__)
 
+// Twiddle tables are reached through a pointer stored in NttPrime, which the compiler would treat
+// as a generic (flat) pointer: flat loads tick both vmcnt and lgkmcnt and serialise against LDS
+// traffic and prefetches.  Reading them through an explicit global-address-space pointer yields
+// plain global_load_dwordx4.
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+typedef const u64x2 __attribute__((address_space(1))) *TwPtr;
+__device__ __forceinline__ TwPtr tw_global(const ulonglong2 *p) { return (TwPtr)(const void *)p; }
+
 // Harvey forward butterfly, values in [0,4q) — scalar/arithmetic.rs:43-59
 __device__ __forceinline__ void fwd_bfly(u64 &x, u64 &y, u64 w, u64 wp, u64 q, u64 two_q) {
     const u64 tx = reduce_once(x, two_q);
@@ -95,19 +103,27 @@ __device__ __forceinline__ u32 maybe_uniform(u32 v) {
 
 // forward stages on register bits JHI..JLO (element bits POS+JHI .. POS+JLO)
 template <int POS, int JHI, int JLO, bool UNIFORM>
-__device__ __forceinline__ void fwd_regpass(u64 (&x)[16], const ulonglong2 *__restrict__ tw, u32 n_plus_e,
+__device__ __forceinline__ void fwd_regpass(u64 (&x)[16], TwPtr tw, u32 n_plus_e,
                                             u64 q, u64 two_q) {
 #pragma unroll
     for (int j = JHI; j >= JLO; --j) {
         const u32 base = maybe_uniform<POS, UNIFORM>(n_plus_e >> (POS + j + 1));
 #pragma unroll
         for (int u = 0; u < (16 >> (j + 1)); ++u) {
-            const ulonglong2 w = tw[base + u];
+#if defined(PFHE_ABL_CONST_TW)
+            const u64x2 w = u64x2{q - 12345 - u, two_q + base};
+#else
+            const u64x2 w = tw[base + u];
+#endif
+#if !defined(PFHE_ABL_NO_MATH)
 #pragma unroll
             for (int v = 0; v < (1 << j); ++v) {
                 const int k0 = (u << (j + 1)) | v, k1 = k0 | (1 << j);
                 fwd_bfly(x[k0], x[k1], w.x, w.y, q, two_q);
             }
+#else
+            x[u] += w.x;
+#endif
         }
     }
 }
@@ -117,7 +133,7 @@ __device__ __forceinline__ void fwd_regpass(u64 (&x)[16], const ulonglong2 *__re
 template <int POS, int JLO, int JHI, bool UNIFORM, bool LAZY>
 __device__ __forceinline__ void inv_regpass(u64 (&x)[16], const NttPrime *__restrict__ P, u32 n, u32 e_abs,
                                             u64 q, u64 two_q, bool final_stage) {
-    const ulonglong2 *__restrict__ tw = P->inv;
+    const TwPtr tw = tw_global(P->inv);
 #pragma unroll
     for (int j = JLO; j <= JHI; ++j) {
         const u32 p = POS + j;
@@ -129,7 +145,7 @@ __device__ __forceinline__ void inv_regpass(u64 (&x)[16], const NttPrime *__rest
             const u32 base = maybe_uniform<POS, UNIFORM>(1 + n - (n >> p) + (e_abs >> (p + 1)));
 #pragma unroll
             for (int u = 0; u < (16 >> (j + 1)); ++u) {
-                const ulonglong2 w = tw[base + u];
+                const u64x2 w = tw[base + u];
 #pragma unroll
                 for (int v = 0; v < (1 << j); ++v) {
                     const int k0 = (u << (j + 1)) | v, k1 = k0 | (1 << j);
@@ -143,6 +159,9 @@ __device__ __forceinline__ void inv_regpass(u64 (&x)[16], const NttPrime *__rest
 // registers (layout FROM) -> LDS -> registers (layout TO)
 template <int FROM, int TO, bool SYNC_BEFORE>
 __device__ __forceinline__ void lds_exchange(u64 (&x)[16], u64 *__restrict__ lds, u32 lt) {
+#if defined(PFHE_ABL_NO_LDS)
+    return;
+#endif
     if constexpr (SYNC_BEFORE) __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds[lds_phi(layout<FROM>(lt, k))] = x[k];
@@ -152,7 +171,7 @@ __device__ __forceinline__ void lds_exchange(u64 (&x)[16], u64 *__restrict__ lds
 }
 
 template <int LOGB, int POS, bool FIRST>
-__device__ __forceinline__ void fwd_chain(u64 (&x)[16], u64 *__restrict__ lds, const ulonglong2 *__restrict__ tw,
+__device__ __forceinline__ void fwd_chain(u64 (&x)[16], u64 *__restrict__ lds, TwPtr tw,
                                           u32 n, u32 eblk, u32 lt, u64 q, u64 two_q) {
     constexpr bool UNI = BlockCfg<LOGB>::BPW == 1;
     if constexpr (POS > 0) {
@@ -164,22 +183,31 @@ __device__ __forceinline__ void fwd_chain(u64 (&x)[16], u64 *__restrict__ lds, c
     }
 }
 
+// forward compute core: x holds layout<LOGB-4> on entry and layout<0> (canonical unless LAZY) on exit.
+// LDS_DIRTY: other threads may still be reading the LDS region (sync before the first write).
+template <int LOGB, bool LAZY, bool LDS_DIRTY>
+__device__ __forceinline__ void block_forward_core(u64 (&x)[16], u64 *__restrict__ lds,
+                                                   const NttPrime *__restrict__ P, u32 n, u32 eblk, u32 lt) {
+    constexpr int POS0 = LOGB - 4;
+    constexpr bool UNI = BlockCfg<LOGB>::BPW == 1;
+    const u64 q = P->q, two_q = P->two_q;
+    const TwPtr tw = tw_global(P->fwd);
+    fwd_regpass<POS0, 3, 0, UNI>(x, tw, n + eblk + layout<POS0>(lt, 0), q, two_q);
+    fwd_chain<LOGB, POS0, !LDS_DIRTY>(x, lds, tw, n, eblk, lt, q, two_q);
+    if (!LAZY) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = reduce_once(reduce_once(x[k], two_q), q);
+    }
+}
+
 template <int LOGB, bool LAZY>
 __device__ __forceinline__ void block_forward(u64 (&x)[16], u64 *__restrict__ gptr, u64 *__restrict__ lds,
                                               const NttPrime *__restrict__ P, u32 n, u32 eblk, u32 lt,
                                               bool valid) {
     constexpr int POS0 = LOGB - 4;
-    constexpr bool UNI = BlockCfg<LOGB>::BPW == 1;
-    const u64 q = P->q, two_q = P->two_q;
-    const ulonglong2 *__restrict__ tw = P->fwd;
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = valid ? gptr[layout<POS0>(lt, k)] : 0ull;
-    fwd_regpass<POS0, 3, 0, UNI>(x, tw, n + eblk + layout<POS0>(lt, 0), q, two_q);
-    fwd_chain<LOGB, POS0, true>(x, lds, tw, n, eblk, lt, q, two_q);
-    if (!LAZY) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) x[k] = reduce_once(reduce_once(x[k], two_q), q);
-    }
+    block_forward_core<LOGB, LAZY, false>(x, lds, P, n, eblk, lt);
     if (valid) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) gptr[layout<0>(lt, k)] = x[k];
@@ -202,21 +230,71 @@ __device__ __forceinline__ void inv_chain(u64 (&x)[16], u64 *__restrict__ lds, c
     }
 }
 
+// inverse compute core: x holds layout<0> on entry and layout<LOGB-4> on exit.
+template <int LOGB, bool LAZY, bool LDS_DIRTY>
+__device__ __forceinline__ void block_inverse_core(u64 (&x)[16], u64 *__restrict__ lds,
+                                                   const NttPrime *__restrict__ P, u32 n, u32 eblk, u32 lt,
+                                                   bool final_block) {
+    constexpr bool UNI = BlockCfg<LOGB>::BPW == 1;
+    const u64 q = P->q, two_q = P->two_q;
+    inv_regpass<0, 0, 3, UNI, LAZY>(x, P, n, eblk + layout<0>(lt, 0), q, two_q, LOGB == 4 && final_block);
+    inv_chain<LOGB, 0, !LDS_DIRTY, LAZY>(x, lds, P, n, eblk, lt, q, two_q, final_block);
+}
+
 template <int LOGB, bool LAZY>
 __device__ __forceinline__ void block_inverse(u64 (&x)[16], u64 *__restrict__ gptr, u64 *__restrict__ lds,
                                               const NttPrime *__restrict__ P, u32 n, u32 eblk, u32 lt,
                                               bool valid, bool final_block) {
     constexpr int POSL = LOGB - 4;  // layout of the last register pass
-    constexpr bool UNI = BlockCfg<LOGB>::BPW == 1;
-    const u64 q = P->q, two_q = P->two_q;
 #pragma unroll
     for (int k = 0; k < 16; ++k) x[k] = valid ? gptr[layout<0>(lt, k)] : 0ull;
-    inv_regpass<0, 0, 3, UNI, LAZY>(x, P, n, eblk + layout<0>(lt, 0), q, two_q, LOGB == 4 && final_block);
-    inv_chain<LOGB, 0, true, LAZY>(x, lds, P, n, eblk, lt, q, two_q, final_block);
+    block_inverse_core<LOGB, LAZY, false>(x, lds, P, n, eblk, lt, final_block);
     if (valid) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) gptr[layout<POSL>(lt, k)] = x[k];
     }
+}
+
+// ---- coalesced block I/O through LDS (persistent kernel): 8 x 16-byte vectors per thread in
+//      natural order (vector v = elements 2v, 2v+1), one full KiB per wave instruction ----
+typedef u64x2 __attribute__((address_space(1))) *GVecPtr;
+
+template <int LOGB>
+__device__ __forceinline__ void load_block_vectors(u64x2 (&v)[8], const u64 *gptr, u32 lt) {
+    const TwPtr p = (TwPtr)(const void *)gptr;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = p[lt + BlockCfg<LOGB>::TPB * j];
+}
+
+template <int LOGB>
+__device__ __forceinline__ void store_block_vectors(const u64x2 (&v)[8], u64 *gptr, u32 lt) {
+    const GVecPtr p = (GVecPtr)(void *)gptr;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p[lt + BlockCfg<LOGB>::TPB * j] = v[j];
+}
+
+template <int LOGB>
+__device__ __forceinline__ void lds_put_vectors(const u64x2 (&v)[8], u64 *__restrict__ lds, u32 lt) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<u64x2 *>(lds + lds_phi(2 * (lt + BlockCfg<LOGB>::TPB * j))) = v[j];
+}
+
+template <int LOGB>
+__device__ __forceinline__ void lds_get_vectors(u64x2 (&v)[8], const u64 *__restrict__ lds, u32 lt) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const u64x2 *>(lds + lds_phi(2 * (lt + BlockCfg<LOGB>::TPB * j)));
+}
+
+template <int POS>
+__device__ __forceinline__ void lds_get_layout(u64 (&x)[16], const u64 *__restrict__ lds, u32 lt) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = lds[lds_phi(layout<POS>(lt, k))];
+}
+
+template <int POS>
+__device__ __forceinline__ void lds_put_layout(const u64 (&x)[16], u64 *__restrict__ lds, u32 lt) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[lds_phi(layout<POS>(lt, k))] = x[k];
 }
 
 #endif  // __HIPCC__
