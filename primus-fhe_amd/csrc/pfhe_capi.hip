@@ -2,6 +2,7 @@
 // never throws.  There is deliberately no CPU fallback: without a HIP device every create()
 // fails with PFHE_ERR_NO_DEVICE.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -77,6 +78,7 @@ int make_table_set(u32 log_n, const u64 *moduli, size_t count, int device, std::
     ts->L = (u32)count;
     ts->primes.resize(count);
     const size_t bytes = ts->n * sizeof(ulonglong2);
+    bool all_pm = std::getenv("PFHE_DISABLE_PM") == nullptr;  // tuning switch: force the generic path
     for (size_t i = 0; i < count; ++i) {
         void *fwd = nullptr, *inv = nullptr;
         PFHE_HIP(hipMalloc(&fwd, bytes));
@@ -96,9 +98,36 @@ int make_table_set(u32 log_n, const u64 *moduli, size_t count, int device, std::
         P.bar_hi = host[i].bar_hi;
         P.fwd = static_cast<const ulonglong2 *>(fwd);
         P.inv = static_cast<const ulonglong2 *>(inv);
+        // compact twiddle tables for the pseudo-Mersenne path (no Shoup quotients)
+        u32 pk = 0;
+        u64 pc = 0;
+        P.pm_k = pm_shape(P.q, pk, pc) ? pk : 0;
+        P.pm_pad = 0;
+        P.pm_c = P.pm_k ? pc : 0;
+        P.fwd_w = nullptr;
+        P.inv_w = nullptr;
+        if (P.pm_k) {
+            std::vector<u64> fw(ts->n), iw(ts->n);
+            for (size_t k = 0; k < ts->n; ++k) {
+                fw[k] = host[i].fwd[k].x;
+                iw[k] = host[i].inv[k].x;
+            }
+            void *fwp = nullptr, *iwp = nullptr;
+            PFHE_HIP(hipMalloc(&fwp, ts->n * sizeof(u64)));
+            ts->allocations.push_back(fwp);
+            PFHE_HIP(hipMalloc(&iwp, ts->n * sizeof(u64)));
+            ts->allocations.push_back(iwp);
+            PFHE_HIP(hipMemcpy(fwp, fw.data(), ts->n * sizeof(u64), hipMemcpyHostToDevice));
+            PFHE_HIP(hipMemcpy(iwp, iw.data(), ts->n * sizeof(u64), hipMemcpyHostToDevice));
+            P.fwd_w = static_cast<const u64 *>(fwp);
+            P.inv_w = static_cast<const u64 *>(iwp);
+        } else {
+            all_pm = false;
+        }
         ts->roots.push_back(host[i].root);
         ts->inv_roots.push_back(host[i].inv_root);
     }
+    ts->pm = all_pm;
     void *pd = nullptr;
     PFHE_HIP(hipMalloc(&pd, count * sizeof(NttPrime)));
     ts->allocations.push_back(pd);
@@ -132,8 +161,8 @@ int transform_dev(const TableSet &t, u64 *data, size_t len, bool inverse, bool l
     DeviceGuard g(t.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
     const u64 npolys = units * t.L;
-    return inverse ? ntt_inverse_dev(t.primes_dev, t.L, t.log_n, data, npolys, lazy, s)
-                   : ntt_forward_dev(t.primes_dev, t.L, t.log_n, data, npolys, lazy, s);
+    return inverse ? ntt_inverse_dev(t.primes_dev, t.L, t.log_n, t.pm, data, npolys, lazy, s)
+                   : ntt_forward_dev(t.primes_dev, t.L, t.log_n, t.pm, data, npolys, lazy, s);
 }
 
 // host-pointer wrapper: stage through a temporary device buffer
@@ -539,8 +568,8 @@ int pfhe_dcrt_transform_pass_dev(const pfhe_dcrt *table, uint64_t *poly_dev, siz
     if (len % (t.n * t.L) != 0) return PFHE_ERR_BAD_LENGTH;
     DeviceGuard g(t.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    return ntt_pass_dev(t.primes_dev, t.L, t.log_n, (u64 *)poly_dev, len / t.n, inverse != 0, index, lazy != 0,
-                        (hipStream_t)stream);
+    return ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.pm, (u64 *)poly_dev, len / t.n, inverse != 0, index,
+                        lazy != 0, (hipStream_t)stream);
     PFHE_GUARD_END
 }
 

@@ -70,7 +70,7 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
         const u64 cur = std::min<u64>(p->chunk, batch - done);
         const u64 *in = crt_polys + done * rows * W;
         PFHE_TRY(gadget_decompose_dev(p->rns, p->basis, t.log_n, in, p->digits, cur * rows, s));
-        PFHE_TRY(ntt_forward_dev(t.primes_dev, t.L, t.log_n, p->digits, cur * rows * ell * t.L, false, s));
+        PFHE_TRY(ntt_forward_dev(t.primes_dev, t.L, t.log_n, t.pm, p->digits, cur * rows * ell * t.L, false, s));
         PFHE_TRY(gadget_mulacc_dev(t.primes_dev, t.L, t.log_n, p->k, rows, ell, p->digits,
                                    keys + (keys_shared ? 0 : done * key_words), keys_shared,
                                    result + done * (p->k + 1) * W, cur, accumulate, s));
@@ -351,7 +351,7 @@ int pfhe_extprod_mul_dcrt_ggsw_to_dev(pfhe_extprod_plan *plan, const uint64_t *c
     PFHE_TRY(run_product(plan, (const u64 *)crt_glwe_dev, plan->k + 1, (const u64 *)dcrt_ggsw_dev, shared,
                          (u64 *)result_dev, batch, false, (hipStream_t)stream));
     if (into_coeff_form)  // DcrtGlwe::into_coeff_form, macros/mod.rs:901-911
-        PFHE_TRY(ntt_inverse_dev(t.primes_dev, t.L, t.log_n, (u64 *)result_dev, batch * (plan->k + 1) * t.L, false,
+        PFHE_TRY(ntt_inverse_dev(t.primes_dev, t.L, t.log_n, t.pm, (u64 *)result_dev, batch * (plan->k + 1) * t.L, false,
                                  (hipStream_t)stream));
     return PFHE_OK;
     PFHE_GUARD_END

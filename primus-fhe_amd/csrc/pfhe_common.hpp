@@ -50,7 +50,20 @@ struct NttPrime {
     u64 bar_lo, bar_hi;      // floor(2^128 / q) (BarrettModulus ratio)
     const ulonglong2 *fwd;   // device, N entries
     const ulonglong2 *inv;   // device, N entries
+    // pseudo-Mersenne fast path: q = 2^pm_k - pm_c (pm_k == 0: prime does not qualify)
+    u32 pm_k, pm_pad;
+    u64 pm_c;
+    const u64 *fwd_w;        // device, N entries: the twiddles alone (no Shoup quotient)
+    const u64 *inv_w;
 };
+
+// q = 2^K - c qualifies for PmArith when 40 <= K <= 61 and c < 2^(K-33)
+inline bool pm_shape(u64 q, u32 &k, u64 &c) {
+    k = 64 - (u32)__builtin_clzll(q);
+    if ((q & (q - 1)) == 0) return false;
+    c = (1ull << k) - q;
+    return k >= 40 && k <= 61 && c < (1ull << (k - 33));
+}
 
 struct HostTable {  // host-side result of table construction
     u32 log_n = 0;

@@ -13,6 +13,7 @@ struct TableSet {
     u32 log_n = 0;
     size_t n = 1;
     u32 L = 0;
+    bool pm = false;                       // every prime has the pseudo-Mersenne shape
     std::vector<NttPrime> primes;          // host copies (device pointers inside)
     const NttPrime *primes_dev = nullptr;  // the same array on the device
     const u64 *moduli_dev = nullptr;

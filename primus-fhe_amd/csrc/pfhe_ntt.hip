@@ -11,11 +11,15 @@
 //     registers, fully coalesced 16-byte loads/stores, twiddles wave-uniform (scalar loads);
 //   * one "block" pass: a workgroup owns a contiguous block of 2^LOGB coefficients, every
 //     thread keeps 16 of them in registers, runs 4 radix-2 stages per register pass and
-//     re-shuffles through (padded) LDS between register passes.
+//     re-shuffles through (padded) LDS between register passes; global traffic is 16-byte
+//     coalesced and staged through LDS into/out of the register layouts.
 // N <= 2^14 is a single block pass (one HBM read + one HBM write); N = 2^15..2^17 is one strided
 // pass + one block pass of 2^12.  In terms of a global element index E (bit p is the butterfly
 // distance 2^p) the twiddle index of a forward butterfly is (N + E) >> (p + 1) and of an inverse
 // butterfly 1 + N - (N >> p) + (E >> (p + 1)).
+//
+// Every kernel is instantiated for two arithmetic policies (pfhe_ntt_device.hpp): ShoupArith for
+// arbitrary q < 2^62 and PmArith for pseudo-Mersenne primes q = 2^K - c.
 #include <algorithm>
 #include <cstdio>
 
@@ -29,36 +33,33 @@ namespace pfhe {
 // tiny transforms (N <= 8): one thread per polynomial, straight loops.  Only there so that the
 // whole NttTable domain (log_n >= 0) is served by the device path.
 // ------------------------------------------------------------------------------------------
-template <bool INV, bool LAZY>
-__global__ void ntt_tiny_kernel(u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L,
-                                u32 log_n, u64 npolys) {
+template <bool INV>
+__global__ void ntt_tiny_kernel(u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L, u32 log_n,
+                                u64 npolys, u32 lazy) {
     u64 pid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (pid >= npolys) return;
-    const NttPrime P = primes[pid % L];
+    const ShoupArith ar(primes + pid % L);
     const u32 n = 1u << log_n;
     u64 *x = data + pid * n;
-    const u64 q = P.q, two_q = P.two_q;
     if (!INV) {
         for (u32 p = log_n; p-- > 0;) {
             for (u32 e = 0; e < n; ++e) {
                 if (e & (1u << p)) continue;
-                const u64x2 w = tw_global(P.fwd)[(n + e) >> (p + 1)];
-                fwd_bfly(x[e], x[e | (1u << p)], w.x, w.y, q, two_q);
+                fwd_bfly(ar, x[e], x[e | (1u << p)], ar.fwd_tw((n + e) >> (p + 1)));
             }
         }
-        if (!LAZY && log_n > 0)
-            for (u32 e = 0; e < n; ++e) x[e] = reduce_once(reduce_once(x[e], two_q), q);
+        if (!lazy && log_n > 0)
+            for (u32 e = 0; e < n; ++e) x[e] = csub(csub(x[e], ar.two_q), ar.q);
     } else {
         for (u32 p = 0; p + 1 < log_n; ++p) {
             for (u32 e = 0; e < n; ++e) {
                 if (e & (1u << p)) continue;
-                const u64x2 w = tw_global(P.inv)[1 + n - (n >> p) + (e >> (p + 1))];
-                inv_bfly(x[e], x[e | (1u << p)], w.x, w.y, q, two_q);
+                inv_bfly(ar, x[e], x[e | (1u << p)], ar.inv_tw(1 + n - (n >> p) + (e >> (p + 1))));
             }
         }
         if (log_n > 0) {
             const u32 h = n >> 1;
-            for (u32 e = 0; e < h; ++e) inv_final_bfly<LAZY>(x[e], x[e + h], P);
+            for (u32 e = 0; e < h; ++e) inv_final_bfly(ar, x[e], x[e + h], lazy != 0);
         }
     }
 }
@@ -70,11 +71,10 @@ __global__ void ntt_tiny_kernel(u64 *__restrict__ data, const NttPrime *__restri
 //   inverse: stages with butterfly distance S ... S*2^(K-1); FINAL marks that the top stage is
 //            the last stage of the whole transform (fused N^-1 scaling, table.rs:283-318).
 // ------------------------------------------------------------------------------------------
-template <int K, int VEC, bool INV, bool FINAL, bool LAZY>
+template <class A, int K, int VEC, bool INV, bool FINAL>
 __global__ __launch_bounds__(256) void ntt_strided_kernel(u64 *__restrict__ data,
-                                                          const NttPrime *__restrict__ primes,
-                                                          u32 L, u32 log_n, u32 log_s,
-                                                          u64 total_threads) {
+                                                          const NttPrime *__restrict__ primes, u32 L,
+                                                          u32 log_n, u32 log_s, u64 total_threads, u32 lazy) {
     constexpr int R = 1 << K;
     u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total_threads) return;
@@ -85,9 +85,7 @@ __global__ __launch_bounds__(256) void ntt_strided_kernel(u64 *__restrict__ data
     // hi and pid are identical for all 64 lanes of a wave (2^log_cols >= 64 threads per value)
     const u32 hi = __builtin_amdgcn_readfirstlane((u32)((gid >> log_cols) & ((1ull << log_hi) - 1)));
     const u32 pid_lo = __builtin_amdgcn_readfirstlane((u32)(gid >> (log_cols + log_hi)));
-    const u32 limb = pid_lo % L;
-    const NttPrime *__restrict__ P = primes + limb;
-    const u64 q = P->q, two_q = P->two_q;
+    const A ar(primes + pid_lo % L);
     const u32 n = 1u << log_n;
     const u32 ebase = hi << (log_s + K);  // element index of register 0, column 0
     u64 *__restrict__ ptr = data + (u64)pid_lo * n + ebase + (u64)col * VEC;
@@ -96,7 +94,7 @@ __global__ __launch_bounds__(256) void ntt_strided_kernel(u64 *__restrict__ data
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         if constexpr (VEC == 2) {
-            ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(ptr + ((u64)k << log_s));
+            const u64x2 v = *reinterpret_cast<const u64x2 *>(ptr + ((u64)k << log_s));
             x[k][0] = v.x;
             x[k][1] = v.y;
         } else {
@@ -105,52 +103,49 @@ __global__ __launch_bounds__(256) void ntt_strided_kernel(u64 *__restrict__ data
     }
 
     if constexpr (!INV) {
-        const TwPtr tw = tw_global(P->fwd);
 #pragma unroll
         for (int j = K - 1; j >= 0; --j) {
             const u32 base = (n + ebase) >> (log_s + j + 1);
 #pragma unroll
             for (int u = 0; u < (R >> (j + 1)); ++u) {
-                const u64x2 w = tw[base + u];
+                const typename A::Tw w = ar.fwd_tw(base + u);
 #pragma unroll
                 for (int v = 0; v < (1 << j); ++v) {
                     const int k0 = (u << (j + 1)) | v, k1 = k0 | (1 << j);
 #pragma unroll
-                    for (int c = 0; c < VEC; ++c) fwd_bfly(x[k0][c], x[k1][c], w.x, w.y, q, two_q);
+                    for (int c = 0; c < VEC; ++c) fwd_bfly(ar, x[k0][c], x[k1][c], w);
                 }
             }
         }
     } else {
-        const TwPtr tw = tw_global(P->inv);
+        constexpr int JTOP = FINAL ? K - 1 : K;  // the fused final stage is handled after the loop
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
+        for (int j = 0; j < JTOP; ++j) {
             const u32 p = log_s + j;
-            if (FINAL && j == K - 1) {
-                const NttPrime PP = *P;
+            const u32 base = 1 + n - (n >> p) + (ebase >> (p + 1));
 #pragma unroll
-                for (int v = 0; v < (1 << j); ++v)
+            for (int u = 0; u < (R >> (j + 1)); ++u) {
+                const typename A::Tw w = ar.inv_tw(base + u);
 #pragma unroll
-                    for (int c = 0; c < VEC; ++c) inv_final_bfly<LAZY>(x[v][c], x[v | (1 << j)][c], PP);
-            } else {
-                const u32 base = 1 + n - (n >> p) + (ebase >> (p + 1));
+                for (int v = 0; v < (1 << j); ++v) {
+                    const int k0 = (u << (j + 1)) | v, k1 = k0 | (1 << j);
 #pragma unroll
-                for (int u = 0; u < (R >> (j + 1)); ++u) {
-                    const u64x2 w = tw[base + u];
-#pragma unroll
-                    for (int v = 0; v < (1 << j); ++v) {
-                        const int k0 = (u << (j + 1)) | v, k1 = k0 | (1 << j);
-#pragma unroll
-                        for (int c = 0; c < VEC; ++c) inv_bfly(x[k0][c], x[k1][c], w.x, w.y, q, two_q);
-                    }
+                    for (int c = 0; c < VEC; ++c) inv_bfly(ar, x[k0][c], x[k1][c], w);
                 }
             }
+        }
+        if constexpr (FINAL) {
+#pragma unroll
+            for (int v = 0; v < R / 2; ++v)
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) inv_final_bfly(ar, x[v][c], x[v + R / 2][c], lazy != 0);
         }
     }
 
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         if constexpr (VEC == 2) {
-            *reinterpret_cast<ulonglong2 *>(ptr + ((u64)k << log_s)) = ulonglong2{x[k][0], x[k][1]};
+            *reinterpret_cast<u64x2 *>(ptr + ((u64)k << log_s)) = u64x2{x[k][0], x[k][1]};
         } else {
             ptr[(u64)k << log_s] = x[k][0];
         }
@@ -161,13 +156,13 @@ __global__ __launch_bounds__(256) void ntt_strided_kernel(u64 *__restrict__ data
 // block pass: a workgroup owns BPW contiguous blocks of B = 2^LOGB coefficients (BPW > 1 only
 // for B < 4096 so that a workgroup always has 256+ threads).
 //   forward: the LAST LOGB stages of the transform (distances B/2 ... 1), canonical reduction
-//            fused into the final stage (scalar/transform.rs:104-116) unless LAZY.
+//            fused into the final stage (scalar/transform.rs:104-116) unless lazy.
 //   inverse: the FIRST LOGB stages (distances 1 ... B/2); when B == N the final stage carries
 //            the fused N^-1 / N^-1*w scaling (scalar/transform.rs:283-318).
 // ------------------------------------------------------------------------------------------
-template <int LOGB, bool INV, bool LAZY>
+template <class A, int LOGB, bool INV>
 __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) void ntt_block_kernel(
-    u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L, u32 log_n, u64 total_blocks) {
+    u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L, u32 log_n, u64 total_blocks, u32 lazy) {
     using Cfg = BlockCfg<LOGB>;
     extern __shared__ __attribute__((aligned(16))) u64 lds_raw[];
 
@@ -180,91 +175,38 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) void ntt_block_kernel(
     const u32 log_nb = log_n - LOGB;  // blocks per polynomial
     const u64 pid = blk >> log_nb;
     const u32 bi = (u32)(blk & ((1ull << log_nb) - 1));
-    const u32 limb = (u32)(pid % L);
-    const NttPrime *__restrict__ P = primes + limb;
+    const A ar(primes + (u32)(pid % L));
     const u32 n = 1u << log_n;
     const u32 eblk = bi << LOGB;
     u64 *__restrict__ gptr = data + pid * n + eblk;
     u64 *__restrict__ lds = lds_raw + (size_t)sub * Cfg::LDS_WORDS;
 
-    u64 x[16];
-#if defined(PFHE_DIRECT_IO)
-    if constexpr (!INV) {
-        block_forward<LOGB, LAZY>(x, gptr, lds, P, n, eblk, lt, valid);
-    } else {
-        block_inverse<LOGB, LAZY>(x, gptr, lds, P, n, eblk, lt, valid, log_n == LOGB);
-    }
-#else
     // all global traffic as 16-byte vectors in natural order (1 KiB per wave instruction), staged
     // through LDS into / out of the register layouts of the first / last register pass
     u64x2 io[8];
-    if (valid) load_block_vectors<LOGB>(io, gptr, lt);
+    if (valid) {
+        load_block_vectors<LOGB>(io, gptr, lt);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) io[j] = u64x2{0, 0};
+    }
     lds_put_vectors<LOGB>(io, lds, lt);
     __syncthreads();
+    u64 x[16];
     if constexpr (!INV) {
         lds_get_layout<LOGB - 4>(x, lds, lt);
-        block_forward_core<LOGB, LAZY, true>(x, lds, P, n, eblk, lt);
+        block_forward_core<A, LOGB>(ar, x, lds, n, eblk, lt, lazy != 0);
         __syncthreads();
         lds_put_layout<0>(x, lds, lt);
     } else {
         lds_get_layout<0>(x, lds, lt);
-        block_inverse_core<LOGB, LAZY, true>(x, lds, P, n, eblk, lt, log_n == LOGB);
+        block_inverse_core<A, LOGB>(ar, x, lds, n, eblk, lt, log_n == LOGB, lazy != 0);
         __syncthreads();
         lds_put_layout<LOGB - 4>(x, lds, lt);
     }
     __syncthreads();
     lds_get_vectors<LOGB>(io, lds, lt);
     if (valid) store_block_vectors<LOGB>(io, gptr, lt);
-#endif
-}
-
-// ------------------------------------------------------------------------------------------
-// persistent block pass (LOGB >= 12): a workgroup loops over blocks; all global traffic is
-// 16-byte coalesced (staged through LDS in natural order) and the NEXT block's input is
-// prefetched into registers while the current block is transformed, so HBM latency overlaps
-// the butterfly arithmetic instead of being exposed once per workgroup.
-// ------------------------------------------------------------------------------------------
-template <int LOGB, bool INV, bool LAZY>
-__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS, (LOGB == 12 ? 3 : 1)) void ntt_block_persistent_kernel(
-    u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L, u32 log_n, u64 total_blocks) {
-    using Cfg = BlockCfg<LOGB>;
-    static_assert(Cfg::BPW == 1, "persistent variant is for one block per workgroup");
-    extern __shared__ __attribute__((aligned(16))) u64 lds[];
-    const u32 lt = threadIdx.x;
-    const u32 log_nb = log_n - LOGB;
-    const u32 n = 1u << log_n;
-    u64 blk = blockIdx.x;
-    if (blk >= total_blocks) return;
-    u64x2 io[8];
-    load_block_vectors<LOGB>(io, data + (blk << LOGB), lt);
-    for (; blk < total_blocks; blk += gridDim.x) {
-        const u64 pid = blk >> log_nb;
-        const u32 eblk = (u32)(blk & ((1ull << log_nb) - 1)) << LOGB;
-        const NttPrime *__restrict__ P = primes + (u32)(pid % L);
-        u64 *__restrict__ gptr = data + (blk << LOGB);
-        __syncthreads();  // previous iteration's LDS readers are done
-        lds_put_vectors<LOGB>(io, lds, lt);
-        __syncthreads();
-        u64 next = blk + gridDim.x;
-        if (next >= total_blocks) next = blk;  // last iteration: harmless re-read, keeps the prefetch unconditional
-        load_block_vectors<LOGB>(io, data + (next << LOGB), lt);
-        u64 x[16];
-        if constexpr (!INV) {
-            lds_get_layout<LOGB - 4>(x, lds, lt);
-            block_forward_core<LOGB, LAZY, true>(x, lds, P, n, eblk, lt);
-            __syncthreads();
-            lds_put_layout<0>(x, lds, lt);
-        } else {
-            lds_get_layout<0>(x, lds, lt);
-            block_inverse_core<LOGB, LAZY, true>(x, lds, P, n, eblk, lt, log_n == LOGB);
-            __syncthreads();
-            lds_put_layout<LOGB - 4>(x, lds, lt);
-        }
-        __syncthreads();
-        u64x2 out[8];
-        lds_get_vectors<LOGB>(out, lds, lt);
-        store_block_vectors<LOGB>(out, gptr, lt);
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -272,41 +214,18 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS, (LOGB == 12 ? 3 : 1)) void
 // ------------------------------------------------------------------------------------------
 namespace {
 
-int device_cu_count() {
-    static thread_local int cached[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (cached[dev] == 0) {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        cached[dev] = cus;
-    }
-    return cached[dev];
-}
-
-template <int LOGB, bool INV, bool LAZY>
-int launch_block(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys, hipStream_t s) {
+template <class A, int LOGB, bool INV>
+int launch_block(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys, bool lazy, hipStream_t s) {
     using Cfg = BlockCfg<LOGB>;
     const u64 total_blocks = npolys << (log_n - LOGB);
-    u64 grid = (total_blocks + Cfg::BPW - 1) / Cfg::BPW;
+    const u64 grid = (total_blocks + Cfg::BPW - 1) / Cfg::BPW;
     if (grid == 0) return PFHE_OK;
-    constexpr size_t lds_bytes = (size_t)Cfg::BPW * Cfg::LDS_WORDS * sizeof(u64);
-#if defined(PFHE_NO_PERSISTENT)
-    constexpr bool kPersistent = false;
-#else
-    constexpr bool kPersistent = LOGB >= 12;
-#endif
-    if constexpr (kPersistent) {
-        // resident workgroups per CU are bounded by LDS (160 KiB); loop over the rest
-        const u64 per_cu = std::max<u64>(1, (160 * 1024) / lds_bytes);
-        grid = std::min<u64>(grid, (u64)device_cu_count() * per_cu);
-    }
     if (grid > 0x7fffffffull) {
         set_last_error("batch too large for one launch");
         return PFHE_ERR_BAD_LENGTH;
     }
-    auto kern = kPersistent ? ntt_block_persistent_kernel<LOGB < 12 ? 12 : LOGB, INV, LAZY>
-                            : ntt_block_kernel<LOGB, INV, LAZY>;
+    constexpr size_t lds_bytes = (size_t)Cfg::BPW * Cfg::LDS_WORDS * sizeof(u64);
+    auto kern = ntt_block_kernel<A, LOGB, INV>;
     if (lds_bytes > 64 * 1024) {
         static thread_local bool configured[64] = {};
         int dev = 0;
@@ -318,18 +237,18 @@ int launch_block(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys
         }
     }
     hipLaunchKernelGGL(kern, dim3((u32)grid), dim3(Cfg::THREADS), lds_bytes, s, data, primes, L, log_n,
-                       total_blocks);
+                       total_blocks, lazy ? 1u : 0u);
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
 }
 
-template <bool INV, bool LAZY>
-int dispatch_block(int logb, u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys,
+template <class A, bool INV>
+int dispatch_block(int logb, u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys, bool lazy,
                    hipStream_t s) {
     switch (logb) {
 #define PFHE_CASE(B) \
     case B:          \
-        return launch_block<B, INV, LAZY>(data, primes, L, log_n, npolys, s);
+        return launch_block<A, B, INV>(data, primes, L, log_n, npolys, lazy, s);
         PFHE_CASE(4) PFHE_CASE(5) PFHE_CASE(6) PFHE_CASE(7) PFHE_CASE(8) PFHE_CASE(9) PFHE_CASE(10)
         PFHE_CASE(11) PFHE_CASE(12) PFHE_CASE(13) PFHE_CASE(14)
 #undef PFHE_CASE
@@ -338,8 +257,8 @@ int dispatch_block(int logb, u64 *data, const NttPrime *primes, u32 L, u32 log_n
     return PFHE_ERR_UNSUPPORTED;
 }
 
-template <int K, int VEC, bool INV, bool FINAL, bool LAZY>
-int launch_strided(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u32 log_s, u64 npolys,
+template <class A, int K, int VEC, bool INV, bool FINAL>
+int launch_strided(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u32 log_s, u64 npolys, bool lazy,
                    hipStream_t s) {
     const u64 total = (npolys << (log_n - K)) >> (VEC == 2 ? 1 : 0);
     const u64 grid = (total + 255) / 256;
@@ -348,24 +267,53 @@ int launch_strided(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u32 log_
         set_last_error("batch too large for one launch");
         return PFHE_ERR_BAD_LENGTH;
     }
-    hipLaunchKernelGGL((ntt_strided_kernel<K, VEC, INV, FINAL, LAZY>), dim3((u32)grid), dim3(256), 0, s,
-                       data, primes, L, log_n, log_s, total);
+    hipLaunchKernelGGL((ntt_strided_kernel<A, K, VEC, INV, FINAL>), dim3((u32)grid), dim3(256), 0, s, data, primes,
+                       L, log_n, log_s, total, lazy ? 1u : 0u);
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
 }
 
-template <bool INV, bool FINAL, bool LAZY>
-int dispatch_strided(int k, u64 *data, const NttPrime *primes, u32 L, u32 log_n, u32 log_s, u64 npolys,
+template <class A, bool INV, bool FINAL>
+int dispatch_strided(int k, u64 *data, const NttPrime *primes, u32 L, u32 log_n, u32 log_s, u64 npolys, bool lazy,
                      hipStream_t s) {
     switch (k) {
-        case 1: return launch_strided<1, 2, INV, FINAL, LAZY>(data, primes, L, log_n, log_s, npolys, s);
-        case 2: return launch_strided<2, 2, INV, FINAL, LAZY>(data, primes, L, log_n, log_s, npolys, s);
-        case 3: return launch_strided<3, 2, INV, FINAL, LAZY>(data, primes, L, log_n, log_s, npolys, s);
-        case 4: return launch_strided<4, 2, INV, FINAL, LAZY>(data, primes, L, log_n, log_s, npolys, s);
-        case 5: return launch_strided<5, 1, INV, FINAL, LAZY>(data, primes, L, log_n, log_s, npolys, s);
+        case 1: return launch_strided<A, 1, 2, INV, FINAL>(data, primes, L, log_n, log_s, npolys, lazy, s);
+        case 2: return launch_strided<A, 2, 2, INV, FINAL>(data, primes, L, log_n, log_s, npolys, lazy, s);
+        case 3: return launch_strided<A, 3, 2, INV, FINAL>(data, primes, L, log_n, log_s, npolys, lazy, s);
+        case 4: return launch_strided<A, 4, 2, INV, FINAL>(data, primes, L, log_n, log_s, npolys, lazy, s);
+        case 5: return launch_strided<A, 5, 1, INV, FINAL>(data, primes, L, log_n, log_s, npolys, lazy, s);
     }
     set_last_error("unsupported strided radix");
     return PFHE_ERR_UNSUPPORTED;
+}
+
+int launch_tiny(bool inverse, const NttPrime *primes, u32 L, u32 log_n, u64 *data, u64 npolys, bool lazy,
+                hipStream_t s) {
+    if (log_n == 0 || npolys == 0) return PFHE_OK;
+    const dim3 g((u32)((npolys + 255) / 256)), t(256);
+    if (inverse) hipLaunchKernelGGL(ntt_tiny_kernel<true>, g, t, 0, s, data, primes, L, log_n, npolys, lazy ? 1u : 0u);
+    else hipLaunchKernelGGL(ntt_tiny_kernel<false>, g, t, 0, s, data, primes, L, log_n, npolys, lazy ? 1u : 0u);
+    PFHE_HIP(hipGetLastError());
+    return PFHE_OK;
+}
+
+// one pass of the plan, in execution order (forward: strided passes then block; inverse: block
+// then strided passes, the last of which carries the fused final stage)
+template <class A>
+int run_pass(const NttPlan &plan, const NttPrime *primes, u32 L, u32 log_n, u64 *data, u64 npolys, bool inverse,
+             int index, bool lazy, hipStream_t s) {
+    const int block_at = inverse ? 0 : plan.n_strided;
+    if (index == block_at) {
+        return inverse ? dispatch_block<A, true>(plan.block_log, data, primes, L, log_n, npolys, lazy, s)
+                       : dispatch_block<A, false>(plan.block_log, data, primes, L, log_n, npolys, lazy, s);
+    }
+    const int i = inverse ? plan.n_strided - index : index;  // index into plan.strided (forward order)
+    u32 log_s = log_n;
+    for (int j = 0; j <= i; ++j) log_s -= plan.strided[j];
+    const int k = plan.strided[i];
+    if (!inverse) return dispatch_strided<A, false, false>(k, data, primes, L, log_n, log_s, npolys, false, s);
+    if (i == 0) return dispatch_strided<A, true, true>(k, data, primes, L, log_n, log_s, npolys, lazy, s);
+    return dispatch_strided<A, true, false>(k, data, primes, L, log_n, log_s, npolys, false, s);
 }
 
 }  // namespace
@@ -392,53 +340,6 @@ NttPlan make_ntt_plan(u32 log_n) {
     return p;
 }
 
-template <bool LAZY>
-static int forward_impl(const NttPrime *primes, u32 L, u32 log_n, u64 *data, u64 npolys, hipStream_t s) {
-    const NttPlan plan = make_ntt_plan(log_n);
-    if (plan.tiny) {
-        if (log_n == 0 || npolys == 0) return PFHE_OK;
-        hipLaunchKernelGGL((ntt_tiny_kernel<false, LAZY>), dim3((u32)((npolys + 255) / 256)), dim3(256), 0, s,
-                           data, primes, L, log_n, npolys);
-        PFHE_HIP(hipGetLastError());
-        return PFHE_OK;
-    }
-    // forward: strided passes first (largest distances), block pass last
-    u32 top = log_n;  // bits [top-1 ...] still to be processed
-    for (int i = 0; i < plan.n_strided; ++i) {
-        const int k = plan.strided[i];
-        const u32 log_s = top - k;
-        PFHE_TRY((dispatch_strided<false, false, false>(k, data, primes, L, log_n, log_s, npolys, s)));
-        top = log_s;
-    }
-    return dispatch_block<false, LAZY>(plan.block_log, data, primes, L, log_n, npolys, s);
-}
-
-template <bool LAZY>
-static int inverse_impl(const NttPrime *primes, u32 L, u32 log_n, u64 *data, u64 npolys, hipStream_t s) {
-    const NttPlan plan = make_ntt_plan(log_n);
-    if (plan.tiny) {
-        if (log_n == 0 || npolys == 0) return PFHE_OK;
-        hipLaunchKernelGGL((ntt_tiny_kernel<true, LAZY>), dim3((u32)((npolys + 255) / 256)), dim3(256), 0, s,
-                           data, primes, L, log_n, npolys);
-        PFHE_HIP(hipGetLastError());
-        return PFHE_OK;
-    }
-    PFHE_TRY((dispatch_block<true, LAZY>(plan.block_log, data, primes, L, log_n, npolys, s)));
-    u32 log_s = (u32)plan.block_log;
-    for (int i = plan.n_strided - 1; i >= 0; --i) {
-        const int k = plan.strided[i];
-        const bool final_pass = (i == 0);
-        if (final_pass) {
-            PFHE_TRY((dispatch_strided<true, true, LAZY>(k, data, primes, L, log_n, log_s, npolys, s)));
-        } else {
-            PFHE_TRY((dispatch_strided<true, false, false>(k, data, primes, L, log_n, log_s, npolys, s)));
-        }
-        log_s += k;
-    }
-    return PFHE_OK;
-}
-
-// Profiling hooks: run / name ONE pass of the plan (pass order is execution order).
 int ntt_num_passes(u32 log_n) {
     const NttPlan plan = make_ntt_plan(log_n);
     return plan.tiny ? 1 : plan.n_strided + 1;
@@ -459,39 +360,30 @@ void ntt_pass_name(u32 log_n, bool inverse, int index, char *buf, size_t cap) {
     }
 }
 
-int ntt_pass_dev(const NttPrime *primes, u32 L, u32 log_n, u64 *data, u64 npolys, bool inverse, int index,
+int ntt_pass_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u64 *data, u64 npolys, bool inverse, int index,
                  bool lazy, hipStream_t s) {
     const NttPlan plan = make_ntt_plan(log_n);
     if (index < 0 || index >= ntt_num_passes(log_n)) return PFHE_ERR_BAD_ARGUMENT;
-    if (plan.tiny) return inverse ? ntt_inverse_dev(primes, L, log_n, data, npolys, lazy, s)
-                                  : ntt_forward_dev(primes, L, log_n, data, npolys, lazy, s);
-    const int block_at = inverse ? 0 : plan.n_strided;
-    if (index == block_at) {
-        if (inverse) return lazy ? dispatch_block<true, true>(plan.block_log, data, primes, L, log_n, npolys, s)
-                                 : dispatch_block<true, false>(plan.block_log, data, primes, L, log_n, npolys, s);
-        return lazy ? dispatch_block<false, true>(plan.block_log, data, primes, L, log_n, npolys, s)
-                    : dispatch_block<false, false>(plan.block_log, data, primes, L, log_n, npolys, s);
-    }
-    const int i = inverse ? plan.n_strided - index : index;  // index into plan.strided (forward order)
-    u32 log_s = log_n;
-    for (int j = 0; j <= i; ++j) log_s -= plan.strided[j];
-    const int k = plan.strided[i];
-    if (!inverse) return dispatch_strided<false, false, false>(k, data, primes, L, log_n, log_s, npolys, s);
-    if (i == 0) return lazy ? dispatch_strided<true, true, true>(k, data, primes, L, log_n, log_s, npolys, s)
-                            : dispatch_strided<true, true, false>(k, data, primes, L, log_n, log_s, npolys, s);
-    return dispatch_strided<true, false, false>(k, data, primes, L, log_n, log_s, npolys, s);
+    if (plan.tiny) return launch_tiny(inverse, primes, L, log_n, data, npolys, lazy, s);
+    return pm ? run_pass<PmArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s)
+              : run_pass<ShoupArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s);
 }
 
-int ntt_forward_dev(const NttPrime *primes, u32 L, u32 log_n, u64 *data, u64 npolys, bool lazy,
-                    hipStream_t s) {
-    return lazy ? forward_impl<true>(primes, L, log_n, data, npolys, s)
-                : forward_impl<false>(primes, L, log_n, data, npolys, s);
+static int transform(const NttPrime *primes, u32 L, u32 log_n, bool pm, u64 *data, u64 npolys, bool inverse,
+                     bool lazy, hipStream_t s) {
+    const int passes = ntt_num_passes(log_n);
+    for (int i = 0; i < passes; ++i) PFHE_TRY(ntt_pass_dev(primes, L, log_n, pm, data, npolys, inverse, i, lazy, s));
+    return PFHE_OK;
 }
 
-int ntt_inverse_dev(const NttPrime *primes, u32 L, u32 log_n, u64 *data, u64 npolys, bool lazy,
+int ntt_forward_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u64 *data, u64 npolys, bool lazy,
                     hipStream_t s) {
-    return lazy ? inverse_impl<true>(primes, L, log_n, data, npolys, s)
-                : inverse_impl<false>(primes, L, log_n, data, npolys, s);
+    return transform(primes, L, log_n, pm, data, npolys, false, lazy, s);
+}
+
+int ntt_inverse_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u64 *data, u64 npolys, bool lazy,
+                    hipStream_t s) {
+    return transform(primes, L, log_n, pm, data, npolys, true, lazy, s);
 }
 
 }  // namespace pfhe

@@ -17,52 +17,135 @@ struct NttPlan {
 };
 NttPlan make_ntt_plan(u32 log_n);
 
-int ntt_forward_dev(const NttPrime *primes, u32 L, u32 log_n, u64 *data, u64 npolys, bool lazy,
+// `pm` selects the pseudo-Mersenne arithmetic (every prime of the table qualifies, NttPrime::pm_k)
+int ntt_forward_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u64 *data, u64 npolys, bool lazy,
                     hipStream_t s);
-int ntt_inverse_dev(const NttPrime *primes, u32 L, u32 log_n, u64 *data, u64 npolys, bool lazy,
+int ntt_inverse_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u64 *data, u64 npolys, bool lazy,
                     hipStream_t s);
 
 int ntt_num_passes(u32 log_n);
 void ntt_pass_name(u32 log_n, bool inverse, int index, char *buf, size_t cap);
-int ntt_pass_dev(const NttPrime *primes, u32 L, u32 log_n, u64 *data, u64 npolys, bool inverse, int index,
-                 bool lazy, hipStream_t s);
+int ntt_pass_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u64 *data, u64 npolys, bool inverse,
+                 int index, bool lazy, hipStream_t s);
 
 #if defined(__HIPCC__)
 
-// Twiddle tables are reached through a pointer stored in NttPrime, which the compiler would treat
-// as a generic (flat) pointer: flat loads tick both vmcnt and lgkmcnt and serialise against LDS
-// traffic and prefetches.  Reading them through an explicit global-address-space pointer yields
-// plain global_load_dwordx4.
+// Tables are reached through pointers stored in NttPrime, which the compiler would treat as
+// generic (flat) pointers: flat loads tick both vmcnt and lgkmcnt and serialise against LDS
+// traffic.  Reading through explicit global-address-space pointers yields plain global_load.
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));
-typedef const u64x2 __attribute__((address_space(1))) *TwPtr;
-__device__ __forceinline__ TwPtr tw_global(const ulonglong2 *p) { return (TwPtr)(const void *)p; }
+typedef const u64x2 __attribute__((address_space(1))) *GCVec2Ptr;
+typedef u64x2 __attribute__((address_space(1))) *GVec2Ptr;
+typedef const u64 __attribute__((address_space(1))) *GCWordPtr;
+
+// x mod m for x < 2m, using the borrow of the subtraction as the select condition
+__device__ __forceinline__ u64 csub(u64 x, u64 m) {
+    u64 d;
+    const bool borrow = __builtin_usubll_overflow(x, m, &d);
+    return borrow ? x : d;
+}
+
+// ------------------------------------------------------------------------------------------
+// Arithmetic policies.  Both provide w*y mod q in [0,2q) for any y < 2^63 ("lazy multiply"), which
+// is all the Harvey / Gentleman-Sande butterflies need (scalar/arithmetic.rs:32-79).
+//
+// ShoupArith — any prime q < 2^62: the reference's own scheme, ShoupFactor / mul_mod_lazy
+//   (primus_factor/src/shoup_factor/mod.rs:124-131): 10 32-bit multiplies per product.
+// PmArith — primes of the shape q = 2^K - c with 40 <= K <= 61 and c < 2^(K-33) (every
+//   "largest NTT-friendly prime below a power of two", incl. the reference's 50/60-bit test
+//   moduli): 2^K = c (mod q), so the 128-bit product is folded twice with the small constant c:
+//   7 multiplies, no precomputed quotient (8-byte twiddles).  Exact integer arithmetic: canonical
+//   outputs are identical to the Shoup path's, lazy outputs agree mod q.
+// ------------------------------------------------------------------------------------------
+struct ShoupArith {
+    struct Tw {
+        u64 w, wp;
+    };
+    u64 q, two_q;
+    GCVec2Ptr fwd, inv;
+    u64 inv_n, inv_n_p, inv_n_w, inv_n_w_p;
+
+    __device__ __forceinline__ explicit ShoupArith(const NttPrime *__restrict__ P)
+        : q(P->q), two_q(P->two_q), fwd((GCVec2Ptr)(const void *)P->fwd), inv((GCVec2Ptr)(const void *)P->inv),
+          inv_n(P->inv_n), inv_n_p(P->inv_n_p), inv_n_w(P->inv_n_w), inv_n_w_p(P->inv_n_w_p) {}
+    __device__ __forceinline__ Tw fwd_tw(u32 i) const {
+        const u64x2 v = fwd[i];
+        return Tw{v.x, v.y};
+    }
+    __device__ __forceinline__ Tw inv_tw(u32 i) const {
+        const u64x2 v = inv[i];
+        return Tw{v.x, v.y};
+    }
+    __device__ __forceinline__ Tw tw_inv_n() const { return Tw{inv_n, inv_n_p}; }
+    __device__ __forceinline__ Tw tw_inv_n_w() const { return Tw{inv_n_w, inv_n_w_p}; }
+    __device__ __forceinline__ u64 mul_lazy(u64 y, Tw t) const { return t.w * y - q * mulhi64(t.wp, y); }
+};
+
+struct PmArith {
+    struct Tw {
+        u64 w;
+    };
+    u64 q, two_q;
+    GCWordPtr fwd, inv;
+    u64 inv_n, inv_n_w;
+    u32 c, sh;  // q = 2^K - c, sh = K - 32
+    u32 mask;   // 2^(K-32) - 1
+
+    __device__ __forceinline__ explicit PmArith(const NttPrime *__restrict__ P)
+        : q(P->q), two_q(P->two_q), fwd((GCWordPtr)(const void *)P->fwd_w), inv((GCWordPtr)(const void *)P->inv_w),
+          inv_n(P->inv_n), inv_n_w(P->inv_n_w), c((u32)P->pm_c), sh(P->pm_k - 32), mask((1u << (P->pm_k - 32)) - 1) {}
+    __device__ __forceinline__ Tw fwd_tw(u32 i) const { return Tw{fwd[i]}; }
+    __device__ __forceinline__ Tw inv_tw(u32 i) const { return Tw{inv[i]}; }
+    __device__ __forceinline__ Tw tw_inv_n() const { return Tw{inv_n}; }
+    __device__ __forceinline__ Tw tw_inv_n_w() const { return Tw{inv_n_w}; }
+    // P = w*y < 2^(K+63); P = phi*2^K + plo == phi*c + plo =: R < 2^(K+33); R = rh*2^K + rl == rh*c + rl
+    // < 2^K + 2^32*c < 2q.  All partial sums fit 64 bits for y < 2^63, w < 2^K <= 2^61, c < 2^(K-33).
+    __device__ __forceinline__ u64 mul_lazy(u64 y, Tw t) const {
+        const u32 y0 = (u32)y, y1 = (u32)(y >> 32), w0 = (u32)t.w, w1 = (u32)(t.w >> 32);
+        const u64 lo = (u64)w0 * y0;
+        u64 mid = (u64)w0 * y1 + (lo >> 32);
+        mid += (u64)w1 * y0;
+        const u64 hi = (u64)w1 * y1 + (mid >> 32);
+        const u32 l0 = (u32)lo, l1 = (u32)mid, h0 = (u32)hi, h1 = (u32)(hi >> 32);
+        const u32 f0 = __builtin_amdgcn_alignbit(h0, l1, sh);  // (P >> K) low word
+        const u32 f1 = __builtin_amdgcn_alignbit(h1, h0, sh);  // (P >> K) high word
+        const u64 plo = ((u64)(l1 & mask) << 32) | l0;
+        const u64 a = (u64)f0 * c + plo;
+        const u64 b = (u64)f1 * c + (a >> 32);
+        const u32 rh = __builtin_amdgcn_alignbit((u32)(b >> 32), (u32)b, sh);
+        const u64 rl = ((u64)((u32)b & mask) << 32) | (u32)a;
+        return (u64)rh * c + rl;
+    }
+};
 
 // Harvey forward butterfly, values in [0,4q) — scalar/arithmetic.rs:43-59
-__device__ __forceinline__ void fwd_bfly(u64 &x, u64 &y, u64 w, u64 wp, u64 q, u64 two_q) {
-    const u64 tx = reduce_once(x, two_q);
-    const u64 t = mul_shoup_lazy(y, w, wp, q);
+template <class A>
+__device__ __forceinline__ void fwd_bfly(const A &ar, u64 &x, u64 &y, typename A::Tw w) {
+    const u64 tx = csub(x, ar.two_q);
+    const u64 t = ar.mul_lazy(y, w);
     x = tx + t;
-    y = tx + two_q - t;
+    y = tx + ar.two_q - t;
 }
 
 // Gentleman-Sande inverse butterfly, values in [0,2q) — scalar/arithmetic.rs:63-79
-__device__ __forceinline__ void inv_bfly(u64 &x, u64 &y, u64 w, u64 wp, u64 q, u64 two_q) {
+template <class A>
+__device__ __forceinline__ void inv_bfly(const A &ar, u64 &x, u64 &y, typename A::Tw w) {
     const u64 tx = x + y;
-    const u64 ty = x + two_q - y;
-    x = reduce_once(tx, two_q);
-    y = mul_shoup_lazy(ty, w, wp, q);
+    const u64 ty = x + ar.two_q - y;
+    x = csub(tx, ar.two_q);
+    y = ar.mul_lazy(ty, w);
 }
 
 // last inverse stage fused with N^-1 (x) and N^-1*w (y) — scalar/transform.rs:283-318
-template <bool LAZY>
-__device__ __forceinline__ void inv_final_bfly(u64 &x, u64 &y, const NttPrime &P) {
-    const u64 tx = reduce_once(x + y, P.two_q);
-    const u64 ty = x + P.two_q - y;
-    u64 rx = mul_shoup_lazy(tx, P.inv_n, P.inv_n_p, P.q);
-    u64 ry = mul_shoup_lazy(ty, P.inv_n_w, P.inv_n_w_p, P.q);
-    if (!LAZY) {
-        rx = reduce_once(rx, P.q);
-        ry = reduce_once(ry, P.q);
+template <class A>
+__device__ __forceinline__ void inv_final_bfly(const A &ar, u64 &x, u64 &y, bool lazy) {
+    const u64 tx = csub(x + y, ar.two_q);
+    const u64 ty = x + ar.two_q - y;
+    u64 rx = ar.mul_lazy(tx, ar.tw_inv_n());
+    u64 ry = ar.mul_lazy(ty, ar.tw_inv_n_w());
+    if (!lazy) {
+        rx = csub(rx, ar.q);
+        ry = csub(ry, ar.q);
     }
     x = rx;
     y = ry;
@@ -72,10 +155,10 @@ template <int LOGB>
 struct BlockCfg {
     static_assert(LOGB >= 4 && LOGB <= 14, "block pass handles 2^4 .. 2^14 coefficients");
     static constexpr int B = 1 << LOGB;
-    static constexpr int TPB = B / 16;                      // threads per block of coefficients
-    static constexpr int THREADS = TPB > 256 ? TPB : 256;   // workgroup size
-    static constexpr int BPW = THREADS / TPB;               // coefficient blocks per workgroup
-    static constexpr int LDS_WORDS = B + B / 8;             // 16 words + 2 words of padding
+    static constexpr int TPB = B / 16;                     // threads per block of coefficients
+    static constexpr int THREADS = TPB > 256 ? TPB : 256;  // workgroup size
+    static constexpr int BPW = THREADS / TPB;              // coefficient blocks per workgroup
+    static constexpr int LDS_WORDS = B + B / 8;            // 16 words + 2 words of padding
 };
 
 // padded LDS index of block-local element e: every 16 words are followed by 2 pad words, which
@@ -101,174 +184,135 @@ __device__ __forceinline__ u32 maybe_uniform(u32 v) {
     }
 }
 
-// forward stages on register bits JHI..JLO (element bits POS+JHI .. POS+JLO)
-template <int POS, int JHI, int JLO, bool UNIFORM>
-__device__ __forceinline__ void fwd_regpass(u64 (&x)[16], TwPtr tw, u32 n_plus_e,
-                                            u64 q, u64 two_q) {
+// forward stages on register bits JHI..JLO (element bits POS+JHI .. POS+JLO); twiddle of the
+// butterfly at global element E, distance 2^p: fwd[(N + E) >> (p + 1)]
+template <class A, int POS, int JHI, int JLO, bool UNIFORM>
+__device__ __forceinline__ void fwd_regpass(const A &ar, u64 (&x)[16], u32 n_plus_e) {
 #pragma unroll
     for (int j = JHI; j >= JLO; --j) {
         const u32 base = maybe_uniform<POS, UNIFORM>(n_plus_e >> (POS + j + 1));
 #pragma unroll
         for (int u = 0; u < (16 >> (j + 1)); ++u) {
-#if defined(PFHE_ABL_CONST_TW)
-            const u64x2 w = u64x2{q - 12345 - u, two_q + base};
-#else
-            const u64x2 w = tw[base + u];
-#endif
-#if !defined(PFHE_ABL_NO_MATH)
+            const typename A::Tw w = ar.fwd_tw(base + u);
 #pragma unroll
             for (int v = 0; v < (1 << j); ++v) {
                 const int k0 = (u << (j + 1)) | v, k1 = k0 | (1 << j);
-                fwd_bfly(x[k0], x[k1], w.x, w.y, q, two_q);
+                fwd_bfly(ar, x[k0], x[k1], w);
             }
-#else
-            x[u] += w.x;
-#endif
         }
     }
 }
 
-// inverse stages on register bits JLO..JHI; when `final_stage` the top stage (j == JHI) is the
-// last stage of the whole transform.
-template <int POS, int JLO, int JHI, bool UNIFORM, bool LAZY>
-__device__ __forceinline__ void inv_regpass(u64 (&x)[16], const NttPrime *__restrict__ P, u32 n, u32 e_abs,
-                                            u64 q, u64 two_q, bool final_stage) {
-    const TwPtr tw = tw_global(P->inv);
+// inverse stages on register bits JLO..JHI: inv[1 + N - (N >> p) + (E >> (p + 1))]; when
+// `final_stage` the top stage (j == JHI) is the last stage of the whole transform.
+template <class A, int POS, int JLO, int JHI, bool UNIFORM>
+__device__ __forceinline__ void inv_regpass(const A &ar, u64 (&x)[16], u32 n, u32 e_abs, bool final_stage,
+                                            bool lazy) {
 #pragma unroll
     for (int j = JLO; j <= JHI; ++j) {
         const u32 p = POS + j;
         if (j == JHI && final_stage) {
-            const NttPrime PP = *P;
 #pragma unroll
-            for (int v = 0; v < 8; ++v) inv_final_bfly<LAZY>(x[v], x[v | 8], PP);
+            for (int v = 0; v < 8; ++v) inv_final_bfly(ar, x[v], x[v | 8], lazy);
         } else {
             const u32 base = maybe_uniform<POS, UNIFORM>(1 + n - (n >> p) + (e_abs >> (p + 1)));
 #pragma unroll
             for (int u = 0; u < (16 >> (j + 1)); ++u) {
-                const u64x2 w = tw[base + u];
+                const typename A::Tw w = ar.inv_tw(base + u);
 #pragma unroll
                 for (int v = 0; v < (1 << j); ++v) {
                     const int k0 = (u << (j + 1)) | v, k1 = k0 | (1 << j);
-                    inv_bfly(x[k0], x[k1], w.x, w.y, q, two_q);
+                    inv_bfly(ar, x[k0], x[k1], w);
                 }
             }
         }
     }
 }
 
-// registers (layout FROM) -> LDS -> registers (layout TO)
-template <int FROM, int TO, bool SYNC_BEFORE>
-__device__ __forceinline__ void lds_exchange(u64 (&x)[16], u64 *__restrict__ lds, u32 lt) {
-#if defined(PFHE_ABL_NO_LDS)
-    return;
-#endif
-    if constexpr (SYNC_BEFORE) __syncthreads();
+template <int POS>
+__device__ __forceinline__ void lds_get_layout(u64 (&x)[16], const u64 *__restrict__ lds, u32 lt) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) lds[lds_phi(layout<FROM>(lt, k))] = x[k];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) x[k] = lds[lds_phi(layout<TO>(lt, k))];
+    for (int k = 0; k < 16; ++k) x[k] = lds[lds_phi(layout<POS>(lt, k))];
 }
 
-template <int LOGB, int POS, bool FIRST>
-__device__ __forceinline__ void fwd_chain(u64 (&x)[16], u64 *__restrict__ lds, TwPtr tw,
-                                          u32 n, u32 eblk, u32 lt, u64 q, u64 two_q) {
+template <int POS>
+__device__ __forceinline__ void lds_put_layout(const u64 (&x)[16], u64 *__restrict__ lds, u32 lt) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[lds_phi(layout<POS>(lt, k))] = x[k];
+}
+
+// registers (layout FROM) -> LDS -> registers (layout TO); the LDS region may still be read by
+// other threads on entry, hence the leading barrier.
+template <int FROM, int TO>
+__device__ __forceinline__ void lds_exchange(u64 (&x)[16], u64 *__restrict__ lds, u32 lt) {
+    __syncthreads();
+    lds_put_layout<FROM>(x, lds, lt);
+    __syncthreads();
+    lds_get_layout<TO>(x, lds, lt);
+}
+
+template <class A, int LOGB, int POS>
+__device__ __forceinline__ void fwd_chain(const A &ar, u64 (&x)[16], u64 *__restrict__ lds, u32 n, u32 eblk, u32 lt) {
     constexpr bool UNI = BlockCfg<LOGB>::BPW == 1;
     if constexpr (POS > 0) {
         constexpr int NPOS = POS >= 4 ? POS - 4 : 0;
         constexpr int JHI = POS >= 4 ? 3 : POS - 1;
-        lds_exchange<POS, NPOS, !FIRST>(x, lds, lt);
-        fwd_regpass<NPOS, JHI, 0, UNI>(x, tw, n + eblk + layout<NPOS>(lt, 0), q, two_q);
-        fwd_chain<LOGB, NPOS, false>(x, lds, tw, n, eblk, lt, q, two_q);
+        lds_exchange<POS, NPOS>(x, lds, lt);
+        fwd_regpass<A, NPOS, JHI, 0, UNI>(ar, x, n + eblk + layout<NPOS>(lt, 0));
+        fwd_chain<A, LOGB, NPOS>(ar, x, lds, n, eblk, lt);
     }
 }
 
-// forward compute core: x holds layout<LOGB-4> on entry and layout<0> (canonical unless LAZY) on exit.
-// LDS_DIRTY: other threads may still be reading the LDS region (sync before the first write).
-template <int LOGB, bool LAZY, bool LDS_DIRTY>
-__device__ __forceinline__ void block_forward_core(u64 (&x)[16], u64 *__restrict__ lds,
-                                                   const NttPrime *__restrict__ P, u32 n, u32 eblk, u32 lt) {
+// forward compute core: x holds layout<LOGB-4> on entry and layout<0> (canonical unless lazy) on exit
+template <class A, int LOGB>
+__device__ __forceinline__ void block_forward_core(const A &ar, u64 (&x)[16], u64 *__restrict__ lds, u32 n,
+                                                   u32 eblk, u32 lt, bool lazy) {
     constexpr int POS0 = LOGB - 4;
     constexpr bool UNI = BlockCfg<LOGB>::BPW == 1;
-    const u64 q = P->q, two_q = P->two_q;
-    const TwPtr tw = tw_global(P->fwd);
-    fwd_regpass<POS0, 3, 0, UNI>(x, tw, n + eblk + layout<POS0>(lt, 0), q, two_q);
-    fwd_chain<LOGB, POS0, !LDS_DIRTY>(x, lds, tw, n, eblk, lt, q, two_q);
-    if (!LAZY) {
+    fwd_regpass<A, POS0, 3, 0, UNI>(ar, x, n + eblk + layout<POS0>(lt, 0));
+    fwd_chain<A, LOGB, POS0>(ar, x, lds, n, eblk, lt);
+    if (!lazy) {  // [0,4q) -> [0,q): scalar/transform.rs:104-116
 #pragma unroll
-        for (int k = 0; k < 16; ++k) x[k] = reduce_once(reduce_once(x[k], two_q), q);
+        for (int k = 0; k < 16; ++k) x[k] = csub(csub(x[k], ar.two_q), ar.q);
     }
 }
 
-template <int LOGB, bool LAZY>
-__device__ __forceinline__ void block_forward(u64 (&x)[16], u64 *__restrict__ gptr, u64 *__restrict__ lds,
-                                              const NttPrime *__restrict__ P, u32 n, u32 eblk, u32 lt,
-                                              bool valid) {
-    constexpr int POS0 = LOGB - 4;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) x[k] = valid ? gptr[layout<POS0>(lt, k)] : 0ull;
-    block_forward_core<LOGB, LAZY, false>(x, lds, P, n, eblk, lt);
-    if (valid) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) gptr[layout<0>(lt, k)] = x[k];
-    }
-}
-
-template <int LOGB, int POS, bool FIRST, bool LAZY>
-__device__ __forceinline__ void inv_chain(u64 (&x)[16], u64 *__restrict__ lds, const NttPrime *__restrict__ P,
-                                          u32 n, u32 eblk, u32 lt, u64 q, u64 two_q, bool final_block) {
+template <class A, int LOGB, int POS>
+__device__ __forceinline__ void inv_chain(const A &ar, u64 (&x)[16], u64 *__restrict__ lds, u32 n, u32 eblk, u32 lt,
+                                          bool final_block, bool lazy) {
     constexpr bool UNI = BlockCfg<LOGB>::BPW == 1;
     constexpr int DONE = POS + 4;  // element bits already processed
     if constexpr (DONE < LOGB) {
         constexpr int NPOS = DONE <= LOGB - 4 ? DONE : LOGB - 4;
         constexpr int JLO = DONE - NPOS;
         constexpr bool LAST = NPOS + 4 >= LOGB;
-        lds_exchange<POS, NPOS, !FIRST>(x, lds, lt);
-        inv_regpass<NPOS, JLO, 3, UNI, LAZY>(x, P, n, eblk + layout<NPOS>(lt, 0), q, two_q,
-                                             LAST && final_block);
-        inv_chain<LOGB, NPOS, false, LAZY>(x, lds, P, n, eblk, lt, q, two_q, final_block);
+        lds_exchange<POS, NPOS>(x, lds, lt);
+        inv_regpass<A, NPOS, JLO, 3, UNI>(ar, x, n, eblk + layout<NPOS>(lt, 0), LAST && final_block, lazy);
+        inv_chain<A, LOGB, NPOS>(ar, x, lds, n, eblk, lt, final_block, lazy);
     }
 }
 
-// inverse compute core: x holds layout<0> on entry and layout<LOGB-4> on exit.
-template <int LOGB, bool LAZY, bool LDS_DIRTY>
-__device__ __forceinline__ void block_inverse_core(u64 (&x)[16], u64 *__restrict__ lds,
-                                                   const NttPrime *__restrict__ P, u32 n, u32 eblk, u32 lt,
-                                                   bool final_block) {
+// inverse compute core: x holds layout<0> on entry and layout<LOGB-4> on exit
+template <class A, int LOGB>
+__device__ __forceinline__ void block_inverse_core(const A &ar, u64 (&x)[16], u64 *__restrict__ lds, u32 n,
+                                                   u32 eblk, u32 lt, bool final_block, bool lazy) {
     constexpr bool UNI = BlockCfg<LOGB>::BPW == 1;
-    const u64 q = P->q, two_q = P->two_q;
-    inv_regpass<0, 0, 3, UNI, LAZY>(x, P, n, eblk + layout<0>(lt, 0), q, two_q, LOGB == 4 && final_block);
-    inv_chain<LOGB, 0, !LDS_DIRTY, LAZY>(x, lds, P, n, eblk, lt, q, two_q, final_block);
+    inv_regpass<A, 0, 0, 3, UNI>(ar, x, n, eblk + layout<0>(lt, 0), LOGB == 4 && final_block, lazy);
+    inv_chain<A, LOGB, 0>(ar, x, lds, n, eblk, lt, final_block, lazy);
 }
 
-template <int LOGB, bool LAZY>
-__device__ __forceinline__ void block_inverse(u64 (&x)[16], u64 *__restrict__ gptr, u64 *__restrict__ lds,
-                                              const NttPrime *__restrict__ P, u32 n, u32 eblk, u32 lt,
-                                              bool valid, bool final_block) {
-    constexpr int POSL = LOGB - 4;  // layout of the last register pass
-#pragma unroll
-    for (int k = 0; k < 16; ++k) x[k] = valid ? gptr[layout<0>(lt, k)] : 0ull;
-    block_inverse_core<LOGB, LAZY, false>(x, lds, P, n, eblk, lt, final_block);
-    if (valid) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) gptr[layout<POSL>(lt, k)] = x[k];
-    }
-}
-
-// ---- coalesced block I/O through LDS (persistent kernel): 8 x 16-byte vectors per thread in
-//      natural order (vector v = elements 2v, 2v+1), one full KiB per wave instruction ----
-typedef u64x2 __attribute__((address_space(1))) *GVecPtr;
-
+// ---- coalesced block I/O: 8 x 16-byte vectors per thread in natural order (vector v = elements
+//      2v, 2v+1), one full KiB per wave instruction, staged through LDS ----
 template <int LOGB>
 __device__ __forceinline__ void load_block_vectors(u64x2 (&v)[8], const u64 *gptr, u32 lt) {
-    const TwPtr p = (TwPtr)(const void *)gptr;
+    const GCVec2Ptr p = (GCVec2Ptr)(const void *)gptr;
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = p[lt + BlockCfg<LOGB>::TPB * j];
 }
 
 template <int LOGB>
 __device__ __forceinline__ void store_block_vectors(const u64x2 (&v)[8], u64 *gptr, u32 lt) {
-    const GVecPtr p = (GVecPtr)(void *)gptr;
+    const GVec2Ptr p = (GVec2Ptr)(void *)gptr;
 #pragma unroll
     for (int j = 0; j < 8; ++j) p[lt + BlockCfg<LOGB>::TPB * j] = v[j];
 }
@@ -283,18 +327,6 @@ template <int LOGB>
 __device__ __forceinline__ void lds_get_vectors(u64x2 (&v)[8], const u64 *__restrict__ lds, u32 lt) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const u64x2 *>(lds + lds_phi(2 * (lt + BlockCfg<LOGB>::TPB * j)));
-}
-
-template <int POS>
-__device__ __forceinline__ void lds_get_layout(u64 (&x)[16], const u64 *__restrict__ lds, u32 lt) {
-#pragma unroll
-    for (int k = 0; k < 16; ++k) x[k] = lds[lds_phi(layout<POS>(lt, k))];
-}
-
-template <int POS>
-__device__ __forceinline__ void lds_put_layout(const u64 (&x)[16], u64 *__restrict__ lds, u32 lt) {
-#pragma unroll
-    for (int k = 0; k < 16; ++k) lds[lds_phi(layout<POS>(lt, k))] = x[k];
 }
 
 #endif  // __HIPCC__

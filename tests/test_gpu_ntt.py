@@ -215,3 +215,36 @@ def test_full_size_roundtrip_and_spot_checks(pf, orc):
         assert np.array_equal(to_host(x[e * L * n:(e + 1) * L * n]), ref)
     d.inverse_transform_dev(x)
     assert torch.equal(x, orig)
+
+
+@pytest.mark.parametrize("q", [Q61[0], Q61[2], 1125899906826241, 1152921504606830593, 562949953392641])
+@pytest.mark.parametrize("log_n", [4, 9, 12, 13])
+def test_pseudo_mersenne_path_equals_generic_path(pf, orc, q, log_n, monkeypatch):
+    """Primes q = 2^K - c take the PmArith kernels; PFHE_DISABLE_PM forces the generic ShoupArith
+    kernels for the same table.  Canonical outputs must be identical (and equal to the oracle),
+    lazy outputs must agree mod q."""
+    if log_n > max_log(q):
+        pytest.skip("modulus has no 2N-th root")
+    rng = np.random.default_rng(log_n + q % 1000)
+    n = 1 << log_n
+    a = rand_mod(rng, q, 3 * n)
+    a[:4] = [0, q - 1, 1, q // 2]
+    o = orc.U64NttTable(log_n, q)
+    ref = a.copy(); o.transform_slice(ref)
+    outs = []
+    for disable in (False, True):
+        if disable:
+            monkeypatch.setenv("PFHE_DISABLE_PM", "1")
+        else:
+            monkeypatch.delenv("PFHE_DISABLE_PM", raising=False)
+        t = pf.U64NttTable(log_n, q)
+        f = a.copy(); t.transform_slice(f)
+        assert np.array_equal(f, ref)
+        lz = a.copy(); t.lazy_transform_slice(lz)
+        assert lz.max() < 4 * q and np.array_equal(lz % np.uint64(q), ref)
+        lzi = ref.copy(); t.lazy_inverse_transform_slice(lzi)
+        assert lzi.max() < 2 * q and np.array_equal(lzi % np.uint64(q), a)
+        t.inverse_transform_slice(f)
+        assert np.array_equal(f, a)
+        outs.append(f)
+    assert np.array_equal(outs[0], outs[1])
