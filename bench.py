@@ -44,6 +44,9 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=4096, help="RNS polynomials per GPU (default: BASELINE config 3')")
     ap.add_argument("--ext-batch", type=int, default=1024, help="ciphertexts in the external-product leg (config 4)")
     ap.add_argument("--ext-chunk", type=int, default=0, help="ciphertexts per internal pass of the external product")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for the timing barrier "
+                    "(nccl = RCCL; gloo + --one-device lets two ranks share one GPU for a plumbing check)")
+    ap.add_argument("--one-device", action="store_true", help="debug: every rank uses cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -64,7 +67,7 @@ def cpu_baseline(seconds: float):
         oracle.use_library(oracle.build(native=True, out_dir=tmp))
     except Exception:
         oracle.build()
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     n = 1 << LOG_N
     tabs = [oracle.U64NttTable(LOG_N, q) for q in Q61]
     rng = np.random.default_rng(1)
@@ -108,12 +111,17 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback); use gpurun")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     n, L, batch = 1 << LOG_N, 3, args.batch
     words = batch * L * n
@@ -130,7 +138,8 @@ def main():
         # order) is a valid input of the next, so the timed loop needs no re-initialisation
         table.transform_dev(x)
 
-    dt = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, dist, "cuda")
+    dt = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, dist,
+                     "cuda" if args.dist_backend == "nccl" else "cpu")
 
     limb_ntts = world * batch * L * args.steps
     value = limb_ntts / dt

@@ -1,0 +1,219 @@
+// pfhe.hpp — header-only C++17 mirror of the reference's operator interface over the C ABI
+// (include/pfhe.h).  Same type names, method names and argument meaning as the Rust traits:
+//   U64NttTable   — primus_ntt::NttTable for U64NttTable   (crates/primus_ntt/src/ntt/mod.rs:16-113)
+//   U64DcrtTable  — primus_ntt::DcrtTable for U64DcrtTable (crates/primus_ntt/src/dcrt/mod.rs:19-135)
+//   RNSBase, BigUintApproxSignedBasis, DcrtGlevContext, mul_dcrt_ggsw_to
+//                 — primus_rns / primus_decompose / primus_lattice entry points of the RNS
+//                   gadget external product (crates/primus_lattice/src/glwe/crt.rs:200-227)
+// Errors: constructors throw pfhe::Error carrying the pfhe_status (the reference returns
+// Result<_, NttError>); in-place transforms throw on length mismatch where the reference
+// debug_asserts.  Slices are (pointer, length-in-words) pairs, in place, like `&mut [u64]`.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "pfhe.h"
+
+namespace pfhe {
+
+class Error : public std::runtime_error {
+  public:
+    Error(int status, const std::string &what) : std::runtime_error(what), status_(status) {}
+    int status() const noexcept { return status_; }
+
+  private:
+    int status_;
+};
+
+inline void check(int status) {
+    if (status != PFHE_OK) {
+        std::string msg = pfhe_status_string(status);
+        const char *detail = pfhe_last_error();
+        if (detail && *detail) msg += std::string(": ") + detail;
+        throw Error(status, msg);
+    }
+}
+
+class U64NttTable {
+  public:
+    U64NttTable(uint32_t log_n, uint64_t modulus, int device = 0) { check(pfhe_ntt_create(log_n, modulus, device, &h_)); }
+    ~U64NttTable() { pfhe_ntt_destroy(h_); }
+    U64NttTable(U64NttTable &&o) noexcept : h_(std::exchange(o.h_, nullptr)) {}
+    U64NttTable(const U64NttTable &) = delete;
+    U64NttTable &operator=(const U64NttTable &) = delete;
+
+    size_t poly_length() const { return pfhe_ntt_poly_length(h_); }
+    size_t n() const { return poly_length(); }
+    uint32_t log_n() const { return pfhe_ntt_log_n(h_); }
+    uint64_t modulus() const { return pfhe_ntt_modulus(h_); }
+    uint64_t root() const { return pfhe_ntt_root(h_); }
+    uint64_t inv_root() const { return pfhe_ntt_inv_root(h_); }
+    uint64_t inv_n() const { return pfhe_ntt_inv_n(h_); }
+
+    void transform_slice(uint64_t *poly, size_t len) const { check(pfhe_ntt_transform_slice(h_, poly, len)); }
+    void inverse_transform_slice(uint64_t *v, size_t len) const { check(pfhe_ntt_inverse_transform_slice(h_, v, len)); }
+    void lazy_transform_slice(uint64_t *poly, size_t len) const { check(pfhe_ntt_lazy_transform_slice(h_, poly, len)); }
+    void lazy_inverse_transform_slice(uint64_t *v, size_t len) const { check(pfhe_ntt_lazy_inverse_transform_slice(h_, v, len)); }
+    void transform_monomial(uint64_t coeff, size_t degree, uint64_t *values, size_t len) const {
+        check(pfhe_ntt_transform_monomial(h_, coeff, degree, values, len));
+    }
+    void transform_coeff_one_monomial(size_t degree, uint64_t *values, size_t len) const {
+        check(pfhe_ntt_transform_coeff_one_monomial(h_, degree, values, len));
+    }
+    void transform_coeff_minus_one_monomial(size_t degree, uint64_t *values, size_t len) const {
+        check(pfhe_ntt_transform_coeff_minus_one_monomial(h_, degree, values, len));
+    }
+    // device-resident batches (asynchronous on `stream`)
+    void transform_dev(uint64_t *poly_dev, size_t len, bool lazy = false, void *stream = nullptr) const {
+        check(pfhe_ntt_transform_dev(h_, poly_dev, len, lazy, stream));
+    }
+    void inverse_transform_dev(uint64_t *v_dev, size_t len, bool lazy = false, void *stream = nullptr) const {
+        check(pfhe_ntt_inverse_transform_dev(h_, v_dev, len, lazy, stream));
+    }
+    const pfhe_ntt *handle() const { return h_; }
+
+  private:
+    pfhe_ntt *h_ = nullptr;
+};
+
+class U64DcrtTable {
+  public:
+    U64DcrtTable(uint32_t log_n, const std::vector<uint64_t> &moduli, int device = 0) {
+        check(pfhe_dcrt_create(log_n, moduli.data(), moduli.size(), device, &h_));
+    }
+    ~U64DcrtTable() { pfhe_dcrt_destroy(h_); }
+    U64DcrtTable(U64DcrtTable &&o) noexcept : h_(std::exchange(o.h_, nullptr)) {}
+    U64DcrtTable(const U64DcrtTable &) = delete;
+    U64DcrtTable &operator=(const U64DcrtTable &) = delete;
+
+    size_t poly_length() const { return pfhe_dcrt_poly_length(h_); }
+    size_t moduli_count() const { return pfhe_dcrt_moduli_count(h_); }
+    size_t crt_poly_length() const { return pfhe_dcrt_crt_poly_length(h_); }
+    uint64_t modulus(size_t i) const { return pfhe_dcrt_modulus(h_, i); }
+
+    void transform_slice(uint64_t *poly, size_t len) const { check(pfhe_dcrt_transform_slice(h_, poly, len)); }
+    void inverse_transform_slice(uint64_t *poly, size_t len) const { check(pfhe_dcrt_inverse_transform_slice(h_, poly, len)); }
+    void lazy_transform_slice(uint64_t *poly, size_t len) const { check(pfhe_dcrt_lazy_transform_slice(h_, poly, len)); }
+    void lazy_inverse_transform_slice(uint64_t *poly, size_t len) const { check(pfhe_dcrt_lazy_inverse_transform_slice(h_, poly, len)); }
+    void transform_monomial(uint64_t coeff, size_t degree, uint64_t *values, size_t len) const {
+        check(pfhe_dcrt_transform_monomial(h_, coeff, degree, values, len));
+    }
+    void transform_dev(uint64_t *poly_dev, size_t len, bool lazy = false, void *stream = nullptr) const {
+        check(pfhe_dcrt_transform_dev(h_, poly_dev, len, lazy, stream));
+    }
+    void inverse_transform_dev(uint64_t *poly_dev, size_t len, bool lazy = false, void *stream = nullptr) const {
+        check(pfhe_dcrt_inverse_transform_dev(h_, poly_dev, len, lazy, stream));
+    }
+    // DcrtPolynomial::mul_assign / add_mul_assign (crates/primus_poly/src/dcrt/mul.rs:176, mod.rs:105)
+    void mul_assign_dev(uint64_t *a, size_t len_a, const uint64_t *b, size_t len_b, void *stream = nullptr) const {
+        check(pfhe_dcrt_mul_assign_dev(h_, a, len_a, b, len_b, stream));
+    }
+    void add_mul_assign_dev(uint64_t *acc, const uint64_t *a, size_t len_a, const uint64_t *b, size_t len_b,
+                            void *stream = nullptr) const {
+        check(pfhe_dcrt_add_mul_assign_dev(h_, acc, a, len_a, b, len_b, stream));
+    }
+    // CrtRlwe::mul_dcrt_polynomial_to + into_coeff_form (crates/primus_lattice/src/rlwe/crt.rs:42-65)
+    void mul_dcrt_polynomial_dev(uint64_t *crt_poly, size_t len, const uint64_t *dcrt_poly, size_t len_b,
+                                 void *stream = nullptr) const {
+        check(pfhe_dcrt_mul_dcrt_polynomial_dev(h_, crt_poly, len, dcrt_poly, len_b, stream));
+    }
+    const pfhe_dcrt *handle() const { return h_; }
+
+  private:
+    pfhe_dcrt *h_ = nullptr;
+};
+
+class RNSBase {
+  public:
+    explicit RNSBase(const std::vector<uint64_t> &moduli, int device = 0) {
+        check(pfhe_rns_create(moduli.data(), moduli.size(), device, &h_));
+    }
+    ~RNSBase() { pfhe_rns_destroy(h_); }
+    RNSBase(const RNSBase &) = delete;
+    RNSBase &operator=(const RNSBase &) = delete;
+    size_t moduli_count() const { return pfhe_rns_moduli_count(h_); }
+    size_t big_uint_value_len() const { return pfhe_rns_big_uint_value_len(h_); }
+    std::vector<uint64_t> moduli_product() const {
+        std::vector<uint64_t> q(big_uint_value_len());
+        check(pfhe_rns_moduli_product(h_, q.data(), q.size()));
+        return q;
+    }
+    void compose_multiple_values_to(const uint64_t *multi_residues, size_t len_in, uint64_t *big_uint_values,
+                                    size_t len_out, size_t value_count) const {
+        check(pfhe_rns_compose_multiple_values_to(h_, multi_residues, len_in, big_uint_values, len_out, value_count));
+    }
+    void wrapping_decompose_small_values_to(const uint64_t *small_values, size_t value_count, uint64_t *multi_residues,
+                                            size_t len_out, uint64_t small_value_modulus) const {
+        check(pfhe_rns_wrapping_decompose_small_values_to(h_, small_values, value_count, multi_residues, len_out,
+                                                          small_value_modulus));
+    }
+    const pfhe_rns *handle() const { return h_; }
+
+  private:
+    pfhe_rns *h_ = nullptr;
+};
+
+class BigUintApproxSignedBasis {
+  public:
+    BigUintApproxSignedBasis(const RNSBase &base, uint32_t log_basis, size_t reverse_length = 0) {
+        check(pfhe_basis_create(base.handle(), log_basis, reverse_length, &h_));
+    }
+    ~BigUintApproxSignedBasis() { pfhe_basis_destroy(h_); }
+    BigUintApproxSignedBasis(const BigUintApproxSignedBasis &) = delete;
+    BigUintApproxSignedBasis &operator=(const BigUintApproxSignedBasis &) = delete;
+    size_t decompose_length() const { return pfhe_basis_decompose_length(h_); }
+    uint32_t log_basis() const { return pfhe_basis_log_basis(h_); }
+    uint32_t drop_bits() const { return pfhe_basis_drop_bits(h_); }
+    uint64_t basis_value() const { return pfhe_basis_basis_value(h_); }
+    void init_value_carry_slice_inplace(uint64_t *values, size_t len, uint8_t *carries, size_t count) const {
+        check(pfhe_basis_init_value_carry_slice_inplace(h_, values, len, carries, count));
+    }
+    void unsigned_decompose_slice_to(size_t level, const uint64_t *values, size_t len, uint64_t *digits,
+                                     uint8_t *carries, size_t count) const {
+        check(pfhe_basis_unsigned_decompose_slice_to(h_, level, values, len, digits, carries, count));
+    }
+    const pfhe_basis *handle() const { return h_; }
+
+  private:
+    pfhe_basis *h_ = nullptr;
+};
+
+// DcrtGlevContext (crates/primus_lattice/src/context/glev.rs:4-68) + the handles the reference
+// passes next to it; one per stream, not concurrently usable.
+class DcrtGlevContext {
+  public:
+    DcrtGlevContext(const U64DcrtTable &table, const RNSBase &base, const BigUintApproxSignedBasis &basis,
+                    size_t glwe_dimension = 1, size_t chunk = 0) {
+        check(pfhe_extprod_plan_create(table.handle(), base.handle(), basis.handle(), glwe_dimension, chunk, &h_));
+    }
+    ~DcrtGlevContext() { pfhe_extprod_plan_destroy(h_); }
+    DcrtGlevContext(const DcrtGlevContext &) = delete;
+    DcrtGlevContext &operator=(const DcrtGlevContext &) = delete;
+    pfhe_extprod_plan *handle() const { return h_; }
+
+  private:
+    pfhe_extprod_plan *h_ = nullptr;
+};
+
+// CrtGlwe::mul_dcrt_ggsw_to (crates/primus_lattice/src/glwe/crt.rs:200-227), host slices
+inline void mul_dcrt_ggsw_to(const uint64_t *crt_glwe, size_t len_glwe, const uint64_t *dcrt_ggsw, size_t len_ggsw,
+                             uint64_t *result, size_t len_result, DcrtGlevContext &context,
+                             bool into_coeff_form = false) {
+    check(pfhe_extprod_mul_dcrt_ggsw_to(context.handle(), crt_glwe, len_glwe, dcrt_ggsw, len_ggsw, result, len_result,
+                                        into_coeff_form));
+}
+
+// device-resident batches
+inline void mul_dcrt_ggsw_to_dev(const uint64_t *crt_glwe_dev, size_t len_glwe, const uint64_t *dcrt_ggsw_dev,
+                                 size_t len_ggsw, uint64_t *result_dev, size_t len_result, DcrtGlevContext &context,
+                                 bool into_coeff_form = false, void *stream = nullptr) {
+    check(pfhe_extprod_mul_dcrt_ggsw_to_dev(context.handle(), crt_glwe_dev, len_glwe, dcrt_ggsw_dev, len_ggsw,
+                                            result_dev, len_result, into_coeff_form, stream));
+}
+
+}  // namespace pfhe

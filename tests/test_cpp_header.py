@@ -1,0 +1,48 @@
+"""The C++ mirror (include/pfhe.hpp) compiles against the C ABI and links to libpfhe_hip.so;
+without a GPU its constructors report NoDevice through pfhe::Error (no CPU fallback)."""
+import os
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = r'''
+#include <cstdio>
+#include "pfhe.hpp"
+int main() {
+    try {
+        pfhe::U64DcrtTable t(10, {2305843009211596801ull, 2305843009210023937ull, 2305843009208713217ull});
+        std::vector<uint64_t> a(3 * 1024, 1), b = a;
+        t.transform_slice(a.data(), a.size());
+        t.inverse_transform_slice(a.data(), a.size());
+        std::printf(a == b ? "roundtrip ok\n" : "roundtrip MISMATCH\n");
+        return a == b ? 0 : 1;
+    } catch (const pfhe::Error &e) {
+        std::printf("pfhe::Error %d: %s\n", e.status(), e.what());
+        return e.status() == PFHE_ERR_NO_DEVICE ? 42 : 2;
+    }
+}
+'''
+
+
+def test_cpp_mirror_compiles_and_runs():
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    import primus_fhe_amd as p
+    lib_dir = os.path.dirname(p.library_path())
+    if not os.path.exists(p.library_path()):
+        pytest.skip("libpfhe_hip.so not built")
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.cpp")
+        open(src, "w").write(SRC)
+        exe = os.path.join(d, "t")
+        subprocess.run(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
+                        "-L", lib_dir, "-lpfhe_hip", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+        r = subprocess.run([exe], capture_output=True, text=True)
+        import torch
+        if torch.cuda.is_available():
+            assert r.returncode == 0 and "roundtrip ok" in r.stdout, r.stdout + r.stderr
+        else:
+            assert r.returncode == 42 and "NO_DEVICE" not in r.stderr, r.stdout + r.stderr
