@@ -79,6 +79,8 @@ struct ShoupArith {
     __device__ __forceinline__ Tw tw_inv_n() const { return Tw{inv_n, inv_n_p}; }
     __device__ __forceinline__ Tw tw_inv_n_w() const { return Tw{inv_n_w, inv_n_w_p}; }
     __device__ __forceinline__ u64 mul_lazy(u64 y, Tw t) const { return t.w * y - q * mulhi64(t.wp, y); }
+    // x in [0,4q) -> [0,2q)
+    __device__ __forceinline__ u64 reduce_x(u64 x) const { return csub(x, two_q); }
 };
 
 struct PmArith {
@@ -116,12 +118,19 @@ struct PmArith {
         const u64 rl = ((u64)((u32)b & mask) << 32) | (u32)a;
         return (u64)rh * c + rl;
     }
+    // any 64-bit x -> x mod~ q in [0, 2^K + 2^(K-9)) (2^K = c folds the bits above K): three
+    // instructions without a carry chain, cheaper than the compare-and-subtract of the generic path
+    __device__ __forceinline__ u64 reduce_x(u64 x) const {
+        const u32 x1 = (u32)(x >> 32);
+        const u64 low = ((u64)(x1 & mask) << 32) | (u32)x;
+        return (u64)(x1 >> sh) * c + low;
+    }
 };
 
 // Harvey forward butterfly, values in [0,4q) — scalar/arithmetic.rs:43-59
 template <class A>
 __device__ __forceinline__ void fwd_bfly(const A &ar, u64 &x, u64 &y, typename A::Tw w) {
-    const u64 tx = csub(x, ar.two_q);
+    const u64 tx = ar.reduce_x(x);
     const u64 t = ar.mul_lazy(y, w);
     x = tx + t;
     y = tx + ar.two_q - t;
@@ -132,14 +141,14 @@ template <class A>
 __device__ __forceinline__ void inv_bfly(const A &ar, u64 &x, u64 &y, typename A::Tw w) {
     const u64 tx = x + y;
     const u64 ty = x + ar.two_q - y;
-    x = csub(tx, ar.two_q);
+    x = ar.reduce_x(tx);
     y = ar.mul_lazy(ty, w);
 }
 
 // last inverse stage fused with N^-1 (x) and N^-1*w (y) — scalar/transform.rs:283-318
 template <class A>
 __device__ __forceinline__ void inv_final_bfly(const A &ar, u64 &x, u64 &y, bool lazy) {
-    const u64 tx = csub(x + y, ar.two_q);
+    const u64 tx = ar.reduce_x(x + y);
     const u64 ty = x + ar.two_q - y;
     u64 rx = ar.mul_lazy(tx, ar.tw_inv_n());
     u64 ry = ar.mul_lazy(ty, ar.tw_inv_n_w());

@@ -23,39 +23,54 @@ __device__ __forceinline__ Bar load_bar(const NttPrime *__restrict__ primes, u32
     return Bar{P->q, P->bar_lo, P->bar_hi};
 }
 
-// MODE 0: a = a*b ; MODE 1: acc = a*b + acc
+// MODE 0: acc = acc*b ; MODE 1: acc = a*b + acc.  Each thread handles UNROLL 16-byte vectors per
+// iteration, one workgroup-stride apart, so that several independent loads are in flight.
 template <int MODE, bool PAIR>
-__global__ __launch_bounds__(kPwThreads) void pointwise_kernel(u64 *acc, const u64 *a,
-                                                               const u64 *__restrict__ b,
+__global__ __launch_bounds__(kPwThreads) void pointwise_kernel(u64 *acc, const u64 *a, const u64 *__restrict__ b,
                                                                const NttPrime *__restrict__ primes, u32 L,
                                                                u32 log_n, u64 len, u64 len_b) {
     constexpr u64 V = PAIR ? 2 : 1;
+    constexpr int UNROLL = 4;
     const u64 nvec = len / V;
     const bool shared_b = len_b != len;
-    for (u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (u64)gridDim.x * blockDim.x) {
-        const u64 i = v * V;
-        const u32 limb = (u32)((i >> log_n) % L);
-        const Bar m = load_bar(primes, limb);
-        const u64 ib = shared_b ? (i % len_b) : i;
-        if constexpr (PAIR) {
-            const ulonglong2 av = *reinterpret_cast<const ulonglong2 *>((MODE == 0 ? acc : a) + i);
-            const ulonglong2 bv = *reinterpret_cast<const ulonglong2 *>(b + ib);
-            ulonglong2 r;
-            if constexpr (MODE == 0) {
-                r.x = mul_mod_barrett(av.x, bv.x, m.q, m.lo, m.hi);
-                r.y = mul_mod_barrett(av.y, bv.y, m.q, m.lo, m.hi);
+    const u64 tile = (u64)gridDim.x * blockDim.x;
+    for (u64 v0 = (u64)blockIdx.x * blockDim.x + threadIdx.x; v0 < nvec; v0 += tile * UNROLL) {
+        u64 av[UNROLL][2], bv[UNROLL][2], cv[UNROLL][2];
+        Bar m[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const u64 v = v0 + tile * u;
+            if (v >= nvec) continue;
+            const u64 i = v * V;
+            m[u] = load_bar(primes, (u32)((i >> log_n) % L));
+            const u64 ib = shared_b ? (i % len_b) : i;
+            if constexpr (PAIR) {
+                const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>((MODE == 0 ? acc : a) + i);
+                const ulonglong2 y = *reinterpret_cast<const ulonglong2 *>(b + ib);
+                av[u][0] = x.x; av[u][1] = x.y; bv[u][0] = y.x; bv[u][1] = y.y;
+                if constexpr (MODE == 1) {
+                    const ulonglong2 z = *reinterpret_cast<const ulonglong2 *>(acc + i);
+                    cv[u][0] = z.x; cv[u][1] = z.y;
+                }
             } else {
-                const ulonglong2 cv = *reinterpret_cast<const ulonglong2 *>(acc + i);
-                r.x = mul_add_mod_barrett(av.x, bv.x, cv.x, m.q, m.lo, m.hi);
-                r.y = mul_add_mod_barrett(av.y, bv.y, cv.y, m.q, m.lo, m.hi);
+                av[u][0] = (MODE == 0 ? acc : a)[i];
+                bv[u][0] = b[ib];
+                if constexpr (MODE == 1) cv[u][0] = acc[i];
             }
-            *reinterpret_cast<ulonglong2 *>(acc + i) = r;
-        } else {
-            if constexpr (MODE == 0) {
-                acc[i] = mul_mod_barrett(acc[i], b[ib], m.q, m.lo, m.hi);
-            } else {
-                acc[i] = mul_add_mod_barrett(a[i], b[ib], acc[i], m.q, m.lo, m.hi);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const u64 v = v0 + tile * u;
+            if (v >= nvec) continue;
+            const u64 i = v * V;
+            u64 r[2];
+#pragma unroll
+            for (int e = 0; e < (int)V; ++e) {
+                if constexpr (MODE == 0) r[e] = mul_mod_barrett(av[u][e], bv[u][e], m[u].q, m[u].lo, m[u].hi);
+                else r[e] = mul_add_mod_barrett(av[u][e], bv[u][e], cv[u][e], m[u].q, m[u].lo, m[u].hi);
             }
+            if constexpr (PAIR) *reinterpret_cast<ulonglong2 *>(acc + i) = ulonglong2{r[0], r[1]};
+            else acc[i] = r[0];
         }
     }
 }
@@ -111,8 +126,8 @@ int pointwise_dev(int mode, u64 *acc, const u64 *a, const u64 *b, const NttPrime
                   u64 len, u64 len_b, hipStream_t s) {
     if (len == 0) return PFHE_OK;
     const bool pair = log_n >= 1 && (len % 2 == 0) && (len_b % 2 == 0);
-    const u64 items = pair ? len / 2 : len;
-    const dim3 g(grid_for(items)), t(kPwThreads);
+    const u64 items = (pair ? len / 2 : len + 3) / 4;  // 4 vectors per thread and iteration
+    const dim3 g(grid_for(items ? items : 1)), t(kPwThreads);
     if (mode == 0) {
         if (pair) hipLaunchKernelGGL((pointwise_kernel<0, true>), g, t, 0, s, acc, a, b, primes, L, log_n, len, len_b);
         else hipLaunchKernelGGL((pointwise_kernel<0, false>), g, t, 0, s, acc, a, b, primes, L, log_n, len, len_b);
