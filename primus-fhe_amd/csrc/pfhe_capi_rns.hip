@@ -1,5 +1,6 @@
 // pfhe_capi_rns.hip — extern "C" boundary for RNSBase, BigUintApproxSignedBasis and the RNS gadget
 // external product (include/pfhe.h, second half).
+#include <cstdlib>
 #include <memory>
 #include <new>
 
@@ -21,13 +22,25 @@ struct pfhe_extprod_plan {
     BasisDev basis{};
     u32 k = 1;
     size_t chunk = 1;
-    u64 *digits = nullptr;  // chunk * (k+1) * ell * L * N words of device scratch
-    size_t digits_words = 0;
+    // two digit buffers of chunk * (k+1) * ell * L * N words: while the (VALU-bound) transform +
+    // multiply-accumulate of chunk c runs on stream `sb`, the (HBM-bound) decomposition + strided
+    // pass of chunk c+1 fills the other buffer on stream `sa`
+    u64 *digits[2] = {nullptr, nullptr};
+    size_t digits_words = 0;  // per buffer
+    hipStream_t sa = nullptr, sb = nullptr;
+    hipEvent_t fork = nullptr, join_a = nullptr, join_b = nullptr;
+    hipEvent_t produced[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
     ~pfhe_extprod_plan() {
-        if (digits && table) {
-            DeviceGuard g(table->device);
-            (void)hipFree(digits);
-        }
+        if (!table) return;
+        DeviceGuard g(table->device);
+        if (sa) (void)hipStreamSynchronize(sa);
+        if (sb) (void)hipStreamSynchronize(sb);
+        for (u64 *d : digits)
+            if (d) (void)hipFree(d);
+        for (hipEvent_t e : {fork, join_a, join_b, produced[0], produced[1], consumed[0], consumed[1]})
+            if (e) (void)hipEventDestroy(e);
+        if (sa) (void)hipStreamDestroy(sa);
+        if (sb) (void)hipStreamDestroy(sb);
     }
 };
 
@@ -59,22 +72,71 @@ int plan_check(const pfhe_extprod_plan *p) {
 }
 
 // one row of the product: acc[e] += glev[e or shared] (x) crt_poly[e]   (glwe/dcrt.rs:178-255)
-// rows == k+1 with `zero_first` gives CrtGlwe::mul_dcrt_ggsw_to (glwe/crt.rs:200-227).
+// rows == k+1 without `accumulate` gives CrtGlwe::mul_dcrt_ggsw_to (glwe/crt.rs:200-227).
+// Chunks of ciphertexts are software-pipelined over the plan's two streams and two digit buffers.
 int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 *keys, bool keys_shared, u64 *result,
                 u64 batch, bool accumulate, hipStream_t s) {
     const TableSet &t = *p->table;
     const u64 W = (u64)t.L * t.n;
     const u32 ell = p->basis.ell;
     const u64 key_words = (u64)rows * ell * (p->k + 1) * W;
-    for (u64 done = 0; done < batch; done += p->chunk) {
+    const bool fused = gadget_fused_supported(t.log_n, p->k) && std::getenv("PFHE_DISABLE_FUSED_EXTPROD") == nullptr;
+    const int passes = ntt_num_passes(t.log_n);
+    const bool fused_decompose = gadget_decompose_strided_supported(t.log_n, p->rns.value_len) &&
+                                 std::getenv("PFHE_DISABLE_FUSED_DECOMPOSE") == nullptr;
+    PFHE_HIP(hipEventRecord(p->fork, s));
+    PFHE_HIP(hipStreamWaitEvent(p->sa, p->fork, 0));
+    PFHE_HIP(hipStreamWaitEvent(p->sb, p->fork, 0));
+    // Software pipeline over chunks of ciphertexts, two digit buffers, two streams:
+    //   stream a (HBM-bound kernels): decomposition + strided passes of chunk c, then the
+    //            multiply-accumulate of chunk c-1 (unfused variant);
+    //   stream b (VALU-bound kernels): block pass of the transform (+ fused multiply-accumulate).
+    // The memory-bound and the ALU-bound workgroups co-reside on the CUs and hide each other.
+    u64 index = 0;
+    u64 prev_done = 0, prev_cur = 0;
+    auto issue_mulacc = [&](u64 idx, u64 done0, u64 cur0) -> int {
+        const int b0 = (int)(idx & 1);
+        PFHE_HIP(hipStreamWaitEvent(p->sa, p->consumed[b0], 0));
+        return gadget_mulacc_dev(t.primes_dev, t.L, t.log_n, p->k, rows, ell, p->digits[b0],
+                                 keys + (keys_shared ? 0 : done0 * key_words), keys_shared,
+                                 result + done0 * (p->k + 1) * W, cur0, accumulate, p->sa);
+    };
+    for (u64 done = 0; done < batch; done += p->chunk, ++index) {
         const u64 cur = std::min<u64>(p->chunk, batch - done);
-        const u64 *in = crt_polys + done * rows * W;
-        PFHE_TRY(gadget_decompose_dev(p->rns, p->basis, t.log_n, in, p->digits, cur * rows, s));
-        PFHE_TRY(ntt_forward_dev(t.primes_dev, t.L, t.log_n, t.pm, p->digits, cur * rows * ell * t.L, false, s));
-        PFHE_TRY(gadget_mulacc_dev(t.primes_dev, t.L, t.log_n, p->k, rows, ell, p->digits,
-                                   keys + (keys_shared ? 0 : done * key_words), keys_shared,
-                                   result + done * (p->k + 1) * W, cur, accumulate, s));
+        const int buf = (int)(index & 1);
+        u64 *dg = p->digits[buf];
+        const u64 npolys = cur * rows * ell * t.L;
+        // ---- stream a: steps (1)-(4) + strided passes into digit buffer `buf` ----
+        if (fused && index >= 2) PFHE_HIP(hipStreamWaitEvent(p->sa, p->consumed[buf], 0));
+        if (fused_decompose) {
+            PFHE_TRY(gadget_decompose_strided_dev(p->rns, p->basis, t.primes_dev, t.log_n, t.pm,
+                                                  crt_polys + done * rows * W, dg, cur * rows, p->sa));
+        } else {
+            PFHE_TRY(gadget_decompose_dev(p->rns, p->basis, t.log_n, crt_polys + done * rows * W, dg, cur * rows, p->sa));
+            for (int i = 0; i < passes - 1; ++i)
+                PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.pm, dg, npolys, false, i, false, p->sa));
+        }
+        PFHE_HIP(hipEventRecord(p->produced[buf], p->sa));
+        // ---- stream b: block pass (last pass of the transform) ----
+        PFHE_HIP(hipStreamWaitEvent(p->sb, p->produced[buf], 0));
+        if (fused) {
+            PFHE_TRY(gadget_block_mulacc_dev(t.primes_dev, t.L, t.log_n, t.pm, p->k, rows * ell, dg,
+                                             keys + (keys_shared ? 0 : done * key_words), keys_shared,
+                                             result + done * (p->k + 1) * W, cur, accumulate, p->sb));
+        } else {
+            PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.pm, dg, npolys, false, passes - 1, false, p->sb));
+        }
+        PFHE_HIP(hipEventRecord(p->consumed[buf], p->sb));
+        // ---- stream a: multiply-accumulate of the PREVIOUS chunk (its block pass has had time to run) ----
+        if (!fused && index >= 1) PFHE_TRY(issue_mulacc(index - 1, prev_done, prev_cur));
+        prev_done = done;
+        prev_cur = cur;
     }
+    if (!fused && index >= 1) PFHE_TRY(issue_mulacc(index - 1, prev_done, prev_cur));
+    PFHE_HIP(hipEventRecord(p->join_a, p->sa));
+    PFHE_HIP(hipEventRecord(p->join_b, p->sb));
+    PFHE_HIP(hipStreamWaitEvent(s, p->join_a, 0));
+    PFHE_HIP(hipStreamWaitEvent(s, p->join_b, 0));
     return PFHE_OK;
 }
 
@@ -313,20 +375,29 @@ int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *rns, const 
     p->rns = rns->h.dev;
     p->basis = basis->h.dev;
     p->k = (u32)glwe_dimension;
-    p->chunk = chunk ? chunk : 8;
+    p->chunk = chunk ? chunk : 32;
     p->digits_words = p->chunk * (p->k + 1) * p->basis.ell * t->L * t->n;
     DeviceGuard g(t->device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    void *d = nullptr;
-    PFHE_HIP(hipMalloc(&d, p->digits_words * sizeof(u64)));
-    p->digits = (u64 *)d;
+    for (int i = 0; i < 2; ++i) {
+        void *d = nullptr;
+        PFHE_HIP(hipMalloc(&d, p->digits_words * sizeof(u64)));
+        p->digits[i] = (u64 *)d;
+        PFHE_HIP(hipEventCreateWithFlags(&p->produced[i], hipEventDisableTiming));
+        PFHE_HIP(hipEventCreateWithFlags(&p->consumed[i], hipEventDisableTiming));
+    }
+    PFHE_HIP(hipStreamCreateWithFlags(&p->sa, hipStreamNonBlocking));
+    PFHE_HIP(hipStreamCreateWithFlags(&p->sb, hipStreamNonBlocking));
+    PFHE_HIP(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
+    PFHE_HIP(hipEventCreateWithFlags(&p->join_a, hipEventDisableTiming));
+    PFHE_HIP(hipEventCreateWithFlags(&p->join_b, hipEventDisableTiming));
     *out = p.release();
     return PFHE_OK;
     PFHE_GUARD_END
 }
 
 void pfhe_extprod_plan_destroy(pfhe_extprod_plan *p) { delete p; }
-size_t pfhe_extprod_plan_scratch_bytes(const pfhe_extprod_plan *p) { return p ? p->digits_words * 8 : 0; }
+size_t pfhe_extprod_plan_scratch_bytes(const pfhe_extprod_plan *p) { return p ? 2 * p->digits_words * 8 : 0; }
 
 int pfhe_extprod_mul_dcrt_ggsw_to_dev(pfhe_extprod_plan *plan, const uint64_t *crt_glwe_dev, size_t len_glwe,
                                       const uint64_t *dcrt_ggsw_dev, size_t len_ggsw, uint64_t *result_dev,

@@ -1,0 +1,247 @@
+// pfhe_extprod.hip — fused kernel of the RNS gadget external product.
+//
+// Reference dataflow per digit polynomial (primus_lattice/src/glwe/dcrt.rs:228-254):
+//   table.transform_slice(digit)  ->  for every component c: acc_c += key_c * digit_hat
+// Here the LAST pass of the forward transform (block pass, pfhe_ntt.hip) and the multiply-accumulate
+// are one kernel: a workgroup owns one 2^12-coefficient block of one limb of one ciphertext, loops
+// over the rows*ell digit polynomials, transforms each block on chip and accumulates key * digit_hat
+// into registers; the transformed digits are never written back (the unfused path writes and
+// re-reads 8*(k+1)*ell*L*N bytes per ciphertext).  Accumulation is exact modular arithmetic (canonical
+// result), so the value equals the reference's sequence of reduce_mul_add calls.
+#include <type_traits>
+
+#include "pfhe_common.hpp"
+#include "pfhe_modmath.hpp"
+#include "pfhe_ntt_device.hpp"
+#include "pfhe_rns.hpp"
+#include "pfhe_rns_device.hpp"
+
+namespace pfhe {
+
+namespace {
+
+// modular multiply-accumulate policies matching the NTT arithmetic policies
+__device__ __forceinline__ u64 mac(const PmArith &ar, u64 acc, u64 d, u64 k) {
+    // acc < 2^K + 2^(K-9), product term < 1.5 * 2^K  =>  sum < 2^63, folded back below 2^K + 2^(K-9)
+    return ar.reduce_x(acc + ar.mul_lazy(d, PmArith::Tw{k}));
+}
+
+struct BarrettMac {
+    u64 q, lo, hi;
+};
+__device__ __forceinline__ u64 mac(const BarrettMac &m, u64 acc, u64 d, u64 k) {
+    return mul_add_mod_barrett(d, k, acc, m.q, m.lo, m.hi);
+}
+
+template <class A, int NC>
+__global__ __launch_bounds__(256, 2) void gadget_block_mulacc_kernel(const u64 *__restrict__ digits,
+                                                                  const u64 *__restrict__ ggsw, u64 ggsw_stride,
+                                                                  u64 *__restrict__ result,
+                                                                  const NttPrime *__restrict__ primes, u32 L, u32 log_n,
+                                                                  u32 terms, u64 total_blocks, u32 accumulate) {
+    constexpr int LOGB = 12;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const u32 lt = threadIdx.x;
+    const u64 blk = blockIdx.x;
+    if (blk >= total_blocks) return;
+    const u32 log_nb = log_n - LOGB;
+    const u32 n = 1u << log_n;
+    // blk -> (ciphertext e, limb r, block bi)
+    const u32 bi = (u32)(blk & ((1ull << log_nb) - 1));
+    const u64 er = blk >> log_nb;
+    const u32 r = (u32)(er % L);
+    const u64 e = er / L;
+    const NttPrime *__restrict__ P = primes + r;
+    const A ar(P);
+    const u32 eblk = bi << LOGB;
+    const u64 W = (u64)L << log_n;
+    const u64 limb_off = ((u64)r << log_n) + eblk;
+    const u64 *__restrict__ dg = digits + e * terms * W + limb_off;
+    const u64 *__restrict__ key = ggsw + e * ggsw_stride + limb_off;
+    u64 *__restrict__ out = result + e * NC * W + limb_off;
+
+    u64x2 acc[NC][8];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (accumulate) {
+            load_block_vectors<LOGB>(acc[c], out + (u64)c * W, lt);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[c][j] = u64x2{0, 0};
+        }
+    }
+
+    for (u32 ij = 0; ij < terms; ++ij) {
+        u64x2 io[8];
+        load_block_vectors<LOGB>(io, dg + (u64)ij * W, lt);
+        __syncthreads();  // previous iteration's LDS readers are done
+        lds_put_vectors<LOGB>(io, lds, lt);
+        __syncthreads();
+        u64 x[16];
+        lds_get_layout<LOGB - 4>(x, lds, lt);
+        block_forward_core<A, LOGB>(ar, x, lds, n, eblk, lt, /*lazy=*/true);  // digit_hat mod~ q
+        __syncthreads();
+        lds_put_layout<0>(x, lds, lt);
+        __syncthreads();
+        lds_get_vectors<LOGB>(io, lds, lt);  // natural order again: same positions as the key vectors
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            u64x2 kv[8];
+            load_block_vectors<LOGB>(kv, key + ((u64)ij * NC + c) * W, lt);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if constexpr (std::is_same<A, PmArith>::value) {
+                    acc[c][j].x = mac(ar, acc[c][j].x, io[j].x, kv[j].x);
+                    acc[c][j].y = mac(ar, acc[c][j].y, io[j].y, kv[j].y);
+                } else {
+                    // the lazy transform leaves digit_hat in [0,4q): Barrett takes any product < q*2^64
+                    const BarrettMac m{P->q, P->bar_lo, P->bar_hi};
+                    acc[c][j].x = mac(m, acc[c][j].x, io[j].x, kv[j].x);
+                    acc[c][j].y = mac(m, acc[c][j].y, io[j].y, kv[j].y);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if constexpr (std::is_same<A, PmArith>::value) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {  // [0, 2^K + 2^(K-9)) -> canonical
+                acc[c][j].x = csub(acc[c][j].x, ar.q);
+                acc[c][j].y = csub(acc[c][j].y, ar.q);
+            }
+        }
+        store_block_vectors<LOGB>(acc[c], out + (u64)c * W, lt);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Steps (1)-(4) of glwe/dcrt.rs:219-244 fused with the FIRST (strided) pass of the forward
+// transform: a thread owns one column t of one input CRT polynomial, i.e. the 2^K coefficients
+// t + S*k (S = N / 2^K) that a strided-pass thread would own.  It CRT-composes them once, then for
+// every gadget level and every limb produces the 2^K centred digit residues in registers, runs the
+// K radix-2 stages on them and stores the result where the strided pass would have stored it.  The
+// coefficient-domain digit polynomials (8*ell*L*N bytes per input polynomial) are never written.
+// ------------------------------------------------------------------------------------------
+template <class A, int LEN, int K>
+__global__ __launch_bounds__(256) void gadget_decompose_strided_kernel(RnsDev R, BasisDev B, const NttPrime *__restrict__ primes,
+                                                                      u32 log_n, const u64 *__restrict__ crt,
+                                                                      u64 *__restrict__ out, u64 total_threads) {
+    constexpr int RK = 1 << K;
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total_threads) return;
+    const u32 log_s = log_n - K;
+    const u32 n = 1u << log_n;
+    const u32 col = (u32)(gid & ((1ull << log_s) - 1));
+    const u64 poly = gid >> log_s;
+    const u64 *__restrict__ in = crt + poly * R.L * n + col;
+
+    // (1) compose + (2) carry init, one big integer per owned coefficient
+    u64 v[RK][LEN];
+    u32 carries = 0;
+#pragma unroll
+    for (int k = 0; k < RK; ++k) {
+        u64 r[kMaxLimbs];
+        for (u32 i = 0; i < R.L; ++i) r[i] = in[(u64)i * n + ((u64)k << log_s)];
+        compose<LEN>(R, r, v[k]);
+        carries |= init_value_carry<LEN>(B, v[k]) << k;
+    }
+    const u64 half = (B.basis + 1) / 2;
+    u64 *__restrict__ o = out + poly * B.ell * R.L * n + col;
+#pragma unroll 1
+    for (u32 j = 0; j < B.ell; ++j) {
+        // (3) digit j of every owned coefficient
+        u64 u[RK];
+#pragma unroll
+        for (int k = 0; k < RK; ++k) {
+            const u64 temp = window<LEN>(v[k], B.drop_bits + j * B.log_basis, B.basis_minus_one, B.log_basis) +
+                             ((carries >> k) & 1u);
+            const u32 cbit = (temp & B.carry_mask) != 0;
+            carries = (carries & ~(1u << k)) | (cbit << k);
+            u[k] = temp & B.basis_minus_one;
+        }
+#pragma unroll 1
+        for (u32 i = 0; i < R.L; ++i) {
+            // (4) centred lift into limb i, then the strided pass of that limb's transform
+            const A ar(primes + i);
+            u64 x[RK][1];
+#pragma unroll
+            for (int k = 0; k < RK; ++k) x[k][0] = (B.basis != 2 && u[k] >= half) ? R.q[i] - B.basis + u[k] : u[k];
+            strided_forward_regs<A, K, 1>(ar, x, n, 0u, log_s);
+            u64 *__restrict__ dst = o + ((u64)j * R.L + i) * n;
+#pragma unroll
+            for (int k = 0; k < RK; ++k) dst[(u64)k << log_s] = x[k][0];
+        }
+    }
+}
+
+template <class A, int K>
+int launch_decompose_strided(const RnsDev &r, const BasisDev &b, const NttPrime *primes, u32 log_n, const u64 *crt,
+                             u64 *digits, u64 npolys, hipStream_t s) {
+    const u64 total = npolys << (log_n - K);
+    const u32 grid = (u32)((total + 255) / 256);
+    switch (r.value_len) {
+#define PFHE_CASE(LEN)                                                                                          \
+    case LEN:                                                                                                   \
+        hipLaunchKernelGGL((gadget_decompose_strided_kernel<A, LEN, K>), dim3(grid), dim3(256), 0, s, r, b, primes, \
+                           log_n, crt, digits, total);                                                          \
+        break;
+        PFHE_CASE(1) PFHE_CASE(2) PFHE_CASE(3) PFHE_CASE(4)
+#undef PFHE_CASE
+        default: return PFHE_ERR_UNSUPPORTED;
+    }
+    PFHE_HIP(hipGetLastError());
+    return PFHE_OK;
+}
+
+}  // namespace
+
+bool gadget_fused_supported(u32 log_n, u32 k) { return k == 1 && make_ntt_plan(log_n).block_log == 12; }
+
+int gadget_block_mulacc_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u32 k, u32 terms, const u64 *digits,
+                            const u64 *ggsw, bool ggsw_shared, u64 *result, u64 batch, bool accumulate,
+                            hipStream_t s) {
+    if (!gadget_fused_supported(log_n, k)) return PFHE_ERR_UNSUPPORTED;
+    using Cfg = BlockCfg<12>;
+    const u64 total_blocks = (batch * L) << (log_n - 12);
+    if (total_blocks == 0) return PFHE_OK;
+    if (total_blocks > 0x7fffffffull) return PFHE_ERR_BAD_LENGTH;
+    const u64 ggsw_words = ((u64)terms * (k + 1) * L) << log_n;
+    constexpr size_t lds_bytes = (size_t)Cfg::LDS_WORDS * sizeof(u64);
+    const u64 stride = ggsw_shared ? 0ull : ggsw_words;
+    if (pm) {
+        hipLaunchKernelGGL((gadget_block_mulacc_kernel<PmArith, 2>), dim3((u32)total_blocks), dim3(256), lds_bytes, s,
+                           digits, ggsw, stride, result, primes, L, log_n, terms, total_blocks, accumulate ? 1u : 0u);
+    } else {
+        hipLaunchKernelGGL((gadget_block_mulacc_kernel<ShoupArith, 2>), dim3((u32)total_blocks), dim3(256), lds_bytes, s,
+                           digits, ggsw, stride, result, primes, L, log_n, terms, total_blocks, accumulate ? 1u : 0u);
+    }
+    PFHE_HIP(hipGetLastError());
+    return PFHE_OK;
+}
+
+}  // namespace pfhe
+
+namespace pfhe {
+
+// decomposition fused with the first strided pass: two-pass transforms whose strided pass has at
+// most 4 stages (N = 2^13 * 2^K... i.e. block 2^12 and K <= 4) and big integers of at most 4 limbs
+bool gadget_decompose_strided_supported(u32 log_n, u32 value_len) {
+    const NttPlan plan = make_ntt_plan(log_n);
+    return !plan.tiny && plan.n_strided == 1 && plan.strided[0] >= 3 && plan.strided[0] <= 4 && value_len <= 4;
+}
+
+int gadget_decompose_strided_dev(const RnsDev &r, const BasisDev &b, const NttPrime *primes, u32 log_n, bool pm,
+                                 const u64 *crt_polys, u64 *digits, u64 npolys, hipStream_t s) {
+    if (!gadget_decompose_strided_supported(log_n, r.value_len)) return PFHE_ERR_UNSUPPORTED;
+    if (npolys == 0) return PFHE_OK;
+    const int k = make_ntt_plan(log_n).strided[0];
+    if (pm) {
+        return k == 4 ? launch_decompose_strided<PmArith, 4>(r, b, primes, log_n, crt_polys, digits, npolys, s)
+                      : launch_decompose_strided<PmArith, 3>(r, b, primes, log_n, crt_polys, digits, npolys, s);
+    }
+    return k == 4 ? launch_decompose_strided<ShoupArith, 4>(r, b, primes, log_n, crt_polys, digits, npolys, s)
+                  : launch_decompose_strided<ShoupArith, 3>(r, b, primes, log_n, crt_polys, digits, npolys, s);
+}
+
+}  // namespace pfhe

@@ -160,6 +160,27 @@ __device__ __forceinline__ void inv_final_bfly(const A &ar, u64 &x, u64 &y, bool
     y = ry;
 }
 
+// K forward stages on 2^K register-resident coefficients at stride 2^log_s (element index of
+// register 0 = ebase): the body of the forward strided pass, shared with the fused decomposition.
+template <class A, int K, int VEC>
+__device__ __forceinline__ void strided_forward_regs(const A &ar, u64 (&x)[1 << K][VEC], u32 n, u32 ebase, u32 log_s) {
+    constexpr int R = 1 << K;
+#pragma unroll
+    for (int j = K - 1; j >= 0; --j) {
+        const u32 base = (n + ebase) >> (log_s + j + 1);
+#pragma unroll
+        for (int u = 0; u < (R >> (j + 1)); ++u) {
+            const typename A::Tw w = ar.fwd_tw(base + u);
+#pragma unroll
+            for (int v = 0; v < (1 << j); ++v) {
+                const int k0 = (u << (j + 1)) | v, k1 = k0 | (1 << j);
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) fwd_bfly(ar, x[k0][c], x[k1][c], w);
+            }
+        }
+    }
+}
+
 template <int LOGB>
 struct BlockCfg {
     static_assert(LOGB >= 4 && LOGB <= 14, "block pass handles 2^4 .. 2^14 coefficients");

@@ -65,4 +65,15 @@ int gadget_decompose_dev(const RnsDev &r, const BasisDev &b, u32 log_n, const u6
 int gadget_mulacc_dev(const NttPrime *primes, u32 L, u32 log_n, u32 k, u32 rows, u32 ell, const u64 *digits,
                       const u64 *ggsw, bool ggsw_shared, u64 *result, u64 batch, bool accumulate, hipStream_t s);
 
+// Fused "last forward pass + multiply-accumulate" (pfhe_extprod.hip): `digits` must already have gone
+// through the strided passes of the forward transform.  Available for k = 1 and a 2^12 block pass.
+bool gadget_fused_supported(u32 log_n, u32 k);
+// Steps (1)-(4) fused with the first (strided) pass of the forward transform (pfhe_extprod.hip).
+bool gadget_decompose_strided_supported(u32 log_n, u32 value_len);
+int gadget_decompose_strided_dev(const RnsDev &r, const BasisDev &b, const NttPrime *primes, u32 log_n, bool pm,
+                                 const u64 *crt_polys, u64 *digits, u64 npolys, hipStream_t s);
+int gadget_block_mulacc_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u32 k, u32 terms, const u64 *digits,
+                            const u64 *ggsw, bool ggsw_shared, u64 *result, u64 batch, bool accumulate,
+                            hipStream_t s);
+
 }  // namespace pfhe

@@ -1,0 +1,108 @@
+// pfhe_rns_device.hpp — device functions of the RNS / gadget steps, shared by pfhe_rns.hip (one
+// kernel per reference slice function) and pfhe_extprod.hip (fused kernels).
+#pragma once
+
+#include "pfhe_modmath.hpp"
+#include "pfhe_rns.hpp"
+
+namespace pfhe {
+
+// v (LEN limbs, canonical in [0,Q)) = CRT lift of residues r[0..L)  — base.rs:609-633.
+template <int LEN>
+__device__ __forceinline__ void compose(const RnsDev &R, const u64 *r, u64 (&v)[LEN]) {
+#pragma unroll
+    for (int j = 0; j < LEN; ++j) v[j] = 0;
+    for (u32 i = 0; i < R.L; ++i) {
+        const u64 t = mul_shoup(r[i], R.inv_punct[i], R.inv_punct_p[i], R.q[i]);
+        // v += P_i * t  (LEN limbs + carry word)
+        u64 carry = 0;
+#pragma unroll
+        for (int j = 0; j < LEN; ++j) {
+            const u64 lo = R.punct[i][j] * t;
+            const u64 hi = mulhi64(R.punct[i][j], t);
+            u64 s = v[j] + lo;
+            u64 c1 = s < lo;
+            u64 s2 = s + carry;
+            c1 += s2 < carry;
+            v[j] = s2;
+            carry = hi + c1;
+        }
+        // if carry != 0 or v >= Q: v -= Q
+        bool ge = carry != 0;
+        if (!ge) {
+            ge = true;  // equal counts as >=
+#pragma unroll
+            for (int j = LEN - 1; j >= 0; --j) {
+                if (v[j] != R.Q[j]) {
+                    ge = v[j] > R.Q[j];
+                    break;
+                }
+            }
+        }
+        if (ge) {
+            u64 borrow = 0;
+#pragma unroll
+            for (int j = 0; j < LEN; ++j) {
+                const u64 d = v[j] - R.Q[j];
+                const u64 b1 = v[j] < R.Q[j];
+                const u64 d2 = d - borrow;
+                const u64 b2 = d < borrow;
+                v[j] = d2;
+                borrow = b1 | b2;
+            }
+        }
+    }
+}
+
+// basis.rs:334-349: if v >= threshold: v += add ; returns the initial carry bit
+template <int LEN>
+__device__ __forceinline__ u32 init_value_carry(const BasisDev &B, u64 (&v)[LEN]) {
+    if (B.mode & 2u) {
+        bool ge = true;
+#pragma unroll
+        for (int j = LEN - 1; j >= 0; --j) {
+            if (v[j] != B.threshold[j]) {
+                ge = v[j] > B.threshold[j];
+                break;
+            }
+        }
+        if (ge) {
+            u64 carry = 0;
+#pragma unroll
+            for (int j = 0; j < LEN; ++j) {
+                const u64 s = v[j] + B.add[j];
+                const u64 c1 = s < v[j];
+                const u64 s2 = s + carry;
+                const u64 c2 = s2 < s;
+                v[j] = s2;
+                carry = c1 | c2;
+            }
+        }
+    }
+    u32 carry = 0;
+    if (B.mode & 1u) {
+        u64 limb = 0;
+#pragma unroll
+        for (int j = 0; j < LEN; ++j)
+            if ((u32)j == B.carry_index) limb = v[j];
+        carry = (limb & B.carry_bit_mask) != 0;
+    }
+    return carry;
+}
+
+// window of log_basis bits starting at bit `start` of the LEN-limb value — common.rs:132-140
+template <int LEN>
+__device__ __forceinline__ u64 window(const u64 (&v)[LEN], u32 start, u64 mask, u32 log_basis) {
+    const u32 idx = start >> 6, shr = start & 63;
+    u64 lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 0; j < LEN; ++j) {
+        if ((u32)j == idx) lo = v[j];
+        if ((u32)j == idx + 1) hi = v[j];
+    }
+    u64 w = lo >> shr;
+    if (shr + log_basis > 64) w |= hi << (64 - shr);
+    return w & mask;
+}
+
+}  // namespace pfhe

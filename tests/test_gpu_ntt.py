@@ -248,3 +248,30 @@ def test_pseudo_mersenne_path_equals_generic_path(pf, orc, q, log_n, monkeypatch
         assert np.array_equal(f, a)
         outs.append(f)
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_two_stream_overlap_path_matches_oracle(pf, orc, monkeypatch):
+    """Batches >= 512 MiB of a two-pass transform are tiled over two internal HIP streams
+    (pfhe_ntt.hip `transform`); results must equal the single-stream path and the oracle, and work
+    queued on the caller's stream afterwards must see the finished data."""
+    import torch
+    log_n, batch = 16, 352  # 352 * 3 * 512 KiB = 528 MiB
+    n, L = 1 << log_n, 3
+    rng = np.random.default_rng(77)
+    d, o = pf.U64DcrtTable(log_n, Q61), orc.U64DcrtTable(log_n, Q61)
+    a = rand_rns(rng, Q61, n, batch)
+    x = to_dev(a)
+    d.transform_dev(x)
+    y = x.clone()  # ordered after the join on the same (current) stream
+    got = to_host(y)
+    monkeypatch.setenv("PFHE_DISABLE_OVERLAP", "1")
+    x1 = to_dev(a)
+    d.transform_dev(x1)
+    assert np.array_equal(got, to_host(x1))
+    monkeypatch.delenv("PFHE_DISABLE_OVERLAP")
+    for e in (0, 123, batch - 1):
+        ref = a[e * L * n:(e + 1) * L * n].copy()
+        o.transform_slice(ref)
+        assert np.array_equal(got[e * L * n:(e + 1) * L * n], ref)
+    d.inverse_transform_dev(x)
+    assert np.array_equal(to_host(x), a)
