@@ -108,28 +108,7 @@ __global__ __launch_bounds__(256) void ntt_strided_kernel(u64 *__restrict__ data
     if constexpr (!INV) {
         strided_forward_regs<A, K, VEC>(ar, x, n, ebase, log_s);
     } else {
-        constexpr int JTOP = FINAL ? K - 1 : K;  // the fused final stage is handled after the loop
-#pragma unroll
-        for (int j = 0; j < JTOP; ++j) {
-            const u32 p = log_s + j;
-            const u32 base = 1 + n - (n >> p) + (ebase >> (p + 1));
-#pragma unroll
-            for (int u = 0; u < (R >> (j + 1)); ++u) {
-                const typename A::Tw w = ar.inv_tw(base + u);
-#pragma unroll
-                for (int v = 0; v < (1 << j); ++v) {
-                    const int k0 = (u << (j + 1)) | v, k1 = k0 | (1 << j);
-#pragma unroll
-                    for (int c = 0; c < VEC; ++c) inv_bfly(ar, x[k0][c], x[k1][c], w);
-                }
-            }
-        }
-        if constexpr (FINAL) {
-#pragma unroll
-            for (int v = 0; v < R / 2; ++v)
-#pragma unroll
-                for (int c = 0; c < VEC; ++c) inv_final_bfly(ar, x[v][c], x[v + R / 2][c], lazy != 0);
-        }
+        strided_inverse_regs<A, K, VEC, FINAL>(ar, x, n, ebase, log_s, lazy != 0);
     }
 
 #pragma unroll

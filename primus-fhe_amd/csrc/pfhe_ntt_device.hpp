@@ -181,6 +181,36 @@ __device__ __forceinline__ void strided_forward_regs(const A &ar, u64 (&x)[1 << 
     }
 }
 
+// inverse counterpart: K stages at distances 2^log_s ... 2^(log_s+K-1); FINAL fuses the N^-1 scaling
+// of the last stage of the whole transform (scalar/transform.rs:283-318).
+template <class A, int K, int VEC, bool FINAL>
+__device__ __forceinline__ void strided_inverse_regs(const A &ar, u64 (&x)[1 << K][VEC], u32 n, u32 ebase, u32 log_s,
+                                                     bool lazy) {
+    constexpr int R = 1 << K;
+    constexpr int JTOP = FINAL ? K - 1 : K;
+#pragma unroll
+    for (int j = 0; j < JTOP; ++j) {
+        const u32 p = log_s + j;
+        const u32 base = 1 + n - (n >> p) + (ebase >> (p + 1));
+#pragma unroll
+        for (int u = 0; u < (R >> (j + 1)); ++u) {
+            const typename A::Tw w = ar.inv_tw(base + u);
+#pragma unroll
+            for (int v = 0; v < (1 << j); ++v) {
+                const int k0 = (u << (j + 1)) | v, k1 = k0 | (1 << j);
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) inv_bfly(ar, x[k0][c], x[k1][c], w);
+            }
+        }
+    }
+    if constexpr (FINAL) {
+#pragma unroll
+        for (int v = 0; v < R / 2; ++v)
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) inv_final_bfly(ar, x[v][c], x[v + R / 2][c], lazy);
+    }
+}
+
 template <int LOGB>
 struct BlockCfg {
     static_assert(LOGB >= 4 && LOGB <= 14, "block pass handles 2^4 .. 2^14 coefficients");
