@@ -104,6 +104,37 @@ def cpu_baseline(seconds: float):
     }
 
 
+def pmc_traffic(kernel: str, batch: int):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 +
+    WRITE_SIZE, separate --pmc runs of tools/profile_ntt.py at this shape; profiles/*_rocprof.json).
+    bench.py cannot collect counters itself; null when no matching profile is committed."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof.json")), reverse=True):
+        try:
+            rows = json.load(open(path))["kernels"]
+        except Exception:
+            continue
+        want = "ntt_block_kernel" if "block" in kernel else "ntt_strided_kernel"
+        inv = "inv" in kernel
+        best = None
+        for r in rows:
+            k = r["kernel"]
+            if want not in k or r.get("hbm_bytes_per_launch") is None:
+                continue
+            is_inv = (", true>" in k) if "block" in want else (", true, true>" in k)
+            if is_inv != inv:
+                continue
+            if best is None or r["grid_size"] > best["grid_size"]:
+                best = r
+        # only a launch of the same shape counts: block pass = 16 workgroups of 256 per polynomial,
+        # strided pass = N/32 threads per polynomial
+        want_grid = batch * 3 * ((1 << LOG_N) // 16 if "block" in want else (1 << LOG_N) // 32)
+        if best and best["grid_size"] == want_grid:
+            return {"bytes_per_launch": best["hbm_bytes_per_launch"], "source": os.path.basename(path),
+                    "method": "2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes (MI355X_MICROARCH.md, HBM)"}
+    return None
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -182,7 +213,7 @@ def main():
         alg_bytes = 16 * n * batch * L  # each pass reads and writes every coefficient once
         achieved = alg_bytes / (dom[1] * 1e-3) / 1e9
         result["roofline"] = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                              "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom[0], batch),
                               "avg_launch_ms": dom[1], "algorithmic_bytes_per_launch": alg_bytes}
         result["kernels_ms"] = {k: v for k, v in per_pass}
         # the single-pass loops above left x in an arbitrary state: restore canonical residues
@@ -224,7 +255,7 @@ def main():
         result["external_product"] = {
             "value": ep_batch / dte, "unit": "RLWE external products/s (CrtGlwe x DcrtGgsw -> coefficient form)",
             "batch": ep_batch, "ms_per_batch": dte * 1e3, "gadget": {"log_basis": 30, "ell": 6, "k": 1},
-            "ggsw": "one shared 36 MiB DcrtGgsw", "chunk": args.ext_chunk or 8,
+            "ggsw": "one shared 36 MiB DcrtGgsw", "chunk": args.ext_chunk or 32,
             "hbm_roofline_frac": ep_batch / dte * 96 * n / (HBM_PEAK_GBS * 1e9),
             "limb_ntts_per_product": 42}
         del ggsw, out, ctx

@@ -13,6 +13,10 @@ import ctypes as C
 import os
 import sys
 
+# one launch per pass over the whole batch (no two-stream tiling), so that per-launch counters refer
+# to the same launch shape as bench.py's per-kernel timing leg
+os.environ.setdefault("PFHE_DISABLE_OVERLAP", "1")
+
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
