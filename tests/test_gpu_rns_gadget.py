@@ -225,3 +225,47 @@ def test_config4_shape_vs_oracle(pf, orc):
     dout = to_dev(np.zeros_like(glwe))
     pf.mul_dcrt_ggsw_to_dev(to_dev(glwe), to_dev(ggsw), dout, ctx)
     assert np.array_equal(to_host(dout), exp)
+
+
+def test_config4_full_batch_properties(pf, orc):
+    """BASELINE config 4 at its full batch (1024 ciphertexts, one shared 36 MiB GGSW, chunked and
+    pipelined over two streams): oracle spot checks, batch-independence (a ciphertext's result does not
+    depend on its neighbours), zero-in => zero-out (tfhe_external_product.rs:134 analogue) and
+    coefficient-form output == inverse transform of the NTT-form output."""
+    import ctypes as C
+    import torch
+    from primus_fhe_amd._lib import check, u64p
+    log_n, k, batch = 16, 1, 1024
+    n, L = 1 << log_n, 3
+    table, base = pf.U64DcrtTable(log_n, Q61), pf.RNSBase(Q61)
+    basis = pf.BigUintApproxSignedBasis(base, 30)
+    ctx = pf.DcrtGlevContext(table, base, basis, k)
+    glwe_len, ggsw_len = ctx.glwe_len(), ctx.ggsw_len()
+    mods = np.array(Q61, np.uint64)
+
+    def fill(words, seed):
+        x = torch.empty(words, dtype=torch.int64, device="cuda")
+        check(pf.lib().pfhe_fill_uniform_dev(0, C.c_void_p(x.data_ptr()), words, mods.ctypes.data_as(u64p), L, n, seed, None))
+        return x
+
+    glwe, ggsw = fill(batch * glwe_len, 41), fill(ggsw_len, 42)
+    glwe[5 * glwe_len:6 * glwe_len] = 0  # one all-zero ciphertext
+    out = torch.empty_like(glwe)
+    pf.mul_dcrt_ggsw_to_dev(glwe, ggsw, out, ctx)
+    torch.cuda.synchronize()
+    otable, obase = orc.U64DcrtTable(log_n, Q61), orc.RNSBase(Q61)
+    obasis = orc.BigUintApproxSignedBasis(obase, 30)
+    hk = to_host(ggsw)
+    for e in (0, 31, 32, 777, batch - 1):  # chunk boundaries included (chunk = 32)
+        exp = orc.mul_dcrt_ggsw_to(otable, obase, obasis, k, to_host(glwe[e * glwe_len:(e + 1) * glwe_len]).copy(), hk)
+        assert np.array_equal(to_host(out[e * glwe_len:(e + 1) * glwe_len]), exp), e
+    assert int(out[5 * glwe_len:6 * glwe_len].abs().max()) == 0
+    # batch independence: the same ciphertext alone gives the same result
+    single = torch.empty(glwe_len, dtype=torch.int64, device="cuda")
+    pf.mul_dcrt_ggsw_to_dev(glwe[777 * glwe_len:778 * glwe_len].clone(), ggsw, single, ctx)
+    assert torch.equal(single, out[777 * glwe_len:778 * glwe_len])
+    # coefficient form == inverse transform of the NTT form
+    coeff = torch.empty_like(glwe)
+    pf.mul_dcrt_ggsw_to_dev(glwe, ggsw, coeff, ctx, into_coeff_form=True)
+    table.inverse_transform_dev(out)
+    assert torch.equal(coeff, out)
