@@ -166,6 +166,22 @@ int pfhe_dcrt_mul_assign_dev(const pfhe_dcrt *table, uint64_t *a_dev, size_t len
 int pfhe_dcrt_add_mul_assign_dev(const pfhe_dcrt *table, uint64_t *acc_dev,
                                  const uint64_t *a_dev, size_t len_a, const uint64_t *b_dev,
                                  size_t len_b, void *stream);
+/* GLWE butterfly (self, result) = (self + rhs, (self_orig - rhs) * w), canonical in and out, over
+ * every DCRT polynomial of a (batch of) DcrtGlwe:
+ *   DcrtGlwe::butterfly_mul_dcrt_polynomial_to — primus_lattice/src/glwe/dcrt.rs:128-155
+ *     (-> DcrtPolynomial::butterfly_mul_to, primus_poly/src/dcrt/mod.rs:125-160); w = len_w plain
+ *     residues: one DCRT polynomial (L*N, shared by all components) or len.
+ *   DcrtGlwe::butterfly_mul_factor_to — glwe/dcrt.rs:157-175 (-> DcrtPolynomial::butterfly_mul_factor_to,
+ *     primus_poly/src/dcrt/mul.rs:15-30,196-222); w = ShoupFactor<u64> pairs (value, quotient),
+ *     len_w = 2*L*N (shared) or 2*len words. */
+int pfhe_dcrt_butterfly_mul_dcrt_polynomial_to_dev(const pfhe_dcrt *table, uint64_t *a_dev,
+                                                   const uint64_t *rhs_dev, size_t len,
+                                                   const uint64_t *dcrt_poly_dev, size_t len_w,
+                                                   uint64_t *result_dev, void *stream);
+int pfhe_dcrt_butterfly_mul_factor_to_dev(const pfhe_dcrt *table, uint64_t *a_dev,
+                                          const uint64_t *rhs_dev, size_t len,
+                                          const uint64_t *factor_poly_dev, size_t len_w,
+                                          uint64_t *result_dev, void *stream);
 /* Fused "NTT -> pointwise mul by dcrt_poly -> INTT" of CRT polynomials in place:
  * CrtRlwe::mul_dcrt_polynomial_to (primus_lattice/src/rlwe/crt.rs:42-65) followed by
  * DcrtRlwe::into_coeff_form (primus_lattice/src/macros/mod.rs:901-911) per CRT polynomial. */

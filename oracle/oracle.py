@@ -93,6 +93,8 @@ def _load(path: str | None = None) -> C.CDLL:
     sig("orc_dcrt_poly_mul_assign", None, vp, _u64p, _u64p)
     sig("orc_dcrt_poly_add_mul_assign", None, vp, _u64p, _u64p, _u64p)
     sig("orc_naive_negacyclic_mul", None, u64, _u64p, _u64p, _u64p, sz)
+    sig("orc_dcrt_poly_butterfly_mul_factor_to", None, vp, _u64p, _u64p, _u64p, _u64p)
+    sig("orc_dcrt_poly_butterfly_mul_to", None, vp, _u64p, _u64p, _u64p, _u64p)
 
     sig("orc_rns_new", ci, _u64p, sz, C.POINTER(vp))
     sig("orc_rns_free", None, vp)
@@ -315,6 +317,17 @@ class U64DcrtTable:
 
     def add_mul_assign(self, acc, a, b):
         lib().orc_dcrt_poly_add_mul_assign(self._h, _p(acc), _p(a), _p(b))
+
+    def butterfly_mul_factor_to(self, a, s, w_pairs):
+        """(a, b) = (a + s, (a - s) * w) with ShoupFactor pairs; a is updated in place, b returned."""
+        b = np.empty_like(a)
+        lib().orc_dcrt_poly_butterfly_mul_factor_to(self._h, _p(a), _p(s), _p(w_pairs), _p(b))
+        return b
+
+    def butterfly_mul_to(self, a, s, w):
+        b = np.empty_like(a)
+        lib().orc_dcrt_poly_butterfly_mul_to(self._h, _p(a), _p(s), _p(w), _p(b))
+        return b
 
 
 def naive_negacyclic_mul(q, a, b):

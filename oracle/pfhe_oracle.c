@@ -624,6 +624,38 @@ void orc_dcrt_poly_add_mul_assign(const orc_dcrt *t, uint64_t *acc, const uint64
         orc_reduce_add_mul_slice_assign(t->tables[i]->q, acc + i * t->n, a + i * t->n, b + i * t->n, t->n);
 }
 
+/* primus_poly/src/dcrt/mul.rs:15-30 (slice_butterfly) applied per limb as in
+ * DcrtPolynomial::butterfly_mul_factor_to (:196-222): a' = a + s, b = (a - s) * w, all canonical.
+ * `w` holds ShoupFactor pairs (value, quotient), L*N of them. */
+void orc_dcrt_poly_butterfly_mul_factor_to(const orc_dcrt *t, uint64_t *a, const uint64_t *s, const uint64_t *w_pairs,
+                                           uint64_t *b) {
+    for (size_t i = 0; i < t->count; ++i) {
+        const uint64_t q = t->tables[i]->q;
+        for (size_t j = 0; j < t->n; ++j) {
+            const size_t e = i * t->n + j;
+            const uint64_t a_orig = a[e];
+            a[e] = orc_reduce_add(q, a_orig, s[e]);
+            const uint64_t diff = orc_reduce_sub(q, a_orig, s[e]);
+            b[e] = orc_shoup_mul(w_pairs[2 * e], w_pairs[2 * e + 1], diff, q);
+        }
+    }
+}
+
+/* DcrtPolynomial::butterfly_mul_to (primus_poly/src/dcrt/mod.rs:125-160): same with a plain
+ * multiplicand and a Barrett product. */
+void orc_dcrt_poly_butterfly_mul_to(const orc_dcrt *t, uint64_t *a, const uint64_t *s, const uint64_t *w, uint64_t *b) {
+    for (size_t i = 0; i < t->count; ++i) {
+        orc_barrett m;
+        if (orc_barrett_new(t->tables[i]->q, &m)) return;
+        for (size_t j = 0; j < t->n; ++j) {
+            const size_t e = i * t->n + j;
+            const uint64_t a_orig = a[e];
+            a[e] = orc_reduce_add(m.value, a_orig, s[e]);
+            b[e] = orc_barrett_mul(&m, orc_reduce_sub(m.value, a_orig, s[e]), w[e]);
+        }
+    }
+}
+
 /* primus_poly/src/poly/mul.rs:107-134 (output zeroed first: the reference accumulates into a
  * caller-zeroed buffer) */
 void orc_naive_negacyclic_mul(uint64_t q, const uint64_t *a, const uint64_t *b, uint64_t *c, size_t n) {

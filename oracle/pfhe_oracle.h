@@ -137,6 +137,14 @@ void orc_dcrt_poly_mul_assign(const orc_dcrt *t, uint64_t *a, const uint64_t *b)
 void orc_dcrt_poly_add_mul_assign(const orc_dcrt *t, uint64_t *acc, const uint64_t *a,
                                   const uint64_t *b);
 
+/* GLWE butterfly (a, b) = (a + s, (a - s) * w): DcrtPolynomial::butterfly_mul_factor_to
+ * (primus_poly/src/dcrt/mul.rs:15-30,196-222; w = L*N ShoupFactor pairs) and butterfly_mul_to
+ * (primus_poly/src/dcrt/mod.rs:125-160; w = plain residues). */
+void orc_dcrt_poly_butterfly_mul_factor_to(const orc_dcrt *t, uint64_t *a, const uint64_t *s,
+                                           const uint64_t *w_pairs, uint64_t *b);
+void orc_dcrt_poly_butterfly_mul_to(const orc_dcrt *t, uint64_t *a, const uint64_t *s, const uint64_t *w,
+                                    uint64_t *b);
+
 /* ---------------- schoolbook negacyclic product (primus_poly/src/poly/mul.rs:107-134) --- */
 void orc_naive_negacyclic_mul(uint64_t q, const uint64_t *a, const uint64_t *b, uint64_t *out,
                               size_t n);

@@ -94,6 +94,8 @@ def _declare(lib: C.CDLL) -> None:
     sig("pfhe_dcrt_mul_assign_dev", ci, vp, vp, sz, vp, sz, vp)
     sig("pfhe_dcrt_add_mul_assign_dev", ci, vp, vp, vp, sz, vp, sz, vp)
     sig("pfhe_dcrt_mul_dcrt_polynomial_dev", ci, vp, vp, sz, vp, sz, vp)
+    sig("pfhe_dcrt_butterfly_mul_dcrt_polynomial_to_dev", ci, vp, vp, vp, sz, vp, sz, vp, vp)
+    sig("pfhe_dcrt_butterfly_mul_factor_to_dev", ci, vp, vp, vp, sz, vp, sz, vp, vp)
     u8p = C.POINTER(C.c_uint8)
     sig("pfhe_rns_create", ci, u64p, sz, ci, C.POINTER(vp))
     sig("pfhe_rns_destroy", None, vp)

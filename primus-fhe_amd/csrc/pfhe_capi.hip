@@ -549,6 +549,40 @@ int pfhe_dcrt_add_mul_assign_dev(const pfhe_dcrt *table, uint64_t *acc_dev, cons
     PFHE_GUARD_END
 }
 
+static int butterfly_api(const pfhe_dcrt *table, bool factor, uint64_t *a_dev, const uint64_t *rhs_dev, size_t len,
+                         const uint64_t *w_dev, size_t len_w, uint64_t *result_dev, void *stream) {
+    if (!table) return PFHE_ERR_BAD_ARGUMENT;
+    const TableSet &t = *table->t;
+    const size_t unit = t.n * t.L;
+    if (len % unit != 0 || (len_w != unit * (factor ? 2 : 1) && len_w != len * (factor ? 2 : 1))) {
+        set_last_error("butterfly: slices must be multiples of L*N words; the multiplicand is one polynomial "
+                       "(shared) or matches the batch (ShoupFactor slices count two words per coefficient)");
+        return PFHE_ERR_BAD_LENGTH;
+    }
+    if (len == 0) return PFHE_OK;
+    if (!a_dev || !rhs_dev || !w_dev || !result_dev) return PFHE_ERR_BAD_ARGUMENT;
+    DeviceGuard g(t.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    return butterfly_dev(factor, (u64 *)a_dev, (const u64 *)rhs_dev, (const u64 *)w_dev, (u64 *)result_dev, t.primes_dev,
+                         t.L, t.log_n, len, factor ? len_w / 2 : len_w, (hipStream_t)stream);
+}
+
+int pfhe_dcrt_butterfly_mul_dcrt_polynomial_to_dev(const pfhe_dcrt *table, uint64_t *a_dev, const uint64_t *rhs_dev,
+                                                   size_t len, const uint64_t *dcrt_poly_dev, size_t len_w,
+                                                   uint64_t *result_dev, void *stream) {
+    PFHE_GUARD_BEGIN
+    return butterfly_api(table, false, a_dev, rhs_dev, len, dcrt_poly_dev, len_w, result_dev, stream);
+    PFHE_GUARD_END
+}
+
+int pfhe_dcrt_butterfly_mul_factor_to_dev(const pfhe_dcrt *table, uint64_t *a_dev, const uint64_t *rhs_dev, size_t len,
+                                          const uint64_t *factor_poly_dev, size_t len_w, uint64_t *result_dev,
+                                          void *stream) {
+    PFHE_GUARD_BEGIN
+    return butterfly_api(table, true, a_dev, rhs_dev, len, factor_poly_dev, len_w, result_dev, stream);
+    PFHE_GUARD_END
+}
+
 int pfhe_dcrt_transform_num_passes(const pfhe_dcrt *table) {
     return table ? ntt_num_passes(table->t->log_n) : 0;
 }

@@ -75,6 +75,29 @@ __global__ __launch_bounds__(kPwThreads) void pointwise_kernel(u64 *acc, const u
     }
 }
 
+// GLWE butterfly (a, b) = (a + s, (a - s) * w), canonical in and out:
+//   FACTOR: w = ShoupFactor pairs (value, quotient)   DcrtPolynomial::butterfly_mul_factor_to, dcrt/mul.rs:15-30,196-222
+//   else  : w = plain residues, Barrett product        DcrtPolynomial::butterfly_mul_to, dcrt/mod.rs:125-160
+template <bool FACTOR>
+__global__ __launch_bounds__(kPwThreads) void butterfly_kernel(u64 *__restrict__ a, const u64 *__restrict__ s,
+                                                               const u64 *__restrict__ w, u64 *__restrict__ b,
+                                                               const NttPrime *__restrict__ primes, u32 L, u32 log_n,
+                                                               u64 len, u64 len_w) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (u64)gridDim.x * blockDim.x) {
+        const Bar m = load_bar(primes, (u32)((i >> log_n) % L));
+        const u64 iw = i % len_w;
+        const u64 x = a[i], y = s[i];
+        a[i] = add_mod(x, y, m.q);
+        const u64 d = sub_mod(x, y, m.q);
+        if constexpr (FACTOR) {
+            const ulonglong2 f = reinterpret_cast<const ulonglong2 *>(w)[iw];
+            b[i] = mul_shoup(d, f.x, f.y, m.q);
+        } else {
+            b[i] = mul_mod_barrett(d, w[iw], m.q, m.lo, m.hi);
+        }
+    }
+}
+
 __device__ __forceinline__ u64 splitmix64(u64 seed, u64 i) {
     u64 z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -135,6 +158,16 @@ int pointwise_dev(int mode, u64 *acc, const u64 *a, const u64 *b, const NttPrime
         if (pair) hipLaunchKernelGGL((pointwise_kernel<1, true>), g, t, 0, s, acc, a, b, primes, L, log_n, len, len_b);
         else hipLaunchKernelGGL((pointwise_kernel<1, false>), g, t, 0, s, acc, a, b, primes, L, log_n, len, len_b);
     }
+    PFHE_HIP(hipGetLastError());
+    return PFHE_OK;
+}
+
+int butterfly_dev(bool factor, u64 *a, const u64 *s, const u64 *w, u64 *b, const NttPrime *primes, u32 L, u32 log_n,
+                  u64 len, u64 len_w, hipStream_t st) {
+    if (len == 0) return PFHE_OK;
+    const dim3 g(grid_for(len)), t(kPwThreads);
+    if (factor) hipLaunchKernelGGL(butterfly_kernel<true>, g, t, 0, st, a, s, w, b, primes, L, log_n, len, len_w);
+    else hipLaunchKernelGGL(butterfly_kernel<false>, g, t, 0, st, a, s, w, b, primes, L, log_n, len, len_w);
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
 }

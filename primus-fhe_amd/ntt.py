@@ -170,6 +170,22 @@ class U64DcrtTable:
             raise PfheError(32, "acc and a differ in length")
         check(lib().pfhe_dcrt_add_mul_assign_dev(self._h, pc, pa, na, pb, nb, _stream(stream)))
 
+    def butterfly_mul_dcrt_polynomial_to_dev(self, a, rhs, dcrt_poly, result, stream=None):
+        """DcrtGlwe::butterfly_mul_dcrt_polynomial_to (primus_lattice/src/glwe/dcrt.rs:128-155):
+        (a, result) = (a + rhs, (a_orig - rhs) * dcrt_poly)."""
+        (pa, na), (ps, ns), (pw, nw), (pr, nr) = _dev(a), _dev(rhs), _dev(dcrt_poly), _dev(result)
+        if not (na == ns == nr):
+            raise PfheError(32, "a, rhs and result differ in length")
+        check(lib().pfhe_dcrt_butterfly_mul_dcrt_polynomial_to_dev(self._h, pa, ps, na, pw, nw, pr, _stream(stream)))
+
+    def butterfly_mul_factor_to_dev(self, a, rhs, factor_poly, result, stream=None):
+        """DcrtGlwe::butterfly_mul_factor_to (glwe/dcrt.rs:157-175): factor_poly holds
+        ShoupFactor<u64> (value, quotient) pairs, two words per coefficient."""
+        (pa, na), (ps, ns), (pw, nw), (pr, nr) = _dev(a), _dev(rhs), _dev(factor_poly), _dev(result)
+        if not (na == ns == nr):
+            raise PfheError(32, "a, rhs and result differ in length")
+        check(lib().pfhe_dcrt_butterfly_mul_factor_to_dev(self._h, pa, ps, na, pw, nw, pr, _stream(stream)))
+
     def mul_dcrt_polynomial_dev(self, crt_poly, dcrt_poly, stream=None):
         """CrtRlwe::mul_dcrt_polynomial_to + into_coeff_form (primus_lattice/src/rlwe/crt.rs:42-65,
         macros/mod.rs:901-911): NTT -> pointwise multiply -> INTT, in place."""

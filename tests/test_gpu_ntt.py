@@ -275,3 +275,33 @@ def test_two_stream_overlap_path_matches_oracle(pf, orc, monkeypatch):
         assert np.array_equal(got[e * L * n:(e + 1) * L * n], ref)
     d.inverse_transform_dev(x)
     assert np.array_equal(to_host(x), a)
+
+
+@pytest.mark.parametrize("log_n,batch", [(4, 3), (12, 4)])
+def test_glwe_butterfly_ops(pf, orc, log_n, batch):
+    """DcrtGlwe::butterfly_mul_factor_to / butterfly_mul_dcrt_polynomial_to (glwe/dcrt.rs:128-175):
+    (a, b) = (a + s, (a - s) * w) with a shared multiplicand, ShoupFactor pairs or plain residues."""
+    rng = np.random.default_rng(log_n)
+    n, W = 1 << log_n, 3 << log_n
+    d, o = pf.U64DcrtTable(log_n, Q61), orc.U64DcrtTable(log_n, Q61)
+    a, s = rand_rns(rng, Q61, n, batch), rand_rns(rng, Q61, n, batch)
+    a[:3] = [0, Q61[0] - 1, 5]; s[:3] = [Q61[0] - 1, Q61[0] - 1, 7]
+    w = rand_rns(rng, Q61, n, 1)
+    pairs = np.empty(2 * W, np.uint64)
+    pairs[0::2] = w
+    pairs[1::2] = [(int(v) << 64) // Q61[i // n] for i, v in enumerate(w)]
+    exp_a, exp_b = a.copy(), np.empty_like(a)
+    for e in range(batch):
+        exp_b[e * W:(e + 1) * W] = o.butterfly_mul_factor_to(exp_a[e * W:(e + 1) * W], s[e * W:(e + 1) * W].copy(), pairs)
+    chk = a[:W].copy()
+    assert np.array_equal(o.butterfly_mul_to(chk, s[:W].copy(), w), exp_b[:W])  # both reference forms agree
+    for factor in (True, False):
+        da, db = to_dev(a), to_dev(np.zeros_like(a))
+        if factor:
+            d.butterfly_mul_factor_to_dev(da, to_dev(s), to_dev(pairs), db)
+        else:
+            d.butterfly_mul_dcrt_polynomial_to_dev(da, to_dev(s), to_dev(w), db)
+        assert np.array_equal(to_host(da), exp_a) and np.array_equal(to_host(db), exp_b)
+    with pytest.raises(pf.PfheError) as e:
+        d.butterfly_mul_dcrt_polynomial_to_dev(to_dev(a), to_dev(s), to_dev(w[:-1].copy()), to_dev(a))
+    assert e.value.kind == "BadLength"
