@@ -154,6 +154,12 @@ int pfhe_dcrt_lazy_inverse_transform_slice(const pfhe_dcrt *table, uint64_t *pol
 /* DcrtTable::transform_monomial & co — dcrt/mod.rs:105-134.  `values` receives L*N words. */
 int pfhe_dcrt_transform_monomial(const pfhe_dcrt *table, uint64_t coeff, size_t degree,
                                  uint64_t *values, size_t len);
+/* transform_coeff_one_monomial / transform_coeff_minus_one_monomial — dcrt/mod.rs:113-134
+ * (-X^degree uses q_i - 1 in limb i). */
+int pfhe_dcrt_transform_coeff_one_monomial(const pfhe_dcrt *table, size_t degree, uint64_t *values,
+                                           size_t len);
+int pfhe_dcrt_transform_coeff_minus_one_monomial(const pfhe_dcrt *table, size_t degree,
+                                                 uint64_t *values, size_t len);
 int pfhe_dcrt_transform_dev(const pfhe_dcrt *table, uint64_t *poly_dev, size_t len, int lazy,
                             void *stream);
 int pfhe_dcrt_inverse_transform_dev(const pfhe_dcrt *table, uint64_t *poly_dev, size_t len,
@@ -285,6 +291,12 @@ int pfhe_extprod_add_dcrt_glev_mul_crt_poly_assign_dev(pfhe_extprod_plan *plan, 
                                                        size_t len_acc, const uint64_t *dcrt_glev_dev,
                                                        size_t len_glev, const uint64_t *crt_poly_dev,
                                                        size_t len_poly, void *stream);
+
+/* DcrtGlev::mul_crt_poly_to — primus_lattice/src/glev/dcrt.rs:45-110: result = glev (x) crt_poly
+ * (one GGSW row; overwrites instead of accumulating). */
+int pfhe_extprod_glev_mul_crt_poly_to_dev(pfhe_extprod_plan *plan, const uint64_t *dcrt_glev_dev,
+                                          size_t len_glev, const uint64_t *crt_poly_dev, size_t len_poly,
+                                          uint64_t *result_dev, size_t len_result, void *stream);
 
 /* Profiling hooks (bench.py / rocprofv3): a transform is executed as a short sequence of kernel
  * passes (DESIGN.md "Kernels"); these run or name ONE pass so that each kernel can be timed with

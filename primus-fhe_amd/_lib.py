@@ -89,6 +89,8 @@ def _declare(lib: C.CDLL) -> None:
     for g in ("modulus", "root", "inv_n"):
         sig("pfhe_dcrt_" + g, u64, vp, sz)
     sig("pfhe_dcrt_transform_monomial", ci, vp, u64, sz, vp, sz)
+    sig("pfhe_dcrt_transform_coeff_one_monomial", ci, vp, sz, vp, sz)
+    sig("pfhe_dcrt_transform_coeff_minus_one_monomial", ci, vp, sz, vp, sz)
     sig("pfhe_dcrt_transform_dev", ci, vp, vp, sz, ci, vp)
     sig("pfhe_dcrt_inverse_transform_dev", ci, vp, vp, sz, ci, vp)
     sig("pfhe_dcrt_mul_assign_dev", ci, vp, vp, sz, vp, sz, vp)
@@ -124,6 +126,7 @@ def _declare(lib: C.CDLL) -> None:
     sig("pfhe_extprod_mul_dcrt_ggsw_to", ci, vp, vp, sz, vp, sz, vp, sz, ci)
     sig("pfhe_extprod_mul_dcrt_ggsw_to_dev", ci, vp, vp, sz, vp, sz, vp, sz, ci, vp)
     sig("pfhe_extprod_add_dcrt_glev_mul_crt_poly_assign_dev", ci, vp, vp, sz, vp, sz, vp, sz, vp)
+    sig("pfhe_extprod_glev_mul_crt_poly_to_dev", ci, vp, vp, sz, vp, sz, vp, sz, vp)
     sig("pfhe_dcrt_transform_num_passes", ci, vp)
     sig("pfhe_dcrt_transform_pass_name", C.c_char_p, vp, ci, ci)
     sig("pfhe_dcrt_transform_pass_dev", ci, vp, vp, sz, ci, ci, ci, vp)

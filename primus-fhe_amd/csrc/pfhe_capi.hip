@@ -206,7 +206,10 @@ int pointwise(const TableSet &t, int mode, u64 *acc, const u64 *a, size_t len_a,
     return pointwise_dev(mode, acc, a, b, t.primes_dev, t.L, t.log_n, len_a, len_b, s);
 }
 
-int monomial(const TableSet &t, u64 coeff, size_t degree, u64 *values, size_t len, bool host, hipStream_t s) {
+// minus_one: the coefficient of limb i is q_i - 1 (DcrtTable::transform_coeff_minus_one_monomial,
+// primus_ntt/src/dcrt/mod.rs:124-134); otherwise `coeff` for every limb.
+int monomial(const TableSet &t, u64 coeff, size_t degree, u64 *values, size_t len, bool host, hipStream_t s,
+             bool minus_one = false) {
     if (!values) return PFHE_ERR_BAD_ARGUMENT;
     if (len != t.n * t.L) {
         set_last_error("monomial output must be exactly one polynomial");
@@ -215,12 +218,13 @@ int monomial(const TableSet &t, u64 coeff, size_t degree, u64 *values, size_t le
     std::vector<u64> c(2 * t.L);
     for (u32 i = 0; i < t.L; ++i) {
         const u64 q = t.primes[i].q;
-        if (coeff >= q) {
+        const u64 ci = minus_one ? q - 1 : coeff;
+        if (ci >= q) {
             set_last_error("monomial coefficient must be reduced modulo every modulus");
             return PFHE_ERR_BAD_ARGUMENT;
         }
-        c[i] = coeff;
-        c[t.L + i] = (u64)(((unsigned __int128)coeff << 64) / q);
+        c[i] = ci;
+        c[t.L + i] = (u64)(((unsigned __int128)ci << 64) / q);
     }
     DeviceGuard g(t.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
@@ -514,6 +518,17 @@ int pfhe_dcrt_transform_monomial(const pfhe_dcrt *table, uint64_t coeff, size_t 
     PFHE_GUARD_BEGIN
     if (!table) return PFHE_ERR_BAD_ARGUMENT;
     return monomial(*table->t, coeff, degree, (u64 *)values, len, true, nullptr);
+    PFHE_GUARD_END
+}
+
+int pfhe_dcrt_transform_coeff_one_monomial(const pfhe_dcrt *table, size_t degree, uint64_t *values, size_t len) {
+    return pfhe_dcrt_transform_monomial(table, 1, degree, values, len);
+}
+
+int pfhe_dcrt_transform_coeff_minus_one_monomial(const pfhe_dcrt *table, size_t degree, uint64_t *values, size_t len) {
+    PFHE_GUARD_BEGIN
+    if (!table) return PFHE_ERR_BAD_ARGUMENT;
+    return monomial(*table->t, 0, degree, (u64 *)values, len, true, nullptr, /*minus_one=*/true);
     PFHE_GUARD_END
 }
 

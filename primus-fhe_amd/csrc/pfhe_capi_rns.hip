@@ -450,6 +450,28 @@ int pfhe_extprod_add_dcrt_glev_mul_crt_poly_assign_dev(pfhe_extprod_plan *plan, 
     PFHE_GUARD_END
 }
 
+int pfhe_extprod_glev_mul_crt_poly_to_dev(pfhe_extprod_plan *plan, const uint64_t *dcrt_glev_dev, size_t len_glev,
+                                          const uint64_t *crt_poly_dev, size_t len_poly, uint64_t *result_dev,
+                                          size_t len_result, void *stream) {
+    PFHE_GUARD_BEGIN
+    PFHE_TRY(plan_check(plan));
+    const TableSet &t = *plan->table;
+    const size_t W = (size_t)t.L * t.n, glwe = (plan->k + 1) * W, glev = plan->basis.ell * glwe;
+    if (len_poly % W != 0) return PFHE_ERR_BAD_LENGTH;
+    const u64 batch = len_poly / W;
+    if (len_result != batch * glwe || (len_glev != glev && len_glev != batch * glev)) {
+        set_last_error("glev product: result must be batch*(k+1)*L*N words and the GLev one or batch of ell*(k+1)*L*N");
+        return PFHE_ERR_BAD_LENGTH;
+    }
+    if (batch == 0) return PFHE_OK;
+    if (!result_dev || !dcrt_glev_dev || !crt_poly_dev) return PFHE_ERR_BAD_ARGUMENT;
+    DeviceGuard g(t.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    return run_product(plan, (const u64 *)crt_poly_dev, 1, (const u64 *)dcrt_glev_dev, len_glev == glev,
+                       (u64 *)result_dev, batch, false, (hipStream_t)stream);
+    PFHE_GUARD_END
+}
+
 int pfhe_extprod_mul_dcrt_ggsw_to(pfhe_extprod_plan *plan, const uint64_t *crt_glwe, size_t len_glwe,
                                   const uint64_t *dcrt_ggsw, size_t len_ggsw, uint64_t *result, size_t len_result,
                                   int into_coeff_form) {

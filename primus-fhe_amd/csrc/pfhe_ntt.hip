@@ -298,6 +298,10 @@ NttPlan make_ntt_plan(u32 log_n) {
         return p;
     }
     p.block_log = kTwoPassBlockLog;
+    if (const char *e = std::getenv("PFHE_BLOCK_LOG")) {  // tuning switch: block size under strided passes
+        const int b = std::atoi(e);
+        if (b >= 8 && b <= 12 && (int)log_n - b >= 1) p.block_log = b;
+    }
     int rest = (int)log_n - p.block_log;
     // fewest strided passes with at most 5 stages each, balanced
     int passes = (rest + 4) / 5;

@@ -64,3 +64,9 @@ def add_dcrt_glev_mul_crt_poly_assign_dev(acc, dcrt_glev, crt_poly, context: Dcr
     (pc, nc), (pg, ng), (pp, np_) = _dev(acc), _dev(dcrt_glev), _dev(crt_poly)
     check(lib().pfhe_extprod_add_dcrt_glev_mul_crt_poly_assign_dev(context._h, pc, nc, pg, ng, pp, np_,
                                                                    _stream(stream)))
+
+
+def glev_mul_crt_poly_to_dev(dcrt_glev, crt_poly, result, context: DcrtGlevContext, stream=None):
+    """DcrtGlev::mul_crt_poly_to (primus_lattice/src/glev/dcrt.rs:45-110): result = glev (x) crt_poly."""
+    (pg, ng), (pp, np_), (pr, nr) = _dev(dcrt_glev), _dev(crt_poly), _dev(result)
+    check(lib().pfhe_extprod_glev_mul_crt_poly_to_dev(context._h, pg, ng, pp, np_, pr, nr, _stream(stream)))

@@ -148,7 +148,11 @@ class U64DcrtTable:
         check(lib().pfhe_dcrt_transform_monomial(self._h, coeff, degree, *_host(values)))
 
     def transform_coeff_one_monomial(self, degree: int, values):
-        self.transform_monomial(1, degree, values)
+        check(lib().pfhe_dcrt_transform_coeff_one_monomial(self._h, degree, *_host(values)))
+
+    def transform_coeff_minus_one_monomial(self, degree: int, values):
+        """-X^degree: q_i - 1 in limb i (primus_ntt/src/dcrt/mod.rs:124-134)."""
+        check(lib().pfhe_dcrt_transform_coeff_minus_one_monomial(self._h, degree, *_host(values)))
 
     def transform_dev(self, poly, lazy: bool = False, stream=None):
         p, n = _dev(poly)

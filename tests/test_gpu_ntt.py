@@ -133,6 +133,10 @@ def test_dcrt_table(pf, orc, log_n, batch):
     d.transform_monomial(5, 3, mono)
     exp = np.concatenate([o.table(i).transform_monomial(5, 3) for i in range(3)])
     assert np.array_equal(mono, exp)
+    d.transform_coeff_one_monomial(7, mono)
+    assert np.array_equal(mono, np.concatenate([o.table(i).transform_coeff_one_monomial(7) for i in range(3)]))
+    d.transform_coeff_minus_one_monomial(7, mono)
+    assert np.array_equal(mono, np.concatenate([o.table(i).transform_coeff_minus_one_monomial(7) for i in range(3)]))
 
 
 @pytest.mark.parametrize("log_n,batch", [(4, 3), (11, 5), (13, 2)])

@@ -211,6 +211,14 @@ def test_add_dcrt_glev_mul_crt_poly_assign(pf, orc):
     dacc = to_dev(acc)
     pf.add_dcrt_glev_mul_crt_poly_assign_dev(dacc, to_dev(glev), to_dev(poly), ctx)
     assert np.array_equal(to_host(dacc), exp)
+    # DcrtGlev::mul_crt_poly_to (glev/dcrt.rs:45-110) overwrites: equals the accumulation into zeros
+    exp0 = np.zeros_like(acc)
+    for e in range(batch):
+        a = exp0[e * (k + 1) * W:(e + 1) * (k + 1) * W]
+        orc.add_dcrt_glev_mul_crt_poly_assign(otable, obase, obasis, k, a, glev, poly[e * W:(e + 1) * W].copy())
+    dres = to_dev(acc)  # stale contents must be overwritten
+    pf.glev_mul_crt_poly_to_dev(to_dev(glev), to_dev(poly), dres, ctx)
+    assert np.array_equal(to_host(dres), exp0)
 
 
 def test_config4_shape_vs_oracle(pf, orc):
