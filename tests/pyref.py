@@ -197,3 +197,49 @@ def external_product_coeff(moduli, n, k, gadget: Gadget, crt_glwe, key_coeff):
                     prod = negacyclic_mul([x % q for x in d], key_coeff[i][j][c][r], q)
                     out[c][r] = [(x + y) % q for x, y in zip(out[c][r], prod)]
     return out
+
+
+def ntt_fast(a, q: int, log_n: int, psi: int | None = None):
+    """Same output as ntt_direct in O(N log N): recursive splitting of Z_q[X]/(X^m - psi^e) into
+    (X^(m/2) - psi^(e/2)) and (X^(m/2) + psi^(e/2)), left factor first.  Python ints throughout."""
+    n = 1 << log_n
+    psi = psi or minimal_primitive_root(log_n + 1, q)
+    two_n = 2 * n
+
+    def rec(c, e):
+        m = len(c)
+        if m == 1:
+            return c
+        h = m // 2
+        w = pow(psi, e // 2, q)
+        t = [w * c[j + h] % q for j in range(h)]
+        lo = [(c[j] + t[j]) % q for j in range(h)]
+        hi = [(c[j] - t[j]) % q for j in range(h)]
+        return rec(lo, e // 2) + rec(hi, (e // 2 + n) % two_n)
+
+    return rec([int(x) % q for x in a], n)
+
+
+def intt_fast(v, q: int, log_n: int, psi: int | None = None):
+    """Inverse of ntt_fast (undoes each split: lo = (L+R)/2, hi = (L-R)/(2w))."""
+    n = 1 << log_n
+    psi = psi or minimal_primitive_root(log_n + 1, q)
+    two_n = 2 * n
+    half = pow(2, -1, q)
+
+    def rec(c, e):
+        m = len(c)
+        if m == 1:
+            return c
+        h = m // 2
+        L, R = rec(c[:h], e // 2), rec(c[h:], (e // 2 + n) % two_n)
+        winv = pow(psi, -(e // 2), q) * half % q
+        return [(x + y) * half % q for x, y in zip(L, R)] + [(x - y) * winv % q for x, y in zip(L, R)]
+
+    return rec([int(x) for x in v], n)
+
+
+def negacyclic_mul_fast(a, b, q: int, log_n: int):
+    psi = minimal_primitive_root(log_n + 1, q)
+    fa, fb = ntt_fast(a, q, log_n, psi), ntt_fast(b, q, log_n, psi)
+    return intt_fast([x * y % q for x, y in zip(fa, fb)], q, log_n, psi)
