@@ -306,6 +306,97 @@ const char *pfhe_dcrt_transform_pass_name(const pfhe_dcrt *table, int inverse, i
 int pfhe_dcrt_transform_pass_dev(const pfhe_dcrt *table, uint64_t *poly_dev, size_t len, int inverse,
                                  int index, int lazy, void *stream);
 
+/* =====================================================================================
+ * u32 tables — U32NttTable (primus_ntt/src/ntt/prime32/table.rs:37-91, NttTable impl :184-470)
+ * and U32DcrtTable (primus_ntt/src/dcrt/prime32.rs:11-128).  Same contracts as the 64-bit
+ * tables with uint32_t words; q < 2^30 (table.rs:195-200 -> PFHE_ERR_MODULUS_TOO_LARGE).
+ * Butterflies are the reference's Barrett-32 ones (prime32/scalar/arithmetic.rs:16-51).
+ * ===================================================================================== */
+typedef struct pfhe_ntt32 pfhe_ntt32;
+
+/* NttTable::new — prime32/table.rs:184-333 */
+int pfhe_ntt32_create(uint32_t log_n, uint32_t modulus, int device, pfhe_ntt32 **out);
+void pfhe_ntt32_destroy(pfhe_ntt32 *table);
+/* getters — table.rs:103-137 */
+size_t pfhe_ntt32_poly_length(const pfhe_ntt32 *table);
+uint32_t pfhe_ntt32_log_n(const pfhe_ntt32 *table);
+uint32_t pfhe_ntt32_modulus(const pfhe_ntt32 *table);
+uint32_t pfhe_ntt32_root(const pfhe_ntt32 *table);
+uint32_t pfhe_ntt32_inv_root(const pfhe_ntt32 *table);
+uint32_t pfhe_ntt32_inv_n(const pfhe_ntt32 *table);
+int pfhe_ntt32_device(const pfhe_ntt32 *table);
+/* transform_slice / inverse_transform_slice / lazy_* — table.rs:356-374 (host pointers) */
+int pfhe_ntt32_transform_slice(const pfhe_ntt32 *table, uint32_t *poly, size_t len);
+int pfhe_ntt32_inverse_transform_slice(const pfhe_ntt32 *table, uint32_t *values, size_t len);
+int pfhe_ntt32_lazy_transform_slice(const pfhe_ntt32 *table, uint32_t *poly, size_t len);
+int pfhe_ntt32_lazy_inverse_transform_slice(const pfhe_ntt32 *table, uint32_t *values, size_t len);
+/* transform_monomial / transform_coeff_one_monomial / transform_coeff_minus_one_monomial —
+ * table.rs:376-470 */
+int pfhe_ntt32_transform_monomial(const pfhe_ntt32 *table, uint32_t coeff, size_t degree,
+                                  uint32_t *values, size_t len);
+int pfhe_ntt32_transform_coeff_one_monomial(const pfhe_ntt32 *table, size_t degree,
+                                            uint32_t *values, size_t len);
+int pfhe_ntt32_transform_coeff_minus_one_monomial(const pfhe_ntt32 *table, size_t degree,
+                                                  uint32_t *values, size_t len);
+/* device-pointer variants */
+int pfhe_ntt32_transform_dev(const pfhe_ntt32 *table, uint32_t *poly_dev, size_t len, int lazy,
+                             void *stream);
+int pfhe_ntt32_inverse_transform_dev(const pfhe_ntt32 *table, uint32_t *values_dev, size_t len,
+                                     int lazy, void *stream);
+int pfhe_ntt32_transform_monomial_dev(const pfhe_ntt32 *table, uint32_t coeff, size_t degree,
+                                      uint32_t *values_dev, size_t len, void *stream);
+/* NttPolynomial<u32>::mul_assign / add_mul_assign (primus_poly/src/ntt/mul.rs:84-90,
+ * ntt/mod.rs:101-112 with BarrettModulus<u32>) */
+int pfhe_ntt32_mul_assign_dev(const pfhe_ntt32 *table, uint32_t *a_dev, size_t len_a,
+                              const uint32_t *b_dev, size_t len_b, void *stream);
+int pfhe_ntt32_add_mul_assign_dev(const pfhe_ntt32 *table, uint32_t *acc_dev,
+                                  const uint32_t *a_dev, size_t len_a, const uint32_t *b_dev,
+                                  size_t len_b, void *stream);
+
+typedef struct pfhe_dcrt32 pfhe_dcrt32;
+
+/* DcrtTable::new — dcrt/prime32.rs:24-43 */
+int pfhe_dcrt32_create(uint32_t log_n, const uint32_t *moduli, size_t moduli_count, int device,
+                       pfhe_dcrt32 **out);
+void pfhe_dcrt32_destroy(pfhe_dcrt32 *table);
+size_t pfhe_dcrt32_poly_length(const pfhe_dcrt32 *table);     /* dcrt/prime32.rs:56 */
+size_t pfhe_dcrt32_moduli_count(const pfhe_dcrt32 *table);    /* :61 */
+size_t pfhe_dcrt32_crt_poly_length(const pfhe_dcrt32 *table); /* :66 */
+int pfhe_dcrt32_device(const pfhe_dcrt32 *table);
+uint32_t pfhe_dcrt32_modulus(const pfhe_dcrt32 *table, size_t i);
+uint32_t pfhe_dcrt32_root(const pfhe_dcrt32 *table, size_t i);
+/* transform_slice / inverse_transform_slice / lazy_* — dcrt/prime32.rs:96-127 */
+int pfhe_dcrt32_transform_slice(const pfhe_dcrt32 *table, uint32_t *poly, size_t len);
+int pfhe_dcrt32_inverse_transform_slice(const pfhe_dcrt32 *table, uint32_t *poly, size_t len);
+int pfhe_dcrt32_lazy_transform_slice(const pfhe_dcrt32 *table, uint32_t *poly, size_t len);
+int pfhe_dcrt32_lazy_inverse_transform_slice(const pfhe_dcrt32 *table, uint32_t *poly, size_t len);
+/* DcrtTable::transform_monomial & co — dcrt/mod.rs:107-134 */
+int pfhe_dcrt32_transform_monomial(const pfhe_dcrt32 *table, uint32_t coeff, size_t degree,
+                                   uint32_t *values, size_t len);
+int pfhe_dcrt32_transform_coeff_one_monomial(const pfhe_dcrt32 *table, size_t degree,
+                                             uint32_t *values, size_t len);
+int pfhe_dcrt32_transform_coeff_minus_one_monomial(const pfhe_dcrt32 *table, size_t degree,
+                                                   uint32_t *values, size_t len);
+int pfhe_dcrt32_transform_dev(const pfhe_dcrt32 *table, uint32_t *poly_dev, size_t len, int lazy,
+                              void *stream);
+int pfhe_dcrt32_inverse_transform_dev(const pfhe_dcrt32 *table, uint32_t *poly_dev, size_t len,
+                                      int lazy, void *stream);
+/* DcrtPolynomial<u32>::mul_assign / add_mul_assign — primus_poly/src/dcrt/mul.rs:176-187,
+ * dcrt/mod.rs:105-123 */
+int pfhe_dcrt32_mul_assign_dev(const pfhe_dcrt32 *table, uint32_t *a_dev, size_t len_a,
+                               const uint32_t *b_dev, size_t len_b, void *stream);
+int pfhe_dcrt32_add_mul_assign_dev(const pfhe_dcrt32 *table, uint32_t *acc_dev,
+                                   const uint32_t *a_dev, size_t len_a, const uint32_t *b_dev,
+                                   size_t len_b, void *stream);
+/* synthetic residues: word i = floor(splitmix64(seed, i) * q_limb(i) / 2^64) */
+int pfhe_dcrt32_fill_uniform_dev(const pfhe_dcrt32 *table, uint32_t *dst_dev, size_t len,
+                                 uint64_t seed, void *stream);
+/* profiling hooks (one kernel launch per pass), as pfhe_dcrt_transform_pass_dev */
+int pfhe_dcrt32_transform_num_passes(const pfhe_dcrt32 *table);
+const char *pfhe_dcrt32_transform_pass_name(const pfhe_dcrt32 *table, int inverse, int index);
+int pfhe_dcrt32_transform_pass_dev(const pfhe_dcrt32 *table, uint32_t *poly_dev, size_t len,
+                                   int inverse, int index, int lazy, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _u64p = C.POINTER(C.c_uint64)
 _u8p = C.POINTER(C.c_uint8)
+_u32p = C.POINTER(C.c_uint32)
 
 
 def build(native: bool = False, out_dir: str | None = None) -> str:
@@ -82,6 +83,25 @@ def _load(path: str | None = None) -> C.CDLL:
     sig("orc_uint_ntt_new", ci, u32, u64, C.POINTER(vp))
     sig("orc_uint_ntt_free", None, vp)
     sig("orc_uint_ntt_transform_monomial", None, vp, u64, sz, _u64p)
+
+    sig("orc_u32_mul_mod_lazy", u32, u32, u32, u32, u32)
+    sig("orc_u32_ntt_new", ci, u32, u32, C.POINTER(vp))
+    sig("orc_u32_ntt_free", None, vp)
+    sig("orc_u32_ntt_n", sz, vp)
+    for g in ("modulus", "root", "inv_root", "inv_n", "inv_n_w"):
+        sig("orc_u32_ntt_" + g, u32, vp)
+    for g in ("roots", "inv_roots"):
+        sig("orc_u32_ntt_" + g, _u32p, vp)
+    sig("orc_u32_ntt_scalar_forward", None, vp, _u32p, u32)
+    sig("orc_u32_ntt_scalar_inverse", None, vp, _u32p, u32)
+    for g in ("transform_slice", "inverse_transform_slice", "lazy_transform_slice",
+              "lazy_inverse_transform_slice"):
+        sig("orc_u32_ntt_" + g, None, vp, _u32p)
+    sig("orc_u32_ntt_transform_monomial", None, vp, u32, sz, _u32p)
+    sig("orc_u32_ntt_transform_coeff_one_monomial", None, vp, sz, _u32p)
+    sig("orc_u32_ntt_transform_coeff_minus_one_monomial", None, vp, sz, _u32p)
+    sig("orc_u32_reduce_mul_slice_assign", None, u32, _u32p, _u32p, sz)
+    sig("orc_u32_reduce_add_mul_slice_assign", None, u32, _u32p, _u32p, _u32p, sz)
 
     sig("orc_dcrt_new", ci, u32, _u64p, sz, C.POINTER(vp))
     sig("orc_dcrt_free", None, vp)
@@ -247,6 +267,113 @@ class U64NttTable:
         out = np.empty(self.n, np.uint64)
         lib().orc_u64_ntt_transform_coeff_minus_one_monomial(self._h, degree, _p(out))
         return out
+
+
+def _p32(a: np.ndarray):
+    assert a.dtype == np.uint32 and a.flags.c_contiguous
+    return a.ctypes.data_as(_u32p)
+
+
+class U32NttTable:
+    """primus_ntt::U32NttTable, scalar backend (prime32/table.rs, prime32/scalar/transform.rs)."""
+
+    def __init__(self, log_n: int, q: int):
+        h = C.c_void_p()
+        rc = lib().orc_u32_ntt_new(log_n, q, C.byref(h))
+        if rc:
+            raise OracleError(rc)
+        self._h = h
+        self.n = 1 << log_n
+        self.log_n = log_n
+        self.q = q
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_u32_ntt_free(self._h)
+            self._h = None
+
+    root = property(lambda s: int(lib().orc_u32_ntt_root(s._h)))
+    inv_root = property(lambda s: int(lib().orc_u32_ntt_inv_root(s._h)))
+    inv_n = property(lambda s: int(lib().orc_u32_ntt_inv_n(s._h)))
+    inv_n_w = property(lambda s: int(lib().orc_u32_ntt_inv_n_w(s._h)))
+    roots = property(lambda s: np.ctypeslib.as_array(lib().orc_u32_ntt_roots(s._h), (s.n,)).copy())
+    inv_roots = property(lambda s: np.ctypeslib.as_array(lib().orc_u32_ntt_inv_roots(s._h), (s.n,)).copy())
+
+    def _each(self, fn, a: np.ndarray):
+        assert a.dtype == np.uint32 and a.flags.c_contiguous and a.size % self.n == 0
+        flat = a.reshape(-1)
+        base = flat.ctypes.data
+        for i in range(flat.size // self.n):
+            fn(self._h, C.cast(base + 4 * self.n * i, _u32p))
+
+    def transform_slice(self, a): self._each(lib().orc_u32_ntt_transform_slice, a)
+    def inverse_transform_slice(self, a): self._each(lib().orc_u32_ntt_inverse_transform_slice, a)
+    def lazy_transform_slice(self, a): self._each(lib().orc_u32_ntt_lazy_transform_slice, a)
+    def lazy_inverse_transform_slice(self, a): self._each(lib().orc_u32_ntt_lazy_inverse_transform_slice, a)
+
+    def transform_monomial(self, coeff, degree):
+        out = np.empty(self.n, np.uint32)
+        lib().orc_u32_ntt_transform_monomial(self._h, coeff, degree, _p32(out))
+        return out
+
+    def transform_coeff_one_monomial(self, degree):
+        out = np.empty(self.n, np.uint32)
+        lib().orc_u32_ntt_transform_coeff_one_monomial(self._h, degree, _p32(out))
+        return out
+
+    def transform_coeff_minus_one_monomial(self, degree):
+        out = np.empty(self.n, np.uint32)
+        lib().orc_u32_ntt_transform_coeff_minus_one_monomial(self._h, degree, _p32(out))
+        return out
+
+    def mul_assign(self, a, b):
+        lib().orc_u32_reduce_mul_slice_assign(self.q, _p32(a), _p32(b), a.size)
+
+    def add_mul_assign(self, acc, a, b):
+        lib().orc_u32_reduce_add_mul_slice_assign(self.q, _p32(acc), _p32(a), _p32(b), a.size)
+
+
+class U32DcrtTable:
+    """primus_ntt::U32DcrtTable (dcrt/prime32.rs): one U32NttTable per limb, modulus-major data."""
+
+    def __init__(self, log_n: int, moduli):
+        self.moduli = [int(m) for m in moduli]
+        self.tables = [U32NttTable(log_n, q) for q in self.moduli]
+        self.log_n, self.n, self.count = log_n, 1 << log_n, len(self.moduli)
+        self.crt_poly_length = self.n * self.count
+
+    def _each(self, name, a):
+        assert a.size % self.crt_poly_length == 0
+        v = a.reshape(-1, self.count, self.n)
+        for e in range(v.shape[0]):
+            for r, t in enumerate(self.tables):
+                getattr(t, name)(v[e, r])
+
+    def transform_slice(self, a): self._each("transform_slice", a)
+    def inverse_transform_slice(self, a): self._each("inverse_transform_slice", a)
+    def lazy_transform_slice(self, a): self._each("lazy_transform_slice", a)
+    def lazy_inverse_transform_slice(self, a): self._each("lazy_inverse_transform_slice", a)
+
+    def mul_assign(self, a, b):
+        va, vb = a.reshape(-1, self.count, self.n), b.reshape(-1, self.count, self.n)
+        for e in range(va.shape[0]):
+            for r, t in enumerate(self.tables):
+                t.mul_assign(va[e, r], vb[e if vb.shape[0] > 1 else 0, r])
+
+    def add_mul_assign(self, acc, a, b):
+        vc, va, vb = (x.reshape(-1, self.count, self.n) for x in (acc, a, b))
+        for e in range(va.shape[0]):
+            for r, t in enumerate(self.tables):
+                t.add_mul_assign(vc[e, r], va[e, r], vb[e if vb.shape[0] > 1 else 0, r])
+
+    def transform_monomial(self, coeff, degree):
+        return np.concatenate([t.transform_monomial(coeff, degree) for t in self.tables])
+
+    def transform_coeff_one_monomial(self, degree):
+        return np.concatenate([t.transform_coeff_one_monomial(degree) for t in self.tables])
+
+    def transform_coeff_minus_one_monomial(self, degree):
+        return np.concatenate([t.transform_coeff_minus_one_monomial(degree) for t in self.tables])
 
 
 class UintNttTable:

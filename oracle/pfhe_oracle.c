@@ -447,6 +447,202 @@ void orc_u64_ntt_transform_coeff_minus_one_monomial(const orc_u64_ntt *t, size_t
 }
 
 /* ========================================================================== */
+/* U32NttTable — primus_ntt/src/ntt/prime32/{table.rs, scalar/arithmetic.rs, scalar/transform.rs} */
+/* ========================================================================== */
+
+/* arithmetic.rs:3-6 */
+static inline uint32_t reduce_once32(uint32_t x, uint32_t q) { uint32_t d = x - q; return x < d ? x : d; }
+/* arithmetic.rs:10-13 */
+static inline uint32_t reduce_twice32(uint32_t x, uint32_t q, uint32_t two_q) { return reduce_once32(reduce_once32(x, two_q), q); }
+/* arithmetic.rs:16-20 */
+uint32_t orc_u32_mul_mod_lazy(uint32_t y, uint32_t w, uint32_t w_precon, uint32_t q) {
+    uint32_t qhat = (uint32_t)(((uint64_t)y * (uint64_t)w_precon) >> 32);
+    return w * y - q * qhat;
+}
+/* arithmetic.rs:23-36 */
+static inline void fwd_butterfly32(uint32_t *x, uint32_t *y, uint32_t w, uint32_t wp, uint32_t q, uint32_t two_q) {
+    uint32_t tx = reduce_once32(*x, two_q);
+    uint32_t ty = orc_u32_mul_mod_lazy(*y, w, wp, q);
+    *x = tx + ty;
+    *y = tx + two_q - ty;
+}
+/* arithmetic.rs:39-51 */
+static inline void inv_butterfly32(uint32_t *x, uint32_t *y, uint32_t w, uint32_t wp, uint32_t q, uint32_t two_q) {
+    uint32_t tx = *x + *y;
+    uint32_t ty = *x + two_q - *y;
+    *x = reduce_once32(tx, two_q);
+    *y = orc_u32_mul_mod_lazy(ty, w, wp, q);
+}
+/* ShoupFactor::<u32>::quotient_for: floor(w * 2^32 / q) (shoup_factor/mod.rs:39,65-67) */
+static inline uint32_t shoup_quotient32(uint32_t w, uint32_t q) { return (uint32_t)(((uint64_t)w << 32) / q); }
+
+struct orc_u32_ntt {
+    size_t n;
+    uint32_t log_n, q, two_q, root, inv_root;
+    uint32_t inv_n, inv_n_precon, inv_n_w, inv_n_w_precon;
+    uint32_t *roots, *roots_precon, *inv_roots, *inv_roots_precon;
+    uint32_t *ordinal_roots; /* 2n */
+    size_t *rev;
+};
+
+/* table.rs:184-333 */
+int orc_u32_ntt_new(uint32_t log_n, uint32_t q, orc_u32_ntt **out) {
+    uint64_t root64;
+    int rc = orc_minimal_primitive_root(log_n + 1, q, &root64); /* :189 */
+    if (rc) return rc;
+    if (q >= (1u << 30)) return ORC_ERR_MODULUS_TOO_LARGE; /* :195-200 */
+    const uint32_t root = (uint32_t)root64;
+
+    orc_u32_ntt *t = (orc_u32_ntt *)calloc(1, sizeof(*t));
+    const size_t n = (size_t)1 << log_n;
+    t->n = n; t->log_n = log_n; t->q = q; t->two_q = q << 1; t->root = root;
+    t->ordinal_roots = (uint32_t *)malloc(2 * n * sizeof(uint32_t));
+    t->roots = (uint32_t *)calloc(n, sizeof(uint32_t));
+    t->roots_precon = (uint32_t *)calloc(n, sizeof(uint32_t));
+    t->inv_roots = (uint32_t *)calloc(n, sizeof(uint32_t));
+    t->inv_roots_precon = (uint32_t *)calloc(n, sizeof(uint32_t));
+    t->rev = (size_t *)malloc(n * sizeof(size_t));
+
+    /* :205-214 ordinal powers by ShoupFactor::factor_mul_modulo */
+    const uint32_t root_p = shoup_quotient32(root, q);
+    t->ordinal_roots[0] = 1;
+    if (2 * n > 1) t->ordinal_roots[1] = root;
+    uint32_t power = root;
+    for (size_t i = 2; i < 2 * n; ++i) {
+        power = reduce_once32(orc_u32_mul_mod_lazy(power, root, root_p, q), q);
+        t->ordinal_roots[i] = power;
+    }
+    t->inv_root = t->ordinal_roots[2 * n - 1]; /* :216 */
+    for (size_t i = 0; i < n; ++i) t->rev[i] = reverse_lsbs(i, log_n); /* :220 */
+    t->roots[0] = 1;
+    for (size_t i = 0; i < n; ++i) t->roots[t->rev[i]] = t->ordinal_roots[i]; /* :223-227 */
+    t->inv_roots[0] = 1;
+    for (size_t i = 0; i + 1 < n; ++i) t->inv_roots[t->rev[i] + 1] = t->ordinal_roots[2 * n - 1 - i]; /* :230-234 */
+    for (size_t i = 0; i < n; ++i) { /* :237-250 */
+        t->roots_precon[i] = shoup_quotient32(t->roots[i], q);
+        t->inv_roots_precon[i] = shoup_quotient32(t->inv_roots[i], q);
+    }
+    t->inv_n = (uint32_t)orc_inv_mod((uint64_t)(n % q), q); /* :253 (mod_inv via xgcd) */
+    t->inv_n_precon = shoup_quotient32(t->inv_n, q);
+    const uint32_t last_w = t->inv_roots[n - 1]; /* :257-259 */
+    t->inv_n_w = reduce_once32(orc_u32_mul_mod_lazy(last_w, t->inv_n, t->inv_n_precon, q), q);
+    t->inv_n_w_precon = (uint32_t)(((uint64_t)t->inv_n_w << 32) / q);
+    *out = t;
+    return ORC_OK;
+}
+
+void orc_u32_ntt_free(orc_u32_ntt *t) {
+    if (!t) return;
+    free(t->roots); free(t->roots_precon); free(t->inv_roots); free(t->inv_roots_precon);
+    free(t->ordinal_roots); free(t->rev); free(t);
+}
+
+size_t orc_u32_ntt_n(const orc_u32_ntt *t) { return t->n; }
+uint32_t orc_u32_ntt_modulus(const orc_u32_ntt *t) { return t->q; }
+uint32_t orc_u32_ntt_root(const orc_u32_ntt *t) { return t->root; }
+uint32_t orc_u32_ntt_inv_root(const orc_u32_ntt *t) { return t->inv_root; }
+uint32_t orc_u32_ntt_inv_n(const orc_u32_ntt *t) { return t->inv_n; }
+uint32_t orc_u32_ntt_inv_n_w(const orc_u32_ntt *t) { return t->inv_n_w; }
+const uint32_t *orc_u32_ntt_roots(const orc_u32_ntt *t) { return t->roots; }
+const uint32_t *orc_u32_ntt_inv_roots(const orc_u32_ntt *t) { return t->inv_roots; }
+
+/* scalar/transform.rs:13-140; the t = 8/4/2/1 arms are unrolled forms of the generic arm */
+void orc_u32_ntt_scalar_forward(const orc_u32_ntt *tb, uint32_t *values, uint32_t output_mod_factor) {
+    const size_t n = tb->n;
+    const uint32_t q = tb->q, two_q = tb->two_q;
+    size_t ri = 1, t = n >> 1, m = 1;
+    while (m < n) {
+        for (size_t c = 0; c < n; c += 2 * t) {
+            const uint32_t w = tb->roots[ri], wp = tb->roots_precon[ri];
+            ++ri;
+            for (size_t j = 0; j < t; ++j) fwd_butterfly32(&values[c + j], &values[c + j + t], w, wp, q, two_q);
+            if (t == 1 && output_mod_factor == 1) { /* :104-114 */
+                values[c] = reduce_twice32(values[c], q, two_q);
+                values[c + 1] = reduce_twice32(values[c + 1], q, two_q);
+            }
+        }
+        t >>= 1;
+        m <<= 1;
+    }
+}
+
+/* scalar/transform.rs:152-272 */
+void orc_u32_ntt_scalar_inverse(const orc_u32_ntt *tb, uint32_t *values, uint32_t output_mod_factor) {
+    const size_t n = tb->n;
+    const uint32_t q = tb->q, two_q = tb->two_q;
+    size_t ri = 1, t = 1, m = n >> 1;
+    while (m > 1) {
+        for (size_t c = 0; c < n; c += 2 * t) {
+            const uint32_t w = tb->inv_roots[ri], wp = tb->inv_roots_precon[ri];
+            ++ri;
+            for (size_t j = 0; j < t; ++j) inv_butterfly32(&values[c + j], &values[c + j + t], w, wp, q, two_q);
+        }
+        t <<= 1;
+        m >>= 1;
+    }
+    const size_t h = n / 2; /* :253-271 */
+    for (size_t i = 0; i < h; ++i) {
+        uint32_t *x = &values[i], *y = &values[i + h];
+        uint32_t tx = reduce_once32(*x + *y, two_q);
+        uint32_t ty = *x + two_q - *y;
+        uint32_t rx = orc_u32_mul_mod_lazy(tx, tb->inv_n, tb->inv_n_precon, q);
+        uint32_t ry = orc_u32_mul_mod_lazy(ty, tb->inv_n_w, tb->inv_n_w_precon, q);
+        if (output_mod_factor == 1) { rx = reduce_once32(rx, q); ry = reduce_once32(ry, q); }
+        *x = rx; *y = ry;
+    }
+}
+
+/* table.rs:356-374 */
+void orc_u32_ntt_lazy_transform_slice(const orc_u32_ntt *t, uint32_t *p) { orc_u32_ntt_scalar_forward(t, p, 4); }
+void orc_u32_ntt_transform_slice(const orc_u32_ntt *t, uint32_t *p) { orc_u32_ntt_scalar_forward(t, p, 1); }
+void orc_u32_ntt_lazy_inverse_transform_slice(const orc_u32_ntt *t, uint32_t *v) { orc_u32_ntt_scalar_inverse(t, v, 2); }
+void orc_u32_ntt_inverse_transform_slice(const orc_u32_ntt *t, uint32_t *v) { orc_u32_ntt_scalar_inverse(t, v, 1); }
+
+/* table.rs:376-426 */
+void orc_u32_ntt_transform_monomial(const orc_u32_ntt *t, uint32_t coeff, size_t degree, uint32_t *values) {
+    const size_t n = t->n;
+    if (coeff == 0) { memset(values, 0, n * sizeof(uint32_t)); return; }
+    if (degree == 0) { for (size_t i = 0; i < n; ++i) values[i] = coeff; return; }
+    const size_t mask = (2 * n) - 1;
+    if (coeff == 1) {
+        for (size_t i = 0; i < n; ++i) values[i] = t->ordinal_roots[((2 * t->rev[i] + 1) * degree) & mask];
+    } else if (coeff == t->q - 1) {
+        for (size_t i = 0; i < n; ++i) values[i] = t->ordinal_roots[(((2 * t->rev[i] + 1) * degree) & mask) ^ n];
+    } else {
+        const uint32_t cp = shoup_quotient32(coeff, t->q);
+        for (size_t i = 0; i < n; ++i) {
+            uint32_t w = t->ordinal_roots[((2 * t->rev[i] + 1) * degree) & mask];
+            values[i] = reduce_once32(orc_u32_mul_mod_lazy(w, coeff, cp, t->q), t->q);
+        }
+    }
+}
+
+/* table.rs:428-447 */
+void orc_u32_ntt_transform_coeff_one_monomial(const orc_u32_ntt *t, size_t degree, uint32_t *values) {
+    const size_t n = t->n;
+    if (degree == 0) { for (size_t i = 0; i < n; ++i) values[i] = 1; return; }
+    const size_t mask = (2 * n) - 1;
+    for (size_t i = 0; i < n; ++i) values[i] = t->ordinal_roots[((2 * t->rev[i] + 1) * degree) & mask];
+}
+
+/* table.rs:449-470 */
+void orc_u32_ntt_transform_coeff_minus_one_monomial(const orc_u32_ntt *t, size_t degree, uint32_t *values) {
+    const size_t n = t->n;
+    if (degree == 0) { for (size_t i = 0; i < n; ++i) values[i] = t->q - 1; return; }
+    const size_t mask = (2 * n) - 1;
+    for (size_t i = 0; i < n; ++i) values[i] = t->ordinal_roots[(((2 * t->rev[i] + 1) * degree) & mask) ^ n];
+}
+
+/* Pointwise product / multiply-accumulate of NTT-domain u32 polynomials: BarrettModulus<u32>
+ * reduce_mul / reduce_mul_add return the canonical residue (barrett/ops.rs), i.e. a*b mod q. */
+void orc_u32_reduce_mul_slice_assign(uint32_t q, uint32_t *a, const uint32_t *b, size_t n) {
+    for (size_t i = 0; i < n; ++i) a[i] = (uint32_t)(((uint64_t)a[i] * b[i]) % q);
+}
+void orc_u32_reduce_add_mul_slice_assign(uint32_t q, uint32_t *acc, const uint32_t *a, const uint32_t *b, size_t n) {
+    for (size_t i = 0; i < n; ++i) acc[i] = (uint32_t)(((uint64_t)a[i] * b[i] + acc[i]) % q);
+}
+
+/* ========================================================================== */
 /* UintNttTable<u64> — primus_ntt/src/ntt/primitive.rs (the reference's own oracle) */
 /* ========================================================================== */
 

@@ -124,6 +124,31 @@ void orc_uint_ntt_transform_monomial(const orc_uint_ntt *t, uint64_t coeff, size
                                      uint64_t *values);
 
 /* ---------------- U64DcrtTable (dcrt/prime64.rs) ---------------- */
+/* ---------------- U32NttTable (prime32/table.rs, prime32/scalar/) ---------------- */
+typedef struct orc_u32_ntt orc_u32_ntt;
+uint32_t orc_u32_mul_mod_lazy(uint32_t y, uint32_t w, uint32_t w_precon, uint32_t q);
+int orc_u32_ntt_new(uint32_t log_n, uint32_t q, orc_u32_ntt **out);
+void orc_u32_ntt_free(orc_u32_ntt *t);
+size_t orc_u32_ntt_n(const orc_u32_ntt *t);
+uint32_t orc_u32_ntt_modulus(const orc_u32_ntt *t);
+uint32_t orc_u32_ntt_root(const orc_u32_ntt *t);
+uint32_t orc_u32_ntt_inv_root(const orc_u32_ntt *t);
+uint32_t orc_u32_ntt_inv_n(const orc_u32_ntt *t);
+uint32_t orc_u32_ntt_inv_n_w(const orc_u32_ntt *t);
+const uint32_t *orc_u32_ntt_roots(const orc_u32_ntt *t);
+const uint32_t *orc_u32_ntt_inv_roots(const orc_u32_ntt *t);
+void orc_u32_ntt_scalar_forward(const orc_u32_ntt *t, uint32_t *values, uint32_t output_mod_factor);
+void orc_u32_ntt_scalar_inverse(const orc_u32_ntt *t, uint32_t *values, uint32_t output_mod_factor);
+void orc_u32_ntt_transform_slice(const orc_u32_ntt *t, uint32_t *poly);
+void orc_u32_ntt_inverse_transform_slice(const orc_u32_ntt *t, uint32_t *values);
+void orc_u32_ntt_lazy_transform_slice(const orc_u32_ntt *t, uint32_t *poly);
+void orc_u32_ntt_lazy_inverse_transform_slice(const orc_u32_ntt *t, uint32_t *values);
+void orc_u32_ntt_transform_monomial(const orc_u32_ntt *t, uint32_t coeff, size_t degree, uint32_t *values);
+void orc_u32_ntt_transform_coeff_one_monomial(const orc_u32_ntt *t, size_t degree, uint32_t *values);
+void orc_u32_ntt_transform_coeff_minus_one_monomial(const orc_u32_ntt *t, size_t degree, uint32_t *values);
+void orc_u32_reduce_mul_slice_assign(uint32_t q, uint32_t *a, const uint32_t *b, size_t n);
+void orc_u32_reduce_add_mul_slice_assign(uint32_t q, uint32_t *acc, const uint32_t *a, const uint32_t *b, size_t n);
+
 typedef struct orc_dcrt orc_dcrt;
 int orc_dcrt_new(uint32_t log_n, const uint64_t *moduli, size_t count, orc_dcrt **out);
 void orc_dcrt_free(orc_dcrt *t);

@@ -131,6 +131,38 @@ def _declare(lib: C.CDLL) -> None:
     sig("pfhe_dcrt_transform_pass_name", C.c_char_p, vp, ci, ci)
     sig("pfhe_dcrt_transform_pass_dev", ci, vp, vp, sz, ci, ci, ci, vp)
 
+    # u32 tables
+    u32p = C.POINTER(u32)
+    sig("pfhe_ntt32_create", ci, u32, u32, ci, C.POINTER(vp))
+    sig("pfhe_ntt32_destroy", None, vp)
+    sig("pfhe_ntt32_poly_length", sz, vp)
+    for g in ("log_n", "modulus", "root", "inv_root", "inv_n"):
+        sig("pfhe_ntt32_" + g, u32, vp)
+    sig("pfhe_ntt32_device", ci, vp)
+    sig("pfhe_dcrt32_create", ci, u32, u32p, sz, ci, C.POINTER(vp))
+    sig("pfhe_dcrt32_destroy", None, vp)
+    for g in ("poly_length", "moduli_count", "crt_poly_length"):
+        sig("pfhe_dcrt32_" + g, sz, vp)
+    sig("pfhe_dcrt32_device", ci, vp)
+    for g in ("modulus", "root"):
+        sig("pfhe_dcrt32_" + g, u32, vp, sz)
+    for pre in ("pfhe_ntt32_", "pfhe_dcrt32_"):
+        for g in ("transform_slice", "inverse_transform_slice", "lazy_transform_slice",
+                  "lazy_inverse_transform_slice"):
+            sig(pre + g, ci, vp, vp, sz)
+        sig(pre + "transform_monomial", ci, vp, u32, sz, vp, sz)
+        sig(pre + "transform_coeff_one_monomial", ci, vp, sz, vp, sz)
+        sig(pre + "transform_coeff_minus_one_monomial", ci, vp, sz, vp, sz)
+        sig(pre + "transform_dev", ci, vp, vp, sz, ci, vp)
+        sig(pre + "inverse_transform_dev", ci, vp, vp, sz, ci, vp)
+        sig(pre + "mul_assign_dev", ci, vp, vp, sz, vp, sz, vp)
+        sig(pre + "add_mul_assign_dev", ci, vp, vp, vp, sz, vp, sz, vp)
+    sig("pfhe_ntt32_transform_monomial_dev", ci, vp, u32, sz, vp, sz, vp)
+    sig("pfhe_dcrt32_fill_uniform_dev", ci, vp, vp, sz, u64, vp)
+    sig("pfhe_dcrt32_transform_num_passes", ci, vp)
+    sig("pfhe_dcrt32_transform_pass_name", C.c_char_p, vp, ci, ci)
+    sig("pfhe_dcrt32_transform_pass_dev", ci, vp, vp, sz, ci, ci, ci, vp)
+
 
 def lib() -> C.CDLL:
     """Load libpfhe_hip.so.  Fails loudly when it has not been built — there is no fallback."""

@@ -62,8 +62,14 @@ int build_host_table(u32 log_n, u64 q, HostTable &out) {
     }
     u64 psi = 0;
     // NttTable::new searches the root first (table.rs:312), then rejects q >= 2^62 (:318-323).
-    PFHE_TRY(minimal_root_of_unity(log_n + 1, q, psi));
-    if (q >= (1ull << 62)) return PFHE_ERR_MODULUS_TOO_LARGE;
+    if (int rc = minimal_root_of_unity(log_n + 1, q, psi)) {
+        set_last_error("there is no primitive 2N-th root of unity modulo this modulus");
+        return rc;
+    }
+    if (q >= (1ull << 62)) {
+        set_last_error("modulus is too large for a u64 NTT table (max 62 bits)");
+        return PFHE_ERR_MODULUS_TOO_LARGE;
+    }
 
     const size_t n = (size_t)1 << log_n;
     out.log_n = log_n;

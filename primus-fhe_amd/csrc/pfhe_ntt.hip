@@ -18,8 +18,9 @@
 // distance 2^p) the twiddle index of a forward butterfly is (N + E) >> (p + 1) and of an inverse
 // butterfly 1 + N - (N >> p) + (E >> (p + 1)).
 //
-// Every kernel is instantiated for two arithmetic policies (pfhe_ntt_device.hpp): ShoupArith for
-// arbitrary q < 2^62 and PmArith for pseudo-Mersenne primes q = 2^K - c.
+// Every kernel is instantiated for three arithmetic policies (pfhe_ntt_device.hpp): ShoupArith for
+// arbitrary q < 2^62, PmArith for pseudo-Mersenne primes q = 2^K - c, and B32Arith for the u32
+// tables (q < 2^30), where a 64-bit word carries two adjacent u32 coefficients.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -52,7 +53,7 @@ __global__ void ntt_tiny_kernel(u64 *__restrict__ data, const NttPrime *__restri
             }
         }
         if (!lazy && log_n > 0)
-            for (u32 e = 0; e < n; ++e) x[e] = csub(csub(x[e], ar.two_q), ar.q);
+            for (u32 e = 0; e < n; ++e) x[e] = ar.reduce_4q(x[e]);
     } else {
         for (u32 p = 0; p + 1 < log_n; ++p) {
             for (u32 e = 0; e < n; ++e) {
@@ -333,13 +334,17 @@ void ntt_pass_name(u32 log_n, bool inverse, int index, char *buf, size_t cap) {
     }
 }
 
-int ntt_pass_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u64 *data, u64 npolys, bool inverse, int index,
+int ntt_pass_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, bool inverse, int index,
                  bool lazy, hipStream_t s) {
     const NttPlan plan = make_ntt_plan(log_n);
     if (index < 0 || index >= ntt_num_passes(log_n)) return PFHE_ERR_BAD_ARGUMENT;
+    if (arith == kArithB32) {
+        if (plan.tiny) return PFHE_ERR_UNSUPPORTED;  // N <= 16 is served by ntt32_tiny_kernel
+        return run_pass<B32Arith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s);
+    }
     if (plan.tiny) return launch_tiny(inverse, primes, L, log_n, data, npolys, lazy, s);
-    return pm ? run_pass<PmArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s)
-              : run_pass<ShoupArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s);
+    return arith == kArithPm ? run_pass<PmArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s)
+                             : run_pass<ShoupArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -396,7 +401,7 @@ void release_overlap_ctx(int dev, OverlapCtx *c) {
 
 }  // namespace
 
-static int transform(const NttPrime *primes, u32 L, u32 log_n, bool pm, u64 *data, u64 npolys, bool inverse,
+static int transform(const NttPrime *primes, u32 L, u32 log_n, int pm, u64 *data, u64 npolys, bool inverse,
                      bool lazy, hipStream_t s) {
     const int passes = ntt_num_passes(log_n);
     const u64 bytes = (npolys << log_n) * sizeof(u64);
@@ -438,14 +443,80 @@ static int transform(const NttPrime *primes, u32 L, u32 log_n, bool pm, u64 *dat
     return rc;
 }
 
-int ntt_forward_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u64 *data, u64 npolys, bool lazy,
+int ntt_forward_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, bool lazy,
                     hipStream_t s) {
-    return transform(primes, L, log_n, pm, data, npolys, false, lazy, s);
+    return transform(primes, L, log_n, arith, data, npolys, false, lazy, s);
 }
 
-int ntt_inverse_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u64 *data, u64 npolys, bool lazy,
+int ntt_inverse_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, bool lazy,
                     hipStream_t s) {
-    return transform(primes, L, log_n, pm, data, npolys, true, lazy, s);
+    return transform(primes, L, log_n, arith, data, npolys, true, lazy, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// u32 tables (U32NttTable, prime32/table.rs): N <= 16 runs the reference's loop nest with one
+// thread per polynomial (scalar/transform.rs:13-273); larger N view the data as N/2 64-bit words
+// (two adjacent coefficients each) and run the word kernels above with B32Arith.
+// ------------------------------------------------------------------------------------------
+template <bool INV>
+__global__ void ntt32_tiny_kernel(u32 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L, u32 log_n,
+                                  u64 npolys, u32 lazy) {
+    u64 pid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pid >= npolys) return;
+    const B32Arith ar(primes + pid % L);
+    const u32 n = 1u << log_n, two_q = ar.two_q32;
+    u32 *x = data + pid * n;
+    if (!INV) {
+        for (u32 p = log_n; p-- > 0;) {
+            for (u32 e = 0; e < n; ++e) {
+                if (e & (1u << p)) continue;
+                const u32 f = e | (1u << p);
+                const B32Arith::Tw w = ar.fwd_tw((n + e) >> (p + 1));
+                const u32 tx = B32Arith::once(x[e], two_q), t = ar.mul1(x[f], w);
+                x[e] = tx + t;
+                x[f] = tx + two_q - t;
+            }
+        }
+        if (!lazy)
+            for (u32 e = 0; e < n; ++e) x[e] = B32Arith::once(B32Arith::once(x[e], two_q), ar.q);
+    } else {
+        const GCWordPtr inv = ar.inv - (n >> 1);  // NttPrime::inv_w is biased by N/2 entries
+        for (u32 p = 0; p + 1 < log_n; ++p) {
+            for (u32 e = 0; e < n; ++e) {
+                if (e & (1u << p)) continue;
+                const u32 f = e | (1u << p);
+                const B32Arith::Tw w = B32Arith::unpack(inv[1 + n - (n >> p) + (e >> (p + 1))]);
+                const u32 a = x[e], b = x[f];
+                x[e] = B32Arith::once(a + b, two_q);
+                x[f] = ar.mul1(a + two_q - b, w);
+            }
+        }
+        const u32 h = n >> 1;
+        for (u32 e = 0; e < h; ++e) {  // scalar/transform.rs:253-271
+            const u32 a = x[e], b = x[e + h];
+            u32 rx = ar.mul1(B32Arith::once(a + b, two_q), ar.inv_n);
+            u32 ry = ar.mul1(a + two_q - b, ar.inv_n_w);
+            if (!lazy) {
+                rx = B32Arith::once(rx, ar.q);
+                ry = B32Arith::once(ry, ar.q);
+            }
+            x[e] = rx;
+            x[e + h] = ry;
+        }
+    }
+}
+
+int ntt32_transform_dev(const NttPrime *primes, u32 L, u32 log_n, u32 *data, u64 npolys, bool inverse, bool lazy,
+                        hipStream_t s) {
+    if (log_n == 0 || npolys == 0) return PFHE_OK;  // N = 1: the reference's loops do not execute
+    if (log_n <= 4) {
+        const dim3 g((u32)((npolys + 255) / 256)), t(256);
+        if (inverse) hipLaunchKernelGGL(ntt32_tiny_kernel<true>, g, t, 0, s, data, primes, L, log_n, npolys, lazy ? 1u : 0u);
+        else hipLaunchKernelGGL(ntt32_tiny_kernel<false>, g, t, 0, s, data, primes, L, log_n, npolys, lazy ? 1u : 0u);
+        PFHE_HIP(hipGetLastError());
+        return PFHE_OK;
+    }
+    return transform(primes, L, log_n - 1, kArithB32, reinterpret_cast<u64 *>(data), npolys, inverse, lazy, s);
 }
 
 }  // namespace pfhe

@@ -17,15 +17,22 @@ struct NttPlan {
 };
 NttPlan make_ntt_plan(u32 log_n);
 
-// `pm` selects the pseudo-Mersenne arithmetic (every prime of the table qualifies, NttPrime::pm_k)
-int ntt_forward_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u64 *data, u64 npolys, bool lazy,
+// `arith` selects the arithmetic policy: kArithShoup (any q < 2^62), kArithPm (every prime of the
+// table has the pseudo-Mersenne shape, NttPrime::pm_k) or kArithB32 (32-bit tables: `data` holds
+// pairs of u32 coefficients and log_n counts 64-bit WORDS, i.e. log2(N) - 1).  A bool converts to
+// the first two.
+enum : int { kArithShoup = 0, kArithPm = 1, kArithB32 = 2 };
+int ntt_forward_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, bool lazy,
                     hipStream_t s);
-int ntt_inverse_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u64 *data, u64 npolys, bool lazy,
+int ntt_inverse_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, bool lazy,
                     hipStream_t s);
+// U32NttTable / U32DcrtTable transforms (log_n = log2 of the polynomial length in coefficients)
+int ntt32_transform_dev(const NttPrime *primes, u32 L, u32 log_n, u32 *data, u64 npolys, bool inverse, bool lazy,
+                        hipStream_t s);
 
 int ntt_num_passes(u32 log_n);
 void ntt_pass_name(u32 log_n, bool inverse, int index, char *buf, size_t cap);
-int ntt_pass_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u64 *data, u64 npolys, bool inverse,
+int ntt_pass_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, bool inverse,
                  int index, bool lazy, hipStream_t s);
 
 #if defined(__HIPCC__)
@@ -81,6 +88,9 @@ struct ShoupArith {
     __device__ __forceinline__ u64 mul_lazy(u64 y, Tw t) const { return t.w * y - q * mulhi64(t.wp, y); }
     // x in [0,4q) -> [0,2q)
     __device__ __forceinline__ u64 reduce_x(u64 x) const { return csub(x, two_q); }
+    __device__ __forceinline__ u64 reduce_2q(u64 x) const { return csub(x, q); }              // [0,2q) -> [0,q)
+    __device__ __forceinline__ u64 reduce_4q(u64 x) const { return csub(csub(x, two_q), q); }  // [0,4q) -> [0,q)
+    static constexpr bool kPacked = false;
 };
 
 struct PmArith {
@@ -125,6 +135,60 @@ struct PmArith {
         const u64 low = ((u64)(x1 & mask) << 32) | (u32)x;
         return (u64)(x1 >> sh) * c + low;
     }
+    __device__ __forceinline__ u64 reduce_2q(u64 x) const { return csub(x, q); }
+    __device__ __forceinline__ u64 reduce_4q(u64 x) const { return csub(csub(x, two_q), q); }
+    static constexpr bool kPacked = false;
+};
+
+// B32Arith — the u32 tables (U32NttTable, q < 2^30): a 64-bit word carries the two adjacent
+//   coefficients 2i (low half) and 2i+1 (high half), so that every kernel written for 64-bit words
+//   moves and shuffles u32 data at full width.  All stages with butterfly distance >= 2 pair word
+//   with word and use one twiddle for both halves; the distance-1 stage is the extra "intra-word"
+//   stage of the block pass.  Arithmetic is the reference's Barrett-32 lazy multiply
+//   (prime32/scalar/arithmetic.rs:16-51) on each half; packed additions never carry across the
+//   halves because every lazy value is < 4q < 2^32.
+//   Twiddle tables hold {w, floor(w*2^32/q)} as one 64-bit entry.  In word units the forward index
+//   formula is unchanged; the inverse one is off by N/2, which NttPrime::inv_w already includes.
+struct B32Arith {
+    struct Tw {
+        u32 w, wp;
+    };
+    u32 q, two_q32;
+    u64 two_q;  // 2q in both halves
+    GCWordPtr fwd, inv;
+    Tw inv_n, inv_n_w;
+    static constexpr bool kPacked = true;
+
+    __device__ __forceinline__ explicit B32Arith(const NttPrime *__restrict__ P)
+        : q((u32)P->q), two_q32((u32)P->two_q), two_q(P->two_q | (P->two_q << 32)),
+          fwd((GCWordPtr)(const void *)P->fwd_w), inv((GCWordPtr)(const void *)P->inv_w),
+          inv_n{(u32)P->inv_n, (u32)P->inv_n_p}, inv_n_w{(u32)P->inv_n_w, (u32)P->inv_n_w_p} {}
+    static __device__ __forceinline__ Tw unpack(u64 v) { return Tw{(u32)v, (u32)(v >> 32)}; }
+    static __device__ __forceinline__ u64 pack(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
+    __device__ __forceinline__ Tw fwd_tw(u32 i) const { return unpack(fwd[i]); }
+    __device__ __forceinline__ Tw inv_tw(u32 i) const { return unpack(inv[i]); }
+    __device__ __forceinline__ Tw tw_inv_n() const { return inv_n; }
+    __device__ __forceinline__ Tw tw_inv_n_w() const { return inv_n_w; }
+    // arithmetic.rs:16-20: w*y - q*floor(y*w'/2^32), wrapping, in [0,2q)
+    __device__ __forceinline__ u32 mul1(u32 y, Tw t) const { return t.w * y - q * __umulhi(y, t.wp); }
+    static __device__ __forceinline__ u32 once(u32 x, u32 m) { return min(x, x - m); }  // arithmetic.rs:3-6
+    __device__ __forceinline__ u64 mul_lazy(u64 y, Tw t) const { return pack(mul1((u32)y, t), mul1((u32)(y >> 32), t)); }
+    __device__ __forceinline__ u64 reduce_x(u64 x) const { return pack(once((u32)x, two_q32), once((u32)(x >> 32), two_q32)); }
+    __device__ __forceinline__ u64 reduce_2q(u64 x) const { return pack(once((u32)x, q), once((u32)(x >> 32), q)); }
+    __device__ __forceinline__ u64 reduce_4q(u64 x) const { return reduce_2q(reduce_x(x)); }
+
+    // distance-1 stage, forward: word at word index i uses roots[N/2 + i] (n = N/2 words)
+    __device__ __forceinline__ u64 fwd_intra(u64 x, u32 n_plus_i) const {
+        const Tw w = fwd_tw(n_plus_i);
+        const u32 tx = once((u32)x, two_q32), t = mul1((u32)(x >> 32), w);
+        return pack(tx + t, tx + two_q32 - t);
+    }
+    // distance-1 stage, inverse: inv_roots[1 + i]; `inv` is biased by n words
+    __device__ __forceinline__ u64 inv_intra(u64 x, u32 n, u32 i) const {
+        const Tw w = unpack(inv[(long)(1 + i) - (long)n]);
+        const u32 a = (u32)x, b = (u32)(x >> 32);
+        return pack(once(a + b, two_q32), mul1(a + two_q32 - b, w));
+    }
 };
 
 // Harvey forward butterfly, values in [0,4q) — scalar/arithmetic.rs:43-59
@@ -153,8 +217,8 @@ __device__ __forceinline__ void inv_final_bfly(const A &ar, u64 &x, u64 &y, bool
     u64 rx = ar.mul_lazy(tx, ar.tw_inv_n());
     u64 ry = ar.mul_lazy(ty, ar.tw_inv_n_w());
     if (!lazy) {
-        rx = csub(rx, ar.q);
-        ry = csub(ry, ar.q);
+        rx = ar.reduce_2q(rx);
+        ry = ar.reduce_2q(ry);
     }
     x = rx;
     y = ry;
@@ -331,9 +395,13 @@ __device__ __forceinline__ void block_forward_core(const A &ar, u64 (&x)[16], u6
     constexpr bool UNI = BlockCfg<LOGB>::BPW == 1;
     fwd_regpass<A, POS0, 3, 0, UNI>(ar, x, n + eblk + layout<POS0>(lt, 0));
     fwd_chain<A, LOGB, POS0>(ar, x, lds, n, eblk, lt);
+    if constexpr (A::kPacked) {  // distance-1 stage between the halves of each word
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = ar.fwd_intra(x[k], n + eblk + layout<0>(lt, k));
+    }
     if (!lazy) {  // [0,4q) -> [0,q): scalar/transform.rs:104-116
 #pragma unroll
-        for (int k = 0; k < 16; ++k) x[k] = csub(csub(x[k], ar.two_q), ar.q);
+        for (int k = 0; k < 16; ++k) x[k] = ar.reduce_4q(x[k]);
     }
 }
 
@@ -357,6 +425,10 @@ template <class A, int LOGB>
 __device__ __forceinline__ void block_inverse_core(const A &ar, u64 (&x)[16], u64 *__restrict__ lds, u32 n,
                                                    u32 eblk, u32 lt, bool final_block, bool lazy) {
     constexpr bool UNI = BlockCfg<LOGB>::BPW == 1;
+    if constexpr (A::kPacked) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = ar.inv_intra(x[k], n, eblk + layout<0>(lt, k));
+    }
     inv_regpass<A, 0, 0, 3, UNI>(ar, x, n, eblk + layout<0>(lt, 0), LOGB == 4 && final_block, lazy);
     inv_chain<A, LOGB, 0>(ar, x, lds, n, eblk, lt, final_block, lazy);
 }

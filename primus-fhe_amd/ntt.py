@@ -195,3 +195,145 @@ class U64DcrtTable:
         macros/mod.rs:901-911): NTT -> pointwise multiply -> INTT, in place."""
         (pa, na), (pb, nb) = _dev(crt_poly), _dev(dcrt_poly)
         check(lib().pfhe_dcrt_mul_dcrt_polynomial_dev(self._h, pa, na, pb, nb, _stream(stream)))
+
+
+# ---------------------------------------------------------------------------------------------
+# u32 tables — primus_ntt::U32NttTable (ntt/prime32/table.rs:37) / U32DcrtTable (dcrt/prime32.rs:11)
+# ---------------------------------------------------------------------------------------------
+
+def _host32(a: np.ndarray):
+    if not isinstance(a, np.ndarray) or a.dtype != np.uint32 or not a.flags.c_contiguous:
+        raise TypeError("expected a C-contiguous numpy uint32 array")
+    return a.ctypes.data_as(C.c_void_p), a.size
+
+
+def _dev32(x):
+    """(device pointer, number of 32-bit words) of a torch CUDA tensor or a (ptr, words) pair."""
+    if isinstance(x, tuple):
+        return C.c_void_p(int(x[0])), int(x[1])
+    if hasattr(x, "data_ptr"):
+        if x.element_size() != 4 or not x.is_contiguous() or not x.is_cuda:
+            raise TypeError("expected a contiguous 32-bit CUDA tensor")
+        return C.c_void_p(x.data_ptr()), x.numel()
+    raise TypeError("expected a torch CUDA tensor or a (device_ptr, words) tuple")
+
+
+class _U32Common:
+    """Methods shared by the two u32 tables; `_pre` is the C symbol prefix."""
+
+    _pre = ""
+
+    def _f(self, name):
+        return getattr(lib(), self._pre + name)
+
+    def transform_slice(self, poly): check(self._f("transform_slice")(self._h, *_host32(poly)))
+    def inverse_transform_slice(self, values): check(self._f("inverse_transform_slice")(self._h, *_host32(values)))
+    def lazy_transform_slice(self, poly): check(self._f("lazy_transform_slice")(self._h, *_host32(poly)))
+    def lazy_inverse_transform_slice(self, values): check(self._f("lazy_inverse_transform_slice")(self._h, *_host32(values)))
+
+    def transform_monomial(self, coeff: int, degree: int, values):
+        check(self._f("transform_monomial")(self._h, coeff, degree, *_host32(values)))
+
+    def transform_coeff_one_monomial(self, degree: int, values):
+        check(self._f("transform_coeff_one_monomial")(self._h, degree, *_host32(values)))
+
+    def transform_coeff_minus_one_monomial(self, degree: int, values):
+        check(self._f("transform_coeff_minus_one_monomial")(self._h, degree, *_host32(values)))
+
+    def transform_dev(self, poly, lazy: bool = False, stream=None):
+        p, n = _dev32(poly)
+        check(self._f("transform_dev")(self._h, p, n, int(lazy), _stream(stream)))
+
+    def inverse_transform_dev(self, values, lazy: bool = False, stream=None):
+        p, n = _dev32(values)
+        check(self._f("inverse_transform_dev")(self._h, p, n, int(lazy), _stream(stream)))
+
+    def mul_assign_dev(self, a, b, stream=None):
+        """a *= b pointwise (b: same length, or one polynomial shared by the batch)."""
+        pa, na = _dev32(a)
+        pb, nb = _dev32(b)
+        check(self._f("mul_assign_dev")(self._h, pa, na, pb, nb, _stream(stream)))
+
+    def add_mul_assign_dev(self, acc, a, b, stream=None):
+        pc, nc = _dev32(acc)
+        pa, na = _dev32(a)
+        pb, nb = _dev32(b)
+        if nc != na:
+            raise PfheError(32, "accumulator and multiplicand differ in length")
+        check(self._f("add_mul_assign_dev")(self._h, pc, pa, na, pb, nb, _stream(stream)))
+
+
+class U32NttTable(_U32Common):
+    """primus_ntt::U32NttTable — negacyclic NTT over one prime q < 2^30, u32 data (table.rs:37-470)."""
+
+    _pre = "pfhe_ntt32_"
+
+    def __init__(self, log_n: int, modulus: int, device: int = 0):
+        h = C.c_void_p()
+        check(lib().pfhe_ntt32_create(log_n, modulus, device, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                lib().pfhe_ntt32_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def poly_length(self) -> int: return int(lib().pfhe_ntt32_poly_length(self._h))
+    def n(self) -> int: return self.poly_length()
+    def log_n(self) -> int: return int(lib().pfhe_ntt32_log_n(self._h))
+    def modulus(self) -> int: return int(lib().pfhe_ntt32_modulus(self._h))
+    def root(self) -> int: return int(lib().pfhe_ntt32_root(self._h))
+    def inv_root(self) -> int: return int(lib().pfhe_ntt32_inv_root(self._h))
+    def inv_n(self) -> int: return int(lib().pfhe_ntt32_inv_n(self._h))
+    def device(self) -> int: return int(lib().pfhe_ntt32_device(self._h))
+
+    def transform_monomial_dev(self, coeff: int, degree: int, values, stream=None):
+        p, n = _dev32(values)
+        check(lib().pfhe_ntt32_transform_monomial_dev(self._h, coeff, degree, p, n, _stream(stream)))
+
+
+class U32DcrtTable(_U32Common):
+    """primus_ntt::U32DcrtTable — one U32NttTable per RNS limb; unit = L*N words, modulus-major."""
+
+    _pre = "pfhe_dcrt32_"
+
+    def __init__(self, log_n: int, moduli, device: int = 0):
+        arr = (C.c_uint32 * len(moduli))(*[int(m) for m in moduli])
+        h = C.c_void_p()
+        check(lib().pfhe_dcrt32_create(log_n, arr, len(moduli), device, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                lib().pfhe_dcrt32_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def poly_length(self) -> int: return int(lib().pfhe_dcrt32_poly_length(self._h))
+    def moduli_count(self) -> int: return int(lib().pfhe_dcrt32_moduli_count(self._h))
+    def crt_poly_length(self) -> int: return int(lib().pfhe_dcrt32_crt_poly_length(self._h))
+    def device(self) -> int: return int(lib().pfhe_dcrt32_device(self._h))
+    def moduli(self): return [int(lib().pfhe_dcrt32_modulus(self._h, i)) for i in range(self.moduli_count())]
+    def roots(self): return [int(lib().pfhe_dcrt32_root(self._h, i)) for i in range(self.moduli_count())]
+
+    def fill_uniform_dev(self, dst, seed: int, stream=None):
+        """Synthetic residues (bench input): uniform in [0, q_limb) from SplitMix64(seed)."""
+        p, n = _dev32(dst)
+        check(lib().pfhe_dcrt32_fill_uniform_dev(self._h, p, n, seed, _stream(stream)))
+
+    def transform_num_passes(self) -> int:
+        return int(lib().pfhe_dcrt32_transform_num_passes(self._h))
+
+    def transform_pass_name(self, inverse: bool, index: int) -> str:
+        return lib().pfhe_dcrt32_transform_pass_name(self._h, int(inverse), index).decode()
+
+    def transform_pass_dev(self, poly, inverse: bool, index: int, lazy: bool = False, stream=None):
+        p, n = _dev32(poly)
+        check(lib().pfhe_dcrt32_transform_pass_dev(self._h, p, n, int(inverse), index, int(lazy), _stream(stream)))
