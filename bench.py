@@ -259,6 +259,22 @@ def main():
             "hbm_roofline_frac": ep_batch / dte * 96 * n / (HBM_PEAK_GBS * 1e9),
             "limb_ntts_per_product": 42}
         del ggsw, out, ctx
+        # ---- §8f rank 1: the u32 / low-q tables at the same shape (N=2^16, three 30-bit primes) ----
+        q30 = [1073479681, 1071513601, 1070727169]
+        t32 = p.U32DcrtTable(LOG_N, q30, device=local_rank)
+        x32 = x.view(torch.int32)[:words]           # reuse the first half of the resident buffer
+        t32.fill_uniform_dev(x32, 0x5EED000000000032)
+        t32.transform_dev(x32)
+        torch.cuda.synchronize()
+        reps = max(3, args.steps)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            t32.transform_dev(x32)
+        torch.cuda.synchronize()
+        dt32 = (time.perf_counter() - t0) / reps
+        result["ntt_u32"] = {"value": batch * L / dt32, "unit": "NTT/s (forward limb-NTTs, u32 data, 30-bit primes)",
+                             "ms_per_batch": dt32 * 1e3, "moduli": q30,
+                             "hbm_roofline_frac": batch * L / dt32 * 8 * n / (HBM_PEAK_GBS * 1e9)}
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
 

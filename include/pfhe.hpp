@@ -2,6 +2,7 @@
 // (include/pfhe.h).  Same type names, method names and argument meaning as the Rust traits:
 //   U64NttTable   — primus_ntt::NttTable for U64NttTable   (crates/primus_ntt/src/ntt/mod.rs:16-113)
 //   U64DcrtTable  — primus_ntt::DcrtTable for U64DcrtTable (crates/primus_ntt/src/dcrt/mod.rs:19-135)
+//   U32NttTable, U32DcrtTable — the u32 / low-q tables (ntt/prime32/table.rs, dcrt/prime32.rs)
 //   RNSBase, BigUintApproxSignedBasis, DcrtGlevContext, mul_dcrt_ggsw_to
 //                 — primus_rns / primus_decompose / primus_lattice entry points of the RNS
 //                   gadget external product (crates/primus_lattice/src/glwe/crt.rs:200-227)
@@ -126,6 +127,90 @@ class U64DcrtTable {
 
   private:
     pfhe_dcrt *h_ = nullptr;
+};
+
+// primus_ntt::U32NttTable (crates/primus_ntt/src/ntt/prime32/table.rs:37) — q < 2^30, u32 data
+class U32NttTable {
+  public:
+    U32NttTable(uint32_t log_n, uint32_t modulus, int device = 0) { check(pfhe_ntt32_create(log_n, modulus, device, &h_)); }
+    ~U32NttTable() { pfhe_ntt32_destroy(h_); }
+    U32NttTable(U32NttTable &&o) noexcept : h_(std::exchange(o.h_, nullptr)) {}
+    U32NttTable(const U32NttTable &) = delete;
+    U32NttTable &operator=(const U32NttTable &) = delete;
+
+    size_t poly_length() const { return pfhe_ntt32_poly_length(h_); }
+    size_t n() const { return poly_length(); }
+    uint32_t log_n() const { return pfhe_ntt32_log_n(h_); }
+    uint32_t modulus() const { return pfhe_ntt32_modulus(h_); }
+    uint32_t root() const { return pfhe_ntt32_root(h_); }
+    uint32_t inv_root() const { return pfhe_ntt32_inv_root(h_); }
+    uint32_t inv_n() const { return pfhe_ntt32_inv_n(h_); }
+
+    void transform_slice(uint32_t *poly, size_t len) const { check(pfhe_ntt32_transform_slice(h_, poly, len)); }
+    void inverse_transform_slice(uint32_t *v, size_t len) const { check(pfhe_ntt32_inverse_transform_slice(h_, v, len)); }
+    void lazy_transform_slice(uint32_t *poly, size_t len) const { check(pfhe_ntt32_lazy_transform_slice(h_, poly, len)); }
+    void lazy_inverse_transform_slice(uint32_t *v, size_t len) const { check(pfhe_ntt32_lazy_inverse_transform_slice(h_, v, len)); }
+    void transform_monomial(uint32_t coeff, size_t degree, uint32_t *values, size_t len) const {
+        check(pfhe_ntt32_transform_monomial(h_, coeff, degree, values, len));
+    }
+    void transform_coeff_one_monomial(size_t degree, uint32_t *values, size_t len) const {
+        check(pfhe_ntt32_transform_coeff_one_monomial(h_, degree, values, len));
+    }
+    void transform_coeff_minus_one_monomial(size_t degree, uint32_t *values, size_t len) const {
+        check(pfhe_ntt32_transform_coeff_minus_one_monomial(h_, degree, values, len));
+    }
+    void transform_dev(uint32_t *poly_dev, size_t len, bool lazy = false, void *stream = nullptr) const {
+        check(pfhe_ntt32_transform_dev(h_, poly_dev, len, lazy, stream));
+    }
+    void inverse_transform_dev(uint32_t *v_dev, size_t len, bool lazy = false, void *stream = nullptr) const {
+        check(pfhe_ntt32_inverse_transform_dev(h_, v_dev, len, lazy, stream));
+    }
+    const pfhe_ntt32 *handle() const { return h_; }
+
+  private:
+    pfhe_ntt32 *h_ = nullptr;
+};
+
+// primus_ntt::U32DcrtTable (crates/primus_ntt/src/dcrt/prime32.rs:11)
+class U32DcrtTable {
+  public:
+    U32DcrtTable(uint32_t log_n, const std::vector<uint32_t> &moduli, int device = 0) {
+        check(pfhe_dcrt32_create(log_n, moduli.data(), moduli.size(), device, &h_));
+    }
+    ~U32DcrtTable() { pfhe_dcrt32_destroy(h_); }
+    U32DcrtTable(U32DcrtTable &&o) noexcept : h_(std::exchange(o.h_, nullptr)) {}
+    U32DcrtTable(const U32DcrtTable &) = delete;
+    U32DcrtTable &operator=(const U32DcrtTable &) = delete;
+
+    size_t poly_length() const { return pfhe_dcrt32_poly_length(h_); }
+    size_t moduli_count() const { return pfhe_dcrt32_moduli_count(h_); }
+    size_t crt_poly_length() const { return pfhe_dcrt32_crt_poly_length(h_); }
+    uint32_t modulus(size_t i) const { return pfhe_dcrt32_modulus(h_, i); }
+
+    void transform_slice(uint32_t *poly, size_t len) const { check(pfhe_dcrt32_transform_slice(h_, poly, len)); }
+    void inverse_transform_slice(uint32_t *poly, size_t len) const { check(pfhe_dcrt32_inverse_transform_slice(h_, poly, len)); }
+    void lazy_transform_slice(uint32_t *poly, size_t len) const { check(pfhe_dcrt32_lazy_transform_slice(h_, poly, len)); }
+    void lazy_inverse_transform_slice(uint32_t *poly, size_t len) const { check(pfhe_dcrt32_lazy_inverse_transform_slice(h_, poly, len)); }
+    void transform_monomial(uint32_t coeff, size_t degree, uint32_t *values, size_t len) const {
+        check(pfhe_dcrt32_transform_monomial(h_, coeff, degree, values, len));
+    }
+    void transform_dev(uint32_t *poly_dev, size_t len, bool lazy = false, void *stream = nullptr) const {
+        check(pfhe_dcrt32_transform_dev(h_, poly_dev, len, lazy, stream));
+    }
+    void inverse_transform_dev(uint32_t *poly_dev, size_t len, bool lazy = false, void *stream = nullptr) const {
+        check(pfhe_dcrt32_inverse_transform_dev(h_, poly_dev, len, lazy, stream));
+    }
+    void mul_assign_dev(uint32_t *a, size_t len_a, const uint32_t *b, size_t len_b, void *stream = nullptr) const {
+        check(pfhe_dcrt32_mul_assign_dev(h_, a, len_a, b, len_b, stream));
+    }
+    void add_mul_assign_dev(uint32_t *acc, const uint32_t *a, size_t len_a, const uint32_t *b, size_t len_b,
+                            void *stream = nullptr) const {
+        check(pfhe_dcrt32_add_mul_assign_dev(h_, acc, a, len_a, b, len_b, stream));
+    }
+    const pfhe_dcrt32 *handle() const { return h_; }
+
+  private:
+    pfhe_dcrt32 *h_ = nullptr;
 };
 
 class RNSBase {

@@ -170,12 +170,57 @@ struct B32Arith {
     __device__ __forceinline__ Tw tw_inv_n() const { return inv_n; }
     __device__ __forceinline__ Tw tw_inv_n_w() const { return inv_n_w; }
     // arithmetic.rs:16-20: w*y - q*floor(y*w'/2^32), wrapping, in [0,2q)
+    // (v_mad_u64_u32 forms of this product were measured and are not faster: on gfx950 v_mul_lo_u32 /
+    // v_mul_hi_u32 issue in ~1.5 full-rate slots, tools/microbench4.hip)
     __device__ __forceinline__ u32 mul1(u32 y, Tw t) const { return t.w * y - q * __umulhi(y, t.wp); }
     static __device__ __forceinline__ u32 once(u32 x, u32 m) { return min(x, x - m); }  // arithmetic.rs:3-6
     __device__ __forceinline__ u64 mul_lazy(u64 y, Tw t) const { return pack(mul1((u32)y, t), mul1((u32)(y >> 32), t)); }
     __device__ __forceinline__ u64 reduce_x(u64 x) const { return pack(once((u32)x, two_q32), once((u32)(x >> 32), two_q32)); }
     __device__ __forceinline__ u64 reduce_2q(u64 x) const { return pack(once((u32)x, q), once((u32)(x >> 32), q)); }
     __device__ __forceinline__ u64 reduce_4q(u64 x) const { return reduce_2q(reduce_x(x)); }
+
+    // butterflies on both halves with 32-bit operations only (no 64-bit carries)
+    __device__ __forceinline__ void fwd1(u32 &x, u32 &y, Tw w) const {
+        const u32 tx = once(x, two_q32), t = mul1(y, w);
+        x = tx + t;
+        y = tx + two_q32 - t;
+    }
+    __device__ __forceinline__ void inv1(u32 &x, u32 &y, Tw w) const {
+        const u32 tx = x + y, ty = x + two_q32 - y;
+        x = once(tx, two_q32);
+        y = mul1(ty, w);
+    }
+    __device__ __forceinline__ void fwd_bfly(u64 &x, u64 &y, Tw w) const {
+        u32 x0 = (u32)x, x1 = (u32)(x >> 32), y0 = (u32)y, y1 = (u32)(y >> 32);
+        fwd1(x0, y0, w);
+        fwd1(x1, y1, w);
+        x = pack(x0, x1);
+        y = pack(y0, y1);
+    }
+    __device__ __forceinline__ void inv_bfly(u64 &x, u64 &y, Tw w) const {
+        u32 x0 = (u32)x, x1 = (u32)(x >> 32), y0 = (u32)y, y1 = (u32)(y >> 32);
+        inv1(x0, y0, w);
+        inv1(x1, y1, w);
+        x = pack(x0, x1);
+        y = pack(y0, y1);
+    }
+    __device__ __forceinline__ void final1(u32 &x, u32 &y, bool lazy) const {  // scalar/transform.rs:253-271
+        const u32 tx = once(x + y, two_q32), ty = x + two_q32 - y;
+        u32 rx = mul1(tx, inv_n), ry = mul1(ty, inv_n_w);
+        if (!lazy) {
+            rx = once(rx, q);
+            ry = once(ry, q);
+        }
+        x = rx;
+        y = ry;
+    }
+    __device__ __forceinline__ void inv_final_bfly(u64 &x, u64 &y, bool lazy) const {
+        u32 x0 = (u32)x, x1 = (u32)(x >> 32), y0 = (u32)y, y1 = (u32)(y >> 32);
+        final1(x0, y0, lazy);
+        final1(x1, y1, lazy);
+        x = pack(x0, x1);
+        y = pack(y0, y1);
+    }
 
     // distance-1 stage, forward: word at word index i uses roots[N/2 + i] (n = N/2 words)
     __device__ __forceinline__ u64 fwd_intra(u64 x, u32 n_plus_i) const {
@@ -194,6 +239,10 @@ struct B32Arith {
 // Harvey forward butterfly, values in [0,4q) — scalar/arithmetic.rs:43-59
 template <class A>
 __device__ __forceinline__ void fwd_bfly(const A &ar, u64 &x, u64 &y, typename A::Tw w) {
+    if constexpr (A::kPacked) {
+        ar.fwd_bfly(x, y, w);
+        return;
+    }
     const u64 tx = ar.reduce_x(x);
     const u64 t = ar.mul_lazy(y, w);
     x = tx + t;
@@ -203,6 +252,10 @@ __device__ __forceinline__ void fwd_bfly(const A &ar, u64 &x, u64 &y, typename A
 // Gentleman-Sande inverse butterfly, values in [0,2q) — scalar/arithmetic.rs:63-79
 template <class A>
 __device__ __forceinline__ void inv_bfly(const A &ar, u64 &x, u64 &y, typename A::Tw w) {
+    if constexpr (A::kPacked) {
+        ar.inv_bfly(x, y, w);
+        return;
+    }
     const u64 tx = x + y;
     const u64 ty = x + ar.two_q - y;
     x = ar.reduce_x(tx);
@@ -212,6 +265,10 @@ __device__ __forceinline__ void inv_bfly(const A &ar, u64 &x, u64 &y, typename A
 // last inverse stage fused with N^-1 (x) and N^-1*w (y) — scalar/transform.rs:283-318
 template <class A>
 __device__ __forceinline__ void inv_final_bfly(const A &ar, u64 &x, u64 &y, bool lazy) {
+    if constexpr (A::kPacked) {
+        ar.inv_final_bfly(x, y, lazy);
+        return;
+    }
     const u64 tx = ar.reduce_x(x + y);
     const u64 ty = x + ar.two_q - y;
     u64 rx = ar.mul_lazy(tx, ar.tw_inv_n());

@@ -17,8 +17,13 @@ int main() {
         std::vector<uint64_t> a(3 * 1024, 1), b = a;
         t.transform_slice(a.data(), a.size());
         t.inverse_transform_slice(a.data(), a.size());
-        std::printf(a == b ? "roundtrip ok\n" : "roundtrip MISMATCH\n");
-        return a == b ? 0 : 1;
+        pfhe::U32DcrtTable t32(10, {1073479681u, 1071513601u});
+        std::vector<uint32_t> c(2 * 1024, 7), d = c;
+        t32.transform_slice(c.data(), c.size());
+        t32.inverse_transform_slice(c.data(), c.size());
+        const bool ok = a == b && c == d;
+        std::printf(ok ? "roundtrip ok\n" : "roundtrip MISMATCH\n");
+        return ok ? 0 : 1;
     } catch (const pfhe::Error &e) {
         std::printf("pfhe::Error %d: %s\n", e.status(), e.what());
         return e.status() == PFHE_ERR_NO_DEVICE ? 42 : 2;
