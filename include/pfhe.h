@@ -307,6 +307,43 @@ int pfhe_dcrt_transform_pass_dev(const pfhe_dcrt *table, uint64_t *poly_dev, siz
                                  int index, int lazy, void *stream);
 
 /* =====================================================================================
+ * BaseConverter — primus_rns/src/converter.rs:21 — and RNSBase::decompose_big_uint_values_to
+ * (primus_rns/src/base.rs:457-481).  Residue arrays are modulus-major, as in the reference; the
+ * reference's coefficient-major `scratch` argument has no counterpart (the scaled residues stay
+ * in registers).
+ * ===================================================================================== */
+typedef struct pfhe_conv pfhe_conv;
+
+/* BaseConverter::new(input_base, output_base) — converter.rs:43-69 (the bases are copied) */
+int pfhe_conv_create(const pfhe_rns *input_base, const pfhe_rns *output_base, pfhe_conv **out);
+void pfhe_conv_destroy(pfhe_conv *conv);
+size_t pfhe_conv_input_moduli_count(const pfhe_conv *conv);  /* converter.rs:82 */
+size_t pfhe_conv_output_moduli_count(const pfhe_conv *conv); /* :87 */
+/* row-major output-by-input matrix (Q/q_i) mod p_j — converter.rs:28-32 */
+int pfhe_conv_base_change_matrix(const pfhe_conv *conv, uint64_t *out, size_t len);
+/* fast_convert_array — converter.rs:192-218.  len_in = L_in * poly_length, len_out = L_out *
+ * poly_length. */
+int pfhe_conv_fast_convert_array(const pfhe_conv *conv, const uint64_t *crt_poly_in, size_t len_in,
+                                 uint64_t *crt_poly_out, size_t len_out, size_t poly_length);
+int pfhe_conv_fast_convert_array_dev(const pfhe_conv *conv, const uint64_t *crt_poly_in_dev,
+                                     size_t len_in, uint64_t *crt_poly_out_dev, size_t len_out,
+                                     size_t poly_length, void *stream);
+/* exact_convert_array — converter.rs:274-364 (single output modulus; f64 correction term) */
+int pfhe_conv_exact_convert_array(const pfhe_conv *conv, const uint64_t *crt_poly_in, size_t len_in,
+                                  uint64_t *crt_poly_out, size_t len_out, size_t poly_length);
+int pfhe_conv_exact_convert_array_dev(const pfhe_conv *conv, const uint64_t *crt_poly_in_dev,
+                                      size_t len_in, uint64_t *crt_poly_out_dev, size_t len_out,
+                                      size_t poly_length, void *stream);
+/* RNSBase::decompose_big_uint_values_to — base.rs:457-481 */
+int pfhe_rns_decompose_big_uint_values_to(const pfhe_rns *base, const uint64_t *big_uint_values,
+                                          size_t len_in, uint64_t *multi_residues, size_t len_out,
+                                          size_t value_count);
+int pfhe_rns_decompose_big_uint_values_to_dev(const pfhe_rns *base,
+                                              const uint64_t *big_uint_values_dev, size_t len_in,
+                                              uint64_t *multi_residues_dev, size_t len_out,
+                                              size_t value_count, void *stream);
+
+/* =====================================================================================
  * u32 tables — U32NttTable (primus_ntt/src/ntt/prime32/table.rs:37-91, NttTable impl :184-470)
  * and U32DcrtTable (primus_ntt/src/dcrt/prime32.rs:11-128).  Same contracts as the 64-bit
  * tables with uint32_t words; q < 2^30 (table.rs:195-200 -> PFHE_ERR_MODULUS_TOO_LARGE).

@@ -128,6 +128,13 @@ def _load(path: str | None = None) -> C.CDLL:
     sig("orc_rns_decompose_big_uint_values_to", None, vp, _u64p, _u64p, sz)
     sig("orc_rns_wrapping_decompose_small_values_to", None, vp, _u64p, _u64p, sz, u64)
 
+    sig("orc_conv_new", ci, vp, vp, C.POINTER(vp))
+    sig("orc_conv_free", None, vp)
+    sig("orc_conv_matrix", _u64p, vp)
+    sig("orc_conv_fast_convert", None, vp, _u64p, _u64p, _u64p)
+    sig("orc_conv_fast_convert_array", None, vp, _u64p, _u64p, sz, _u64p)
+    sig("orc_conv_exact_convert_array", ci, vp, _u64p, _u64p, sz)
+
     sig("orc_basis_new", ci, vp, u32, sz, C.POINTER(vp))
     sig("orc_basis_free", None, vp)
     sig("orc_basis_decompose_length", sz, vp)
@@ -509,6 +516,44 @@ class RNSBase:
         sv = np.ascontiguousarray(small_values, np.uint64)
         out = np.empty(self.count * sv.size, np.uint64)
         lib().orc_rns_wrapping_decompose_small_values_to(self._h, _p(sv), _p(out), sv.size, small_value_modulus)
+        return out
+
+
+class BaseConverter:
+    """primus_rns::BaseConverter<u64, BarrettModulus<u64>> (converter.rs)."""
+
+    def __init__(self, input_base: RNSBase, output_base: RNSBase):
+        h = C.c_void_p()
+        rc = lib().orc_conv_new(input_base._h, output_base._h, C.byref(h))
+        if rc:
+            raise OracleError(rc)
+        self._h = h
+        self.input_base, self.output_base = input_base, output_base  # keep the borrowed bases alive
+        self.base_change_matrix = _arr(lib().orc_conv_matrix(h), input_base.count * output_base.count)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_conv_free(self._h)
+            self._h = None
+
+    def fast_convert(self, residues_in):
+        r = np.ascontiguousarray(residues_in, np.uint64)
+        out = np.empty(self.output_base.count, np.uint64)
+        scratch = np.empty(self.input_base.count, np.uint64)
+        lib().orc_conv_fast_convert(self._h, _p(r), _p(out), _p(scratch))
+        return out
+
+    def fast_convert_array(self, crt_poly_in, poly_length):
+        out = np.empty(self.output_base.count * poly_length, np.uint64)
+        scratch = np.empty(self.input_base.count * poly_length, np.uint64)
+        lib().orc_conv_fast_convert_array(self._h, _p(crt_poly_in), _p(out), poly_length, _p(scratch))
+        return out
+
+    def exact_convert_array(self, crt_poly_in, poly_length):
+        out = np.empty(poly_length, np.uint64)
+        rc = lib().orc_conv_exact_convert_array(self._h, _p(crt_poly_in), _p(out), poly_length)
+        if rc:
+            raise OracleError(rc)
         return out
 
 

@@ -1028,6 +1028,112 @@ void orc_rns_decompose_big_uint_values_to(const orc_rns *b, const uint64_t *big_
             multi_residues[i * value_count + c] = big_mod_u64(big_uint_values + c * b->value_len, b->value_len, b->moduli[i]);
 }
 
+/* ========================================================================== */
+/* BaseConverter — primus_rns/src/converter.rs                                  */
+/* ========================================================================== */
+
+struct orc_conv {
+    const orc_rns *in, *out;   /* borrowed: the caller keeps both bases alive */
+    orc_barrett *out_mod;      /* BarrettModulus of every output modulus */
+    uint64_t *matrix;          /* out.count rows x in.count columns: (Q/q_i) mod p_j  (converter.rs:54-62) */
+    uint64_t q_mod_p0;         /* Q mod p_0 (exact_convert_array, converter.rs:345) */
+};
+
+/* converter.rs:43-69 */
+int orc_conv_new(const orc_rns *in, const orc_rns *out, orc_conv **res) {
+    orc_conv *c = (orc_conv *)calloc(1, sizeof(*c));
+    c->in = in; c->out = out;
+    c->matrix = (uint64_t *)malloc(in->count * out->count * sizeof(uint64_t));
+    c->out_mod = (orc_barrett *)malloc(out->count * sizeof(orc_barrett));
+    for (size_t j = 0; j < out->count; ++j) {
+        orc_barrett_new(out->moduli[j], &c->out_mod[j]);
+        for (size_t i = 0; i < in->count; ++i)
+            c->matrix[j * in->count + i] = big_mod_u64(in->punctured + i * in->value_len, in->value_len, out->moduli[j]);
+    }
+    c->q_mod_p0 = big_mod_u64(in->product, in->value_len, out->moduli[0]);
+    *res = c;
+    return ORC_OK;
+}
+
+void orc_conv_free(orc_conv *c) { if (c) { free(c->matrix); free(c->out_mod); free(c); } }
+const uint64_t *orc_conv_matrix(const orc_conv *c) { return c->matrix; }
+
+/* compact/slice.rs:369-405 (reduce_dot_product): 128-bit accumulation in chunks of
+ * DOT_PRODUCT_INNER_CHUNK = 16 (compact/mod.rs:14), BarrettModulus::reduce of each chunk
+ * (barrett/mod.rs:99-139), chunks folded with reduce_add. */
+static uint64_t dot_product_mod(const orc_barrett *m, const uint64_t *a, const uint64_t *b, size_t len) {
+    const size_t K = 16;
+    uint64_t inter = 0;
+    size_t full = len / K;
+    for (size_t ch = 0; ch < full; ++ch) {
+        u128 c = 0;
+        for (size_t t = 0; t < K; ++t) c += (u128)a[ch * K + t] * b[ch * K + t];
+        inter = orc_reduce_add(m->value, inter, orc_barrett_reduce_wide(m, (uint64_t)c, (uint64_t)(c >> 64)));
+    }
+    u128 c = 0;
+    for (size_t t = full * K; t < len; ++t) c += (u128)a[t] * b[t];
+    return orc_reduce_add(m->value, orc_barrett_reduce_wide(m, (uint64_t)c, (uint64_t)(c >> 64)), inter);
+}
+
+/* converter.rs:111-141 */
+void orc_conv_fast_convert(const orc_conv *c, const uint64_t *residues_in, uint64_t *residues_out, uint64_t *scratch) {
+    const orc_rns *in = c->in;
+    for (size_t i = 0; i < in->count; ++i) scratch[i] = shoup_full(in->inv_punct[i], residues_in[i], in->moduli[i]);
+    for (size_t j = 0; j < c->out->count; ++j)
+        residues_out[j] = dot_product_mod(&c->out_mod[j], scratch, c->matrix + j * in->count, in->count);
+}
+
+/* converter.rs:144-178: coefficient-major scratch; the `inv == 1` arm (x mod q_i) equals the
+ * Shoup product by 1 */
+static void fill_scratch(const orc_conv *c, const uint64_t *crt_poly_in, size_t poly_length, uint64_t *scratch) {
+    const orc_rns *in = c->in;
+    for (size_t i = 0; i < in->count; ++i)
+        for (size_t t = 0; t < poly_length; ++t) {
+            const uint64_t x = crt_poly_in[i * poly_length + t];
+            scratch[t * in->count + i] = in->inv_punct[i].value == 1 ? x % in->moduli[i]
+                                                                     : shoup_full(in->inv_punct[i], x, in->moduli[i]);
+        }
+}
+
+/* converter.rs:192-218 */
+void orc_conv_fast_convert_array(const orc_conv *c, const uint64_t *crt_poly_in, uint64_t *crt_poly_out,
+                                 size_t poly_length, uint64_t *scratch) {
+    const size_t lin = c->in->count;
+    fill_scratch(c, crt_poly_in, poly_length, scratch);
+    for (size_t j = 0; j < c->out->count; ++j)
+        for (size_t t = 0; t < poly_length; ++t)
+            crt_poly_out[j * poly_length + t] = dot_product_mod(&c->out_mod[j], scratch + t * lin, c->matrix + j * lin, lin);
+}
+
+/* converter.rs:274-364: the only floating-point code near the path.  v_i = f64(temp_i) / f64(q_i)
+ * (IEEE division), summed left to right from 0.0, rounded by (sum + 0.5) as u64 (truncation,
+ * saturating).  Compile without -ffast-math / FMA contraction (there is no a*b+c here). */
+int orc_conv_exact_convert_array(const orc_conv *c, const uint64_t *crt_poly_in, uint64_t *crt_poly_out,
+                                 size_t poly_length) {
+    if (c->out->count != 1) return ORC_ERR_BAD_ARG; /* assert_eq!(output_moduli_count(), 1) */
+    const orc_rns *in = c->in;
+    const size_t lin = in->count;
+    uint64_t *temp = (uint64_t *)malloc(lin * poly_length * sizeof(uint64_t));
+    fill_scratch(c, crt_poly_in, poly_length, temp);
+    const orc_barrett *p = &c->out_mod[0];
+    for (size_t t = 0; t < poly_length; ++t) {
+        volatile double sum = 0.0; /* Iterator::sum::<f64>() starts at 0.0 and adds in order */
+        for (size_t i = 0; i < lin; ++i) {
+            const double dividend = (double)temp[t * lin + i];
+            const double divisor = (double)in->moduli[i];
+            sum = sum + dividend / divisor;
+        }
+        const double r = sum + 0.5;
+        uint64_t v;
+        if (!(r > 0.0)) v = 0; else if (r >= 18446744073709551616.0) v = UINT64_MAX; else v = (uint64_t)r;
+        const uint64_t dot = dot_product_mod(p, temp + t * lin, c->matrix, lin);
+        const uint64_t vq = orc_barrett_mul(p, v, c->q_mod_p0);
+        crt_poly_out[t] = orc_reduce_sub(p->value, dot, vq);
+    }
+    free(temp);
+    return ORC_OK;
+}
+
 /* base.rs:279-312 + slice::wrapping_decompose_chunk_to :721-730 */
 void orc_rns_wrapping_decompose_small_values_to(const orc_rns *b, const uint64_t *small_values,
                                                 uint64_t *multi_residues, size_t value_count,

@@ -214,6 +214,18 @@ void orc_basis_unsigned_decompose_slice_to(const orc_basis *b, size_t level,
                                            const uint64_t *values, uint64_t *digits,
                                            uint8_t *carries, size_t count);
 
+/* ---------------- BaseConverter (primus_rns/src/converter.rs) ---------------- */
+typedef struct orc_conv orc_conv;
+int orc_conv_new(const orc_rns *in, const orc_rns *out, orc_conv **res); /* borrows both bases */
+void orc_conv_free(orc_conv *c);
+const uint64_t *orc_conv_matrix(const orc_conv *c);
+void orc_conv_fast_convert(const orc_conv *c, const uint64_t *residues_in, uint64_t *residues_out,
+                           uint64_t *scratch);
+void orc_conv_fast_convert_array(const orc_conv *c, const uint64_t *crt_poly_in, uint64_t *crt_poly_out,
+                                 size_t poly_length, uint64_t *scratch);
+int orc_conv_exact_convert_array(const orc_conv *c, const uint64_t *crt_poly_in, uint64_t *crt_poly_out,
+                                 size_t poly_length);
+
 /* ---------------- RNS gadget external product (primus_lattice) ---------------- */
 /* DcrtGlwe::add_dcrt_glev_mul_crt_poly_assign, glwe/dcrt.rs:178-255.
  * acc: (k+1)*L*N words (DcrtGlwe), glev: ell*(k+1)*L*N words, crt_poly: L*N words. */

@@ -10,8 +10,8 @@ from ._lib import PfheError, build, lib, library_path, status_string  # noqa: F4
 from .lattice import (DcrtGlevContext, add_dcrt_glev_mul_crt_poly_assign_dev, glev_mul_crt_poly_to_dev,  # noqa: F401
                       mul_dcrt_ggsw_to, mul_dcrt_ggsw_to_dev)
 from .ntt import NttError, U32DcrtTable, U32NttTable, U64DcrtTable, U64NttTable  # noqa: F401
-from .rns import BigUintApproxSignedBasis, RNSBase, RNSError  # noqa: F401
+from .rns import BaseConverter, BigUintApproxSignedBasis, RNSBase, RNSError  # noqa: F401
 
 __all__ = ["PfheError", "NttError", "RNSError", "U64NttTable", "U64DcrtTable", "U32NttTable", "U32DcrtTable", "RNSBase",
-           "BigUintApproxSignedBasis", "DcrtGlevContext", "mul_dcrt_ggsw_to", "mul_dcrt_ggsw_to_dev",
+           "BigUintApproxSignedBasis", "BaseConverter", "DcrtGlevContext", "mul_dcrt_ggsw_to", "mul_dcrt_ggsw_to_dev",
            "add_dcrt_glev_mul_crt_poly_assign_dev", "glev_mul_crt_poly_to_dev", "build", "lib", "library_path", "status_string"]

@@ -131,6 +131,17 @@ def _declare(lib: C.CDLL) -> None:
     sig("pfhe_dcrt_transform_pass_name", C.c_char_p, vp, ci, ci)
     sig("pfhe_dcrt_transform_pass_dev", ci, vp, vp, sz, ci, ci, ci, vp)
 
+    sig("pfhe_conv_create", ci, vp, vp, C.POINTER(vp))
+    sig("pfhe_conv_destroy", None, vp)
+    sig("pfhe_conv_input_moduli_count", sz, vp)
+    sig("pfhe_conv_output_moduli_count", sz, vp)
+    sig("pfhe_conv_base_change_matrix", ci, vp, vp, sz)
+    for g in ("fast_convert_array", "exact_convert_array"):
+        sig("pfhe_conv_" + g, ci, vp, vp, sz, vp, sz, sz)
+        sig("pfhe_conv_" + g + "_dev", ci, vp, vp, sz, vp, sz, sz, vp)
+    sig("pfhe_rns_decompose_big_uint_values_to", ci, vp, vp, sz, vp, sz, sz)
+    sig("pfhe_rns_decompose_big_uint_values_to_dev", ci, vp, vp, sz, vp, sz, sz, vp)
+
     # u32 tables
     u32p = C.POINTER(u32)
     sig("pfhe_ntt32_create", ci, u32, u32, ci, C.POINTER(vp))

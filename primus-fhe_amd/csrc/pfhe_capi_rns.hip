@@ -10,9 +10,6 @@
 
 using namespace pfhe;
 
-struct pfhe_rns {
-    RnsHost h;
-};
 struct pfhe_basis {
     BasisHost h;
 };

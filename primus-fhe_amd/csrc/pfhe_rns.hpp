@@ -77,3 +77,8 @@ int gadget_block_mulacc_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u
                             hipStream_t s);
 
 }  // namespace pfhe
+
+// handle behind the C ABI's `pfhe_rns` (shared by pfhe_capi_rns.hip and pfhe_convert.hip)
+struct pfhe_rns {
+    pfhe::RnsHost h;
+};

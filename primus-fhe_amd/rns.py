@@ -72,6 +72,60 @@ class RNSBase:
                                                                     small_value_modulus, _stream(stream)))
 
 
+    def decompose_big_uint_values_to(self, big_uint_values, multi_residues, value_count: int):
+        """base.rs:457-481: value_count little-endian big integers -> modulus-major residues."""
+        pi, ni = _host(big_uint_values)
+        po, no = _host(multi_residues)
+        check(lib().pfhe_rns_decompose_big_uint_values_to(self._h, pi, ni, po, no, value_count))
+
+    def decompose_big_uint_values_to_dev(self, big_uint_values, multi_residues, value_count: int, stream=None):
+        (pi, ni), (po, no) = _dev(big_uint_values), _dev(multi_residues)
+        check(lib().pfhe_rns_decompose_big_uint_values_to_dev(self._h, pi, ni, po, no, value_count, _stream(stream)))
+
+
+class BaseConverter:
+    """primus_rns::BaseConverter — precomputed converter between two RNS bases (converter.rs:21-69).
+
+    Arrays are modulus-major like the reference's; its `scratch` argument has no counterpart."""
+
+    def __init__(self, input_base: RNSBase, output_base: RNSBase):
+        h = C.c_void_p()
+        check(lib().pfhe_conv_create(input_base._h, output_base._h, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().pfhe_conv_destroy(h)
+            self._h = None
+
+    def input_moduli_count(self) -> int: return int(lib().pfhe_conv_input_moduli_count(self._h))
+    def output_moduli_count(self) -> int: return int(lib().pfhe_conv_output_moduli_count(self._h))
+
+    def base_change_matrix(self) -> np.ndarray:
+        out = np.empty(self.input_moduli_count() * self.output_moduli_count(), np.uint64)
+        check(lib().pfhe_conv_base_change_matrix(self._h, *_host(out)))
+        return out
+
+    def fast_convert_array(self, crt_poly_in, crt_poly_out, poly_length: int):
+        """converter.rs:192-218."""
+        (pi, ni), (po, no) = _host(crt_poly_in), _host(crt_poly_out)
+        check(lib().pfhe_conv_fast_convert_array(self._h, pi, ni, po, no, poly_length))
+
+    def exact_convert_array(self, crt_poly_in, crt_poly_out, poly_length: int):
+        """converter.rs:274-364 (single output modulus)."""
+        (pi, ni), (po, no) = _host(crt_poly_in), _host(crt_poly_out)
+        check(lib().pfhe_conv_exact_convert_array(self._h, pi, ni, po, no, poly_length))
+
+    def fast_convert_array_dev(self, crt_poly_in, crt_poly_out, poly_length: int, stream=None):
+        (pi, ni), (po, no) = _dev(crt_poly_in), _dev(crt_poly_out)
+        check(lib().pfhe_conv_fast_convert_array_dev(self._h, pi, ni, po, no, poly_length, _stream(stream)))
+
+    def exact_convert_array_dev(self, crt_poly_in, crt_poly_out, poly_length: int, stream=None):
+        (pi, ni), (po, no) = _dev(crt_poly_in), _dev(crt_poly_out)
+        check(lib().pfhe_conv_exact_convert_array_dev(self._h, pi, ni, po, no, poly_length, _stream(stream)))
+
+
 class BigUintApproxSignedBasis:
     """primus_decompose::big_integer::BigUintApproxSignedBasis<u64> (basis.rs:17-211)."""
 
