@@ -628,6 +628,18 @@ int pfhe_dcrt_mul_dcrt_polynomial_dev(const pfhe_dcrt *table, uint64_t *crt_poly
     if (!table) return PFHE_ERR_BAD_ARGUMENT;
     const TableSet &t = *table->t;
     PFHE_TRY(transform_dev(t, (u64 *)crt_poly_dev, len, false, false, (hipStream_t)stream));
+    if (t.log_n >= 4 && len != 0 && std::getenv("PFHE_DISABLE_FUSED_POLYMUL") == nullptr) {
+        // the pointwise product rides on the loads of the inverse transform's first pass
+        if ((!crt_poly_dev || !dcrt_poly_dev)) return PFHE_ERR_BAD_ARGUMENT;
+        if (len_b != len && len_b != t.n * t.L) {
+            set_last_error("multiplicand must have the same length or exactly one polynomial");
+            return PFHE_ERR_BAD_LENGTH;
+        }
+        DeviceGuard g(t.device);
+        if (!g.ok) return PFHE_ERR_NO_DEVICE;
+        return ntt_inverse_mul_dev(t.primes_dev, t.L, t.log_n, t.pm, (u64 *)crt_poly_dev, len / t.n,
+                                   (const u64 *)dcrt_poly_dev, len_b / t.n, (hipStream_t)stream);
+    }
     PFHE_TRY(pointwise(t, 0, (u64 *)crt_poly_dev, nullptr, len, (const u64 *)dcrt_poly_dev, len_b,
                        (hipStream_t)stream));
     return transform_dev(t, (u64 *)crt_poly_dev, len, true, false, (hipStream_t)stream);

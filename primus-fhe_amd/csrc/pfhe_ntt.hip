@@ -130,9 +130,10 @@ __global__ __launch_bounds__(256) void ntt_strided_kernel(u64 *__restrict__ data
 //   inverse: the FIRST LOGB stages (distances 1 ... B/2); when B == N the final stage carries
 //            the fused N^-1 / N^-1*w scaling (scalar/transform.rs:283-318).
 // ------------------------------------------------------------------------------------------
-template <class A, int LOGB, bool INV>
+template <class A, int LOGB, bool INV, bool MUL = false>
 __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) void ntt_block_kernel(
-    u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L, u32 log_n, u64 total_blocks, u32 lazy) {
+    u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L, u32 log_n, u64 total_blocks, u32 lazy,
+    const u64 *__restrict__ mul, u64 mul_polys) {
     using Cfg = BlockCfg<LOGB>;
     extern __shared__ __attribute__((aligned(16))) u64 lds_raw[];
 
@@ -156,6 +157,15 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) void ntt_block_kernel(
     u64x2 io[8];
     if (valid) {
         load_block_vectors<LOGB>(io, gptr, lt);
+        if constexpr (MUL) {  // fused pointwise product (DcrtPolynomial::mul_assign) on the way in
+            u64x2 mv[8];
+            load_block_vectors<LOGB>(mv, mul + (pid % mul_polys) * n + eblk, lt);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                io[j].x = ar.mul_any(io[j].x, mv[j].x);
+                io[j].y = ar.mul_any(io[j].y, mv[j].y);
+            }
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) io[j] = u64x2{0, 0};
@@ -184,8 +194,9 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) void ntt_block_kernel(
 // ------------------------------------------------------------------------------------------
 namespace {
 
-template <class A, int LOGB, bool INV>
-int launch_block(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys, bool lazy, hipStream_t s) {
+template <class A, int LOGB, bool INV, bool MUL = false>
+int launch_block(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys, bool lazy, hipStream_t s,
+                 const u64 *mul = nullptr, u64 mul_polys = 0) {
     using Cfg = BlockCfg<LOGB>;
     const u64 total_blocks = npolys << (log_n - LOGB);
     const u64 grid = (total_blocks + Cfg::BPW - 1) / Cfg::BPW;
@@ -195,7 +206,7 @@ int launch_block(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys
         return PFHE_ERR_BAD_LENGTH;
     }
     constexpr size_t lds_bytes = (size_t)Cfg::BPW * Cfg::LDS_WORDS * sizeof(u64);
-    auto kern = ntt_block_kernel<A, LOGB, INV>;
+    auto kern = ntt_block_kernel<A, LOGB, INV, MUL>;
     if (lds_bytes > 64 * 1024) {
         static thread_local bool configured[64] = {};
         int dev = 0;
@@ -207,18 +218,18 @@ int launch_block(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys
         }
     }
     hipLaunchKernelGGL(kern, dim3((u32)grid), dim3(Cfg::THREADS), lds_bytes, s, data, primes, L, log_n,
-                       total_blocks, lazy ? 1u : 0u);
+                       total_blocks, lazy ? 1u : 0u, mul, mul_polys);
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
 }
 
-template <class A, bool INV>
+template <class A, bool INV, bool MUL = false>
 int dispatch_block(int logb, u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys, bool lazy,
-                   hipStream_t s) {
+                   hipStream_t s, const u64 *mul = nullptr, u64 mul_polys = 0) {
     switch (logb) {
 #define PFHE_CASE(B) \
     case B:          \
-        return launch_block<A, B, INV>(data, primes, L, log_n, npolys, lazy, s);
+        return launch_block<A, B, INV, MUL>(data, primes, L, log_n, npolys, lazy, s, mul, mul_polys);
         PFHE_CASE(4) PFHE_CASE(5) PFHE_CASE(6) PFHE_CASE(7) PFHE_CASE(8) PFHE_CASE(9) PFHE_CASE(10)
         PFHE_CASE(11) PFHE_CASE(12) PFHE_CASE(13) PFHE_CASE(14)
 #undef PFHE_CASE
@@ -271,8 +282,16 @@ int launch_tiny(bool inverse, const NttPrime *primes, u32 L, u32 log_n, u64 *dat
 // then strided passes, the last of which carries the fused final stage)
 template <class A>
 int run_pass(const NttPlan &plan, const NttPrime *primes, u32 L, u32 log_n, u64 *data, u64 npolys, bool inverse,
-             int index, bool lazy, hipStream_t s) {
+             int index, bool lazy, hipStream_t s, const u64 *mul = nullptr, u64 mul_polys = 0) {
     const int block_at = inverse ? 0 : plan.n_strided;
+    if (mul != nullptr) {
+        if constexpr (A::kPacked) {
+            return PFHE_ERR_UNSUPPORTED;
+        } else {
+            if (!inverse || index != block_at) return PFHE_ERR_BAD_ARGUMENT;
+            return dispatch_block<A, true, true>(plan.block_log, data, primes, L, log_n, npolys, lazy, s, mul, mul_polys);
+        }
+    }
     if (index == block_at) {
         return inverse ? dispatch_block<A, true>(plan.block_log, data, primes, L, log_n, npolys, lazy, s)
                        : dispatch_block<A, false>(plan.block_log, data, primes, L, log_n, npolys, lazy, s);
@@ -335,16 +354,17 @@ void ntt_pass_name(u32 log_n, bool inverse, int index, char *buf, size_t cap) {
 }
 
 int ntt_pass_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, bool inverse, int index,
-                 bool lazy, hipStream_t s) {
+                 bool lazy, hipStream_t s, const u64 *mul, u64 mul_polys) {
     const NttPlan plan = make_ntt_plan(log_n);
     if (index < 0 || index >= ntt_num_passes(log_n)) return PFHE_ERR_BAD_ARGUMENT;
     if (arith == kArithB32) {
         if (plan.tiny) return PFHE_ERR_UNSUPPORTED;  // N <= 16 is served by ntt32_tiny_kernel
-        return run_pass<B32Arith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s);
+        return run_pass<B32Arith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys);
     }
-    if (plan.tiny) return launch_tiny(inverse, primes, L, log_n, data, npolys, lazy, s);
-    return arith == kArithPm ? run_pass<PmArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s)
-                             : run_pass<ShoupArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s);
+    if (plan.tiny) return mul ? PFHE_ERR_UNSUPPORTED : launch_tiny(inverse, primes, L, log_n, data, npolys, lazy, s);
+    return arith == kArithPm
+               ? run_pass<PmArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys)
+               : run_pass<ShoupArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -402,7 +422,7 @@ void release_overlap_ctx(int dev, OverlapCtx *c) {
 }  // namespace
 
 static int transform(const NttPrime *primes, u32 L, u32 log_n, int pm, u64 *data, u64 npolys, bool inverse,
-                     bool lazy, hipStream_t s) {
+                     bool lazy, hipStream_t s, const u64 *mul = nullptr, u64 mul_polys = 0) {
     const int passes = ntt_num_passes(log_n);
     const u64 bytes = (npolys << log_n) * sizeof(u64);
     int dev = 0;
@@ -417,7 +437,9 @@ static int transform(const NttPrime *primes, u32 L, u32 log_n, int pm, u64 *data
     }
     OverlapCtx *c = overlap ? acquire_overlap_ctx(dev) : nullptr;
     if (!c) {
-        for (int i = 0; i < passes; ++i) PFHE_TRY(ntt_pass_dev(primes, L, log_n, pm, data, npolys, inverse, i, lazy, s));
+        for (int i = 0; i < passes; ++i)
+            PFHE_TRY(ntt_pass_dev(primes, L, log_n, pm, data, npolys, inverse, i, lazy, s, i == 0 ? mul : nullptr,
+                                  mul_polys));
         return PFHE_OK;
     }
     // tiles are whole multiples of L polynomials so that the limb of a polynomial (index % L) is
@@ -432,7 +454,10 @@ static int transform(const NttPrime *primes, u32 L, u32 log_n, int pm, u64 *data
         if (u1 == u0) continue;
         u64 *ptr = data + ((u0 * L) << log_n);
         const u64 np = (u1 - u0) * L;
-        rc = ntt_pass_dev(primes, L, log_n, pm, ptr, np, inverse, 0, lazy, c->a);
+        // a per-element multiplicand is tiled like the data; a shared one (one unit of L) is not
+        const u64 *mptr = mul == nullptr ? nullptr : (mul_polys == npolys ? mul + ((u0 * L) << log_n) : mul);
+        rc = ntt_pass_dev(primes, L, log_n, pm, ptr, np, inverse, 0, lazy, c->a, mptr,
+                          mul_polys == npolys ? np : mul_polys);
         if (rc != PFHE_OK) break;
         e = hipEventRecord(c->tile[k], c->a);
         if (e == hipSuccess) e = hipStreamWaitEvent(c->b, c->tile[k], 0);
@@ -457,6 +482,13 @@ int ntt_forward_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *da
 int ntt_inverse_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, bool lazy,
                     hipStream_t s) {
     return transform(primes, L, log_n, arith, data, npolys, true, lazy, s);
+}
+
+int ntt_inverse_mul_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, const u64 *mul,
+                        u64 mul_polys, hipStream_t s) {
+    if (mul == nullptr || mul_polys == 0 || mul_polys % L != 0 || (mul_polys != npolys && mul_polys != L))
+        return PFHE_ERR_BAD_ARGUMENT;
+    return transform(primes, L, log_n, arith, data, npolys, true, false, s, mul, mul_polys);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -26,6 +26,11 @@ int ntt_forward_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *da
                     hipStream_t s);
 int ntt_inverse_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, bool lazy,
                     hipStream_t s);
+// inverse transform of data (*) mul, the pointwise product fused into the loads of the first
+// (block) pass; `mul` holds mul_polys limb-polynomials (npolys, or one unit of L shared by the batch).
+// 64-bit policies only.
+int ntt_inverse_mul_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, const u64 *mul,
+                        u64 mul_polys, hipStream_t s);
 // U32NttTable / U32DcrtTable transforms (log_n = log2 of the polynomial length in coefficients)
 int ntt32_transform_dev(const NttPrime *primes, u32 L, u32 log_n, u32 *data, u64 npolys, bool inverse, bool lazy,
                         hipStream_t s);
@@ -33,7 +38,7 @@ int ntt32_transform_dev(const NttPrime *primes, u32 L, u32 log_n, u32 *data, u64
 int ntt_num_passes(u32 log_n);
 void ntt_pass_name(u32 log_n, bool inverse, int index, char *buf, size_t cap);
 int ntt_pass_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, bool inverse,
-                 int index, bool lazy, hipStream_t s);
+                 int index, bool lazy, hipStream_t s, const u64 *mul = nullptr, u64 mul_polys = 0);
 
 #if defined(__HIPCC__)
 
@@ -71,10 +76,14 @@ struct ShoupArith {
     u64 q, two_q;
     GCVec2Ptr fwd, inv;
     u64 inv_n, inv_n_p, inv_n_w, inv_n_w_p;
+    u64 bar_lo, bar_hi;
 
     __device__ __forceinline__ explicit ShoupArith(const NttPrime *__restrict__ P)
         : q(P->q), two_q(P->two_q), fwd((GCVec2Ptr)(const void *)P->fwd), inv((GCVec2Ptr)(const void *)P->inv),
-          inv_n(P->inv_n), inv_n_p(P->inv_n_p), inv_n_w(P->inv_n_w), inv_n_w_p(P->inv_n_w_p) {}
+          inv_n(P->inv_n), inv_n_p(P->inv_n_p), inv_n_w(P->inv_n_w), inv_n_w_p(P->inv_n_w_p), bar_lo(P->bar_lo),
+          bar_hi(P->bar_hi) {}
+    // a*b mod q for two canonical residues (no precomputed quotient): BarrettModulus::reduce_mul
+    __device__ __forceinline__ u64 mul_any(u64 a, u64 b) const { return mul_mod_barrett(a, b, q, bar_lo, bar_hi); }
     __device__ __forceinline__ Tw fwd_tw(u32 i) const {
         const u64x2 v = fwd[i];
         return Tw{v.x, v.y};
@@ -108,6 +117,8 @@ struct PmArith {
           inv_n(P->inv_n), inv_n_w(P->inv_n_w), c((u32)P->pm_c), sh(P->pm_k - 32), mask((1u << (P->pm_k - 32)) - 1) {}
     __device__ __forceinline__ Tw fwd_tw(u32 i) const { return Tw{fwd[i]}; }
     __device__ __forceinline__ Tw inv_tw(u32 i) const { return Tw{inv[i]}; }
+    // a*b mod~ q in [0,2q) for canonical residues: the twiddle multiply needs no precomputation
+    __device__ __forceinline__ u64 mul_any(u64 a, u64 b) const { return mul_lazy(a, Tw{b}); }
     __device__ __forceinline__ Tw tw_inv_n() const { return Tw{inv_n}; }
     __device__ __forceinline__ Tw tw_inv_n_w() const { return Tw{inv_n_w}; }
     // P = w*y < 2^(K+63); P = phi*2^K + plo == phi*c + plo =: R < 2^(K+33); R = rh*2^K + rl == rh*c + rl

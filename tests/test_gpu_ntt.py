@@ -309,3 +309,26 @@ def test_glwe_butterfly_ops(pf, orc, log_n, batch):
     with pytest.raises(pf.PfheError) as e:
         d.butterfly_mul_dcrt_polynomial_to_dev(to_dev(a), to_dev(s), to_dev(w[:-1].copy()), to_dev(a))
     assert e.value.kind == "BadLength"
+
+
+@pytest.mark.parametrize("log_n,moduli,batch", [
+    (4, Q61, 5), (7, Q61[:1], 3), (10, [1125899906826241, 1125899906629633], 4), (12, Q61, 3),
+    (13, [Q62], 2), (14, Q61[:2], 2), (15, [Q62, Q61[0]], 2), (16, Q61, 2), (17, [Q62], 1),
+])
+@pytest.mark.parametrize("shared", [True, False])
+def test_fused_polymul_matches_oracle(pf, orc, log_n, moduli, batch, shared):
+    """pfhe_dcrt_mul_dcrt_polynomial_dev (NTT -> product fused into the inverse transform's first
+    pass -> INTT) for both arithmetic policies, one shared or one multiplicand per polynomial."""
+    rng = np.random.default_rng(log_n + batch)
+    n, L = 1 << log_n, len(moduli)
+    d, o = pf.U64DcrtTable(log_n, moduli), orc.U64DcrtTable(log_n, moduli)
+    a = rand_rns(rng, moduli, n, batch)
+    bh = rand_rns(rng, moduli, n, 1 if shared else batch)
+    exp = a.copy(); o.transform_slice(exp)
+    for i in range(batch):
+        s = slice(i * L * n, (i + 1) * L * n)
+        o.mul_assign(exp[s], bh[:L * n] if shared else bh[s])
+    o.inverse_transform_slice(exp)
+    da = to_dev(a)
+    d.mul_dcrt_polynomial_dev(da, to_dev(bh))
+    assert np.array_equal(to_host(da), exp)
