@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void ntt_strided_kernel(u64 *__restrict__ data
 
 // ------------------------------------------------------------------------------------------
 // block pass: a workgroup owns BPW contiguous blocks of B = 2^LOGB coefficients (BPW > 1 only
-// for B < 4096 so that a workgroup always has 256+ threads).
+// for B < 1024 so that a workgroup is at least one full wave).
 //   forward: the LAST LOGB stages of the transform (distances B/2 ... 1), canonical reduction
 //            fused into the final stage (scalar/transform.rs:104-116) unless lazy.
 //   inverse: the FIRST LOGB stages (distances 1 ... B/2); when B == N the final stage carries

@@ -250,6 +250,10 @@ struct B32Arith {
 // Harvey forward butterfly, values in [0,4q) — scalar/arithmetic.rs:43-59
 template <class A>
 __device__ __forceinline__ void fwd_bfly(const A &ar, u64 &x, u64 &y, typename A::Tw w) {
+#ifdef PFHE_EXPERIMENT_NO_BFLY  // data-movement skeleton (tuning experiments only; results are wrong)
+    x ^= w.w;
+    return;
+#endif
     if constexpr (A::kPacked) {
         ar.fwd_bfly(x, y, w);
         return;
@@ -348,7 +352,13 @@ struct BlockCfg {
     static_assert(LOGB >= 4 && LOGB <= 14, "block pass handles 2^4 .. 2^14 coefficients");
     static constexpr int B = 1 << LOGB;
     static constexpr int TPB = B / 16;                     // threads per block of coefficients
-    static constexpr int THREADS = TPB > 256 ? TPB : 256;  // workgroup size
+// smallest workgroup: one wave.  Small workgroups put more independent workgroups on a CU (LDS is
+// what limits residency), which overlaps their load / compute / store phases better: measured
+// +2..9 % for N = 2^8..2^11 against 256-thread workgroups (tools/build_variant.sh -DPFHE_MIN_WG=256).
+#ifndef PFHE_MIN_WG
+#define PFHE_MIN_WG 64
+#endif
+    static constexpr int THREADS = TPB > PFHE_MIN_WG ? TPB : PFHE_MIN_WG;  // workgroup size
     static constexpr int BPW = THREADS / TPB;              // coefficient blocks per workgroup
     static constexpr int LDS_WORDS = B + B / 8;            // 16 words + 2 words of padding
 };
@@ -445,7 +455,7 @@ __device__ __forceinline__ void lds_exchange(u64 (&x)[16], u64 *__restrict__ lds
 
 template <class A, int LOGB, int POS>
 __device__ __forceinline__ void fwd_chain(const A &ar, u64 (&x)[16], u64 *__restrict__ lds, u32 n, u32 eblk, u32 lt) {
-    constexpr bool UNI = BlockCfg<LOGB>::BPW == 1;
+    constexpr bool UNI = BlockCfg<LOGB>::TPB >= 64;  // a wave never straddles two blocks
     if constexpr (POS > 0) {
         constexpr int NPOS = POS >= 4 ? POS - 4 : 0;
         constexpr int JHI = POS >= 4 ? 3 : POS - 1;
@@ -460,7 +470,7 @@ template <class A, int LOGB>
 __device__ __forceinline__ void block_forward_core(const A &ar, u64 (&x)[16], u64 *__restrict__ lds, u32 n,
                                                    u32 eblk, u32 lt, bool lazy) {
     constexpr int POS0 = LOGB - 4;
-    constexpr bool UNI = BlockCfg<LOGB>::BPW == 1;
+    constexpr bool UNI = BlockCfg<LOGB>::TPB >= 64;  // a wave never straddles two blocks
     fwd_regpass<A, POS0, 3, 0, UNI>(ar, x, n + eblk + layout<POS0>(lt, 0));
     fwd_chain<A, LOGB, POS0>(ar, x, lds, n, eblk, lt);
     if constexpr (A::kPacked) {  // distance-1 stage between the halves of each word
@@ -476,7 +486,7 @@ __device__ __forceinline__ void block_forward_core(const A &ar, u64 (&x)[16], u6
 template <class A, int LOGB, int POS>
 __device__ __forceinline__ void inv_chain(const A &ar, u64 (&x)[16], u64 *__restrict__ lds, u32 n, u32 eblk, u32 lt,
                                           bool final_block, bool lazy) {
-    constexpr bool UNI = BlockCfg<LOGB>::BPW == 1;
+    constexpr bool UNI = BlockCfg<LOGB>::TPB >= 64;  // a wave never straddles two blocks
     constexpr int DONE = POS + 4;  // element bits already processed
     if constexpr (DONE < LOGB) {
         constexpr int NPOS = DONE <= LOGB - 4 ? DONE : LOGB - 4;
@@ -492,7 +502,7 @@ __device__ __forceinline__ void inv_chain(const A &ar, u64 (&x)[16], u64 *__rest
 template <class A, int LOGB>
 __device__ __forceinline__ void block_inverse_core(const A &ar, u64 (&x)[16], u64 *__restrict__ lds, u32 n,
                                                    u32 eblk, u32 lt, bool final_block, bool lazy) {
-    constexpr bool UNI = BlockCfg<LOGB>::BPW == 1;
+    constexpr bool UNI = BlockCfg<LOGB>::TPB >= 64;  // a wave never straddles two blocks
     if constexpr (A::kPacked) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) x[k] = ar.inv_intra(x[k], n, eblk + layout<0>(lt, k));
