@@ -119,9 +119,17 @@ def pmc_traffic(kernel: str, batch: int):
         best = None
         for r in rows:
             k = r["kernel"]
-            if want not in k or r.get("hbm_bytes_per_launch") is None:
+            if want not in k or r.get("hbm_bytes_per_launch") is None or "<" not in k:
                 continue
-            is_inv = (", true>" in k) if "block" in want else (", true, true>" in k)
+            targs = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]
+            if targs[0] == "B32Arith":
+                continue  # the u32 tables' instantiation of the same kernel
+            if "block" in want:  # <A, LOGB, INV, MUL>
+                is_inv = len(targs) > 2 and targs[2] == "true"
+                if len(targs) > 3 and targs[3] == "true":
+                    continue  # fused-product variant reads a second operand
+            else:                # <A, K, VEC, INV, FINAL>
+                is_inv = len(targs) > 3 and targs[3] == "true"
             if is_inv != inv:
                 continue
             if best is None or r["grid_size"] > best["grid_size"]:

@@ -45,5 +45,20 @@ ggsw = torch.empty(ctx.ggsw_len(), dtype=torch.int64, device="cuda")
 check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(ggsw.data_ptr()), ggsw.numel(), mods.ctypes.data_as(u64p), L, n, 2, None))
 out = torch.empty(ep * 2 * L * n, dtype=torch.int64, device="cuda")
 p.mul_dcrt_ggsw_to_dev(x[:ep * 2 * L * n], ggsw, out, ctx, into_coeff_form=True)
+# fused product inside the inverse transform (config 3), shared multiplicand
+t.mul_dcrt_polynomial_dev(x, b)
+# u32 tables at the same shape (three 30-bit primes): 2 forward + 1 inverse
+t32 = p.U32DcrtTable(16, [1073479681, 1071513601, 1070727169])
+x32 = x.view(torch.int32)[:words]
+t32.fill_uniform_dev(x32, 7)
+t32.transform_dev(x32)
+t32.transform_dev(x32)
+t32.inverse_transform_dev(x32)
+# RNS base conversion Q61 -> two 60-bit moduli over 64 Mi coefficients
+cin = x[:3 * (1 << 26)]
+check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(cin.data_ptr()), cin.numel(), mods.ctypes.data_as(u64p), L, 1 << 26, 3, None))
+conv = p.BaseConverter(base, p.RNSBase([1152921504606584833, 1152921504598720513]))
+cout = torch.empty(2 * (1 << 26), dtype=torch.int64, device="cuda")
+conv.fast_convert_array_dev(cin, cout, 1 << 26)
 torch.cuda.synchronize()
 print("profile workload done")
