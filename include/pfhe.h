@@ -18,7 +18,8 @@
  *   - `*_slice` functions take HOST pointers and behave exactly like the reference call
  *     (in place, synchronous).  `*_dev` functions take DEVICE pointers that live on the handle's
  *     GPU plus a hipStream_t (as void*, NULL = default stream); they are asynchronous and are
- *     the measured hot path.
+ *     the measured hot path.  Device buffers must be 16-byte aligned (PFHE_ERR_BAD_ARGUMENT
+ *     otherwise; hipMalloc / pfhe_device_malloc memory always is).
  *   - handles are immutable after creation and may be shared between host threads
  *     (NttTable: Send + Sync, primus_ntt/src/ntt/mod.rs:16); an external-product plan owns
  *     scratch and is NOT concurrently usable (it mirrors `&mut DcrtGlevContext`,

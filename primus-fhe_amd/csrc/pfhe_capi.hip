@@ -156,6 +156,7 @@ static int check_len(const TableSet &t, size_t len, u64 &units) {
 
 int transform_dev(const TableSet &t, u64 *data, size_t len, bool inverse, bool lazy, hipStream_t s) {
     if (!data && len) return PFHE_ERR_BAD_ARGUMENT;
+    PFHE_REQUIRE_ALIGNED(data);
     u64 units = 0;
     PFHE_TRY(check_len(t, len, units));
     DeviceGuard g(t.device);
@@ -195,6 +196,9 @@ int transform_host(const TableSet &t, u64 *host, size_t len, bool inverse, bool 
 int pointwise(const TableSet &t, int mode, u64 *acc, const u64 *a, size_t len_a, const u64 *b, size_t len_b,
               hipStream_t s) {
     if ((!acc || !b || (mode == 1 && !a)) && len_a) return PFHE_ERR_BAD_ARGUMENT;
+    PFHE_REQUIRE_ALIGNED(acc);
+    PFHE_REQUIRE_ALIGNED(a);
+    PFHE_REQUIRE_ALIGNED(b);
     u64 units = 0;
     PFHE_TRY(check_len(t, len_a, units));
     if (len_b != len_a && len_b != t.n * t.L) {
@@ -576,6 +580,10 @@ static int butterfly_api(const pfhe_dcrt *table, bool factor, uint64_t *a_dev, c
     }
     if (len == 0) return PFHE_OK;
     if (!a_dev || !rhs_dev || !w_dev || !result_dev) return PFHE_ERR_BAD_ARGUMENT;
+    PFHE_REQUIRE_ALIGNED(a_dev);
+    PFHE_REQUIRE_ALIGNED(rhs_dev);
+    PFHE_REQUIRE_ALIGNED(w_dev);
+    PFHE_REQUIRE_ALIGNED(result_dev);
     DeviceGuard g(t.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
     return butterfly_dev(factor, (u64 *)a_dev, (const u64 *)rhs_dev, (const u64 *)w_dev, (u64 *)result_dev, t.primes_dev,
@@ -613,6 +621,7 @@ int pfhe_dcrt_transform_pass_dev(const pfhe_dcrt *table, uint64_t *poly_dev, siz
                                  int lazy, void *stream) {
     PFHE_GUARD_BEGIN
     if (!table || (!poly_dev && len)) return PFHE_ERR_BAD_ARGUMENT;
+    PFHE_REQUIRE_ALIGNED(poly_dev);
     const TableSet &t = *table->t;
     if (len % (t.n * t.L) != 0) return PFHE_ERR_BAD_LENGTH;
     DeviceGuard g(t.device);
@@ -631,6 +640,7 @@ int pfhe_dcrt_mul_dcrt_polynomial_dev(const pfhe_dcrt *table, uint64_t *crt_poly
     if (t.log_n >= 4 && len != 0 && std::getenv("PFHE_DISABLE_FUSED_POLYMUL") == nullptr) {
         // the pointwise product rides on the loads of the inverse transform's first pass
         if ((!crt_poly_dev || !dcrt_poly_dev)) return PFHE_ERR_BAD_ARGUMENT;
+        PFHE_REQUIRE_ALIGNED(dcrt_poly_dev);
         if (len_b != len && len_b != t.n * t.L) {
             set_last_error("multiplicand must have the same length or exactly one polynomial");
             return PFHE_ERR_BAD_LENGTH;

@@ -412,6 +412,9 @@ int pfhe_extprod_mul_dcrt_ggsw_to_dev(pfhe_extprod_plan *plan, const uint64_t *c
     const u64 batch = len_glwe / glwe;
     if (batch == 0) return PFHE_OK;
     if (!crt_glwe_dev || !dcrt_ggsw_dev || !result_dev) return PFHE_ERR_BAD_ARGUMENT;
+    PFHE_REQUIRE_ALIGNED(crt_glwe_dev);
+    PFHE_REQUIRE_ALIGNED(dcrt_ggsw_dev);
+    PFHE_REQUIRE_ALIGNED(result_dev);
     DeviceGuard g(t.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
     const bool shared = len_ggsw == ggsw && batch > 1 ? true : (len_ggsw == ggsw);
@@ -440,6 +443,9 @@ int pfhe_extprod_add_dcrt_glev_mul_crt_poly_assign_dev(pfhe_extprod_plan *plan, 
     }
     if (batch == 0) return PFHE_OK;
     if (!acc_dev || !dcrt_glev_dev || !crt_poly_dev) return PFHE_ERR_BAD_ARGUMENT;
+    PFHE_REQUIRE_ALIGNED(acc_dev);
+    PFHE_REQUIRE_ALIGNED(dcrt_glev_dev);
+    PFHE_REQUIRE_ALIGNED(crt_poly_dev);
     DeviceGuard g(t.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
     return run_product(plan, (const u64 *)crt_poly_dev, 1, (const u64 *)dcrt_glev_dev, len_glev == glev,
@@ -462,6 +468,9 @@ int pfhe_extprod_glev_mul_crt_poly_to_dev(pfhe_extprod_plan *plan, const uint64_
     }
     if (batch == 0) return PFHE_OK;
     if (!result_dev || !dcrt_glev_dev || !crt_poly_dev) return PFHE_ERR_BAD_ARGUMENT;
+    PFHE_REQUIRE_ALIGNED(result_dev);
+    PFHE_REQUIRE_ALIGNED(dcrt_glev_dev);
+    PFHE_REQUIRE_ALIGNED(crt_poly_dev);
     DeviceGuard g(t.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
     return run_product(plan, (const u64 *)crt_poly_dev, 1, (const u64 *)dcrt_glev_dev, len_glev == glev,

@@ -31,6 +31,17 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
         if (rc_ != PFHE_OK) return rc_; \
     } while (0)
 
+// The kernels move data as 16-byte vectors: every device buffer handed to a *_dev entry point must
+// be 16-byte aligned (hipMalloc returns 256-byte aligned memory; only odd sub-slices can violate it).
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+#define PFHE_REQUIRE_ALIGNED(ptr)                                                  \
+    do {                                                                           \
+        if (!::pfhe::aligned16(ptr)) {                                             \
+            ::pfhe::set_last_error(#ptr " must be 16-byte aligned");               \
+            return PFHE_ERR_BAD_ARGUMENT;                                          \
+        }                                                                          \
+    } while (0)
+
 // RAII: make `device` current for the scope, restore the previous device afterwards.
 struct DeviceGuard {
     int prev = -1;

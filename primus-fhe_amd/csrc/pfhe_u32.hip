@@ -194,6 +194,7 @@ namespace {
 
 int transform32_dev(const TableSet &t, u32 *data, size_t len, bool inverse, bool lazy, hipStream_t s) {
     if (!data && len) return PFHE_ERR_BAD_ARGUMENT;
+    PFHE_REQUIRE_ALIGNED(data);
     u64 units = 0;
     PFHE_TRY(check_len32(t, len, units));
     DeviceGuard g(t.device);
@@ -230,6 +231,9 @@ int transform32_host(const TableSet &t, u32 *host, size_t len, bool inverse, boo
 int pointwise32(const TableSet &t, int mode, u32 *acc, const u32 *a, size_t len_a, const u32 *b, size_t len_b,
                 hipStream_t s) {
     if ((!acc || !b || (mode == 1 && !a)) && len_a) return PFHE_ERR_BAD_ARGUMENT;
+    PFHE_REQUIRE_ALIGNED(acc);
+    PFHE_REQUIRE_ALIGNED(a);
+    PFHE_REQUIRE_ALIGNED(b);
     u64 units = 0;
     PFHE_TRY(check_len32(t, len_a, units));
     if (len_b != len_a && len_b != t.n * t.L) {
@@ -500,6 +504,7 @@ int pfhe_dcrt32_transform_pass_dev(const pfhe_dcrt32 *table, uint32_t *poly_dev,
                                    int lazy, void *stream) {
     PFHE_GUARD_BEGIN
     if (!table || (!poly_dev && len)) return PFHE_ERR_BAD_ARGUMENT;
+    PFHE_REQUIRE_ALIGNED(poly_dev);
     const TableSet &t = *table->t;
     if (len % (t.n * t.L) != 0) return PFHE_ERR_BAD_LENGTH;
     DeviceGuard g(t.device);

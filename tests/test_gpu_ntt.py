@@ -332,3 +332,19 @@ def test_fused_polymul_matches_oracle(pf, orc, log_n, moduli, batch, shared):
     da = to_dev(a)
     d.mul_dcrt_polynomial_dev(da, to_dev(bh))
     assert np.array_equal(to_host(da), exp)
+
+
+def test_misaligned_device_buffer_is_rejected(pf):
+    """Device buffers must be 16-byte aligned (the kernels move 16-byte vectors)."""
+    import torch
+    d = pf.U64DcrtTable(10, Q61)
+    x = torch.zeros(3 * 1024 + 1, dtype=torch.int64, device="cuda")
+    with pytest.raises(pf.PfheError) as e:
+        d.transform_dev(x[1:])
+    assert e.value.kind == "BadArgument" and "aligned" in str(e.value)
+    d.transform_dev(x[:-1])
+    t32 = pf.U32NttTable(10, 132120577)
+    y = torch.zeros(1024 + 2, dtype=torch.int32, device="cuda")
+    with pytest.raises(pf.PfheError) as e:
+        t32.transform_dev(y[2:])
+    assert e.value.kind == "BadArgument"
