@@ -1,0 +1,154 @@
+"""Seeded randomized differential tests: HIP path (through the C ABI) vs the oracle over random
+NTT-friendly primes of 20..62 bits (both arithmetic policies get exercised: most random primes do
+not have the pseudo-Mersenne shape), 1..6 RNS limbs, ragged batch sizes and every transform plan."""
+import numpy as np
+import pytest
+
+from gpu_util import to_dev, to_host
+
+pytestmark = pytest.mark.gpu
+
+
+def is_prime(n: int) -> bool:
+    if n < 2:
+        return False
+    for p in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        if n % p == 0:
+            return n == p
+    d, s = n - 1, 0
+    while d % 2 == 0:
+        d //= 2
+        s += 1
+    for a in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        x = pow(a, d, n)
+        if x in (1, n - 1):
+            continue
+        for _ in range(s - 1):
+            x = x * x % n
+            if x == n - 1:
+                break
+        else:
+            return False
+    return True
+
+
+def random_ntt_primes(rng, count, bits, log_n):
+    """`count` distinct primes of exactly `bits` bits with 2^(log_n+1) | q - 1."""
+    step = 1 << (log_n + 1)
+    lo, hi = (1 << (bits - 1)) // step + 1, (1 << bits) // step
+    assert hi - lo >= 64 * count, "not enough candidates: raise `bits`"
+    out = []
+    for _ in range(200000):
+        k = int(rng.integers(lo, hi))
+        q = k * step + 1
+        if q.bit_length() == bits and q not in out and is_prime(q):
+            out.append(q)
+            if len(out) == count:
+                return out
+    raise AssertionError("prime search exhausted")
+
+
+@pytest.fixture(scope="module")
+def pf():
+    import primus_fhe_amd as p
+    return p
+
+
+CASES = list(range(60))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_random_u64_tables(pf, orc, case):
+    rng = np.random.default_rng(1000 + case)
+    log_n = int(rng.integers(1, 15)) if case % 5 else int(rng.integers(15, 18))
+    bits = int(rng.integers(max(log_n + 12, 20), 63))
+    L = int(rng.integers(1, 7))
+    batch = int(rng.integers(1, 6)) if log_n > 10 else int(rng.integers(1, 70))
+    moduli = random_ntt_primes(rng, L, bits, log_n)
+    n = 1 << log_n
+    d, o = pf.U64DcrtTable(log_n, moduli), orc.U64DcrtTable(log_n, moduli)
+    assert d.roots() == [o.table(i).root for i in range(L)]
+    a = np.concatenate([rng.integers(0, q, n, dtype=np.uint64) for _ in range(batch) for q in moduli])
+    b = np.concatenate([rng.integers(0, q, n, dtype=np.uint64) for _ in range(batch) for q in moduli])
+    ref = a.copy(); o.transform_slice(ref)
+    da = to_dev(a)
+    d.transform_dev(da)
+    assert np.array_equal(to_host(da), ref), (log_n, moduli, batch)
+    # polynomial product through the fused path, per-element multiplicand
+    fb = b.copy(); o.transform_slice(fb)
+    exp = ref.copy()
+    W = L * n
+    for e in range(batch):
+        o.mul_assign(exp[e * W:(e + 1) * W], fb[e * W:(e + 1) * W])
+    o.inverse_transform_slice(exp)
+    dprod = to_dev(a)
+    d.mul_dcrt_polynomial_dev(dprod, to_dev(fb))
+    assert np.array_equal(to_host(dprod), exp)
+    # lazy forward on [0,4q) inputs agrees mod q and stays in range
+    lz = np.concatenate([rng.integers(0, 4 * q, n, dtype=np.uint64) for _ in range(batch) for q in moduli])
+    can = lz.copy()
+    qs = np.repeat(np.tile(np.array(moduli, np.uint64), batch), n)
+    can %= qs
+    o.transform_slice(can)
+    dl = to_dev(lz)
+    d.transform_dev(dl, lazy=True)
+    got = to_host(dl)
+    assert (got < 4 * qs).all() and np.array_equal(got % qs, can)
+
+
+@pytest.mark.parametrize("case", range(30))
+def test_random_u32_tables(pf, orc, case):
+    rng = np.random.default_rng(2000 + case)
+    log_n = int(rng.integers(1, 15)) if case % 5 else int(rng.integers(15, 18))
+    bits = int(rng.integers(min(max(log_n + 12, 14), 30), 31))
+    L = int(rng.integers(1, 5))
+    batch = int(rng.integers(1, 6)) if log_n > 10 else int(rng.integers(1, 70))
+    moduli = random_ntt_primes(rng, L, bits, log_n)
+    n = 1 << log_n
+    d, o = pf.U32DcrtTable(log_n, moduli), orc.U32DcrtTable(log_n, moduli)
+    a = np.concatenate([rng.integers(0, q, n, dtype=np.uint64).astype(np.uint32) for _ in range(batch) for q in moduli])
+    ref = a.copy(); o.transform_slice(ref)
+    got = a.copy(); d.transform_slice(got)
+    assert np.array_equal(got, ref), (log_n, moduli, batch)
+    d.inverse_transform_slice(got)
+    assert np.array_equal(got, a)
+    lz = a.copy(); d.lazy_transform_slice(lz)
+    lzo = a.copy(); o.lazy_transform_slice(lzo)
+    assert np.array_equal(lz, lzo)
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_random_external_products(pf, orc, case):
+    rng = np.random.default_rng(3000 + case)
+    log_n = int(rng.integers(3, 13)) if case % 4 else 16
+    L = int(rng.integers(1, 4))
+    bits = int(rng.integers(40, 62))
+    k = int(rng.integers(1, 3)) if log_n < 16 else 1
+    moduli = random_ntt_primes(rng, L, bits, log_n)
+    total_bits = sum(q.bit_length() for q in moduli)
+    log_basis = int(rng.integers(4, min(31, min(moduli).bit_length() - 1)))
+    ell_full = 1
+    Q = 1
+    for q in moduli:
+        Q *= q
+    ell_full = Q.bit_length() // log_basis
+    rev = None if case % 3 else int(rng.integers(1, ell_full + 1))
+    batch = int(rng.integers(1, 4))
+    shared = bool(case % 2)
+    n = 1 << log_n
+    ot, ob = orc.U64DcrtTable(log_n, moduli), orc.RNSBase(moduli)
+    obasis = orc.BigUintApproxSignedBasis(ob, log_basis, rev)
+    ell = obasis.decompose_length
+    W = (k + 1) * L * n
+    glwe = np.concatenate([rng.integers(0, q, n, dtype=np.uint64) for _ in range(batch * (k + 1)) for q in moduli])
+    ggsw = np.concatenate([rng.integers(0, q, n, dtype=np.uint64)
+                           for _ in range((1 if shared else batch) * (k + 1) * ell * (k + 1)) for q in moduli])
+    G = (k + 1) * ell * W
+    exp = np.concatenate([orc.mul_dcrt_ggsw_to(ot, ob, obasis, k, glwe[e * W:(e + 1) * W].copy(),
+                                               ggsw[:G] if shared else ggsw[e * G:(e + 1) * G])
+                          for e in range(batch)])
+    t, base = pf.U64DcrtTable(log_n, moduli), pf.RNSBase(moduli)
+    ctx = pf.DcrtGlevContext(t, base, pf.BigUintApproxSignedBasis(base, log_basis, rev), k, int(rng.integers(0, 3)))
+    out = np.empty_like(glwe)
+    pf.mul_dcrt_ggsw_to(glwe, ggsw, out, ctx)
+    assert np.array_equal(out, exp), (log_n, moduli, k, log_basis, rev, batch, shared, total_bits)
