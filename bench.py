@@ -11,9 +11,11 @@ shard across GPUs with no collective: each rank owns its own ba
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line.  Extra legs on rank 0 at N = 1: per-kernel HIP-event timing for the
-roofline object, the fused NTT->mul->INTT rate (config 3), and a bounded CPU run of the oracle
-(the C restatement of the reference's scalar path) for `cpu_baseline`.
+Rank 0 prints ONE JSON line.  Every rank also runs the RLWE external product (config 4; batch 1024
+per GPU, aggregated over ranks = config 5's scaling curve).  Extra legs on rank 0 at N = 1:
+per-kernel HIP-event timing for the roofline object, the fused NTT->mul->INTT rate (config 3), the
+u32 tables, and a bounded CPU run of the oracle (the C restatement of the reference's scalar path)
+for `cpu_baseline`.
 """
 from __future__ import annotations
 
@@ -199,6 +201,33 @@ def main():
         "hbm_roofline_frac": value * 16 * n / world / (HBM_PEAK_GBS * 1e9),
     }
 
+    # ---- config 4 / 5: RNS gadget external product, k=1, logB=30 (ell=6), batch 1024 per GPU, one shared
+    #      GGSW replicated per device; every rank runs it, the rate is aggregated over ranks (weak scaling,
+    #      no collective on the data path) ----
+    ep_batch = min(args.ext_batch, batch)
+    base = p.RNSBase(Q61, device=local_rank)
+    basis = p.BigUintApproxSignedBasis(base, 30)
+    ctx = p.DcrtGlevContext(table, base, basis, 1, args.ext_chunk)
+    glwe_words, ggsw_words = ep_batch * 2 * L * n, ctx.ggsw_len()
+    check(p.lib().pfhe_fill_uniform_dev(local_rank, C.c_void_p(x.data_ptr()), glwe_words, mods.ctypes.data_as(u64p), L, n,
+                                        0x5EED000000000004 + rank, None))
+    glwe = x[:glwe_words]                           # canonical residues: a valid CrtGlwe batch
+    ggsw = torch.empty(ggsw_words, dtype=torch.int64, device="cuda")
+    check(p.lib().pfhe_fill_uniform_dev(local_rank, C.c_void_p(ggsw.data_ptr()), ggsw_words, mods.ctypes.data_as(u64p), L,
+                                        n, 99, None))
+    out = torch.empty(glwe_words, dtype=torch.int64, device="cuda")
+    ep_steps = max(2, args.steps // 3)
+    dte = timed_steps(lambda: p.mul_dcrt_ggsw_to_dev(glwe, ggsw, out, ctx, into_coeff_form=True), ep_steps, 1,
+                      torch.cuda.synchronize, dist, "cuda" if args.dist_backend == "nccl" else "cpu") / ep_steps
+    result["external_product"] = {
+        "value": world * ep_batch / dte, "unit": "RLWE external products/s (CrtGlwe x DcrtGgsw -> coefficient form), "
+                                                 "whole job", "n_gpus": world,
+        "batch_per_gpu": ep_batch, "ms_per_batch": dte * 1e3, "gadget": {"log_basis": 30, "ell": 6, "k": 1},
+        "ggsw": "one shared 36 MiB DcrtGgsw per GPU", "chunk": args.ext_chunk or 32,
+        "hbm_roofline_frac": ep_batch / dte * 96 * n / (HBM_PEAK_GBS * 1e9),
+        "limb_ntts_per_product": 42}
+    del ggsw, out, ctx
+
     if rank == 0 and world == 1:
         # ---- per-kernel timing (HIP events on the launch stream) for the roofline object ----
         npass = p.lib().pfhe_dcrt_transform_num_passes(table._h)
@@ -240,33 +269,6 @@ def main():
         dtp = (time.perf_counter() - t0) / reps
         result["polymul"] = {"value": batch / dtp, "unit": "RNS polynomial products/s (NTT+mul+INTT, shared multiplicand)",
                              "ms_per_batch": dtp * 1e3, "hbm_roofline_frac": batch / dtp * 48 * n / (HBM_PEAK_GBS * 1e9)}
-        # ---- config 4: RNS gadget external product, k=1, logB=30 (ell=6), batch 1024, one shared GGSW ----
-        del bhat
-        ep_batch = min(args.ext_batch, batch)
-        base = p.RNSBase(Q61, device=local_rank)
-        basis = p.BigUintApproxSignedBasis(base, 30)
-        ctx = p.DcrtGlevContext(table, base, basis, 1, args.ext_chunk)
-        glwe_words, ggsw_words = ep_batch * 2 * L * n, ctx.ggsw_len()
-        glwe = x[:glwe_words]                       # canonical residues: a valid CrtGlwe batch
-        ggsw = torch.empty(ggsw_words, dtype=torch.int64, device="cuda")
-        check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(ggsw.data_ptr()), ggsw_words, mods.ctypes.data_as(u64p), L, n,
-                                            99, None))
-        out = torch.empty(glwe_words, dtype=torch.int64, device="cuda")
-        p.mul_dcrt_ggsw_to_dev(glwe, ggsw, out, ctx, into_coeff_form=True)
-        torch.cuda.synchronize()
-        reps = max(2, args.steps // 3)
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            p.mul_dcrt_ggsw_to_dev(glwe, ggsw, out, ctx, into_coeff_form=True)
-        torch.cuda.synchronize()
-        dte = (time.perf_counter() - t0) / reps
-        result["external_product"] = {
-            "value": ep_batch / dte, "unit": "RLWE external products/s (CrtGlwe x DcrtGgsw -> coefficient form)",
-            "batch": ep_batch, "ms_per_batch": dte * 1e3, "gadget": {"log_basis": 30, "ell": 6, "k": 1},
-            "ggsw": "one shared 36 MiB DcrtGgsw", "chunk": args.ext_chunk or 32,
-            "hbm_roofline_frac": ep_batch / dte * 96 * n / (HBM_PEAK_GBS * 1e9),
-            "limb_ntts_per_product": 42}
-        del ggsw, out, ctx
         # ---- §8f rank 1: the u32 / low-q tables at the same shape (N=2^16, three 30-bit primes) ----
         q30 = [1073479681, 1071513601, 1070727169]
         t32 = p.U32DcrtTable(LOG_N, q30, device=local_rank)
