@@ -26,7 +26,7 @@ def build(native: bool = False, out_dir: str | None = None) -> str:
     out = os.path.join(out_dir, "liboracle_native.so")
     subprocess.run(
         ["gcc", "-O3", "-march=native", "-fPIC", "-std=c11", "-shared", "-o", out,
-         os.path.join(_HERE, "pfhe_oracle.c")],
+         os.path.join(_HERE, "pfhe_oracle.c"), os.path.join(_HERE, "pfhe_oracle_avx512.c")],
         check=True,
     )
     return out
@@ -77,6 +77,8 @@ def _load(path: str | None = None) -> C.CDLL:
               "lazy_inverse_transform_slice"):
         sig("orc_u64_ntt_" + g, None, vp, _u64p)
         sig("orc_uint_ntt_" + g, None, vp, _u64p)
+    sig("orc_avx512_available", ci)
+    sig("orc_u64_ntt_forward_avx512", ci, vp, _u64p, ci)
     sig("orc_u64_ntt_transform_monomial", None, vp, u64, sz, _u64p)
     sig("orc_u64_ntt_transform_coeff_one_monomial", None, vp, sz, _u64p)
     sig("orc_u64_ntt_transform_coeff_minus_one_monomial", None, vp, sz, _u64p)
@@ -253,6 +255,16 @@ class U64NttTable:
     def inverse_transform_slice(self, a): self._each(lib().orc_u64_ntt_inverse_transform_slice, a)
     def lazy_transform_slice(self, a): self._each(lib().orc_u64_ntt_lazy_transform_slice, a)
     def lazy_inverse_transform_slice(self, a): self._each(lib().orc_u64_ntt_lazy_inverse_transform_slice, a)
+
+    def transform_slice_avx512(self, a, lazy: bool = False):
+        """Forward transform through the AVX-512 DQ backend (prime64/avx512/); raises when unavailable."""
+        assert a.size % self.n == 0
+        flat = a.reshape(-1)
+        base = flat.ctypes.data
+        for i in range(flat.size // self.n):
+            rc = lib().orc_u64_ntt_forward_avx512(self._h, C.cast(base + 8 * self.n * i, _u64p), int(lazy))
+            if rc:
+                raise OracleError(rc)
 
     def scalar_forward(self, a, bit_shift, output_mod_factor):
         lib().orc_u64_ntt_scalar_forward(self._h, _p(a), bit_shift, output_mod_factor)

@@ -124,6 +124,11 @@ void orc_uint_ntt_transform_monomial(const orc_uint_ntt *t, uint64_t coeff, size
                                      uint64_t *values);
 
 /* ---------------- U64DcrtTable (dcrt/prime64.rs) ---------------- */
+/* AVX-512 (DQ) backend of the forward transform (pfhe_oracle_avx512.c; prime64/avx512/), n >= 16.
+ * Returns ORC_ERR_BAD_ARG when the host lacks AVX-512 DQ. */
+int orc_avx512_available(void);
+int orc_u64_ntt_forward_avx512(const orc_u64_ntt *t, uint64_t *values, int lazy);
+
 /* ---------------- U32NttTable (prime32/table.rs, prime32/scalar/) ---------------- */
 typedef struct orc_u32_ntt orc_u32_ntt;
 uint32_t orc_u32_mul_mod_lazy(uint32_t y, uint32_t w, uint32_t w_precon, uint32_t q);

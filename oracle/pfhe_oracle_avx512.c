@@ -1,0 +1,135 @@
+/*
+ * pfhe_oracle_avx512.c — AVX-512 (DQ) restatement of the reference's vectorised forward NTT for
+ * 64-bit primes (TEST / BENCH INFRASTRUCTURE ONLY, see pfhe_oracle.h).
+ *
+ * On an AVX-512 host U64NttTable dispatches to its HEXL-style kernels
+ * (primus_ntt/src/ntt/prime64/table.rs:408-418); this file restates the BIT_SHIFT = 64 path:
+ *   butterfly          prime64/avx512/butterfly.rs:10-57   (Harvey, approximate quotient)
+ *   mulhi_approx       prime64/avx512/utils/arithmetic.rs:94-127
+ *   small_mod          x -> min(x, x - 2q)                  (utils/arithmetic.rs)
+ *   stage structure    prime64/avx512/transform.rs:13-260, stages.rs: depth-first splitting down
+ *                      to 1024 points, then breadth-first T8 stages and the shuffled T4/T2/T1 stages.
+ * Unlike the reference it does not pre-expand the twiddle tables for T4/T2/T1 (it permutes the
+ * loaded twiddles instead); the arithmetic per butterfly is the same.  Canonical outputs are
+ * identical to the scalar path's (tests/test_oracle_avx512.py); it exists so that bench.py's
+ * cpu_baseline is not handicapped against what the real reference would run on this host.
+ */
+#include <immintrin.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "pfhe_oracle.h"
+
+#define TGT __attribute__((target("avx512f,avx512dq")))
+
+int orc_avx512_available(void) {
+    __builtin_cpu_init();
+    return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq");
+}
+
+TGT static inline __m512i small_mod(__m512i x, __m512i m) { return _mm512_min_epu64(x, _mm512_sub_epi64(x, m)); }
+
+/* utils/arithmetic.rs:94-127: high 64 bits of x*y without the lo*lo partial product (error <= 1) */
+TGT static inline __m512i mulhi_approx(__m512i x, __m512i y) {
+    const __m512i lo_mask = _mm512_set1_epi64(0xFFFFFFFFll);
+    const __m512i x_hi = _mm512_shuffle_epi32(x, (_MM_PERM_ENUM)0xB1), y_hi = _mm512_shuffle_epi32(y, (_MM_PERM_ENUM)0xB1);
+    const __m512i z_lo_hi = _mm512_mul_epu32(x, y_hi), z_hi_lo = _mm512_mul_epu32(x_hi, y), z_hi_hi = _mm512_mul_epu32(x_hi, y_hi);
+    const __m512i sum_lo = _mm512_and_si512(z_lo_hi, lo_mask), sum_mid = _mm512_srli_epi64(z_lo_hi, 32);
+    const __m512i sum_mid2 = _mm512_add_epi64(z_hi_lo, sum_lo);
+    return _mm512_add_epi64(_mm512_add_epi64(z_hi_hi, sum_mid), _mm512_srli_epi64(sum_mid2, 32));
+}
+
+/* butterfly.rs:10-57, BIT_SHIFT = 64 */
+TGT static inline void fwd_bfly(__m512i *x, __m512i *y, __m512i w, __m512i wp, __m512i neg_q, __m512i two_q) {
+    *x = small_mod(*x, two_q);
+    const __m512i qh = mulhi_approx(wp, *y);
+    __m512i t = _mm512_add_epi64(_mm512_mullo_epi64(w, *y), _mm512_mullo_epi64(qh, neg_q)); /* [0,4q) */
+    t = small_mod(t, two_q);
+    *y = _mm512_add_epi64(*x, _mm512_sub_epi64(two_q, t));
+    *x = _mm512_add_epi64(*x, t);
+}
+
+/* one stage with butterfly distance t >= 8 over `n` values whose first group uses roots[ri0] */
+TGT static void stage_t8(uint64_t *v, size_t n, size_t t, const uint64_t *w, const uint64_t *wp, size_t ri0,
+                         __m512i neg_q, __m512i two_q) {
+    size_t ri = ri0;
+    for (size_t c = 0; c < n; c += 2 * t, ++ri) {
+        const __m512i vw = _mm512_set1_epi64((long long)w[ri]), vwp = _mm512_set1_epi64((long long)wp[ri]);
+        for (size_t j = 0; j < t; j += 8) {
+            __m512i x = _mm512_loadu_si512(v + c + j), y = _mm512_loadu_si512(v + c + j + t);
+            fwd_bfly(&x, &y, vw, vwp, neg_q, two_q);
+            _mm512_storeu_si512(v + c + j, x);
+            _mm512_storeu_si512(v + c + j + t, y);
+        }
+    }
+}
+
+/* the last three stages (distances 4, 2, 1) on 16 consecutive values at a time; `m4` = number of
+ * distance-4 groups in this sub-transform, whose roots start at roots[ri4] (then 2*ri4, 4*ri4) */
+TGT static void stages_t4_t2_t1(uint64_t *v, size_t n, const uint64_t *w, const uint64_t *wp, size_t ri4,
+                                __m512i neg_q, __m512i two_q, __m512i q, int canonical) {
+    const __m512i ix4 = _mm512_setr_epi64(0, 1, 2, 3, 8, 9, 10, 11), iy4 = _mm512_setr_epi64(4, 5, 6, 7, 12, 13, 14, 15);
+    const __m512i iw4 = _mm512_setr_epi64(0, 0, 0, 0, 1, 1, 1, 1);
+    const __m512i ix2 = _mm512_setr_epi64(0, 1, 4, 5, 8, 9, 12, 13), iy2 = _mm512_setr_epi64(2, 3, 6, 7, 10, 11, 14, 15);
+    const __m512i iw2 = _mm512_setr_epi64(0, 0, 1, 1, 2, 2, 3, 3);
+    const __m512i oa2 = _mm512_setr_epi64(0, 1, 8, 9, 2, 3, 10, 11), ob2 = _mm512_setr_epi64(4, 5, 12, 13, 6, 7, 14, 15);
+    const __m512i ix1 = _mm512_setr_epi64(0, 2, 4, 6, 8, 10, 12, 14), iy1 = _mm512_setr_epi64(1, 3, 5, 7, 9, 11, 13, 15);
+    const __m512i oa1 = _mm512_setr_epi64(0, 8, 1, 9, 2, 10, 3, 11), ob1 = _mm512_setr_epi64(4, 12, 5, 13, 6, 14, 7, 15);
+    size_t r4 = ri4, r2 = 2 * ri4, r1 = 4 * ri4;
+    for (size_t c = 0; c < n; c += 16, r4 += 2, r2 += 4, r1 += 8) {
+        __m512i a = _mm512_loadu_si512(v + c), b = _mm512_loadu_si512(v + c + 8);
+        /* distance 4 */
+        __m512i x = _mm512_permutex2var_epi64(a, ix4, b), y = _mm512_permutex2var_epi64(a, iy4, b);
+        __m512i vw = _mm512_permutexvar_epi64(iw4, _mm512_maskz_loadu_epi64(0x03, w + r4));
+        __m512i vp = _mm512_permutexvar_epi64(iw4, _mm512_maskz_loadu_epi64(0x03, wp + r4));
+        fwd_bfly(&x, &y, vw, vp, neg_q, two_q);
+        a = _mm512_permutex2var_epi64(x, ix4, y); /* [X0-3, Y0-3] */
+        b = _mm512_permutex2var_epi64(x, iy4, y); /* [X4-7, Y4-7] */
+        /* distance 2 */
+        x = _mm512_permutex2var_epi64(a, ix2, b);
+        y = _mm512_permutex2var_epi64(a, iy2, b);
+        vw = _mm512_permutexvar_epi64(iw2, _mm512_maskz_loadu_epi64(0x0F, w + r2));
+        vp = _mm512_permutexvar_epi64(iw2, _mm512_maskz_loadu_epi64(0x0F, wp + r2));
+        fwd_bfly(&x, &y, vw, vp, neg_q, two_q);
+        a = _mm512_permutex2var_epi64(x, oa2, y);
+        b = _mm512_permutex2var_epi64(x, ob2, y);
+        /* distance 1 */
+        x = _mm512_permutex2var_epi64(a, ix1, b);
+        y = _mm512_permutex2var_epi64(a, iy1, b);
+        vw = _mm512_loadu_si512(w + r1);
+        vp = _mm512_loadu_si512(wp + r1);
+        fwd_bfly(&x, &y, vw, vp, neg_q, two_q);
+        if (canonical) { /* [0,4q) -> [0,q) */
+            x = small_mod(small_mod(x, two_q), q);
+            y = small_mod(small_mod(y, two_q), q);
+        }
+        _mm512_storeu_si512(v + c, _mm512_permutex2var_epi64(x, oa1, y));
+        _mm512_storeu_si512(v + c + 8, _mm512_permutex2var_epi64(x, ob1, y));
+    }
+}
+
+/* transform.rs:13-260: sub-transform of `n` values whose first stage (distance n/2) has its single
+ * group at roots[ri]; the following stage's groups start at roots[2*ri], and so on */
+TGT static void forward_rec(uint64_t *v, size_t n, const uint64_t *w, const uint64_t *wp, size_t ri, __m512i neg_q,
+                            __m512i two_q, __m512i q, int canonical) {
+    if (n > 1024) { /* depth-first: one stage, then the two halves */
+        stage_t8(v, n, n >> 1, w, wp, ri, neg_q, two_q);
+        forward_rec(v, n >> 1, w, wp, 2 * ri, neg_q, two_q, q, canonical);
+        forward_rec(v + (n >> 1), n >> 1, w, wp, 2 * ri + 1, neg_q, two_q, q, canonical);
+        return;
+    }
+    size_t t = n >> 1, r = ri;
+    for (; t >= 8; t >>= 1, r <<= 1) stage_t8(v, n, t, w, wp, r, neg_q, two_q);
+    stages_t4_t2_t1(v, n, w, wp, r, neg_q, two_q, q, canonical);
+}
+
+/* U64NttTable::transform_slice / lazy_transform_slice through the AVX-512 backend (n >= 16) */
+TGT int orc_u64_ntt_forward_avx512(const orc_u64_ntt *t, uint64_t *values, int lazy) {
+    const size_t n = orc_u64_ntt_n(t);
+    if (n < 16 || !orc_avx512_available()) return ORC_ERR_BAD_ARG;
+    const uint64_t qv = orc_u64_ntt_modulus(t);
+    const __m512i q = _mm512_set1_epi64((long long)qv), two_q = _mm512_set1_epi64((long long)(qv << 1));
+    const __m512i neg_q = _mm512_set1_epi64(-(long long)qv);
+    forward_rec(values, n, orc_u64_ntt_roots(t), orc_u64_ntt_roots_precon64(t), 1, neg_q, two_q, q, !lazy);
+    return ORC_OK;
+}
