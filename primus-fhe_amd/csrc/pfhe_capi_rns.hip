@@ -24,6 +24,7 @@ struct pfhe_extprod_plan {
     // pass of chunk c+1 fills the other buffer on stream `sa`
     u64 *digits[2] = {nullptr, nullptr};
     size_t digits_words = 0;  // per buffer
+    int *sdigits = nullptr;   // compact signed digits of one chunk (chunk * (k+1) * ell * N int32), or null
     hipStream_t sa = nullptr, sb = nullptr;
     hipEvent_t fork = nullptr, join_a = nullptr, join_b = nullptr;
     hipEvent_t produced[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
@@ -34,6 +35,7 @@ struct pfhe_extprod_plan {
         if (sb) (void)hipStreamSynchronize(sb);
         for (u64 *d : digits)
             if (d) (void)hipFree(d);
+        if (sdigits) (void)hipFree(sdigits);
         for (hipEvent_t e : {fork, join_a, join_b, produced[0], produced[1], consumed[0], consumed[1]})
             if (e) (void)hipEventDestroy(e);
         if (sa) (void)hipStreamDestroy(sa);
@@ -107,7 +109,7 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
         if (fused && index >= 2) PFHE_HIP(hipStreamWaitEvent(p->sa, p->consumed[buf], 0));
         if (fused_decompose) {
             PFHE_TRY(gadget_decompose_strided_dev(p->rns, p->basis, t.primes_dev, t.log_n, t.pm,
-                                                  crt_polys + done * rows * W, dg, cur * rows, p->sa));
+                                                  crt_polys + done * rows * W, dg, cur * rows, p->sa, p->sdigits));
         } else {
             PFHE_TRY(gadget_decompose_dev(p->rns, p->basis, t.log_n, crt_polys + done * rows * W, dg, cur * rows, p->sa));
             for (int i = 0; i < passes - 1; ++i)
@@ -383,6 +385,12 @@ int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *rns, const 
         PFHE_HIP(hipEventCreateWithFlags(&p->produced[i], hipEventDisableTiming));
         PFHE_HIP(hipEventCreateWithFlags(&p->consumed[i], hipEventDisableTiming));
     }
+    if (gadget_split_decompose_supported(t->log_n, p->rns.value_len, p->basis.log_basis) &&
+        std::getenv("PFHE_DISABLE_SPLIT_DECOMPOSE") == nullptr) {
+        void *d = nullptr;
+        PFHE_HIP(hipMalloc(&d, p->chunk * (p->k + 1) * p->basis.ell * t->n * sizeof(int)));
+        p->sdigits = (int *)d;
+    }
     PFHE_HIP(hipStreamCreateWithFlags(&p->sa, hipStreamNonBlocking));
     PFHE_HIP(hipStreamCreateWithFlags(&p->sb, hipStreamNonBlocking));
     PFHE_HIP(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
@@ -394,7 +402,10 @@ int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *rns, const 
 }
 
 void pfhe_extprod_plan_destroy(pfhe_extprod_plan *p) { delete p; }
-size_t pfhe_extprod_plan_scratch_bytes(const pfhe_extprod_plan *p) { return p ? 2 * p->digits_words * 8 : 0; }
+size_t pfhe_extprod_plan_scratch_bytes(const pfhe_extprod_plan *p) {
+    if (!p) return 0;
+    return 2 * p->digits_words * 8 + (p->sdigits ? p->chunk * (p->k + 1) * p->basis.ell * p->table->n * sizeof(int) : 0);
+}
 
 int pfhe_extprod_mul_dcrt_ggsw_to_dev(pfhe_extprod_plan *plan, const uint64_t *crt_glwe_dev, size_t len_glwe,
                                       const uint64_t *dcrt_ggsw_dev, size_t len_ggsw, uint64_t *result_dev,

@@ -175,6 +175,93 @@ __global__ __launch_bounds__(256) void gadget_decompose_strided_kernel(RnsDev R,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Split form of the same steps, used when the digits fit 32 bits (log_basis <= 31).  The fused kernel
+// above keeps 2^K composed big integers per thread alive across all levels (234 VGPRs at 3 limbs,
+// K = 4: two waves per SIMD); splitting lets the arithmetic-heavy part run at four.
+//   gadget_signed_digits_kernel: steps (1)-(3), one thread per coefficient, all ell BALANCED digits
+//     written as int32 ([poly][level][N], 4*ell*N bytes per input polynomial — the centred lift (4)
+//     of a signed digit d is d or q_i + d, so the limb copies need not be materialised);
+//   digits_strided_kernel: step (4) + the strided pass of (5): a thread owns one column of one
+//     (polynomial, level), reads its 2^K digits once, and for every limb lifts them, runs the K stages
+//     in registers and stores where the strided pass would have stored.
+// ------------------------------------------------------------------------------------------
+template <int LEN>
+__global__ __launch_bounds__(256) void gadget_signed_digits_kernel(RnsDev R, BasisDev B, u32 log_n,
+                                                                  const u64 *__restrict__ crt, int *__restrict__ out,
+                                                                  u64 total) {
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const u32 n = 1u << log_n;
+    const u64 poly = gid >> log_n;
+    const u32 t = (u32)(gid & (n - 1));
+    u64 r[kMaxLimbs];
+    for (u32 i = 0; i < R.L; ++i) r[i] = crt[(poly * R.L + i) * n + t];
+    u64 v[LEN];
+    compose<LEN>(R, r, v);
+    u32 carry = init_value_carry<LEN>(B, v);
+    const u64 half = (B.basis + 1) / 2;
+    int *__restrict__ o = out + poly * B.ell * n + t;
+    for (u32 j = 0; j < B.ell; ++j) {
+        const u64 temp = window<LEN>(v, B.drop_bits + j * B.log_basis, B.basis_minus_one, B.log_basis) + carry;
+        carry = (temp & B.carry_mask) != 0;
+        const u64 u = temp & B.basis_minus_one;
+        o[(u64)j * n] = (B.basis != 2 && u >= half) ? (int)((long long)u - (long long)B.basis) : (int)u;
+    }
+}
+
+template <class A, int K>
+__global__ __launch_bounds__(256, 4) void digits_strided_kernel(const NttPrime *__restrict__ primes, u32 L, u32 log_n,
+                                                               const int *__restrict__ dig, u64 *__restrict__ out,
+                                                               u64 total_threads) {
+    constexpr int RK = 1 << K;
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total_threads) return;
+    const u32 log_s = log_n - K;
+    const u32 n = 1u << log_n;
+    const u32 col = (u32)(gid & ((1ull << log_s) - 1));
+    const u64 pl = gid >> log_s;  // (input polynomial, level)
+    const int *__restrict__ src = dig + pl * n + col;
+    int d[RK];
+#pragma unroll
+    for (int k = 0; k < RK; ++k) d[k] = src[(u64)k << log_s];
+#pragma unroll 1
+    for (u32 i = 0; i < L; ++i) {
+        const A ar(primes + i);
+        u64 x[RK][1];
+        // centred lift (base.rs:279-312): d >= 0 -> d, d < 0 -> q_i - |d|
+#pragma unroll
+        for (int k = 0; k < RK; ++k) x[k][0] = d[k] < 0 ? ar.q + (u64)(long long)d[k] : (u64)d[k];
+        strided_forward_regs<A, K, 1>(ar, x, n, 0u, log_s);
+        u64 *__restrict__ dst = out + (pl * L + i) * n + col;
+#pragma unroll
+        for (int k = 0; k < RK; ++k) dst[(u64)k << log_s] = x[k][0];
+    }
+}
+
+template <class A, int K>
+int launch_digits_strided(const RnsDev &r, const BasisDev &b, const NttPrime *primes, u32 log_n, const u64 *crt,
+                          int *sdigits, u64 *digits, u64 npolys, hipStream_t s) {
+    const u64 coeffs = npolys << log_n;
+    const u32 g1 = (u32)((coeffs + 255) / 256);
+    switch (r.value_len) {
+#define PFHE_CASE(LEN)                                                                                        \
+    case LEN:                                                                                                 \
+        hipLaunchKernelGGL((gadget_signed_digits_kernel<LEN>), dim3(g1), dim3(256), 0, s, r, b, log_n, crt, sdigits, \
+                           coeffs);                                                                           \
+        break;
+        PFHE_CASE(1) PFHE_CASE(2) PFHE_CASE(3) PFHE_CASE(4)
+#undef PFHE_CASE
+        default: return PFHE_ERR_UNSUPPORTED;
+    }
+    PFHE_HIP(hipGetLastError());
+    const u64 total = (npolys * b.ell) << (log_n - K);
+    hipLaunchKernelGGL((digits_strided_kernel<A, K>), dim3((u32)((total + 255) / 256)), dim3(256), 0, s, primes, r.L,
+                       log_n, sdigits, digits, total);
+    PFHE_HIP(hipGetLastError());
+    return PFHE_OK;
+}
+
 template <class A, int K>
 int launch_decompose_strided(const RnsDev &r, const BasisDev &b, const NttPrime *primes, u32 log_n, const u64 *crt,
                              u64 *digits, u64 npolys, hipStream_t s) {
@@ -231,11 +318,24 @@ bool gadget_decompose_strided_supported(u32 log_n, u32 value_len) {
     return !plan.tiny && plan.n_strided == 1 && plan.strided[0] >= 3 && plan.strided[0] <= 4 && value_len <= 4;
 }
 
+// int32 digits: |digit| <= 2^(log_basis - 1)
+bool gadget_split_decompose_supported(u32 log_n, u32 value_len, u32 log_basis) {
+    return gadget_decompose_strided_supported(log_n, value_len) && log_basis <= 31;
+}
+
 int gadget_decompose_strided_dev(const RnsDev &r, const BasisDev &b, const NttPrime *primes, u32 log_n, bool pm,
-                                 const u64 *crt_polys, u64 *digits, u64 npolys, hipStream_t s) {
+                                 const u64 *crt_polys, u64 *digits, u64 npolys, hipStream_t s, int *sdigits) {
     if (!gadget_decompose_strided_supported(log_n, r.value_len)) return PFHE_ERR_UNSUPPORTED;
     if (npolys == 0) return PFHE_OK;
     const int k = make_ntt_plan(log_n).strided[0];
+    if (sdigits != nullptr && gadget_split_decompose_supported(log_n, r.value_len, b.log_basis)) {
+        if (pm) {
+            return k == 4 ? launch_digits_strided<PmArith, 4>(r, b, primes, log_n, crt_polys, sdigits, digits, npolys, s)
+                          : launch_digits_strided<PmArith, 3>(r, b, primes, log_n, crt_polys, sdigits, digits, npolys, s);
+        }
+        return k == 4 ? launch_digits_strided<ShoupArith, 4>(r, b, primes, log_n, crt_polys, sdigits, digits, npolys, s)
+                      : launch_digits_strided<ShoupArith, 3>(r, b, primes, log_n, crt_polys, sdigits, digits, npolys, s);
+    }
     if (pm) {
         return k == 4 ? launch_decompose_strided<PmArith, 4>(r, b, primes, log_n, crt_polys, digits, npolys, s)
                       : launch_decompose_strided<PmArith, 3>(r, b, primes, log_n, crt_polys, digits, npolys, s);
