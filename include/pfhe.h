@@ -126,6 +126,13 @@ int pfhe_ntt_mul_assign_dev(const pfhe_ntt *table, uint64_t *a_dev, size_t len_a
                             const uint64_t *b_dev, size_t len_b, void *stream);
 int pfhe_ntt_add_mul_assign_dev(const pfhe_ntt *table, uint64_t *acc_dev, const uint64_t *a_dev,
                                 size_t len_a, const uint64_t *b_dev, size_t len_b, void *stream);
+/* NttPolynomial::mul_to / mul_add_to — primus_poly/src/ntt/mul.rs:100-107, ntt/mod.rs:169-187:
+ * out = a*b and out = a*b + c (out may alias an input). */
+int pfhe_ntt_mul_to_dev(const pfhe_ntt *table, const uint64_t *a_dev, size_t len_a,
+                        const uint64_t *b_dev, size_t len_b, uint64_t *out_dev, void *stream);
+int pfhe_ntt_mul_add_to_dev(const pfhe_ntt *table, const uint64_t *a_dev, size_t len_a,
+                            const uint64_t *b_dev, size_t len_b, const uint64_t *c_dev,
+                            uint64_t *out_dev, void *stream);
 
 /* =====================================================================================
  * U64DcrtTable — primus_ntt/src/dcrt/prime64.rs:11 implementing DcrtTable
@@ -173,6 +180,13 @@ int pfhe_dcrt_mul_assign_dev(const pfhe_dcrt *table, uint64_t *a_dev, size_t len
 int pfhe_dcrt_add_mul_assign_dev(const pfhe_dcrt *table, uint64_t *acc_dev,
                                  const uint64_t *a_dev, size_t len_a, const uint64_t *b_dev,
                                  size_t len_b, void *stream);
+/* DcrtPolynomial::mul_to (primus_poly/src/dcrt/mul.rs:232-250) and the out-of-place
+ * multiply-add: out = a*b, out = a*b + c (out may alias an input). */
+int pfhe_dcrt_mul_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, size_t len_a,
+                         const uint64_t *b_dev, size_t len_b, uint64_t *out_dev, void *stream);
+int pfhe_dcrt_mul_add_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, size_t len_a,
+                             const uint64_t *b_dev, size_t len_b, const uint64_t *c_dev,
+                             uint64_t *out_dev, void *stream);
 /* GLWE butterfly (self, result) = (self + rhs, (self_orig - rhs) * w), canonical in and out, over
  * every DCRT polynomial of a (batch of) DcrtGlwe:
  *   DcrtGlwe::butterfly_mul_dcrt_polynomial_to — primus_lattice/src/glwe/dcrt.rs:128-155

@@ -131,6 +131,9 @@ def _declare(lib: C.CDLL) -> None:
     sig("pfhe_dcrt_transform_pass_name", C.c_char_p, vp, ci, ci)
     sig("pfhe_dcrt_transform_pass_dev", ci, vp, vp, sz, ci, ci, ci, vp)
 
+    for pre in ("pfhe_ntt_", "pfhe_dcrt_"):
+        sig(pre + "mul_to_dev", ci, vp, vp, sz, vp, sz, vp, vp)
+        sig(pre + "mul_add_to_dev", ci, vp, vp, sz, vp, sz, vp, vp, vp)
     sig("pfhe_conv_create", ci, vp, vp, C.POINTER(vp))
     sig("pfhe_conv_destroy", None, vp)
     sig("pfhe_conv_input_moduli_count", sz, vp)

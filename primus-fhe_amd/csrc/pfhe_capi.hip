@@ -207,7 +207,27 @@ int pointwise(const TableSet &t, int mode, u64 *acc, const u64 *a, size_t len_a,
     }
     DeviceGuard g(t.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    return pointwise_dev(mode, acc, a, b, t.primes_dev, t.L, t.log_n, len_a, len_b, s);
+    return mode == 0 ? pointwise_dev(acc, acc, b, nullptr, t.primes_dev, t.L, t.log_n, len_a, len_b, s)
+                     : pointwise_dev(acc, a, b, acc, t.primes_dev, t.L, t.log_n, len_a, len_b, s);
+}
+
+// out = a*b (+ c): NttPolynomial::mul_to / mul_add_to (primus_poly/src/ntt/mul.rs:100-107, ntt/mod.rs:169-187)
+int pointwise_to(const TableSet &t, u64 *out, const u64 *a, size_t len_a, const u64 *b, size_t len_b, const u64 *c,
+                 bool has_c, hipStream_t s) {
+    if ((!out || !a || !b || (has_c && !c)) && len_a) return PFHE_ERR_BAD_ARGUMENT;
+    PFHE_REQUIRE_ALIGNED(out);
+    PFHE_REQUIRE_ALIGNED(a);
+    PFHE_REQUIRE_ALIGNED(b);
+    PFHE_REQUIRE_ALIGNED(c);
+    u64 units = 0;
+    PFHE_TRY(check_len(t, len_a, units));
+    if (len_b != len_a && len_b != t.n * t.L) {
+        set_last_error("multiplicand must have the same length or exactly one polynomial");
+        return PFHE_ERR_BAD_LENGTH;
+    }
+    DeviceGuard g(t.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    return pointwise_dev(out, a, b, has_c ? c : nullptr, t.primes_dev, t.L, t.log_n, len_a, len_b, s);
 }
 
 // minus_one: the coefficient of limb i is q_i - 1 (DcrtTable::transform_coeff_minus_one_monomial,
@@ -603,6 +623,39 @@ int pfhe_dcrt_butterfly_mul_factor_to_dev(const pfhe_dcrt *table, uint64_t *a_de
                                           void *stream) {
     PFHE_GUARD_BEGIN
     return butterfly_api(table, true, a_dev, rhs_dev, len, factor_poly_dev, len_w, result_dev, stream);
+    PFHE_GUARD_END
+}
+
+int pfhe_ntt_mul_to_dev(const pfhe_ntt *table, const uint64_t *a_dev, size_t len_a, const uint64_t *b_dev, size_t len_b,
+                        uint64_t *out_dev, void *stream) {
+    PFHE_GUARD_BEGIN
+    if (!table) return PFHE_ERR_BAD_ARGUMENT;
+    return pointwise_to(*table->t, (u64 *)out_dev, (const u64 *)a_dev, len_a, (const u64 *)b_dev, len_b, nullptr, false,
+                        (hipStream_t)stream);
+    PFHE_GUARD_END
+}
+int pfhe_ntt_mul_add_to_dev(const pfhe_ntt *table, const uint64_t *a_dev, size_t len_a, const uint64_t *b_dev,
+                            size_t len_b, const uint64_t *c_dev, uint64_t *out_dev, void *stream) {
+    PFHE_GUARD_BEGIN
+    if (!table) return PFHE_ERR_BAD_ARGUMENT;
+    return pointwise_to(*table->t, (u64 *)out_dev, (const u64 *)a_dev, len_a, (const u64 *)b_dev, len_b,
+                        (const u64 *)c_dev, true, (hipStream_t)stream);
+    PFHE_GUARD_END
+}
+int pfhe_dcrt_mul_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, size_t len_a, const uint64_t *b_dev,
+                         size_t len_b, uint64_t *out_dev, void *stream) {
+    PFHE_GUARD_BEGIN
+    if (!table) return PFHE_ERR_BAD_ARGUMENT;
+    return pointwise_to(*table->t, (u64 *)out_dev, (const u64 *)a_dev, len_a, (const u64 *)b_dev, len_b, nullptr, false,
+                        (hipStream_t)stream);
+    PFHE_GUARD_END
+}
+int pfhe_dcrt_mul_add_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, size_t len_a, const uint64_t *b_dev,
+                             size_t len_b, const uint64_t *c_dev, uint64_t *out_dev, void *stream) {
+    PFHE_GUARD_BEGIN
+    if (!table) return PFHE_ERR_BAD_ARGUMENT;
+    return pointwise_to(*table->t, (u64 *)out_dev, (const u64 *)a_dev, len_a, (const u64 *)b_dev, len_b,
+                        (const u64 *)c_dev, true, (hipStream_t)stream);
     PFHE_GUARD_END
 }
 

@@ -3,6 +3,8 @@
 //
 //   mul_assign      a[i] = a[i]*b[i] mod q_r        DcrtPolynomial::mul_assign, dcrt/mul.rs:176-187
 //   add_mul_assign  acc[i] = a[i]*b[i] + acc[i]     DcrtPolynomial::add_mul_assign, dcrt/mod.rs:105-123
+//   mul_to          out[i] = a[i]*b[i]              NttPolynomial::mul_to, ntt/mul.rs:100-107; dcrt/mul.rs:232-250
+//   mul_add_to      out[i] = a[i]*b[i] + c[i]       NttPolynomial::mul_add_to, ntt/mod.rs:169-187
 // (per limb: BarrettModulus::reduce_mul / reduce_mul_add, primus_modulus/src/barrett/ops.rs:276-315)
 #include "pfhe_common.hpp"
 #include "pfhe_modmath.hpp"
@@ -23,12 +25,14 @@ __device__ __forceinline__ Bar load_bar(const NttPrime *__restrict__ primes, u32
     return Bar{P->q, P->bar_lo, P->bar_hi};
 }
 
-// MODE 0: acc = acc*b ; MODE 1: acc = a*b + acc.  Each thread handles UNROLL 16-byte vectors per
-// iteration, one workgroup-stride apart, so that several independent loads are in flight.
-template <int MODE, bool PAIR>
-__global__ __launch_bounds__(kPwThreads) void pointwise_kernel(u64 *acc, const u64 *a, const u64 *__restrict__ b,
-                                                               const NttPrime *__restrict__ primes, u32 L,
-                                                               u32 log_n, u64 len, u64 len_b) {
+// out = a*b (HAS_C: + c), element by element; `out` may alias `a` and/or `c`, which gives the
+// in-place forms (mul_assign: out = a; add_mul_assign: out = c).  Each thread handles UNROLL
+// 16-byte vectors per iteration, one workgroup-stride apart, so that several independent loads
+// are in flight.
+template <bool HAS_C, bool PAIR>
+__global__ __launch_bounds__(kPwThreads) void pointwise_kernel(u64 *out, const u64 *a, const u64 *__restrict__ b,
+                                                               const u64 *c, const NttPrime *__restrict__ primes,
+                                                               u32 L, u32 log_n, u64 len, u64 len_b) {
     constexpr u64 V = PAIR ? 2 : 1;
     constexpr int UNROLL = 4;
     const u64 nvec = len / V;
@@ -45,17 +49,17 @@ __global__ __launch_bounds__(kPwThreads) void pointwise_kernel(u64 *acc, const u
             m[u] = load_bar(primes, (u32)((i >> log_n) % L));
             const u64 ib = shared_b ? (i % len_b) : i;
             if constexpr (PAIR) {
-                const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>((MODE == 0 ? acc : a) + i);
+                const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(a + i);
                 const ulonglong2 y = *reinterpret_cast<const ulonglong2 *>(b + ib);
                 av[u][0] = x.x; av[u][1] = x.y; bv[u][0] = y.x; bv[u][1] = y.y;
-                if constexpr (MODE == 1) {
-                    const ulonglong2 z = *reinterpret_cast<const ulonglong2 *>(acc + i);
+                if constexpr (HAS_C) {
+                    const ulonglong2 z = *reinterpret_cast<const ulonglong2 *>(c + i);
                     cv[u][0] = z.x; cv[u][1] = z.y;
                 }
             } else {
-                av[u][0] = (MODE == 0 ? acc : a)[i];
+                av[u][0] = a[i];
                 bv[u][0] = b[ib];
-                if constexpr (MODE == 1) cv[u][0] = acc[i];
+                if constexpr (HAS_C) cv[u][0] = c[i];
             }
         }
 #pragma unroll
@@ -66,11 +70,11 @@ __global__ __launch_bounds__(kPwThreads) void pointwise_kernel(u64 *acc, const u
             u64 r[2];
 #pragma unroll
             for (int e = 0; e < (int)V; ++e) {
-                if constexpr (MODE == 0) r[e] = mul_mod_barrett(av[u][e], bv[u][e], m[u].q, m[u].lo, m[u].hi);
+                if constexpr (!HAS_C) r[e] = mul_mod_barrett(av[u][e], bv[u][e], m[u].q, m[u].lo, m[u].hi);
                 else r[e] = mul_add_mod_barrett(av[u][e], bv[u][e], cv[u][e], m[u].q, m[u].lo, m[u].hi);
             }
-            if constexpr (PAIR) *reinterpret_cast<ulonglong2 *>(acc + i) = ulonglong2{r[0], r[1]};
-            else acc[i] = r[0];
+            if constexpr (PAIR) *reinterpret_cast<ulonglong2 *>(out + i) = ulonglong2{r[0], r[1]};
+            else out[i] = r[0];
         }
     }
 }
@@ -145,18 +149,18 @@ u32 grid_for(u64 work_items) {
 
 }  // namespace
 
-int pointwise_dev(int mode, u64 *acc, const u64 *a, const u64 *b, const NttPrime *primes, u32 L, u32 log_n,
+int pointwise_dev(u64 *out, const u64 *a, const u64 *b, const u64 *c, const NttPrime *primes, u32 L, u32 log_n,
                   u64 len, u64 len_b, hipStream_t s) {
     if (len == 0) return PFHE_OK;
     const bool pair = log_n >= 1 && (len % 2 == 0) && (len_b % 2 == 0);
     const u64 items = (pair ? len / 2 : len + 3) / 4;  // 4 vectors per thread and iteration
     const dim3 g(grid_for(items ? items : 1)), t(kPwThreads);
-    if (mode == 0) {
-        if (pair) hipLaunchKernelGGL((pointwise_kernel<0, true>), g, t, 0, s, acc, a, b, primes, L, log_n, len, len_b);
-        else hipLaunchKernelGGL((pointwise_kernel<0, false>), g, t, 0, s, acc, a, b, primes, L, log_n, len, len_b);
+    if (c == nullptr) {
+        if (pair) hipLaunchKernelGGL((pointwise_kernel<false, true>), g, t, 0, s, out, a, b, c, primes, L, log_n, len, len_b);
+        else hipLaunchKernelGGL((pointwise_kernel<false, false>), g, t, 0, s, out, a, b, c, primes, L, log_n, len, len_b);
     } else {
-        if (pair) hipLaunchKernelGGL((pointwise_kernel<1, true>), g, t, 0, s, acc, a, b, primes, L, log_n, len, len_b);
-        else hipLaunchKernelGGL((pointwise_kernel<1, false>), g, t, 0, s, acc, a, b, primes, L, log_n, len, len_b);
+        if (pair) hipLaunchKernelGGL((pointwise_kernel<true, true>), g, t, 0, s, out, a, b, c, primes, L, log_n, len, len_b);
+        else hipLaunchKernelGGL((pointwise_kernel<true, false>), g, t, 0, s, out, a, b, c, primes, L, log_n, len, len_b);
     }
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;

@@ -3,8 +3,8 @@
 #include "pfhe_common.hpp"
 
 namespace pfhe {
-// mode 0: acc = acc*b (a is ignored); mode 1: acc = a*b + acc.  b has len_b words: len or one unit.
-int pointwise_dev(int mode, u64 *acc, const u64 *a, const u64 *b, const NttPrime *primes, u32 L, u32 log_n,
+// out = a*b (+ c when c != nullptr); out may alias a and/or c.  b has len_b words: len or one unit.
+int pointwise_dev(u64 *out, const u64 *a, const u64 *b, const u64 *c, const NttPrime *primes, u32 L, u32 log_n,
                   u64 len, u64 len_b, hipStream_t s);
 // (a, b) = (a + s, (a - s) * w); w holds len_w multiplicands (ShoupFactor pairs when `factor`), shared
 // cyclically by the batch.

@@ -114,6 +114,20 @@ class U64NttTable:
             raise PfheError(32, "acc and a differ in length")
         check(lib().pfhe_ntt_add_mul_assign_dev(self._h, pc, pa, na, pb, nb, _stream(stream)))
 
+    def mul_to_dev(self, a, b, out, stream=None):
+        """NttPolynomial::mul_to (primus_poly/src/ntt/mul.rs:100-107): out = a*b."""
+        (pa, na), (pb, nb), (po, no) = _dev(a), _dev(b), _dev(out)
+        if no != na:
+            raise PfheError(32, "output and multiplicand differ in length")
+        check(lib().pfhe_ntt_mul_to_dev(self._h, pa, na, pb, nb, po, _stream(stream)))
+
+    def mul_add_to_dev(self, a, b, c, out, stream=None):
+        """NttPolynomial::mul_add_to (primus_poly/src/ntt/mod.rs:169-187): out = a*b + c."""
+        (pa, na), (pb, nb), (pc, nc), (po, no) = _dev(a), _dev(b), _dev(c), _dev(out)
+        if no != na or nc != na:
+            raise PfheError(32, "operands differ in length")
+        check(lib().pfhe_ntt_mul_add_to_dev(self._h, pa, na, pb, nb, pc, po, _stream(stream)))
+
 
 class U64DcrtTable:
     """primus_ntt::U64DcrtTable — one U64NttTable per RNS limb, modulus-major data (dcrt/prime64.rs)."""
@@ -173,6 +187,20 @@ class U64DcrtTable:
         if nc != na:
             raise PfheError(32, "acc and a differ in length")
         check(lib().pfhe_dcrt_add_mul_assign_dev(self._h, pc, pa, na, pb, nb, _stream(stream)))
+
+    def mul_to_dev(self, a, b, out, stream=None):
+        """NttPolynomial::mul_to (primus_poly/src/ntt/mul.rs:100-107): out = a*b."""
+        (pa, na), (pb, nb), (po, no) = _dev(a), _dev(b), _dev(out)
+        if no != na:
+            raise PfheError(32, "output and multiplicand differ in length")
+        check(lib().pfhe_dcrt_mul_to_dev(self._h, pa, na, pb, nb, po, _stream(stream)))
+
+    def mul_add_to_dev(self, a, b, c, out, stream=None):
+        """NttPolynomial::mul_add_to (primus_poly/src/ntt/mod.rs:169-187): out = a*b + c."""
+        (pa, na), (pb, nb), (pc, nc), (po, no) = _dev(a), _dev(b), _dev(c), _dev(out)
+        if no != na or nc != na:
+            raise PfheError(32, "operands differ in length")
+        check(lib().pfhe_dcrt_mul_add_to_dev(self._h, pa, na, pb, nb, pc, po, _stream(stream)))
 
     def butterfly_mul_dcrt_polynomial_to_dev(self, a, rhs, dcrt_poly, result, stream=None):
         """DcrtGlwe::butterfly_mul_dcrt_polynomial_to (primus_lattice/src/glwe/dcrt.rs:128-155):

@@ -348,3 +348,32 @@ def test_misaligned_device_buffer_is_rejected(pf):
     with pytest.raises(pf.PfheError) as e:
         t32.transform_dev(y[2:])
     assert e.value.kind == "BadArgument"
+
+
+@pytest.mark.parametrize("log_n,moduli,batch", [(0, [97], 5), (3, Q61, 3), (10, Q61[:2], 4), (13, [Q62], 2)])
+def test_out_of_place_products(pf, orc, log_n, moduli, batch):
+    """NttPolynomial / DcrtPolynomial mul_to and mul_add_to (ntt/mul.rs:100-107, ntt/mod.rs:169-187)."""
+    import torch
+    rng = np.random.default_rng(log_n)
+    n, L = 1 << log_n, len(moduli)
+    d, o = pf.U64DcrtTable(log_n, moduli), orc.U64DcrtTable(log_n, moduli)
+    if n * L % 2:  # odd word count per unit: keep every device buffer 16-byte aligned by using one unit
+        batch = 2
+    a, b, c = (rand_rns(rng, moduli, n, batch) for _ in range(3))
+    W = L * n
+    exp_mul, exp_fma = a.copy(), c.copy()
+    for e in range(batch):
+        o.mul_assign(exp_mul[e * W:(e + 1) * W], b[e * W:(e + 1) * W])
+        o.add_mul_assign(exp_fma[e * W:(e + 1) * W], a[e * W:(e + 1) * W], b[e * W:(e + 1) * W])
+    da, db, dc = to_dev(a), to_dev(b), to_dev(c)
+    out = torch.zeros_like(da)
+    d.mul_to_dev(da, db, out)
+    assert np.array_equal(to_host(out), exp_mul) and np.array_equal(to_host(da), a)
+    d.mul_add_to_dev(da, db, dc, out)
+    assert np.array_equal(to_host(out), exp_fma) and np.array_equal(to_host(dc), c)
+    if L == 1:
+        t = pf.U64NttTable(log_n, moduli[0])
+        t.mul_add_to_dev(da, db, dc, out)
+        assert np.array_equal(to_host(out), exp_fma)
+        t.mul_to_dev(da, db, da)  # output may alias an input
+        assert np.array_equal(to_host(da), exp_mul)
