@@ -180,6 +180,16 @@ int pfhe_dcrt_mul_assign_dev(const pfhe_dcrt *table, uint64_t *a_dev, size_t len
 int pfhe_dcrt_add_mul_assign_dev(const pfhe_dcrt *table, uint64_t *acc_dev,
                                  const uint64_t *a_dev, size_t len_a, const uint64_t *b_dev,
                                  size_t len_b, void *stream);
+/* DcrtGlwe::add_dcrt_glwe_mul_dcrt_polynomial_assign — primus_lattice/src/glwe/dcrt.rs:107-126,
+ * batched: acc and dcrt_glwe hold batch ciphertexts of `glwe_polys` (= k+1) RNS polynomials,
+ * dcrt_poly one RNS polynomial per ciphertext (len_poly = len / glwe_polys):
+ * acc[e][c] += dcrt_glwe[e][c] * dcrt_poly[e]. */
+int pfhe_dcrt_add_dcrt_glwe_mul_dcrt_polynomial_assign_dev(const pfhe_dcrt *table,
+                                                           uint64_t *acc_dev,
+                                                           const uint64_t *dcrt_glwe_dev, size_t len,
+                                                           const uint64_t *dcrt_poly_dev,
+                                                           size_t len_poly, size_t glwe_polys,
+                                                           void *stream);
 /* DcrtPolynomial::mul_to (primus_poly/src/dcrt/mul.rs:232-250) and the out-of-place
  * multiply-add: out = a*b, out = a*b + c (out may alias an input). */
 int pfhe_dcrt_mul_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, size_t len_a,

@@ -32,7 +32,7 @@ __device__ __forceinline__ Bar load_bar(const NttPrime *__restrict__ primes, u32
 template <bool HAS_C, bool PAIR>
 __global__ __launch_bounds__(kPwThreads) void pointwise_kernel(u64 *out, const u64 *a, const u64 *__restrict__ b,
                                                                const u64 *c, const NttPrime *__restrict__ primes,
-                                                               u32 L, u32 log_n, u64 len, u64 len_b) {
+                                                               u32 L, u32 log_n, u64 len, u64 len_b, u64 group_words) {
     constexpr u64 V = PAIR ? 2 : 1;
     constexpr int UNROLL = 4;
     const u64 nvec = len / V;
@@ -47,7 +47,11 @@ __global__ __launch_bounds__(kPwThreads) void pointwise_kernel(u64 *out, const u
             if (v >= nvec) continue;
             const u64 i = v * V;
             m[u] = load_bar(primes, (u32)((i >> log_n) % L));
-            const u64 ib = shared_b ? (i % len_b) : i;
+            u64 ib = shared_b ? (i % len_b) : i;
+            if (group_words) {  // one multiplicand unit per group of consecutive units (a ciphertext's k+1 polynomials)
+                const u64 unit = (u64)L << log_n;
+                ib = (i / group_words) * unit + i % unit;
+            }
             if constexpr (PAIR) {
                 const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(a + i);
                 const ulonglong2 y = *reinterpret_cast<const ulonglong2 *>(b + ib);
@@ -150,17 +154,17 @@ u32 grid_for(u64 work_items) {
 }  // namespace
 
 int pointwise_dev(u64 *out, const u64 *a, const u64 *b, const u64 *c, const NttPrime *primes, u32 L, u32 log_n,
-                  u64 len, u64 len_b, hipStream_t s) {
+                  u64 len, u64 len_b, hipStream_t s, u64 group_words) {
     if (len == 0) return PFHE_OK;
     const bool pair = log_n >= 1 && (len % 2 == 0) && (len_b % 2 == 0);
     const u64 items = (pair ? len / 2 : len + 3) / 4;  // 4 vectors per thread and iteration
     const dim3 g(grid_for(items ? items : 1)), t(kPwThreads);
     if (c == nullptr) {
-        if (pair) hipLaunchKernelGGL((pointwise_kernel<false, true>), g, t, 0, s, out, a, b, c, primes, L, log_n, len, len_b);
-        else hipLaunchKernelGGL((pointwise_kernel<false, false>), g, t, 0, s, out, a, b, c, primes, L, log_n, len, len_b);
+        if (pair) hipLaunchKernelGGL((pointwise_kernel<false, true>), g, t, 0, s, out, a, b, c, primes, L, log_n, len, len_b, group_words);
+        else hipLaunchKernelGGL((pointwise_kernel<false, false>), g, t, 0, s, out, a, b, c, primes, L, log_n, len, len_b, group_words);
     } else {
-        if (pair) hipLaunchKernelGGL((pointwise_kernel<true, true>), g, t, 0, s, out, a, b, c, primes, L, log_n, len, len_b);
-        else hipLaunchKernelGGL((pointwise_kernel<true, false>), g, t, 0, s, out, a, b, c, primes, L, log_n, len, len_b);
+        if (pair) hipLaunchKernelGGL((pointwise_kernel<true, true>), g, t, 0, s, out, a, b, c, primes, L, log_n, len, len_b, group_words);
+        else hipLaunchKernelGGL((pointwise_kernel<true, false>), g, t, 0, s, out, a, b, c, primes, L, log_n, len, len_b, group_words);
     }
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;

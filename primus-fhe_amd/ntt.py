@@ -202,6 +202,15 @@ class U64DcrtTable:
             raise PfheError(32, "operands differ in length")
         check(lib().pfhe_dcrt_mul_add_to_dev(self._h, pa, na, pb, nb, pc, po, _stream(stream)))
 
+    def add_dcrt_glwe_mul_dcrt_polynomial_assign_dev(self, acc, dcrt_glwe, dcrt_poly, glwe_polys: int, stream=None):
+        """DcrtGlwe::add_dcrt_glwe_mul_dcrt_polynomial_assign (primus_lattice/src/glwe/dcrt.rs:107-126) over a
+        batch: acc[e][c] += dcrt_glwe[e][c] * dcrt_poly[e], c < glwe_polys = k + 1."""
+        (pc, nc), (pa, na), (pb, nb) = _dev(acc), _dev(dcrt_glwe), _dev(dcrt_poly)
+        if nc != na:
+            raise PfheError(32, "accumulator and ciphertext differ in length")
+        check(lib().pfhe_dcrt_add_dcrt_glwe_mul_dcrt_polynomial_assign_dev(self._h, pc, pa, na, pb, nb, glwe_polys,
+                                                                           _stream(stream)))
+
     def butterfly_mul_dcrt_polynomial_to_dev(self, a, rhs, dcrt_poly, result, stream=None):
         """DcrtGlwe::butterfly_mul_dcrt_polynomial_to (primus_lattice/src/glwe/dcrt.rs:128-155):
         (a, result) = (a + rhs, (a_orig - rhs) * dcrt_poly)."""

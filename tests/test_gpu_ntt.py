@@ -377,3 +377,25 @@ def test_out_of_place_products(pf, orc, log_n, moduli, batch):
         assert np.array_equal(to_host(out), exp_fma)
         t.mul_to_dev(da, db, da)  # output may alias an input
         assert np.array_equal(to_host(da), exp_mul)
+
+
+@pytest.mark.parametrize("log_n,moduli,k,batch", [(4, Q61, 1, 5), (9, Q61[:2], 2, 3), (12, Q61, 1, 4)])
+def test_add_dcrt_glwe_mul_dcrt_polynomial_assign(pf, orc, log_n, moduli, k, batch):
+    """glwe/dcrt.rs:107-126, batched: one multiplicand polynomial per ciphertext, shared by its k+1 polynomials."""
+    rng = np.random.default_rng(log_n + k)
+    n, L = 1 << log_n, len(moduli)
+    W = L * n
+    d, o = pf.U64DcrtTable(log_n, moduli), orc.U64DcrtTable(log_n, moduli)
+    acc, glwe = rand_rns(rng, moduli, n, batch * (k + 1)), rand_rns(rng, moduli, n, batch * (k + 1))
+    poly = rand_rns(rng, moduli, n, batch)
+    exp = acc.copy()
+    for e in range(batch):
+        for c in range(k + 1):
+            s = slice((e * (k + 1) + c) * W, (e * (k + 1) + c + 1) * W)
+            o.add_mul_assign(exp[s], glwe[s], poly[e * W:(e + 1) * W])
+    dacc = to_dev(acc)
+    d.add_dcrt_glwe_mul_dcrt_polynomial_assign_dev(dacc, to_dev(glwe), to_dev(poly), k + 1)
+    assert np.array_equal(to_host(dacc), exp)
+    with pytest.raises(pf.PfheError) as e:
+        d.add_dcrt_glwe_mul_dcrt_polynomial_assign_dev(dacc, to_dev(glwe), to_dev(poly[:-W].copy()), k + 1)
+    assert e.value.kind == "BadLength"
