@@ -79,13 +79,21 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
     const u64 W = (u64)t.L * t.n;
     const u32 ell = p->basis.ell;
     const u64 key_words = (u64)rows * ell * (p->k + 1) * W;
-    const bool fused = gadget_fused_supported(t.log_n, p->k) && std::getenv("PFHE_DISABLE_FUSED_EXTPROD") == nullptr;
+    // a single chunk has nothing to pipeline: run it on the caller's stream without the fork/join events
+    // (latency of small batches); the fused block+multiply-accumulate kernel launches one workgroup per
+    // (ciphertext, limb, block), so it only pays once that fills the chip
+    const bool single = batch <= p->chunk;
+    hipStream_t sa = single ? s : p->sa, sb = single ? s : p->sb;
+    const bool fused = gadget_fused_supported(t.log_n, p->k) && std::getenv("PFHE_DISABLE_FUSED_EXTPROD") == nullptr &&
+                       ((std::min<u64>(batch, p->chunk) * t.L) << (t.log_n - 12)) >= 256;
     const int passes = ntt_num_passes(t.log_n);
     const bool fused_decompose = gadget_decompose_strided_supported(t.log_n, p->rns.value_len) &&
                                  std::getenv("PFHE_DISABLE_FUSED_DECOMPOSE") == nullptr;
-    PFHE_HIP(hipEventRecord(p->fork, s));
-    PFHE_HIP(hipStreamWaitEvent(p->sa, p->fork, 0));
-    PFHE_HIP(hipStreamWaitEvent(p->sb, p->fork, 0));
+    if (!single) {
+        PFHE_HIP(hipEventRecord(p->fork, s));
+        PFHE_HIP(hipStreamWaitEvent(sa, p->fork, 0));
+        PFHE_HIP(hipStreamWaitEvent(sb, p->fork, 0));
+    }
     // Software pipeline over chunks of ciphertexts, two digit buffers, two streams:
     //   stream a (HBM-bound kernels): decomposition + strided passes of chunk c, then the
     //            multiply-accumulate of chunk c-1 (unfused variant);
@@ -95,10 +103,10 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
     u64 prev_done = 0, prev_cur = 0;
     auto issue_mulacc = [&](u64 idx, u64 done0, u64 cur0) -> int {
         const int b0 = (int)(idx & 1);
-        PFHE_HIP(hipStreamWaitEvent(p->sa, p->consumed[b0], 0));
+        if (!single) PFHE_HIP(hipStreamWaitEvent(sa, p->consumed[b0], 0));
         return gadget_mulacc_dev(t.primes_dev, t.L, t.log_n, p->k, rows, ell, p->digits[b0],
                                  keys + (keys_shared ? 0 : done0 * key_words), keys_shared,
-                                 result + done0 * (p->k + 1) * W, cur0, accumulate, p->sa);
+                                 result + done0 * (p->k + 1) * W, cur0, accumulate, sa);
     };
     for (u64 done = 0; done < batch; done += p->chunk, ++index) {
         const u64 cur = std::min<u64>(p->chunk, batch - done);
@@ -106,36 +114,38 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
         u64 *dg = p->digits[buf];
         const u64 npolys = cur * rows * ell * t.L;
         // ---- stream a: steps (1)-(4) + strided passes into digit buffer `buf` ----
-        if (fused && index >= 2) PFHE_HIP(hipStreamWaitEvent(p->sa, p->consumed[buf], 0));
+        if (fused && index >= 2) PFHE_HIP(hipStreamWaitEvent(sa, p->consumed[buf], 0));
         if (fused_decompose) {
             PFHE_TRY(gadget_decompose_strided_dev(p->rns, p->basis, t.primes_dev, t.log_n, t.pm,
-                                                  crt_polys + done * rows * W, dg, cur * rows, p->sa, p->sdigits));
+                                                  crt_polys + done * rows * W, dg, cur * rows, sa, p->sdigits));
         } else {
-            PFHE_TRY(gadget_decompose_dev(p->rns, p->basis, t.log_n, crt_polys + done * rows * W, dg, cur * rows, p->sa));
+            PFHE_TRY(gadget_decompose_dev(p->rns, p->basis, t.log_n, crt_polys + done * rows * W, dg, cur * rows, sa));
             for (int i = 0; i < passes - 1; ++i)
-                PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.pm, dg, npolys, false, i, false, p->sa));
+                PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.pm, dg, npolys, false, i, false, sa));
         }
-        PFHE_HIP(hipEventRecord(p->produced[buf], p->sa));
+        if (!single) PFHE_HIP(hipEventRecord(p->produced[buf], sa));
         // ---- stream b: block pass (last pass of the transform) ----
-        PFHE_HIP(hipStreamWaitEvent(p->sb, p->produced[buf], 0));
+        if (!single) PFHE_HIP(hipStreamWaitEvent(sb, p->produced[buf], 0));
         if (fused) {
             PFHE_TRY(gadget_block_mulacc_dev(t.primes_dev, t.L, t.log_n, t.pm, p->k, rows * ell, dg,
                                              keys + (keys_shared ? 0 : done * key_words), keys_shared,
-                                             result + done * (p->k + 1) * W, cur, accumulate, p->sb));
+                                             result + done * (p->k + 1) * W, cur, accumulate, sb));
         } else {
-            PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.pm, dg, npolys, false, passes - 1, false, p->sb));
+            PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.pm, dg, npolys, false, passes - 1, false, sb));
         }
-        PFHE_HIP(hipEventRecord(p->consumed[buf], p->sb));
+        if (!single) PFHE_HIP(hipEventRecord(p->consumed[buf], sb));
         // ---- stream a: multiply-accumulate of the PREVIOUS chunk (its block pass has had time to run) ----
         if (!fused && index >= 1) PFHE_TRY(issue_mulacc(index - 1, prev_done, prev_cur));
         prev_done = done;
         prev_cur = cur;
     }
     if (!fused && index >= 1) PFHE_TRY(issue_mulacc(index - 1, prev_done, prev_cur));
-    PFHE_HIP(hipEventRecord(p->join_a, p->sa));
-    PFHE_HIP(hipEventRecord(p->join_b, p->sb));
-    PFHE_HIP(hipStreamWaitEvent(s, p->join_a, 0));
-    PFHE_HIP(hipStreamWaitEvent(s, p->join_b, 0));
+    if (!single) {
+        PFHE_HIP(hipEventRecord(p->join_a, sa));
+        PFHE_HIP(hipEventRecord(p->join_b, sb));
+        PFHE_HIP(hipStreamWaitEvent(s, p->join_a, 0));
+        PFHE_HIP(hipStreamWaitEvent(s, p->join_b, 0));
+    }
     return PFHE_OK;
 }
 
