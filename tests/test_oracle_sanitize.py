@@ -1,0 +1,27 @@
+"""AddressSanitizer + UBSan over the oracle's C code (CPU build only; GPU sanitizers are not
+available on the pool): oracle/sanitize_main.c drives every entry point at small sizes."""
+import os
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ORACLE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+
+
+def test_oracle_under_asan_ubsan():
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "sanitize")
+        cmd = ["gcc", "-O1", "-g", "-std=c11", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+               "-fno-omit-frame-pointer", "-I", ORACLE, os.path.join(ORACLE, "sanitize_main.c"),
+               os.path.join(ORACLE, "pfhe_oracle.c"), os.path.join(ORACLE, "pfhe_oracle_avx512.c"), "-o", exe]
+        build = subprocess.run(cmd, capture_output=True, text=True)
+        if build.returncode != 0 and "sanitize" in build.stderr.lower() and "cannot find" in build.stderr.lower():
+            pytest.skip("sanitizer runtime not installed")
+        assert build.returncode == 0, build.stderr
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+        run = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
+        assert run.returncode == 0 and "oracle sanitize run ok" in run.stdout, run.stdout + run.stderr
