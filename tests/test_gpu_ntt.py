@@ -399,3 +399,41 @@ def test_add_dcrt_glwe_mul_dcrt_polynomial_assign(pf, orc, log_n, moduli, k, bat
     with pytest.raises(pf.PfheError) as e:
         d.add_dcrt_glwe_mul_dcrt_polynomial_assign_dev(dacc, to_dev(glwe), to_dev(poly[:-W].copy()), k + 1)
     assert e.value.kind == "BadLength"
+
+
+@pytest.mark.parametrize("shared", [True, False])
+def test_fused_polymul_large_batch_tiled_path(pf, orc, shared):
+    """Batches >= 512 MiB run the two transform passes per tile on two streams; the fused product must
+    follow the tiling of a per-element multiplicand.  Compared with the unfused kernels on the whole
+    batch and with the oracle on three elements."""
+    import os
+    import torch
+    log_n, batch = 16, 360  # 360 x 3 x 512 KiB = 540 MiB
+    n, L = 1 << log_n, 3
+    W = L * n
+    d, o = pf.U64DcrtTable(log_n, Q61), orc.U64DcrtTable(log_n, Q61)
+    mods = np.array(Q61, np.uint64)
+    import ctypes as C
+    from primus_fhe_amd._lib import check, u64p
+
+    def fill(words, seed):
+        x = torch.empty(words, dtype=torch.int64, device="cuda")
+        check(pf.lib().pfhe_fill_uniform_dev(0, C.c_void_p(x.data_ptr()), words, mods.ctypes.data_as(u64p), L, n, seed, None))
+        return x
+
+    a, bh = fill(batch * W, 11), fill(W if shared else batch * W, 12)
+    fused = a.clone()
+    d.mul_dcrt_polynomial_dev(fused, bh)
+    os.environ["PFHE_DISABLE_FUSED_POLYMUL"] = "1"
+    try:
+        plain = a.clone()
+        d.mul_dcrt_polynomial_dev(plain, bh)
+    finally:
+        del os.environ["PFHE_DISABLE_FUSED_POLYMUL"]
+    assert torch.equal(fused, plain)
+    for e in (0, 179, 359):
+        x = to_host(a[e * W:(e + 1) * W]).copy()
+        o.transform_slice(x)
+        o.mul_assign(x, to_host(bh[:W] if shared else bh[e * W:(e + 1) * W]).copy())
+        o.inverse_transform_slice(x)
+        assert np.array_equal(to_host(fused[e * W:(e + 1) * W]), x)
