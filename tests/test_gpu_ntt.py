@@ -437,3 +437,40 @@ def test_fused_polymul_large_batch_tiled_path(pf, orc, shared):
         o.mul_assign(x, to_host(bh[:W] if shared else bh[e * W:(e + 1) * W]).copy())
         o.inverse_transform_slice(x)
         assert np.array_equal(to_host(fused[e * W:(e + 1) * W]), x)
+
+
+def test_tables_are_shareable_between_host_threads(pf, orc):
+    """NttTable: Send + Sync (ntt/mod.rs:16): several host threads use one table concurrently, each on
+    its own stream and buffers, including the large-batch path that borrows pooled internal streams."""
+    import threading
+    import torch
+    log_n = 14
+    n, L = 1 << log_n, 3
+    d, o = pf.U64DcrtTable(log_n, Q61), orc.U64DcrtTable(log_n, Q61)
+    rng = np.random.default_rng(77)
+    inputs = [rand_rns(rng, Q61, n, 6) for _ in range(4)]
+    refs = []
+    for a in inputs:
+        r = a.copy(); o.transform_slice(r); refs.append(r)
+    results, errors = [None] * 4, []
+
+    def worker(i):
+        try:
+            s = torch.cuda.Stream()
+            x = to_dev(inputs[i])
+            with torch.cuda.stream(s):
+                for _ in range(20):
+                    d.transform_dev(x, stream=s)
+                    d.inverse_transform_dev(x, stream=s)
+                d.transform_dev(x, stream=s)
+            s.synchronize()
+            results[i] = to_host(x)
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    for got, ref in zip(results, refs):
+        assert np.array_equal(got, ref)
