@@ -33,8 +33,11 @@ __device__ __forceinline__ u64 mac(const BarrettMac &m, u64 acc, u64 d, u64 k) {
     return mul_add_mod_barrett(d, k, acc, m.q, m.lo, m.hi);
 }
 
+#ifndef PFHE_MULACC_MIN_WG
+#define PFHE_MULACC_MIN_WG 2  // resident workgroups per CU the register allocation is sized for (tuning switch)
+#endif
 template <class A, int NC>
-__global__ __launch_bounds__(256, 2) void gadget_block_mulacc_kernel(const u64 *__restrict__ digits,
+__global__ __launch_bounds__(256, PFHE_MULACC_MIN_WG) void gadget_block_mulacc_kernel(const u64 *__restrict__ digits,
                                                                   const u64 *__restrict__ ggsw, u64 ggsw_stride,
                                                                   u64 *__restrict__ result,
                                                                   const NttPrime *__restrict__ primes, u32 L, u32 log_n,
