@@ -145,7 +145,10 @@ __global__ __launch_bounds__(kPwThreads) void monomial_kernel(u64 *__restrict__ 
 
 u32 grid_for(u64 work_items) {
     u64 g = (work_items + kPwThreads - 1) / kPwThreads;
-    const u64 cap = 256ull * 8;  // 256 CUs x 8 workgroups, grid-stride beyond that
+#ifndef PFHE_PW_WG_PER_CU
+#define PFHE_PW_WG_PER_CU 8
+#endif
+    const u64 cap = 256ull * PFHE_PW_WG_PER_CU;  // 256 CUs x 8 workgroups, grid-stride beyond that
     if (g > cap) g = cap;
     if (g == 0) g = 1;
     return (u32)g;
