@@ -80,9 +80,9 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
     const u32 ell = p->basis.ell;
     const u64 key_words = (u64)rows * ell * (p->k + 1) * W;
     // a single chunk has nothing to pipeline: run it on the caller's stream without the fork/join events
-    // (latency of small batches); the fused block+multiply-accumulate kernel launches one workgroup per
+    // (latency of small batches; also taken, chunk after chunk, while the caller captures a HIP graph); the fused block+multiply-accumulate kernel launches one workgroup per
     // (ciphertext, limb, block), so it only pays once that fills the chip
-    const bool single = batch <= p->chunk;
+    const bool single = batch <= p->chunk || stream_is_capturing(s);
     hipStream_t sa = single ? s : p->sa, sb = single ? s : p->sb;
     const bool fused = gadget_fused_supported(t.log_n, p->k) && std::getenv("PFHE_DISABLE_FUSED_EXTPROD") == nullptr &&
                        ((std::min<u64>(batch, p->chunk) * t.L) << (t.log_n - 12)) >= 256;
@@ -114,7 +114,7 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
         u64 *dg = p->digits[buf];
         const u64 npolys = cur * rows * ell * t.L;
         // ---- stream a: steps (1)-(4) + strided passes into digit buffer `buf` ----
-        if (fused && index >= 2) PFHE_HIP(hipStreamWaitEvent(sa, p->consumed[buf], 0));
+        if (fused && index >= 2 && !single) PFHE_HIP(hipStreamWaitEvent(sa, p->consumed[buf], 0));
         if (fused_decompose) {
             PFHE_TRY(gadget_decompose_strided_dev(p->rns, p->basis, t.primes_dev, t.log_n, t.pm,
                                                   crt_polys + done * rows * W, dg, cur * rows, sa, p->sdigits));

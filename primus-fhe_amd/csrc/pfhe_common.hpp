@@ -42,6 +42,17 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
         }                                                                          \
     } while (0)
 
+// true while `s` is being captured into a HIP graph: the internal multi-stream pipelines are then
+// replaced by their single-stream forms (same kernels, same results)
+inline bool stream_is_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return st != hipStreamCaptureStatusNone;
+}
+
 // RAII: make `device` current for the scope, restore the previous device afterwards.
 struct DeviceGuard {
     int prev = -1;

@@ -428,8 +428,8 @@ static int transform(const NttPrime *primes, u32 L, u32 log_n, int pm, u64 *data
     int dev = 0;
     // (the u32 tables do not gain from the overlap: measured 3.40 ms vs 3.15 ms without, N = 2^16)
     const bool overlap = pm != kArithB32 && passes == 2 && bytes >= kOverlapMinBytes && npolys >= (u64)kOverlapTiles * L &&
-                         std::getenv("PFHE_DISABLE_OVERLAP") == nullptr && hipGetDevice(&dev) == hipSuccess &&
-                         dev >= 0 && dev < 64;
+                         std::getenv("PFHE_DISABLE_OVERLAP") == nullptr && !stream_is_capturing(s) &&
+                         hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
     int tiles = kOverlapTiles;
     if (const char *e = std::getenv("PFHE_OVERLAP_TILES")) {  // tuning switch
         const int v = std::atoi(e);

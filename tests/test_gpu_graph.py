@@ -1,0 +1,79 @@
+"""The *_dev entry points can be captured into a HIP graph and replayed (launch-bound inner loops of a
+caller, e.g. a bootstrapping loop of small external products): they allocate nothing per call, and the
+internal fork/join over the plan's (or the transform's pooled) streams is expressed with events, which
+stream capture follows."""
+import numpy as np
+import pytest
+
+from gpu_util import rand_rns, to_dev
+from pyref import Q61
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pf():
+    import primus_fhe_amd as p
+    return p
+
+
+@pytest.mark.parametrize("chunk,batch", [(0, 2), (1, 3)])  # one chunk (caller's stream) / pipelined chunks
+def test_external_product_and_ntt_in_a_graph(pf, chunk, batch):
+    import torch
+    log_n, k = 12, 1
+    n, L = 1 << log_n, 3
+    rng = np.random.default_rng(chunk)
+    t, base = pf.U64DcrtTable(log_n, Q61), pf.RNSBase(Q61)
+    basis = pf.BigUintApproxSignedBasis(base, 30)
+    ctx = pf.DcrtGlevContext(t, base, basis, k, chunk)
+    ell = basis.decompose_length()
+    dg = to_dev(rand_rns(rng, Q61, n, batch * (k + 1)))
+    dk = to_dev(rand_rns(rng, Q61, n, (k + 1) * ell * (k + 1)))
+    out = torch.zeros_like(dg)
+    s = torch.cuda.Stream()
+
+    def work():
+        pf.mul_dcrt_ggsw_to_dev(dg, dk, out, ctx, into_coeff_form=True, stream=s)
+        t.transform_dev(out, stream=s)
+
+    with torch.cuda.stream(s):
+        work()  # eager reference (also creates every lazily-created stream / event outside the capture)
+    s.synchronize()
+    ref = out.clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        work()
+    for _ in range(2):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+
+
+def test_large_batch_transform_in_a_graph(pf):
+    """>= 512 MiB: the two passes run tile by tile on two pooled internal streams."""
+    import ctypes as C
+    import torch
+    from primus_fhe_amd._lib import check, u64p
+    log_n, batch = 16, 352
+    n, L = 1 << log_n, 3
+    t = pf.U64DcrtTable(log_n, Q61)
+    mods = np.array(Q61, np.uint64)
+    x = torch.empty(batch * L * n, dtype=torch.int64, device="cuda")
+    check(pf.lib().pfhe_fill_uniform_dev(0, C.c_void_p(x.data_ptr()), x.numel(), mods.ctypes.data_as(u64p), L, n, 3, None))
+    orig = x.clone()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        t.transform_dev(x, stream=s)
+    s.synchronize()
+    ref = x.clone()
+    x.copy_(orig)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        t.transform_dev(x, stream=s)
+        t.inverse_transform_dev(x, stream=s)
+        t.transform_dev(x, stream=s)
+    x.copy_(orig)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref)
