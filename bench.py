@@ -111,13 +111,43 @@ def cpu_baseline(seconds: float):
         while time.perf_counter() - t0 < seconds * 0.75:
             done += sum(ex.map(work, range(cores)))
     dt = time.perf_counter() - t0
-    return {
+    out = {
         "value": done / dt, "unit": "NTT/s", "cores": cores, "kind": "port",
         "single_thread_value": single, "single_thread_scalar_value": single_scalar,
         "backend": "avx512dq (restatement of prime64/avx512)" if avx512 else "scalar (restatement of prime64/scalar)",
         "sample": f"{done} forward limb-NTTs of N=2^16 (61-bit primes), oracle "
                   f"{'AVX-512 DQ' if avx512 else 'scalar'} Harvey path, {cores} threads, {dt:.1f} s",
     }
+    # RLWE external product at the config-4 shape (one ciphertext per task, one shared GGSW): the oracle's
+    # restatement of CrtGlwe::mul_dcrt_ggsw_to with its forward transforms on the vector backend when present
+    try:
+        oracle.lib().orc_set_vector_backend(1 if avx512 else 0)
+        dt_tab, base = oracle.U64DcrtTable(LOG_N, Q61), oracle.RNSBase(Q61)
+        basis = oracle.BigUintApproxSignedBasis(base, 30)
+        glwes = [np.concatenate([rng.integers(0, q, n, dtype=np.uint64) for _ in range(2) for q in Q61])
+                 for _ in range(cores)]
+        ggsw = np.concatenate([rng.integers(0, q, n, dtype=np.uint64)
+                               for _ in range(2 * basis.decompose_length * 2) for q in Q61])
+
+        def ep(i):
+            oracle.mul_dcrt_ggsw_to(dt_tab, base, basis, 1, glwes[i], ggsw)
+            return 1
+
+        ep(0)
+        t0 = time.perf_counter()
+        done_ep = 0
+        with ThreadPoolExecutor(cores) as ex:
+            while time.perf_counter() - t0 < max(2.0, seconds * 0.25):
+                done_ep += sum(ex.map(ep, range(cores)))
+        dte = time.perf_counter() - t0
+        out["external_product"] = {
+            "value": done_ep / dte, "unit": "RLWE external products/s (NTT-form output)", "cores": cores,
+            "sample": f"{done_ep} products, N=2^16, 3 primes, k=1, ell=6, {cores} threads, {dte:.1f} s"}
+    except Exception as e:  # the NTT baseline above is the contractual one
+        out["external_product"] = {"error": str(e)[:200]}
+    finally:
+        oracle.lib().orc_set_vector_backend(0)
+    return out
 
 
 def pmc_traffic(kernel: str, batch: int):

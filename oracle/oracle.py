@@ -78,6 +78,8 @@ def _load(path: str | None = None) -> C.CDLL:
         sig("orc_u64_ntt_" + g, None, vp, _u64p)
         sig("orc_uint_ntt_" + g, None, vp, _u64p)
     sig("orc_avx512_available", ci)
+    sig("orc_set_vector_backend", None, ci)
+    sig("orc_get_vector_backend", ci)
     sig("orc_u64_ntt_forward_avx512", ci, vp, _u64p, ci)
     sig("orc_u64_ntt_transform_monomial", None, vp, u64, sz, _u64p)
     sig("orc_u64_ntt_transform_coeff_one_monomial", None, vp, sz, _u64p)

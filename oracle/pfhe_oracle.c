@@ -406,7 +406,17 @@ void orc_u64_ntt_scalar_inverse(const orc_u64_ntt *tb, uint64_t *values, uint32_
 
 /* table.rs:541-563 */
 void orc_u64_ntt_lazy_transform_slice(const orc_u64_ntt *t, uint64_t *p) { orc_u64_ntt_scalar_forward(t, p, 0, 4); }
-void orc_u64_ntt_transform_slice(const orc_u64_ntt *t, uint64_t *p) { orc_u64_ntt_scalar_forward(t, p, 0, 1); }
+/* table.rs:166-302: U64NttTable dispatches to its vector backend when the host has one.  The restatement
+ * keeps the scalar path as the default (it is what the parity tests pin) and switches the canonical
+ * forward transform to the AVX-512 DQ restatement (pfhe_oracle_avx512.c) only on request — used by
+ * bench.py's cpu_baseline so that the CPU figure is what the reference would achieve on that host. */
+static int g_vector_backend = 0;
+void orc_set_vector_backend(int on) { g_vector_backend = on && orc_avx512_available(); }
+int orc_get_vector_backend(void) { return g_vector_backend; }
+void orc_u64_ntt_transform_slice(const orc_u64_ntt *t, uint64_t *p) {
+    if (g_vector_backend && t->n >= 16 && orc_u64_ntt_forward_avx512(t, p, 0) == ORC_OK) return;
+    orc_u64_ntt_scalar_forward(t, p, 0, 1);
+}
 void orc_u64_ntt_lazy_inverse_transform_slice(const orc_u64_ntt *t, uint64_t *v) { orc_u64_ntt_scalar_inverse(t, v, 0, 2); }
 void orc_u64_ntt_inverse_transform_slice(const orc_u64_ntt *t, uint64_t *v) { orc_u64_ntt_scalar_inverse(t, v, 0, 1); }
 

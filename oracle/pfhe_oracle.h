@@ -127,6 +127,10 @@ void orc_uint_ntt_transform_monomial(const orc_uint_ntt *t, uint64_t coeff, size
 /* AVX-512 (DQ) backend of the forward transform (pfhe_oracle_avx512.c; prime64/avx512/), n >= 16.
  * Returns ORC_ERR_BAD_ARG when the host lacks AVX-512 DQ. */
 int orc_avx512_available(void);
+/* process-wide switch (default off): canonical forward transforms of every U64NttTable go through the
+ * AVX-512 backend when the host has one (bench.py's cpu_baseline only) */
+void orc_set_vector_backend(int on);
+int orc_get_vector_backend(void);
 int orc_u64_ntt_forward_avx512(const orc_u64_ntt *t, uint64_t *values, int lazy);
 
 /* ---------------- U32NttTable (prime32/table.rs, prime32/scalar/) ---------------- */
