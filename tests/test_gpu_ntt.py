@@ -474,3 +474,20 @@ def test_tables_are_shareable_between_host_threads(pf, orc):
     assert not errors, errors
     for got, ref in zip(results, refs):
         assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("log_n,q", [(18, Q61[0]), (19, 132120577), (20, Q61[0]), (20, 132120577)])
+def test_largest_degrees(pf, orc, log_n, q):
+    """Up to the reference's MAX_DEGREE_BITS = 20 (prime64/avx512/internal.rs:2): two strided passes + block pass,
+    both arithmetic policies (2^61 - 2^21 + 1 is pseudo-Mersenne, 132120577 is not)."""
+    rng = np.random.default_rng(log_n)
+    n = 1 << log_n
+    t, o = pf.U64NttTable(log_n, q), orc.U64NttTable(log_n, q)
+    assert t.root() == o.root
+    a = rand_mod(rng, q, 2 * n)
+    ref = a.copy(); o.transform_slice(ref)
+    d = to_dev(a)
+    t.transform_dev(d)
+    assert np.array_equal(to_host(d), ref)
+    t.inverse_transform_dev(d)
+    assert np.array_equal(to_host(d), a)
