@@ -152,3 +152,49 @@ def test_random_external_products(pf, orc, case):
     out = np.empty_like(glwe)
     pf.mul_dcrt_ggsw_to(glwe, ggsw, out, ctx)
     assert np.array_equal(out, exp), (log_n, moduli, k, log_basis, rev, batch, shared, total_bits)
+
+
+def pm_prime(K: int, log_n: int, largest_c: bool):
+    """A prime 2^K - c with 2^(log_n+1) | q - 1 and c < 2^(K-33): the largest (or smallest) admissible c."""
+    step = 1 << (log_n + 1)
+    jmax = ((1 << (K - 33)) // step)
+    js = range(jmax, 0, -1) if largest_c else range(1, jmax + 1)
+    for j in js:
+        c = j * step - 1
+        if c < (1 << (K - 33)) and is_prime((1 << K) - c):
+            return (1 << K) - c
+    return None
+
+
+@pytest.mark.parametrize("K", [40, 41, 44, 48, 52, 56, 59, 60, 61])
+@pytest.mark.parametrize("largest_c", [True, False])
+def test_pseudo_mersenne_bounds(pf, orc, K, largest_c):
+    """The pseudo-Mersenne policy at the edges of its admissible shape (K = 40..61, c just below
+    2^(K-33)) with extreme inputs (q-1 everywhere; 4q-1 for the lazy forward transform)."""
+    log_n = min(12, K - 36)
+    q = pm_prime(K, log_n, largest_c)
+    if q is None:
+        pytest.skip("no admissible prime")
+    n = 1 << log_n
+    t, o = pf.U64NttTable(log_n, q), orc.U64NttTable(log_n, q)
+    rng = np.random.default_rng(K)
+    for a in (np.full(2 * n, q - 1, np.uint64), rng.integers(0, q, 2 * n, dtype=np.uint64)):
+        ref = a.copy(); o.transform_slice(ref)
+        d = to_dev(a)
+        t.transform_dev(d)
+        assert np.array_equal(to_host(d), ref), (K, q)
+        t.inverse_transform_dev(d)
+        assert np.array_equal(to_host(d), a)
+        iref = a.copy(); o.inverse_transform_slice(iref)
+        d = to_dev(a); t.inverse_transform_dev(d)
+        assert np.array_equal(to_host(d), iref)
+    lz = np.full(n, 4 * q - 1, np.uint64)
+    can = (lz % np.uint64(q)).copy(); o.transform_slice(can)
+    d = to_dev(lz); t.transform_dev(d, lazy=True)
+    got = to_host(d)
+    assert got.max() < 4 * q and np.array_equal(got % np.uint64(q), can)
+    li = np.full(n, 2 * q - 1, np.uint64)
+    cani = (li % np.uint64(q)).copy(); o.inverse_transform_slice(cani)
+    d = to_dev(li); t.inverse_transform_dev(d, lazy=True)
+    got = to_host(d)
+    assert got.max() < 2 * q and np.array_equal(got % np.uint64(q), cani)
