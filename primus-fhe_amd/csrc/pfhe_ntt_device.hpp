@@ -15,7 +15,7 @@ struct NttPlan {
     int strided[4] = {0, 0, 0, 0};  // stages per strided pass, in forward order
     int block_log = 0;
 };
-NttPlan make_ntt_plan(u32 log_n);
+NttPlan make_ntt_plan(u32 log_n, int arith = 0);  // arith: see kArith* below (plans differ for the u32 tables)
 
 // `arith` selects the arithmetic policy: kArithShoup (any q < 2^62), kArithPm (every prime of the
 // table has the pseudo-Mersenne shape, NttPrime::pm_k) or kArithB32 (32-bit tables: `data` holds
@@ -35,8 +35,8 @@ int ntt_inverse_mul_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64
 int ntt32_transform_dev(const NttPrime *primes, u32 L, u32 log_n, u32 *data, u64 npolys, bool inverse, bool lazy,
                         hipStream_t s);
 
-int ntt_num_passes(u32 log_n);
-void ntt_pass_name(u32 log_n, bool inverse, int index, char *buf, size_t cap);
+int ntt_num_passes(u32 log_n, int arith = 0);
+void ntt_pass_name(u32 log_n, bool inverse, int index, char *buf, size_t cap, int arith = 0);
 int ntt_pass_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, bool inverse,
                  int index, bool lazy, hipStream_t s, const u64 *mul = nullptr, u64 mul_polys = 0);
 

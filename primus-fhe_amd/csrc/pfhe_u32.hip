@@ -485,7 +485,7 @@ int pfhe_dcrt32_fill_uniform_dev(const pfhe_dcrt32 *table, uint32_t *dst_dev, si
 /* profiling hooks: the passes of one transform, as for the 64-bit tables */
 int pfhe_dcrt32_transform_num_passes(const pfhe_dcrt32 *table) {
     if (!table) return 0;
-    return table->t->log_n <= 4 ? 1 : ntt_num_passes(table->t->log_n - 1);
+    return table->t->log_n <= 4 ? 1 : ntt_num_passes(table->t->log_n - 1, kArithB32);
 }
 const char *pfhe_dcrt32_transform_pass_name(const pfhe_dcrt32 *table, int inverse, int index) {
     static thread_local char buf[112];
@@ -496,7 +496,7 @@ const char *pfhe_dcrt32_transform_pass_name(const pfhe_dcrt32 *table, int invers
         return buf;
     }
     char inner[96];
-    ntt_pass_name(table->t->log_n - 1, inverse != 0, index, inner, sizeof inner);
+    ntt_pass_name(table->t->log_n - 1, inverse != 0, index, inner, sizeof inner, kArithB32);
     std::snprintf(buf, sizeof buf, "u32:%s", inner);
     return buf;
 }
