@@ -313,7 +313,12 @@ NttPlan make_ntt_plan(u32 log_n, int arith) {
         p.tiny = true;
         return p;
     }
-    if (log_n <= kMaxSinglePassLog) {
+    u32 max_single = kMaxSinglePassLog;
+    if (const char *e = std::getenv("PFHE_MAX_SINGLE_PASS_LOG")) {  // tuning switch
+        const int v = std::atoi(e);
+        if (v >= 9 && v <= (int)kMaxSinglePassLog) max_single = (u32)v;
+    }
+    if (log_n <= max_single) {
         p.block_log = (int)log_n;
         return p;
     }
@@ -325,6 +330,7 @@ NttPlan make_ntt_plan(u32 log_n, int arith) {
         const int b = std::atoi(e);
         if (b >= 8 && b <= 12 && (int)log_n - b >= 1) p.block_log = b;
     }
+    if (p.block_log >= (int)log_n) p.block_log = (int)log_n - 1;  // only reachable through the tuning switches
     int rest = (int)log_n - p.block_log;
     // fewest strided passes with at most 5 stages each, balanced
     int passes = (rest + 4) / 5;
