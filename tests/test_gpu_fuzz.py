@@ -54,7 +54,10 @@ def pf():
     return p
 
 
-CASES = list(range(60))
+import os
+
+SCALE = int(os.environ.get("PFHE_FUZZ_SCALE", "1"))  # PFHE_FUZZ_SCALE=10 widens every sweep tenfold
+CASES = list(range(60 * SCALE))
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -96,7 +99,7 @@ def test_random_u64_tables(pf, orc, case):
     assert (got < 4 * qs).all() and np.array_equal(got % qs, can)
 
 
-@pytest.mark.parametrize("case", range(30))
+@pytest.mark.parametrize("case", range(30 * SCALE))
 def test_random_u32_tables(pf, orc, case):
     rng = np.random.default_rng(2000 + case)
     log_n = int(rng.integers(1, 15)) if case % 5 else int(rng.integers(15, 18))
@@ -117,7 +120,7 @@ def test_random_u32_tables(pf, orc, case):
     assert np.array_equal(lz, lzo)
 
 
-@pytest.mark.parametrize("case", range(16))
+@pytest.mark.parametrize("case", range(16 * SCALE))
 def test_random_external_products(pf, orc, case):
     rng = np.random.default_rng(3000 + case)
     log_n = int(rng.integers(3, 13)) if case % 4 else 16
