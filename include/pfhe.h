@@ -353,6 +353,11 @@ int pfhe_conv_fast_convert_array(const pfhe_conv *conv, const uint64_t *crt_poly
 int pfhe_conv_fast_convert_array_dev(const pfhe_conv *conv, const uint64_t *crt_poly_in_dev,
                                      size_t len_in, uint64_t *crt_poly_out_dev, size_t len_out,
                                      size_t poly_length, void *stream);
+/* fast_convert_array_to_pair_iter — converter.rs:233-272: two output moduli; `pairs_out_dev`
+ * receives poly_length interleaved (mod p_0, mod p_1) pairs (len_out = 2 * poly_length) */
+int pfhe_conv_fast_convert_array_to_pairs_dev(const pfhe_conv *conv, const uint64_t *crt_poly_in_dev,
+                                              size_t len_in, uint64_t *pairs_out_dev,
+                                              size_t len_out, size_t poly_length, void *stream);
 /* exact_convert_array — converter.rs:274-364 (single output modulus; f64 correction term) */
 int pfhe_conv_exact_convert_array(const pfhe_conv *conv, const uint64_t *crt_poly_in, size_t len_in,
                                   uint64_t *crt_poly_out, size_t len_out, size_t poly_length);

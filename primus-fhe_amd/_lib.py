@@ -143,6 +143,7 @@ def _declare(lib: C.CDLL) -> None:
     for g in ("fast_convert_array", "exact_convert_array"):
         sig("pfhe_conv_" + g, ci, vp, vp, sz, vp, sz, sz)
         sig("pfhe_conv_" + g + "_dev", ci, vp, vp, sz, vp, sz, sz, vp)
+    sig("pfhe_conv_fast_convert_array_to_pairs_dev", ci, vp, vp, sz, vp, sz, sz, vp)
     sig("pfhe_rns_decompose_big_uint_values_to", ci, vp, vp, sz, vp, sz, sz)
     sig("pfhe_rns_decompose_big_uint_values_to_dev", ci, vp, vp, sz, vp, sz, sz, vp)
 

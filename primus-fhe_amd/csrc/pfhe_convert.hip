@@ -67,6 +67,17 @@ __global__ __launch_bounds__(kThreads) void fast_convert_kernel(ConvDev C, const
     for (u32 j = 0; j < C.lout; ++j) out[(u64)j * n + c] = dot_mod(C, j, t);
 }
 
+// fast_convert_array_to_pair_iter (converter.rs:233-272): two output moduli, one (mod p_0, mod p_1) pair per
+// coefficient, written interleaved — one 16-byte store per thread
+__global__ __launch_bounds__(kThreads) void fast_convert_pair_kernel(ConvDev C, const u64 *__restrict__ in,
+                                                                     u64 *__restrict__ out, u64 n) {
+    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    u64 t[kMaxLimbs];
+    load_scaled(C, in, n, c, t);
+    *reinterpret_cast<ulonglong2 *>(out + 2 * c) = ulonglong2{dot_mod(C, 0, t), dot_mod(C, 1, t)};
+}
+
 __global__ __launch_bounds__(kThreads) void exact_convert_kernel(ConvDev C, const u64 *__restrict__ in,
                                                                  u64 *__restrict__ out, u64 n) {
     const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -192,6 +203,26 @@ int pfhe_conv_fast_convert_array_dev(const pfhe_conv *c, const uint64_t *crt_pol
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
     hipLaunchKernelGGL(fast_convert_kernel, dim3(grid_for(poly_length)), dim3(kThreads), 0, (hipStream_t)stream, c->dev,
                        (const u64 *)crt_poly_in_dev, (u64 *)crt_poly_out_dev, (u64)poly_length);
+    PFHE_HIP(hipGetLastError());
+    return PFHE_OK;
+    PFHE_GUARD_END
+}
+
+int pfhe_conv_fast_convert_array_to_pairs_dev(const pfhe_conv *c, const uint64_t *crt_poly_in_dev, size_t len_in,
+                                              uint64_t *pairs_out_dev, size_t len_out, size_t poly_length, void *stream) {
+    PFHE_GUARD_BEGIN
+    if (!c || ((!crt_poly_in_dev || !pairs_out_dev) && poly_length)) return PFHE_ERR_BAD_ARGUMENT;
+    if (c->dev.lout != 2) {  // converter.rs:239-243 asserts
+        set_last_error("output base in fast_convert_array_to_pair must contain exactly two moduli");
+        return PFHE_ERR_BAD_ARGUMENT;
+    }
+    if (len_in != poly_length * c->dev.lin || len_out != 2 * poly_length) return PFHE_ERR_BAD_LENGTH;
+    PFHE_REQUIRE_ALIGNED(pairs_out_dev);
+    if (poly_length == 0) return PFHE_OK;
+    DeviceGuard g(c->device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    hipLaunchKernelGGL(fast_convert_pair_kernel, dim3(grid_for(poly_length)), dim3(kThreads), 0, (hipStream_t)stream,
+                       c->dev, (const u64 *)crt_poly_in_dev, (u64 *)pairs_out_dev, (u64)poly_length);
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
     PFHE_GUARD_END

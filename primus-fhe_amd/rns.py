@@ -121,6 +121,11 @@ class BaseConverter:
         (pi, ni), (po, no) = _dev(crt_poly_in), _dev(crt_poly_out)
         check(lib().pfhe_conv_fast_convert_array_dev(self._h, pi, ni, po, no, poly_length, _stream(stream)))
 
+    def fast_convert_array_to_pairs_dev(self, crt_poly_in, pairs_out, poly_length: int, stream=None):
+        """converter.rs:233-272 (fast_convert_array_to_pair_iter): interleaved (mod p_0, mod p_1) pairs."""
+        (pi, ni), (po, no) = _dev(crt_poly_in), _dev(pairs_out)
+        check(lib().pfhe_conv_fast_convert_array_to_pairs_dev(self._h, pi, ni, po, no, poly_length, _stream(stream)))
+
     def exact_convert_array_dev(self, crt_poly_in, crt_poly_out, poly_length: int, stream=None):
         (pi, ni), (po, no) = _dev(crt_poly_in), _dev(crt_poly_out)
         check(lib().pfhe_conv_exact_convert_array_dev(self._h, pi, ni, po, no, poly_length, _stream(stream)))

@@ -105,3 +105,23 @@ def test_decompose_big_uint_values(pf, orc, moduli):
     back = np.empty_like(big)
     base.compose_multiple_values_to(res, back, count)
     assert np.array_equal(back, big)
+
+
+def test_fast_convert_to_pairs(pf, orc):
+    """fast_convert_array_to_pair_iter (converter.rs:233-272, rns.rs:325-332): (mod p_0, mod p_1) pairs equal the
+    two output rows of fast_convert_array."""
+    import torch
+    rng = np.random.default_rng(17)
+    n = 5000
+    conv = pf.BaseConverter(pf.RNSBase(Q61), pf.RNSBase(Q60S[:2]))
+    oconv = orc.BaseConverter(orc.RNSBase(Q61), orc.RNSBase(Q60S[:2]))
+    x = np.concatenate([rng.integers(0, q, n, dtype=np.uint64) for q in Q61])
+    exp = oconv.fast_convert_array(x, n)
+    pairs = torch.zeros(2 * n, dtype=torch.int64, device="cuda")
+    conv.fast_convert_array_to_pairs_dev(to_dev(x), pairs, n)
+    got = to_host(pairs)
+    assert np.array_equal(got[0::2], exp[:n]) and np.array_equal(got[1::2], exp[n:])
+    three = pf.BaseConverter(pf.RNSBase(Q61), pf.RNSBase(Q60S))
+    with pytest.raises(pf.PfheError) as e:
+        three.fast_convert_array_to_pairs_dev(to_dev(x), pairs, n)
+    assert e.value.kind == "BadArgument"
