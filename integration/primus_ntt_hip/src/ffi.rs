@@ -47,6 +47,8 @@ unsafe extern "C" {
     pub fn pfhe_ntt32_lazy_transform_slice(t: *const pfhe_ntt32, poly: *mut u32, len: usize) -> c_int;
     pub fn pfhe_ntt32_lazy_inverse_transform_slice(t: *const pfhe_ntt32, values: *mut u32, len: usize) -> c_int;
     pub fn pfhe_ntt32_transform_monomial(t: *const pfhe_ntt32, coeff: u32, degree: usize, values: *mut u32, len: usize) -> c_int;
+    pub fn pfhe_ntt32_transform_coeff_one_monomial(t: *const pfhe_ntt32, degree: usize, values: *mut u32, len: usize) -> c_int;
+    pub fn pfhe_ntt32_transform_coeff_minus_one_monomial(t: *const pfhe_ntt32, degree: usize, values: *mut u32, len: usize) -> c_int;
 
     // RNS gadget external product (batched, device resident)
     pub fn pfhe_rns_create(moduli: *const u64, count: usize, device: c_int, out: *mut *mut pfhe_rns) -> c_int;

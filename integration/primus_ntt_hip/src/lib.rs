@@ -238,12 +238,12 @@ impl NttTable for HipU32NttTable {
                   "u32 transform_monomial")
     }
     fn transform_coeff_one_monomial(&self, degree: usize, values: &mut [u32]) {
-        self.transform_monomial(1, degree, values)
+        expect_ok(unsafe { ffi::pfhe_ntt32_transform_coeff_one_monomial(self.h, degree, values.as_mut_ptr(), values.len()) },
+                  "u32 transform_coeff_one_monomial")
     }
     fn transform_coeff_minus_one_monomial(&self, degree: usize, values: &mut [u32]) {
-        // q - 1; the table does not expose q here, so go through a monomial with coefficient -1 via the C ABI
-        // `pfhe_ntt32_transform_coeff_minus_one_monomial` (declared in pfhe.h, add to ffi.rs when used)
-        unimplemented!("bind pfhe_ntt32_transform_coeff_minus_one_monomial")
+        expect_ok(unsafe { ffi::pfhe_ntt32_transform_coeff_minus_one_monomial(self.h, degree, values.as_mut_ptr(), values.len()) },
+                  "u32 transform_coeff_minus_one_monomial")
     }
 }
 
