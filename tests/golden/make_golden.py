@@ -163,8 +163,69 @@ def digests():
     return d
 
 
+def u32_cases():
+    """U32NttTable (prime32): full vectors at N <= 64 from the big-integer evaluation, digests at 2^10 / 2^16."""
+    small, dig = [], []
+    for cid, (log_n, q) in enumerate([(1, 17), (3, 132120577), (5, 268369921), (6, 1073479681)]):
+        n = 1 << log_n
+        a = splitmix_uniform(0x800 + cid, q, n).tolist()
+        psi = pyref.minimal_primitive_root(log_n + 1, q)
+        fwd = pyref.ntt_direct(a, q, log_n, psi).tolist()
+        t = orc.U32NttTable(log_n, q)
+        assert t.root == psi
+        x = np.array(a, np.uint32)
+        t.transform_slice(x)
+        assert x.tolist() == fwd
+        small.append(dict(case=cid, log_n=log_n, q=q, root=psi, seed=0x800 + cid, a=a, ntt_a=fwd))
+    for cid, (log_n, q, batch) in enumerate([(10, 132120577, 2), (16, 1073479681, 1)]):
+        n = 1 << log_n
+        a = splitmix_uniform(0x810 + cid, q, n * batch)
+        t = orc.U32NttTable(log_n, q)
+        x = a.astype(np.uint32)
+        t.transform_slice(x)
+        py = np.concatenate([np.array(pyref.ntt_fast(a[i * n:(i + 1) * n].tolist(), q, log_n), np.uint64)
+                             for i in range(batch)])
+        assert np.array_equal(x.astype(np.uint64), py)
+        dig.append(dict(case=cid, log_n=log_n, q=q, batch=batch, seed=0x810 + cid,
+                        output_sha256=hashlib.sha256(np.ascontiguousarray(x, dtype="<u4").tobytes()).hexdigest()))
+    return dict(small=small, digests=dig)
+
+
+def converter_cases():
+    """BaseConverter: fast_convert_array by its definition on Python integers; exact_convert_array as the
+    centred representative (inputs kept away from Q/2 so that no float rounding decides the branch)."""
+    out = []
+    for cid, (mod_in, mod_out) in enumerate([([17, 19, 23], [29, 31]), (Q61, [1152921504606584833, 1125899906826241]),
+                                             (Q61[:2], Q61[2:])]):
+        n = 16
+        Q = 1
+        for q in mod_in:
+            Q *= q
+        x = np.concatenate([splitmix_uniform(0x900 + 16 * cid + i, q, n) for i, q in enumerate(mod_in)])
+        vals = [pyref.crt_compose([int(x[i * n + t]) for i in range(len(mod_in))], mod_in) for t in range(n)]
+        fast = []
+        for j, p in enumerate(mod_out):
+            for t in range(n):
+                s_ = sum((int(x[i * n + t]) * pow(Q // q, -1, q) % q) * (Q // q) for i, q in enumerate(mod_in))
+                fast.append(s_ % p)
+        oin = orc.RNSBase(mod_in)
+        conv = orc.BaseConverter(oin, orc.RNSBase(mod_out))
+        assert conv.fast_convert_array(x, n).tolist() == fast
+        p0 = mod_out[0]
+        exact = [(v % p0 if 2 * v < Q else (v - Q) % p0) for v in vals]
+        assert all(abs(v / Q - 0.5) > 1e-6 for v in vals)
+        econv = orc.BaseConverter(oin, orc.RNSBase([p0]))
+        assert econv.exact_convert_array(x, n).tolist() == exact
+        out.append(dict(case=cid, input_moduli=[str(m) for m in mod_in], output_moduli=[str(m) for m in mod_out],
+                        seed_base=0x900 + 16 * cid, count=n, fast=[str(v) for v in fast],
+                        exact_to_first_output_modulus=[str(v) for v in exact]))
+    return out
+
+
 def main():
     out = {
+        "u32_ntt.json": u32_cases(),
+        "base_converter.json": converter_cases(),
         "ntt_small.json": small_ntt_cases(),
         "rns_gadget_small.json": rns_gadget_cases(),
         "extprod_small.json": small_extprod_case(),

@@ -221,3 +221,69 @@ def test_gpu_digests(pf, d):
         out = np.empty_like(glwe)
         pf.mul_dcrt_ggsw_to(glwe, ggsw, out, ctx)
         assert digest(out) == d["output_sha256"]
+
+
+# --------------------------------------------------------------------------- u32 tables, base conversion
+
+U32 = load("u32_ntt.json")
+CONV = load("base_converter.json")
+
+
+def _sha32(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a, dtype="<u4").tobytes()).hexdigest()
+
+
+def _conv_input(c):
+    mod_in = [int(m) for m in c["input_moduli"]]
+    return mod_in, np.concatenate([splitmix_uniform(c["seed_base"] + i, q, c["count"]) for i, q in enumerate(mod_in)])
+
+
+def _check_u32(make_table, root_of):
+    for c in U32["small"]:
+        t = make_table(c["log_n"], c["q"])
+        assert root_of(t) == c["root"]
+        x = np.array(c["a"], np.uint32)
+        t.transform_slice(x)
+        assert x.tolist() == c["ntt_a"]
+        t.inverse_transform_slice(x)
+        assert x.tolist() == c["a"]
+    for d in U32["digests"]:
+        t = make_table(d["log_n"], d["q"])
+        x = splitmix_uniform(d["seed"], d["q"], d["batch"] << d["log_n"]).astype(np.uint32)
+        t.transform_slice(x)
+        assert _sha32(x) == d["output_sha256"]
+
+
+def test_oracle_u32_golden(orc):
+    _check_u32(orc.U32NttTable, lambda t: t.root)
+
+
+@pytest.mark.parametrize("c", CONV, ids=lambda c: f"case{c['case']}")
+def test_oracle_converter_golden(orc, c):
+    mod_in, x = _conv_input(c)
+    mod_out = [int(m) for m in c["output_moduli"]]
+    oin = orc.RNSBase(mod_in)
+    assert orc.BaseConverter(oin, orc.RNSBase(mod_out)).fast_convert_array(x, c["count"]).tolist() == [int(v) for v in c["fast"]]
+    assert orc.BaseConverter(oin, orc.RNSBase(mod_out[:1])).exact_convert_array(x, c["count"]).tolist() == \
+        [int(v) for v in c["exact_to_first_output_modulus"]]
+
+
+@pytest.mark.gpu
+def test_gpu_u32_golden(pf):
+    _check_u32(pf.U32NttTable, lambda t: t.root())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", CONV, ids=lambda c: f"case{c['case']}")
+def test_gpu_converter_golden(pf, c):
+    mod_in, x = _conv_input(c)
+    mod_out = [int(m) for m in c["output_moduli"]]
+    n = c["count"]
+    base_in = pf.RNSBase(mod_in)
+    out = np.empty(len(mod_out) * n, np.uint64)
+    pf.BaseConverter(base_in, pf.RNSBase(mod_out)).fast_convert_array(x, out, n)
+    assert out.tolist() == [int(v) for v in c["fast"]]
+    eo = np.empty(n, np.uint64)
+    pf.BaseConverter(base_in, pf.RNSBase(mod_out[:1])).exact_convert_array(x, eo, n)
+    assert eo.tolist() == [int(v) for v in c["exact_to_first_output_modulus"]]
