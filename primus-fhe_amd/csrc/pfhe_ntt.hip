@@ -130,8 +130,13 @@ __global__ __launch_bounds__(256) void ntt_strided_kernel(u64 *__restrict__ data
 //   inverse: the FIRST LOGB stages (distances 1 ... B/2); when B == N the final stage carries
 //            the fused N^-1 / N^-1*w scaling (scalar/transform.rs:283-318).
 // ------------------------------------------------------------------------------------------
+// LDS limits the block pass to four waves per SIMD; telling the compiler so makes it spend registers on
+// instruction-level parallelism instead of chasing a higher occupancy it cannot get (1-3 % measured)
+#ifndef PFHE_BLOCK_WAVES_ATTR
+#define PFHE_BLOCK_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
 template <class A, int LOGB, bool INV, bool MUL = false>
-__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) void ntt_block_kernel(
+__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) PFHE_BLOCK_WAVES_ATTR void ntt_block_kernel(
     u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L, u32 log_n, u64 total_blocks, u32 lazy,
     const u64 *__restrict__ mul, u64 mul_polys) {
     using Cfg = BlockCfg<LOGB>;
