@@ -384,7 +384,7 @@ int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *rns, const 
     p->rns = rns->h.dev;
     p->basis = basis->h.dev;
     p->k = (u32)glwe_dimension;
-    p->chunk = chunk ? chunk : 32;
+    p->chunk = chunk ? chunk : 64;  // measured best at N = 2^16 (16: 26.5 ms, 32: 25.7, 64: 24.7, 128: 24.8 per 1024 products)
     p->digits_words = p->chunk * (p->k + 1) * p->basis.ell * t->L * t->n;
     DeviceGuard g(t->device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
