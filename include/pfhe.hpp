@@ -237,10 +237,48 @@ class RNSBase {
         check(pfhe_rns_wrapping_decompose_small_values_to(h_, small_values, value_count, multi_residues, len_out,
                                                           small_value_modulus));
     }
+    // RNSBase::decompose_big_uint_values_to (crates/primus_rns/src/base.rs:457-481)
+    void decompose_big_uint_values_to(const uint64_t *big_uint_values, size_t len_in, uint64_t *multi_residues,
+                                      size_t len_out, size_t value_count) const {
+        check(pfhe_rns_decompose_big_uint_values_to(h_, big_uint_values, len_in, multi_residues, len_out, value_count));
+    }
     const pfhe_rns *handle() const { return h_; }
 
   private:
     pfhe_rns *h_ = nullptr;
+};
+
+// primus_rns::BaseConverter (crates/primus_rns/src/converter.rs:21): modulus-major arrays; the reference's
+// `scratch` argument has no counterpart
+class BaseConverter {
+  public:
+    BaseConverter(const RNSBase &input_base, const RNSBase &output_base) {
+        check(pfhe_conv_create(input_base.handle(), output_base.handle(), &h_));
+    }
+    ~BaseConverter() { pfhe_conv_destroy(h_); }
+    BaseConverter(const BaseConverter &) = delete;
+    BaseConverter &operator=(const BaseConverter &) = delete;
+    size_t input_moduli_count() const { return pfhe_conv_input_moduli_count(h_); }
+    size_t output_moduli_count() const { return pfhe_conv_output_moduli_count(h_); }
+    void fast_convert_array(const uint64_t *crt_poly_in, size_t len_in, uint64_t *crt_poly_out, size_t len_out,
+                            size_t poly_length) const {
+        check(pfhe_conv_fast_convert_array(h_, crt_poly_in, len_in, crt_poly_out, len_out, poly_length));
+    }
+    void exact_convert_array(const uint64_t *crt_poly_in, size_t len_in, uint64_t *crt_poly_out, size_t len_out,
+                             size_t poly_length) const {
+        check(pfhe_conv_exact_convert_array(h_, crt_poly_in, len_in, crt_poly_out, len_out, poly_length));
+    }
+    void fast_convert_array_dev(const uint64_t *in_dev, size_t len_in, uint64_t *out_dev, size_t len_out,
+                                size_t poly_length, void *stream = nullptr) const {
+        check(pfhe_conv_fast_convert_array_dev(h_, in_dev, len_in, out_dev, len_out, poly_length, stream));
+    }
+    void exact_convert_array_dev(const uint64_t *in_dev, size_t len_in, uint64_t *out_dev, size_t len_out,
+                                 size_t poly_length, void *stream = nullptr) const {
+        check(pfhe_conv_exact_convert_array_dev(h_, in_dev, len_in, out_dev, len_out, poly_length, stream));
+    }
+
+  private:
+    pfhe_conv *h_ = nullptr;
 };
 
 class BigUintApproxSignedBasis {

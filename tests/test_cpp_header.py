@@ -21,7 +21,11 @@ int main() {
         std::vector<uint32_t> c(2 * 1024, 7), d = c;
         t32.transform_slice(c.data(), c.size());
         t32.inverse_transform_slice(c.data(), c.size());
-        const bool ok = a == b && c == d;
+        pfhe::RNSBase in({17, 19, 23}), out2({29, 31});
+        pfhe::BaseConverter conv(in, out2);
+        std::vector<uint64_t> res = {1, 2, 3}, conv_out(2);   // one coefficient, residues (1,2,3)
+        conv.fast_convert_array(res.data(), 3, conv_out.data(), 2, 1);
+        const bool ok = a == b && c == d && conv.input_moduli_count() == 3 && conv_out[0] < 29 && conv_out[1] < 31;
         std::printf(ok ? "roundtrip ok\n" : "roundtrip MISMATCH\n");
         return ok ? 0 : 1;
     } catch (const pfhe::Error &e) {
