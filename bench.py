@@ -293,8 +293,13 @@ def main():
         dom = max(per_pass, key=lambda t: t[1])
         alg_bytes = 16 * n * batch * L  # each pass reads and writes every coefficient once
         achieved = alg_bytes / (dom[1] * 1e-3) / 1e9
+        pmc = pmc_traffic(dom[0], batch)
         result["roofline"] = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom[0], batch),
+                              "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                              # HBM bytes per launch of this kernel from the committed PMC passes (null if none match)
+                              "traffic": pmc["bytes_per_launch"] if pmc else None,
+                              "traffic_unit": "bytes per launch",
+                              "traffic_source": (pmc["source"] + ": " + pmc["method"]) if pmc else None,
                               "avg_launch_ms": dom[1], "algorithmic_bytes_per_launch": alg_bytes,
                               "note": "fraction of the HBM roofline as the metric asks; this kernel is bound by the "
                                       "integer ALU (VALUBusy 98 %, profiles/r01_e_pmc_utilisation.txt), not by HBM"}
