@@ -168,3 +168,18 @@ def test_u32_full_batch_round_trip_properties(pf, orc):
         assert np.array_equal(to_host32(x[s]), ref)
     t.inverse_transform_dev(x)
     assert torch.equal(x, orig)
+
+
+@pytest.mark.parametrize("log_n", [5, 11, 16])
+def test_u32_and_u64_tables_agree_on_the_gpu(pf, log_n):
+    """The same prime through the two independent device paths (packed Barrett-32 words vs 64-bit Shoup)."""
+    q = Q27
+    rng = np.random.default_rng(log_n)
+    a = rand32(rng, q, 3 << log_n)
+    t32, t64 = pf.U32NttTable(log_n, q), pf.U64NttTable(log_n, q)
+    assert t32.root() == t64.root()
+    x32, x64 = a.copy(), a.astype(np.uint64)
+    t32.transform_slice(x32); t64.transform_slice(x64)
+    assert np.array_equal(x32.astype(np.uint64), x64)
+    t32.inverse_transform_slice(x32); t64.inverse_transform_slice(x64)
+    assert np.array_equal(x32, a) and np.array_equal(x64, a.astype(np.uint64))
