@@ -266,7 +266,10 @@ int dispatch_strided(int k, u64 *data, const NttPrime *primes, u32 L, u32 log_n,
         case 1: return launch_strided<A, 1, 2, INV, FINAL>(data, primes, L, log_n, log_s, npolys, lazy, s);
         case 2: return launch_strided<A, 2, 2, INV, FINAL>(data, primes, L, log_n, log_s, npolys, lazy, s);
         case 3: return launch_strided<A, 3, 2, INV, FINAL>(data, primes, L, log_n, log_s, npolys, lazy, s);
-        case 4: return launch_strided<A, 4, 2, INV, FINAL>(data, primes, L, log_n, log_s, npolys, lazy, s);
+        case 4:
+            if (std::getenv("PFHE_STRIDED_VEC1") != nullptr)  // tuning switch: one column per thread (fewer registers)
+                return launch_strided<A, 4, 1, INV, FINAL>(data, primes, L, log_n, log_s, npolys, lazy, s);
+            return launch_strided<A, 4, 2, INV, FINAL>(data, primes, L, log_n, log_s, npolys, lazy, s);
         case 5: return launch_strided<A, 5, 1, INV, FINAL>(data, primes, L, log_n, log_s, npolys, lazy, s);
     }
     set_last_error("unsupported strided radix");
