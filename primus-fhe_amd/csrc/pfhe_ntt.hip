@@ -76,11 +76,9 @@ __global__ void ntt_tiny_kernel(u64 *__restrict__ data, const NttPrime *__restri
 //            the last stage of the whole transform (fused N^-1 scaling, table.rs:283-318).
 // ------------------------------------------------------------------------------------------
 template <class A, int K, int VEC, bool INV, bool FINAL>
-__global__ __launch_bounds__(256) void ntt_strided_kernel(u64 *__restrict__ data,
-                                                          const NttPrime *__restrict__ primes, u32 L,
-                                                          u32 log_n, u32 log_s, u64 total_threads, u32 lazy) {
+__device__ __forceinline__ void strided_pass_body(u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L,
+                                                  u32 log_n, u32 log_s, u64 gid, u64 total_threads, u32 lazy) {
     constexpr int R = 1 << K;
-    u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total_threads) return;
     // gid -> (pid, hi, col): col indexes VEC-wide column groups inside the stride
     const u32 log_cols = log_s - (VEC == 2 ? 1 : 0);
@@ -122,6 +120,14 @@ __global__ __launch_bounds__(256) void ntt_strided_kernel(u64 *__restrict__ data
     }
 }
 
+template <class A, int K, int VEC, bool INV, bool FINAL>
+__global__ __launch_bounds__(256) void ntt_strided_kernel(u64 *__restrict__ data,
+                                                          const NttPrime *__restrict__ primes, u32 L,
+                                                          u32 log_n, u32 log_s, u64 total_threads, u32 lazy) {
+    strided_pass_body<A, K, VEC, INV, FINAL>(data, primes, L, log_n, log_s, (u64)blockIdx.x * blockDim.x + threadIdx.x,
+                                             total_threads, lazy);
+}
+
 // ------------------------------------------------------------------------------------------
 // block pass: a workgroup owns BPW contiguous blocks of B = 2^LOGB coefficients (BPW > 1 only
 // for B < 1024 so that a workgroup is at least one full wave).
@@ -135,13 +141,11 @@ __global__ __launch_bounds__(256) void ntt_strided_kernel(u64 *__restrict__ data
 #ifndef PFHE_BLOCK_WAVES_ATTR
 #define PFHE_BLOCK_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
-template <class A, int LOGB, bool INV, bool MUL = false>
-__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) PFHE_BLOCK_WAVES_ATTR void ntt_block_kernel(
-    u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L, u32 log_n, u64 total_blocks, u32 lazy,
-    const u64 *__restrict__ mul, u64 mul_polys) {
+template <class A, int LOGB, bool INV, bool MUL>
+__device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L,
+                                                u32 log_n, u64 total_blocks, u32 lazy, const u64 *__restrict__ mul,
+                                                u64 mul_polys, u64 *__restrict__ lds_raw) {
     using Cfg = BlockCfg<LOGB>;
-    extern __shared__ __attribute__((aligned(16))) u64 lds_raw[];
-
     const u32 tid = threadIdx.x;
     const u32 sub = Cfg::BPW == 1 ? 0u : tid / Cfg::TPB;
     const u32 lt = Cfg::BPW == 1 ? tid : tid % Cfg::TPB;
@@ -192,6 +196,15 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) PFHE_BLOCK_WAVES_ATTR void
     __syncthreads();
     lds_get_vectors<LOGB>(io, lds, lt);
     if (valid) store_block_vectors<LOGB>(io, gptr, lt);
+}
+
+
+template <class A, int LOGB, bool INV, bool MUL = false>
+__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) PFHE_BLOCK_WAVES_ATTR void ntt_block_kernel(
+    u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L, u32 log_n, u64 total_blocks, u32 lazy,
+    const u64 *__restrict__ mul, u64 mul_polys) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds_raw[];
+    block_pass_body<A, LOGB, INV, MUL>(data, primes, L, log_n, total_blocks, lazy, mul, mul_polys, lds_raw);
 }
 
 // ------------------------------------------------------------------------------------------
