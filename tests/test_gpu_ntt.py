@@ -491,3 +491,32 @@ def test_largest_degrees(pf, orc, log_n, q):
     assert np.array_equal(to_host(d), ref)
     t.inverse_transform_dev(d)
     assert np.array_equal(to_host(d), a)
+
+
+def test_handles_release_their_device_memory(pf):
+    """Creating and destroying tables, bases, converters and external-product plans does not leak HBM."""
+    import gc
+    import torch
+
+    def cycle():
+        t = pf.U64DcrtTable(12, Q61)
+        base = pf.RNSBase(Q61)
+        basis = pf.BigUintApproxSignedBasis(base, 30)
+        ctx = pf.DcrtGlevContext(t, base, basis, 1, 4)
+        conv = pf.BaseConverter(base, pf.RNSBase(Q61[:2]))
+        t32 = pf.U32DcrtTable(12, [132120577, 536813569])
+        x = torch.zeros(3 << 12, dtype=torch.int64, device="cuda")
+        t.transform_dev(x)
+        del ctx, conv, basis, base, t, t32, x
+
+    cycle()
+    gc.collect()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(50):
+        cycle()
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 50 create/destroy cycles"
