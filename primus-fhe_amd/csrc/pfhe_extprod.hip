@@ -21,10 +21,12 @@ namespace pfhe {
 namespace {
 
 // modular multiply-accumulate policies matching the NTT arithmetic policies
+// acc + d*k without folding: a product term is < 1.5 * 2^K (K <= 61), so an accumulator folded below
+// 2^K + 2^(K-9) can take FOUR terms before it must be folded again (1.002 + 4 * 1.5 = 7.002 < 8 = 2^64 / 2^61)
 __device__ __forceinline__ u64 mac(const PmArith &ar, u64 acc, u64 d, u64 k) {
-    // acc < 2^K + 2^(K-9), product term < 1.5 * 2^K  =>  sum < 2^63, folded back below 2^K + 2^(K-9)
-    return ar.reduce_x(acc + ar.mul_lazy(d, PmArith::Tw{k}));
+    return acc + ar.mul_lazy(d, PmArith::Tw{k});
 }
+constexpr u32 kPmMacFoldEvery = 4;
 
 struct BarrettMac {
     u64 q, lo, hi;
@@ -96,6 +98,10 @@ __global__ __launch_bounds__(256, PFHE_MULACC_MIN_WG) void gadget_block_mulacc_k
                 if constexpr (std::is_same<A, PmArith>::value) {
                     acc[c][j].x = mac(ar, acc[c][j].x, io[j].x, kv[j].x);
                     acc[c][j].y = mac(ar, acc[c][j].y, io[j].y, kv[j].y);
+                    if ((ij % kPmMacFoldEvery) == kPmMacFoldEvery - 1) {
+                        acc[c][j].x = ar.reduce_x(acc[c][j].x);
+                        acc[c][j].y = ar.reduce_x(acc[c][j].y);
+                    }
                 } else {
                     // the lazy transform leaves digit_hat in [0,4q): Barrett takes any product < q*2^64
                     const BarrettMac m{P->q, P->bar_lo, P->bar_hi};
@@ -109,9 +115,9 @@ __global__ __launch_bounds__(256, PFHE_MULACC_MIN_WG) void gadget_block_mulacc_k
     for (int c = 0; c < NC; ++c) {
         if constexpr (std::is_same<A, PmArith>::value) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {  // [0, 2^K + 2^(K-9)) -> canonical
-                acc[c][j].x = csub(acc[c][j].x, ar.q);
-                acc[c][j].y = csub(acc[c][j].y, ar.q);
+            for (int j = 0; j < 8; ++j) {  // fold the pending terms, then [0, 2^K + 2^(K-9)) -> canonical
+                acc[c][j].x = csub(ar.reduce_x(acc[c][j].x), ar.q);
+                acc[c][j].y = csub(ar.reduce_x(acc[c][j].y), ar.q);
             }
         }
         store_block_vectors<LOGB>(acc[c], out + (u64)c * W, lt);
