@@ -73,8 +73,11 @@ int plan_check(const pfhe_extprod_plan *p) {
 // one row of the product: acc[e] += glev[e or shared] (x) crt_poly[e]   (glwe/dcrt.rs:178-255)
 // rows == k+1 without `accumulate` gives CrtGlwe::mul_dcrt_ggsw_to (glwe/crt.rs:200-227).
 // Chunks of ciphertexts are software-pipelined over the plan's two streams and two digit buffers.
+// `into_coeff`: the caller wants coefficient-form output; *coeff_done reports whether this function already
+// produced it (small-ring kernel) or the caller still has to run the inverse transform.
 int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 *keys, bool keys_shared, u64 *result,
-                u64 batch, bool accumulate, hipStream_t s) {
+                u64 batch, bool accumulate, hipStream_t s, bool into_coeff = false, bool *coeff_done = nullptr) {
+    if (coeff_done) *coeff_done = false;
     const TableSet &t = *p->table;
     const u64 W = (u64)t.L * t.n;
     const u32 ell = p->basis.ell;
@@ -82,6 +85,20 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
     // a single chunk has nothing to pipeline: run it on the caller's stream without the fork/join events
     // (latency of small batches; also taken, chunk after chunk, while the caller captures a HIP graph); the fused block+multiply-accumulate kernel launches one workgroup per
     // (ciphertext, limb, block), so it only pays once that fills the chip
+    // small rings: digit extraction + ONE kernel for everything else, chunk by chunk on the caller's stream
+    // (one workgroup per (ciphertext, limb) runs 12+ transforms back to back: it needs a batch that fills the chip)
+    if (p->sdigits != nullptr && extprod_small_supported(t.log_n, p->k, p->rns.value_len, p->basis.log_basis) &&
+        batch * t.L >= 1024 && std::getenv("PFHE_DISABLE_SMALL_EXTPROD") == nullptr) {
+        for (u64 done = 0; done < batch; done += p->chunk) {
+            const u64 cur = std::min<u64>(p->chunk, batch - done);
+            PFHE_TRY(gadget_signed_digits_dev(p->rns, p->basis, t.log_n, crt_polys + done * rows * W, p->sdigits, cur * rows, s));
+            PFHE_TRY(extprod_small_dev(t.primes_dev, t.L, t.log_n, t.pm, p->k, rows, ell, p->sdigits,
+                                       keys + (keys_shared ? 0 : done * key_words), keys_shared,
+                                       result + done * (p->k + 1) * W, cur, accumulate, into_coeff, s));
+        }
+        if (coeff_done) *coeff_done = into_coeff;
+        return PFHE_OK;
+    }
     const bool single = batch <= p->chunk || stream_is_capturing(s);
     hipStream_t sa = single ? s : p->sa, sb = single ? s : p->sb;
     const bool fused = gadget_fused_supported(t.log_n, p->k) && std::getenv("PFHE_DISABLE_FUSED_EXTPROD") == nullptr &&
@@ -384,7 +401,14 @@ int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *rns, const 
     p->rns = rns->h.dev;
     p->basis = basis->h.dev;
     p->k = (u32)glwe_dimension;
-    p->chunk = chunk ? chunk : 64;  // measured best at N = 2^16 (16: 26.5 ms, 32: 25.7, 64: 24.7, 128: 24.8 per 1024 products)
+    // default: about 1 GiB of digit polynomials per buffer, at least 64 ciphertexts — 64 is the measured
+    // optimum at N = 2^16, 3 limbs (16: 26.5 ms, 32: 25.7, 64: 24.7, 128: 24.8 per 1024 products); small
+    // rings need many more ciphertexts per launch to amortise the launches
+    if (chunk == 0) {
+        const size_t per_ct = (size_t)(glwe_dimension + 1) * p->basis.ell * t->L * t->n * sizeof(u64);
+        chunk = std::max<size_t>(64, std::min<size_t>(65536, ((size_t)1 << 30) / per_ct));
+    }
+    p->chunk = chunk;
     p->digits_words = p->chunk * (p->k + 1) * p->basis.ell * t->L * t->n;
     DeviceGuard g(t->device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
@@ -395,8 +419,9 @@ int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *rns, const 
         PFHE_HIP(hipEventCreateWithFlags(&p->produced[i], hipEventDisableTiming));
         PFHE_HIP(hipEventCreateWithFlags(&p->consumed[i], hipEventDisableTiming));
     }
-    if (gadget_split_decompose_supported(t->log_n, p->rns.value_len, p->basis.log_basis) &&
-        std::getenv("PFHE_DISABLE_SPLIT_DECOMPOSE") == nullptr) {
+    if ((gadget_split_decompose_supported(t->log_n, p->rns.value_len, p->basis.log_basis) &&
+         std::getenv("PFHE_DISABLE_SPLIT_DECOMPOSE") == nullptr) ||
+        extprod_small_supported(t->log_n, p->k, p->rns.value_len, p->basis.log_basis)) {
         void *d = nullptr;
         PFHE_HIP(hipMalloc(&d, p->chunk * (p->k + 1) * p->basis.ell * t->n * sizeof(int)));
         p->sdigits = (int *)d;
@@ -440,9 +465,10 @@ int pfhe_extprod_mul_dcrt_ggsw_to_dev(pfhe_extprod_plan *plan, const uint64_t *c
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
     const bool shared = len_ggsw == ggsw && batch > 1 ? true : (len_ggsw == ggsw);
     // result.set_zero() (glwe/crt.rs:217) is implied: the first accumulation overwrites
+    bool coeff_done = false;
     PFHE_TRY(run_product(plan, (const u64 *)crt_glwe_dev, plan->k + 1, (const u64 *)dcrt_ggsw_dev, shared,
-                         (u64 *)result_dev, batch, false, (hipStream_t)stream));
-    if (into_coeff_form)  // DcrtGlwe::into_coeff_form, macros/mod.rs:901-911
+                         (u64 *)result_dev, batch, false, (hipStream_t)stream, into_coeff_form != 0, &coeff_done));
+    if (into_coeff_form && !coeff_done)  // DcrtGlwe::into_coeff_form, macros/mod.rs:901-911
         PFHE_TRY(ntt_inverse_dev(t.primes_dev, t.L, t.log_n, t.pm, (u64 *)result_dev, batch * (plan->k + 1) * t.L, false,
                                  (hipStream_t)stream));
     return PFHE_OK;

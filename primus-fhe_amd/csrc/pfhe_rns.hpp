@@ -80,6 +80,15 @@ int gadget_block_mulacc_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u
                             const u64 *ggsw, bool ggsw_shared, u64 *result, u64 batch, bool accumulate,
                             hipStream_t s);
 
+// Small rings (N = 2^10..2^12): digit extraction to int32 + ONE kernel for transforms, multiply-accumulate and
+// (optionally) the inverse transforms (pfhe_extprod.hip, extprod_small_kernel).
+bool extprod_small_supported(u32 log_n, u32 k, u32 value_len, u32 log_basis);
+int gadget_signed_digits_dev(const RnsDev &r, const BasisDev &b, u32 log_n, const u64 *crt_polys, int *sdigits,
+                             u64 npolys, hipStream_t s);
+int extprod_small_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u32 k, u32 rows, u32 ell, const int *sdigits,
+                      const u64 *ggsw, bool ggsw_shared, u64 *result, u64 batch, bool accumulate, bool into_coeff,
+                      hipStream_t s);
+
 }  // namespace pfhe
 
 // handle behind the C ABI's `pfhe_rns` (shared by pfhe_capi_rns.hip and pfhe_convert.hip)

@@ -277,3 +277,52 @@ def test_config4_full_batch_properties(pf, orc):
     pf.mul_dcrt_ggsw_to_dev(glwe, ggsw, coeff, ctx, into_coeff_form=True)
     table.inverse_transform_dev(out)
     assert torch.equal(coeff, out)
+
+
+@pytest.mark.parametrize("log_n,moduli,log_basis", [(10, Q61[:1], 10), (11, Q61[:2], 20), (10, [1125899906826241, 562949953392641], 13)])
+def test_small_ring_fused_path(pf, orc, log_n, moduli, log_basis):
+    """N = 2^10 / 2^11, k = 1, batches that fill the chip take the single-kernel path (digits -> transforms ->
+    multiply-accumulate -> inverse transforms on chip): equal to the separate kernels on the whole batch and to
+    the oracle on sampled ciphertexts, for NTT-form and coefficient-form output and for the accumulating row API."""
+    import os
+    import torch
+    k, batch = 1, 1100
+    n, L = 1 << log_n, len(moduli)
+    W = (k + 1) * L * n
+    rng = np.random.default_rng(log_n + L)
+    ot, ob = orc.U64DcrtTable(log_n, moduli), orc.RNSBase(moduli)
+    obasis = orc.BigUintApproxSignedBasis(ob, log_basis)
+    ell = obasis.decompose_length
+    t, base = pf.U64DcrtTable(log_n, moduli), pf.RNSBase(moduli)
+    ctx = pf.DcrtGlevContext(t, base, pf.BigUintApproxSignedBasis(base, log_basis), k)
+    glwe = rand_rns(rng, moduli, n, batch * (k + 1))
+    ggsw = rand_rns(rng, moduli, n, (k + 1) * ell * (k + 1))
+    dg, dk = to_dev(glwe), to_dev(ggsw)
+    outs = {}
+    for coeff in (False, True):
+        fused = torch.zeros_like(dg)
+        pf.mul_dcrt_ggsw_to_dev(dg, dk, fused, ctx, into_coeff_form=coeff)
+        os.environ["PFHE_DISABLE_SMALL_EXTPROD"] = "1"
+        try:
+            plain = torch.zeros_like(dg)
+            pf.mul_dcrt_ggsw_to_dev(dg, dk, plain, ctx, into_coeff_form=coeff)
+        finally:
+            del os.environ["PFHE_DISABLE_SMALL_EXTPROD"]
+        assert torch.equal(fused, plain)
+        outs[coeff] = to_host(fused)
+    for e in (0, 517, batch - 1):
+        exp = orc.mul_dcrt_ggsw_to(ot, ob, obasis, k, glwe[e * W:(e + 1) * W].copy(), ggsw)
+        assert np.array_equal(outs[False][e * W:(e + 1) * W], exp)
+        ot.inverse_transform_slice(exp)
+        assert np.array_equal(outs[True][e * W:(e + 1) * W], exp)
+    # accumulating single-row API (glwe/dcrt.rs:178-255) through the same kernel
+    acc = rand_rns(rng, moduli, n, batch * (k + 1))
+    glev = rand_rns(rng, moduli, n, ell * (k + 1))
+    poly = rand_rns(rng, moduli, n, batch)
+    dacc = to_dev(acc)
+    pf.add_dcrt_glev_mul_crt_poly_assign_dev(dacc, to_dev(glev), to_dev(poly), ctx)
+    got = to_host(dacc)
+    for e in (0, 733):
+        a = acc[e * W:(e + 1) * W].copy()
+        orc.add_dcrt_glev_mul_crt_poly_assign(ot, ob, obasis, k, a, glev, poly[e * L * n:(e + 1) * L * n].copy())
+        assert np.array_equal(got[e * W:(e + 1) * W], a)
