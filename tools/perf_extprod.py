@@ -40,5 +40,5 @@ for coeff in (False, True):
         p.mul_dcrt_ggsw_to_dev(glwe, ggsw, out, ctx, into_coeff_form=coeff)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    print(f"fused={'0' if os.environ.get('PFHE_DISABLE_FUSED_EXTPROD') else '1'} chunk={chunk or 64} batch={batch} "
+    print(f"fused={'0' if os.environ.get('PFHE_DISABLE_FUSED_EXTPROD') else '1'} chunk={chunk or 'default'} batch={batch} "
           f"coeff_form={coeff}: {dt * 1e3:.2f} ms -> {batch / dt:.0f} ext-products/s ({dt / batch * 1e6:.1f} us each)")
