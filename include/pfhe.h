@@ -52,7 +52,8 @@ typedef enum pfhe_status {
     PFHE_ERR_BAD_ARGUMENT = 33,
     PFHE_ERR_NO_DEVICE = 34,
     PFHE_ERR_HIP = 35,
-    PFHE_ERR_UNSUPPORTED = 36
+    PFHE_ERR_UNSUPPORTED = 36,
+    PFHE_ERR_NO_INVERSE = 37 /* ReduceError::NoInverse: an element of an inversion is not a unit */
 } pfhe_status;
 
 const char *pfhe_status_string(int status);
@@ -219,6 +220,37 @@ int pfhe_dcrt_butterfly_mul_factor_to_dev(const pfhe_dcrt *table, uint64_t *a_de
 int pfhe_dcrt_mul_dcrt_polynomial_dev(const pfhe_dcrt *table, uint64_t *crt_poly_dev,
                                       size_t len, const uint64_t *dcrt_poly_dev, size_t len_b,
                                       void *stream);
+
+/* ---- element-wise family on canonical residues (coefficient or NTT form alike) ----
+ * CrtPolynomial / DcrtPolynomial: add, sub, neg (primus_poly/src/{crt,dcrt}/{add,sub,neg}.rs), mul_scalar,
+ * add_mul_scalar, mul_factor, add_mul_factor, mul_monomial (crt/mul.rs:16-180, dcrt/mul.rs:78-300), inv
+ * (dcrt/inv.rs:19-68); CrtGlwe::{add,sub}_element_wise{,_assign,_to} (primus_lattice/src/macros/mod.rs:367-531),
+ * CrtGlwe::mul_scalar_{assign,to}, mul_factor_to, mul_monic_monomial_assign (glwe/crt.rs:59-175) — a GLWE is k+1
+ * consecutive RNS polynomials, so the same entry points serve both.
+ * `len` = total words, a multiple of L*N; every buffer holds `len` words; `out` may alias `a` (the *_assign
+ * forms) and, for sub, `b` (sub_rev_assign, crt/sub.rs:69).  Inputs must be canonical ([0, q_r)), as in the
+ * reference.  `scalars`: L residues on the host; `factors`: L ShoupFactor (value, quotient) pairs on the host. */
+int pfhe_dcrt_add_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, const uint64_t *b_dev, uint64_t *out_dev,
+                         size_t len, void *stream);
+int pfhe_dcrt_sub_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, const uint64_t *b_dev, uint64_t *out_dev,
+                         size_t len, void *stream);
+int pfhe_dcrt_neg_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, uint64_t *out_dev, size_t len, void *stream);
+int pfhe_dcrt_mul_scalar_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, const uint64_t *scalars,
+                                uint64_t *out_dev, size_t len, void *stream);
+int pfhe_dcrt_add_mul_scalar_assign_dev(const pfhe_dcrt *table, uint64_t *acc_dev, const uint64_t *rhs_dev,
+                                        const uint64_t *scalars, size_t len, void *stream);
+int pfhe_dcrt_mul_factor_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, const uint64_t *factors,
+                                uint64_t *out_dev, size_t len, void *stream);
+int pfhe_dcrt_add_mul_factor_assign_dev(const pfhe_dcrt *table, uint64_t *acc_dev, const uint64_t *rhs_dev,
+                                        const uint64_t *factors, size_t len, void *stream);
+/* self * X^r, 0 <= r < 2N, per N-word polynomial (rotate_right + negation of the wrapped part).  The _to form
+ * needs out != a and moves each word once; the in-place form goes through a stream-ordered scratch tile. */
+int pfhe_dcrt_mul_monomial_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, size_t r, uint64_t *out_dev,
+                                  size_t len, void *stream);
+int pfhe_dcrt_mul_monomial_assign_dev(const pfhe_dcrt *table, uint64_t *data_dev, size_t r, size_t len, void *stream);
+/* Point-wise inverse.  The reference panics on a non-invertible element; this call synchronises the stream and
+ * returns PFHE_ERR_NO_INVERSE (outputs unspecified).  Not capturable into a HIP graph. */
+int pfhe_dcrt_inv_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, uint64_t *out_dev, size_t len, void *stream);
 
 /* =====================================================================================
  * RNSBase<u64, BarrettModulus<u64>> — primus_rns/src/base.rs:26

@@ -117,6 +117,16 @@ def _load(path: str | None = None) -> C.CDLL:
     sig("orc_dcrt_poly_mul_assign", None, vp, _u64p, _u64p)
     sig("orc_dcrt_poly_add_mul_assign", None, vp, _u64p, _u64p, _u64p)
     sig("orc_naive_negacyclic_mul", None, u64, _u64p, _u64p, _u64p, sz)
+    sig("orc_reduce_neg", u64, u64, u64)
+    sig("orc_crt_poly_add_to", None, _u64p, sz, sz, _u64p, _u64p, _u64p)
+    sig("orc_crt_poly_sub_to", None, _u64p, sz, sz, _u64p, _u64p, _u64p)
+    sig("orc_crt_poly_neg_to", None, _u64p, sz, sz, _u64p, _u64p)
+    sig("orc_crt_poly_mul_scalar_to", ci, _u64p, sz, sz, _u64p, _u64p, _u64p)
+    sig("orc_crt_poly_add_mul_scalar_assign", ci, _u64p, sz, sz, _u64p, _u64p, _u64p)
+    sig("orc_crt_poly_mul_factor_to", None, _u64p, sz, sz, _u64p, _u64p, _u64p)
+    sig("orc_crt_poly_add_mul_factor_assign", None, _u64p, sz, sz, _u64p, _u64p, _u64p)
+    sig("orc_crt_poly_mul_monomial_assign", ci, _u64p, sz, sz, _u64p, sz)
+    sig("orc_dcrt_poly_inv_to", ci, _u64p, sz, sz, _u64p, _u64p)
     sig("orc_dcrt_poly_butterfly_mul_factor_to", None, vp, _u64p, _u64p, _u64p, _u64p)
     sig("orc_dcrt_poly_butterfly_mul_to", None, vp, _u64p, _u64p, _u64p, _u64p)
 
@@ -476,6 +486,77 @@ class U64DcrtTable:
         b = np.empty_like(a)
         lib().orc_dcrt_poly_butterfly_mul_to(self._h, _p(a), _p(s), _p(w), _p(b))
         return b
+
+
+class CrtPolyOps:
+    """The element-wise family of primus_poly's CrtPolynomial / DcrtPolynomial (crt/{add,sub,neg,mul}.rs,
+    dcrt/inv.rs) over a batch of RNS polynomials (L limbs x n words each, modulus-major); CrtGlwe's
+    add_element_wise* / mul_scalar_* / mul_factor_to / mul_monic_monomial_assign are the same loops."""
+
+    def __init__(self, moduli, n: int):
+        self.moduli = np.ascontiguousarray(np.array([int(m) for m in moduli], dtype=np.uint64))
+        self.L, self.n = self.moduli.size, int(n)
+        self.unit = self.L * self.n
+
+    def _each(self, *arrays):
+        count = arrays[0].size // self.unit
+        assert all(a.size == count * self.unit for a in arrays)
+        for e in range(count):
+            yield [a[e * self.unit:(e + 1) * self.unit] for a in arrays]
+
+    def _binary(self, fn, a, b):
+        out = np.empty_like(a)
+        for x, y, o in self._each(a, b, out):
+            fn(_p(self.moduli), self.L, self.n, _p(x), _p(y), _p(o))
+        return out
+
+    def add_to(self, a, b): return self._binary(lib().orc_crt_poly_add_to, a, b)
+    def sub_to(self, a, b): return self._binary(lib().orc_crt_poly_sub_to, a, b)
+
+    def neg_to(self, a):
+        out = np.empty_like(a)
+        for x, o in self._each(a, out):
+            lib().orc_crt_poly_neg_to(_p(self.moduli), self.L, self.n, _p(x), _p(o))
+        return out
+
+    def _words(self, values, per_limb):
+        arr = np.ascontiguousarray(np.array(values, dtype=np.uint64).reshape(-1))
+        assert arr.size == per_limb * self.L
+        return arr
+
+    def mul_scalar_to(self, a, scalars):
+        sc, out = self._words(scalars, 1), np.empty_like(a)
+        for x, o in self._each(a, out):
+            assert lib().orc_crt_poly_mul_scalar_to(_p(self.moduli), self.L, self.n, _p(x), _p(sc), _p(o)) == 0
+        return out
+
+    def add_mul_scalar_assign(self, acc, rhs, scalars):
+        sc = self._words(scalars, 1)
+        for c, r in self._each(acc, rhs):
+            assert lib().orc_crt_poly_add_mul_scalar_assign(_p(self.moduli), self.L, self.n, _p(c), _p(r), _p(sc)) == 0
+
+    def mul_factor_to(self, a, factors):
+        f, out = self._words(factors, 2), np.empty_like(a)
+        for x, o in self._each(a, out):
+            lib().orc_crt_poly_mul_factor_to(_p(self.moduli), self.L, self.n, _p(x), _p(f), _p(o))
+        return out
+
+    def add_mul_factor_assign(self, acc, rhs, factors):
+        f = self._words(factors, 2)
+        for c, r in self._each(acc, rhs):
+            lib().orc_crt_poly_add_mul_factor_assign(_p(self.moduli), self.L, self.n, _p(c), _p(r), _p(f))
+
+    def mul_monomial_assign(self, data, r: int):
+        for (x,) in self._each(data):
+            if lib().orc_crt_poly_mul_monomial_assign(_p(self.moduli), self.L, self.n, _p(x), r):
+                raise ValueError("monomial degree must be below 2N")
+
+    def inv_to(self, a):
+        out = np.empty_like(a)
+        for x, o in self._each(a, out):
+            if lib().orc_dcrt_poly_inv_to(_p(self.moduli), self.L, self.n, _p(x), _p(o)):
+                raise ZeroDivisionError("element has no inverse")  # the reference panics
+        return out
 
 
 def naive_negacyclic_mul(q, a, b):

@@ -862,6 +862,130 @@ void orc_dcrt_poly_butterfly_mul_to(const orc_dcrt *t, uint64_t *a, const uint64
     }
 }
 
+/* ---------------- CrtPolynomial / DcrtPolynomial element-wise family ------------------------------
+ * One RNS polynomial (L limbs of n words, modulus-major) per call; a CrtGlwe is k+1 of them and its
+ * add_element_wise* / mul_scalar_* / mul_factor_to / mul_monic_monomial_assign loop the same per-limb
+ * slice operations (primus_lattice/src/macros/mod.rs:367-531, glwe/crt.rs:59-175). */
+
+/* primus_modulus/src/common/uint/primitive.rs:19-25 */
+uint64_t orc_reduce_neg(uint64_t q, uint64_t v) { return v == 0 ? 0 : q - v; }
+
+/* crt/add.rs:51-70 -> reduce_add_slice_to */
+void orc_crt_poly_add_to(const uint64_t *moduli, size_t L, size_t n, const uint64_t *a, const uint64_t *b,
+                         uint64_t *out) {
+    for (size_t i = 0; i < L; ++i)
+        for (size_t j = 0; j < n; ++j) out[i * n + j] = orc_reduce_add(moduli[i], a[i * n + j], b[i * n + j]);
+}
+
+/* crt/sub.rs:47-66 -> reduce_sub_slice_to (sub_rev_assign, :69-82, is the same with out = b) */
+void orc_crt_poly_sub_to(const uint64_t *moduli, size_t L, size_t n, const uint64_t *a, const uint64_t *b,
+                         uint64_t *out) {
+    for (size_t i = 0; i < L; ++i)
+        for (size_t j = 0; j < n; ++j) out[i * n + j] = orc_reduce_sub(moduli[i], a[i * n + j], b[i * n + j]);
+}
+
+/* crt/neg.rs:42-53 -> reduce_neg_slice_to */
+void orc_crt_poly_neg_to(const uint64_t *moduli, size_t L, size_t n, const uint64_t *a, uint64_t *out) {
+    for (size_t i = 0; i < L; ++i)
+        for (size_t j = 0; j < n; ++j) out[i * n + j] = orc_reduce_neg(moduli[i], a[i * n + j]);
+}
+
+/* crt/mul.rs:138-158 -> reduce_mul_scalar_slice_to (compact/slice.rs:145-153): BarrettModulus::reduce_mul */
+int orc_crt_poly_mul_scalar_to(const uint64_t *moduli, size_t L, size_t n, const uint64_t *a,
+                               const uint64_t *scalars, uint64_t *out) {
+    for (size_t i = 0; i < L; ++i) {
+        orc_barrett m;
+        if (orc_barrett_new(moduli[i], &m)) return 1;
+        for (size_t j = 0; j < n; ++j) out[i * n + j] = orc_barrett_mul(&m, a[i * n + j], scalars[i]);
+    }
+    return 0;
+}
+
+/* crt/mul.rs:57-77 -> reduce_add_mul_scalar_slice_assign (compact/slice.rs:277-286):
+ * acc = reduce_mul_add(a, scalar, acc) */
+int orc_crt_poly_add_mul_scalar_assign(const uint64_t *moduli, size_t L, size_t n, uint64_t *acc,
+                                       const uint64_t *rhs, const uint64_t *scalars) {
+    for (size_t i = 0; i < L; ++i) {
+        orc_barrett m;
+        if (orc_barrett_new(moduli[i], &m)) return 1;
+        for (size_t j = 0; j < n; ++j)
+            acc[i * n + j] = orc_barrett_mul_add(&m, rhs[i * n + j], scalars[i], acc[i * n + j]);
+    }
+    return 0;
+}
+
+/* crt/mul.rs:161-180 -> factor_mul_slice_to (primus_factor/src/common/slice.rs:49-58): factor_mul_modulo.
+ * `factors` = L (value, quotient) pairs. */
+void orc_crt_poly_mul_factor_to(const uint64_t *moduli, size_t L, size_t n, const uint64_t *a,
+                                const uint64_t *factors, uint64_t *out) {
+    for (size_t i = 0; i < L; ++i)
+        for (size_t j = 0; j < n; ++j)
+            out[i * n + j] = orc_shoup_mul(factors[2 * i], factors[2 * i + 1], a[i * n + j], moduli[i]);
+}
+
+/* crt/mul.rs:80-99 -> add_factor_mul_slice_assign (common/slice.rs:61-70): reduce_add(acc, factor * rhs) */
+void orc_crt_poly_add_mul_factor_assign(const uint64_t *moduli, size_t L, size_t n, uint64_t *acc,
+                                        const uint64_t *rhs, const uint64_t *factors) {
+    for (size_t i = 0; i < L; ++i)
+        for (size_t j = 0; j < n; ++j) {
+            const uint64_t prod = orc_shoup_mul(factors[2 * i], factors[2 * i + 1], rhs[i * n + j], moduli[i]);
+            const uint64_t sum = acc[i * n + j] + prod; /* common/slice.rs:7-12 */
+            acc[i * n + j] = sum - moduli[i] < sum ? sum - moduli[i] : sum;
+        }
+}
+
+static void rotate_right_words(uint64_t *poly, size_t n, size_t r, uint64_t *tmp) {
+    /* slice::rotate_right(r): element i moves to (i + r) mod n */
+    for (size_t i = 0; i < n; ++i) tmp[(i + r) % n] = poly[i];
+    memcpy(poly, tmp, n * sizeof(uint64_t));
+}
+
+/* crt/mul.rs:102-127 (= CrtGlwe::mul_monic_monomial_assign, glwe/crt.rs:76-113, per CRT polynomial):
+ * r < n: rotate_right(r), negate poly[0..r];  n <= r < 2n: rotate_right(r - n), negate poly[r - n..]. */
+int orc_crt_poly_mul_monomial_assign(const uint64_t *moduli, size_t L, size_t n, uint64_t *data, size_t r) {
+    if (r >= 2 * n) return 1;
+    uint64_t *tmp = (uint64_t *)malloc((n ? n : 1) * sizeof(uint64_t));
+    if (!tmp) return 1;
+    for (size_t i = 0; i < L; ++i) {
+        uint64_t *poly = data + i * n;
+        if (r < n) {
+            rotate_right_words(poly, n, r, tmp);
+            for (size_t j = 0; j < r; ++j) poly[j] = orc_reduce_neg(moduli[i], poly[j]);
+        } else {
+            const size_t rr = r - n;
+            rotate_right_words(poly, n, rr, tmp);
+            for (size_t j = rr; j < n; ++j) poly[j] = orc_reduce_neg(moduli[i], poly[j]);
+        }
+    }
+    free(tmp);
+    return 0;
+}
+
+/* dcrt/inv.rs:55-68 -> BarrettModulus::reduce_inv_slice_to (primus_modulus/src/barrett/slice.rs:535-557):
+ * Montgomery batch inversion over each limb polynomial, `out` as the prefix-product buffer.
+ * Returns 1 where the reference panics (total product not invertible). */
+int orc_dcrt_poly_inv_to(const uint64_t *moduli, size_t L, size_t n, const uint64_t *a, uint64_t *out) {
+    for (size_t i = 0; i < L; ++i) {
+        orc_barrett m;
+        if (orc_barrett_new(moduli[i], &m)) return 1;
+        const uint64_t *in = a + i * n;
+        uint64_t *o = out + i * n;
+        if (n == 0) continue;
+        uint64_t total = 1;
+        for (size_t j = 0; j < n; ++j) {
+            o[j] = total;
+            total = orc_barrett_mul(&m, total, in[j]);
+        }
+        uint64_t suffix = orc_inv_mod(total, moduli[i]);
+        if (suffix == 0) return 1;
+        for (size_t j = n; j-- > 0;) {
+            o[j] = orc_barrett_mul(&m, o[j], suffix);
+            suffix = orc_barrett_mul(&m, suffix, in[j]);
+        }
+    }
+    return 0;
+}
+
 /* primus_poly/src/poly/mul.rs:107-134 (output zeroed first: the reference accumulates into a
  * caller-zeroed buffer) */
 void orc_naive_negacyclic_mul(uint64_t q, const uint64_t *a, const uint64_t *b, uint64_t *c, size_t n) {

@@ -179,6 +179,26 @@ void orc_dcrt_poly_butterfly_mul_factor_to(const orc_dcrt *t, uint64_t *a, const
 void orc_dcrt_poly_butterfly_mul_to(const orc_dcrt *t, uint64_t *a, const uint64_t *s, const uint64_t *w,
                                     uint64_t *b);
 
+/* ---------------- CrtPolynomial / DcrtPolynomial element-wise family ----------------------
+ * (primus_poly/src/crt/{add,sub,neg,mul}.rs, dcrt/inv.rs; CrtGlwe loops the same slices).  One RNS
+ * polynomial of L limbs x n words per call; `factors` = L (value, quotient) pairs. */
+uint64_t orc_reduce_neg(uint64_t q, uint64_t v);
+void orc_crt_poly_add_to(const uint64_t *moduli, size_t L, size_t n, const uint64_t *a, const uint64_t *b,
+                         uint64_t *out);
+void orc_crt_poly_sub_to(const uint64_t *moduli, size_t L, size_t n, const uint64_t *a, const uint64_t *b,
+                         uint64_t *out);
+void orc_crt_poly_neg_to(const uint64_t *moduli, size_t L, size_t n, const uint64_t *a, uint64_t *out);
+int orc_crt_poly_mul_scalar_to(const uint64_t *moduli, size_t L, size_t n, const uint64_t *a,
+                               const uint64_t *scalars, uint64_t *out);
+int orc_crt_poly_add_mul_scalar_assign(const uint64_t *moduli, size_t L, size_t n, uint64_t *acc,
+                                       const uint64_t *rhs, const uint64_t *scalars);
+void orc_crt_poly_mul_factor_to(const uint64_t *moduli, size_t L, size_t n, const uint64_t *a,
+                                const uint64_t *factors, uint64_t *out);
+void orc_crt_poly_add_mul_factor_assign(const uint64_t *moduli, size_t L, size_t n, uint64_t *acc,
+                                        const uint64_t *rhs, const uint64_t *factors);
+int orc_crt_poly_mul_monomial_assign(const uint64_t *moduli, size_t L, size_t n, uint64_t *data, size_t r);
+int orc_dcrt_poly_inv_to(const uint64_t *moduli, size_t L, size_t n, const uint64_t *a, uint64_t *out);
+
 /* ---------------- schoolbook negacyclic product (primus_poly/src/poly/mul.rs:107-134) --- */
 void orc_naive_negacyclic_mul(uint64_t q, const uint64_t *a, const uint64_t *b, uint64_t *out,
                               size_t n);

@@ -14,7 +14,7 @@ u64p = C.POINTER(C.c_uint64)
 STATUS = {
     0: "OK", 1: "NoPrimitiveRoot", 2: "DegreeConversionErr", 3: "DegreeTooLarge", 4: "NttTableErr",
     5: "ModulusTooLarge", 16: "EmptyBase", 17: "CoPrimeError", 18: "UnrepresentableModulus",
-    32: "BadLength", 33: "BadArgument", 34: "NoDevice", 35: "HipError", 36: "Unsupported",
+    32: "BadLength", 33: "BadArgument", 34: "NoDevice", 35: "HipError", 36: "Unsupported", 37: "NoInverse",
 }
 
 
@@ -97,6 +97,16 @@ def _declare(lib: C.CDLL) -> None:
     sig("pfhe_dcrt_add_mul_assign_dev", ci, vp, vp, vp, sz, vp, sz, vp)
     sig("pfhe_dcrt_mul_dcrt_polynomial_dev", ci, vp, vp, sz, vp, sz, vp)
     sig("pfhe_dcrt_butterfly_mul_dcrt_polynomial_to_dev", ci, vp, vp, vp, sz, vp, sz, vp, vp)
+    sig("pfhe_dcrt_add_to_dev", ci, vp, vp, vp, vp, sz, vp)
+    sig("pfhe_dcrt_sub_to_dev", ci, vp, vp, vp, vp, sz, vp)
+    sig("pfhe_dcrt_neg_to_dev", ci, vp, vp, vp, sz, vp)
+    sig("pfhe_dcrt_mul_scalar_to_dev", ci, vp, vp, u64p, vp, sz, vp)
+    sig("pfhe_dcrt_add_mul_scalar_assign_dev", ci, vp, vp, vp, u64p, sz, vp)
+    sig("pfhe_dcrt_mul_factor_to_dev", ci, vp, vp, u64p, vp, sz, vp)
+    sig("pfhe_dcrt_add_mul_factor_assign_dev", ci, vp, vp, vp, u64p, sz, vp)
+    sig("pfhe_dcrt_mul_monomial_to_dev", ci, vp, vp, sz, vp, sz, vp)
+    sig("pfhe_dcrt_mul_monomial_assign_dev", ci, vp, vp, sz, sz, vp)
+    sig("pfhe_dcrt_inv_to_dev", ci, vp, vp, vp, sz, vp)
     sig("pfhe_dcrt_butterfly_mul_factor_to_dev", ci, vp, vp, vp, sz, vp, sz, vp, vp)
     u8p = C.POINTER(C.c_uint8)
     sig("pfhe_rns_create", ci, u64p, sz, ci, C.POINTER(vp))

@@ -306,6 +306,7 @@ const char *pfhe_status_string(int status) {
         case PFHE_ERR_NO_DEVICE: return "no usable HIP device";
         case PFHE_ERR_HIP: return "HIP runtime error";
         case PFHE_ERR_UNSUPPORTED: return "unsupported parameter";
+        case PFHE_ERR_NO_INVERSE: return "element has no inverse";
     }
     return "unknown status";
 }

@@ -211,6 +211,86 @@ class U64DcrtTable:
         check(lib().pfhe_dcrt_add_dcrt_glwe_mul_dcrt_polynomial_assign_dev(self._h, pc, pa, na, pb, nb, glwe_polys,
                                                                            _stream(stream)))
 
+    def fill_uniform_dev(self, dst, seed: int, stream=None):
+        """Synthetic residues (bench / test input): uniform in [0, q_limb) from SplitMix64(seed)."""
+        p, n = _dev(dst)
+        mods = np.array(self.moduli(), np.uint64)
+        check(lib().pfhe_fill_uniform_dev(self.device(), p, n, mods.ctypes.data_as(u64p), mods.size, self.poly_length(),
+                                          seed, _stream(stream)))
+
+    # ---- element-wise family on canonical residues (CrtPolynomial / DcrtPolynomial / CrtGlwe) ----
+    def _same_len(self, *bufs):
+        ptrs = [_dev(b) for b in bufs]
+        if any(n != ptrs[0][1] for _, n in ptrs):
+            raise PfheError(32, "operands differ in length")
+        return [p for p, _ in ptrs], ptrs[0][1]
+
+    def _host_words(self, values, per_limb: int):
+        arr = np.ascontiguousarray(np.array(values, dtype=np.uint64).reshape(-1))
+        if arr.size != per_limb * self.moduli_count():
+            raise PfheError(32, "expected one entry per modulus")
+        return arr
+
+    def add_to_dev(self, a, b, out, stream=None):
+        """CrtPolynomial::add_to / add_assign (primus_poly/src/crt/add.rs:28-70); CrtGlwe::add_element_wise_to
+        (primus_lattice/src/macros/mod.rs:472-500).  out may alias a."""
+        (pa, pb, po), n = self._same_len(a, b, out)
+        check(lib().pfhe_dcrt_add_to_dev(self._h, pa, pb, po, n, _stream(stream)))
+
+    def sub_to_dev(self, a, b, out, stream=None):
+        """CrtPolynomial::sub_to / sub_assign / sub_rev_assign (crt/sub.rs:26-82): out = a - b; out may alias
+        a (sub_assign) or b (sub_rev_assign)."""
+        (pa, pb, po), n = self._same_len(a, b, out)
+        check(lib().pfhe_dcrt_sub_to_dev(self._h, pa, pb, po, n, _stream(stream)))
+
+    def neg_to_dev(self, a, out, stream=None):
+        """CrtPolynomial::neg_to / neg_assign (crt/neg.rs:25-53)."""
+        (pa, po), n = self._same_len(a, out)
+        check(lib().pfhe_dcrt_neg_to_dev(self._h, pa, po, n, _stream(stream)))
+
+    def mul_scalar_to_dev(self, a, scalars, out, stream=None):
+        """CrtPolynomial::mul_scalar_to / mul_scalar_assign (crt/mul.rs:26-34,138-158); CrtGlwe::mul_scalar_to
+        (glwe/crt.rs:132-150): per-limb scalar residues."""
+        (pa, po), n = self._same_len(a, out)
+        sc = self._host_words(scalars, 1)
+        check(lib().pfhe_dcrt_mul_scalar_to_dev(self._h, pa, sc.ctypes.data_as(u64p), po, n, _stream(stream)))
+
+    def add_mul_scalar_assign_dev(self, acc, rhs, scalars, stream=None):
+        """CrtPolynomial::add_mul_scalar_assign (crt/mul.rs:57-77): acc += scalar * rhs."""
+        (pc, pr), n = self._same_len(acc, rhs)
+        sc = self._host_words(scalars, 1)
+        check(lib().pfhe_dcrt_add_mul_scalar_assign_dev(self._h, pc, pr, sc.ctypes.data_as(u64p), n, _stream(stream)))
+
+    def mul_factor_to_dev(self, a, factors, out, stream=None):
+        """CrtPolynomial::mul_factor_to / mul_factor_assign (crt/mul.rs:47-54,161-180); CrtGlwe::mul_factor_to
+        (glwe/crt.rs:153-171): per-limb ShoupFactor (value, quotient) pairs."""
+        (pa, po), n = self._same_len(a, out)
+        f = self._host_words(factors, 2)
+        check(lib().pfhe_dcrt_mul_factor_to_dev(self._h, pa, f.ctypes.data_as(u64p), po, n, _stream(stream)))
+
+    def add_mul_factor_assign_dev(self, acc, rhs, factors, stream=None):
+        """CrtPolynomial::add_mul_factor_assign (crt/mul.rs:80-99): acc += factor * rhs."""
+        (pc, pr), n = self._same_len(acc, rhs)
+        f = self._host_words(factors, 2)
+        check(lib().pfhe_dcrt_add_mul_factor_assign_dev(self._h, pc, pr, f.ctypes.data_as(u64p), n, _stream(stream)))
+
+    def mul_monomial_to_dev(self, a, r: int, out, stream=None):
+        """out = a * X^r (0 <= r < 2N) per polynomial; out-of-place form of CrtPolynomial::mul_monomial_assign."""
+        (pa, po), n = self._same_len(a, out)
+        check(lib().pfhe_dcrt_mul_monomial_to_dev(self._h, pa, r, po, n, _stream(stream)))
+
+    def mul_monomial_assign_dev(self, data, r: int, stream=None):
+        """CrtPolynomial::mul_monomial_assign (crt/mul.rs:102-127); CrtGlwe::mul_monic_monomial_assign
+        (glwe/crt.rs:76-113)."""
+        p, n = _dev(data)
+        check(lib().pfhe_dcrt_mul_monomial_assign_dev(self._h, p, r, n, _stream(stream)))
+
+    def inv_to_dev(self, a, out, stream=None):
+        """DcrtPolynomial::inv_to / inv_assign (dcrt/inv.rs:33-68): point-wise inverse; raises NoInverse where the
+        reference panics."""
+        (pa, po), n = self._same_len(a, out)
+        check(lib().pfhe_dcrt_inv_to_dev(self._h, pa, po, n, _stream(stream)))
+
     def butterfly_mul_dcrt_polynomial_to_dev(self, a, rhs, dcrt_poly, result, stream=None):
         """DcrtGlwe::butterfly_mul_dcrt_polynomial_to (primus_lattice/src/glwe/dcrt.rs:128-155):
         (a, result) = (a + rhs, (a_orig - rhs) * dcrt_poly)."""

@@ -222,10 +222,69 @@ def converter_cases():
     return out
 
 
+def _elementwise_expected(moduli, n, a, b, scalars, r):
+    """Every op of the element-wise family by its definition on Python integers (canonical residues)."""
+    L = len(moduli)
+    unit = L * n
+    A, B = [int(v) for v in a], [int(v) for v in b]
+    q_of = lambda i: moduli[(i // n) % L]
+    s_of = lambda i: scalars[(i // n) % L]
+    exp = {
+        "add": [(x + y) % q_of(i) for i, (x, y) in enumerate(zip(A, B))],
+        "sub": [(x - y) % q_of(i) for i, (x, y) in enumerate(zip(A, B))],
+        "neg": [(-x) % q_of(i) for i, x in enumerate(A)],
+        "mul_scalar": [x * s_of(i) % q_of(i) for i, x in enumerate(A)],
+        "add_mul_scalar": [(x + y * s_of(i)) % q_of(i) for i, (x, y) in enumerate(zip(A, B))],
+        "inv": [pow(x, -1, q_of(i)) for i, x in enumerate(A)],
+    }
+    mono = [0] * len(A)
+    for i, x in enumerate(A):  # a * X^r in Z_q[X]/(X^n + 1), per n-word polynomial
+        base, j = (i // n) * n, i % n
+        d = j + r
+        sign = -1 if (d // n) % 2 else 1
+        mono[base + d % n] = (sign * x) % q_of(i)
+    exp["mul_monomial"] = mono
+    assert len(A) % unit == 0
+    return exp
+
+
+def elementwise_cases():
+    """add / sub / neg / mul_scalar / add_mul_scalar / mul_factor / add_mul_factor / mul_monomial / inv
+    (primus_poly crt/{add,sub,neg,mul}.rs, dcrt/inv.rs): full vectors at N = 8, digests at N = 2^12."""
+    out = {"small": [], "digests": []}
+    for cid, (log_n, moduli, batch, r) in enumerate([(3, [97, Q61[0]], 2, 3), (3, [Q62], 1, 13), (12, Q61, 4, 1000),
+                                                      (12, Q61, 4, 4096 + 77), (10, [1125899906826241], 3, 0)]):
+        n = 1 << log_n
+        a = splitmix_rns(0xA00 + 2 * cid, moduli, n, batch)
+        b = splitmix_rns(0xA01 + 2 * cid, moduli, n, batch)
+        a[a == 0] = 1  # inv needs units
+        scalars = [int(splitmix_uniform(0xA80 + cid, q, 1)[0]) for q in moduli]
+        factors = [v for s_, q in zip(scalars, moduli) for v in (s_, (s_ << 64) // q)]
+        exp = _elementwise_expected(moduli, n, a, b, scalars, r)
+        exp["mul_factor"], exp["add_mul_factor"] = exp["mul_scalar"], exp["add_mul_scalar"]
+        o = orc.CrtPolyOps(moduli, n)
+        got = {"add": o.add_to(a, b), "sub": o.sub_to(a, b), "neg": o.neg_to(a), "mul_scalar": o.mul_scalar_to(a, scalars),
+               "mul_factor": o.mul_factor_to(a, factors), "inv": o.inv_to(a)}
+        acc = a.copy(); o.add_mul_scalar_assign(acc, b, scalars); got["add_mul_scalar"] = acc
+        acc = a.copy(); o.add_mul_factor_assign(acc, b, factors); got["add_mul_factor"] = acc
+        m = a.copy(); o.mul_monomial_assign(m, r); got["mul_monomial"] = m
+        for k_, v in exp.items():
+            assert got[k_].tolist() == v, (cid, k_)
+        head = dict(case=cid, log_n=log_n, moduli=[str(q) for q in moduli], batch=batch, r=r, seed_a=0xA00 + 2 * cid,
+                    seed_b=0xA01 + 2 * cid, scalars=[str(v) for v in scalars], factors=[str(v) for v in factors])
+        if log_n <= 3:
+            out["small"].append(dict(head, a=[str(v) for v in a], b=[str(v) for v in b],
+                                     expected={k_: [str(x) for x in v] for k_, v in exp.items()}))
+        else:
+            out["digests"].append(dict(head, sha256={k_: digest(np.array(v, np.uint64)) for k_, v in exp.items()}))
+    return out
+
+
 def main():
     out = {
         "u32_ntt.json": u32_cases(),
         "base_converter.json": converter_cases(),
+        "elementwise.json": elementwise_cases(),
         "ntt_small.json": small_ntt_cases(),
         "rns_gadget_small.json": rns_gadget_cases(),
         "extprod_small.json": small_extprod_case(),
