@@ -123,9 +123,54 @@ class U64DcrtTable {
                                  void *stream = nullptr) const {
         check(pfhe_dcrt_mul_dcrt_polynomial_dev(h_, crt_poly, len, dcrt_poly, len_b, stream));
     }
+    // CrtPolynomial / DcrtPolynomial / CrtGlwe element-wise family (crates/primus_poly/src/crt/{add,sub,neg,mul}.rs,
+    // dcrt/inv.rs; primus_lattice/src/macros/mod.rs:367-531, glwe/crt.rs:59-175).  `out` may alias `a`.
+    void add_to_dev(const uint64_t *a, const uint64_t *b, uint64_t *out, size_t len, void *stream = nullptr) const {
+        check(pfhe_dcrt_add_to_dev(h_, a, b, out, len, stream));
+    }
+    void sub_to_dev(const uint64_t *a, const uint64_t *b, uint64_t *out, size_t len, void *stream = nullptr) const {
+        check(pfhe_dcrt_sub_to_dev(h_, a, b, out, len, stream));
+    }
+    void neg_to_dev(const uint64_t *a, uint64_t *out, size_t len, void *stream = nullptr) const {
+        check(pfhe_dcrt_neg_to_dev(h_, a, out, len, stream));
+    }
+    void mul_scalar_to_dev(const uint64_t *a, const std::vector<uint64_t> &scalars, uint64_t *out, size_t len,
+                           void *stream = nullptr) const {
+        require_count(scalars.size(), moduli_count());
+        check(pfhe_dcrt_mul_scalar_to_dev(h_, a, scalars.data(), out, len, stream));
+    }
+    void add_mul_scalar_assign_dev(uint64_t *acc, const uint64_t *rhs, const std::vector<uint64_t> &scalars, size_t len,
+                                   void *stream = nullptr) const {
+        require_count(scalars.size(), moduli_count());
+        check(pfhe_dcrt_add_mul_scalar_assign_dev(h_, acc, rhs, scalars.data(), len, stream));
+    }
+    // factors: (value, quotient) per modulus, ShoupFactor (crates/primus_factor/src/shoup_factor/mod.rs:22)
+    void mul_factor_to_dev(const uint64_t *a, const std::vector<uint64_t> &factors, uint64_t *out, size_t len,
+                           void *stream = nullptr) const {
+        require_count(factors.size(), 2 * moduli_count());
+        check(pfhe_dcrt_mul_factor_to_dev(h_, a, factors.data(), out, len, stream));
+    }
+    void add_mul_factor_assign_dev(uint64_t *acc, const uint64_t *rhs, const std::vector<uint64_t> &factors, size_t len,
+                                   void *stream = nullptr) const {
+        require_count(factors.size(), 2 * moduli_count());
+        check(pfhe_dcrt_add_mul_factor_assign_dev(h_, acc, rhs, factors.data(), len, stream));
+    }
+    void mul_monomial_to_dev(const uint64_t *a, size_t r, uint64_t *out, size_t len, void *stream = nullptr) const {
+        check(pfhe_dcrt_mul_monomial_to_dev(h_, a, r, out, len, stream));
+    }
+    void mul_monomial_assign_dev(uint64_t *data, size_t r, size_t len, void *stream = nullptr) const {
+        check(pfhe_dcrt_mul_monomial_assign_dev(h_, data, r, len, stream));
+    }
+    // throws Error(PFHE_ERR_NO_INVERSE) where the reference panics
+    void inv_to_dev(const uint64_t *a, uint64_t *out, size_t len, void *stream = nullptr) const {
+        check(pfhe_dcrt_inv_to_dev(h_, a, out, len, stream));
+    }
     const pfhe_dcrt *handle() const { return h_; }
 
   private:
+    static void require_count(size_t got, size_t want) {
+        if (got != want) throw Error(PFHE_ERR_BAD_LENGTH, "expected one entry per modulus");
+    }
     pfhe_dcrt *h_ = nullptr;
 };
 

@@ -27,7 +27,7 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
 u32 grid_for(u64 items) {
     u64 g = (items + kThreads - 1) / kThreads;
-    const u64 cap = 256ull * 8;
+    const u64 cap = 0x7fffffffull;  // one workgroup per 256 items streams fastest (see pfhe_elementwise.hip)
     if (g > cap) g = cap;
     return (u32)(g ? g : 1);
 }

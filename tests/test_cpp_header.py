@@ -25,7 +25,30 @@ int main() {
         pfhe::BaseConverter conv(in, out2);
         std::vector<uint64_t> res = {1, 2, 3}, conv_out(2);   // one coefficient, residues (1,2,3)
         conv.fast_convert_array(res.data(), 3, conv_out.data(), 2, 1);
-        const bool ok = a == b && c == d && conv.input_moduli_count() == 3 && conv_out[0] < 29 && conv_out[1] < 31;
+        // element-wise family on device buffers: ((a + b) - b) * X^5 * X^(2N-5) == a, and -(-a) == a
+        void *da = nullptr, *db = nullptr, *dx = nullptr;
+        const size_t bytes = a.size() * sizeof(uint64_t);
+        pfhe::check(pfhe_device_malloc(0, bytes, &da));
+        pfhe::check(pfhe_device_malloc(0, bytes, &db));
+        pfhe::check(pfhe_device_malloc(0, bytes, &dx));
+        std::vector<uint64_t> e(a.size());
+        for (size_t i = 0; i < e.size(); ++i) e[i] = 1000003ull * i + 17;
+        pfhe::check(pfhe_memcpy_h2d(0, da, e.data(), bytes, nullptr));
+        pfhe::check(pfhe_memcpy_h2d(0, db, b.data(), bytes, nullptr));
+        uint64_t *pa = (uint64_t *)da, *pb = (uint64_t *)db, *px = (uint64_t *)dx;
+        t.add_to_dev(pa, pb, px, e.size());
+        t.sub_to_dev(px, pb, px, e.size());
+        t.mul_monomial_assign_dev(px, 5, e.size());
+        t.mul_monomial_to_dev(px, 2 * 1024 - 5, pb, e.size());
+        t.neg_to_dev(pb, pb, e.size());
+        t.neg_to_dev(pb, pb, e.size());
+        t.mul_scalar_to_dev(pb, {2, 2, 2}, px, e.size());
+        std::vector<uint64_t> f(e.size());
+        pfhe::check(pfhe_memcpy_d2h(0, f.data(), dx, bytes, nullptr));
+        bool ew_ok = true;
+        for (size_t i = 0; i < e.size(); ++i) ew_ok = ew_ok && f[i] == 2 * e[i];
+        pfhe_device_free(0, da); pfhe_device_free(0, db); pfhe_device_free(0, dx);
+        const bool ok = ew_ok && a == b && c == d && conv.input_moduli_count() == 3 && conv_out[0] < 29 && conv_out[1] < 31;
         std::printf(ok ? "roundtrip ok\n" : "roundtrip MISMATCH\n");
         return ok ? 0 : 1;
     } catch (const pfhe::Error &e) {
