@@ -371,6 +371,10 @@ int pfhe_dcrt_mul_monomial_assign_dev(const pfhe_dcrt *table, uint64_t *data_dev
         return PFHE_ERR_BAD_ARGUMENT;
     }
     if (len == 0) return PFHE_OK;
+    if (stream_is_capturing((hipStream_t)stream)) {
+        set_last_error("mul_monomial_assign allocates a scratch tile; capture mul_monomial_to into a graph instead");
+        return PFHE_ERR_UNSUPPORTED;
+    }
     // a rotation cannot be done in place by independent threads: rotate tiles of up to 1 GiB into a stream-ordered
     // scratch buffer and copy them back (2x the traffic of the out-of-place form)
     hipStream_t s = (hipStream_t)stream;

@@ -78,3 +78,9 @@ def test_cpp_mirror_compiles_and_runs():
             assert r.returncode == 0 and "roundtrip ok" in r.stdout, r.stdout + r.stderr
         else:
             assert r.returncode == 42 and "NO_DEVICE" not in r.stderr, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_on_gpu():
+    """The same program on the GPU box: transforms, base conversion and the element-wise family round-trip."""
+    test_cpp_mirror_compiles_and_runs()

@@ -77,3 +77,43 @@ def test_large_batch_transform_in_a_graph(pf):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(x, ref)
+
+
+def test_cmux_style_step_in_a_graph(pf):
+    """acc += ggsw [.] (acc * X^r - acc): monomial rotation, subtraction, external product and addition — the
+    element-wise kernels and the product captured together and replayed (a blind-rotation step)."""
+    import torch
+    log_n, k, r = 11, 1, 777
+    n = 1 << log_n
+    rng = np.random.default_rng(5)
+    t, base = pf.U64DcrtTable(log_n, Q61), pf.RNSBase(Q61)
+    basis = pf.BigUintApproxSignedBasis(base, 30)
+    ctx = pf.DcrtGlevContext(t, base, basis, k)
+    ell = basis.decompose_length()
+    acc0 = to_dev(rand_rns(rng, Q61, n, k + 1))
+    dk = to_dev(rand_rns(rng, Q61, n, (k + 1) * ell * (k + 1)))
+    acc, diff, prod = acc0.clone(), torch.empty_like(acc0), torch.empty_like(acc0)
+    s = torch.cuda.Stream()
+
+    def step():
+        t.mul_monomial_to_dev(acc, r, diff, stream=s)
+        t.sub_to_dev(diff, acc, diff, stream=s)
+        pf.mul_dcrt_ggsw_to_dev(diff, dk, prod, ctx, into_coeff_form=True, stream=s)
+        t.add_to_dev(acc, prod, acc, stream=s)
+
+    with torch.cuda.stream(s):
+        step()
+        step()
+    s.synchronize()
+    ref = acc.clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        step()
+    with pytest.raises(pf.PfheError):  # refuses, and must not poison the capture machinery afterwards
+        with torch.cuda.graph(torch.cuda.CUDAGraph(), stream=s):
+            t.mul_monomial_assign_dev(diff, 1, stream=s)
+    acc.copy_(acc0)
+    g.replay()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(acc, ref)
