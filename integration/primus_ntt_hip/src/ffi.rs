@@ -7,6 +7,7 @@ macro_rules! opaque { ($($n:ident),*) => { $( #[repr(C)] pub struct $n { _p: [u8
 opaque!(pfhe_ntt, pfhe_dcrt, pfhe_ntt32, pfhe_dcrt32, pfhe_rns, pfhe_basis, pfhe_extprod_plan, pfhe_conv);
 
 pub const PFHE_OK: c_int = 0;
+pub const PFHE_ERR_NO_INVERSE: c_int = 37;
 
 unsafe extern "C" {
     pub fn pfhe_last_error() -> *const c_char;
@@ -37,6 +38,18 @@ unsafe extern "C" {
     pub fn pfhe_dcrt_lazy_inverse_transform_slice(t: *const pfhe_dcrt, poly: *mut u64, len: usize) -> c_int;
     pub fn pfhe_dcrt_transform_dev(t: *const pfhe_dcrt, poly_dev: *mut u64, len: usize, lazy: c_int, stream: *mut c_void) -> c_int;
     pub fn pfhe_dcrt_inverse_transform_dev(t: *const pfhe_dcrt, poly_dev: *mut u64, len: usize, lazy: c_int, stream: *mut c_void) -> c_int;
+
+    // element-wise family on device-resident CRT polynomials / GLWE ciphertexts (len = total words)
+    pub fn pfhe_dcrt_add_to_dev(t: *const pfhe_dcrt, a: *const u64, b: *const u64, out: *mut u64, len: usize, stream: *mut c_void) -> c_int;
+    pub fn pfhe_dcrt_sub_to_dev(t: *const pfhe_dcrt, a: *const u64, b: *const u64, out: *mut u64, len: usize, stream: *mut c_void) -> c_int;
+    pub fn pfhe_dcrt_neg_to_dev(t: *const pfhe_dcrt, a: *const u64, out: *mut u64, len: usize, stream: *mut c_void) -> c_int;
+    pub fn pfhe_dcrt_mul_scalar_to_dev(t: *const pfhe_dcrt, a: *const u64, scalars: *const u64, out: *mut u64, len: usize, stream: *mut c_void) -> c_int;
+    pub fn pfhe_dcrt_add_mul_scalar_assign_dev(t: *const pfhe_dcrt, acc: *mut u64, rhs: *const u64, scalars: *const u64, len: usize, stream: *mut c_void) -> c_int;
+    pub fn pfhe_dcrt_mul_factor_to_dev(t: *const pfhe_dcrt, a: *const u64, factors: *const u64, out: *mut u64, len: usize, stream: *mut c_void) -> c_int;
+    pub fn pfhe_dcrt_add_mul_factor_assign_dev(t: *const pfhe_dcrt, acc: *mut u64, rhs: *const u64, factors: *const u64, len: usize, stream: *mut c_void) -> c_int;
+    pub fn pfhe_dcrt_mul_monomial_to_dev(t: *const pfhe_dcrt, a: *const u64, r: usize, out: *mut u64, len: usize, stream: *mut c_void) -> c_int;
+    pub fn pfhe_dcrt_mul_monomial_assign_dev(t: *const pfhe_dcrt, data: *mut u64, r: usize, len: usize, stream: *mut c_void) -> c_int;
+    pub fn pfhe_dcrt_inv_to_dev(t: *const pfhe_dcrt, a: *const u64, out: *mut u64, len: usize, stream: *mut c_void) -> c_int;
 
     // U32NttTable (same shape with u32 words)
     pub fn pfhe_ntt32_create(log_n: u32, modulus: u32, device: c_int, out: *mut *mut pfhe_ntt32) -> c_int;

@@ -128,6 +128,41 @@ impl HipDcrtTable {
     pub fn handle(&self) -> *const ffi::pfhe_dcrt {
         self.h
     }
+
+    // Device-resident element-wise forms of CrtGlwe / CrtPolynomial methods for a batch in one slice
+    // (crates/primus_lattice/src/macros/mod.rs:367-531, glwe/crt.rs:59-175, primus_poly/src/crt/mul.rs:102-127).
+    // All pointers are device pointers to `len` words; `out` may alias `a`.
+
+    /// `CrtGlwe::add_element_wise_to` / `add_element_wise_assign`.
+    pub unsafe fn add_element_wise_to_dev(&self, a: *const u64, b: *const u64, out: *mut u64, len: usize,
+                                          stream: *mut core::ffi::c_void) -> Result<(), c_int> {
+        status(unsafe { ffi::pfhe_dcrt_add_to_dev(self.h, a, b, out, len, stream) })
+    }
+    /// `CrtGlwe::sub_element_wise_to` / `sub_element_wise_assign`.
+    pub unsafe fn sub_element_wise_to_dev(&self, a: *const u64, b: *const u64, out: *mut u64, len: usize,
+                                          stream: *mut core::ffi::c_void) -> Result<(), c_int> {
+        status(unsafe { ffi::pfhe_dcrt_sub_to_dev(self.h, a, b, out, len, stream) })
+    }
+    /// `CrtGlwe::mul_scalar_to` / `mul_scalar_assign` (`scalar_residue`: one residue per modulus, on the host).
+    pub unsafe fn mul_scalar_to_dev(&self, a: *const u64, scalar_residue: &[u64], out: *mut u64, len: usize,
+                                    stream: *mut core::ffi::c_void) -> Result<(), c_int> {
+        assert_eq!(scalar_residue.len(), self.limbs.len());
+        status(unsafe { ffi::pfhe_dcrt_mul_scalar_to_dev(self.h, a, scalar_residue.as_ptr(), out, len, stream) })
+    }
+    /// `CrtGlwe::mul_monic_monomial_assign(r)` written to a second buffer (`self * X^r`, `r < 2N`).
+    pub unsafe fn mul_monic_monomial_to_dev(&self, a: *const u64, r: usize, out: *mut u64, len: usize,
+                                            stream: *mut core::ffi::c_void) -> Result<(), c_int> {
+        status(unsafe { ffi::pfhe_dcrt_mul_monomial_to_dev(self.h, a, r, out, len, stream) })
+    }
+    /// `DcrtPolynomial::inv_to`; `Err(PFHE_ERR_NO_INVERSE)` where the reference panics.
+    pub unsafe fn inv_to_dev(&self, a: *const u64, out: *mut u64, len: usize, stream: *mut core::ffi::c_void)
+                             -> Result<(), c_int> {
+        status(unsafe { ffi::pfhe_dcrt_inv_to_dev(self.h, a, out, len, stream) })
+    }
+}
+
+fn status(rc: c_int) -> Result<(), c_int> {
+    if rc == ffi::PFHE_OK { Ok(()) } else { Err(rc) }
 }
 
 impl DcrtTable for HipDcrtTable {
