@@ -207,8 +207,8 @@ int pointwise(const TableSet &t, int mode, u64 *acc, const u64 *a, size_t len_a,
     }
     DeviceGuard g(t.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    return mode == 0 ? pointwise_dev(acc, acc, b, nullptr, t.primes_dev, t.L, t.log_n, len_a, len_b, s)
-                     : pointwise_dev(acc, a, b, acc, t.primes_dev, t.L, t.log_n, len_a, len_b, s);
+    return mode == 0 ? pointwise_dev(acc, acc, b, nullptr, t.primes_dev, t.L, t.log_n, len_a, len_b, s, 0, t.pm)
+                     : pointwise_dev(acc, a, b, acc, t.primes_dev, t.L, t.log_n, len_a, len_b, s, 0, t.pm);
 }
 
 // out = a*b (+ c): NttPolynomial::mul_to / mul_add_to (primus_poly/src/ntt/mul.rs:100-107, ntt/mod.rs:169-187)
@@ -227,7 +227,7 @@ int pointwise_to(const TableSet &t, u64 *out, const u64 *a, size_t len_a, const 
     }
     DeviceGuard g(t.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    return pointwise_dev(out, a, b, has_c ? c : nullptr, t.primes_dev, t.L, t.log_n, len_a, len_b, s);
+    return pointwise_dev(out, a, b, has_c ? c : nullptr, t.primes_dev, t.L, t.log_n, len_a, len_b, s, 0, t.pm);
 }
 
 // minus_one: the coefficient of limb i is q_i - 1 (DcrtTable::transform_coeff_minus_one_monomial,
@@ -679,7 +679,7 @@ int pfhe_dcrt_add_dcrt_glwe_mul_dcrt_polynomial_assign_dev(const pfhe_dcrt *tabl
     DeviceGuard g(t.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
     return pointwise_dev((u64 *)acc_dev, (const u64 *)dcrt_glwe_dev, (const u64 *)dcrt_poly_dev, (const u64 *)acc_dev,
-                         t.primes_dev, t.L, t.log_n, len, len_poly, (hipStream_t)stream, (u64)unit * glwe_polys);
+                         t.primes_dev, t.L, t.log_n, len, len_poly, (hipStream_t)stream, (u64)unit * glwe_polys, t.pm);
     PFHE_GUARD_END
 }
 

@@ -8,6 +8,7 @@
 // (per limb: BarrettModulus::reduce_mul / reduce_mul_add, primus_modulus/src/barrett/ops.rs:276-315)
 #include "pfhe_common.hpp"
 #include "pfhe_modmath.hpp"
+#include "pfhe_ntt_device.hpp"
 #include "pfhe_pointwise.hpp"
 
 namespace pfhe {
@@ -53,7 +54,9 @@ __device__ __forceinline__ Bar load_bar(const NttPrime *__restrict__ primes, u32
 // in-place forms (mul_assign: out = a; add_mul_assign: out = c).  Each thread handles UNROLL
 // 16-byte vectors per iteration, one workgroup-stride apart, so that several independent loads
 // are in flight.
-template <bool HAS_C, bool PAIR>
+// PM: every modulus is pseudo-Mersenne (q = 2^K - c): the folding multiply of PmArith replaces the 128-bit Barrett
+// reduction (a third of the instructions); both return the canonical residue.
+template <bool HAS_C, bool PAIR, bool PM>
 __global__ __launch_bounds__(kPwThreads) void pointwise_kernel(u64 *out, const u64 *a, const u64 *__restrict__ b,
                                                                const u64 *c, const NttPrime *__restrict__ primes,
                                                                u32 L, u32 log_n, u64 len, u64 len_b, u64 group_words) {
@@ -66,6 +69,7 @@ __global__ __launch_bounds__(kPwThreads) void pointwise_kernel(u64 *out, const u
     for (u64 v0 = (u64)blockIdx.x * blockDim.x + threadIdx.x; v0 < nvec; v0 += tile * UNROLL) {
         u64 av[UNROLL][2], bv[UNROLL][2], cv[UNROLL][2];
         Bar m[UNROLL];
+        u32 limb_of[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const u64 v = v0 + tile * u;
@@ -76,7 +80,8 @@ __global__ __launch_bounds__(kPwThreads) void pointwise_kernel(u64 *out, const u
             u32 p = (u32)(i >> log_n);
             if (log_n >= 7) p = __builtin_amdgcn_readfirstlane(p);
             const u32 unit_idx = p / L, limb = p - unit_idx * L;
-            m[u] = load_bar(primes, limb);
+            limb_of[u] = limb;
+            if constexpr (!PM) m[u] = load_bar(primes, limb);
             u64 ib = i;
             if (shared_b || group_words) {
                 // shared: the one unit of b; grouped: one unit per `group_units` consecutive units of a
@@ -103,10 +108,20 @@ __global__ __launch_bounds__(kPwThreads) void pointwise_kernel(u64 *out, const u
             if (v >= nvec) continue;
             const u64 i = v * V;
             u64 r[2];
+            if constexpr (PM) {
+                const PmArith ar(primes + limb_of[u]);
 #pragma unroll
-            for (int e = 0; e < (int)V; ++e) {
-                if constexpr (!HAS_C) r[e] = mul_mod_barrett(av[u][e], bv[u][e], m[u].q, m[u].lo, m[u].hi);
-                else r[e] = mul_add_mod_barrett(av[u][e], bv[u][e], cv[u][e], m[u].q, m[u].lo, m[u].hi);
+                for (int e = 0; e < (int)V; ++e) {
+                    const u64 prod = ar.mul_any(av[u][e], bv[u][e]);  // [0, 2q)
+                    if constexpr (!HAS_C) r[e] = ar.reduce_2q(prod);
+                    else r[e] = ar.reduce_4q(prod + cv[u][e]);      // < 3q
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < (int)V; ++e) {
+                    if constexpr (!HAS_C) r[e] = mul_mod_barrett(av[u][e], bv[u][e], m[u].q, m[u].lo, m[u].hi);
+                    else r[e] = mul_add_mod_barrett(av[u][e], bv[u][e], cv[u][e], m[u].q, m[u].lo, m[u].hi);
+                }
             }
             if constexpr (PAIR) pw_store(out + i, pw_vec{r[0], r[1]});
             else out[i] = r[0];
@@ -188,18 +203,26 @@ u32 grid_for(u64 work_items) {
 }  // namespace
 
 int pointwise_dev(u64 *out, const u64 *a, const u64 *b, const u64 *c, const NttPrime *primes, u32 L, u32 log_n,
-                  u64 len, u64 len_b, hipStream_t s, u64 group_words) {
+                  u64 len, u64 len_b, hipStream_t s, u64 group_words, bool pm) {
     if (len == 0) return PFHE_OK;
     const bool pair = log_n >= 1 && (len % 2 == 0) && (len_b % 2 == 0);
     const u64 items = ((pair ? len / 2 : len) + PFHE_PW_UNROLL - 1) / PFHE_PW_UNROLL;  // vectors per thread and iteration
     const dim3 g(grid_for(items ? items : 1)), t(kPwThreads);
-    if (c == nullptr) {
-        if (pair) hipLaunchKernelGGL((pointwise_kernel<false, true>), g, t, 0, s, out, a, b, c, primes, L, log_n, len, len_b, group_words);
-        else hipLaunchKernelGGL((pointwise_kernel<false, false>), g, t, 0, s, out, a, b, c, primes, L, log_n, len, len_b, group_words);
-    } else {
-        if (pair) hipLaunchKernelGGL((pointwise_kernel<true, true>), g, t, 0, s, out, a, b, c, primes, L, log_n, len, len_b, group_words);
-        else hipLaunchKernelGGL((pointwise_kernel<true, false>), g, t, 0, s, out, a, b, c, primes, L, log_n, len, len_b, group_words);
+#define PFHE_PW_LAUNCH(HAS_C, PAIR, PM)                                                                               \
+    hipLaunchKernelGGL((pointwise_kernel<HAS_C, PAIR, PM>), g, t, 0, s, out, a, b, c, primes, L, log_n, len, len_b, \
+                       group_words)
+    const int variant = (c != nullptr ? 4 : 0) | (pair ? 2 : 0) | (pm ? 1 : 0);
+    switch (variant) {
+        case 0: PFHE_PW_LAUNCH(false, false, false); break;
+        case 1: PFHE_PW_LAUNCH(false, false, true); break;
+        case 2: PFHE_PW_LAUNCH(false, true, false); break;
+        case 3: PFHE_PW_LAUNCH(false, true, true); break;
+        case 4: PFHE_PW_LAUNCH(true, false, false); break;
+        case 5: PFHE_PW_LAUNCH(true, false, true); break;
+        case 6: PFHE_PW_LAUNCH(true, true, false); break;
+        default: PFHE_PW_LAUNCH(true, true, true); break;
     }
+#undef PFHE_PW_LAUNCH
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
 }

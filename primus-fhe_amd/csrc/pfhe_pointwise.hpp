@@ -5,8 +5,9 @@
 namespace pfhe {
 // out = a*b (+ c when c != nullptr); out may alias a and/or c.  b has len_b words: len or one unit;
 // with group_words != 0, b holds one unit per `group_words` consecutive words of a (len_b = len / group * unit).
+// pm: every prime has the pseudo-Mersenne shape (TableSet::pm) -> folding multiply instead of Barrett.
 int pointwise_dev(u64 *out, const u64 *a, const u64 *b, const u64 *c, const NttPrime *primes, u32 L, u32 log_n,
-                  u64 len, u64 len_b, hipStream_t s, u64 group_words = 0);
+                  u64 len, u64 len_b, hipStream_t s, u64 group_words = 0, bool pm = false);
 // (a, b) = (a + s, (a - s) * w); w holds len_w multiplicands (ShoupFactor pairs when `factor`), shared
 // cyclically by the batch.
 int butterfly_dev(bool factor, u64 *a, const u64 *s, const u64 *w, u64 *b, const NttPrime *primes, u32 L, u32 log_n,
