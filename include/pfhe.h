@@ -229,7 +229,9 @@ int pfhe_dcrt_mul_dcrt_polynomial_dev(const pfhe_dcrt *table, uint64_t *crt_poly
  * consecutive RNS polynomials, so the same entry points serve both.
  * `len` = total words, a multiple of L*N; every buffer holds `len` words; `out` may alias `a` (the *_assign
  * forms) and, for sub, `b` (sub_rev_assign, crt/sub.rs:69).  Inputs must be canonical ([0, q_r)), as in the
- * reference.  `scalars`: L residues on the host; `factors`: L ShoupFactor (value, quotient) pairs on the host. */
+ * reference.  `scalars`: L residues on the host; `factors`: L ShoupFactor (value, quotient) pairs on the host.
+ * The single-modulus NttPolynomial / Polynomial forms (primus_poly/src/ntt/{add,sub,neg,inv}.rs) are the L = 1 case:
+ * bind them to a pfhe_dcrt created with one modulus. */
 int pfhe_dcrt_add_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, const uint64_t *b_dev, uint64_t *out_dev,
                          size_t len, void *stream);
 int pfhe_dcrt_sub_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, const uint64_t *b_dev, uint64_t *out_dev,
