@@ -302,7 +302,7 @@ def main():
                               "traffic_source": (pmc["source"] + ": " + pmc["method"]) if pmc else None,
                               "avg_launch_ms": dom[1], "algorithmic_bytes_per_launch": alg_bytes,
                               "note": "fraction of the HBM roofline as the metric asks; this kernel is bound by the "
-                                      "integer ALU (VALUBusy 98 %, profiles/r01_e_pmc_utilisation.txt), not by HBM"}
+                                      "integer ALU (VALUBusy 98 %, profiles/r01_f_pmc_utilisation.txt), not by HBM"}
         result["kernels_ms"] = {k: v for k, v in per_pass}
         # the single-pass loops above left x in an arbitrary state: restore canonical residues
         check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(x.data_ptr()), words, mods.ctypes.data_as(u64p), L, n, 5, None))
