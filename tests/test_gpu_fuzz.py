@@ -196,6 +196,13 @@ def test_pseudo_mersenne_bounds(pf, orc, K, largest_c):
     d = to_dev(lz); t.transform_dev(d, lazy=True)
     got = to_host(d)
     assert got.max() < 4 * q and np.array_equal(got % np.uint64(q), can)
+    # point-wise products take the folding multiply for these primes: extreme and random operands
+    dt, ot = pf.U64DcrtTable(log_n, [q]), orc.U64DcrtTable(log_n, [q])
+    for x, y, z in ((np.full(n, q - 1, np.uint64),) * 3, tuple(rng.integers(0, q, n, dtype=np.uint64) for _ in range(3))):
+        e1 = x.copy(); ot.mul_assign(e1, y)
+        d1 = to_dev(x); dt.mul_assign_dev(d1, to_dev(y)); assert np.array_equal(to_host(d1), e1)
+        e2 = [(int(u) * int(v) + int(w)) % q for u, v, w in zip(x, y, z)]
+        d2 = to_dev(z); dt.add_mul_assign_dev(d2, to_dev(x), to_dev(y)); assert to_host(d2).tolist() == e2
     li = np.full(n, 2 * q - 1, np.uint64)
     cani = (li % np.uint64(q)).copy(); o.inverse_transform_slice(cani)
     d = to_dev(li); t.inverse_transform_dev(d, lazy=True)
