@@ -286,6 +286,23 @@ int pfhe_rns_wrapping_decompose_small_values_to_dev(const pfhe_rns *base,
                                                     size_t value_count, uint64_t *multi_residues_dev,
                                                     size_t len_out, uint64_t small_value_modulus,
                                                     void *stream);
+/* add_wrapping_decompose_small_values_scaled — base.rs:326-384 (+ slice::wrapping_decompose_chunk_scaled_to
+ * :739-757): acc[i][c] = reduce_add(acc[i][c], factor_i * lift_i(small[c])) with the centred lift above (m == 2
+ * takes the unsigned branch, base.rs:371-378); add_decompose_small_values_scaled — base.rs:398-416: the same
+ * without the lift (= add_decompose_small_polynomial_scaled, :429-443).  `acc`: L*value_count words,
+ * modulus-major, accumulated in place; `factors`: L ShoupFactor (value, quotient) pairs on the host. */
+int pfhe_rns_add_wrapping_decompose_small_values_scaled(const pfhe_rns *base, const uint64_t *small_values,
+                                                        size_t value_count, uint64_t *acc, size_t len_acc,
+                                                        uint64_t small_value_modulus, const uint64_t *factors);
+int pfhe_rns_add_wrapping_decompose_small_values_scaled_dev(const pfhe_rns *base, const uint64_t *small_values_dev,
+                                                            size_t value_count, uint64_t *acc_dev, size_t len_acc,
+                                                            uint64_t small_value_modulus, const uint64_t *factors,
+                                                            void *stream);
+int pfhe_rns_add_decompose_small_values_scaled(const pfhe_rns *base, const uint64_t *small_values, size_t value_count,
+                                               uint64_t *acc, size_t len_acc, const uint64_t *factors);
+int pfhe_rns_add_decompose_small_values_scaled_dev(const pfhe_rns *base, const uint64_t *small_values_dev,
+                                                   size_t value_count, uint64_t *acc_dev, size_t len_acc,
+                                                   const uint64_t *factors, void *stream);
 
 /* =====================================================================================
  * BigUintApproxSignedBasis<u64> — primus_decompose/src/big_integer/basis.rs:17

@@ -141,6 +141,8 @@ def _load(path: str | None = None) -> C.CDLL:
     sig("orc_rns_decompose_to", None, vp, _u64p, _u64p)
     sig("orc_rns_decompose_big_uint_values_to", None, vp, _u64p, _u64p, sz)
     sig("orc_rns_wrapping_decompose_small_values_to", None, vp, _u64p, _u64p, sz, u64)
+    sig("orc_rns_add_wrapping_decompose_small_values_scaled", None, vp, _u64p, _u64p, sz, u64, _u64p)
+    sig("orc_rns_add_decompose_small_values_scaled", None, vp, _u64p, _u64p, sz, _u64p)
 
     sig("orc_conv_new", ci, vp, vp, C.POINTER(vp))
     sig("orc_conv_free", None, vp)
@@ -612,6 +614,21 @@ class RNSBase:
         out = np.empty(self.count * sv.size, np.uint64)
         lib().orc_rns_wrapping_decompose_small_values_to(self._h, _p(sv), _p(out), sv.size, small_value_modulus)
         return out
+
+
+    def add_wrapping_decompose_small_values_scaled(self, small_values, acc, small_value_modulus, factors):
+        """base.rs:326-384; acc (modulus-major, count * len(small_values) words) is updated in place."""
+        sv = np.ascontiguousarray(small_values, np.uint64)
+        f = np.ascontiguousarray(np.array(factors, np.uint64).reshape(-1))
+        assert acc.size == self.count * sv.size and f.size == 2 * self.count
+        lib().orc_rns_add_wrapping_decompose_small_values_scaled(self._h, _p(sv), _p(acc), sv.size, small_value_modulus, _p(f))
+
+    def add_decompose_small_values_scaled(self, small_values, acc, factors):
+        """base.rs:398-416."""
+        sv = np.ascontiguousarray(small_values, np.uint64)
+        f = np.ascontiguousarray(np.array(factors, np.uint64).reshape(-1))
+        assert acc.size == self.count * sv.size and f.size == 2 * self.count
+        lib().orc_rns_add_decompose_small_values_scaled(self._h, _p(sv), _p(acc), sv.size, _p(f))
 
 
 class BaseConverter:

@@ -1287,6 +1287,35 @@ void orc_rns_wrapping_decompose_small_values_to(const orc_rns *b, const uint64_t
     }
 }
 
+/* base.rs:326-384 + slice::wrapping_decompose_chunk_scaled_to :739-757: centred lift, Shoup product by the
+ * modulus' factor, compact reduce_add into acc; small_value_modulus == 2 takes add_factor_mul_slice_assign on the
+ * raw values (:371-378).  `factors` = count (value, quotient) pairs. */
+void orc_rns_add_wrapping_decompose_small_values_scaled(const orc_rns *b, const uint64_t *small_values, uint64_t *acc,
+                                                        size_t value_count, uint64_t small_value_modulus,
+                                                        const uint64_t *factors) {
+    const uint64_t half = (small_value_modulus + 1) / 2;
+    for (size_t i = 0; i < b->count; ++i) {
+        const uint64_t q = b->moduli[i], temp = q - small_value_modulus;
+        uint64_t *a = acc + i * value_count;
+        for (size_t c = 0; c < value_count; ++c) {
+            const uint64_t v = small_values[c];
+            const uint64_t centred = (small_value_modulus != 2 && v >= half) ? temp + v : v;
+            a[c] = orc_reduce_add(q, a[c], orc_shoup_mul(factors[2 * i], factors[2 * i + 1], centred, q));
+        }
+    }
+}
+
+/* base.rs:398-416 (and add_decompose_small_polynomial_scaled :429-443): the same without the lift */
+void orc_rns_add_decompose_small_values_scaled(const orc_rns *b, const uint64_t *small_values, uint64_t *acc,
+                                               size_t value_count, const uint64_t *factors) {
+    for (size_t i = 0; i < b->count; ++i) {
+        const uint64_t q = b->moduli[i];
+        uint64_t *a = acc + i * value_count;
+        for (size_t c = 0; c < value_count; ++c)
+            a[c] = orc_reduce_add(q, a[c], orc_shoup_mul(factors[2 * i], factors[2 * i + 1], small_values[c], q));
+    }
+}
+
 /* ========================================================================== */
 /* BigUintApproxSignedBasis<u64> — primus_decompose/src/big_integer/{basis,common}.rs */
 /* ========================================================================== */

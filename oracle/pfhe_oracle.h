@@ -220,6 +220,11 @@ void orc_rns_decompose_big_uint_values_to(const orc_rns *b, const uint64_t *big_
 void orc_rns_wrapping_decompose_small_values_to(const orc_rns *b, const uint64_t *small_values,
                                                 uint64_t *multi_residues, size_t value_count,
                                                 uint64_t small_value_modulus);
+void orc_rns_add_wrapping_decompose_small_values_scaled(const orc_rns *b, const uint64_t *small_values, uint64_t *acc,
+                                                        size_t value_count, uint64_t small_value_modulus,
+                                                        const uint64_t *factors);
+void orc_rns_add_decompose_small_values_scaled(const orc_rns *b, const uint64_t *small_values, uint64_t *acc,
+                                               size_t value_count, const uint64_t *factors);
 
 /* ---------------- BigUintApproxSignedBasis<u64> (primus_decompose/src/big_integer) ----- */
 typedef struct orc_basis orc_basis;

@@ -118,6 +118,10 @@ def _declare(lib: C.CDLL) -> None:
     sig("pfhe_rns_compose_multiple_values_to_dev", ci, vp, vp, sz, vp, sz, sz, vp)
     sig("pfhe_rns_wrapping_decompose_small_values_to", ci, vp, vp, sz, vp, sz, u64)
     sig("pfhe_rns_wrapping_decompose_small_values_to_dev", ci, vp, vp, sz, vp, sz, u64, vp)
+    sig("pfhe_rns_add_wrapping_decompose_small_values_scaled", ci, vp, vp, sz, vp, sz, u64, u64p)
+    sig("pfhe_rns_add_wrapping_decompose_small_values_scaled_dev", ci, vp, vp, sz, vp, sz, u64, u64p, vp)
+    sig("pfhe_rns_add_decompose_small_values_scaled", ci, vp, vp, sz, vp, sz, u64p)
+    sig("pfhe_rns_add_decompose_small_values_scaled_dev", ci, vp, vp, sz, vp, sz, u64p, vp)
     sig("pfhe_basis_create", ci, vp, u32, sz, C.POINTER(vp))
     sig("pfhe_basis_destroy", None, vp)
     sig("pfhe_basis_decompose_length", sz, vp)

@@ -270,6 +270,78 @@ int pfhe_rns_wrapping_decompose_small_values_to(const pfhe_rns *r, const uint64_
     PFHE_GUARD_END
 }
 
+static int add_scaled_common(const pfhe_rns *r, const uint64_t *small_dev, size_t value_count, uint64_t *acc_dev,
+                             size_t len_acc, uint64_t small_value_modulus, bool centred, const uint64_t *factors,
+                             void *stream) {
+    if (!r || !factors || ((!small_dev || !acc_dev) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
+    if (len_acc != value_count * r->h.dev.L) return PFHE_ERR_BAD_LENGTH;
+    for (u32 i = 0; i < r->h.dev.L; ++i) {
+        if (centred && (small_value_modulus >= r->h.dev.q[i] || small_value_modulus < 2)) {  // base.rs:337-341
+            set_last_error("small_value_modulus must be >= 2 and smaller than every RNS modulus");
+            return PFHE_ERR_BAD_ARGUMENT;
+        }
+        if (factors[2 * i] >= r->h.dev.q[i]) {
+            set_last_error("factor values must be reduced modulo their modulus");
+            return PFHE_ERR_BAD_ARGUMENT;
+        }
+    }
+    DeviceGuard g(r->h.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    // base.rs:343,371-378: a small modulus of two takes the unsigned branch (a 1 stays +1)
+    const bool lift = centred && small_value_modulus != 2;
+    return rns_add_decompose_scaled_dev(r->h.dev, (const u64 *)small_dev, (u64 *)acc_dev, value_count, small_value_modulus,
+                                        lift, (const u64 *)factors, (hipStream_t)stream);
+}
+
+int pfhe_rns_add_wrapping_decompose_small_values_scaled_dev(const pfhe_rns *r, const uint64_t *small_values_dev,
+                                                            size_t value_count, uint64_t *acc_dev, size_t len_acc,
+                                                            uint64_t small_value_modulus, const uint64_t *factors,
+                                                            void *stream) {
+    PFHE_GUARD_BEGIN
+    return add_scaled_common(r, small_values_dev, value_count, acc_dev, len_acc, small_value_modulus, true, factors, stream);
+    PFHE_GUARD_END
+}
+
+int pfhe_rns_add_decompose_small_values_scaled_dev(const pfhe_rns *r, const uint64_t *small_values_dev, size_t value_count,
+                                                   uint64_t *acc_dev, size_t len_acc, const uint64_t *factors,
+                                                   void *stream) {
+    PFHE_GUARD_BEGIN
+    return add_scaled_common(r, small_values_dev, value_count, acc_dev, len_acc, 0, false, factors, stream);
+    PFHE_GUARD_END
+}
+
+static int add_scaled_host(const pfhe_rns *r, const uint64_t *small_values, size_t value_count, uint64_t *acc,
+                           size_t len_acc, uint64_t small_value_modulus, bool centred, const uint64_t *factors) {
+    if (!r || !factors || ((!small_values || !acc) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
+    if (len_acc != value_count * r->h.dev.L) return PFHE_ERR_BAD_LENGTH;
+    if (value_count == 0) return PFHE_OK;
+    DeviceGuard g(r->h.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    Staging st;
+    void *in = nullptr, *a = nullptr;
+    PFHE_TRY(st.upload(small_values, value_count * 8, &in));
+    PFHE_TRY(st.upload(acc, len_acc * 8, &a));
+    PFHE_TRY(add_scaled_common(r, (const uint64_t *)in, value_count, (uint64_t *)a, len_acc, small_value_modulus, centred,
+                               factors, nullptr));
+    PFHE_HIP(hipMemcpy(acc, a, len_acc * 8, hipMemcpyDeviceToHost));
+    return PFHE_OK;
+}
+
+int pfhe_rns_add_wrapping_decompose_small_values_scaled(const pfhe_rns *r, const uint64_t *small_values,
+                                                        size_t value_count, uint64_t *acc, size_t len_acc,
+                                                        uint64_t small_value_modulus, const uint64_t *factors) {
+    PFHE_GUARD_BEGIN
+    return add_scaled_host(r, small_values, value_count, acc, len_acc, small_value_modulus, true, factors);
+    PFHE_GUARD_END
+}
+
+int pfhe_rns_add_decompose_small_values_scaled(const pfhe_rns *r, const uint64_t *small_values, size_t value_count,
+                                               uint64_t *acc, size_t len_acc, const uint64_t *factors) {
+    PFHE_GUARD_BEGIN
+    return add_scaled_host(r, small_values, value_count, acc, len_acc, 0, false, factors);
+    PFHE_GUARD_END
+}
+
 /* ------------------------------ BigUintApproxSignedBasis ------------------------------ */
 
 int pfhe_basis_create(const pfhe_rns *rns, uint32_t log_basis, size_t reverse_length, pfhe_basis **out) {

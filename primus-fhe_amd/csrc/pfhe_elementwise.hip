@@ -235,12 +235,14 @@ int check_common(const pfhe_dcrt *table, const void *p0, const void *p1, const v
         return PFHE_ERR_BAD_LENGTH;
     }
     if (t.L > (u32)kMaxEwLimbs) return PFHE_ERR_UNSUPPORTED;
-    return capi_check_device(t.device);
+    return PFHE_OK;
 }
 
 template <int OP>
 int binary_op(const pfhe_dcrt *table, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t len, void *stream) {
     if (int st = check_common(table, a, b, out, len)) return st;
+    DeviceGuard guard(capi_table_of(table)->device);
+    if (!guard.ok) return PFHE_ERR_NO_DEVICE;
     return launch_elementwise<OP>(*capi_table_of(table), (u64 *)out, (const u64 *)a, (const u64 *)b, len, EwScalars{}, (hipStream_t)stream);
 }
 
@@ -296,6 +298,8 @@ int pfhe_dcrt_sub_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, const ui
 int pfhe_dcrt_neg_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, uint64_t *out_dev, size_t len, void *stream) {
     PFHE_GUARD_BEGIN
     if (int st = check_common(table, a_dev, a_dev, out_dev, len)) return st;
+    DeviceGuard guard(capi_table_of(table)->device);
+    if (!guard.ok) return PFHE_ERR_NO_DEVICE;
     return launch_elementwise<kNeg>(*capi_table_of(table), (u64 *)out_dev, (const u64 *)a_dev, nullptr, len, EwScalars{},
                                     (hipStream_t)stream);
     PFHE_GUARD_END
@@ -305,6 +309,8 @@ int pfhe_dcrt_mul_scalar_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, c
                                 uint64_t *out_dev, size_t len, void *stream) {
     PFHE_GUARD_BEGIN
     if (int st = check_common(table, a_dev, a_dev, out_dev, len)) return st;
+    DeviceGuard guard(capi_table_of(table)->device);
+    if (!guard.ok) return PFHE_ERR_NO_DEVICE;
     EwScalars sc{};
     if (int st = load_scalars(*capi_table_of(table), scalars, false, sc)) return st;
     return launch_elementwise<kMulScalar>(*capi_table_of(table), (u64 *)out_dev, (const u64 *)a_dev, nullptr, len, sc,
@@ -316,6 +322,8 @@ int pfhe_dcrt_add_mul_scalar_assign_dev(const pfhe_dcrt *table, uint64_t *acc_de
                                         const uint64_t *scalars, size_t len, void *stream) {
     PFHE_GUARD_BEGIN
     if (int st = check_common(table, acc_dev, rhs_dev, acc_dev, len)) return st;
+    DeviceGuard guard(capi_table_of(table)->device);
+    if (!guard.ok) return PFHE_ERR_NO_DEVICE;
     EwScalars sc{};
     if (int st = load_scalars(*capi_table_of(table), scalars, false, sc)) return st;
     return launch_elementwise<kAddMulScalar>(*capi_table_of(table), (u64 *)acc_dev, (const u64 *)acc_dev, (const u64 *)rhs_dev, len,
@@ -327,6 +335,8 @@ int pfhe_dcrt_mul_factor_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, c
                                 uint64_t *out_dev, size_t len, void *stream) {
     PFHE_GUARD_BEGIN
     if (int st = check_common(table, a_dev, a_dev, out_dev, len)) return st;
+    DeviceGuard guard(capi_table_of(table)->device);
+    if (!guard.ok) return PFHE_ERR_NO_DEVICE;
     EwScalars sc{};
     if (int st = load_scalars(*capi_table_of(table), factors, true, sc)) return st;
     return launch_elementwise<kMulFactor>(*capi_table_of(table), (u64 *)out_dev, (const u64 *)a_dev, nullptr, len, sc,
@@ -338,6 +348,8 @@ int pfhe_dcrt_add_mul_factor_assign_dev(const pfhe_dcrt *table, uint64_t *acc_de
                                         const uint64_t *factors, size_t len, void *stream) {
     PFHE_GUARD_BEGIN
     if (int st = check_common(table, acc_dev, rhs_dev, acc_dev, len)) return st;
+    DeviceGuard guard(capi_table_of(table)->device);
+    if (!guard.ok) return PFHE_ERR_NO_DEVICE;
     EwScalars sc{};
     if (int st = load_scalars(*capi_table_of(table), factors, true, sc)) return st;
     return launch_elementwise<kAddMulFactor>(*capi_table_of(table), (u64 *)acc_dev, (const u64 *)acc_dev, (const u64 *)rhs_dev, len,
@@ -349,6 +361,8 @@ int pfhe_dcrt_mul_monomial_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev,
                                   size_t len, void *stream) {
     PFHE_GUARD_BEGIN
     if (int st = check_common(table, a_dev, a_dev, out_dev, len)) return st;
+    DeviceGuard guard(capi_table_of(table)->device);
+    if (!guard.ok) return PFHE_ERR_NO_DEVICE;
     const TableSet &t = *capi_table_of(table);
     if (r >= 2 * t.n) {
         set_last_error("monomial degree must be below 2N");
@@ -365,6 +379,8 @@ int pfhe_dcrt_mul_monomial_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev,
 int pfhe_dcrt_mul_monomial_assign_dev(const pfhe_dcrt *table, uint64_t *data_dev, size_t r, size_t len, void *stream) {
     PFHE_GUARD_BEGIN
     if (int st = check_common(table, data_dev, data_dev, data_dev, len)) return st;
+    DeviceGuard guard(capi_table_of(table)->device);
+    if (!guard.ok) return PFHE_ERR_NO_DEVICE;
     const TableSet &t = *capi_table_of(table);
     if (r >= 2 * t.n) {
         set_last_error("monomial degree must be below 2N");
@@ -398,6 +414,8 @@ int pfhe_dcrt_mul_monomial_assign_dev(const pfhe_dcrt *table, uint64_t *data_dev
 int pfhe_dcrt_inv_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, uint64_t *out_dev, size_t len, void *stream) {
     PFHE_GUARD_BEGIN
     if (int st = check_common(table, a_dev, a_dev, out_dev, len)) return st;
+    DeviceGuard guard(capi_table_of(table)->device);
+    if (!guard.ok) return PFHE_ERR_NO_DEVICE;
     if (len == 0) return PFHE_OK;
     const TableSet &t = *capi_table_of(table);
     hipStream_t s = (hipStream_t)stream;

@@ -65,6 +65,29 @@ __global__ __launch_bounds__(kThreads) void wrapping_decompose_kernel(RnsDev R, 
     }
 }
 
+// acc[i][c] = reduce_add(acc[i][c], factor_i * lift_i(small[c])): RNSBase::add_wrapping_decompose_small_values_scaled
+// (base.rs:326-384, slice::wrapping_decompose_chunk_scaled_to :739-757) when `centred`, else
+// add_decompose_small_values_scaled (base.rs:398-416; also the reference's small_value_modulus == 2 branch).
+// `fv` / `fq`: the ShoupFactor (value, quotient) of each modulus.
+struct ScaledFactors {
+    u64 value[kMaxLimbs], quotient[kMaxLimbs];
+};
+__global__ __launch_bounds__(kThreads) void add_decompose_scaled_kernel(RnsDev R, const u64 *__restrict__ small,
+                                                                       u64 *__restrict__ acc, u64 count,
+                                                                       u64 small_modulus, bool centred,
+                                                                       ScaledFactors F) {
+    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= count) return;
+    const u64 v = small[c];
+    const u64 half = (small_modulus + 1) / 2;
+    for (u32 i = 0; i < R.L; ++i) {
+        const u64 q = R.q[i];
+        const u64 lifted = (centred && v >= half) ? q - small_modulus + v : v;
+        const u64 idx = (u64)i * count + c;
+        acc[idx] = add_mod(acc[idx], mul_shoup(lifted, F.value[i], F.quotient[i], q), q);
+    }
+}
+
 template <int LEN>
 __global__ __launch_bounds__(kThreads) void init_value_carry_kernel(BasisDev B, u64 *__restrict__ values,
                                                                     unsigned char *__restrict__ carries, u64 count) {
@@ -217,6 +240,20 @@ int rns_wrapping_decompose_dev(const RnsDev &r, const u64 *small, u64 *multi, u6
     if (count == 0) return PFHE_OK;
     hipLaunchKernelGGL(wrapping_decompose_kernel, dim3(grid_for(count)), dim3(kThreads), 0, s, r, small, multi, count,
                        small_modulus);
+    PFHE_HIP(hipGetLastError());
+    return PFHE_OK;
+}
+
+int rns_add_decompose_scaled_dev(const RnsDev &r, const u64 *small_values, u64 *acc, u64 value_count,
+                                 u64 small_value_modulus, bool centred, const u64 *factor_pairs, hipStream_t s) {
+    if (value_count == 0) return PFHE_OK;
+    ScaledFactors f{};
+    for (u32 i = 0; i < r.L; ++i) {
+        f.value[i] = factor_pairs[2 * i];
+        f.quotient[i] = factor_pairs[2 * i + 1];
+    }
+    hipLaunchKernelGGL(add_decompose_scaled_kernel, dim3(grid_for(value_count)), dim3(kThreads), 0, s, r, small_values, acc,
+                       value_count, small_value_modulus, centred, f);
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
 }

@@ -51,6 +51,9 @@ int rns_compose_dev(const RnsDev &r, const u64 *multi_residues, u64 *big_uint_va
                     hipStream_t s);
 int rns_wrapping_decompose_dev(const RnsDev &r, const u64 *small_values, u64 *multi_residues, u64 value_count,
                                u64 small_value_modulus, hipStream_t s);
+// acc += factor * lift(small) per modulus (centred lift unless !centred); factor_pairs: L host (value, quotient) pairs
+int rns_add_decompose_scaled_dev(const RnsDev &r, const u64 *small_values, u64 *acc, u64 value_count,
+                                 u64 small_value_modulus, bool centred, const u64 *factor_pairs, hipStream_t s);
 int basis_init_value_carry_dev(const BasisDev &b, u64 *values, unsigned char *carries, u64 count, hipStream_t s);
 int basis_unsigned_decompose_dev(const BasisDev &b, u32 level, const u64 *values, u64 *digits,
                                  unsigned char *carries, u64 count, hipStream_t s);

@@ -72,6 +72,51 @@ class RNSBase:
                                                                     small_value_modulus, _stream(stream)))
 
 
+    @staticmethod
+    def _factor_words(factors, count):
+        f = np.ascontiguousarray(np.array(factors, dtype=np.uint64).reshape(-1))
+        if f.size != 2 * count:
+            raise PfheError(32, "expected one (value, quotient) pair per modulus")
+        return f
+
+    def add_wrapping_decompose_small_values_scaled(self, small_values, acc, value_count: int, small_value_modulus: int,
+                                                   factors):
+        """base.rs:326-384: acc[i][c] += factor_i * centred_lift_i(small[c]) (in place; factors = ShoupFactor pairs)."""
+        (pi, ni), (pa, na) = _host(small_values), _host(acc)
+        if ni != value_count:
+            raise PfheError(32, "small_values.len() must equal value_count")
+        f = self._factor_words(factors, self.moduli_count())
+        check(lib().pfhe_rns_add_wrapping_decompose_small_values_scaled(self._h, pi, value_count, pa, na,
+                                                                        small_value_modulus, f.ctypes.data_as(u64p)))
+
+    def add_decompose_small_values_scaled(self, small_values, acc, value_count: int, factors):
+        """base.rs:398-416 (= add_decompose_small_polynomial_scaled, :429-443): acc[i][c] += factor_i * small[c]."""
+        (pi, ni), (pa, na) = _host(small_values), _host(acc)
+        if ni != value_count:
+            raise PfheError(32, "small_values.len() must equal value_count")
+        f = self._factor_words(factors, self.moduli_count())
+        check(lib().pfhe_rns_add_decompose_small_values_scaled(self._h, pi, value_count, pa, na, f.ctypes.data_as(u64p)))
+
+    add_decompose_small_polynomial_scaled = add_decompose_small_values_scaled
+
+    def add_wrapping_decompose_small_values_scaled_dev(self, small_values, acc, value_count: int,
+                                                       small_value_modulus: int, factors, stream=None):
+        (pi, ni), (pa, na) = _dev(small_values), _dev(acc)
+        if ni != value_count:
+            raise PfheError(32, "small_values.len() must equal value_count")
+        f = self._factor_words(factors, self.moduli_count())
+        check(lib().pfhe_rns_add_wrapping_decompose_small_values_scaled_dev(self._h, pi, value_count, pa, na,
+                                                                            small_value_modulus, f.ctypes.data_as(u64p),
+                                                                            _stream(stream)))
+
+    def add_decompose_small_values_scaled_dev(self, small_values, acc, value_count: int, factors, stream=None):
+        (pi, ni), (pa, na) = _dev(small_values), _dev(acc)
+        if ni != value_count:
+            raise PfheError(32, "small_values.len() must equal value_count")
+        f = self._factor_words(factors, self.moduli_count())
+        check(lib().pfhe_rns_add_decompose_small_values_scaled_dev(self._h, pi, value_count, pa, na,
+                                                                   f.ctypes.data_as(u64p), _stream(stream)))
+
     def decompose_big_uint_values_to(self, big_uint_values, multi_residues, value_count: int):
         """base.rs:457-481: value_count little-endian big integers -> modulus-major residues."""
         pi, ni = _host(big_uint_values)
