@@ -282,6 +282,20 @@ class RNSBase {
         check(pfhe_rns_wrapping_decompose_small_values_to(h_, small_values, value_count, multi_residues, len_out,
                                                           small_value_modulus));
     }
+    // RNSBase::add_wrapping_decompose_small_values_scaled / add_decompose_small_values_scaled
+    // (crates/primus_rns/src/base.rs:326-416); factors = (value, quotient) per modulus
+    void add_wrapping_decompose_small_values_scaled(const uint64_t *small_values, size_t value_count, uint64_t *acc,
+                                                    size_t len_acc, uint64_t small_value_modulus,
+                                                    const std::vector<uint64_t> &factors) const {
+        if (factors.size() != 2 * moduli_count()) throw Error(PFHE_ERR_BAD_LENGTH, "expected one factor per modulus");
+        check(pfhe_rns_add_wrapping_decompose_small_values_scaled(h_, small_values, value_count, acc, len_acc,
+                                                                  small_value_modulus, factors.data()));
+    }
+    void add_decompose_small_values_scaled(const uint64_t *small_values, size_t value_count, uint64_t *acc, size_t len_acc,
+                                           const std::vector<uint64_t> &factors) const {
+        if (factors.size() != 2 * moduli_count()) throw Error(PFHE_ERR_BAD_LENGTH, "expected one factor per modulus");
+        check(pfhe_rns_add_decompose_small_values_scaled(h_, small_values, value_count, acc, len_acc, factors.data()));
+    }
     // RNSBase::decompose_big_uint_values_to (crates/primus_rns/src/base.rs:457-481)
     void decompose_big_uint_values_to(const uint64_t *big_uint_values, size_t len_in, uint64_t *multi_residues,
                                       size_t len_out, size_t value_count) const {
