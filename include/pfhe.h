@@ -337,6 +337,20 @@ int pfhe_basis_unsigned_decompose_slice_to_dev(const pfhe_basis *basis, size_t l
                                                const uint64_t *values_dev, size_t len,
                                                uint64_t *digits_dev, uint8_t *carries_dev,
                                                size_t count, void *stream);
+/* init_value_carry_slice_to — basis.rs:371-420: the out-of-place form (input untouched). */
+int pfhe_basis_init_value_carry_slice_to(const pfhe_basis *basis, const uint64_t *values, size_t len,
+                                         uint64_t *adjusted_values, uint8_t *carries, size_t count);
+int pfhe_basis_init_value_carry_slice_to_dev(const pfhe_basis *basis, const uint64_t *values_dev, size_t len,
+                                             uint64_t *adjusted_values_dev, uint8_t *carries_dev, size_t count,
+                                             void *stream);
+/* decomposer_iter().nth(level).decompose_slice_to — big_integer/common.rs:289-306 (-> decompose_to :255-272): the
+ * SIGNED digit as a residue modulo Q, big_uint_value_len limbs per value (a negative digit d is stored as Q + d);
+ * len_out must equal len; input and output must be distinct buffers. */
+int pfhe_basis_decompose_slice_to(const pfhe_basis *basis, size_t level, const uint64_t *values, size_t len,
+                                  uint64_t *decomposed_values, size_t len_out, uint8_t *carries, size_t count);
+int pfhe_basis_decompose_slice_to_dev(const pfhe_basis *basis, size_t level, const uint64_t *values_dev, size_t len,
+                                      uint64_t *decomposed_values_dev, size_t len_out, uint8_t *carries_dev,
+                                      size_t count, void *stream);
 
 /* =====================================================================================
  * RNS gadget external product — primus_lattice

@@ -162,6 +162,8 @@ def _load(path: str | None = None) -> C.CDLL:
         sig("orc_basis_" + g, _u64p, vp)
     sig("orc_basis_init_value_carry_slice_inplace", None, vp, _u64p, _u8p, sz)
     sig("orc_basis_unsigned_decompose_slice_to", None, vp, sz, _u64p, _u64p, _u8p, sz)
+    sig("orc_basis_init_value_carry_slice_to", None, vp, _u64p, _u64p, _u8p, sz)
+    sig("orc_basis_decompose_slice_to", None, vp, sz, _u64p, _u64p, _u8p, sz)
     sig("orc_add_dcrt_glev_mul_crt_poly_assign", None, vp, vp, vp, sz, _u64p, _u64p, _u64p)
     sig("orc_mul_dcrt_ggsw_to", None, vp, vp, vp, sz, _u64p, _u64p, _u64p)
     return lib
@@ -705,6 +707,18 @@ class BigUintApproxSignedBasis:
         lib().orc_basis_unsigned_decompose_slice_to(self._h, level, _p(values), _p(digits),
                                                     carries.ctypes.data_as(_u8p), count)
         return digits
+
+    def init_value_carry_slice_to(self, values, count):
+        """basis.rs:371-420: (adjusted values, carries), input untouched."""
+        adjusted, carries = np.empty_like(values), np.zeros(count, np.uint8)
+        lib().orc_basis_init_value_carry_slice_to(self._h, _p(values), _p(adjusted), carries.ctypes.data_as(_u8p), count)
+        return adjusted, carries
+
+    def decompose_slice_to(self, level, values, carries, count):
+        """common.rs:289-306: signed digits as residues modulo Q (value_len limbs each); carries updated."""
+        out = np.empty(values.size, np.uint64)
+        lib().orc_basis_decompose_slice_to(self._h, level, _p(values), _p(out), carries.ctypes.data_as(_u8p), count)
+        return out
 
 
 def add_dcrt_glev_mul_crt_poly_assign(table: U64DcrtTable, rns: RNSBase, basis, k, acc, glev, crt_poly):

@@ -1331,6 +1331,7 @@ struct orc_basis {
     size_t carry_index; uint64_t carry_bit_mask;
     uint64_t *scalars, *scalars_residue;
     value_mask_t *masks;
+    uint64_t *modulus_sub_basis; /* Q - B, value_len limbs (basis.rs:133-134) */
 };
 
 /* common.rs:83-103 */
@@ -1428,6 +1429,13 @@ int orc_basis_new(const orc_rns *rns, uint32_t log_basis, size_t reverse_length,
     b->scalars_residue = (uint64_t *)calloc(dlen * rns->count, sizeof(uint64_t));
     for (size_t j = 0; j < dlen; ++j) orc_rns_decompose_to(rns, b->scalars + j * len, b->scalars_residue + j * rns->count);
     /* value masks :175-181 */
+    b->modulus_sub_basis = (uint64_t *)calloc(len, sizeof(uint64_t)); /* basis.rs:133-134 */
+    {
+        uint64_t bv[64] = {0};
+        bv[0] = basis;
+        memcpy(b->modulus_sub_basis, modulus, len * sizeof(uint64_t));
+        (void)big_sub_assign(b->modulus_sub_basis, bv, len);
+    }
     b->masks = (value_mask_t *)malloc(dlen * sizeof(value_mask_t));
     b->masks[0] = value_mask_new(bm1, drop);
     for (size_t j = 1; j < dlen; ++j) b->masks[j] = value_mask_next(b->masks[j - 1], log_basis);
@@ -1437,7 +1445,7 @@ int orc_basis_new(const orc_rns *rns, uint32_t log_basis, size_t reverse_length,
 
 void orc_basis_free(orc_basis *b) {
     if (!b) return;
-    free(b->threshold); free(b->add); free(b->scalars); free(b->scalars_residue); free(b->masks); free(b);
+    free(b->threshold); free(b->add); free(b->scalars); free(b->scalars_residue); free(b->masks); free(b->modulus_sub_basis); free(b);
 }
 size_t orc_basis_decompose_length(const orc_basis *b) { return b->decompose_length; }
 uint32_t orc_basis_log_basis(const orc_basis *b) { return b->log_basis; }
@@ -1469,6 +1477,37 @@ void orc_basis_unsigned_decompose_slice_to(const orc_basis *b, size_t level, con
         uint64_t temp = value_mask_get(vm, values + c * b->value_len) + (uint64_t)carries[c];
         carries[c] = (uint8_t)((temp & b->carry_mask) != 0);
         digits[c] = temp & b->basis_minus_one;
+    }
+}
+
+/* basis.rs:371-420 (init_value_carry_slice_to): the out-of-place form */
+void orc_basis_init_value_carry_slice_to(const orc_basis *b, const uint64_t *values, uint64_t *adjusted,
+                                         uint8_t *carries, size_t count) {
+    memcpy(adjusted, values, count * b->value_len * sizeof(uint64_t));
+    orc_basis_init_value_carry_slice_inplace(b, adjusted, carries, count);
+}
+
+/* common.rs:255-272 (decompose_to) over a slice (:289-306): the SIGNED digit as a residue modulo Q — a digit
+ * temp with the carry set stands for temp - B, stored as (Q - B) + temp; temp == B is the digit 0. */
+void orc_basis_decompose_slice_to(const orc_basis *b, size_t level, const uint64_t *values, uint64_t *decomposed,
+                                  uint8_t *carries, size_t count) {
+    const value_mask_t *vm = &b->masks[level];
+    const size_t len = b->value_len;
+    for (size_t c = 0; c < count; ++c) {
+        uint64_t temp = value_mask_get(vm, values + c * len) + (uint64_t)carries[c];
+        uint64_t *d = decomposed + c * len;
+        carries[c] = (uint8_t)((temp & b->carry_mask) != 0);
+        memset(d, 0, len * sizeof(uint64_t));
+        if (carries[c]) {
+            if (temp <= b->basis_minus_one) {
+                uint64_t tv[64] = {0};
+                tv[0] = temp;
+                memcpy(d, b->modulus_sub_basis, len * sizeof(uint64_t));
+                (void)big_add_assign(d, tv, len);
+            }
+        } else {
+            d[0] = temp;
+        }
     }
 }
 

@@ -247,6 +247,10 @@ void orc_basis_init_value_carry_slice_inplace(const orc_basis *b, uint64_t *valu
 void orc_basis_unsigned_decompose_slice_to(const orc_basis *b, size_t level,
                                            const uint64_t *values, uint64_t *digits,
                                            uint8_t *carries, size_t count);
+void orc_basis_init_value_carry_slice_to(const orc_basis *b, const uint64_t *values, uint64_t *adjusted,
+                                         uint8_t *carries, size_t count);
+void orc_basis_decompose_slice_to(const orc_basis *b, size_t level, const uint64_t *values, uint64_t *decomposed,
+                                  uint8_t *carries, size_t count);
 
 /* ---------------- BaseConverter (primus_rns/src/converter.rs) ---------------- */
 typedef struct orc_conv orc_conv;

@@ -134,6 +134,10 @@ def _declare(lib: C.CDLL) -> None:
     sig("pfhe_basis_init_value_carry_slice_inplace_dev", ci, vp, vp, sz, vp, sz, vp)
     sig("pfhe_basis_unsigned_decompose_slice_to", ci, vp, sz, vp, sz, vp, vp, sz)
     sig("pfhe_basis_unsigned_decompose_slice_to_dev", ci, vp, sz, vp, sz, vp, vp, sz, vp)
+    sig("pfhe_basis_init_value_carry_slice_to", ci, vp, vp, sz, vp, vp, sz)
+    sig("pfhe_basis_init_value_carry_slice_to_dev", ci, vp, vp, sz, vp, vp, sz, vp)
+    sig("pfhe_basis_decompose_slice_to", ci, vp, sz, vp, sz, vp, sz, vp, sz)
+    sig("pfhe_basis_decompose_slice_to_dev", ci, vp, sz, vp, sz, vp, sz, vp, sz, vp)
     sig("pfhe_extprod_plan_create", ci, vp, vp, vp, sz, sz, C.POINTER(vp))
     sig("pfhe_extprod_plan_destroy", None, vp)
     sig("pfhe_extprod_plan_scratch_bytes", sz, vp)

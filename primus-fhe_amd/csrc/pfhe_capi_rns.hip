@@ -4,6 +4,8 @@
 #include <memory>
 #include <new>
 
+#include <cstring>
+
 #include "pfhe_capi_internal.hpp"
 #include "pfhe_ntt_device.hpp"
 #include "pfhe_rns.hpp"
@@ -436,6 +438,71 @@ int pfhe_basis_unsigned_decompose_slice_to(const pfhe_basis *b, size_t level, co
     PFHE_TRY(basis_unsigned_decompose_dev(b->h.dev, (u32)level, (const u64 *)v, (u64 *)d, (unsigned char *)c, count,
                                           nullptr));
     PFHE_HIP(hipMemcpy(digits, d, count * 8, hipMemcpyDeviceToHost));
+    PFHE_HIP(hipMemcpy(carries, c, count, hipMemcpyDeviceToHost));
+    return PFHE_OK;
+    PFHE_GUARD_END
+}
+
+int pfhe_basis_init_value_carry_slice_to_dev(const pfhe_basis *b, const uint64_t *values_dev, size_t len,
+                                             uint64_t *adjusted_dev, uint8_t *carries_dev, size_t count, void *stream) {
+    PFHE_GUARD_BEGIN
+    if (!b || ((!values_dev || !adjusted_dev || !carries_dev) && count)) return PFHE_ERR_BAD_ARGUMENT;
+    if (len != count * b->h.dev.value_len) return PFHE_ERR_BAD_LENGTH;  // basis.rs:378-379
+    if (count == 0) return PFHE_OK;
+    DeviceGuard g(b->h.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    if (adjusted_dev != values_dev)
+        PFHE_HIP(hipMemcpyAsync(adjusted_dev, values_dev, len * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return basis_init_value_carry_dev(b->h.dev, (u64 *)adjusted_dev, carries_dev, count, (hipStream_t)stream);
+    PFHE_GUARD_END
+}
+
+int pfhe_basis_init_value_carry_slice_to(const pfhe_basis *b, const uint64_t *values, size_t len, uint64_t *adjusted,
+                                         uint8_t *carries, size_t count) {
+    PFHE_GUARD_BEGIN
+    if (!b || ((!values || !adjusted || !carries) && count)) return PFHE_ERR_BAD_ARGUMENT;
+    if (len != count * b->h.dev.value_len) return PFHE_ERR_BAD_LENGTH;
+    if (count == 0) return PFHE_OK;
+    if (adjusted != values) std::memcpy(adjusted, values, len * 8);
+    return pfhe_basis_init_value_carry_slice_inplace(b, adjusted, len, carries, count);
+    PFHE_GUARD_END
+}
+
+int pfhe_basis_decompose_slice_to_dev(const pfhe_basis *b, size_t level, const uint64_t *values_dev, size_t len,
+                                      uint64_t *decomposed_dev, size_t len_out, uint8_t *carries_dev, size_t count,
+                                      void *stream) {
+    PFHE_GUARD_BEGIN
+    if (!b || ((!values_dev || !decomposed_dev || !carries_dev) && count)) return PFHE_ERR_BAD_ARGUMENT;
+    if (level >= b->h.dev.ell) return PFHE_ERR_BAD_ARGUMENT;
+    if (len != count * b->h.dev.value_len || len_out != len) return PFHE_ERR_BAD_LENGTH;  // common.rs:296-297
+    if (count && values_dev == decomposed_dev) {
+        set_last_error("decompose_slice_to needs distinct input and output buffers");
+        return PFHE_ERR_BAD_ARGUMENT;
+    }
+    DeviceGuard g(b->h.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    return basis_signed_decompose_dev(b->h.rns, b->h.dev, (u32)level, (const u64 *)values_dev, (u64 *)decomposed_dev,
+                                      carries_dev, count, (hipStream_t)stream);
+    PFHE_GUARD_END
+}
+
+int pfhe_basis_decompose_slice_to(const pfhe_basis *b, size_t level, const uint64_t *values, size_t len,
+                                  uint64_t *decomposed, size_t len_out, uint8_t *carries, size_t count) {
+    PFHE_GUARD_BEGIN
+    if (!b || ((!values || !decomposed || !carries) && count)) return PFHE_ERR_BAD_ARGUMENT;
+    if (level >= b->h.dev.ell) return PFHE_ERR_BAD_ARGUMENT;
+    if (len != count * b->h.dev.value_len || len_out != len) return PFHE_ERR_BAD_LENGTH;
+    if (count == 0) return PFHE_OK;
+    DeviceGuard g(b->h.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    Staging st;
+    void *v = nullptr, *d = nullptr, *c = nullptr;
+    PFHE_TRY(st.upload(values, len * 8, &v));
+    PFHE_TRY(st.alloc(len * 8, &d));
+    PFHE_TRY(st.upload(carries, count, &c));
+    PFHE_TRY(basis_signed_decompose_dev(b->h.rns, b->h.dev, (u32)level, (const u64 *)v, (u64 *)d, (unsigned char *)c, count,
+                                        nullptr));
+    PFHE_HIP(hipMemcpy(decomposed, d, len * 8, hipMemcpyDeviceToHost));
     PFHE_HIP(hipMemcpy(carries, c, count, hipMemcpyDeviceToHost));
     return PFHE_OK;
     PFHE_GUARD_END

@@ -114,6 +114,34 @@ __global__ __launch_bounds__(kThreads) void unsigned_decompose_kernel(BasisDev B
     digits[c] = temp & B.basis_minus_one;
 }
 
+// common.rs:255-272 over a slice (:289-306): the signed digit as a residue modulo Q.  With the carry set the digit
+// temp stands for temp - B and is stored as (Q - B) + temp; temp == B is the digit 0.
+__global__ __launch_bounds__(kThreads) void signed_decompose_kernel(RnsDev R, BasisDev B, u32 level,
+                                                                   const u64 *__restrict__ values,
+                                                                   u64 *__restrict__ out,
+                                                                   unsigned char *__restrict__ carries, u64 count) {
+    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= count) return;
+    const u32 len = B.value_len;
+    const u32 start = B.drop_bits + level * B.log_basis;
+    const u64 temp = window_dyn(values + c * len, start, B.basis_minus_one, B.log_basis) + carries[c];
+    const bool carry = (temp & B.carry_mask) != 0;
+    carries[c] = carry;
+    u64 *d = out + c * len;
+    if (carry && temp <= B.basis_minus_one) {
+        // Q - (B - temp), limb by limb with borrow (B - temp >= 1)
+        u64 sub = B.basis - temp;
+        for (u32 j = 0; j < len; ++j) {
+            const u64 q = R.Q[j];
+            d[j] = q - sub;
+            sub = q < sub ? 1 : 0;
+        }
+    } else {
+        for (u32 j = 0; j < len; ++j) d[j] = 0;
+        if (!carry) d[0] = temp;
+    }
+}
+
 // ---- fused steps (1)-(4): one thread per coefficient, big integer kept in registers ----
 template <int LEN>
 __global__ __launch_bounds__(kThreads) void gadget_decompose_kernel(RnsDev R, BasisDev B, u32 log_n,
@@ -270,6 +298,15 @@ int basis_unsigned_decompose_dev(const BasisDev &b, u32 level, const u64 *values
     if (count == 0) return PFHE_OK;
     hipLaunchKernelGGL(unsigned_decompose_kernel, dim3(grid_for(count)), dim3(kThreads), 0, s, b, level, values, digits,
                        carries, count);
+    PFHE_HIP(hipGetLastError());
+    return PFHE_OK;
+}
+
+int basis_signed_decompose_dev(const RnsDev &r, const BasisDev &b, u32 level, const u64 *values, u64 *decomposed,
+                               unsigned char *carries, u64 count, hipStream_t s) {
+    if (count == 0) return PFHE_OK;
+    hipLaunchKernelGGL(signed_decompose_kernel, dim3(grid_for(count)), dim3(kThreads), 0, s, r, b, level, values,
+                       decomposed, carries, count);
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
 }

@@ -57,6 +57,9 @@ int rns_add_decompose_scaled_dev(const RnsDev &r, const u64 *small_values, u64 *
 int basis_init_value_carry_dev(const BasisDev &b, u64 *values, unsigned char *carries, u64 count, hipStream_t s);
 int basis_unsigned_decompose_dev(const BasisDev &b, u32 level, const u64 *values, u64 *digits,
                                  unsigned char *carries, u64 count, hipStream_t s);
+// signed digits as residues modulo Q, value_len limbs each (common.rs:255-272, 289-306)
+int basis_signed_decompose_dev(const RnsDev &r, const BasisDev &b, u32 level, const u64 *values, u64 *decomposed,
+                               unsigned char *carries, u64 count, hipStream_t s);
 // Fused steps (1)-(4) of add_dcrt_glev_mul_crt_poly_assign (glwe/dcrt.rs:219-244) for `npolys` CRT
 // polynomials of L*N words: writes, per input polynomial, ell digit polynomials in CRT form
 // (centred lift), laid out [poly][level][limb][N].

@@ -213,6 +213,33 @@ class BigUintApproxSignedBasis:
         check(lib().pfhe_basis_init_value_carry_slice_inplace(self._h, pv, nv, carries.ctypes.data_as(C.c_void_p),
                                                               carries.size))
 
+    def init_value_carry_slice_to(self, big_uint_values, adjust_big_uint_values, carries):
+        """basis.rs:371-420: out-of-place form of init_value_carry_slice_inplace."""
+        (pv, nv), (pa, na) = _host(big_uint_values), _host(adjust_big_uint_values)
+        assert carries.dtype in (np.uint8, np.bool_) and carries.flags.c_contiguous
+        if na != nv:
+            raise PfheError(32, "values and adjusted values differ in length")
+        check(lib().pfhe_basis_init_value_carry_slice_to(self._h, pv, nv, pa, carries.ctypes.data_as(C.c_void_p),
+                                                         carries.size))
+
+    def decompose_slice_to(self, level: int, big_uint_values, decomposed_big_uint_values, carries):
+        """decomposer_iter().nth(level).decompose_slice_to(...) — common.rs:289-306: signed digits modulo Q."""
+        (pv, nv), (pd, nd) = _host(big_uint_values), _host(decomposed_big_uint_values)
+        check(lib().pfhe_basis_decompose_slice_to(self._h, level, pv, nv, pd, nd, carries.ctypes.data_as(C.c_void_p),
+                                                  carries.size))
+
+    def init_value_carry_slice_to_dev(self, values, adjusted, carries, stream=None):
+        (pv, nv), (pa, na) = _dev(values), _dev(adjusted)
+        if na != nv:
+            raise PfheError(32, "values and adjusted values differ in length")
+        check(lib().pfhe_basis_init_value_carry_slice_to_dev(self._h, pv, nv, pa, C.c_void_p(carries.data_ptr()),
+                                                             carries.numel(), _stream(stream)))
+
+    def decompose_slice_to_dev(self, level: int, values, decomposed, carries, stream=None):
+        (pv, nv), (pd, nd) = _dev(values), _dev(decomposed)
+        check(lib().pfhe_basis_decompose_slice_to_dev(self._h, level, pv, nv, pd, nd, C.c_void_p(carries.data_ptr()),
+                                                      carries.numel(), _stream(stream)))
+
     def unsigned_decompose_slice_to(self, level: int, big_uint_values, decomposed_unsigned_values, carries):
         """decomposer_iter().nth(level).unsigned_decompose_slice_to(...) — common.rs:309-325."""
         pv, nv = _host(big_uint_values)
