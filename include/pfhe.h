@@ -388,6 +388,16 @@ int pfhe_extprod_add_dcrt_glev_mul_crt_poly_assign_dev(pfhe_extprod_plan *plan, 
 int pfhe_extprod_glev_mul_crt_poly_to_dev(pfhe_extprod_plan *plan, const uint64_t *dcrt_glev_dev,
                                           size_t len_glev, const uint64_t *crt_poly_dev, size_t len_poly,
                                           uint64_t *result_dev, size_t len_result, void *stream);
+/* The same two products with the polynomial given as a BigUintPolynomial (big_uint_value_len limbs per
+ * coefficient, canonical modulo Q): DcrtGlwe::add_dcrt_glev_mul_big_uint_poly_assign — glwe/dcrt.rs:258-338 — and
+ * DcrtGlev::mul_big_uint_poly_to — glev/dcrt.rs:113-175.  len_poly = batch * big_uint_value_len * N. */
+int pfhe_extprod_add_dcrt_glev_mul_big_uint_poly_assign_dev(pfhe_extprod_plan *plan, uint64_t *acc_dev, size_t len_acc,
+                                                            const uint64_t *dcrt_glev_dev, size_t len_glev,
+                                                            const uint64_t *big_uint_poly_dev, size_t len_poly,
+                                                            void *stream);
+int pfhe_extprod_glev_mul_big_uint_poly_to_dev(pfhe_extprod_plan *plan, const uint64_t *dcrt_glev_dev, size_t len_glev,
+                                               const uint64_t *big_uint_poly_dev, size_t len_poly, uint64_t *result_dev,
+                                               size_t len_result, void *stream);
 
 /* Profiling hooks (bench.py / rocprofv3): a transform is executed as a short sequence of kernel
  * passes (DESIGN.md "Kernels"); these run or name ONE pass so that each kernel can be timed with

@@ -165,6 +165,7 @@ def _load(path: str | None = None) -> C.CDLL:
     sig("orc_basis_init_value_carry_slice_to", None, vp, _u64p, _u64p, _u8p, sz)
     sig("orc_basis_decompose_slice_to", None, vp, sz, _u64p, _u64p, _u8p, sz)
     sig("orc_add_dcrt_glev_mul_crt_poly_assign", None, vp, vp, vp, sz, _u64p, _u64p, _u64p)
+    sig("orc_add_dcrt_glev_mul_big_uint_poly_assign", None, vp, vp, vp, sz, _u64p, _u64p, _u64p)
     sig("orc_mul_dcrt_ggsw_to", None, vp, vp, vp, sz, _u64p, _u64p, _u64p)
     return lib
 
@@ -723,6 +724,11 @@ class BigUintApproxSignedBasis:
 
 def add_dcrt_glev_mul_crt_poly_assign(table: U64DcrtTable, rns: RNSBase, basis, k, acc, glev, crt_poly):
     lib().orc_add_dcrt_glev_mul_crt_poly_assign(table._h, rns._h, basis._h, k, _p(acc), _p(glev), _p(crt_poly))
+
+
+def add_dcrt_glev_mul_big_uint_poly_assign(table: U64DcrtTable, rns: RNSBase, basis, k, acc, glev, big_uint_poly):
+    """glwe/dcrt.rs:258-338: the polynomial as value_len-limb big integers modulo Q."""
+    lib().orc_add_dcrt_glev_mul_big_uint_poly_assign(table._h, rns._h, basis._h, k, _p(acc), _p(glev), _p(big_uint_poly))
 
 
 def mul_dcrt_ggsw_to(table: U64DcrtTable, rns: RNSBase, basis, k, crt_glwe, dcrt_ggsw):

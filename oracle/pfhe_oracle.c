@@ -1539,6 +1539,28 @@ void orc_add_dcrt_glev_mul_crt_poly_assign(const orc_dcrt *table, const orc_rns 
     free(adjust); free(digits); free(carries); free(multi);
 }
 
+/* glwe/dcrt.rs:258-338 (and glev/dcrt.rs:113-175 when acc starts at zero): as above with the polynomial given as
+ * big integers modulo Q — init_value_carry_slice_to replaces compose + init_value_carry_slice_inplace */
+void orc_add_dcrt_glev_mul_big_uint_poly_assign(const orc_dcrt *table, const orc_rns *rns, const orc_basis *basis,
+                                                size_t k, uint64_t *acc, const uint64_t *dcrt_glev,
+                                                const uint64_t *big_uint_poly) {
+    const size_t n = table->n, L = table->count, W = L * n, len = rns->value_len;
+    const size_t glwe_len = (k + 1) * W;
+    uint64_t *adjust = (uint64_t *)malloc(n * len * sizeof(uint64_t));
+    uint64_t *digits = (uint64_t *)malloc(n * sizeof(uint64_t));
+    uint8_t *carries = (uint8_t *)malloc(n);
+    uint64_t *multi = (uint64_t *)malloc(W * sizeof(uint64_t));
+    orc_basis_init_value_carry_slice_to(basis, big_uint_poly, adjust, carries, n); /* :301-306 */
+    for (size_t j = 0; j < basis->decompose_length; ++j) {                         /* :308-337 */
+        const uint64_t *glwe = dcrt_glev + j * glwe_len;
+        orc_basis_unsigned_decompose_slice_to(basis, j, adjust, digits, carries, n);
+        orc_rns_wrapping_decompose_small_values_to(rns, digits, multi, n, basis->basis);
+        orc_dcrt_transform_slice(table, multi);
+        for (size_t c = 0; c <= k; ++c) orc_dcrt_poly_add_mul_assign(table, acc + c * W, glwe + c * W, multi);
+    }
+    free(adjust); free(digits); free(carries); free(multi);
+}
+
 /* glwe/crt.rs:200-227 */
 void orc_mul_dcrt_ggsw_to(const orc_dcrt *table, const orc_rns *rns, const orc_basis *basis, size_t k,
                           const uint64_t *crt_glwe, const uint64_t *dcrt_ggsw, uint64_t *result) {

@@ -272,6 +272,9 @@ void orc_add_dcrt_glev_mul_crt_poly_assign(const orc_dcrt *table, const orc_rns 
                                            uint64_t *acc, const uint64_t *dcrt_glev,
                                            const uint64_t *crt_poly);
 /* CrtGlwe::mul_dcrt_ggsw_to, glwe/crt.rs:200-227.  result stays in DCRT (NTT) form. */
+void orc_add_dcrt_glev_mul_big_uint_poly_assign(const orc_dcrt *table, const orc_rns *rns, const orc_basis *basis,
+                                                size_t k, uint64_t *acc, const uint64_t *dcrt_glev,
+                                                const uint64_t *big_uint_poly);
 void orc_mul_dcrt_ggsw_to(const orc_dcrt *table, const orc_rns *rns, const orc_basis *basis,
                           size_t glwe_dimension, const uint64_t *crt_glwe,
                           const uint64_t *dcrt_ggsw, uint64_t *result);

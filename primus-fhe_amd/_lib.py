@@ -145,6 +145,8 @@ def _declare(lib: C.CDLL) -> None:
     sig("pfhe_extprod_mul_dcrt_ggsw_to_dev", ci, vp, vp, sz, vp, sz, vp, sz, ci, vp)
     sig("pfhe_extprod_add_dcrt_glev_mul_crt_poly_assign_dev", ci, vp, vp, sz, vp, sz, vp, sz, vp)
     sig("pfhe_extprod_glev_mul_crt_poly_to_dev", ci, vp, vp, sz, vp, sz, vp, sz, vp)
+    sig("pfhe_extprod_add_dcrt_glev_mul_big_uint_poly_assign_dev", ci, vp, vp, sz, vp, sz, vp, sz, vp)
+    sig("pfhe_extprod_glev_mul_big_uint_poly_to_dev", ci, vp, vp, sz, vp, sz, vp, sz, vp)
     sig("pfhe_dcrt_transform_num_passes", ci, vp)
     sig("pfhe_dcrt_transform_pass_name", C.c_char_p, vp, ci, ci)
     sig("pfhe_dcrt_transform_pass_dev", ci, vp, vp, sz, ci, ci, ci, vp)

@@ -77,11 +77,16 @@ int plan_check(const pfhe_extprod_plan *p) {
 // Chunks of ciphertexts are software-pipelined over the plan's two streams and two digit buffers.
 // `into_coeff`: the caller wants coefficient-form output; *coeff_done reports whether this function already
 // produced it (small-ring kernel) or the caller still has to run the inverse transform.
+// `big_input`: the input polynomials are BigUintPolynomials (value_len limbs per coefficient) instead of CRT ones.
 int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 *keys, bool keys_shared, u64 *result,
-                u64 batch, bool accumulate, hipStream_t s, bool into_coeff = false, bool *coeff_done = nullptr) {
+                u64 batch, bool accumulate, hipStream_t s, bool into_coeff = false, bool *coeff_done = nullptr,
+                bool big_input = false) {
     if (coeff_done) *coeff_done = false;
     const TableSet &t = *p->table;
     const u64 W = (u64)t.L * t.n;
+    RnsDev rns = p->rns;
+    rns.big_input = big_input ? 1u : 0u;
+    const u64 in_words = big_input ? (u64)rns.value_len * t.n : W;  // words per input polynomial
     const u32 ell = p->basis.ell;
     const u64 key_words = (u64)rows * ell * (p->k + 1) * W;
     // a single chunk has nothing to pipeline: run it on the caller's stream without the fork/join events
@@ -93,7 +98,7 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
         batch * t.L >= 1024 && std::getenv("PFHE_DISABLE_SMALL_EXTPROD") == nullptr) {
         for (u64 done = 0; done < batch; done += p->chunk) {
             const u64 cur = std::min<u64>(p->chunk, batch - done);
-            PFHE_TRY(gadget_signed_digits_dev(p->rns, p->basis, t.log_n, crt_polys + done * rows * W, p->sdigits, cur * rows, s));
+            PFHE_TRY(gadget_signed_digits_dev(rns, p->basis, t.log_n, crt_polys + done * rows * in_words, p->sdigits, cur * rows, s));
             PFHE_TRY(extprod_small_dev(t.primes_dev, t.L, t.log_n, t.pm, p->k, rows, ell, p->sdigits,
                                        keys + (keys_shared ? 0 : done * key_words), keys_shared,
                                        result + done * (p->k + 1) * W, cur, accumulate, into_coeff, s));
@@ -135,10 +140,10 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
         // ---- stream a: steps (1)-(4) + strided passes into digit buffer `buf` ----
         if (fused && index >= 2 && !single) PFHE_HIP(hipStreamWaitEvent(sa, p->consumed[buf], 0));
         if (fused_decompose) {
-            PFHE_TRY(gadget_decompose_strided_dev(p->rns, p->basis, t.primes_dev, t.log_n, t.pm,
-                                                  crt_polys + done * rows * W, dg, cur * rows, sa, p->sdigits));
+            PFHE_TRY(gadget_decompose_strided_dev(rns, p->basis, t.primes_dev, t.log_n, t.pm,
+                                                  crt_polys + done * rows * in_words, dg, cur * rows, sa, p->sdigits));
         } else {
-            PFHE_TRY(gadget_decompose_dev(p->rns, p->basis, t.log_n, crt_polys + done * rows * W, dg, cur * rows, sa));
+            PFHE_TRY(gadget_decompose_dev(rns, p->basis, t.log_n, crt_polys + done * rows * in_words, dg, cur * rows, sa));
             for (int i = 0; i < passes - 1; ++i)
                 PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.pm, dg, npolys, false, i, false, sa));
         }
@@ -661,6 +666,50 @@ int pfhe_extprod_glev_mul_crt_poly_to_dev(pfhe_extprod_plan *plan, const uint64_
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
     return run_product(plan, (const u64 *)crt_poly_dev, 1, (const u64 *)dcrt_glev_dev, len_glev == glev,
                        (u64 *)result_dev, batch, false, (hipStream_t)stream);
+    PFHE_GUARD_END
+}
+
+// DcrtGlwe::add_dcrt_glev_mul_big_uint_poly_assign (glwe/dcrt.rs:258-338) / DcrtGlev::mul_big_uint_poly_to
+// (glev/dcrt.rs:113-175): the GLev rows against polynomials given as big integers modulo Q
+static int glev_big_uint_common(pfhe_extprod_plan *plan, uint64_t *out_dev, size_t len_out, const uint64_t *dcrt_glev_dev,
+                                size_t len_glev, const uint64_t *big_uint_poly_dev, size_t len_poly, bool accumulate,
+                                void *stream) {
+    PFHE_TRY(plan_check(plan));
+    const TableSet &t = *plan->table;
+    const size_t W = (size_t)t.L * t.n, glwe = (plan->k + 1) * W, glev = plan->basis.ell * glwe;
+    const size_t in_words = (size_t)plan->rns.value_len * t.n;
+    if (len_poly % in_words != 0) return PFHE_ERR_BAD_LENGTH;  // glwe/dcrt.rs:277
+    const u64 batch = len_poly / in_words;
+    if (len_out != batch * glwe || (len_glev != glev && len_glev != batch * glev)) {
+        set_last_error("glev product: acc/result must be batch*(k+1)*L*N words and the GLev one or batch of ell*(k+1)*L*N");
+        return PFHE_ERR_BAD_LENGTH;
+    }
+    if (batch == 0) return PFHE_OK;
+    if (!out_dev || !dcrt_glev_dev || !big_uint_poly_dev) return PFHE_ERR_BAD_ARGUMENT;
+    PFHE_REQUIRE_ALIGNED(out_dev);
+    PFHE_REQUIRE_ALIGNED(dcrt_glev_dev);
+    PFHE_REQUIRE_ALIGNED(big_uint_poly_dev);
+    DeviceGuard g(t.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    return run_product(plan, (const u64 *)big_uint_poly_dev, 1, (const u64 *)dcrt_glev_dev, len_glev == glev,
+                       (u64 *)out_dev, batch, accumulate, (hipStream_t)stream, false, nullptr, true);
+}
+
+int pfhe_extprod_add_dcrt_glev_mul_big_uint_poly_assign_dev(pfhe_extprod_plan *plan, uint64_t *acc_dev, size_t len_acc,
+                                                            const uint64_t *dcrt_glev_dev, size_t len_glev,
+                                                            const uint64_t *big_uint_poly_dev, size_t len_poly,
+                                                            void *stream) {
+    PFHE_GUARD_BEGIN
+    return glev_big_uint_common(plan, acc_dev, len_acc, dcrt_glev_dev, len_glev, big_uint_poly_dev, len_poly, true, stream);
+    PFHE_GUARD_END
+}
+
+int pfhe_extprod_glev_mul_big_uint_poly_to_dev(pfhe_extprod_plan *plan, const uint64_t *dcrt_glev_dev, size_t len_glev,
+                                               const uint64_t *big_uint_poly_dev, size_t len_poly, uint64_t *result_dev,
+                                               size_t len_result, void *stream) {
+    PFHE_GUARD_BEGIN
+    return glev_big_uint_common(plan, result_dev, len_result, dcrt_glev_dev, len_glev, big_uint_poly_dev, len_poly, false,
+                                stream);
     PFHE_GUARD_END
 }
 

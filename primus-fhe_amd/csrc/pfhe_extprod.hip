@@ -150,9 +150,15 @@ __global__ __launch_bounds__(256) void gadget_decompose_strided_kernel(RnsDev R,
     u32 carries = 0;
 #pragma unroll
     for (int k = 0; k < RK; ++k) {
-        u64 r[kMaxLimbs];
-        for (u32 i = 0; i < R.L; ++i) r[i] = in[(u64)i * n + ((u64)k << log_s)];
-        compose<LEN>(R, r, v[k]);
+        if (R.big_input) {
+            const u64 *__restrict__ big = crt + (poly * n + col + ((u64)k << log_s)) * LEN;
+#pragma unroll
+            for (int j = 0; j < LEN; ++j) v[k][j] = big[j];
+        } else {
+            u64 r[kMaxLimbs];
+            for (u32 i = 0; i < R.L; ++i) r[i] = in[(u64)i * n + ((u64)k << log_s)];
+            compose<LEN>(R, r, v[k]);
+        }
         carries |= init_value_carry<LEN>(B, v[k]) << k;
     }
     const u64 half = (B.basis + 1) / 2;
@@ -204,10 +210,15 @@ __global__ __launch_bounds__(256) void gadget_signed_digits_kernel(RnsDev R, Bas
     const u32 n = 1u << log_n;
     const u64 poly = gid >> log_n;
     const u32 t = (u32)(gid & (n - 1));
-    u64 r[kMaxLimbs];
-    for (u32 i = 0; i < R.L; ++i) r[i] = crt[(poly * R.L + i) * n + t];
     u64 v[LEN];
-    compose<LEN>(R, r, v);
+    if (R.big_input) {  // BigUintPolynomial input (glwe/dcrt.rs:258-338): already composed
+#pragma unroll
+        for (int j = 0; j < LEN; ++j) v[j] = crt[(poly * n + t) * LEN + j];
+    } else {
+        u64 r[kMaxLimbs];
+        for (u32 i = 0; i < R.L; ++i) r[i] = crt[(poly * R.L + i) * n + t];
+        compose<LEN>(R, r, v);
+    }
     u32 carry = init_value_carry<LEN>(B, v);
     const u64 half = (B.basis + 1) / 2;
     int *__restrict__ o = out + poly * B.ell * n + t;

@@ -151,11 +151,16 @@ __global__ __launch_bounds__(kThreads) void gadget_decompose_kernel(RnsDev R, Ba
     if (gid >= total) return;
     const u64 n = 1ull << log_n;
     const u64 poly = gid >> log_n, t = gid & (n - 1);
-    const u64 *__restrict__ in = crt + poly * R.L * n + t;
-    u64 r[kMaxLimbs];
-    for (u32 i = 0; i < R.L; ++i) r[i] = in[(u64)i * n];
     u64 v[LEN];
-    compose<LEN>(R, r, v);
+    if (R.big_input) {  // glwe/dcrt.rs:258-338: the polynomial arrives composed
+#pragma unroll
+        for (int j = 0; j < LEN; ++j) v[j] = crt[(poly * n + t) * LEN + j];
+    } else {
+        const u64 *__restrict__ in = crt + poly * R.L * n + t;
+        u64 r[kMaxLimbs];
+        for (u32 i = 0; i < R.L; ++i) r[i] = in[(u64)i * n];
+        compose<LEN>(R, r, v);
+    }
     u32 carry = init_value_carry<LEN>(B, v);
     const u64 half = (B.basis + 1) / 2;
     u64 *__restrict__ o = out + poly * B.ell * R.L * n + t;

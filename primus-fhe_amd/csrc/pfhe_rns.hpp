@@ -13,6 +13,9 @@ constexpr int kMaxLimbs = 8;  // RNS moduli / big-integer limbs supported by the
 // RNSBase<u64, BarrettModulus<u64>> constants (primus_rns/src/base.rs:26-117), passed by value.
 struct RnsDev {
     u32 L, value_len;
+    // 1: the decomposition kernels read their input as big integers (value_len limbs per coefficient,
+    // coefficient-major: BigUintPolynomial) instead of composing it from L residues (CrtPolynomial)
+    u32 big_input, pad_;
     u64 q[kMaxLimbs];
     u64 inv_punct[kMaxLimbs], inv_punct_p[kMaxLimbs];  // (Q/q_i)^-1 mod q_i and its Shoup quotient
     u64 punct[kMaxLimbs][kMaxLimbs];                    // Q/q_i, little-endian limbs

@@ -70,3 +70,17 @@ def glev_mul_crt_poly_to_dev(dcrt_glev, crt_poly, result, context: DcrtGlevConte
     """DcrtGlev::mul_crt_poly_to (primus_lattice/src/glev/dcrt.rs:45-110): result = glev (x) crt_poly."""
     (pg, ng), (pp, np_), (pr, nr) = _dev(dcrt_glev), _dev(crt_poly), _dev(result)
     check(lib().pfhe_extprod_glev_mul_crt_poly_to_dev(context._h, pg, ng, pp, np_, pr, nr, _stream(stream)))
+
+
+def add_dcrt_glev_mul_big_uint_poly_assign_dev(acc, dcrt_glev, big_uint_poly, context: DcrtGlevContext, stream=None):
+    """DcrtGlwe::add_dcrt_glev_mul_big_uint_poly_assign (glwe/dcrt.rs:258-338): acc += glev (x) big_uint_poly, the
+    polynomial given as big integers modulo Q (big_uint_value_len limbs per coefficient)."""
+    (pc, nc), (pg, ng), (pp, np_) = _dev(acc), _dev(dcrt_glev), _dev(big_uint_poly)
+    check(lib().pfhe_extprod_add_dcrt_glev_mul_big_uint_poly_assign_dev(context._h, pc, nc, pg, ng, pp, np_,
+                                                                        _stream(stream)))
+
+
+def glev_mul_big_uint_poly_to_dev(dcrt_glev, big_uint_poly, result, context: DcrtGlevContext, stream=None):
+    """DcrtGlev::mul_big_uint_poly_to (primus_lattice/src/glev/dcrt.rs:113-175): result = glev (x) big_uint_poly."""
+    (pg, ng), (pp, np_), (pr, nr) = _dev(dcrt_glev), _dev(big_uint_poly), _dev(result)
+    check(lib().pfhe_extprod_glev_mul_big_uint_poly_to_dev(context._h, pg, ng, pp, np_, pr, nr, _stream(stream)))
