@@ -191,6 +191,11 @@ int pfhe_dcrt_add_dcrt_glwe_mul_dcrt_polynomial_assign_dev(const pfhe_dcrt *tabl
                                                            const uint64_t *dcrt_poly_dev,
                                                            size_t len_poly, size_t glwe_polys,
                                                            void *stream);
+/* DcrtGlwe::mul_dcrt_polynomial_to — glwe/dcrt.rs:377-395, batched the same way:
+ * result[e][c] = dcrt_glwe[e][c] * dcrt_poly[e]; result may alias dcrt_glwe. */
+int pfhe_dcrt_glwe_mul_dcrt_polynomial_to_dev(const pfhe_dcrt *table, const uint64_t *dcrt_glwe_dev, size_t len,
+                                              const uint64_t *dcrt_poly_dev, size_t len_poly, size_t glwe_polys,
+                                              uint64_t *result_dev, void *stream);
 /* DcrtPolynomial::mul_to (primus_poly/src/dcrt/mul.rs:232-250) and the out-of-place
  * multiply-add: out = a*b, out = a*b + c (out may alias an input). */
 int pfhe_dcrt_mul_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, size_t len_a,

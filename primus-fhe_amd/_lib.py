@@ -155,6 +155,7 @@ def _declare(lib: C.CDLL) -> None:
         sig(pre + "mul_to_dev", ci, vp, vp, sz, vp, sz, vp, vp)
         sig(pre + "mul_add_to_dev", ci, vp, vp, sz, vp, sz, vp, vp, vp)
     sig("pfhe_dcrt_add_dcrt_glwe_mul_dcrt_polynomial_assign_dev", ci, vp, vp, vp, sz, vp, sz, sz, vp)
+    sig("pfhe_dcrt_glwe_mul_dcrt_polynomial_to_dev", ci, vp, vp, sz, vp, sz, sz, vp, vp)
     sig("pfhe_conv_create", ci, vp, vp, C.POINTER(vp))
     sig("pfhe_conv_destroy", None, vp)
     sig("pfhe_conv_input_moduli_count", sz, vp)

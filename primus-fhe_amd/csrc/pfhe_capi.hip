@@ -683,6 +683,28 @@ int pfhe_dcrt_add_dcrt_glwe_mul_dcrt_polynomial_assign_dev(const pfhe_dcrt *tabl
     PFHE_GUARD_END
 }
 
+int pfhe_dcrt_glwe_mul_dcrt_polynomial_to_dev(const pfhe_dcrt *table, const uint64_t *dcrt_glwe_dev, size_t len,
+                                              const uint64_t *dcrt_poly_dev, size_t len_poly, size_t glwe_polys,
+                                              uint64_t *result_dev, void *stream) {
+    PFHE_GUARD_BEGIN
+    if (!table || glwe_polys == 0 || ((!result_dev || !dcrt_glwe_dev || !dcrt_poly_dev) && len)) return PFHE_ERR_BAD_ARGUMENT;
+    PFHE_REQUIRE_ALIGNED(result_dev);
+    PFHE_REQUIRE_ALIGNED(dcrt_glwe_dev);
+    PFHE_REQUIRE_ALIGNED(dcrt_poly_dev);
+    const TableSet &t = *table->t;
+    const size_t unit = t.n * t.L;
+    if (len % (unit * glwe_polys) != 0 || len_poly != len / glwe_polys) {
+        set_last_error("expected batch*(k+1) polynomials in the glwe / result and batch polynomials in dcrt_poly");
+        return PFHE_ERR_BAD_LENGTH;
+    }
+    if (len == 0) return PFHE_OK;
+    DeviceGuard g(t.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    return pointwise_dev((u64 *)result_dev, (const u64 *)dcrt_glwe_dev, (const u64 *)dcrt_poly_dev, nullptr, t.primes_dev,
+                         t.L, t.log_n, len, len_poly, (hipStream_t)stream, (u64)unit * glwe_polys, t.pm);
+    PFHE_GUARD_END
+}
+
 int pfhe_dcrt_transform_num_passes(const pfhe_dcrt *table) {
     return table ? ntt_num_passes(table->t->log_n) : 0;
 }

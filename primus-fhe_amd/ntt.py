@@ -291,6 +291,14 @@ class U64DcrtTable:
         (pa, po), n = self._same_len(a, out)
         check(lib().pfhe_dcrt_inv_to_dev(self._h, pa, po, n, _stream(stream)))
 
+    def glwe_mul_dcrt_polynomial_to_dev(self, dcrt_glwe, dcrt_poly, result, glwe_polys: int, stream=None):
+        """DcrtGlwe::mul_dcrt_polynomial_to (primus_lattice/src/glwe/dcrt.rs:377-395) over a batch:
+        result[e][c] = dcrt_glwe[e][c] * dcrt_poly[e], c < glwe_polys = k + 1."""
+        (pa, na), (pb, nb), (pr, nr) = _dev(dcrt_glwe), _dev(dcrt_poly), _dev(result)
+        if nr != na:
+            raise PfheError(32, "result and ciphertext differ in length")
+        check(lib().pfhe_dcrt_glwe_mul_dcrt_polynomial_to_dev(self._h, pa, na, pb, nb, glwe_polys, pr, _stream(stream)))
+
     def butterfly_mul_dcrt_polynomial_to_dev(self, a, rhs, dcrt_poly, result, stream=None):
         """DcrtGlwe::butterfly_mul_dcrt_polynomial_to (primus_lattice/src/glwe/dcrt.rs:128-155):
         (a, result) = (a + rhs, (a_orig - rhs) * dcrt_poly)."""

@@ -396,6 +396,17 @@ def test_add_dcrt_glwe_mul_dcrt_polynomial_assign(pf, orc, log_n, moduli, k, bat
     dacc = to_dev(acc)
     d.add_dcrt_glwe_mul_dcrt_polynomial_assign_dev(dacc, to_dev(glwe), to_dev(poly), k + 1)
     assert np.array_equal(to_host(dacc), exp)
+    # DcrtGlwe::mul_dcrt_polynomial_to (glwe/dcrt.rs:377-395), batched the same way; result may alias the input
+    expm = glwe.copy()
+    for e in range(batch):
+        for c in range(k + 1):
+            s = slice((e * (k + 1) + c) * W, (e * (k + 1) + c + 1) * W)
+            o.mul_assign(expm[s], poly[e * W:(e + 1) * W])
+    dg, dres = to_dev(glwe), to_dev(acc)
+    d.glwe_mul_dcrt_polynomial_to_dev(dg, to_dev(poly), dres, k + 1)
+    assert np.array_equal(to_host(dres), expm) and np.array_equal(to_host(dg), glwe)
+    d.glwe_mul_dcrt_polynomial_to_dev(dg, to_dev(poly), dg, k + 1)
+    assert np.array_equal(to_host(dg), expm)
     with pytest.raises(pf.PfheError) as e:
         d.add_dcrt_glwe_mul_dcrt_polynomial_assign_dev(dacc, to_dev(glwe), to_dev(poly[:-W].copy()), k + 1)
     assert e.value.kind == "BadLength"
