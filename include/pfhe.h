@@ -251,7 +251,8 @@ int pfhe_dcrt_mul_factor_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, c
 int pfhe_dcrt_add_mul_factor_assign_dev(const pfhe_dcrt *table, uint64_t *acc_dev, const uint64_t *rhs_dev,
                                         const uint64_t *factors, size_t len, void *stream);
 /* self * X^r, 0 <= r < 2N, per N-word polynomial (rotate_right + negation of the wrapped part).  The _to form
- * needs out != a and moves each word once; the in-place form goes through a stream-ordered scratch tile. */
+ * needs out != a and moves each word once; the in-place form keeps a polynomial in one workgroup's registers for
+ * 2^9 <= N <= 2^14 and goes through a stream-ordered scratch tile (twice the traffic, not capturable) otherwise. */
 int pfhe_dcrt_mul_monomial_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, size_t r, uint64_t *out_dev,
                                   size_t len, void *stream);
 int pfhe_dcrt_mul_monomial_assign_dev(const pfhe_dcrt *table, uint64_t *data_dev, size_t r, size_t len, void *stream);

@@ -15,6 +15,7 @@
 //   inv                       dcrt/inv.rs:19-68 -> Montgomery batch inversion (barrett/slice.rs:505-558); here each
 //                             thread inverts the product of 16 strided elements of one limb polynomial
 #include <algorithm>
+#include <cstdlib>
 
 #include "pfhe_capi_internal.hpp"
 #include "pfhe_modmath.hpp"
@@ -157,6 +158,31 @@ __global__ __launch_bounds__(kEwThreads) void monomial_rotate_kernel(u64 *__rest
         }
         if constexpr (PAIR) ew_store(out + i, ew_vec{r[0], r[1]});
         else out[i] = r[0];
+    }
+}
+
+// In-place X^r for rings that fit one workgroup's registers (2^9 <= N <= 2^14): a workgroup owns one N-word
+// polynomial, every thread loads its WPT words (lane-consecutive 8-byte accesses), the workgroup waits until all
+// of them have arrived, and only then are the rotated (and, past the wrap, negated) words written back.
+template <int WPT>
+__global__ __launch_bounds__(1024) void monomial_inplace_kernel(u64 *__restrict__ data, const NttPrime *__restrict__ primes,
+                                                               u32 L, u32 log_n, u32 rot, bool high) {
+    const u32 n = 1u << log_n, mask = n - 1, threads = n / WPT;
+    const u64 poly = blockIdx.x;
+    u64 *__restrict__ base = data + poly * n;
+    const u64 q = primes[(u32)(poly % L)].q;
+    const u32 lt = threadIdx.x;
+    u64 v[WPT];
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) v[j] = __builtin_nontemporal_load(base + lt + threads * j);
+    // the loads must have RETURNED (not merely issued) before any wave of the workgroup overwrites their addresses
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+        const u32 i = lt + threads * j, d = i + rot;
+        const bool negate = (d >= n) != high;
+        __builtin_nontemporal_store(negate ? neg_mod(v[j], q) : v[j], base + (d & mask));
     }
 }
 
@@ -387,6 +413,24 @@ int pfhe_dcrt_mul_monomial_assign_dev(const pfhe_dcrt *table, uint64_t *data_dev
         return PFHE_ERR_BAD_ARGUMENT;
     }
     if (len == 0) return PFHE_OK;
+    if (t.log_n >= 9 && t.log_n <= 14 && len / t.n <= 0x7fffffffull && std::getenv("PFHE_DISABLE_MONOMIAL_INPLACE") == nullptr) {
+        // truly in place: one workgroup per polynomial, data held in registers across the barrier
+        const bool high = r >= t.n;
+        const u32 rot = (u32)(high ? r - t.n : r);
+        const dim3 g((u32)(len / t.n));
+        u64 *d = (u64 *)data_dev;
+        hipStream_t st = (hipStream_t)stream;
+        switch (t.log_n) {
+            case 9: hipLaunchKernelGGL(monomial_inplace_kernel<2>, g, dim3(256), 0, st, d, t.primes_dev, t.L, t.log_n, rot, high); break;
+            case 10: hipLaunchKernelGGL(monomial_inplace_kernel<4>, g, dim3(256), 0, st, d, t.primes_dev, t.L, t.log_n, rot, high); break;
+            case 11: hipLaunchKernelGGL(monomial_inplace_kernel<8>, g, dim3(256), 0, st, d, t.primes_dev, t.L, t.log_n, rot, high); break;
+            case 12: hipLaunchKernelGGL(monomial_inplace_kernel<16>, g, dim3(256), 0, st, d, t.primes_dev, t.L, t.log_n, rot, high); break;
+            case 13: hipLaunchKernelGGL(monomial_inplace_kernel<16>, g, dim3(512), 0, st, d, t.primes_dev, t.L, t.log_n, rot, high); break;
+            default: hipLaunchKernelGGL(monomial_inplace_kernel<16>, g, dim3(1024), 0, st, d, t.primes_dev, t.L, t.log_n, rot, high); break;
+        }
+        PFHE_HIP(hipGetLastError());
+        return PFHE_OK;
+    }
     if (stream_is_capturing((hipStream_t)stream)) {
         set_last_error("mul_monomial_assign allocates a scratch tile; capture mul_monomial_to into a graph instead");
         return PFHE_ERR_UNSUPPORTED;

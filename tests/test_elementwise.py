@@ -249,3 +249,29 @@ def test_gpu_properties_at_benchmark_size(pf):
     assert torch.equal(y, a)                                   # (a^-1)^-1 = a
     t.mul_to_dev(a, x, y)
     assert int((y != 1).count_nonzero()) == 0                   # a * a^-1 = 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log_n", [8, 9, 10, 12, 13, 14, 15])
+def test_gpu_monomial_in_place_forms_agree(pf, log_n):
+    """mul_monomial_assign: rings of 2^9 .. 2^14 words rotate inside one workgroup's registers, others through a
+    scratch tile; both equal the out-of-place kernel for every kind of degree."""
+    import os
+    import torch
+    n, polys = 1 << log_n, 37
+    t = pf.U64DcrtTable(log_n, Q61)
+    a = torch.empty(polys * 3 * n, dtype=torch.int64, device="cuda")
+    t.fill_uniform_dev(a, log_n)
+    exp = torch.empty_like(a)
+    for r in (0, 1, 3, n // 2 + 1, n - 1, n, n + 2, 2 * n - 1):
+        t.mul_monomial_to_dev(a, r, exp)
+        x = a.clone()
+        t.mul_monomial_assign_dev(x, r)
+        assert torch.equal(x, exp), r
+        os.environ["PFHE_DISABLE_MONOMIAL_INPLACE"] = "1"
+        try:
+            y = a.clone()
+            t.mul_monomial_assign_dev(y, r)
+        finally:
+            del os.environ["PFHE_DISABLE_MONOMIAL_INPLACE"]
+        assert torch.equal(y, exp), r

@@ -109,9 +109,21 @@ def test_cmux_style_step_in_a_graph(pf):
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, stream=s):
         step()
-    with pytest.raises(pf.PfheError):  # refuses, and must not poison the capture machinery afterwards
+    # beyond N = 2^14 the in-place rotation needs a scratch tile: it refuses to be captured, and must not poison
+    # the capture machinery afterwards (at N = 2^11 it runs in registers and is capturable like the rest)
+    big = pf.U64DcrtTable(15, Q61[:1])
+    xb = torch.zeros(1 << 15, dtype=torch.int64, device="cuda")
+    with pytest.raises(pf.PfheError):
         with torch.cuda.graph(torch.cuda.CUDAGraph(), stream=s):
-            t.mul_monomial_assign_dev(diff, 1, stream=s)
+            big.mul_monomial_assign_dev(xb, 1, stream=s)
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=s):
+        t.mul_monomial_assign_dev(diff, 5, stream=s)
+        t.mul_monomial_assign_dev(diff, 2 * n - 5, stream=s)
+    before = diff.clone()
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(diff, before)  # X^5 * X^(2N-5) = 1
     acc.copy_(acc0)
     g.replay()
     g.replay()

@@ -46,7 +46,7 @@ for name, fn, nbytes in (
         ("add_mul_factor_assign", lambda: t.add_mul_factor_assign_dev(o, b, factors), 24 * words),
         ("mul_monomial_to r=12345", lambda: t.mul_monomial_to_dev(a, 12345 % (2 * n), o), 16 * words),
         ("mul_monomial_to r=N+2", lambda: t.mul_monomial_to_dev(a, n + 2, o), 16 * words),
-        ("mul_monomial_assign", lambda: t.mul_monomial_assign_dev(o, 12345 % (2 * n)), 16 * words),
+        ("mul_monomial_assign (in place)", lambda: t.mul_monomial_assign_dev(o, 12345 % (2 * n)), 16 * words),
         ("inv_to", lambda: t.inv_to_dev(a, o), 16 * words)):
     ms = timed(fn, 3 if name == "inv_to" else 10)
     print(f"{name:26s} {ms:8.3f} ms  {nbytes / ms / 1e6:7.0f} GB/s  ({100 * nbytes / ms / 1e6 / 8000:.0f} % of 8 TB/s)")
