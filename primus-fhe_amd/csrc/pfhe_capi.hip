@@ -608,7 +608,7 @@ static int butterfly_api(const pfhe_dcrt *table, bool factor, uint64_t *a_dev, c
     DeviceGuard g(t.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
     return butterfly_dev(factor, (u64 *)a_dev, (const u64 *)rhs_dev, (const u64 *)w_dev, (u64 *)result_dev, t.primes_dev,
-                         t.L, t.log_n, len, factor ? len_w / 2 : len_w, (hipStream_t)stream);
+                         t.L, t.log_n, len, factor ? len_w / 2 : len_w, (hipStream_t)stream, t.pm);
 }
 
 int pfhe_dcrt_butterfly_mul_dcrt_polynomial_to_dev(const pfhe_dcrt *table, uint64_t *a_dev, const uint64_t *rhs_dev,

@@ -132,22 +132,57 @@ __global__ __launch_bounds__(kPwThreads) void pointwise_kernel(u64 *out, const u
 // GLWE butterfly (a, b) = (a + s, (a - s) * w), canonical in and out:
 //   FACTOR: w = ShoupFactor pairs (value, quotient)   DcrtPolynomial::butterfly_mul_factor_to, dcrt/mul.rs:15-30,196-222
 //   else  : w = plain residues, Barrett product        DcrtPolynomial::butterfly_mul_to, dcrt/mod.rs:125-160
-template <bool FACTOR>
+template <bool FACTOR, bool PAIR, bool PM>
 __global__ __launch_bounds__(kPwThreads) void butterfly_kernel(u64 *__restrict__ a, const u64 *__restrict__ s,
                                                                const u64 *__restrict__ w, u64 *__restrict__ b,
                                                                const NttPrime *__restrict__ primes, u32 L, u32 log_n,
-                                                               u64 len, u64 len_w) {
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (u64)gridDim.x * blockDim.x) {
-        const Bar m = load_bar(primes, (u32)((i >> log_n) % L));
-        const u64 iw = i % len_w;
-        const u64 x = a[i], y = s[i];
-        a[i] = add_mod(x, y, m.q);
-        const u64 d = sub_mod(x, y, m.q);
-        if constexpr (FACTOR) {
-            const ulonglong2 f = reinterpret_cast<const ulonglong2 *>(w)[iw];
-            b[i] = mul_shoup(d, f.x, f.y, m.q);
+                                                               u64 len, bool shared_w) {
+    constexpr u64 V = PAIR ? 2 : 1;
+    const u64 nvec = len / V;
+    for (u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (u64)gridDim.x * blockDim.x) {
+        const u64 i = v * V;
+        u32 p = (u32)(i >> log_n);  // wave-uniform once a polynomial spans a wave's 128 words
+        if (log_n >= 7) p = __builtin_amdgcn_readfirstlane(p);
+        const u32 limb = p % L;
+        const NttPrime *P = primes + limb;
+        const u64 q = P->q;
+        const u64 iw = shared_w ? (((u64)limb << log_n) + (i & (((u64)1 << log_n) - 1))) : i;
+        u64 x[2], y[2], wv[2], wq[2];
+        if constexpr (PAIR) {
+            const pw_vec xv = pw_load(a + i), yv = pw_load(s + i);
+            x[0] = xv[0]; x[1] = xv[1]; y[0] = yv[0]; y[1] = yv[1];
+            if constexpr (FACTOR) {
+                const pw_vec f0 = shared_w ? *reinterpret_cast<const pw_vec *>(w + 2 * iw) : pw_load(w + 2 * iw);
+                const pw_vec f1 = shared_w ? *reinterpret_cast<const pw_vec *>(w + 2 * iw + 2) : pw_load(w + 2 * iw + 2);
+                wv[0] = f0[0]; wq[0] = f0[1]; wv[1] = f1[0]; wq[1] = f1[1];
+            } else {
+                const pw_vec f = shared_w ? *reinterpret_cast<const pw_vec *>(w + iw) : pw_load(w + iw);
+                wv[0] = f[0]; wv[1] = f[1];
+            }
         } else {
-            b[i] = mul_mod_barrett(d, w[iw], m.q, m.lo, m.hi);
+            x[0] = a[i]; y[0] = s[i];
+            if constexpr (FACTOR) { wv[0] = w[2 * iw]; wq[0] = w[2 * iw + 1]; } else wv[0] = w[iw];
+        }
+        u64 ra[2], rb[2];
+#pragma unroll
+        for (int e = 0; e < (int)V; ++e) {
+            ra[e] = add_mod(x[e], y[e], q);
+            const u64 d = sub_mod(x[e], y[e], q);
+            if constexpr (FACTOR) {
+                rb[e] = mul_shoup(d, wv[e], wq[e], q);
+            } else if constexpr (PM) {
+                const PmArith ar(P);
+                rb[e] = ar.reduce_2q(ar.mul_any(d, wv[e]));
+            } else {
+                rb[e] = mul_mod_barrett(d, wv[e], q, P->bar_lo, P->bar_hi);
+            }
+        }
+        if constexpr (PAIR) {
+            pw_store(a + i, pw_vec{ra[0], ra[1]});
+            pw_store(b + i, pw_vec{rb[0], rb[1]});
+        } else {
+            a[i] = ra[0];
+            b[i] = rb[0];
         }
     }
 }
@@ -228,11 +263,21 @@ int pointwise_dev(u64 *out, const u64 *a, const u64 *b, const u64 *c, const NttP
 }
 
 int butterfly_dev(bool factor, u64 *a, const u64 *s, const u64 *w, u64 *b, const NttPrime *primes, u32 L, u32 log_n,
-                  u64 len, u64 len_w, hipStream_t st) {
+                  u64 len, u64 len_w, hipStream_t st, bool pm) {
     if (len == 0) return PFHE_OK;
-    const dim3 g(grid_for(len)), t(kPwThreads);
-    if (factor) hipLaunchKernelGGL(butterfly_kernel<true>, g, t, 0, st, a, s, w, b, primes, L, log_n, len, len_w);
-    else hipLaunchKernelGGL(butterfly_kernel<false>, g, t, 0, st, a, s, w, b, primes, L, log_n, len, len_w);
+    const bool shared = len_w != len;  // len_w counts multiplicands (a factor is two words)
+    const bool pair = log_n >= 1;
+    const dim3 g(grid_for(pair ? len / 2 : len)), t(kPwThreads);
+#define PFHE_BF_LAUNCH(F, PR, PMV) \
+    hipLaunchKernelGGL((butterfly_kernel<F, PR, PMV>), g, t, 0, st, a, s, w, b, primes, L, log_n, len, shared)
+    if (factor) {
+        if (pair) PFHE_BF_LAUNCH(true, true, false); else PFHE_BF_LAUNCH(true, false, false);
+    } else if (pm) {
+        if (pair) PFHE_BF_LAUNCH(false, true, true); else PFHE_BF_LAUNCH(false, false, true);
+    } else {
+        if (pair) PFHE_BF_LAUNCH(false, true, false); else PFHE_BF_LAUNCH(false, false, false);
+    }
+#undef PFHE_BF_LAUNCH
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
 }

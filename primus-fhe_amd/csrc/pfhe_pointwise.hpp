@@ -11,7 +11,7 @@ int pointwise_dev(u64 *out, const u64 *a, const u64 *b, const u64 *c, const NttP
 // (a, b) = (a + s, (a - s) * w); w holds len_w multiplicands (ShoupFactor pairs when `factor`), shared
 // cyclically by the batch.
 int butterfly_dev(bool factor, u64 *a, const u64 *s, const u64 *w, u64 *b, const NttPrime *primes, u32 L, u32 log_n,
-                  u64 len, u64 len_w, hipStream_t st);
+                  u64 len, u64 len_w, hipStream_t st, bool pm = false);
 int fill_uniform_dev(u64 *dst, u64 len, const u64 *moduli_dev, u64 count, u64 poly_len, u64 seed,
                      hipStream_t s);
 int monomial_dev(u64 *out, const NttPrime *primes, u32 L, u32 log_n, u64 degree, const u64 *coeff_dev,
