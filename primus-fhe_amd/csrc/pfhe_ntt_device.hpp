@@ -464,23 +464,39 @@ __device__ __forceinline__ void lds_put_layout(const u64 (&x)[16], u64 *__restri
     for (int k = 0; k < 16; ++k) lds[lds_phi(layout<POS>(lt, k))] = x[k];
 }
 
-// registers (layout FROM) -> LDS -> registers (layout TO); the LDS region may still be read by
-// other threads on entry, hence the leading barrier.
-template <int FROM, int TO>
+// registers (layout FROM) -> LDS -> registers (layout TO).
+// FIRST: the exchange opens a chain, so other threads may still be reading the LDS region (staging of the caller):
+// a workgroup barrier precedes the writes.  Later exchanges of a chain need none: a thread overwrites exactly the
+// slots it read in the previous exchange (layout FROM is that exchange's layout TO).
+// The threads that trade words in one exchange have ids inside one aligned block of 2^max(FROM, TO) threads; up to
+// 2^6 that is a single wave, whose LDS accesses execute in program order: no workgroup barrier between the
+// writes and the reads either (PFHE_NO_WAVE_LOCAL_EXCHANGE restores both barriers everywhere).
+template <int FROM, int TO, bool FIRST>
 __device__ __forceinline__ void lds_exchange(u64 (&x)[16], u64 *__restrict__ lds, u32 lt) {
-    __syncthreads();
+#ifdef PFHE_NO_WAVE_LOCAL_EXCHANGE
+    constexpr bool kLead = true, kWaveLocal = false;
+#else
+    constexpr bool kLead = FIRST, kWaveLocal = (FROM > TO ? FROM : TO) <= 6;
+#endif
+    if constexpr (kLead) __syncthreads();
     lds_put_layout<FROM>(x, lds, lt);
-    __syncthreads();
+    if constexpr (kWaveLocal) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
     lds_get_layout<TO>(x, lds, lt);
 }
 
-template <class A, int LOGB, int POS>
+template <class A, int LOGB, int POS, bool FIRST = false>
 __device__ __forceinline__ void fwd_chain(const A &ar, u64 (&x)[16], u64 *__restrict__ lds, u32 n, u32 eblk, u32 lt) {
     constexpr bool UNI = BlockCfg<LOGB>::TPB >= 64;  // a wave never straddles two blocks
     if constexpr (POS > 0) {
         constexpr int NPOS = POS >= 4 ? POS - 4 : 0;
         constexpr int JHI = POS >= 4 ? 3 : POS - 1;
-        lds_exchange<POS, NPOS>(x, lds, lt);
+        lds_exchange<POS, NPOS, FIRST>(x, lds, lt);
         fwd_regpass<A, NPOS, JHI, 0, UNI>(ar, x, n + eblk + layout<NPOS>(lt, 0));
         fwd_chain<A, LOGB, NPOS>(ar, x, lds, n, eblk, lt);
     }
@@ -493,7 +509,7 @@ __device__ __forceinline__ void block_forward_core(const A &ar, u64 (&x)[16], u6
     constexpr int POS0 = LOGB - 4;
     constexpr bool UNI = BlockCfg<LOGB>::TPB >= 64;  // a wave never straddles two blocks
     fwd_regpass<A, POS0, 3, 0, UNI>(ar, x, n + eblk + layout<POS0>(lt, 0));
-    fwd_chain<A, LOGB, POS0>(ar, x, lds, n, eblk, lt);
+    fwd_chain<A, LOGB, POS0, true>(ar, x, lds, n, eblk, lt);
     if constexpr (A::kPacked) {  // distance-1 stage between the halves of each word
 #pragma unroll
         for (int k = 0; k < 16; ++k) x[k] = ar.fwd_intra(x[k], n + eblk + layout<0>(lt, k));
@@ -504,7 +520,7 @@ __device__ __forceinline__ void block_forward_core(const A &ar, u64 (&x)[16], u6
     }
 }
 
-template <class A, int LOGB, int POS>
+template <class A, int LOGB, int POS, bool FIRST = false>
 __device__ __forceinline__ void inv_chain(const A &ar, u64 (&x)[16], u64 *__restrict__ lds, u32 n, u32 eblk, u32 lt,
                                           bool final_block, bool lazy) {
     constexpr bool UNI = BlockCfg<LOGB>::TPB >= 64;  // a wave never straddles two blocks
@@ -513,7 +529,7 @@ __device__ __forceinline__ void inv_chain(const A &ar, u64 (&x)[16], u64 *__rest
         constexpr int NPOS = DONE <= LOGB - 4 ? DONE : LOGB - 4;
         constexpr int JLO = DONE - NPOS;
         constexpr bool LAST = NPOS + 4 >= LOGB;
-        lds_exchange<POS, NPOS>(x, lds, lt);
+        lds_exchange<POS, NPOS, FIRST>(x, lds, lt);
         inv_regpass<A, NPOS, JLO, 3, UNI>(ar, x, n, eblk + layout<NPOS>(lt, 0), LAST && final_block, lazy);
         inv_chain<A, LOGB, NPOS>(ar, x, lds, n, eblk, lt, final_block, lazy);
     }
@@ -529,7 +545,7 @@ __device__ __forceinline__ void block_inverse_core(const A &ar, u64 (&x)[16], u6
         for (int k = 0; k < 16; ++k) x[k] = ar.inv_intra(x[k], n, eblk + layout<0>(lt, k));
     }
     inv_regpass<A, 0, 0, 3, UNI>(ar, x, n, eblk + layout<0>(lt, 0), LOGB == 4 && final_block, lazy);
-    inv_chain<A, LOGB, 0>(ar, x, lds, n, eblk, lt, final_block, lazy);
+    inv_chain<A, LOGB, 0, true>(ar, x, lds, n, eblk, lt, final_block, lazy);
 }
 
 // ---- coalesced block I/O: 8 x 16-byte vectors per thread in natural order (vector v = elements
