@@ -152,6 +152,13 @@ __global__ __launch_bounds__(256) void ntt_strided_kernel(u64 *__restrict__ data
 #ifndef PFHE_BLOCK_WAVES_ATTR
 #define PFHE_BLOCK_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
+// x is filled from the staging region by lds_get_layout, so the first exchange needs no barrier in front of it
+#ifdef PFHE_BLOCK_LEAD_BARRIER
+constexpr bool kBlockLeadBarrier = true;
+#else
+constexpr bool kBlockLeadBarrier = false;
+#endif
+
 template <class A, int LOGB, bool INV, bool MUL>
 __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L,
                                                 u32 log_n, u64 total_blocks, u32 lazy, const u64 *__restrict__ mul,
@@ -195,12 +202,12 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
     u64 x[16];
     if constexpr (!INV) {
         lds_get_layout<LOGB - 4>(x, lds, lt);
-        block_forward_core<A, LOGB>(ar, x, lds, n, eblk, lt, lazy != 0);
+        block_forward_core<A, LOGB, kBlockLeadBarrier>(ar, x, lds, n, eblk, lt, lazy != 0);
         __syncthreads();
         lds_put_layout<0>(x, lds, lt);
     } else {
         lds_get_layout<0>(x, lds, lt);
-        block_inverse_core<A, LOGB>(ar, x, lds, n, eblk, lt, log_n == LOGB, lazy != 0);
+        block_inverse_core<A, LOGB, kBlockLeadBarrier>(ar, x, lds, n, eblk, lt, log_n == LOGB, lazy != 0);
         __syncthreads();
         lds_put_layout<LOGB - 4>(x, lds, lt);
     }

@@ -503,13 +503,15 @@ __device__ __forceinline__ void fwd_chain(const A &ar, u64 (&x)[16], u64 *__rest
 }
 
 // forward compute core: x holds layout<LOGB-4> on entry and layout<0> (canonical unless lazy) on exit
-template <class A, int LOGB>
+// LEAD = false: the caller filled x by lds_get_layout<LOGB-4> from this LDS region (so the first exchange, too,
+// only overwrites slots its own thread read last) and needs no barrier in front of it.
+template <class A, int LOGB, bool LEAD = true>
 __device__ __forceinline__ void block_forward_core(const A &ar, u64 (&x)[16], u64 *__restrict__ lds, u32 n,
                                                    u32 eblk, u32 lt, bool lazy) {
     constexpr int POS0 = LOGB - 4;
     constexpr bool UNI = BlockCfg<LOGB>::TPB >= 64;  // a wave never straddles two blocks
     fwd_regpass<A, POS0, 3, 0, UNI>(ar, x, n + eblk + layout<POS0>(lt, 0));
-    fwd_chain<A, LOGB, POS0, true>(ar, x, lds, n, eblk, lt);
+    fwd_chain<A, LOGB, POS0, LEAD>(ar, x, lds, n, eblk, lt);
     if constexpr (A::kPacked) {  // distance-1 stage between the halves of each word
 #pragma unroll
         for (int k = 0; k < 16; ++k) x[k] = ar.fwd_intra(x[k], n + eblk + layout<0>(lt, k));
@@ -536,7 +538,7 @@ __device__ __forceinline__ void inv_chain(const A &ar, u64 (&x)[16], u64 *__rest
 }
 
 // inverse compute core: x holds layout<0> on entry and layout<LOGB-4> on exit
-template <class A, int LOGB>
+template <class A, int LOGB, bool LEAD = true>
 __device__ __forceinline__ void block_inverse_core(const A &ar, u64 (&x)[16], u64 *__restrict__ lds, u32 n,
                                                    u32 eblk, u32 lt, bool final_block, bool lazy) {
     constexpr bool UNI = BlockCfg<LOGB>::TPB >= 64;  // a wave never straddles two blocks
@@ -545,7 +547,7 @@ __device__ __forceinline__ void block_inverse_core(const A &ar, u64 (&x)[16], u6
         for (int k = 0; k < 16; ++k) x[k] = ar.inv_intra(x[k], n, eblk + layout<0>(lt, k));
     }
     inv_regpass<A, 0, 0, 3, UNI>(ar, x, n, eblk + layout<0>(lt, 0), LOGB == 4 && final_block, lazy);
-    inv_chain<A, LOGB, 0, true>(ar, x, lds, n, eblk, lt, final_block, lazy);
+    inv_chain<A, LOGB, 0, LEAD>(ar, x, lds, n, eblk, lt, final_block, lazy);
 }
 
 // ---- coalesced block I/O: 8 x 16-byte vectors per thread in natural order (vector v = elements
