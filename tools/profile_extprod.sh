@@ -5,6 +5,7 @@ python3 - <<'PY'
 import csv,glob,os
 f=glob.glob(os.environ['GRAFT_REPO_ROOT']+'/gpurun_out/ep/t/**/*kernel_stats.csv', recursive=True)[0]
 for r in csv.DictReader(open(f)):
-    print(r['Name'].split('(')[0][-64:], r['Calls'], round(float(r['AverageNs'])/1e3,1),'us', r['Percentage'])
+    name = r['Name'].replace('void ', '').replace('pfhe::(anonymous namespace)::', '').replace('pfhe::', '').split('(')[0]
+    print(f"{name:60s} calls {int(r['Calls']):5d}  avg {float(r['AverageNs'])/1e3:9.1f} us  {float(r['Percentage']):6.2f} %")
 PY
 rm -rf $O/t
