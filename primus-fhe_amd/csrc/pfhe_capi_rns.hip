@@ -21,9 +21,12 @@ struct pfhe_extprod_plan {
     BasisDev basis{};
     u32 k = 1;
     size_t chunk = 1;
-    // two digit buffers of chunk * (k+1) * ell * L * N words: while the (VALU-bound) transform +
-    // multiply-accumulate of chunk c runs on stream `sb`, the (HBM-bound) decomposition + strided
-    // pass of chunk c+1 fills the other buffer on stream `sa`
+    // digit buffer(s) of chunk * (k+1) * ell * L * N words.  Chunks run one after the other on the caller's stream
+    // (every kernel of the product is bound by the same integer ALU: 20.4 ms per 1024 products at N = 2^16 against
+    // 20.9 ms for the software pipeline).  PFHE_EXTPROD_PIPELINE=1 at plan creation restores that pipeline: a
+    // second buffer, decomposition + strided pass of chunk c+1 on stream `sa` beside the transform +
+    // multiply-accumulate of chunk c on stream `sb`.
+    bool pipeline = false;
     u64 *digits[2] = {nullptr, nullptr};
     size_t digits_words = 0;  // per buffer
     int *sdigits = nullptr;   // compact signed digits of one chunk (chunk * (k+1) * ell * N int32), or null
@@ -74,7 +77,8 @@ int plan_check(const pfhe_extprod_plan *p) {
 
 // one row of the product: acc[e] += glev[e or shared] (x) crt_poly[e]   (glwe/dcrt.rs:178-255)
 // rows == k+1 without `accumulate` gives CrtGlwe::mul_dcrt_ggsw_to (glwe/crt.rs:200-227).
-// Chunks of ciphertexts are software-pipelined over the plan's two streams and two digit buffers.
+// Chunks of ciphertexts run one after the other on the caller's stream, or (plan created under
+// PFHE_EXTPROD_PIPELINE) software-pipelined over the plan's two streams and two digit buffers.
 // `into_coeff`: the caller wants coefficient-form output; *coeff_done reports whether this function already
 // produced it (small-ring kernel) or the caller still has to run the inverse transform.
 // `big_input`: the input polynomials are BigUintPolynomials (value_len limbs per coefficient) instead of CRT ones.
@@ -106,7 +110,7 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
         if (coeff_done) *coeff_done = into_coeff;
         return PFHE_OK;
     }
-    const bool single = batch <= p->chunk || stream_is_capturing(s);
+    const bool single = !p->pipeline || batch <= p->chunk || stream_is_capturing(s);
     hipStream_t sa = single ? s : p->sa, sb = single ? s : p->sb;
     const bool fused = gadget_fused_supported(t.log_n, p->k) && std::getenv("PFHE_DISABLE_FUSED_EXTPROD") == nullptr &&
                        ((std::min<u64>(batch, p->chunk) * t.L) << (t.log_n - 12)) >= 256;
@@ -126,7 +130,7 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
     u64 index = 0;
     u64 prev_done = 0, prev_cur = 0;
     auto issue_mulacc = [&](u64 idx, u64 done0, u64 cur0) -> int {
-        const int b0 = (int)(idx & 1);
+        const int b0 = single ? 0 : (int)(idx & 1);
         if (!single) PFHE_HIP(hipStreamWaitEvent(sa, p->consumed[b0], 0));
         return gadget_mulacc_dev(t.primes_dev, t.L, t.log_n, p->k, rows, ell, p->digits[b0],
                                  keys + (keys_shared ? 0 : done0 * key_words), keys_shared,
@@ -134,7 +138,7 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
     };
     for (u64 done = 0; done < batch; done += p->chunk, ++index) {
         const u64 cur = std::min<u64>(p->chunk, batch - done);
-        const int buf = (int)(index & 1);
+        const int buf = single ? 0 : (int)(index & 1);  // one stream: one buffer, reused in stream order
         u64 *dg = p->digits[buf];
         const u64 npolys = cur * rows * ell * t.L;
         // ---- stream a: steps (1)-(4) + strided passes into digit buffer `buf` ----
@@ -158,12 +162,19 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
             PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.pm, dg, npolys, false, passes - 1, false, sb));
         }
         if (!single) PFHE_HIP(hipEventRecord(p->consumed[buf], sb));
-        // ---- stream a: multiply-accumulate of the PREVIOUS chunk (its block pass has had time to run) ----
-        if (!fused && index >= 1) PFHE_TRY(issue_mulacc(index - 1, prev_done, prev_cur));
+        if (!fused) {
+            if (single) {
+                // one stream, one digit buffer: multiply-accumulate this chunk before the next one overwrites it
+                PFHE_TRY(issue_mulacc(index, done, cur));
+            } else if (index >= 1) {
+                // ---- stream a: multiply-accumulate of the PREVIOUS chunk (its block pass has had time to run) ----
+                PFHE_TRY(issue_mulacc(index - 1, prev_done, prev_cur));
+            }
+        }
         prev_done = done;
         prev_cur = cur;
     }
-    if (!fused && index >= 1) PFHE_TRY(issue_mulacc(index - 1, prev_done, prev_cur));
+    if (!fused && !single && index >= 1) PFHE_TRY(issue_mulacc(index - 1, prev_done, prev_cur));
     if (!single) {
         PFHE_HIP(hipEventRecord(p->join_a, sa));
         PFHE_HIP(hipEventRecord(p->join_b, sb));
@@ -556,9 +567,10 @@ int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *rns, const 
     p->digits_words = p->chunk * (p->k + 1) * p->basis.ell * t->L * t->n;
     DeviceGuard g(t->device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    p->pipeline = std::getenv("PFHE_EXTPROD_PIPELINE") != nullptr;
     for (int i = 0; i < 2; ++i) {
         void *d = nullptr;
-        PFHE_HIP(hipMalloc(&d, p->digits_words * sizeof(u64)));
+        if (i == 0 || p->pipeline) PFHE_HIP(hipMalloc(&d, p->digits_words * sizeof(u64)));
         p->digits[i] = (u64 *)d;
         PFHE_HIP(hipEventCreateWithFlags(&p->produced[i], hipEventDisableTiming));
         PFHE_HIP(hipEventCreateWithFlags(&p->consumed[i], hipEventDisableTiming));
@@ -583,7 +595,7 @@ int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *rns, const 
 void pfhe_extprod_plan_destroy(pfhe_extprod_plan *p) { delete p; }
 size_t pfhe_extprod_plan_scratch_bytes(const pfhe_extprod_plan *p) {
     if (!p) return 0;
-    return 2 * p->digits_words * 8 + (p->sdigits ? p->chunk * (p->k + 1) * p->basis.ell * p->table->n * sizeof(int) : 0);
+    return (p->pipeline ? 2 : 1) * p->digits_words * 8 + (p->sdigits ? p->chunk * (p->k + 1) * p->basis.ell * p->table->n * sizeof(int) : 0);
 }
 
 int pfhe_extprod_mul_dcrt_ggsw_to_dev(pfhe_extprod_plan *plan, const uint64_t *crt_glwe_dev, size_t len_glwe,

@@ -326,3 +326,31 @@ def test_small_ring_fused_path(pf, orc, log_n, moduli, log_basis):
         a = acc[e * W:(e + 1) * W].copy()
         orc.add_dcrt_glev_mul_crt_poly_assign(ot, ob, obasis, k, a, glev, poly[e * L * n:(e + 1) * L * n].copy())
         assert np.array_equal(got[e * W:(e + 1) * W], a)
+
+
+def test_pipelined_chunks_equal_serial_chunks(pf):
+    """Chunks of a batch run one after the other by default; a plan created under PFHE_EXTPROD_PIPELINE=1 overlaps
+    the decomposition of chunk c+1 with the transforms of chunk c on two internal streams.  Same words either way,
+    for the fused (N = 2^12) and the unfused (N = 2^9) kernels."""
+    import os
+    import torch
+    for log_n in (12, 9):
+        k, batch, n = 1, 7, 1 << log_n
+        rng = np.random.default_rng(log_n)
+        t, base = pf.U64DcrtTable(log_n, Q61), pf.RNSBase(Q61)
+        basis = pf.BigUintApproxSignedBasis(base, 30)
+        ell = basis.decompose_length()
+        dg = to_dev(rand_rns(rng, Q61, n, batch * (k + 1)))
+        dk = to_dev(rand_rns(rng, Q61, n, batch * (k + 1) * ell * (k + 1)))  # one GGSW per ciphertext
+        outs = []
+        for pipeline in (False, True):
+            if pipeline:
+                os.environ["PFHE_EXTPROD_PIPELINE"] = "1"
+            try:
+                ctx = pf.DcrtGlevContext(t, base, basis, k, 2)  # chunks of 2 ciphertexts: 4 chunks, the last one short
+            finally:
+                os.environ.pop("PFHE_EXTPROD_PIPELINE", None)
+            out = torch.zeros_like(dg)
+            pf.mul_dcrt_ggsw_to_dev(dg, dk, out, ctx, into_coeff_form=True)
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1])
