@@ -201,32 +201,45 @@ __global__ __launch_bounds__(256) void gadget_decompose_strided_kernel(RnsDev R,
 //     (polynomial, level), reads its 2^K digits once, and for every limb lifts them, runs the K stages
 //     in registers and stores where the strided pass would have stored.
 // ------------------------------------------------------------------------------------------
+// Two adjacent coefficients per thread: 16-byte loads of the residues, 8-byte stores of the digit pairs.
 template <int LEN>
 __global__ __launch_bounds__(256) void gadget_signed_digits_kernel(RnsDev R, BasisDev B, u32 log_n,
                                                                   const u64 *__restrict__ crt, int *__restrict__ out,
-                                                                  u64 total) {
+                                                                  u64 total_pairs) {
     const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total) return;
+    if (gid >= total_pairs) return;
     const u32 n = 1u << log_n;
-    const u64 poly = gid >> log_n;
-    const u32 t = (u32)(gid & (n - 1));
-    u64 v[LEN];
+    const u64 poly = (gid * 2) >> log_n;
+    const u32 t = (u32)((gid * 2) & (n - 1));
+    u64 v[2][LEN];
     if (R.big_input) {  // BigUintPolynomial input (glwe/dcrt.rs:258-338): already composed
 #pragma unroll
-        for (int j = 0; j < LEN; ++j) v[j] = crt[(poly * n + t) * LEN + j];
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int j = 0; j < LEN; ++j) v[e][j] = crt[(poly * n + t + e) * LEN + j];
     } else {
-        u64 r[kMaxLimbs];
-        for (u32 i = 0; i < R.L; ++i) r[i] = crt[(poly * R.L + i) * n + t];
-        compose<LEN>(R, r, v);
+        u64 r[2][kMaxLimbs];
+        for (u32 i = 0; i < R.L; ++i) {
+            const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(crt + (poly * R.L + i) * n + t);
+            r[0][i] = w.x;
+            r[1][i] = w.y;
+        }
+        compose<LEN>(R, r[0], v[0]);
+        compose<LEN>(R, r[1], v[1]);
     }
-    u32 carry = init_value_carry<LEN>(B, v);
+    u32 carry[2] = {init_value_carry<LEN>(B, v[0]), init_value_carry<LEN>(B, v[1])};
     const u64 half = (B.basis + 1) / 2;
     int *__restrict__ o = out + poly * B.ell * n + t;
     for (u32 j = 0; j < B.ell; ++j) {
-        const u64 temp = window<LEN>(v, B.drop_bits + j * B.log_basis, B.basis_minus_one, B.log_basis) + carry;
-        carry = (temp & B.carry_mask) != 0;
-        const u64 u = temp & B.basis_minus_one;
-        o[(u64)j * n] = (B.basis != 2 && u >= half) ? (int)((long long)u - (long long)B.basis) : (int)u;
+        int d[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const u64 temp = window<LEN>(v[e], B.drop_bits + j * B.log_basis, B.basis_minus_one, B.log_basis) + carry[e];
+            carry[e] = (temp & B.carry_mask) != 0;
+            const u64 u = temp & B.basis_minus_one;
+            d[e] = (B.basis != 2 && u >= half) ? (int)((long long)u - (long long)B.basis) : (int)u;
+        }
+        *reinterpret_cast<int2 *>(o + (u64)j * n) = int2{d[0], d[1]};
     }
 }
 
@@ -262,7 +275,7 @@ __global__ __launch_bounds__(256, 4) void digits_strided_kernel(const NttPrime *
 template <class A, int K>
 int launch_digits_strided(const RnsDev &r, const BasisDev &b, const NttPrime *primes, u32 log_n, const u64 *crt,
                           int *sdigits, u64 *digits, u64 npolys, hipStream_t s) {
-    const u64 coeffs = npolys << log_n;
+    const u64 coeffs = (npolys << log_n) / 2;  // two coefficients per thread (N >= 2^9 on this path)
     const u32 g1 = (u32)((coeffs + 255) / 256);
     switch (r.value_len) {
 #define PFHE_CASE(LEN)                                                                                        \
@@ -478,7 +491,7 @@ bool extprod_small_supported(u32 log_n, u32 k, u32 value_len, u32 log_basis) {
 // steps (1)-(3) alone: balanced int32 digits of `npolys` CRT polynomials ([poly][level][N])
 int gadget_signed_digits_dev(const RnsDev &r, const BasisDev &b, u32 log_n, const u64 *crt_polys, int *sdigits,
                              u64 npolys, hipStream_t s) {
-    const u64 coeffs = npolys << log_n;
+    const u64 coeffs = (npolys << log_n) / 2;  // two coefficients per thread
     if (coeffs == 0) return PFHE_OK;
     const u32 g1 = (u32)((coeffs + 255) / 256);
     switch (r.value_len) {
