@@ -84,8 +84,9 @@ __global__ __launch_bounds__(256, PFHE_MULACC_MIN_WG) void gadget_block_mulacc_k
         __syncthreads();
         u64 x[16];
         lds_get_layout<LOGB - 4>(x, lds, lt);
-        block_forward_core<A, LOGB>(ar, x, lds, n, eblk, lt, /*lazy=*/true);  // digit_hat mod~ q
-        __syncthreads();
+        // (no barrier in front of the first exchange or of the write-back: in both a thread overwrites exactly the
+        // LDS slots it read last — pfhe_ntt_device.hpp, lds_exchange)
+        block_forward_core<A, LOGB, false>(ar, x, lds, n, eblk, lt, /*lazy=*/true);  // digit_hat mod~ q
         lds_put_layout<0>(x, lds, lt);
         __syncthreads();
         lds_get_vectors<LOGB>(io, lds, lt);  // natural order again: same positions as the key vectors

@@ -203,12 +203,12 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
     if constexpr (!INV) {
         lds_get_layout<LOGB - 4>(x, lds, lt);
         block_forward_core<A, LOGB, kBlockLeadBarrier>(ar, x, lds, n, eblk, lt, lazy != 0);
-        __syncthreads();
+        if constexpr (kBlockLeadBarrier) __syncthreads();  // else: the write-back reuses the slots each thread read last
         lds_put_layout<0>(x, lds, lt);
     } else {
         lds_get_layout<0>(x, lds, lt);
         block_inverse_core<A, LOGB, kBlockLeadBarrier>(ar, x, lds, n, eblk, lt, log_n == LOGB, lazy != 0);
-        __syncthreads();
+        if constexpr (kBlockLeadBarrier) __syncthreads();
         lds_put_layout<LOGB - 4>(x, lds, lt);
     }
     __syncthreads();
