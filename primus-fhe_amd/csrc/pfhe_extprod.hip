@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, PFHE_MULACC_MIN_WG) void gadget_block_mulacc_k
     for (u32 ij = 0; ij < terms; ++ij) {
         u64x2 io[8];
         load_block_vectors<LOGB>(io, dg + (u64)ij * W, lt);
-        __syncthreads();  // previous iteration's LDS readers are done
+        // (no barrier: these are the slots this thread read with lds_get_vectors at the end of the previous iteration)
         lds_put_vectors<LOGB>(io, lds, lt);
         __syncthreads();
         u64 x[16];
