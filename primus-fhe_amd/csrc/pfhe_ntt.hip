@@ -420,11 +420,15 @@ int ntt_pass_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data,
 // (its VALU is half idle) and the block pass is VALU-bound (its memory pipe is mostly idle):
 // the batch is cut into tiles and the strided pass of tile k+1 runs on a second stream while the
 // block pass of tile k runs on the first, so the two kinds of workgroups share the CUs.
-// Measured on MI355X at N = 2^16, 12 288 polynomials: 6.34 ms -> 5.76 ms with 8 tiles.
+// Measured on MI355X at N = 2^16, 12 288 polynomials: 6.34 ms -> 5.76 ms with 8 tiles (first measurement; today
+// 5.93 ms as two full-size launches, 5.60 ms with 12 tiles).
 // ------------------------------------------------------------------------------------------
 namespace {
 
-constexpr int kOverlapTiles = 8;
+#ifndef PFHE_OVERLAP_TILES_DEFAULT
+#define PFHE_OVERLAP_TILES_DEFAULT 12  // 8: 5.67 ms, 12: 5.60 ms, 16: 5.61 ms per 12 288 NTTs of 2^16
+#endif
+constexpr int kOverlapTiles = PFHE_OVERLAP_TILES_DEFAULT;
 constexpr u64 kOverlapMinBytes = 512ull << 20;  // below this the extra launches do not pay
 
 struct OverlapCtx {
