@@ -481,7 +481,7 @@ static int transform(const NttPrime *primes, u32 L, u32 log_n, int pm, u64 *data
     // (the u32 tables do not gain from the overlap: measured 3.40 ms vs 3.15 ms without, N = 2^16)
     // (the inverse direction, block pass first, measures 2 % slower tiled than as two full-size launches: 5.98 vs
     // 5.85 ms; PFHE_OVERLAP_INVERSE=1 tiles it anyway)
-    static const bool overlap_inverse = std::getenv("PFHE_OVERLAP_INVERSE") != nullptr;
+    const bool overlap_inverse = std::getenv("PFHE_OVERLAP_INVERSE") != nullptr;
     const bool overlap = pm != kArithB32 && passes == 2 && (!inverse || overlap_inverse) && bytes >= kOverlapMinBytes && npolys >= (u64)kOverlapTiles * L &&
                          std::getenv("PFHE_DISABLE_OVERLAP") == nullptr && !stream_is_capturing(s) &&
                          hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;

@@ -435,6 +435,18 @@ def test_fused_polymul_large_batch_tiled_path(pf, orc, shared):
     a, bh = fill(batch * W, 11), fill(W if shared else batch * W, 12)
     fused = a.clone()
     d.mul_dcrt_polynomial_dev(fused, bh)
+    os.environ["PFHE_OVERLAP_INVERSE"] = "1"  # the inverse direction is not tiled by default: exercise its tiling too
+    try:
+        tiled = a.clone()
+        d.mul_dcrt_polynomial_dev(tiled, bh)
+        inv_tiled = a.clone()
+        d.inverse_transform_dev(inv_tiled)
+    finally:
+        del os.environ["PFHE_OVERLAP_INVERSE"]
+    assert torch.equal(fused, tiled)
+    inv_plain = a.clone()
+    d.inverse_transform_dev(inv_plain)
+    assert torch.equal(inv_plain, inv_tiled)
     os.environ["PFHE_DISABLE_FUSED_POLYMUL"] = "1"
     try:
         plain = a.clone()
