@@ -173,7 +173,8 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
     const u32 log_nb = log_n - LOGB;  // blocks per polynomial
     const u64 pid = blk >> log_nb;
     const u32 bi = (u32)(blk & ((1ull << log_nb) - 1));
-    const A ar(primes + (u32)(pid % L));
+    const u32 limb = (u32)(pid % L);
+    const A ar(primes + limb);
     const u32 n = 1u << log_n;
     const u32 eblk = bi << LOGB;
     u64 *__restrict__ gptr = data + pid * n + eblk;
@@ -184,18 +185,29 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
     u64x2 io[8];
     if (valid) {
         load_block_vectors<LOGB>(io, gptr, lt);
-        if constexpr (MUL) {  // fused pointwise product (DcrtPolynomial::mul_assign) on the way in
-            u64x2 mv[8];
-            load_block_vectors<LOGB>(mv, mul + (pid % mul_polys) * n + eblk, lt);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                io[j].x = ar.mul_any(io[j].x, mv[j].x);
-                io[j].y = ar.mul_any(io[j].y, mv[j].y);
-            }
-        }
     } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) io[j] = u64x2{0, 0};
+    }
+    if constexpr (MUL) {  // fused pointwise product (DcrtPolynomial::mul_assign) on the way in
+        // The multiplicand is one RNS polynomial (mul_polys == L, indexed by the limb) or one polynomial per data
+        // polynomial (mul_polys == polynomials of this launch, indexed by pid).  The multiplies sit OUTSIDE the
+        // `valid` branch on purpose: inside it, the zero high half of the zero-extended 32-bit constant c was
+        // defined in the branch, reached the rest of the kernel as a phi the compiler could not fold, and every
+        // multiplication by c in the transform became two (5.3 instead of 4.2 ms per 12 288 transforms).
+        u64x2 mv[8];
+        if (valid) {
+            const u64 mpoly = mul_polys == (u64)L ? (u64)limb : pid;
+            load_block_vectors<LOGB>(mv, mul + mpoly * n + eblk, lt);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mv[j] = u64x2{0, 0};
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            io[j].x = ar.mul_any(io[j].x, mv[j].x);
+            io[j].y = ar.mul_any(io[j].y, mv[j].y);
+        }
     }
     lds_put_vectors<LOGB>(io, lds, lt);
     __syncthreads();
