@@ -519,7 +519,10 @@ def test_largest_degrees(pf, orc, log_n, q):
 def test_handles_release_their_device_memory(pf):
     """Creating and destroying tables, bases, converters and external-product plans does not leak HBM."""
     import gc
+    import os
     import torch
+    if os.environ.get("PYTEST_XDIST_WORKER"):
+        pytest.skip("device-wide free-memory readings are meaningless while other xdist workers allocate")
 
     def cycle():
         t = pf.U64DcrtTable(12, Q61)
