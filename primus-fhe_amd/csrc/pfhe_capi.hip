@@ -80,16 +80,43 @@ int make_table_set(u32 log_n, const u64 *moduli, size_t count, int device, std::
     const size_t bytes = ts->n * sizeof(ulonglong2);
     bool all_pm = std::getenv("PFHE_DISABLE_PM") == nullptr;  // tuning switch: force the generic path
     for (size_t i = 0; i < count; ++i) {
-        void *fwd = nullptr, *inv = nullptr;
-        PFHE_HIP(hipMalloc(&fwd, bytes));
-        ts->allocations.push_back(fwd);
-        PFHE_HIP(hipMalloc(&inv, bytes));
-        ts->allocations.push_back(inv);
-        PFHE_HIP(hipMemcpy(fwd, host[i].fwd.data(), bytes, hipMemcpyHostToDevice));
-        PFHE_HIP(hipMemcpy(inv, host[i].inv.data(), bytes, hipMemcpyHostToDevice));
+        u32 pk = 0;
+        u64 pc = 0;
+        if (!pm_shape(host[i].q, pk, pc)) all_pm = false;
+    }
+    const auto upload = [&](const void *src, size_t nbytes, const void **dst) -> int {
+        void *d = nullptr;
+        PFHE_HIP(hipMalloc(&d, nbytes));
+        ts->allocations.push_back(d);
+        PFHE_HIP(hipMemcpy(d, src, nbytes, hipMemcpyHostToDevice));
+        *dst = d;
+        return PFHE_OK;
+    };
+    // the lane-ordered copy of the last four stages' twiddles (NttPrime::fwd_last / inv_last)
+    const auto last_order = [&](const std::vector<ulonglong2> &fwd, const std::vector<ulonglong2> &inv,
+                                std::vector<ulonglong2> &fl, std::vector<ulonglong2> &il) {
+        const size_t n = ts->n, groups = n / 16;
+        fl.assign(15 * groups, ulonglong2{0, 0});
+        il.assign(15 * groups, ulonglong2{0, 0});
+        for (int j = 3; j >= 0; --j) {
+            const size_t per = (size_t)8 >> j;  // twiddles per group at distance 2^j
+            for (size_t u = 0; u < per; ++u)
+                for (size_t g = 0; g < groups; ++g) {
+                    const size_t off = (per - 1 + u) * groups + g;
+                    fl[off] = fwd[(n >> (j + 1)) + g * per + u];
+                    il[off] = inv[1 + n - (n >> j) + g * per + u];
+                }
+        }
+    };
+    for (size_t i = 0; i < count; ++i) {
+        const void *fwd = nullptr, *inv = nullptr;
+        PFHE_TRY(upload(host[i].fwd.data(), bytes, &fwd));
+        PFHE_TRY(upload(host[i].inv.data(), bytes, &inv));
         NttPrime &P = ts->primes[i];
+        std::memset(&P, 0, sizeof P);
         P.q = host[i].q;
         P.two_q = host[i].q << 1;
+        P.q3 = 3 * host[i].q;
         P.inv_n = host[i].inv_n;
         P.inv_n_p = (u64)(((unsigned __int128)host[i].inv_n << 64) / host[i].q);
         P.inv_n_w = host[i].inv_n_w;
@@ -98,31 +125,35 @@ int make_table_set(u32 log_n, const u64 *moduli, size_t count, int device, std::
         P.bar_hi = host[i].bar_hi;
         P.fwd = static_cast<const ulonglong2 *>(fwd);
         P.inv = static_cast<const ulonglong2 *>(inv);
-        // compact twiddle tables for the pseudo-Mersenne path (no Shoup quotients)
         u32 pk = 0;
         u64 pc = 0;
         P.pm_k = pm_shape(P.q, pk, pc) ? pk : 0;
-        P.pm_pad = 0;
         P.pm_c = P.pm_k ? pc : 0;
-        P.fwd_w = nullptr;
-        P.inv_w = nullptr;
+        std::vector<ulonglong2> fl, il;
         if (P.pm_k) {
-            std::vector<u64> fw(ts->n), iw(ts->n);
+            // {w, w * 2^32 mod q}: the twiddle product of PmArith splits the multiplicand, not the twiddle
+            const auto shifted = [&](u64 w) { return (u64)(((unsigned __int128)w << 32) % P.q); };
+            std::vector<ulonglong2> fw(ts->n), iw(ts->n);
             for (size_t k = 0; k < ts->n; ++k) {
-                fw[k] = host[i].fwd[k].x;
-                iw[k] = host[i].inv[k].x;
+                fw[k] = ulonglong2{host[i].fwd[k].x, shifted(host[i].fwd[k].x)};
+                iw[k] = ulonglong2{host[i].inv[k].x, shifted(host[i].inv[k].x)};
             }
-            void *fwp = nullptr, *iwp = nullptr;
-            PFHE_HIP(hipMalloc(&fwp, ts->n * sizeof(u64)));
-            ts->allocations.push_back(fwp);
-            PFHE_HIP(hipMalloc(&iwp, ts->n * sizeof(u64)));
-            ts->allocations.push_back(iwp);
-            PFHE_HIP(hipMemcpy(fwp, fw.data(), ts->n * sizeof(u64), hipMemcpyHostToDevice));
-            PFHE_HIP(hipMemcpy(iwp, iw.data(), ts->n * sizeof(u64), hipMemcpyHostToDevice));
-            P.fwd_w = static_cast<const u64 *>(fwp);
-            P.inv_w = static_cast<const u64 *>(iwp);
-        } else {
-            all_pm = false;
+            const void *fwp = nullptr, *iwp = nullptr;
+            PFHE_TRY(upload(fw.data(), bytes, &fwp));
+            PFHE_TRY(upload(iw.data(), bytes, &iwp));
+            P.fwd_p = static_cast<const ulonglong2 *>(fwp);
+            P.inv_p = static_cast<const ulonglong2 *>(iwp);
+            P.inv_n_2 = shifted(P.inv_n);
+            P.inv_n_w_2 = shifted(P.inv_n_w);
+            if (all_pm && log_n >= 4) last_order(fw, iw, fl, il);
+        }
+        if (!all_pm && log_n >= 4) last_order(host[i].fwd, host[i].inv, fl, il);
+        if (!fl.empty()) {
+            const void *flp = nullptr, *ilp = nullptr;
+            PFHE_TRY(upload(fl.data(), fl.size() * sizeof(ulonglong2), &flp));
+            PFHE_TRY(upload(il.data(), il.size() * sizeof(ulonglong2), &ilp));
+            P.fwd_last = static_cast<const ulonglong2 *>(flp);
+            P.inv_last = static_cast<const ulonglong2 *>(ilp);
         }
         ts->roots.push_back(host[i].root);
         ts->inv_roots.push_back(host[i].inv_root);

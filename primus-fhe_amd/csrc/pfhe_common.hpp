@@ -75,8 +75,19 @@ struct NttPrime {
     // pseudo-Mersenne fast path: q = 2^pm_k - pm_c (pm_k == 0: prime does not qualify)
     u32 pm_k, pm_pad;
     u64 pm_c;
-    const u64 *fwd_w;        // device, N entries: the twiddles alone (no Shoup quotient)
+    const u64 *fwd_w;        // device: u32 tables only ({w, floor(w*2^32/q)} packed in one word, pfhe_u32.hip)
     const u64 *inv_w;
+    const ulonglong2 *fwd_p; // device, N entries {w, w*2^32 mod q}: twiddles of the pseudo-Mersenne path, same
+    const ulonglong2 *inv_p; // indexing as fwd / inv (null when the prime does not qualify)
+    u64 inv_n_2, inv_n_w_2;  // inv_n * 2^32 mod q, inv_n_w * 2^32 mod q
+    u64 q3;                  // 3q (the multiple of q the pseudo-Mersenne butterflies subtract from)
+    // Twiddles of the four stages at distances 8, 4, 2, 1 (the register pass of a block pass in which a thread owns 16
+    // consecutive coefficients), re-ordered so that the 64 lanes of a wave load 64 consecutive entries: stage at distance
+    // 2^j (j = 3..0) has 2^(3-j) twiddles per group g of 16 coefficients; entry ((2^(3-j) - 1) + u) * (N/16) + g holds
+    // fwd[(N >> (j+1)) + g * 2^(3-j) + u] (inv_last: inv[1 + N - (N >> j) + g * 2^(3-j) + u]).  15N/16 entries of the
+    // kind the arithmetic policy in use wants ({w, Shoup quotient} or {w, w * 2^32 mod q}); null for N < 16.
+    const ulonglong2 *fwd_last;
+    const ulonglong2 *inv_last;
 };
 
 // q = 2^K - c qualifies for PmArith when 40 <= K <= 61 and c < 2^(K-33)

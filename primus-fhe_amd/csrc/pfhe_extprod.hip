@@ -24,7 +24,7 @@ namespace {
 // acc + d*k without folding: a product term is < 1.5 * 2^K (K <= 61), so an accumulator folded below
 // 2^K + 2^(K-9) can take FOUR terms before it must be folded again (1.002 + 4 * 1.5 = 7.002 < 8 = 2^64 / 2^61)
 __device__ __forceinline__ u64 mac(const PmArith &ar, u64 acc, u64 d, u64 k) {
-    return acc + ar.mul_lazy(d, PmArith::Tw{k});
+    return acc + ar.mul_full(d, k);
 }
 constexpr u32 kPmMacFoldEvery = 4;
 

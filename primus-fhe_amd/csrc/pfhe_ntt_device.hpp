@@ -3,6 +3,9 @@
 
 #include "pfhe_common.hpp"
 #include "pfhe_modmath.hpp"
+#if defined(__HIPCC__)
+#include "pfhe_pm_asm.hpp"
+#endif
 
 namespace pfhe {
 
@@ -49,6 +52,10 @@ typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 typedef const u64x2 __attribute__((address_space(1))) *GCVec2Ptr;
 typedef u64x2 __attribute__((address_space(1))) *GVec2Ptr;
 typedef const u64 __attribute__((address_space(1))) *GCWordPtr;
+// constant address space: a load whose address is wave-uniform becomes a scalar load (s_load_dwordx4) whatever the
+// alias analysis concludes; with a per-lane address it is an ordinary global load.  The tables are never written
+// while a kernel runs.
+typedef const u64x2 __attribute__((address_space(4))) *CCVec2Ptr;
 
 // x mod m for x < 2m, using the borrow of the subtraction as the select condition
 __device__ __forceinline__ u64 csub(u64 x, u64 m) {
@@ -88,14 +95,25 @@ struct ShoupArith {
         u64 w, wp;
     };
     u64 q, two_q;
-    GCVec2Ptr fwd, inv;
+    GCVec2Ptr fwd, inv, fwd_last, inv_last;
     u64 inv_n, inv_n_p, inv_n_w, inv_n_w_p;
     u64 bar_lo, bar_hi;
 
     __device__ __forceinline__ explicit ShoupArith(const NttPrime *__restrict__ P)
         : q(P->q), two_q(P->two_q), fwd((GCVec2Ptr)(const void *)P->fwd), inv((GCVec2Ptr)(const void *)P->inv),
+          fwd_last((GCVec2Ptr)(const void *)P->fwd_last), inv_last((GCVec2Ptr)(const void *)P->inv_last),
           inv_n(P->inv_n), inv_n_p(P->inv_n_p), inv_n_w(P->inv_n_w), inv_n_w_p(P->inv_n_w_p), bar_lo(P->bar_lo),
           bar_hi(P->bar_hi) {}
+    // lane-ordered twiddles of the stages at distances 8..1 (NttPrime::fwd_last / inv_last)
+    static constexpr bool kLastTables = true;
+    __device__ __forceinline__ Tw fwd_tw_last(u32 off) const {
+        const u64x2 v = fwd_last[off];
+        return Tw{v.x, v.y};
+    }
+    __device__ __forceinline__ Tw inv_tw_last(u32 off) const {
+        const u64x2 v = inv_last[off];
+        return Tw{v.x, v.y};
+    }
     // a*b mod q for two canonical residues (no precomputed quotient): BarrettModulus::reduce_mul
     __device__ __forceinline__ u64 mul_any(u64 a, u64 b) const { return mul_mod_barrett(a, b, q, bar_lo, bar_hi); }
     __device__ __forceinline__ Tw fwd_tw(u32 i) const {
@@ -114,37 +132,107 @@ struct ShoupArith {
     __device__ __forceinline__ u64 reduce_2q(u64 x) const { return csub(x, q); }              // [0,2q) -> [0,q)
     __device__ __forceinline__ u64 reduce_4q(u64 x) const { return csub(csub(x, two_q), q); }  // [0,4q) -> [0,q)
     static constexpr bool kPacked = false;
+    static constexpr bool kWide = false;
 };
 
+// v_mad_u64_u32 with its carry-out kept (an SGPR pair: one bit per lane), and the add-with-carry that consumes it.
+// The compiler's own form of "64-bit sum that may overflow" is a compare + select + 64-bit add (three more
+// instructions per twiddle multiply).
+__device__ __forceinline__ u64 mad_u64_carry(u32 a, u32 b, u64 c, u64 &carry) {
+    u64 d;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ u32 add_carry(u32 a, u64 carry) {
+    u32 d;
+    u64 unused;
+    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(d), "=s"(unused) : "v"(a), "s"(carry));
+    return d;
+}
+// a - b on 64-bit values as one borrow chain (the compiler puts an s_nop between the two halves)
+__device__ __forceinline__ u64 sub_u64(u64 a, u64 b) {
+    u32 d0, d1;
+    asm("v_sub_co_u32 %0, vcc, %2, %4\n\tv_subb_co_u32 %1, vcc, %3, %5, vcc"
+        : "=&v"(d0), "=&v"(d1)
+        : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32))
+        : "vcc");
+    return ((u64)d1 << 32) | d0;
+}
+
 struct PmArith {
+    // twiddle w and w2 = w * 2^32 mod q: y*w = y0*w + y1*w2 (mod q) needs four 32x32 products and its sum
+    // stays below 2^(K+33), so ONE fold finishes the reduction (five multiply-adds per twiddle product
+    // instead of the eight of the full 128-bit product folded twice)
     struct Tw {
-        u64 w;
+        u64 w, w2;
     };
-    u64 q, two_q;
-    GCWordPtr fwd, inv;
-    u64 inv_n, inv_n_w;
-    u32 c, sh;  // q = 2^K - c, sh = K - 32
-    u32 mask;   // 2^(K-32) - 1
+    u64 q, q3;  // q3 = 3q: the multiple of q the butterflies subtract from
+    CCVec2Ptr fwd, inv;
+    GCVec2Ptr fwd_last, inv_last;
+    Tw inv_n, inv_n_w;
+    u32 c, c2, sh;  // q = 2^K - c, c2 = 2c, sh = K - 32
+    u32 mask;       // 2^(K-32) - 1
+    u32 vsh, vmask, vmask1;  // sh, mask and 2^(K-31) - 1 held in VGPRs for the asm butterflies (pfhe_pm_asm.hpp)
 
     __device__ __forceinline__ explicit PmArith(const NttPrime *__restrict__ P)
-        : q(P->q), two_q(P->two_q), fwd((GCWordPtr)(const void *)P->fwd_w), inv((GCWordPtr)(const void *)P->inv_w),
-          inv_n(P->inv_n), inv_n_w(P->inv_n_w), c((u32)P->pm_c), sh(P->pm_k - 32), mask((1u << (P->pm_k - 32)) - 1) {}
-    __device__ __forceinline__ Tw fwd_tw(u32 i) const { return Tw{fwd[i]}; }
-    __device__ __forceinline__ Tw inv_tw(u32 i) const { return Tw{inv[i]}; }
-    // a*b mod~ q in [0,2q) for canonical residues: the twiddle multiply needs no precomputation
-    __device__ __forceinline__ u64 mul_any(u64 a, u64 b) const { return mul_lazy(a, Tw{b}); }
-    __device__ __forceinline__ Tw tw_inv_n() const { return Tw{inv_n}; }
-    __device__ __forceinline__ Tw tw_inv_n_w() const { return Tw{inv_n_w}; }
-    // P = w*y < 2^(K+63); P = phi*2^K + plo == phi*c + plo =: R < 2^(K+33); R = rh*2^K + rl == rh*c + rl
-    // < 2^K + 2^32*c < 2q.  All partial sums fit 64 bits for y < 2^63, w < 2^K <= 2^61, c < 2^(K-33).
+        : q(P->q), q3(P->q3), fwd((CCVec2Ptr)(const void *)P->fwd_p), inv((CCVec2Ptr)(const void *)P->inv_p),
+          fwd_last((GCVec2Ptr)(const void *)P->fwd_last), inv_last((GCVec2Ptr)(const void *)P->inv_last),
+          inv_n{P->inv_n, P->inv_n_2}, inv_n_w{P->inv_n_w, P->inv_n_w_2}, c((u32)P->pm_c), c2(2 * (u32)P->pm_c),
+          sh(P->pm_k - 32), mask((1u << (P->pm_k - 32)) - 1), vsh(sh), vmask(mask), vmask1(2 * mask + 1) {
+        asm volatile("" : "+v"(vsh), "+v"(vmask), "+v"(vmask1));  // as uniform values they would live in SGPRs
+    }
+    __device__ __forceinline__ Tw fwd_tw(u32 i) const {
+#ifdef PFHE_EXPERIMENT_CONST_TW  // timing experiment only (wrong results): what do the twiddle loads cost?
+        return inv_n;
+#endif
+        const u64x2 v = fwd[i];
+        return Tw{v.x, v.y};
+    }
+    __device__ __forceinline__ Tw inv_tw(u32 i) const {
+        const u64x2 v = inv[i];
+        return Tw{v.x, v.y};
+    }
+    __device__ __forceinline__ Tw tw_inv_n() const { return inv_n; }
+    __device__ __forceinline__ Tw tw_inv_n_w() const { return inv_n_w; }
+    static constexpr bool kLastTables = true;
+    __device__ __forceinline__ Tw fwd_tw_last(u32 off) const {
+        const u64x2 v = fwd_last[off];
+        return Tw{v.x, v.y};
+    }
+    __device__ __forceinline__ Tw inv_tw_last(u32 off) const {
+        const u64x2 v = inv_last[off];
+        return Tw{v.x, v.y};
+    }
+
+    // Twiddle product, y any 64-bit value: S = y0*w + y1*w2 < 2^32 * 2q < 2^(K+33); 2^(K+1) = 2c (mod q), so
+    // S = hp*2^(K+1) + L == hp*2c + L =: T with hp < 2^32, L < 2^(K+1), hp*2c < 2^K: T < 3 * 2^K and T <= 3q
+    // (c < 2^(K-33)).  Column 0 (y0*w0 + y1*v0) can exceed 64 bits: its carry-out has weight 2^64 = bit 32 of the
+    // column-1 sum and is added there.
     __device__ __forceinline__ u64 mul_lazy(u64 y, Tw t) const {
-        const u32 y0 = (u32)y, y1 = (u32)(y >> 32), w0 = (u32)t.w, w1 = (u32)(t.w >> 32);
+        const u32 y0 = (u32)y, y1 = (u32)(y >> 32), w0 = (u32)t.w, w1 = (u32)(t.w >> 32), v0 = (u32)t.w2,
+                  v1 = (u32)(t.w2 >> 32);
+        const u64 t0 = (u64)y0 * w0;
+        u64 carry;
+        const u64 t1 = mad_u64_carry(y1, v0, t0, carry);
+        u64 t2 = (u64)y0 * w1 + (t1 >> 32);
+        asm("" : "+v"(t2));  // keeps (t1 >> 32) as the addend of this multiply-add (see the note in mul_full)
+        const u64 t3 = (u64)y1 * v1 + t2;
+        const u32 t3h = add_carry((u32)(t3 >> 32), carry);
+        const u32 hp = __builtin_amdgcn_alignbit(t3h, (u32)t3, sh + 1);     // S >> (K+1)
+        const u64 lo = ((u64)((u32)t3 & (2 * mask + 1)) << 32) | (u32)t1;   // S mod 2^(K+1)
+        return (u64)hp * c2 + lo;
+    }
+    // a*b mod~ q in [0,2q) for two data words (no precomputation on b), a < 2^63: the full 128-bit product folded
+    // twice.  P = b*a < 2^(K+63); P = phi*2^K + plo == phi*c + plo =: R < 2^(K+33); R = rh*2^K + rl == rh*c + rl
+    // < 2^K + 2^32*c < 2q.  All partial sums fit 64 bits for a < 2^63, b < 2^K <= 2^61, c < 2^(K-33).
+    __device__ __forceinline__ u64 mul_full(u64 y, u64 w) const {
+        const u32 y0 = (u32)y, y1 = (u32)(y >> 32), w0 = (u32)w, w1 = (u32)(w >> 32);
         const u64 lo = (u64)w0 * y0;
         u64 mid = (u64)w0 * y1 + (lo >> 32);
         // Opaque to the optimiser, no instruction: without it LLVM re-associates the sum into
-        // mad(w0,y1,0); mad(w1,y0,.); 64-bit add of (lo >> 32) — one more instruction per butterfly than
-        // feeding (lo >> 32) to the first multiply-add (block pass 4.06 -> 3.95 ms).  PFHE_NO_MID_BARRIER restores
-        // the compiler's form; a volatile barrier also pins the schedule and is 6 % slower.
+        // mad(w0,y1,0); mad(w1,y0,.); 64-bit add of (lo >> 32) — one more instruction per product than
+        // feeding (lo >> 32) to the first multiply-add.  PFHE_NO_MID_BARRIER restores the compiler's form;
+        // a volatile barrier also pins the schedule and is 6 % slower.
 #ifndef PFHE_NO_MID_BARRIER
         asm("" : "+v"(mid));
 #endif
@@ -160,7 +248,8 @@ struct PmArith {
         const u64 rl = ((u64)((u32)b & mask) << 32) | (u32)a;
         return (u64)rh * c + rl;
     }
-    // any 64-bit x -> x mod~ q in [0, 2^K + 2^(K-9)) (2^K = c folds the bits above K): three
+    __device__ __forceinline__ u64 mul_any(u64 a, u64 b) const { return mul_full(a, b); }
+    // any 64-bit x -> x mod~ q in [0, 2^K + 2^31) (2^K = c folds the bits above K): three
     // instructions without a carry chain, cheaper than the compare-and-subtract of the generic path
     __device__ __forceinline__ u64 reduce_x(u64 x) const {
         const u32 x1 = (u32)(x >> 32);
@@ -168,8 +257,13 @@ struct PmArith {
         return (u64)(x1 >> sh) * c + low;
     }
     __device__ __forceinline__ u64 reduce_2q(u64 x) const { return csub(x, q); }
-    __device__ __forceinline__ u64 reduce_4q(u64 x) const { return csub(csub(x, two_q), q); }
+    // any 64-bit x -> [0,q)
+    __device__ __forceinline__ u64 canon(u64 x) const { return csub(reduce_x(x), q); }
+    __device__ __forceinline__ u64 reduce_4q(u64 x) const { return canon(x); }
     static constexpr bool kPacked = false;
+    // "wide" lazy domain: butterfly values are arbitrary 64-bit representatives bounded by the analysis at
+    // fwd_bfly / inv_bfly below, not the reference's [0,4q) / [0,2q)
+    static constexpr bool kWide = true;
 };
 
 // B32Arith — the u32 tables (U32NttTable, q < 2^30): a 64-bit word carries the two adjacent
@@ -190,6 +284,8 @@ struct B32Arith {
     GCWordPtr fwd, inv;
     Tw inv_n, inv_n_w;
     static constexpr bool kPacked = true;
+    static constexpr bool kWide = false;
+    static constexpr bool kLastTables = false;
 
     __device__ __forceinline__ explicit B32Arith(const NttPrime *__restrict__ P)
         : q((u32)P->q), two_q32((u32)P->two_q), two_q(P->two_q | (P->two_q << 32)),
@@ -268,8 +364,17 @@ struct B32Arith {
     }
 };
 
-// Harvey forward butterfly, values in [0,4q) — scalar/arithmetic.rs:43-59
-template <class A>
+// Harvey forward butterfly, values in [0,4q) — scalar/arithmetic.rs:43-59.
+//
+// Wide policies (PmArith), in units of U = 2^K (K <= 61, so 8U <= 2^64): a twiddle product is T < 3U and T <= 3q
+// for ANY 64-bit multiplicand, and a folded value is X < U + 2^31.  A butterfly that folds x first gives
+// x' = X + T < 4U + 2^31 and y' = X + 3q - T < 4U + 2^31; one that does NOT fold an input below 4U + 2^31 gives
+// x' < 7U + 2^31 and y' < 7U + 2^31, which still fit 64 bits and are valid inputs of a folding butterfly or of the
+// twiddle product.  So every OTHER stage may skip the fold (FOLD = false); two skipping stages must never
+// follow each other.  Inputs of a transform are below 4q < 4U by the reference's contract, so its first stage may
+// skip as well.  The callers' pattern: a block pass folds at odd distances (2^p, p odd), a strided pass at its
+// even register bits (so its last stage folds, whatever follows).
+template <bool FOLD = true, bool UNI = false, class A>
 __device__ __forceinline__ void fwd_bfly(const A &ar, u64 &x, u64 &y, typename A::Tw w) {
 #ifdef PFHE_EXPERIMENT_NO_BFLY  // data-movement skeleton (tuning experiments only; results are wrong)
     x ^= w.w;
@@ -277,25 +382,44 @@ __device__ __forceinline__ void fwd_bfly(const A &ar, u64 &x, u64 &y, typename A
 #endif
     if constexpr (A::kPacked) {
         ar.fwd_bfly(x, y, w);
-        return;
+    } else if constexpr (A::kWide) {
+#ifndef PFHE_NO_ASM_BFLY
+        pm_fwd_bfly1<FOLD, UNI>(ar, x, y, w);
+#else
+        const u64 tx = FOLD ? ar.reduce_x(x) : x;
+        const u64 t = ar.mul_lazy(y, w);
+        x = tx + t;
+        y = sub_u64(tx + ar.q3, t);
+#endif
+    } else {
+        const u64 tx = ar.reduce_x(x);
+        const u64 t = ar.mul_lazy(y, w);
+        x = tx + t;
+        y = tx + ar.two_q - t;
     }
-    const u64 tx = ar.reduce_x(x);
-    const u64 t = ar.mul_lazy(y, w);
-    x = tx + t;
-    y = tx + ar.two_q - t;
 }
 
-// Gentleman-Sande inverse butterfly, values in [0,2q) — scalar/arithmetic.rs:63-79
-template <class A>
+// Gentleman-Sande inverse butterfly, values in [0,2q) — scalar/arithmetic.rs:63-79.
+// Wide policies: inputs below 3U; x' = fold(x + y) < U + 2^31, y' = (x + 3q - y) * w < 3U.
+template <bool UNI = false, class A>
 __device__ __forceinline__ void inv_bfly(const A &ar, u64 &x, u64 &y, typename A::Tw w) {
     if constexpr (A::kPacked) {
         ar.inv_bfly(x, y, w);
+    } else if constexpr (A::kWide) {
+#ifndef PFHE_NO_ASM_BFLY
+        pm_inv_bfly1<UNI>(ar, x, y, w);
         return;
+#endif
+        const u64 tx = x + y;
+        const u64 ty = sub_u64(x + ar.q3, y);
+        x = ar.reduce_x(tx);
+        y = ar.mul_lazy(ty, w);
+    } else {
+        const u64 tx = x + y;
+        const u64 ty = x + ar.two_q - y;
+        x = ar.reduce_x(tx);
+        y = ar.mul_lazy(ty, w);
     }
-    const u64 tx = x + y;
-    const u64 ty = x + ar.two_q - y;
-    x = ar.reduce_x(tx);
-    y = ar.mul_lazy(ty, w);
 }
 
 // last inverse stage fused with N^-1 (x) and N^-1*w (y) — scalar/transform.rs:283-318
@@ -303,18 +427,37 @@ template <class A>
 __device__ __forceinline__ void inv_final_bfly(const A &ar, u64 &x, u64 &y, bool lazy) {
     if constexpr (A::kPacked) {
         ar.inv_final_bfly(x, y, lazy);
-        return;
+    } else if constexpr (A::kWide) {
+        const u64 tx = x + y;  // the twiddle product takes any 64-bit value: no fold in front of it
+        const u64 ty = sub_u64(x + ar.q3, y);
+        const u64 rx = ar.mul_lazy(tx, ar.tw_inv_n());
+        const u64 ry = ar.mul_lazy(ty, ar.tw_inv_n_w());
+        // lazy results must honour the reference's [0,2q) contract: one fold (< U + 2^31 < 2q)
+        x = lazy ? ar.reduce_x(rx) : ar.canon(rx);
+        y = lazy ? ar.reduce_x(ry) : ar.canon(ry);
+    } else {
+        const u64 tx = ar.reduce_x(x + y);
+        const u64 ty = x + ar.two_q - y;
+        u64 rx = ar.mul_lazy(tx, ar.tw_inv_n());
+        u64 ry = ar.mul_lazy(ty, ar.tw_inv_n_w());
+        if (!lazy) {
+            rx = ar.reduce_2q(rx);
+            ry = ar.reduce_2q(ry);
+        }
+        x = rx;
+        y = ry;
     }
-    const u64 tx = ar.reduce_x(x + y);
-    const u64 ty = x + ar.two_q - y;
-    u64 rx = ar.mul_lazy(tx, ar.tw_inv_n());
-    u64 ry = ar.mul_lazy(ty, ar.tw_inv_n_w());
-    if (!lazy) {
-        rx = ar.reduce_2q(rx);
-        ry = ar.reduce_2q(ry);
+}
+
+// end of a forward transform: the lazy result honours the reference's [0,4q) contract, the plain one is canonical
+// (scalar/transform.rs:104-116)
+template <class A>
+__device__ __forceinline__ u64 fwd_finish(const A &ar, u64 x, bool lazy) {
+    if constexpr (A::kWide) {
+        return lazy ? ar.reduce_x(x) : ar.canon(x);
+    } else {
+        return lazy ? x : ar.reduce_4q(x);
     }
-    x = rx;
-    y = ry;
 }
 
 // K forward stages on 2^K register-resident coefficients at stride 2^log_s (element index of
@@ -332,7 +475,11 @@ __device__ __forceinline__ void strided_forward_regs(const A &ar, u64 (&x)[1 << 
             for (int v = 0; v < (1 << j); ++v) {
                 const int k0 = (u << (j + 1)) | v, k1 = k0 | (1 << j);
 #pragma unroll
-                for (int c = 0; c < VEC; ++c) fwd_bfly(ar, x[k0][c], x[k1][c], w);
+                for (int c = 0; c < VEC; ++c) {
+                    // (the twiddle index is wave-uniform in every strided kernel: scalar registers)
+                    if (j & 1) fwd_bfly<false, true>(ar, x[k0][c], x[k1][c], w);
+                    else fwd_bfly<true, true>(ar, x[k0][c], x[k1][c], w);
+                }
             }
         }
     }
@@ -356,7 +503,7 @@ __device__ __forceinline__ void strided_inverse_regs(const A &ar, u64 (&x)[1 << 
             for (int v = 0; v < (1 << j); ++v) {
                 const int k0 = (u << (j + 1)) | v, k1 = k0 | (1 << j);
 #pragma unroll
-                for (int c = 0; c < VEC; ++c) inv_bfly(ar, x[k0][c], x[k1][c], w);
+                for (int c = 0; c < VEC; ++c) inv_bfly<true>(ar, x[k0][c], x[k1][c], w);
             }
         }
     }
@@ -410,17 +557,40 @@ __device__ __forceinline__ u32 maybe_uniform(u32 v) {
 // forward stages on register bits JHI..JLO (element bits POS+JHI .. POS+JLO); twiddle of the
 // butterfly at global element E, distance 2^p: fwd[(N + E) >> (p + 1)]
 template <class A, int POS, int JHI, int JLO, bool UNIFORM>
-__device__ __forceinline__ void fwd_regpass(const A &ar, u64 (&x)[16], u32 n_plus_e) {
+__device__ __forceinline__ void fwd_regpass(const A &ar, u64 (&x)[16], u32 n_plus_e, u32 n) {
 #pragma unroll
     for (int j = JHI; j >= JLO; --j) {
         const u32 base = maybe_uniform<POS, UNIFORM>(n_plus_e >> (POS + j + 1));
+        // POS == 0: every lane has twiddles of its own; the lane-ordered tables make the wave's loads contiguous
+        const u32 last_off = (((8u >> j) - 1) * (n >> 4)) + ((n_plus_e - n) >> 4);
+        constexpr bool kUni = UNIFORM && POS >= 6;  // maybe_uniform: the twiddle sits in scalar registers
+        typename A::Tw w[8];
 #pragma unroll
         for (int u = 0; u < (16 >> (j + 1)); ++u) {
-            const typename A::Tw w = ar.fwd_tw(base + u);
+            if constexpr (POS == 0 && A::kLastTables) w[u] = ar.fwd_tw_last(last_off + (u32)u * (n >> 4));
+            else w[u] = ar.fwd_tw(base + u);
+        }
+#if !defined(PFHE_NO_ASM_BFLY_PAIRS) && !defined(PFHE_NO_ASM_BFLY)
+        if constexpr (A::kWide) {
+            // two butterflies per asm block (independent instruction streams interleaved): butterfly b of the stage
+            // has u = b >> j, v = b & (2^j - 1)
+#pragma unroll
+            for (int b = 0; b < 8; b += 2) {
+                const int ua = b >> j, va = b & ((1 << j) - 1), ub = (b + 1) >> j, vb = (b + 1) & ((1 << j) - 1);
+                const int a0 = (ua << (j + 1)) | va, a1 = a0 | (1 << j), b0 = (ub << (j + 1)) | vb, b1 = b0 | (1 << j);
+                if ((POS + j) & 1) pm_fwd_bfly2<true, kUni>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
+                else pm_fwd_bfly2<false, kUni>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
+            }
+            continue;
+        }
+#endif
+#pragma unroll
+        for (int u = 0; u < (16 >> (j + 1)); ++u) {
 #pragma unroll
             for (int v = 0; v < (1 << j); ++v) {
                 const int k0 = (u << (j + 1)) | v, k1 = k0 | (1 << j);
-                fwd_bfly(ar, x[k0], x[k1], w);
+                if ((POS + j) & 1) fwd_bfly<true, kUni>(ar, x[k0], x[k1], w[u]);  // distance 2^(POS+j)
+                else fwd_bfly<false, kUni>(ar, x[k0], x[k1], w[u]);
             }
         }
     }
@@ -439,13 +609,31 @@ __device__ __forceinline__ void inv_regpass(const A &ar, u64 (&x)[16], u32 n, u3
             for (int v = 0; v < 8; ++v) inv_final_bfly(ar, x[v], x[v | 8], lazy);
         } else {
             const u32 base = maybe_uniform<POS, UNIFORM>(1 + n - (n >> p) + (e_abs >> (p + 1)));
+            const u32 last_off = (((8u >> j) - 1) * (n >> 4)) + (e_abs >> 4);  // POS == 0: lane-ordered tables
+            constexpr bool kUni = UNIFORM && POS >= 6;
+            typename A::Tw w[8];
 #pragma unroll
             for (int u = 0; u < (16 >> (j + 1)); ++u) {
-                const typename A::Tw w = ar.inv_tw(base + u);
+                if constexpr (POS == 0 && A::kLastTables) w[u] = ar.inv_tw_last(last_off + (u32)u * (n >> 4));
+                else w[u] = ar.inv_tw(base + u);
+            }
+#if !defined(PFHE_NO_ASM_BFLY_PAIRS) && !defined(PFHE_NO_ASM_BFLY)
+            if constexpr (A::kWide) {  // two butterflies per asm block, as in fwd_regpass
+#pragma unroll
+                for (int b = 0; b < 8; b += 2) {
+                    const int ua = b >> j, va = b & ((1 << j) - 1), ub = (b + 1) >> j, vb = (b + 1) & ((1 << j) - 1);
+                    const int a0 = (ua << (j + 1)) | va, a1 = a0 | (1 << j), b0 = (ub << (j + 1)) | vb, b1 = b0 | (1 << j);
+                    pm_inv_bfly2<kUni>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
+                }
+                continue;
+            }
+#endif
+#pragma unroll
+            for (int u = 0; u < (16 >> (j + 1)); ++u) {
 #pragma unroll
                 for (int v = 0; v < (1 << j); ++v) {
                     const int k0 = (u << (j + 1)) | v, k1 = k0 | (1 << j);
-                    inv_bfly(ar, x[k0], x[k1], w);
+                    inv_bfly<kUni>(ar, x[k0], x[k1], w[u]);
                 }
             }
         }
@@ -497,7 +685,7 @@ __device__ __forceinline__ void fwd_chain(const A &ar, u64 (&x)[16], u64 *__rest
         constexpr int NPOS = POS >= 4 ? POS - 4 : 0;
         constexpr int JHI = POS >= 4 ? 3 : POS - 1;
         lds_exchange<POS, NPOS, FIRST>(x, lds, lt);
-        fwd_regpass<A, NPOS, JHI, 0, UNI>(ar, x, n + eblk + layout<NPOS>(lt, 0));
+        fwd_regpass<A, NPOS, JHI, 0, UNI>(ar, x, n + eblk + layout<NPOS>(lt, 0), n);
         fwd_chain<A, LOGB, NPOS>(ar, x, lds, n, eblk, lt);
     }
 }
@@ -510,13 +698,16 @@ __device__ __forceinline__ void block_forward_core(const A &ar, u64 (&x)[16], u6
                                                    u32 eblk, u32 lt, bool lazy) {
     constexpr int POS0 = LOGB - 4;
     constexpr bool UNI = BlockCfg<LOGB>::TPB >= 64;  // a wave never straddles two blocks
-    fwd_regpass<A, POS0, 3, 0, UNI>(ar, x, n + eblk + layout<POS0>(lt, 0));
+    fwd_regpass<A, POS0, 3, 0, UNI>(ar, x, n + eblk + layout<POS0>(lt, 0), n);
     fwd_chain<A, LOGB, POS0, LEAD>(ar, x, lds, n, eblk, lt);
     if constexpr (A::kPacked) {  // distance-1 stage between the halves of each word
 #pragma unroll
         for (int k = 0; k < 16; ++k) x[k] = ar.fwd_intra(x[k], n + eblk + layout<0>(lt, k));
     }
-    if (!lazy) {  // [0,4q) -> [0,q): scalar/transform.rs:104-116
+    if constexpr (A::kWide) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = fwd_finish(ar, x[k], lazy);
+    } else if (!lazy) {  // [0,4q) -> [0,q): scalar/transform.rs:104-116
 #pragma unroll
         for (int k = 0; k < 16; ++k) x[k] = ar.reduce_4q(x[k]);
     }
