@@ -77,6 +77,9 @@ int make_table_set(u32 log_n, const u64 *moduli, size_t count, int device, std::
     ts->n = (size_t)1 << log_n;
     ts->L = (u32)count;
     ts->primes.resize(count);
+    ts->tune = NttTuning::from_env();
+    ts->fused_polymul = std::getenv("PFHE_DISABLE_FUSED_POLYMUL") == nullptr;
+    ts->monomial_inplace = std::getenv("PFHE_DISABLE_MONOMIAL_INPLACE") == nullptr;
     const size_t bytes = ts->n * sizeof(ulonglong2);
     bool all_pm = std::getenv("PFHE_DISABLE_PM") == nullptr;  // tuning switch: force the generic path
     for (size_t i = 0; i < count; ++i) {
@@ -193,8 +196,8 @@ int transform_dev(const TableSet &t, u64 *data, size_t len, bool inverse, bool l
     DeviceGuard g(t.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
     const u64 npolys = units * t.L;
-    return inverse ? ntt_inverse_dev(t.primes_dev, t.L, t.log_n, t.pm, data, npolys, lazy, s)
-                   : ntt_forward_dev(t.primes_dev, t.L, t.log_n, t.pm, data, npolys, lazy, s);
+    return inverse ? ntt_inverse_dev(t.primes_dev, t.L, t.log_n, t.pm, data, npolys, lazy, s, t.tune)
+                   : ntt_forward_dev(t.primes_dev, t.L, t.log_n, t.pm, data, npolys, lazy, s, t.tune);
 }
 
 // host-pointer wrapper: stage through a temporary device buffer
@@ -270,7 +273,11 @@ int monomial(const TableSet &t, u64 coeff, size_t degree, u64 *values, size_t le
         set_last_error("monomial output must be exactly one polynomial");
         return PFHE_ERR_BAD_LENGTH;
     }
-    std::vector<u64> c(2 * t.L);
+    if (t.L > kMaxMonomialLimbs) {
+        set_last_error("monomial transforms support at most 16 moduli");
+        return PFHE_ERR_UNSUPPORTED;
+    }
+    MonomialScalars sc{};
     for (u32 i = 0; i < t.L; ++i) {
         const u64 q = t.primes[i].q;
         const u64 ci = minus_one ? q - 1 : coeff;
@@ -278,26 +285,21 @@ int monomial(const TableSet &t, u64 coeff, size_t degree, u64 *values, size_t le
             set_last_error("monomial coefficient must be reduced modulo every modulus");
             return PFHE_ERR_BAD_ARGUMENT;
         }
-        c[i] = ci;
-        c[t.L + i] = (u64)(((unsigned __int128)ci << 64) / q);
+        sc.value[i] = ci;
+        sc.quotient[i] = (u64)(((unsigned __int128)ci << 64) / q);
     }
     DeviceGuard g(t.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    void *cd = nullptr;
-    PFHE_HIP(hipMalloc(&cd, c.size() * sizeof(u64)));
-    int rc = PFHE_OK;
-    hipError_t e = hipMemcpyAsync(cd, c.data(), c.size() * sizeof(u64), hipMemcpyHostToDevice, s);
-    void *out_dev = values;
-    if (e == hipSuccess && host) e = hipMalloc(&out_dev, len * sizeof(u64));
-    if (e == hipSuccess) {
-        const u64 deg = (u64)degree & (2 * (u64)t.n - 1);
-        rc = monomial_dev(static_cast<u64 *>(out_dev), t.primes_dev, t.L, t.log_n, deg, static_cast<u64 *>(cd),
-                          static_cast<u64 *>(cd) + t.L, s);
-        if (rc == PFHE_OK && host) e = hipMemcpy(values, out_dev, len * sizeof(u64), hipMemcpyDeviceToHost);
-        if (rc == PFHE_OK && e == hipSuccess) e = hipStreamSynchronize(s);  // c and cd must outlive the kernel
-    }
-    if (host && out_dev != values) (void)hipFree(out_dev);
-    (void)hipFree(cd);
+    const u64 deg = (u64)degree & (2 * (u64)t.n - 1);
+    if (!host)  // device output: one launch on the caller's stream, nothing else (capturable)
+        return monomial_dev(values, t.primes_dev, t.L, t.log_n, deg, sc, s);
+    void *out_dev = nullptr;
+    PFHE_HIP(hipMalloc(&out_dev, len * sizeof(u64)));
+    int rc = monomial_dev(static_cast<u64 *>(out_dev), t.primes_dev, t.L, t.log_n, deg, sc, s);
+    hipError_t e = hipSuccess;
+    if (rc == PFHE_OK) e = hipMemcpyAsync(values, out_dev, len * sizeof(u64), hipMemcpyDeviceToHost, s);
+    if (rc == PFHE_OK && e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(out_dev);
     if (e != hipSuccess) return hip_fail(e, "monomial transform", __FILE__, __LINE__);
     return rc;
 }
@@ -737,13 +739,13 @@ int pfhe_dcrt_glwe_mul_dcrt_polynomial_to_dev(const pfhe_dcrt *table, const uint
 }
 
 int pfhe_dcrt_transform_num_passes(const pfhe_dcrt *table) {
-    return table ? ntt_num_passes(table->t->log_n) : 0;
+    return table ? ntt_num_passes(table->t->log_n, table->t->pm, table->t->tune) : 0;
 }
 
 const char *pfhe_dcrt_transform_pass_name(const pfhe_dcrt *table, int inverse, int index) {
     static thread_local char buf[96];
     buf[0] = 0;
-    if (table) ntt_pass_name(table->t->log_n, inverse != 0, index, buf, sizeof buf);
+    if (table) ntt_pass_name(table->t->log_n, inverse != 0, index, buf, sizeof buf, table->t->pm, table->t->tune);
     return buf;
 }
 
@@ -757,7 +759,7 @@ int pfhe_dcrt_transform_pass_dev(const pfhe_dcrt *table, uint64_t *poly_dev, siz
     DeviceGuard g(t.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
     return ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.pm, (u64 *)poly_dev, len / t.n, inverse != 0, index,
-                        lazy != 0, (hipStream_t)stream);
+                        lazy != 0, (hipStream_t)stream, nullptr, 0, t.tune);
     PFHE_GUARD_END
 }
 
@@ -766,19 +768,26 @@ int pfhe_dcrt_mul_dcrt_polynomial_dev(const pfhe_dcrt *table, uint64_t *crt_poly
     PFHE_GUARD_BEGIN
     if (!table) return PFHE_ERR_BAD_ARGUMENT;
     const TableSet &t = *table->t;
+    // every argument is checked BEFORE the forward transform is enqueued: a call that fails leaves the caller's
+    // polynomial in coefficient form
+    if ((!crt_poly_dev || !dcrt_poly_dev) && len) return PFHE_ERR_BAD_ARGUMENT;
+    PFHE_REQUIRE_ALIGNED(crt_poly_dev);
+    PFHE_REQUIRE_ALIGNED(dcrt_poly_dev);
+    if (len % (t.n * t.L) != 0) {
+        set_last_error("slice length is not a multiple of the polynomial length");
+        return PFHE_ERR_BAD_LENGTH;
+    }
+    if (len_b != len && len_b != t.n * t.L) {
+        set_last_error("multiplicand must have the same length or exactly one polynomial");
+        return PFHE_ERR_BAD_LENGTH;
+    }
     PFHE_TRY(transform_dev(t, (u64 *)crt_poly_dev, len, false, false, (hipStream_t)stream));
-    if (t.log_n >= 4 && len != 0 && std::getenv("PFHE_DISABLE_FUSED_POLYMUL") == nullptr) {
+    if (t.log_n >= 4 && len != 0 && t.fused_polymul) {
         // the pointwise product rides on the loads of the inverse transform's first pass
-        if ((!crt_poly_dev || !dcrt_poly_dev)) return PFHE_ERR_BAD_ARGUMENT;
-        PFHE_REQUIRE_ALIGNED(dcrt_poly_dev);
-        if (len_b != len && len_b != t.n * t.L) {
-            set_last_error("multiplicand must have the same length or exactly one polynomial");
-            return PFHE_ERR_BAD_LENGTH;
-        }
         DeviceGuard g(t.device);
         if (!g.ok) return PFHE_ERR_NO_DEVICE;
         return ntt_inverse_mul_dev(t.primes_dev, t.L, t.log_n, t.pm, (u64 *)crt_poly_dev, len / t.n,
-                                   (const u64 *)dcrt_poly_dev, len_b / t.n, (hipStream_t)stream);
+                                   (const u64 *)dcrt_poly_dev, len_b / t.n, (hipStream_t)stream, t.tune);
     }
     PFHE_TRY(pointwise(t, 0, (u64 *)crt_poly_dev, nullptr, len, (const u64 *)dcrt_poly_dev, len_b,
                        (hipStream_t)stream));

@@ -27,6 +27,8 @@ struct pfhe_extprod_plan {
     // second buffer, decomposition + strided pass of chunk c+1 on stream `sa` beside the transform +
     // multiply-accumulate of chunk c on stream `sb`.
     bool pipeline = false;
+    // PFHE_DISABLE_SMALL_EXTPROD / _FUSED_EXTPROD / _FUSED_DECOMPOSE, read at plan creation
+    bool use_small = true, use_fused = true, use_fused_decompose = true;
     u64 *digits[2] = {nullptr, nullptr};
     size_t digits_words = 0;  // per buffer
     int *sdigits = nullptr;   // compact signed digits of one chunk (chunk * (k+1) * ell * N int32), or null
@@ -99,7 +101,7 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
     // small rings: digit extraction + ONE kernel for everything else, chunk by chunk on the caller's stream
     // (one workgroup per (ciphertext, limb) runs 12+ transforms back to back: it needs a batch that fills the chip)
     if (p->sdigits != nullptr && extprod_small_supported(t.log_n, p->k, p->rns.value_len, p->basis.log_basis) &&
-        batch * t.L >= 1024 && std::getenv("PFHE_DISABLE_SMALL_EXTPROD") == nullptr) {
+        batch * t.L >= 1024 && p->use_small) {
         for (u64 done = 0; done < batch; done += p->chunk) {
             const u64 cur = std::min<u64>(p->chunk, batch - done);
             PFHE_TRY(gadget_signed_digits_dev(rns, p->basis, t.log_n, crt_polys + done * rows * in_words, p->sdigits, cur * rows, s));
@@ -112,11 +114,11 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
     }
     const bool single = !p->pipeline || batch <= p->chunk || stream_is_capturing(s);
     hipStream_t sa = single ? s : p->sa, sb = single ? s : p->sb;
-    const bool fused = gadget_fused_supported(t.log_n, p->k) && std::getenv("PFHE_DISABLE_FUSED_EXTPROD") == nullptr &&
+    const bool fused = gadget_fused_supported(t.log_n, p->k) && p->use_fused &&
                        ((std::min<u64>(batch, p->chunk) * t.L) << (t.log_n - 12)) >= 256;
-    const int passes = ntt_num_passes(t.log_n);
+    const int passes = ntt_num_passes(t.log_n, t.pm, t.tune);
     const bool fused_decompose = gadget_decompose_strided_supported(t.log_n, p->rns.value_len) &&
-                                 std::getenv("PFHE_DISABLE_FUSED_DECOMPOSE") == nullptr;
+                                 p->use_fused_decompose;
     if (!single) {
         PFHE_HIP(hipEventRecord(p->fork, s));
         PFHE_HIP(hipStreamWaitEvent(sa, p->fork, 0));
@@ -149,7 +151,7 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
         } else {
             PFHE_TRY(gadget_decompose_dev(rns, p->basis, t.log_n, crt_polys + done * rows * in_words, dg, cur * rows, sa));
             for (int i = 0; i < passes - 1; ++i)
-                PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.pm, dg, npolys, false, i, false, sa));
+                PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.pm, dg, npolys, false, i, false, sa, nullptr, 0, t.tune));
         }
         if (!single) PFHE_HIP(hipEventRecord(p->produced[buf], sa));
         // ---- stream b: block pass (last pass of the transform) ----
@@ -159,7 +161,7 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
                                              keys + (keys_shared ? 0 : done * key_words), keys_shared,
                                              result + done * (p->k + 1) * W, cur, accumulate, sb));
         } else {
-            PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.pm, dg, npolys, false, passes - 1, false, sb));
+            PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.pm, dg, npolys, false, passes - 1, false, sb, nullptr, 0, t.tune));
         }
         if (!single) PFHE_HIP(hipEventRecord(p->consumed[buf], sb));
         if (!fused) {
@@ -567,7 +569,11 @@ int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *rns, const 
     p->digits_words = p->chunk * (p->k + 1) * p->basis.ell * t->L * t->n;
     DeviceGuard g(t->device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    // tuning switches: read here, once, and kept in the plan (nothing on the launch path calls getenv)
     p->pipeline = std::getenv("PFHE_EXTPROD_PIPELINE") != nullptr;
+    p->use_small = std::getenv("PFHE_DISABLE_SMALL_EXTPROD") == nullptr;
+    p->use_fused = std::getenv("PFHE_DISABLE_FUSED_EXTPROD") == nullptr;
+    p->use_fused_decompose = std::getenv("PFHE_DISABLE_FUSED_DECOMPOSE") == nullptr;
     for (int i = 0; i < 2; ++i) {
         void *d = nullptr;
         if (i == 0 || p->pipeline) PFHE_HIP(hipMalloc(&d, p->digits_words * sizeof(u64)));
@@ -626,7 +632,7 @@ int pfhe_extprod_mul_dcrt_ggsw_to_dev(pfhe_extprod_plan *plan, const uint64_t *c
                          (u64 *)result_dev, batch, false, (hipStream_t)stream, into_coeff_form != 0, &coeff_done));
     if (into_coeff_form && !coeff_done)  // DcrtGlwe::into_coeff_form, macros/mod.rs:901-911
         PFHE_TRY(ntt_inverse_dev(t.primes_dev, t.L, t.log_n, t.pm, (u64 *)result_dev, batch * (plan->k + 1) * t.L, false,
-                                 (hipStream_t)stream));
+                                 (hipStream_t)stream, t.tune));
     return PFHE_OK;
     PFHE_GUARD_END
 }

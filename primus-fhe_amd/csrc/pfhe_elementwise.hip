@@ -413,7 +413,7 @@ int pfhe_dcrt_mul_monomial_assign_dev(const pfhe_dcrt *table, uint64_t *data_dev
         return PFHE_ERR_BAD_ARGUMENT;
     }
     if (len == 0) return PFHE_OK;
-    if (t.log_n >= 9 && t.log_n <= 14 && len / t.n <= 0x7fffffffull && std::getenv("PFHE_DISABLE_MONOMIAL_INPLACE") == nullptr) {
+    if (t.log_n >= 9 && t.log_n <= 14 && len / t.n <= 0x7fffffffull && t.monomial_inplace) {
         // truly in place: one workgroup per polynomial, data held in registers across the barrier
         const bool high = r >= t.n;
         const u32 rot = (u32)(high ? r - t.n : r);

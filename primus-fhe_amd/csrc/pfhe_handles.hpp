@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "pfhe_common.hpp"
+#include "pfhe_ntt_device.hpp"
 
 namespace pfhe {
 
@@ -14,6 +15,10 @@ struct TableSet {
     size_t n = 1;
     u32 L = 0;
     bool pm = false;                       // every prime has the pseudo-Mersenne shape
+    // tuning switches, read from the environment once, when the handle is created
+    NttTuning tune;
+    bool fused_polymul = true;             // cleared by PFHE_DISABLE_FUSED_POLYMUL
+    bool monomial_inplace = true;          // cleared by PFHE_DISABLE_MONOMIAL_INPLACE
     std::vector<NttPrime> primes;          // host copies (device pointers inside)
     const NttPrime *primes_dev = nullptr;  // the same array on the device
     const u64 *moduli_dev = nullptr;

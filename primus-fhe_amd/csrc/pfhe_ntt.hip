@@ -304,13 +304,13 @@ int launch_strided(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u32 log_
 
 template <class A, bool INV, bool FINAL>
 int dispatch_strided(int k, u64 *data, const NttPrime *primes, u32 L, u32 log_n, u32 log_s, u64 npolys, bool lazy,
-                     hipStream_t s) {
+                     hipStream_t s, bool vec1) {
     switch (k) {
         case 1: return launch_strided<A, 1, 2, INV, FINAL>(data, primes, L, log_n, log_s, npolys, lazy, s);
         case 2: return launch_strided<A, 2, 2, INV, FINAL>(data, primes, L, log_n, log_s, npolys, lazy, s);
         case 3: return launch_strided<A, 3, 2, INV, FINAL>(data, primes, L, log_n, log_s, npolys, lazy, s);
         case 4:
-            if (std::getenv("PFHE_STRIDED_VEC1") != nullptr)  // tuning switch: one column per thread (fewer registers)
+            if (vec1)  // tuning switch: one column per thread (fewer registers)
                 return launch_strided<A, 4, 1, INV, FINAL>(data, primes, L, log_n, log_s, npolys, lazy, s);
             return launch_strided<A, 4, 2, INV, FINAL>(data, primes, L, log_n, log_s, npolys, lazy, s);
         case 5: return launch_strided<A, 5, 1, INV, FINAL>(data, primes, L, log_n, log_s, npolys, lazy, s);
@@ -333,7 +333,7 @@ int launch_tiny(bool inverse, const NttPrime *primes, u32 L, u32 log_n, u64 *dat
 // then strided passes, the last of which carries the fused final stage)
 template <class A>
 int run_pass(const NttPlan &plan, const NttPrime *primes, u32 L, u32 log_n, u64 *data, u64 npolys, bool inverse,
-             int index, bool lazy, hipStream_t s, const u64 *mul = nullptr, u64 mul_polys = 0) {
+             int index, bool lazy, hipStream_t s, const u64 *mul, u64 mul_polys, bool vec1) {
     const int block_at = inverse ? 0 : plan.n_strided;
     if (mul != nullptr) {
         if constexpr (A::kPacked) {
@@ -351,24 +351,38 @@ int run_pass(const NttPlan &plan, const NttPrime *primes, u32 L, u32 log_n, u64 
     u32 log_s = log_n;
     for (int j = 0; j <= i; ++j) log_s -= plan.strided[j];
     const int k = plan.strided[i];
-    if (!inverse) return dispatch_strided<A, false, false>(k, data, primes, L, log_n, log_s, npolys, false, s);
-    if (i == 0) return dispatch_strided<A, true, true>(k, data, primes, L, log_n, log_s, npolys, lazy, s);
-    return dispatch_strided<A, true, false>(k, data, primes, L, log_n, log_s, npolys, false, s);
+    if (!inverse) return dispatch_strided<A, false, false>(k, data, primes, L, log_n, log_s, npolys, false, s, vec1);
+    if (i == 0) return dispatch_strided<A, true, true>(k, data, primes, L, log_n, log_s, npolys, lazy, s, vec1);
+    return dispatch_strided<A, true, false>(k, data, primes, L, log_n, log_s, npolys, false, s, vec1);
 }
 
 }  // namespace
 
-NttPlan make_ntt_plan(u32 log_n, int arith) {
+static int env_int(const char *name, int lo, int hi) {
+    const char *e = std::getenv(name);
+    if (!e) return 0;
+    const int v = std::atoi(e);
+    return v >= lo && v <= hi ? v : 0;
+}
+
+NttTuning NttTuning::from_env() {
+    NttTuning t;
+    t.overlap = std::getenv("PFHE_DISABLE_OVERLAP") == nullptr;
+    t.overlap_inverse = std::getenv("PFHE_OVERLAP_INVERSE") != nullptr;
+    t.overlap_tiles = env_int("PFHE_OVERLAP_TILES", 2, 4096);
+    t.strided_vec1 = std::getenv("PFHE_STRIDED_VEC1") != nullptr;
+    t.max_single_pass_log = env_int("PFHE_MAX_SINGLE_PASS_LOG", 9, (int)kMaxSinglePassLog);
+    t.block_log = env_int("PFHE_BLOCK_LOG", 8, 12);
+    return t;
+}
+
+NttPlan make_ntt_plan(u32 log_n, int arith, const NttTuning &tune) {
     NttPlan p;
     if (log_n <= 3) {
         p.tiny = true;
         return p;
     }
-    u32 max_single = kMaxSinglePassLog;
-    if (const char *e = std::getenv("PFHE_MAX_SINGLE_PASS_LOG")) {  // tuning switch
-        const int v = std::atoi(e);
-        if (v >= 9 && v <= (int)kMaxSinglePassLog) max_single = (u32)v;
-    }
+    const u32 max_single = tune.max_single_pass_log ? (u32)tune.max_single_pass_log : kMaxSinglePassLog;
     if (log_n <= max_single) {
         p.block_log = (int)log_n;
         return p;
@@ -377,10 +391,7 @@ NttPlan make_ntt_plan(u32 log_n, int arith) {
     // u32 tables at N = 2^16 (2^15 words): 4 strided stages + blocks of 2^11 words in 128-thread workgroups
     // (8 resident per CU) measured 3.05 ms against 3.24 ms for 3 + 2^12
     if (arith == 2 /* kArithB32 */ && log_n == 15) p.block_log = 11;
-    if (const char *e = std::getenv("PFHE_BLOCK_LOG")) {  // tuning switch: block size under strided passes
-        const int b = std::atoi(e);
-        if (b >= 8 && b <= 12 && (int)log_n - b >= 1) p.block_log = b;
-    }
+    if (tune.block_log && (int)log_n - tune.block_log >= 1) p.block_log = tune.block_log;  // tuning switch
     if (p.block_log >= (int)log_n) p.block_log = (int)log_n - 1;  // only reachable through the tuning switches
     int rest = (int)log_n - p.block_log;
     // fewest strided passes with at most 5 stages each, balanced
@@ -393,13 +404,13 @@ NttPlan make_ntt_plan(u32 log_n, int arith) {
     return p;
 }
 
-int ntt_num_passes(u32 log_n, int arith) {
-    const NttPlan plan = make_ntt_plan(log_n, arith);
+int ntt_num_passes(u32 log_n, int arith, const NttTuning &tune) {
+    const NttPlan plan = make_ntt_plan(log_n, arith, tune);
     return plan.tiny ? 1 : plan.n_strided + 1;
 }
 
-void ntt_pass_name(u32 log_n, bool inverse, int index, char *buf, size_t cap, int arith) {
-    const NttPlan plan = make_ntt_plan(log_n, arith);
+void ntt_pass_name(u32 log_n, bool inverse, int index, char *buf, size_t cap, int arith, const NttTuning &tune) {
+    const NttPlan plan = make_ntt_plan(log_n, arith, tune);
     if (plan.tiny) {
         std::snprintf(buf, cap, "ntt_tiny_kernel");
         return;
@@ -414,17 +425,18 @@ void ntt_pass_name(u32 log_n, bool inverse, int index, char *buf, size_t cap, in
 }
 
 int ntt_pass_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, bool inverse, int index,
-                 bool lazy, hipStream_t s, const u64 *mul, u64 mul_polys) {
-    const NttPlan plan = make_ntt_plan(log_n, arith);
-    if (index < 0 || index >= ntt_num_passes(log_n, arith)) return PFHE_ERR_BAD_ARGUMENT;
+                 bool lazy, hipStream_t s, const u64 *mul, u64 mul_polys, const NttTuning &tune) {
+    const NttPlan plan = make_ntt_plan(log_n, arith, tune);
+    if (index < 0 || index >= (plan.tiny ? 1 : plan.n_strided + 1)) return PFHE_ERR_BAD_ARGUMENT;
+    const bool v1 = tune.strided_vec1;
     if (arith == kArithB32) {
         if (plan.tiny) return PFHE_ERR_UNSUPPORTED;  // N <= 16 is served by ntt32_tiny_kernel
-        return run_pass<B32Arith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys);
+        return run_pass<B32Arith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys, v1);
     }
     if (plan.tiny) return mul ? PFHE_ERR_UNSUPPORTED : launch_tiny(inverse, primes, L, log_n, data, npolys, lazy, s);
     return arith == kArithPm
-               ? run_pass<PmArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys)
-               : run_pass<ShoupArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys);
+               ? run_pass<PmArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys, v1)
+               : run_pass<ShoupArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys, v1);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -445,34 +457,79 @@ constexpr u64 kOverlapMinBytes = 512ull << 20;  // below this the extra launches
 
 struct OverlapCtx {
     hipStream_t a = nullptr, b = nullptr;
-    hipEvent_t fork = nullptr, join_a = nullptr, join_b = nullptr;
-    hipEvent_t tile[kOverlapTiles] = {};
+    hipEvent_t fork = nullptr, join_a = nullptr, join_b = nullptr, done = nullptr;
+    std::vector<hipEvent_t> tile;
+    bool done_recorded = false;  // `done` marks the end of the last user's work on streams a and b
+    ~OverlapCtx() {
+        for (hipEvent_t e : tile)
+            if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {fork, join_a, join_b, done})
+            if (e) (void)hipEventDestroy(e);
+        if (a) (void)hipStreamDestroy(a);
+        if (b) (void)hipStreamDestroy(b);
+    }
 };
 
 std::mutex g_overlap_mutex;
 std::vector<OverlapCtx *> g_overlap_free[64];
 
-OverlapCtx *acquire_overlap_ctx(int dev) {
+// PFHE_TEST_FAIL_OVERLAP_CTX (read once): fail the creation after N successful HIP objects, to exercise the
+// clean-up path (tests/test_gpu_ntt.py); never set in production
+int overlap_fail_after() {
+    static const int v = [] {
+        const char *e = std::getenv("PFHE_TEST_FAIL_OVERLAP_CTX");
+        return e ? std::atoi(e) : -1;
+    }();
+    return v;
+}
+
+OverlapCtx *acquire_overlap_ctx(int dev, int tiles) {
+    OverlapCtx *c = nullptr;
     {
         std::lock_guard<std::mutex> lock(g_overlap_mutex);
+        // A context returns to the free list while its streams may still be busy.  Prefer one whose last user has
+        // finished (another caller stream would otherwise queue silently behind that work); with several busy ones
+        // around, create a new context rather than wait, up to a small pool.
         auto &fl = g_overlap_free[dev];
-        if (!fl.empty()) {
-            OverlapCtx *c = fl.back();
+        for (size_t i = fl.size(); i-- > 0;) {
+            if (!fl[i]->done_recorded || hipEventQuery(fl[i]->done) == hipSuccess) {
+                c = fl[i];
+                fl.erase(fl.begin() + (long)i);
+                break;
+            }
+        }
+        (void)hipGetLastError();  // hipEventQuery reports "not ready" as an error code
+        if (!c && fl.size() >= 8) {
+            c = fl.back();
             fl.pop_back();
-            return c;
         }
     }
-    auto *c = new OverlapCtx();
-    bool ok = hipStreamCreateWithFlags(&c->a, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&c->b, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&c->join_a, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&c->join_b, hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; ok && i < kOverlapTiles; ++i)
-        ok = hipEventCreateWithFlags(&c->tile[i], hipEventDisableTiming) == hipSuccess;
+    int made = 0;
+    const int fail_after = overlap_fail_after();
+    const auto ok_stream = [&](hipStream_t *st) {
+        if (fail_after >= 0 && made >= fail_after) return false;
+        ++made;
+        return hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess;
+    };
+    const auto ok_event = [&](hipEvent_t *ev) {
+        if (fail_after >= 0 && made >= fail_after) return false;
+        ++made;
+        return hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
+    };
+    bool ok = true;
+    if (!c) {
+        c = new OverlapCtx();
+        ok = ok_stream(&c->a) && ok_stream(&c->b) && ok_event(&c->fork) && ok_event(&c->join_a) && ok_event(&c->join_b) &&
+             ok_event(&c->done);
+    }
+    while (ok && (int)c->tile.size() < tiles) {
+        hipEvent_t ev = nullptr;
+        ok = ok_event(&ev);
+        if (ok) c->tile.push_back(ev);
+    }
     if (!ok) {
         (void)hipGetLastError();
-        delete c;  // leaks whatever was created on this failure path; the caller falls back to one stream
+        delete c;  // the destructor releases whatever was created; the caller falls back to one stream
         return nullptr;
     }
     return c;
@@ -486,27 +543,23 @@ void release_overlap_ctx(int dev, OverlapCtx *c) {
 }  // namespace
 
 static int transform(const NttPrime *primes, u32 L, u32 log_n, int pm, u64 *data, u64 npolys, bool inverse,
-                     bool lazy, hipStream_t s, const u64 *mul = nullptr, u64 mul_polys = 0) {
-    const int passes = ntt_num_passes(log_n, pm);
+                     bool lazy, hipStream_t s, const NttTuning &tune, const u64 *mul = nullptr, u64 mul_polys = 0) {
+    const int passes = ntt_num_passes(log_n, pm, tune);
     const u64 bytes = (npolys << log_n) * sizeof(u64);
     int dev = 0;
     // (the u32 tables do not gain from the overlap: measured 3.40 ms vs 3.15 ms without, N = 2^16)
     // (the inverse direction, block pass first, measures 2 % slower tiled than as two full-size launches: 5.98 vs
-    // 5.85 ms; PFHE_OVERLAP_INVERSE=1 tiles it anyway)
-    const bool overlap_inverse = std::getenv("PFHE_OVERLAP_INVERSE") != nullptr;
-    const bool overlap = pm != kArithB32 && passes == 2 && (!inverse || overlap_inverse) && bytes >= kOverlapMinBytes && npolys >= (u64)kOverlapTiles * L &&
-                         std::getenv("PFHE_DISABLE_OVERLAP") == nullptr && !stream_is_capturing(s) &&
-                         hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
-    int tiles = kOverlapTiles;
-    if (const char *e = std::getenv("PFHE_OVERLAP_TILES")) {  // tuning switch
-        const int v = std::atoi(e);
-        if (v >= 2 && v <= kOverlapTiles) tiles = v;
-    }
-    OverlapCtx *c = overlap ? acquire_overlap_ctx(dev) : nullptr;
+    // 5.85 ms; PFHE_OVERLAP_INVERSE=1 at table creation tiles it anyway)
+    int tiles = tune.overlap_tiles ? tune.overlap_tiles : kOverlapTiles;
+    if ((u64)tiles * L > npolys) tiles = (int)(npolys / L);
+    const bool overlap = pm != kArithB32 && passes == 2 && (!inverse || tune.overlap_inverse) && bytes >= kOverlapMinBytes &&
+                         tiles >= 2 && tune.overlap && !stream_is_capturing(s) && hipGetDevice(&dev) == hipSuccess &&
+                         dev >= 0 && dev < 64;
+    OverlapCtx *c = overlap ? acquire_overlap_ctx(dev, tiles) : nullptr;
     if (!c) {
         for (int i = 0; i < passes; ++i)
             PFHE_TRY(ntt_pass_dev(primes, L, log_n, pm, data, npolys, inverse, i, lazy, s, i == 0 ? mul : nullptr,
-                                  mul_polys));
+                                  mul_polys, tune));
         return PFHE_OK;
     }
     // tiles are whole multiples of L polynomials so that the limb of a polynomial (index % L) is
@@ -524,38 +577,42 @@ static int transform(const NttPrime *primes, u32 L, u32 log_n, int pm, u64 *data
         // a per-element multiplicand is tiled like the data; a shared one (one unit of L) is not
         const u64 *mptr = mul == nullptr ? nullptr : (mul_polys == npolys ? mul + ((u0 * L) << log_n) : mul);
         rc = ntt_pass_dev(primes, L, log_n, pm, ptr, np, inverse, 0, lazy, c->a, mptr,
-                          mul_polys == npolys ? np : mul_polys);
+                          mul_polys == npolys ? np : mul_polys, tune);
         if (rc != PFHE_OK) break;
         e = hipEventRecord(c->tile[k], c->a);
         if (e == hipSuccess) e = hipStreamWaitEvent(c->b, c->tile[k], 0);
         if (e != hipSuccess) break;
-        rc = ntt_pass_dev(primes, L, log_n, pm, ptr, np, inverse, 1, lazy, c->b);
+        rc = ntt_pass_dev(primes, L, log_n, pm, ptr, np, inverse, 1, lazy, c->b, nullptr, 0, tune);
     }
     // join: everything later on the caller's stream waits for both internal streams
     if (e == hipSuccess) e = hipEventRecord(c->join_a, c->a);
     if (e == hipSuccess) e = hipEventRecord(c->join_b, c->b);
     if (e == hipSuccess) e = hipStreamWaitEvent(s, c->join_a, 0);
     if (e == hipSuccess) e = hipStreamWaitEvent(s, c->join_b, 0);
+    if (e == hipSuccess) {
+        e = hipEventRecord(c->done, s);
+        c->done_recorded = e == hipSuccess;
+    }
     release_overlap_ctx(dev, c);
     if (e != hipSuccess) return hip_fail(e, "two-stream transform", __FILE__, __LINE__);
     return rc;
 }
 
 int ntt_forward_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, bool lazy,
-                    hipStream_t s) {
-    return transform(primes, L, log_n, arith, data, npolys, false, lazy, s);
+                    hipStream_t s, const NttTuning &tune) {
+    return transform(primes, L, log_n, arith, data, npolys, false, lazy, s, tune);
 }
 
 int ntt_inverse_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, bool lazy,
-                    hipStream_t s) {
-    return transform(primes, L, log_n, arith, data, npolys, true, lazy, s);
+                    hipStream_t s, const NttTuning &tune) {
+    return transform(primes, L, log_n, arith, data, npolys, true, lazy, s, tune);
 }
 
 int ntt_inverse_mul_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, const u64 *mul,
-                        u64 mul_polys, hipStream_t s) {
+                        u64 mul_polys, hipStream_t s, const NttTuning &tune) {
     if (mul == nullptr || mul_polys == 0 || mul_polys % L != 0 || (mul_polys != npolys && mul_polys != L))
         return PFHE_ERR_BAD_ARGUMENT;
-    return transform(primes, L, log_n, arith, data, npolys, true, false, s, mul, mul_polys);
+    return transform(primes, L, log_n, arith, data, npolys, true, false, s, tune, mul, mul_polys);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -612,7 +669,7 @@ __global__ void ntt32_tiny_kernel(u32 *__restrict__ data, const NttPrime *__rest
 }
 
 int ntt32_transform_dev(const NttPrime *primes, u32 L, u32 log_n, u32 *data, u64 npolys, bool inverse, bool lazy,
-                        hipStream_t s) {
+                        hipStream_t s, const NttTuning &tune) {
     if (log_n == 0 || npolys == 0) return PFHE_OK;  // N = 1: the reference's loops do not execute
     if (log_n <= 4) {
         const dim3 g((u32)((npolys + 255) / 256)), t(256);
@@ -621,7 +678,7 @@ int ntt32_transform_dev(const NttPrime *primes, u32 L, u32 log_n, u32 *data, u64
         PFHE_HIP(hipGetLastError());
         return PFHE_OK;
     }
-    return transform(primes, L, log_n - 1, kArithB32, reinterpret_cast<u64 *>(data), npolys, inverse, lazy, s);
+    return transform(primes, L, log_n - 1, kArithB32, reinterpret_cast<u64 *>(data), npolys, inverse, lazy, s, tune);
 }
 
 }  // namespace pfhe

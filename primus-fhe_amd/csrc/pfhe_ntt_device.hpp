@@ -18,7 +18,20 @@ struct NttPlan {
     int strided[4] = {0, 0, 0, 0};  // stages per strided pass, in forward order
     int block_log = 0;
 };
-NttPlan make_ntt_plan(u32 log_n, int arith = 0);  // arith: see kArith* below (plans differ for the u32 tables)
+
+// Tuning switches of the transforms.  The PFHE_* environment variables are read ONCE, when a table handle is
+// created (NttTuning::from_env), and travel inside the handle: nothing on the launch path calls getenv, and two
+// tables created under different settings keep their own.
+struct NttTuning {
+    bool overlap = true;           // PFHE_DISABLE_OVERLAP clears it: two-pass transforms of big batches run tiled on two streams
+    bool overlap_inverse = false;  // PFHE_OVERLAP_INVERSE: tile the inverse direction too
+    int overlap_tiles = 0;         // PFHE_OVERLAP_TILES (0: built-in default)
+    bool strided_vec1 = false;     // PFHE_STRIDED_VEC1: one column per thread in the 4-stage strided pass
+    int max_single_pass_log = 0;   // PFHE_MAX_SINGLE_PASS_LOG (0: built-in default)
+    int block_log = 0;             // PFHE_BLOCK_LOG: block size under strided passes (0: built-in default)
+    static NttTuning from_env();
+};
+NttPlan make_ntt_plan(u32 log_n, int arith = 0, const NttTuning &tune = NttTuning());  // arith: see kArith* below
 
 // `arith` selects the arithmetic policy: kArithShoup (any q < 2^62), kArithPm (every prime of the
 // table has the pseudo-Mersenne shape, NttPrime::pm_k) or kArithB32 (32-bit tables: `data` holds
@@ -26,24 +39,32 @@ NttPlan make_ntt_plan(u32 log_n, int arith = 0);  // arith: see kArith* below (p
 // the first two.
 enum : int { kArithShoup = 0, kArithPm = 1, kArithB32 = 2 };
 int ntt_forward_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, bool lazy,
-                    hipStream_t s);
+                    hipStream_t s, const NttTuning &tune = NttTuning());
 int ntt_inverse_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, bool lazy,
-                    hipStream_t s);
+                    hipStream_t s, const NttTuning &tune = NttTuning());
 // inverse transform of data (*) mul, the pointwise product fused into the loads of the first
 // (block) pass; `mul` holds mul_polys limb-polynomials (npolys, or one unit of L shared by the batch).
 // 64-bit policies only.
 int ntt_inverse_mul_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, const u64 *mul,
-                        u64 mul_polys, hipStream_t s);
+                        u64 mul_polys, hipStream_t s, const NttTuning &tune = NttTuning());
 // U32NttTable / U32DcrtTable transforms (log_n = log2 of the polynomial length in coefficients)
 int ntt32_transform_dev(const NttPrime *primes, u32 L, u32 log_n, u32 *data, u64 npolys, bool inverse, bool lazy,
-                        hipStream_t s);
+                        hipStream_t s, const NttTuning &tune = NttTuning());
 
-int ntt_num_passes(u32 log_n, int arith = 0);
-void ntt_pass_name(u32 log_n, bool inverse, int index, char *buf, size_t cap, int arith = 0);
+int ntt_num_passes(u32 log_n, int arith = 0, const NttTuning &tune = NttTuning());
+void ntt_pass_name(u32 log_n, bool inverse, int index, char *buf, size_t cap, int arith = 0,
+                   const NttTuning &tune = NttTuning());
 int ntt_pass_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, bool inverse,
-                 int index, bool lazy, hipStream_t s, const u64 *mul = nullptr, u64 mul_polys = 0);
+                 int index, bool lazy, hipStream_t s, const u64 *mul = nullptr, u64 mul_polys = 0,
+                 const NttTuning &tune = NttTuning());
 
 #if defined(__HIPCC__)
+
+// Wave-local LDS exchanges without a workgroup barrier, readfirstlane'd twiddle indices and the 64-bit carry masks
+// of the inline asm all assume 64-lane wavefronts.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(__AMDGCN_WAVEFRONT_SIZE) && __AMDGCN_WAVEFRONT_SIZE != 64
+#error "libpfhe_hip is written for wave64 targets (gfx950)"
+#endif
 
 // Tables are reached through pointers stored in NttPrime, which the compiler would treat as
 // generic (flat) pointers: flat loads tick both vmcnt and lgkmcnt and serialise against LDS

@@ -206,8 +206,7 @@ __global__ __launch_bounds__(kPwThreads) void fill_uniform_kernel(u64 *__restric
 // NTT of coeff * X^degree: out[i] = coeff * psi^((2*brv(i)+1)*degree mod 2N)  (table.rs:565-609)
 __global__ __launch_bounds__(kPwThreads) void monomial_kernel(u64 *__restrict__ out,
                                                               const NttPrime *__restrict__ primes, u32 L,
-                                                              u32 log_n, u64 degree, const u64 *__restrict__ coeff,
-                                                              const u64 *__restrict__ coeff_p) {
+                                                              u32 log_n, u64 degree, MonomialScalars sc) {
     const u64 n = 1ull << log_n;
     const u64 total = n * L;
     for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (u64)gridDim.x * blockDim.x) {
@@ -220,7 +219,7 @@ __global__ __launch_bounds__(kPwThreads) void monomial_kernel(u64 *__restrict__ 
         const u32 kb = log_n == 0 ? 0u : (__brev(k) >> (32 - log_n));
         u64 w = P->fwd[kb].x;         // psi^k
         if (idx >= n) w = P->q - w;   // psi^(k+N) = -psi^k
-        out[t] = mul_shoup(w, coeff[limb], coeff_p[limb], P->q);
+        out[t] = mul_shoup(w, sc.value[limb], sc.quotient[limb], P->q);
     }
 }
 
@@ -291,11 +290,11 @@ int fill_uniform_dev(u64 *dst, u64 len, const u64 *moduli_dev, u64 count, u64 po
     return PFHE_OK;
 }
 
-int monomial_dev(u64 *out, const NttPrime *primes, u32 L, u32 log_n, u64 degree, const u64 *coeff_dev,
-                 const u64 *coeff_p_dev, hipStream_t s) {
+int monomial_dev(u64 *out, const NttPrime *primes, u32 L, u32 log_n, u64 degree, const MonomialScalars &sc,
+                 hipStream_t s) {
     const u64 total = ((u64)L) << log_n;
     hipLaunchKernelGGL(monomial_kernel, dim3(grid_for(total)), dim3(kPwThreads), 0, s, out, primes, L, log_n,
-                       degree, coeff_dev, coeff_p_dev);
+                       degree, sc);
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
 }

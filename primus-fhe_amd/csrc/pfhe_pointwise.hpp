@@ -14,6 +14,13 @@ int butterfly_dev(bool factor, u64 *a, const u64 *s, const u64 *w, u64 *b, const
                   u64 len, u64 len_w, hipStream_t st, bool pm = false);
 int fill_uniform_dev(u64 *dst, u64 len, const u64 *moduli_dev, u64 count, u64 poly_len, u64 seed,
                      hipStream_t s);
-int monomial_dev(u64 *out, const NttPrime *primes, u32 L, u32 log_n, u64 degree, const u64 *coeff_dev,
-                 const u64 *coeff_p_dev, hipStream_t s);
+// Per-limb monomial coefficient and its Shoup quotient, passed to the kernel BY VALUE: the device entry points
+// then need no allocation, copy or synchronisation and can be captured into a HIP graph.
+constexpr u32 kMaxMonomialLimbs = 16;
+struct MonomialScalars {
+    u64 value[kMaxMonomialLimbs];
+    u64 quotient[kMaxMonomialLimbs];
+};
+int monomial_dev(u64 *out, const NttPrime *primes, u32 L, u32 log_n, u64 degree, const MonomialScalars &sc,
+                 hipStream_t s);
 }  // namespace pfhe

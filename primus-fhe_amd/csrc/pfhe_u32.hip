@@ -17,6 +17,7 @@
 #include "pfhe_handles.hpp"
 #include "pfhe_modmath.hpp"
 #include "pfhe_ntt_device.hpp"
+#include "pfhe_pointwise.hpp"
 
 namespace pfhe {
 
@@ -82,7 +83,7 @@ __global__ void pointwise32_small_kernel(u32 *acc, const u32 *a, const u32 *__re
 // psi^k for k < N is the low half of the packed forward table at brv(k), psi^(k+N) = -psi^k.
 __global__ __launch_bounds__(kThreads) void monomial32_kernel(u32 *__restrict__ out,
                                                               const NttPrime *__restrict__ primes, u32 L, u32 log_n,
-                                                              u64 degree, const u32 *__restrict__ coeff) {
+                                                              u64 degree, MonomialScalars sc) {
     const u64 n = 1ull << log_n;
     const u64 total = n * L;
     for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (u64)gridDim.x * blockDim.x) {
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(kThreads) void monomial32_kernel(u32 *__restrict__ 
         const u32 kb = log_n == 0 ? 0u : (__brev(k) >> (32 - log_n));
         u32 w = (u32)P->fwd_w[kb];
         if (idx >= n) w = q - w;
-        out[t] = red64((u64)w * coeff[limb], q, P->bar_lo);
+        out[t] = red64((u64)w * (u32)sc.value[limb], q, P->bar_lo);
     }
 }
 
@@ -199,7 +200,7 @@ int transform32_dev(const TableSet &t, u32 *data, size_t len, bool inverse, bool
     PFHE_TRY(check_len32(t, len, units));
     DeviceGuard g(t.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    return ntt32_transform_dev(t.primes_dev, t.L, t.log_n, data, units * t.L, inverse, lazy, s);
+    return ntt32_transform_dev(t.primes_dev, t.L, t.log_n, data, units * t.L, inverse, lazy, s, t.tune);
 }
 
 template <class F>
@@ -265,32 +266,33 @@ int monomial32(const TableSet &t, u32 coeff, size_t degree, u32 *values, size_t 
         set_last_error("monomial output must be exactly one polynomial");
         return PFHE_ERR_BAD_LENGTH;
     }
-    std::vector<u32> c(t.L);
+    if (t.L > kMaxMonomialLimbs) {
+        set_last_error("monomial transforms support at most 16 moduli");
+        return PFHE_ERR_UNSUPPORTED;
+    }
+    MonomialScalars sc{};
     for (u32 i = 0; i < t.L; ++i) {
         const u32 q = (u32)t.primes[i].q;
-        c[i] = minus_one ? q - 1 : coeff;
-        if (c[i] >= q) {
+        const u32 ci = minus_one ? q - 1 : coeff;
+        if (ci >= q) {
             set_last_error("monomial coefficient must be reduced modulo every modulus");
             return PFHE_ERR_BAD_ARGUMENT;
         }
+        sc.value[i] = ci;
     }
     DeviceGuard g(t.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    void *cd = nullptr;
-    PFHE_HIP(hipMalloc(&cd, c.size() * sizeof(u32)));
-    hipError_t e = hipMemcpyAsync(cd, c.data(), c.size() * sizeof(u32), hipMemcpyHostToDevice, s);
+    const u64 deg = (u64)degree & (2 * (u64)t.n - 1);
     void *out_dev = values;
-    if (e == hipSuccess && host) e = hipMalloc(&out_dev, len * sizeof(u32));
-    if (e == hipSuccess) {
-        const u64 deg = (u64)degree & (2 * (u64)t.n - 1);
-        hipLaunchKernelGGL(monomial32_kernel, dim3(grid_for(len)), dim3(kThreads), 0, s, static_cast<u32 *>(out_dev),
-                           t.primes_dev, t.L, t.log_n, deg, static_cast<const u32 *>(cd));
-        e = hipGetLastError();
-        if (e == hipSuccess && host) e = hipMemcpy(values, out_dev, len * sizeof(u32), hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);  // c and cd must outlive the kernel
+    if (host) PFHE_HIP(hipMalloc(&out_dev, len * sizeof(u32)));
+    hipLaunchKernelGGL(monomial32_kernel, dim3(grid_for(len)), dim3(kThreads), 0, s, static_cast<u32 *>(out_dev),
+                       t.primes_dev, t.L, t.log_n, deg, sc);
+    hipError_t e = hipGetLastError();
+    if (host) {  // the device form is this one launch (capturable); only the host form copies back and waits
+        if (e == hipSuccess) e = hipMemcpyAsync(values, out_dev, len * sizeof(u32), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        (void)hipFree(out_dev);
     }
-    if (host && out_dev != values) (void)hipFree(out_dev);
-    (void)hipFree(cd);
     if (e != hipSuccess) return hip_fail(e, "monomial transform", __FILE__, __LINE__);
     return PFHE_OK;
 }
@@ -485,7 +487,7 @@ int pfhe_dcrt32_fill_uniform_dev(const pfhe_dcrt32 *table, uint32_t *dst_dev, si
 /* profiling hooks: the passes of one transform, as for the 64-bit tables */
 int pfhe_dcrt32_transform_num_passes(const pfhe_dcrt32 *table) {
     if (!table) return 0;
-    return table->t->log_n <= 4 ? 1 : ntt_num_passes(table->t->log_n - 1, kArithB32);
+    return table->t->log_n <= 4 ? 1 : ntt_num_passes(table->t->log_n - 1, kArithB32, table->t->tune);
 }
 const char *pfhe_dcrt32_transform_pass_name(const pfhe_dcrt32 *table, int inverse, int index) {
     static thread_local char buf[112];
@@ -496,7 +498,7 @@ const char *pfhe_dcrt32_transform_pass_name(const pfhe_dcrt32 *table, int invers
         return buf;
     }
     char inner[96];
-    ntt_pass_name(table->t->log_n - 1, inverse != 0, index, inner, sizeof inner, kArithB32);
+    ntt_pass_name(table->t->log_n - 1, inverse != 0, index, inner, sizeof inner, kArithB32, table->t->tune);
     std::snprintf(buf, sizeof buf, "u32:%s", inner);
     return buf;
 }

@@ -263,15 +263,16 @@ def test_gpu_monomial_in_place_forms_agree(pf, log_n):
     a = torch.empty(polys * 3 * n, dtype=torch.int64, device="cuda")
     t.fill_uniform_dev(a, log_n)
     exp = torch.empty_like(a)
+    os.environ["PFHE_DISABLE_MONOMIAL_INPLACE"] = "1"  # switches are read when a table is created
+    try:
+        t_scratch = pf.U64DcrtTable(log_n, Q61)
+    finally:
+        del os.environ["PFHE_DISABLE_MONOMIAL_INPLACE"]
     for r in (0, 1, 3, n // 2 + 1, n - 1, n, n + 2, 2 * n - 1):
         t.mul_monomial_to_dev(a, r, exp)
         x = a.clone()
         t.mul_monomial_assign_dev(x, r)
         assert torch.equal(x, exp), r
-        os.environ["PFHE_DISABLE_MONOMIAL_INPLACE"] = "1"
-        try:
-            y = a.clone()
-            t.mul_monomial_assign_dev(y, r)
-        finally:
-            del os.environ["PFHE_DISABLE_MONOMIAL_INPLACE"]
+        y = a.clone()
+        t_scratch.mul_monomial_assign_dev(y, r)
         assert torch.equal(y, exp), r

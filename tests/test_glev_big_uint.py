@@ -55,11 +55,11 @@ def test_gpu_matches_oracle(pf, orc, switch, log_n, k, moduli, log_basis, batch)
     n, L = 1 << log_n, len(moduli)
     ot, ob, obasis, poly, big, glev, acc = make(orc, rng, log_n, k, moduli, log_basis, batch)
     W, vl = L * n, ob.value_len
-    t, base = pf.U64DcrtTable(log_n, moduli), pf.RNSBase(moduli)
-    ctx = pf.DcrtGlevContext(t, base, pf.BigUintApproxSignedBasis(base, log_basis), k)
     if switch:
-        os.environ[switch] = "1"
+        os.environ[switch] = "1"  # switches are read when the table / the plan is created
     try:
+        t, base = pf.U64DcrtTable(log_n, moduli), pf.RNSBase(moduli)
+        ctx = pf.DcrtGlevContext(t, base, pf.BigUintApproxSignedBasis(base, log_basis), k)
         dacc = to_dev(acc)
         pf.add_dcrt_glev_mul_big_uint_poly_assign_dev(dacc, to_dev(glev), to_dev(big), ctx)
         dres = to_dev(acc)  # stale contents must be overwritten

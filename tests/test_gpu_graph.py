@@ -129,3 +129,30 @@ def test_cmux_style_step_in_a_graph(pf):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(acc, ref)
+
+
+def test_monomial_transforms_in_a_graph(pf):
+    """transform_monomial_dev & co. are ONE launch on the caller's stream (the per-limb coefficient and its Shoup
+    quotient travel as kernel arguments): no allocation, copy or synchronisation, hence capturable — a CMUX loop
+    builds X^d in NTT form every step."""
+    import torch
+    log_n = 11
+    n = 1 << log_n
+    t, t32 = pf.U64NttTable(log_n, Q61[0]), pf.U32NttTable(log_n, 132120577)
+    out = torch.zeros(n, dtype=torch.int64, device="cuda")
+    out32 = torch.zeros(n, dtype=torch.int32, device="cuda")
+    exp = np.zeros(n, np.uint64)
+    t.transform_monomial(7, 321, exp)  # host form of the same transform
+    exp32 = np.zeros(n, np.uint32)
+    t32.transform_monomial(7, 321, exp32)
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        t.transform_monomial_dev(7, 321, out, stream=s)
+        t32.transform_monomial_dev(7, 321, out32, stream=s)
+    out.zero_()
+    out32.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), exp)
+    assert np.array_equal(out32.cpu().numpy().view(np.uint32), exp32)

@@ -3,6 +3,8 @@
 Mirrors primus_ntt/src/ntt/prime64/tests.rs and primus_ntt/tests/ntt.rs, with the oracle
 (oracle/pfhe_oracle.c) standing where the reference's UintNttTable stands.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -268,11 +270,12 @@ def test_two_stream_overlap_path_matches_oracle(pf, orc, monkeypatch):
     d.transform_dev(x)
     y = x.clone()  # ordered after the join on the same (current) stream
     got = to_host(y)
-    monkeypatch.setenv("PFHE_DISABLE_OVERLAP", "1")
-    x1 = to_dev(a)
-    d.transform_dev(x1)
-    assert np.array_equal(got, to_host(x1))
+    monkeypatch.setenv("PFHE_DISABLE_OVERLAP", "1")  # switches are read when a table is created
+    d1 = pf.U64DcrtTable(log_n, Q61)
     monkeypatch.delenv("PFHE_DISABLE_OVERLAP")
+    x1 = to_dev(a)
+    d1.transform_dev(x1)
+    assert np.array_equal(got, to_host(x1))
     for e in (0, 123, batch - 1):
         ref = a[e * L * n:(e + 1) * L * n].copy()
         o.transform_slice(ref)
@@ -435,24 +438,27 @@ def test_fused_polymul_large_batch_tiled_path(pf, orc, shared):
     a, bh = fill(batch * W, 11), fill(W if shared else batch * W, 12)
     fused = a.clone()
     d.mul_dcrt_polynomial_dev(fused, bh)
-    os.environ["PFHE_OVERLAP_INVERSE"] = "1"  # the inverse direction is not tiled by default: exercise its tiling too
+    # the inverse direction is not tiled by default: exercise its tiling too (switches are read at table creation)
+    os.environ["PFHE_OVERLAP_INVERSE"] = "1"
     try:
-        tiled = a.clone()
-        d.mul_dcrt_polynomial_dev(tiled, bh)
-        inv_tiled = a.clone()
-        d.inverse_transform_dev(inv_tiled)
+        d_tiled = pf.U64DcrtTable(log_n, Q61)
     finally:
         del os.environ["PFHE_OVERLAP_INVERSE"]
+    tiled = a.clone()
+    d_tiled.mul_dcrt_polynomial_dev(tiled, bh)
+    inv_tiled = a.clone()
+    d_tiled.inverse_transform_dev(inv_tiled)
     assert torch.equal(fused, tiled)
     inv_plain = a.clone()
     d.inverse_transform_dev(inv_plain)
     assert torch.equal(inv_plain, inv_tiled)
     os.environ["PFHE_DISABLE_FUSED_POLYMUL"] = "1"
     try:
-        plain = a.clone()
-        d.mul_dcrt_polynomial_dev(plain, bh)
+        d_plain = pf.U64DcrtTable(log_n, Q61)
     finally:
         del os.environ["PFHE_DISABLE_FUSED_POLYMUL"]
+    plain = a.clone()
+    d_plain.mul_dcrt_polynomial_dev(plain, bh)
     assert torch.equal(fused, plain)
     for e in (0, 179, 359):
         x = to_host(a[e * W:(e + 1) * W]).copy()
@@ -546,3 +552,107 @@ def test_handles_release_their_device_memory(pf):
     torch.cuda.empty_cache()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 50 create/destroy cycles"
+
+
+@pytest.mark.gpu
+def test_overlap_context_creation_failure_is_clean():
+    """The two-stream transform falls back to one stream when its streams / events cannot be created, and the
+    partially built context is destroyed (PFHE_TEST_FAIL_OVERLAP_CTX=N fails the N+1-th HIP object; the switch is
+    read once per process, hence the subprocess).  Results must equal the single-stream path's."""
+    import subprocess
+    import sys
+    script = r"""
+import os, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+import primus_fhe_amd as pf
+Q61 = [2305843009211596801, 2305843009210023937, 2305843009208713217]
+log_n, batch = 16, 352
+t = pf.U64DcrtTable(log_n, Q61)
+x = torch.empty(batch * 3 << log_n, dtype=torch.int64, device="cuda")
+t.fill_uniform_dev(x, 5)
+ref = x.clone()
+os.environ["PFHE_DISABLE_OVERLAP"] = "1"
+t1 = pf.U64DcrtTable(log_n, Q61)
+t1.transform_dev(ref)
+def rounds(k):
+    for _ in range(k):
+        y = x.clone()
+        t.transform_dev(y)      # context creation fails every time: single-stream fallback
+        assert torch.equal(y, ref)
+        del y
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info()[0]
+rounds(5)                       # torch's caching allocator settles (clone, comparison workspaces)
+free0 = rounds(5)
+free1 = rounds(40)
+assert free0 - free1 < (16 << 20), (free0, free1)
+print("ok")
+"""
+    for fail_after in (0, 3, 7):
+        env = dict(os.environ, PFHE_TEST_FAIL_OVERLAP_CTX=str(fail_after))
+        env.pop("PFHE_DISABLE_OVERLAP", None)
+        r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0 and "ok" in r.stdout, (fail_after, r.stdout[-500:], r.stderr[-2000:])
+
+
+def _fill(pf, words, moduli, n, seed):
+    import ctypes as C
+    import torch
+    from primus_fhe_amd._lib import check, u64p
+    x = torch.empty(words, dtype=torch.int64, device="cuda")
+    mods = np.array(moduli, np.uint64)
+    check(pf.lib().pfhe_fill_uniform_dev(0, C.c_void_p(x.data_ptr()), words, mods.ctypes.data_as(u64p), len(moduli), n,
+                                         seed, None))
+    return x
+
+
+def test_config3_full_batch_every_element(pf, orc):
+    """BASELINE config 3' at its full batch: EVERY one of the 12 288 limb transforms is compared with the oracle's
+    scalar restatement (all host cores, slab by slab), forward and inverse — a tiling or tile-boundary bug that
+    cancels in a round trip cannot hide."""
+    import torch
+    from gpu_util import oracle_map
+    log_n, batch = 16, 4096
+    n, L = 1 << log_n, 3
+    W = L * n
+    d, o = pf.U64DcrtTable(log_n, Q61), orc.U64DcrtTable(log_n, Q61)
+    x = _fill(pf, batch * W, Q61, n, 0x5EED000000000003)
+    orig = x.clone()
+    d.transform_dev(x)
+    torch.cuda.synchronize()
+    slab = 256  # RNS polynomials per host slab (384 MiB)
+    for s0 in range(0, batch, slab):
+        ref = to_host(orig[s0 * W:(s0 + slab) * W]).copy()
+        oracle_map(o.transform_slice, ref, W)
+        assert np.array_equal(to_host(x[s0 * W:(s0 + slab) * W]), ref), s0
+    # inverse direction on the transformed batch, every element again (the oracle inverts its own forward output)
+    y = x.clone()
+    d.inverse_transform_dev(y)
+    assert torch.equal(y, orig)
+    for s0 in (0, batch // 2, batch - slab):  # and the oracle's inverse of the GPU's forward output
+        ref = to_host(x[s0 * W:(s0 + slab) * W]).copy()
+        oracle_map(o.inverse_transform_slice, ref, W)
+        assert np.array_equal(to_host(orig[s0 * W:(s0 + slab) * W]), ref), s0
+
+
+def test_config2_full_batch(pf, orc):
+    """BASELINE config 2: N = 2^14, one 61-bit prime, 4096 polynomials — forward and inverse, every polynomial
+    against the oracle."""
+    import torch
+    from gpu_util import oracle_map
+    log_n, batch, q = 14, 4096, Q61[0]
+    n = 1 << log_n
+    d, o = pf.U64NttTable(log_n, q), orc.U64NttTable(log_n, q)
+    x = _fill(pf, batch * n, [q], n, 0x5EED000000000002)
+    orig = x.clone()
+    d.transform_dev(x)
+    ref = to_host(orig).copy()
+    oracle_map(o.transform_slice, ref, n)
+    assert np.array_equal(to_host(x), ref)
+    inv = to_host(x).copy()
+    d.inverse_transform_dev(x)
+    assert torch.equal(x, orig)
+    oracle_map(o.inverse_transform_slice, inv, n)
+    assert np.array_equal(inv, to_host(orig))

@@ -295,6 +295,11 @@ def test_small_ring_fused_path(pf, orc, log_n, moduli, log_basis):
     ell = obasis.decompose_length
     t, base = pf.U64DcrtTable(log_n, moduli), pf.RNSBase(moduli)
     ctx = pf.DcrtGlevContext(t, base, pf.BigUintApproxSignedBasis(base, log_basis), k)
+    os.environ["PFHE_DISABLE_SMALL_EXTPROD"] = "1"  # switches are read when a plan is created
+    try:
+        ctx_plain = pf.DcrtGlevContext(t, base, pf.BigUintApproxSignedBasis(base, log_basis), k)
+    finally:
+        del os.environ["PFHE_DISABLE_SMALL_EXTPROD"]
     glwe = rand_rns(rng, moduli, n, batch * (k + 1))
     ggsw = rand_rns(rng, moduli, n, (k + 1) * ell * (k + 1))
     dg, dk = to_dev(glwe), to_dev(ggsw)
@@ -302,12 +307,8 @@ def test_small_ring_fused_path(pf, orc, log_n, moduli, log_basis):
     for coeff in (False, True):
         fused = torch.zeros_like(dg)
         pf.mul_dcrt_ggsw_to_dev(dg, dk, fused, ctx, into_coeff_form=coeff)
-        os.environ["PFHE_DISABLE_SMALL_EXTPROD"] = "1"
-        try:
-            plain = torch.zeros_like(dg)
-            pf.mul_dcrt_ggsw_to_dev(dg, dk, plain, ctx, into_coeff_form=coeff)
-        finally:
-            del os.environ["PFHE_DISABLE_SMALL_EXTPROD"]
+        plain = torch.zeros_like(dg)
+        pf.mul_dcrt_ggsw_to_dev(dg, dk, plain, ctx_plain, into_coeff_form=coeff)
         assert torch.equal(fused, plain)
         outs[coeff] = to_host(fused)
     for e in (0, 517, batch - 1):
@@ -354,3 +355,42 @@ def test_pipelined_chunks_equal_serial_chunks(pf):
             pf.mul_dcrt_ggsw_to_dev(dg, dk, out, ctx, into_coeff_form=True)
             outs.append(out)
         assert torch.equal(outs[0], outs[1])
+
+
+def test_config4_full_batch_every_ciphertext(pf, orc):
+    """BASELINE config 4 at its full batch: every one of the 1024 external products compared with the oracle
+    (scalar restatement of CrtGlwe::mul_dcrt_ggsw_to, one ciphertext per task on all host cores)."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+
+    import torch
+    from gpu_util import usable_cores
+    from primus_fhe_amd._lib import check, u64p
+    log_n, k, batch = 16, 1, 1024
+    n, L = 1 << log_n, 3
+    table, base = pf.U64DcrtTable(log_n, Q61), pf.RNSBase(Q61)
+    basis = pf.BigUintApproxSignedBasis(base, 30)
+    ctx = pf.DcrtGlevContext(table, base, basis, k)
+    G = ctx.glwe_len()
+    mods = np.array(Q61, np.uint64)
+
+    def fill(words, seed):
+        x = torch.empty(words, dtype=torch.int64, device="cuda")
+        check(pf.lib().pfhe_fill_uniform_dev(0, C.c_void_p(x.data_ptr()), words, mods.ctypes.data_as(u64p), L, n, seed, None))
+        return x
+
+    glwe, ggsw = fill(batch * G, 0x5EED000000000004), fill(ctx.ggsw_len(), 99)
+    out = torch.empty_like(glwe)
+    pf.mul_dcrt_ggsw_to_dev(glwe, ggsw, out, ctx)
+    torch.cuda.synchronize()
+    otable, obase = orc.U64DcrtTable(log_n, Q61), orc.RNSBase(Q61)
+    obasis = orc.BigUintApproxSignedBasis(obase, 30)
+    hk, hg, ho = to_host(ggsw), to_host(glwe), to_host(out)
+
+    def one(e):
+        exp = orc.mul_dcrt_ggsw_to(otable, obase, obasis, k, hg[e * G:(e + 1) * G], hk)
+        return bool(np.array_equal(ho[e * G:(e + 1) * G], exp))
+
+    with ThreadPoolExecutor(usable_cores()) as ex:
+        ok = list(ex.map(one, range(batch)))
+    assert all(ok), [e for e, v in enumerate(ok) if not v][:10]

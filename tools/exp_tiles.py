@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Forward RNS NTT at the bench shape for several tile counts of the two-stream transform (PFHE_OVERLAP_TILES is read
-per call).  Question: with tiles small enough to stay in the 256 MiB Infinity Cache, does the block pass read its
+"""Forward RNS NTT at the bench shape for several tile counts of the two-stream transform (switches are read when
+a table is created, so every setting gets a table of its own).  Question: with tiles small enough to stay in the 256 MiB Infinity Cache, does the block pass read its
 input on-die (one HBM read + one HBM write per transform instead of two of each)?"""
 import ctypes as C
 import os
@@ -17,7 +17,6 @@ from primus_fhe_amd._lib import check, u64p  # noqa: E402
 Q61 = [2305843009211596801, 2305843009210023937, 2305843009208713217]
 log_n, batch, reps = 16, int(os.environ.get("BATCH", "4096")), int(os.environ.get("REPS", "10"))
 n, L = 1 << log_n, 3
-t = p.U64DcrtTable(log_n, Q61)
 words = batch * L * n
 x = torch.empty(words, dtype=torch.int64, device="cuda")
 mods = np.array(Q61, np.uint64)
@@ -29,9 +28,9 @@ for tiles in [int(v) for v in os.environ.get("TILES", "1,12,16,24,32,48,64,96,12
     else:
         os.environ.pop("PFHE_DISABLE_OVERLAP", None)
         os.environ["PFHE_OVERLAP_TILES"] = str(tiles)
+    os.environ["PFHE_OVERLAP_INVERSE"] = "1"
+    t = p.U64DcrtTable(log_n, Q61)
     for inverse, fn in ((0, t.transform_dev), (1, t.inverse_transform_dev)):
-        if inverse:
-            os.environ["PFHE_OVERLAP_INVERSE"] = "1"
         fn(x)
         fn(x)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
