@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=4096, help="RNS polynomials per GPU (default: BASELINE config 3')")
     ap.add_argument("--ext-batch", type=int, default=1024, help="ciphertexts in the external-product leg (config 4)")
     ap.add_argument("--ext-chunk", type=int, default=0, help="ciphertexts per internal pass of the external product")
+    ap.add_argument("--ext-total", type=int, default=8192, help="BASELINE config 5: ciphertexts of the FIXED job that is "
+                    "split over the ranks (strong scaling); 0 skips that leg")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for the timing barrier "
                     "(nccl = RCCL; gloo + --one-device lets two ranks share one GPU for a plumbing check)")
     ap.add_argument("--one-device", action="store_true", help="debug: every rank uses cuda:0")
@@ -114,7 +116,7 @@ def cpu_baseline(seconds: float):
     out = {
         "value": done / dt, "unit": "NTT/s", "cores": cores, "kind": "port",
         "single_thread_value": single, "single_thread_scalar_value": single_scalar,
-        "backend": "avx512dq (restatement of prime64/avx512)" if avx512 else "scalar (restatement of prime64/scalar)",
+        "backend": "fwd+inv AVX-512 DQ (restatement of prime64/avx512)" if avx512 else "scalar (restatement of prime64/scalar)",
         "sample": f"{done} forward limb-NTTs of N=2^16 (61-bit primes), oracle "
                   f"{'AVX-512 DQ' if avx512 else 'scalar'} Harvey path, {cores} threads, {dt:.1f} s",
     }
@@ -129,8 +131,9 @@ def cpu_baseline(seconds: float):
         ggsw = np.concatenate([rng.integers(0, q, n, dtype=np.uint64)
                                for _ in range(2 * basis.decompose_length * 2) for q in Q61])
 
-        def ep(i):
-            oracle.mul_dcrt_ggsw_to(dt_tab, base, basis, 1, glwes[i], ggsw)
+        def ep(i):  # CrtGlwe::mul_dcrt_ggsw_to + DcrtGlwe::into_coeff_form, like the GPU leg
+            r = oracle.mul_dcrt_ggsw_to(dt_tab, base, basis, 1, glwes[i], ggsw)
+            dt_tab.inverse_transform_slice(r)
             return 1
 
         ep(0)
@@ -141,8 +144,27 @@ def cpu_baseline(seconds: float):
                 done_ep += sum(ex.map(ep, range(cores)))
         dte = time.perf_counter() - t0
         out["external_product"] = {
-            "value": done_ep / dte, "unit": "RLWE external products/s (NTT-form output)", "cores": cores,
+            "value": done_ep / dte, "unit": "RLWE external products/s (coefficient-form output)", "cores": cores,
             "sample": f"{done_ep} products, N=2^16, 3 primes, k=1, ell=6, {cores} threads, {dte:.1f} s"}
+        # config 3: NTT -> pointwise product with a shared multiplicand -> INTT, one RNS polynomial per task
+        polys = [np.concatenate([rng.integers(0, q, n, dtype=np.uint64) for q in Q61]) for _ in range(cores)]
+        bhat = np.concatenate([rng.integers(0, q, n, dtype=np.uint64) for q in Q61])
+
+        def pm(i):
+            dt_tab.transform_slice(polys[i])
+            dt_tab.mul_assign(polys[i], bhat)
+            dt_tab.inverse_transform_slice(polys[i])
+            return 1
+
+        pm(0)
+        t0 = time.perf_counter()
+        done_pm = 0
+        with ThreadPoolExecutor(cores) as ex:
+            while time.perf_counter() - t0 < max(1.0, seconds * 0.1):
+                done_pm += sum(ex.map(pm, range(cores)))
+        dtp = time.perf_counter() - t0
+        out["polymul"] = {"value": done_pm / dtp, "unit": "RNS polynomial products/s (NTT+mul+INTT)", "cores": cores,
+                          "sample": f"{done_pm} products, N=2^16, 3 primes, {cores} threads, {dtp:.1f} s"}
     except Exception as e:  # the NTT baseline above is the contractual one
         out["external_product"] = {"error": str(e)[:200]}
     finally:
@@ -270,7 +292,52 @@ def main():
         "ggsw": "one shared 36 MiB DcrtGgsw per GPU", "chunk": args.ext_chunk or "default (64 at this shape)",
         "hbm_roofline_frac": ep_batch / dte * 96 * n / (HBM_PEAK_GBS * 1e9),
         "limb_ntts_per_product": 42}
-    del ggsw, out, ctx
+    # kernel groups of the product, HIP events on the launch stream (rank 0): which one dominates, and its share of
+    # the HBM roofline on its algorithmic bytes (digits of (k+1)*ell*L polynomials in, (k+1)*L polynomials out)
+    if rank == 0:
+        try:
+            s_cur = torch.cuda.current_stream()
+            ms_dec, ms_mac, launches = p.profile_mul_dcrt_ggsw_to_dev(glwe, ggsw, out, ctx, stream=s_cur.cuda_stream)
+            dom_ms = max(ms_dec, ms_mac)
+            mac_bytes = ep_batch * (2 * 6 * L + 2 * L) * n * 8  # transformed digits read + result written (key: L2)
+            dec_bytes = ep_batch * (2 * L + 2 * 6 * L) * n * 8  # CRT polynomials read + strided-pass digits written
+            dom_bytes = mac_bytes if ms_mac >= ms_dec else dec_bytes
+            result["external_product"]["roofline"] = {
+                "bound": "hbm", "kernel": "gadget_block_mulacc_kernel (block pass of the digits' transform + multiply-accumulate)"
+                if ms_mac >= ms_dec else "gadget_signed_digits_kernel + digits_strided_kernel",
+                "avg_launch_ms": dom_ms / max(1, launches), "launches_per_batch": launches,
+                "ms_per_batch": {"digits_and_strided_pass": ms_dec, "block_pass_and_multiply_accumulate": ms_mac},
+                "achieved": dom_bytes / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_batch": dom_bytes, "traffic": None,
+                "note": "the kernel runs 12 block transforms per output block: bound by the integer ALU "
+                        "(profiles/r02_extprod_pmc.txt), not by HBM"}
+        except Exception as e:  # measurement aid only
+            result["external_product"]["roofline"] = {"error": str(e)[:200]}
+    del out
+    # ---- config 5 as BASELINE.md defines it: a FIXED job of --ext-total ciphertexts split over the ranks ----
+    if args.ext_total > 0:
+        from primus_fhe_amd.shard import shard_range, strong_scaling_leg
+        b5, e5 = shard_range(args.ext_total, world, rank)
+        mine = e5 - b5
+        g5 = torch.empty(max(1, mine) * 2 * L * n, dtype=torch.int64, device="cuda")
+        check(p.lib().pfhe_fill_uniform_dev(local_rank, C.c_void_p(g5.data_ptr()), g5.numel(), mods.ctypes.data_as(u64p), L,
+                                            n, 0x5EED000000000005 + b5, None))
+        o5 = torch.empty_like(g5)
+
+        def run_shard(begin, end):
+            if end > begin:
+                p.mul_dcrt_ggsw_to_dev(g5[:(end - begin) * 2 * L * n], ggsw, o5[:(end - begin) * 2 * L * n], ctx,
+                                       into_coeff_form=True)
+
+        leg = strong_scaling_leg(args.ext_total, world, rank, run_shard, max(2, args.steps // 5), 1,
+                                 torch.cuda.synchronize, dist, "cuda" if args.dist_backend == "nccl" else "cpu")
+        leg.update({"unit": "RLWE external products/s, whole job (BASELINE config 5: batch split over the GPUs, "
+                            "no collective on the data path)",
+                    "hbm_roofline_frac": leg["value"] / world * 96 * n / (HBM_PEAK_GBS * 1e9)})
+        result["external_product_config5"] = leg
+        del g5, o5
+    del ggsw, ctx
 
     if rank == 0 and world == 1:
         # ---- per-kernel timing (HIP events on the launch stream) for the roofline object ----
@@ -301,10 +368,56 @@ def main():
                               "traffic_unit": "bytes per launch",
                               "traffic_source": (pmc["source"] + ": " + pmc["method"]) if pmc else None,
                               "avg_launch_ms": dom[1], "algorithmic_bytes_per_launch": alg_bytes,
-                              "note": "fraction of the HBM roofline as the metric asks; this kernel is bound by the "
-                                      "integer ALU (VALUBusy 98 %, profiles/r01_f_pmc_utilisation.txt), not by HBM"}
+                              "note": "fraction of the HBM roofline as the metric asks; the kernel's own limit is the "
+                                      "integer ALU and its LDS / twiddle traffic (profiles/r02_*), not HBM"}
         result["kernels_ms"] = {k: v for k, v in per_pass}
         # the single-pass loops above left x in an arbitrary state: restore canonical residues
+        check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(x.data_ptr()), words, mods.ctypes.data_as(u64p), L, n, 5, None))
+        # ---- the inverse transform at the same shape (U64DcrtTable::inverse_transform_slice, prime64/table.rs:560) ----
+        def time_ms(fn, reps):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps * 1e3
+
+        reps = max(3, args.steps)
+        ms_inv = time_ms(lambda: table.inverse_transform_dev(x), reps)
+        result["intt"] = {"value": batch * L / ms_inv * 1e3, "unit": "NTT/s (inverse limb-NTTs, N=2^16, 3 primes)",
+                          "ms_per_batch": ms_inv, "hbm_roofline_frac": batch * L / ms_inv * 1e3 * 16 * n / (HBM_PEAK_GBS * 1e9)}
+        check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(x.data_ptr()), words, mods.ctypes.data_as(u64p), L, n, 6, None))
+        # ---- the generic-prime path (ShoupArith, the reference's own ShoupFactor scheme) on the same data: what
+        #      any q < 2^62 that is not of pseudo-Mersenne shape gets ----
+        os.environ["PFHE_DISABLE_PM"] = "1"  # read once, when the table is created
+        try:
+            table_shoup = p.U64DcrtTable(LOG_N, Q61, device=local_rank)
+        finally:
+            del os.environ["PFHE_DISABLE_PM"]
+        ms_sh = time_ms(lambda: table_shoup.transform_dev(x), reps)
+        ms_shi = time_ms(lambda: table_shoup.inverse_transform_dev(x), reps)
+        result["ntt_generic_prime"] = {
+            "value": batch * L / ms_sh * 1e3, "unit": "NTT/s (forward limb-NTTs, ShoupArith: any q < 2^62)",
+            "ms_per_batch": ms_sh, "inverse_ms_per_batch": ms_shi,
+            "hbm_roofline_frac": batch * L / ms_sh * 1e3 * 16 * n / (HBM_PEAK_GBS * 1e9)}
+        del table_shoup
+        check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(x.data_ptr()), words, mods.ctypes.data_as(u64p), L, n, 5, None))
+        # ---- BASELINE config 2: N = 2^14, one 61-bit prime, batch 4096 (single block pass: one HBM read + write) ----
+        n14, b14 = 1 << 14, 4096
+        t14 = p.U64NttTable(14, Q61[0], device=local_rank)
+        x14 = x[:b14 * n14]
+        m14 = np.array(Q61[:1], np.uint64)
+        check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(x14.data_ptr()), b14 * n14, m14.ctypes.data_as(u64p), 1, n14, 14, None))
+        ms14 = time_ms(lambda: t14.transform_dev(x14), 4 * reps)
+        ms14i = time_ms(lambda: t14.inverse_transform_dev(x14), 4 * reps)
+        result["ntt_2p14"] = {
+            "workload": "BASELINE configs[1]: N=2^14, q=%d, batch=%d, in place" % (Q61[0], b14),
+            "forward": {"value": b14 / ms14 * 1e3, "unit": "NTT/s", "ms_per_batch": ms14,
+                        "hbm_roofline_frac": b14 / ms14 * 1e3 * 16 * n14 / (HBM_PEAK_GBS * 1e9)},
+            "inverse": {"value": b14 / ms14i * 1e3, "unit": "NTT/s", "ms_per_batch": ms14i,
+                        "hbm_roofline_frac": b14 / ms14i * 1e3 * 16 * n14 / (HBM_PEAK_GBS * 1e9)}}
+        del t14
         check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(x.data_ptr()), words, mods.ctypes.data_as(u64p), L, n, 5, None))
         # ---- config 3: fused NTT -> pointwise mul (shared multiplicand) -> INTT ----
         bhat = torch.empty(L * n, dtype=torch.int64, device="cuda")

@@ -81,6 +81,7 @@ def _load(path: str | None = None) -> C.CDLL:
     sig("orc_set_vector_backend", None, ci)
     sig("orc_get_vector_backend", ci)
     sig("orc_u64_ntt_forward_avx512", ci, vp, _u64p, ci)
+    sig("orc_u64_ntt_inverse_avx512", ci, vp, _u64p, ci)
     sig("orc_u64_ntt_transform_monomial", None, vp, u64, sz, _u64p)
     sig("orc_u64_ntt_transform_coeff_one_monomial", None, vp, sz, _u64p)
     sig("orc_u64_ntt_transform_coeff_minus_one_monomial", None, vp, sz, _u64p)
@@ -280,6 +281,16 @@ class U64NttTable:
         base = flat.ctypes.data
         for i in range(flat.size // self.n):
             rc = lib().orc_u64_ntt_forward_avx512(self._h, C.cast(base + 8 * self.n * i, _u64p), int(lazy))
+            if rc:
+                raise OracleError(rc)
+
+    def inverse_transform_slice_avx512(self, a, lazy: bool = False):
+        """Inverse transform through the AVX-512 DQ backend (prime64/avx512/transform.rs:205); raises when unavailable."""
+        assert a.size % self.n == 0
+        flat = a.reshape(-1)
+        base = flat.ctypes.data
+        for i in range(flat.size // self.n):
+            rc = lib().orc_u64_ntt_inverse_avx512(self._h, C.cast(base + 8 * self.n * i, _u64p), int(lazy))
             if rc:
                 raise OracleError(rc)
 

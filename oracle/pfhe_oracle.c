@@ -418,7 +418,10 @@ void orc_u64_ntt_transform_slice(const orc_u64_ntt *t, uint64_t *p) {
     orc_u64_ntt_scalar_forward(t, p, 0, 1);
 }
 void orc_u64_ntt_lazy_inverse_transform_slice(const orc_u64_ntt *t, uint64_t *v) { orc_u64_ntt_scalar_inverse(t, v, 0, 2); }
-void orc_u64_ntt_inverse_transform_slice(const orc_u64_ntt *t, uint64_t *v) { orc_u64_ntt_scalar_inverse(t, v, 0, 1); }
+void orc_u64_ntt_inverse_transform_slice(const orc_u64_ntt *t, uint64_t *v) {
+    if (g_vector_backend && t->n >= 16 && orc_u64_ntt_inverse_avx512(t, v, 0) == ORC_OK) return;
+    orc_u64_ntt_scalar_inverse(t, v, 0, 1);
+}
 
 /* table.rs:565-609 */
 void orc_u64_ntt_transform_monomial(const orc_u64_ntt *t, uint64_t coeff, size_t degree,

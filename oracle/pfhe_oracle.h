@@ -132,6 +132,7 @@ int orc_avx512_available(void);
 void orc_set_vector_backend(int on);
 int orc_get_vector_backend(void);
 int orc_u64_ntt_forward_avx512(const orc_u64_ntt *t, uint64_t *values, int lazy);
+int orc_u64_ntt_inverse_avx512(const orc_u64_ntt *t, uint64_t *values, int lazy);
 
 /* ---------------- U32NttTable (prime32/table.rs, prime32/scalar/) ---------------- */
 typedef struct orc_u32_ntt orc_u32_ntt;

@@ -9,7 +9,7 @@ constructors raise.
 from ._lib import PfheError, build, lib, library_path, status_string  # noqa: F401
 from .lattice import (DcrtGlevContext, add_dcrt_glev_mul_big_uint_poly_assign_dev,  # noqa: F401
                       add_dcrt_glev_mul_crt_poly_assign_dev, glev_mul_big_uint_poly_to_dev, glev_mul_crt_poly_to_dev,
-                      mul_dcrt_ggsw_to, mul_dcrt_ggsw_to_dev)
+                      mul_dcrt_ggsw_to, mul_dcrt_ggsw_to_dev, profile_mul_dcrt_ggsw_to_dev)
 from .ntt import NttError, U32DcrtTable, U32NttTable, U64DcrtTable, U64NttTable  # noqa: F401
 from .rns import BaseConverter, BigUintApproxSignedBasis, RNSBase, RNSError  # noqa: F401
 

@@ -143,6 +143,7 @@ def _declare(lib: C.CDLL) -> None:
     sig("pfhe_extprod_plan_scratch_bytes", sz, vp)
     sig("pfhe_extprod_mul_dcrt_ggsw_to", ci, vp, vp, sz, vp, sz, vp, sz, ci)
     sig("pfhe_extprod_mul_dcrt_ggsw_to_dev", ci, vp, vp, sz, vp, sz, vp, sz, ci, vp)
+    sig("pfhe_extprod_profile_dev", ci, vp, vp, sz, vp, sz, vp, sz, C.POINTER(C.c_double), C.POINTER(sz), vp)
     sig("pfhe_extprod_add_dcrt_glev_mul_crt_poly_assign_dev", ci, vp, vp, sz, vp, sz, vp, sz, vp)
     sig("pfhe_extprod_glev_mul_crt_poly_to_dev", ci, vp, vp, sz, vp, sz, vp, sz, vp)
     sig("pfhe_extprod_add_dcrt_glev_mul_big_uint_poly_assign_dev", ci, vp, vp, sz, vp, sz, vp, sz, vp)

@@ -29,6 +29,9 @@ struct pfhe_extprod_plan {
     bool pipeline = false;
     // PFHE_DISABLE_SMALL_EXTPROD / _FUSED_EXTPROD / _FUSED_DECOMPOSE, read at plan creation
     bool use_small = true, use_fused = true, use_fused_decompose = true;
+    // measurement aid (pfhe_extprod_profile_dev): when non-null, run_product records an event before the
+    // decomposition, between the decomposition and the transform / multiply-accumulate, and after it, per chunk
+    std::vector<hipEvent_t> *prof = nullptr;
     u64 *digits[2] = {nullptr, nullptr};
     size_t digits_words = 0;  // per buffer
     int *sdigits = nullptr;   // compact signed digits of one chunk (chunk * (k+1) * ell * N int32), or null
@@ -143,6 +146,15 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
         const int buf = single ? 0 : (int)(index & 1);  // one stream: one buffer, reused in stream order
         u64 *dg = p->digits[buf];
         const u64 npolys = cur * rows * ell * t.L;
+        const auto stamp = [&](hipStream_t st) -> int {
+            if (p->prof == nullptr) return PFHE_OK;
+            hipEvent_t ev = nullptr;
+            PFHE_HIP(hipEventCreate(&ev));
+            p->prof->push_back(ev);
+            PFHE_HIP(hipEventRecord(ev, st));
+            return PFHE_OK;
+        };
+        PFHE_TRY(stamp(sa));
         // ---- stream a: steps (1)-(4) + strided passes into digit buffer `buf` ----
         if (fused && index >= 2 && !single) PFHE_HIP(hipStreamWaitEvent(sa, p->consumed[buf], 0));
         if (fused_decompose) {
@@ -154,6 +166,7 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
                 PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.pm, dg, npolys, false, i, false, sa, nullptr, 0, t.tune));
         }
         if (!single) PFHE_HIP(hipEventRecord(p->produced[buf], sa));
+        PFHE_TRY(stamp(sa));
         // ---- stream b: block pass (last pass of the transform) ----
         if (!single) PFHE_HIP(hipStreamWaitEvent(sb, p->produced[buf], 0));
         if (fused) {
@@ -164,6 +177,7 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
             PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.pm, dg, npolys, false, passes - 1, false, sb, nullptr, 0, t.tune));
         }
         if (!single) PFHE_HIP(hipEventRecord(p->consumed[buf], sb));
+        PFHE_TRY(stamp(sb));
         if (!fused) {
             if (single) {
                 // one stream, one digit buffer: multiply-accumulate this chunk before the next one overwrites it
@@ -634,6 +648,37 @@ int pfhe_extprod_mul_dcrt_ggsw_to_dev(pfhe_extprod_plan *plan, const uint64_t *c
         PFHE_TRY(ntt_inverse_dev(t.primes_dev, t.L, t.log_n, t.pm, (u64 *)result_dev, batch * (plan->k + 1) * t.L, false,
                                  (hipStream_t)stream, t.tune));
     return PFHE_OK;
+    PFHE_GUARD_END
+}
+
+int pfhe_extprod_profile_dev(pfhe_extprod_plan *plan, const uint64_t *crt_glwe_dev, size_t len_glwe,
+                             const uint64_t *dcrt_ggsw_dev, size_t len_ggsw, uint64_t *result_dev, size_t len_result,
+                             double *ms_out, size_t *launches_out, void *stream) {
+    PFHE_GUARD_BEGIN
+    PFHE_TRY(plan_check(plan));
+    if (!ms_out || !launches_out) return PFHE_ERR_BAD_ARGUMENT;
+    if (plan->pipeline) {
+        set_last_error("profiling needs a plan without the two-stream pipeline");
+        return PFHE_ERR_UNSUPPORTED;
+    }
+    std::vector<hipEvent_t> ev;
+    plan->prof = &ev;
+    int rc = pfhe_extprod_mul_dcrt_ggsw_to_dev(plan, crt_glwe_dev, len_glwe, dcrt_ggsw_dev, len_ggsw, result_dev,
+                                               len_result, 0, stream);
+    plan->prof = nullptr;
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    ms_out[0] = ms_out[1] = 0.0;
+    *launches_out = ev.size() / 3;
+    for (size_t i = 0; rc == PFHE_OK && e == hipSuccess && i + 2 < ev.size(); i += 3) {
+        float a = 0, b = 0;
+        e = hipEventElapsedTime(&a, ev[i], ev[i + 1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&b, ev[i + 1], ev[i + 2]);
+        ms_out[0] += a;  // digit extraction + lifting strided pass
+        ms_out[1] += b;  // block pass of the transform + multiply-accumulate
+    }
+    for (hipEvent_t x : ev) (void)hipEventDestroy(x);
+    if (e != hipSuccess) return hip_fail(e, "external-product profile", __FILE__, __LINE__);
+    return rc;
     PFHE_GUARD_END
 }
 

@@ -59,6 +59,17 @@ def mul_dcrt_ggsw_to_dev(crt_glwe, dcrt_ggsw, result, context: DcrtGlevContext, 
                                                   _stream(stream)))
 
 
+def profile_mul_dcrt_ggsw_to_dev(crt_glwe, dcrt_ggsw, result, context: DcrtGlevContext, stream=None):
+    """Measurement aid: the product (NTT-form output) with HIP events between its kernel groups.  Returns
+    (ms of digit extraction + lifting strided pass, ms of block pass + multiply-accumulate, launches of each)."""
+    import ctypes as C
+    (pa, na), (pk, nk), (pr, nr) = _dev(crt_glwe), _dev(dcrt_ggsw), _dev(result)
+    ms = (C.c_double * 2)()
+    launches = C.c_size_t(0)
+    check(lib().pfhe_extprod_profile_dev(context._h, pa, na, pk, nk, pr, nr, ms, C.byref(launches), _stream(stream)))
+    return float(ms[0]), float(ms[1]), int(launches.value)
+
+
 def add_dcrt_glev_mul_crt_poly_assign_dev(acc, dcrt_glev, crt_poly, context: DcrtGlevContext, stream=None):
     """DcrtGlwe::add_dcrt_glev_mul_crt_poly_assign (glwe/dcrt.rs:178-255): acc += glev (x) crt_poly."""
     (pc, nc), (pg, ng), (pp, np_) = _dev(acc), _dev(dcrt_glev), _dev(crt_poly)

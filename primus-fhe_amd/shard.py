@@ -44,3 +44,14 @@ def timed_steps(step, steps: int, warmup: int, sync, dist=None, device=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
+
+
+def strong_scaling_leg(total: int, world: int, rank: int, run_shard, steps: int, warmup: int, sync, dist=None,
+                       device=None):
+    """BASELINE config 5: a FIXED job of `total` independent units (ciphertexts) split over the ranks in contiguous
+    ranges (shard_range) with no data-path collective.  `run_shard(begin, end)` processes this rank's range once; one
+    step = every rank doing that.  Returns a dict with the whole-job rate (total * steps / max-over-ranks time)."""
+    begin, end = shard_range(total, world, rank)
+    dt = timed_steps(lambda: run_shard(begin, end), steps, warmup, sync, dist, device)
+    return {"scaling": "strong", "batch_total": total, "n_gpus": world, "range_of_rank0": [begin, end] if rank == 0 else None,
+            "units_this_rank": end - begin, "steps": steps, "seconds": dt, "value": total * steps / dt}

@@ -47,6 +47,21 @@ def _worker(rank, world, port, q):
             table.transform_slice(mine)
 
     dt = timed_steps(step, steps=2, warmup=1, sync=lambda: None, dist=dist, device="cpu")
+    # BASELINE config 5 (strong scaling): a fixed job of `batch` units split over the ranks — the code path bench.py
+    # runs for its external_product_config5 leg, with the oracle standing in for the device work
+    from primus_fhe_amd.shard import strong_scaling_leg
+    seen = []
+
+    def run_shard(begin, end):
+        seen.append((begin, end))
+        work = data[begin * 3 * n:end * 3 * n].copy()
+        table.transform_slice(work)
+
+    leg = strong_scaling_leg(batch, world, rank, run_shard, steps=2, warmup=1, sync=lambda: None, dist=dist, device="cpu")
+    units = torch.tensor([leg["units_this_rank"]], dtype=torch.int64)
+    dist.all_reduce(units)
+    leg_ok = (int(units.item()) == batch and leg["scaling"] == "strong" and leg["batch_total"] == batch and
+              len(seen) == 3 and all(r == (b, e) for r in seen) and abs(leg["value"] - batch * 2 / leg["seconds"]) < 1e-6)
     # gather the shards (test-only collective) and compare with the unsharded transform
     parts = [None] * world
     dist.all_gather_object(parts, (b, e, mine))
@@ -55,7 +70,7 @@ def _worker(rank, world, port, q):
         full = data.copy()
         table.transform_slice(full)
         got = np.concatenate([p[2] for p in sorted(parts, key=lambda t: t[0])])
-        q.put((np.array_equal(got, full), [(p[0], p[1]) for p in parts], dt, len(calls)))
+        q.put((np.array_equal(got, full) and leg_ok, [(p[0], p[1]) for p in parts], dt, len(calls)))
 
 
 def test_shard_range_properties():
