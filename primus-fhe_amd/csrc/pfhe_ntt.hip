@@ -131,8 +131,10 @@ __device__ __forceinline__ void strided_pass_body(u64 *__restrict__ data, const 
     }
 }
 
+// 128 registers at most: a SIMD's 512 then hold three block-pass waves (128 each) AND one wave of this kernel, which is
+// what lets the two-stream transform overlap the streaming pass with the computing one (at 136 the mix did not fit)
 template <class A, int K, int VEC, bool INV, bool FINAL>
-__global__ __launch_bounds__(256) void ntt_strided_kernel(u64 *__restrict__ data,
+__global__ __launch_bounds__(256, K <= 4 ? 4 : 1) void ntt_strided_kernel(u64 *__restrict__ data,
                                                           const NttPrime *__restrict__ primes, u32 L,
                                                           u32 log_n, u32 log_s, u64 total_threads, u32 lazy) {
     strided_pass_body<A, K, VEC, INV, FINAL>(data, primes, L, log_n, log_s, (u64)blockIdx.x * blockDim.x + threadIdx.x,
@@ -183,6 +185,7 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
     // all global traffic as 16-byte vectors in natural order (1 KiB per wave instruction), staged
     // through LDS into / out of the register layouts of the first / last register pass
     u64x2 io[8];
+    PFHE_STAMP(0);
     if (valid) {
         load_block_vectors<LOGB>(io, gptr, lt);
     } else {
@@ -209,12 +212,18 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
             io[j].y = ar.mul_any(io[j].y, mv[j].y);
         }
     }
+#ifdef PFHE_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PFHE_STAMP(1);  // global loads landed
+#endif
     lds_put_vectors<LOGB>(io, lds, lt);
     __syncthreads();
+    PFHE_STAMP(2);  // staged
     u64 x[16];
     if constexpr (!INV) {
         lds_get_layout<LOGB - 4>(x, lds, lt);
         block_forward_core<A, LOGB, kBlockLeadBarrier>(ar, x, lds, n, eblk, lt, lazy != 0);
+        PFHE_STAMP(8);  // compute done (stamps 3..7 inside the core)
         if constexpr (kBlockLeadBarrier) __syncthreads();  // else: the write-back reuses the slots each thread read last
         lds_put_layout<0>(x, lds, lt);
     } else {
@@ -224,8 +233,13 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
         lds_put_layout<LOGB - 4>(x, lds, lt);
     }
     __syncthreads();
+    PFHE_STAMP(9);
     lds_get_vectors<LOGB>(io, lds, lt);
     if (valid) store_block_vectors<LOGB>(io, gptr, lt);
+#ifdef PFHE_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    PFHE_STAMP(10);
 }
 
 
@@ -375,6 +389,13 @@ NttTuning NttTuning::from_env() {
     t.block_log = env_int("PFHE_BLOCK_LOG", 8, 12);
     return t;
 }
+
+#ifdef PFHE_STAMPS
+extern "C" int pfhe_debug_read_stamps(unsigned long long *out, size_t wgs) {
+    if (wgs > (size_t)kStampWgs) wgs = kStampWgs;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), wgs * kStampSlots * sizeof(u64)) == hipSuccess ? 0 : 35;
+}
+#endif
 
 NttPlan make_ntt_plan(u32 log_n, int arith, const NttTuning &tune) {
     NttPlan p;

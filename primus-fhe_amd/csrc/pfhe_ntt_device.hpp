@@ -66,6 +66,22 @@ int ntt_pass_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data,
 #error "libpfhe_hip is written for wave64 targets (gfx950)"
 #endif
 
+#ifdef PFHE_STAMPS
+// Diagnostic build (tools/build_variant.sh stamps -DPFHE_STAMPS): wave 0 of the first workgroups stamps s_memtime at
+// the phase boundaries of the block pass into a device array read back by pfhe_debug_read_stamps.  Never in the
+// product build: the stamps cost ~10 % of the wave's cycles.
+constexpr int kStampSlots = 12, kStampWgs = 1 << 16;
+static __device__ u64 g_stamps[kStampWgs][kStampSlots];
+#define PFHE_STAMP(i)                                                                          \
+    do {                                                                                       \
+        if (threadIdx.x == 0 && blockIdx.x < kStampWgs) g_stamps[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define PFHE_STAMP(i) \
+    do {              \
+    } while (0)
+#endif
+
 // Tables are reached through pointers stored in NttPrime, which the compiler would treat as
 // generic (flat) pointers: flat loads tick both vmcnt and lgkmcnt and serialise against LDS
 // traffic.  Reading through explicit global-address-space pointers yields plain global_load.
@@ -706,7 +722,13 @@ __device__ __forceinline__ void fwd_chain(const A &ar, u64 (&x)[16], u64 *__rest
         constexpr int NPOS = POS >= 4 ? POS - 4 : 0;
         constexpr int JHI = POS >= 4 ? 3 : POS - 1;
         lds_exchange<POS, NPOS, FIRST>(x, lds, lt);
+#ifdef PFHE_STAMPS
+        PFHE_STAMP(NPOS == 0 ? 6 : 4);
+#endif
         fwd_regpass<A, NPOS, JHI, 0, UNI>(ar, x, n + eblk + layout<NPOS>(lt, 0), n);
+#ifdef PFHE_STAMPS
+        PFHE_STAMP(NPOS == 0 ? 7 : 5);
+#endif
         fwd_chain<A, LOGB, NPOS>(ar, x, lds, n, eblk, lt);
     }
 }
@@ -720,6 +742,9 @@ __device__ __forceinline__ void block_forward_core(const A &ar, u64 (&x)[16], u6
     constexpr int POS0 = LOGB - 4;
     constexpr bool UNI = BlockCfg<LOGB>::TPB >= 64;  // a wave never straddles two blocks
     fwd_regpass<A, POS0, 3, 0, UNI>(ar, x, n + eblk + layout<POS0>(lt, 0), n);
+#ifdef PFHE_STAMPS
+    PFHE_STAMP(3);
+#endif
     fwd_chain<A, LOGB, POS0, LEAD>(ar, x, lds, n, eblk, lt);
     if constexpr (A::kPacked) {  // distance-1 stage between the halves of each word
 #pragma unroll

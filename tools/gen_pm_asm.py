@@ -27,8 +27,13 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 # temporary register sets (pairs must start at an even register): A, B, E, C
 # cy: where the set keeps carries (every v_mad_u64_u32 writes a carry-out, wanted or not): interleaved butterflies
 # must not share it
-SETS = [dict(A=(120, 121), B=(122, 123), E=(124, 125), C=(126, 127), cy="vcc"),
-        dict(A=(112, 113), B=(114, 115), E=(116, 117), C=(118, 119), cy="%[cyb]")]
+# LOW register numbers: a kernel's register count is its highest register + 1, and v2..v17 are always in use anyway
+# (the work-item ids arrive in v0..v2 and are consumed before the first butterfly)
+SETS = [dict(A=(2, 3), B=(4, 5), E=(6, 7), C=(8, 9), cy="vcc"),
+        dict(A=(10, 11), B=(12, 13), E=(14, 15), C=(16, 17), cy="%[cyb]")]
+if os.environ.get("PM_ASM_HIGH_TEMPS"):  # experiment: the first placement tried (forces 128 registers on every kernel)
+    SETS = [dict(A=(120, 121), B=(122, 123), E=(124, 125), C=(126, 127), cy="vcc"),
+            dict(A=(112, 113), B=(114, 115), E=(116, 117), C=(118, 119), cy="%[cyb]")]
 
 
 def pair(p):
@@ -162,7 +167,7 @@ def gen_inv(ways, uni):
 HEADER = '''// pfhe_pm_asm.hpp — GENERATED by tools/gen_pm_asm.py; do not edit by hand.
 //
 // Pseudo-Mersenne NTT butterflies (q = 2^K - c) as hand-scheduled gfx950 instruction sequences with fixed temporary
-// registers (v112..v127), one butterfly or two interleaved ones per asm block.  See the generator for the cost
+// registers (v2..v17), one butterfly or two interleaved ones per asm block.  See the generator for the cost
 // model and for why this is not C++.  The arithmetic is PmArith's (pfhe_ntt_device.hpp): twiddle product
 // T = fold(y0*w + y1*w2) <= 3q with w2 = w*2^32 mod q; forward x' = X + T, y' = X + 3q - T with X = x or fold(x);
 // inverse x' = fold(x + y), y' = (x + 3q - y)*w.  `A` must provide q3, c, c2, sh = K - 32 and, held in VGPRs (an SGPR operand doubles the cost of a
