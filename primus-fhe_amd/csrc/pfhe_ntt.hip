@@ -133,8 +133,11 @@ __device__ __forceinline__ void strided_pass_body(u64 *__restrict__ data, const 
 
 // 128 registers at most: a SIMD's 512 then hold three block-pass waves (128 each) AND one wave of this kernel, which is
 // what lets the two-stream transform overlap the streaming pass with the computing one (at 136 the mix did not fit)
+// VEC == 1 is the LIGHT form (at most 96 registers): PFHE_LIGHT_STRIDED selects it for the strided pass that runs
+// beside a block pass in the two-stream transform.  Measured: no gain (5.41 vs 5.37 ms per step) — it only fits next to
+// four block-pass waves when those are squeezed to 96 registers, which costs the block pass more than the overlap returns.
 template <class A, int K, int VEC, bool INV, bool FINAL>
-__global__ __launch_bounds__(256, K <= 4 ? 4 : 1) void ntt_strided_kernel(u64 *__restrict__ data,
+__global__ __launch_bounds__(256, K <= 4 ? (VEC == 1 ? 5 : 4) : 1) void ntt_strided_kernel(u64 *__restrict__ data,
                                                           const NttPrime *__restrict__ primes, u32 L,
                                                           u32 log_n, u32 log_s, u64 total_threads, u32 lazy) {
     strided_pass_body<A, K, VEC, INV, FINAL>(data, primes, L, log_n, log_s, (u64)blockIdx.x * blockDim.x + threadIdx.x,
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256, K <= 4 ? 4 : 1) void ntt_strided_kernel(u64 *_
 // LDS limits the block pass to four waves per SIMD; telling the compiler so makes it spend registers on
 // instruction-level parallelism instead of chasing a higher occupancy it cannot get (1-3 % measured)
 #ifndef PFHE_BLOCK_WAVES_ATTR
-#define PFHE_BLOCK_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#define PFHE_BLOCK_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4, 4), amdgpu_num_vgpr(104)))
 #endif
 // x is filled from the staging region by lds_get_layout, so the first exchange needs no barrier in front of it
 #ifdef PFHE_BLOCK_LEAD_BARRIER
@@ -385,6 +388,7 @@ NttTuning NttTuning::from_env() {
     t.overlap_inverse = std::getenv("PFHE_OVERLAP_INVERSE") != nullptr;
     t.overlap_tiles = env_int("PFHE_OVERLAP_TILES", 2, 4096);
     t.strided_vec1 = std::getenv("PFHE_STRIDED_VEC1") != nullptr;
+    t.light_strided = std::getenv("PFHE_LIGHT_STRIDED") != nullptr;
     t.max_single_pass_log = env_int("PFHE_MAX_SINGLE_PASS_LOG", 9, (int)kMaxSinglePassLog);
     t.block_log = env_int("PFHE_BLOCK_LOG", 8, 12);
     return t;
@@ -587,6 +591,8 @@ static int transform(const NttPrime *primes, u32 L, u32 log_n, int pm, u64 *data
     // unchanged inside a tile
     const u64 units = npolys / L;
     int rc = PFHE_OK;
+    NttTuning light = tune;  // the strided pass that runs beside a block pass takes its 64-register form
+    light.strided_vec1 = tune.light_strided;
     hipError_t e = hipEventRecord(c->fork, s);
     if (e == hipSuccess) e = hipStreamWaitEvent(c->a, c->fork, 0);
     if (e == hipSuccess) e = hipStreamWaitEvent(c->b, c->fork, 0);
@@ -598,12 +604,12 @@ static int transform(const NttPrime *primes, u32 L, u32 log_n, int pm, u64 *data
         // a per-element multiplicand is tiled like the data; a shared one (one unit of L) is not
         const u64 *mptr = mul == nullptr ? nullptr : (mul_polys == npolys ? mul + ((u0 * L) << log_n) : mul);
         rc = ntt_pass_dev(primes, L, log_n, pm, ptr, np, inverse, 0, lazy, c->a, mptr,
-                          mul_polys == npolys ? np : mul_polys, tune);
+                          mul_polys == npolys ? np : mul_polys, inverse ? tune : light);
         if (rc != PFHE_OK) break;
         e = hipEventRecord(c->tile[k], c->a);
         if (e == hipSuccess) e = hipStreamWaitEvent(c->b, c->tile[k], 0);
         if (e != hipSuccess) break;
-        rc = ntt_pass_dev(primes, L, log_n, pm, ptr, np, inverse, 1, lazy, c->b, nullptr, 0, tune);
+        rc = ntt_pass_dev(primes, L, log_n, pm, ptr, np, inverse, 1, lazy, c->b, nullptr, 0, inverse ? light : tune);
     }
     // join: everything later on the caller's stream waits for both internal streams
     if (e == hipSuccess) e = hipEventRecord(c->join_a, c->a);

@@ -26,7 +26,8 @@ struct NttTuning {
     bool overlap = true;           // PFHE_DISABLE_OVERLAP clears it: two-pass transforms of big batches run tiled on two streams
     bool overlap_inverse = false;  // PFHE_OVERLAP_INVERSE: tile the inverse direction too
     int overlap_tiles = 0;         // PFHE_OVERLAP_TILES (0: built-in default)
-    bool strided_vec1 = false;     // PFHE_STRIDED_VEC1: one column per thread in the 4-stage strided pass
+    bool strided_vec1 = false;     // PFHE_STRIDED_VEC1: one column per thread in the 4-stage strided pass (64 registers)
+    bool light_strided = false;    // PFHE_LIGHT_STRIDED: the tiled transform runs the one-column strided pass beside the block pass
     int max_single_pass_log = 0;   // PFHE_MAX_SINGLE_PASS_LOG (0: built-in default)
     int block_log = 0;             // PFHE_BLOCK_LOG: block size under strided passes (0: built-in default)
     static NttTuning from_env();
@@ -591,6 +592,14 @@ __device__ __forceinline__ u32 maybe_uniform(u32 v) {
     }
 }
 
+// chunks of a forward register pass in execution order (software-pipelined twiddle loads): stage JHI, JHI-1, ... as
+// wholes, the 8-twiddle stage 0 (when it is part of the pass) as two halves
+__host__ __device__ constexpr int fwd_chunk_j(int c, int jhi, int jlo) { return (jlo == 0 && c >= jhi) ? 0 : jhi - c; }
+__host__ __device__ constexpr int fwd_chunk_u0(int c, int jhi, int jlo) { return (jlo == 0 && c >= jhi) ? (c - jhi) * 4 : 0; }
+__host__ __device__ constexpr int fwd_chunk_u1(int c, int jhi, int jlo) {
+    return (jlo == 0 && c >= jhi) ? (c - jhi) * 4 + 4 : (16 >> (fwd_chunk_j(c, jhi, jlo) + 1));
+}
+
 // forward stages on register bits JHI..JLO (element bits POS+JHI .. POS+JLO); twiddle of the
 // butterfly at global element E, distance 2^p: fwd[(N + E) >> (p + 1)]
 template <class A, int POS, int JHI, int JLO, bool UNIFORM>
@@ -602,25 +611,56 @@ __device__ __forceinline__ void fwd_regpass(const A &ar, u64 (&x)[16], u32 n_plu
         const u32 last_off = (((8u >> j) - 1) * (n >> 4)) + ((n_plus_e - n) >> 4);
         constexpr bool kUni = UNIFORM && POS >= 6;  // maybe_uniform: the twiddle sits in scalar registers
         typename A::Tw w[8];
-#pragma unroll
-        for (int u = 0; u < (16 >> (j + 1)); ++u) {
+        const auto load_tw = [&](int u) {
             if constexpr (POS == 0 && A::kLastTables) w[u] = ar.fwd_tw_last(last_off + (u32)u * (n >> 4));
             else w[u] = ar.fwd_tw(base + u);
-        }
+        };
 #if !defined(PFHE_NO_ASM_BFLY_PAIRS) && !defined(PFHE_NO_ASM_BFLY)
         if constexpr (A::kWide) {
             // two butterflies per asm block (independent instruction streams interleaved): butterfly b of the stage
             // has u = b >> j, v = b & (2^j - 1)
+            if constexpr (kUni) {
 #pragma unroll
-            for (int b = 0; b < 8; b += 2) {
-                const int ua = b >> j, va = b & ((1 << j) - 1), ub = (b + 1) >> j, vb = (b + 1) & ((1 << j) - 1);
-                const int a0 = (ua << (j + 1)) | va, a1 = a0 | (1 << j), b0 = (ub << (j + 1)) | vb, b1 = b0 | (1 << j);
-                if ((POS + j) & 1) pm_fwd_bfly2<true, kUni>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
-                else pm_fwd_bfly2<false, kUni>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
+                for (int u = 0; u < (16 >> (j + 1)); ++u) load_tw(u);
+#pragma unroll
+                for (int b = 0; b < 8; b += 2) {
+                    const int ua = b >> j, va = b & ((1 << j) - 1), ub = (b + 1) >> j, vb = (b + 1) & ((1 << j) - 1);
+                    const int a0 = (ua << (j + 1)) | va, a1 = a0 | (1 << j), b0 = (ub << (j + 1)) | vb, b1 = b0 | (1 << j);
+                    if ((POS + j) & 1) pm_fwd_bfly2<true, true>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
+                    else pm_fwd_bfly2<false, true>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
+                }
             }
-            continue;
+#ifndef PFHE_PIPELINED_TWIDDLES
+            else {
+                if (j == 0) {  // the eight twiddles of the last stage in two halves (32 registers at once otherwise)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                        for (int u = 4 * h; u < 4 * h + 4; ++u) load_tw(u);
+#pragma unroll
+                        for (int b = 4 * h; b < 4 * h + 4; b += 2) {
+                            if ((POS + j) & 1) pm_fwd_bfly2<true, false>(ar, x[2 * b], x[2 * b + 1], w[b], x[2 * b + 2], x[2 * b + 3], w[b + 1]);
+                            else pm_fwd_bfly2<false, false>(ar, x[2 * b], x[2 * b + 1], w[b], x[2 * b + 2], x[2 * b + 3], w[b + 1]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < (16 >> (j + 1)); ++u) load_tw(u);
+#pragma unroll
+                    for (int b = 0; b < 8; b += 2) {
+                        const int ua = b >> j, va = b & ((1 << j) - 1), ub = (b + 1) >> j, vb = (b + 1) & ((1 << j) - 1);
+                        const int a0 = (ua << (j + 1)) | va, a1 = a0 | (1 << j), b0 = (ub << (j + 1)) | vb, b1 = b0 | (1 << j);
+                        if ((POS + j) & 1) pm_fwd_bfly2<true, false>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
+                        else pm_fwd_bfly2<false, false>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
+                    }
+                }
+            }
+#endif
+            continue;  // (PFHE_PIPELINED_TWIDDLES: per-lane twiddles take the software-pipelined form below the loop)
         }
 #endif
+#pragma unroll
+        for (int u = 0; u < (16 >> (j + 1)); ++u) load_tw(u);
 #pragma unroll
         for (int u = 0; u < (16 >> (j + 1)); ++u) {
 #pragma unroll
@@ -631,6 +671,45 @@ __device__ __forceinline__ void fwd_regpass(const A &ar, u64 (&x)[16], u32 n_plu
             }
         }
     }
+#if !defined(PFHE_NO_ASM_BFLY_PAIRS) && !defined(PFHE_NO_ASM_BFLY) && defined(PFHE_PIPELINED_TWIDDLES)
+    if constexpr (A::kWide && !(UNIFORM && POS >= 6)) {
+        // Per-lane twiddles (vector registers, four per twiddle).  Left alone the compiler issues all fifteen loads of
+        // the pass up front: 60 registers.  Here the loads of the NEXT chunk (a stage, or half of the 8-twiddle last
+        // stage) are issued just before the butterflies of the current one and scheduling barriers keep them
+        // there: at most 8 twiddles are live, which lets the block pass fit 96 registers (five waves per SIMD: four of
+        // its own and one of the streaming pass beside it).
+        typename A::Tw tw[4][8];
+        const auto load_chunk = [&](int j, int u0, int u1) {
+            const u32 base = n_plus_e >> (POS + j + 1);
+            const u32 last_off = (((8u >> j) - 1) * (n >> 4)) + ((n_plus_e - n) >> 4);
+#pragma unroll
+            for (int u = u0; u < u1; ++u) {
+                if constexpr (POS == 0 && A::kLastTables) tw[j][u] = ar.fwd_tw_last(last_off + (u32)u * (n >> 4));
+                else tw[j][u] = ar.fwd_tw(base + u);
+            }
+        };
+        const auto run_chunk = [&](int j, int u0, int u1) {
+#pragma unroll
+            for (int b = u0 << j; b < (u1 << j); b += 2) {
+                const int ua = b >> j, va = b & ((1 << j) - 1), ub = (b + 1) >> j, vb = (b + 1) & ((1 << j) - 1);
+                const int a0 = (ua << (j + 1)) | va, a1 = a0 | (1 << j), b0 = (ub << (j + 1)) | vb, b1 = b0 | (1 << j);
+                if ((POS + j) & 1) pm_fwd_bfly2<true, false>(ar, x[a0], x[a1], tw[j][ua], x[b0], x[b1], tw[j][ub]);
+                else pm_fwd_bfly2<false, false>(ar, x[a0], x[a1], tw[j][ua], x[b0], x[b1], tw[j][ub]);
+            }
+        };
+        // chunks in execution order: stage j as a whole, the last stage (j == 0) in two halves
+        constexpr int kChunks = (JHI - JLO + 1) + (JLO == 0 ? 1 : 0);
+        load_chunk(fwd_chunk_j(0, JHI, JLO), fwd_chunk_u0(0, JHI, JLO), fwd_chunk_u1(0, JHI, JLO));
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c) {
+            if (c + 1 < kChunks)
+                load_chunk(fwd_chunk_j(c + 1, JHI, JLO), fwd_chunk_u0(c + 1, JHI, JLO), fwd_chunk_u1(c + 1, JHI, JLO));
+            __builtin_amdgcn_sched_barrier(0);
+            run_chunk(fwd_chunk_j(c, JHI, JLO), fwd_chunk_u0(c, JHI, JLO), fwd_chunk_u1(c, JHI, JLO));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#endif
 }
 
 // inverse stages on register bits JLO..JHI: inv[1 + N - (N >> p) + (E >> (p + 1))]; when
@@ -677,16 +756,27 @@ __device__ __forceinline__ void inv_regpass(const A &ar, u64 (&x)[16], u32 n, u3
     }
 }
 
+// Padded LDS index of register k in layout POS = index of register 0 + a compile-time constant: the bit fields of
+// layout<POS>(lt, k) are disjoint, so lds_phi(layout(lt, k)) = lds_phi(layout(lt, 0)) + (k << POS) + 2 * ((k << POS) >> 4).
+// One address register per layout and immediate offsets in the ds instructions, instead of sixteen computed addresses
+// (which the compiler hoisted and, under register pressure, spilled).
+template <int POS>
+__host__ __device__ constexpr u32 lds_koff(int k) {
+    return ((u32)k << POS) + 2u * (((u32)k << POS) >> 4);
+}
+
 template <int POS>
 __device__ __forceinline__ void lds_get_layout(u64 (&x)[16], const u64 *__restrict__ lds, u32 lt) {
+    const u64 *__restrict__ base = lds + lds_phi(layout<POS>(lt, 0));
 #pragma unroll
-    for (int k = 0; k < 16; ++k) x[k] = lds[lds_phi(layout<POS>(lt, k))];
+    for (int k = 0; k < 16; ++k) x[k] = base[lds_koff<POS>(k)];
 }
 
 template <int POS>
 __device__ __forceinline__ void lds_put_layout(const u64 (&x)[16], u64 *__restrict__ lds, u32 lt) {
+    u64 *__restrict__ base = lds + lds_phi(layout<POS>(lt, 0));
 #pragma unroll
-    for (int k = 0; k < 16; ++k) lds[lds_phi(layout<POS>(lt, k))] = x[k];
+    for (int k = 0; k < 16; ++k) base[lds_koff<POS>(k)] = x[k];
 }
 
 // registers (layout FROM) -> LDS -> registers (layout TO).
@@ -751,8 +841,16 @@ __device__ __forceinline__ void block_forward_core(const A &ar, u64 (&x)[16], u6
         for (int k = 0; k < 16; ++k) x[k] = ar.fwd_intra(x[k], n + eblk + layout<0>(lt, k));
     }
     if constexpr (A::kWide) {
+#if !defined(PFHE_NO_ASM_BFLY)
+        if (!lazy) {  // one uniform branch for the whole thread, two elements per asm block
 #pragma unroll
-        for (int k = 0; k < 16; ++k) x[k] = fwd_finish(ar, x[k], lazy);
+            for (int k = 0; k < 16; k += 2) pm_canon2(ar, x[k], x[k + 1]);
+        } else
+#endif
+        {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) x[k] = fwd_finish(ar, x[k], lazy);
+        }
     } else if (!lazy) {  // [0,4q) -> [0,q): scalar/transform.rs:104-116
 #pragma unroll
         for (int k = 0; k < 16; ++k) x[k] = ar.reduce_4q(x[k]);
@@ -803,16 +901,34 @@ __device__ __forceinline__ void store_block_vectors(const u64x2 (&v)[8], u64 *gp
     for (int j = 0; j < 8; ++j) p[lt + BlockCfg<LOGB>::TPB * j] = v[j];
 }
 
+// vector v = lt + TPB*j holds elements 2v, 2v+1: padded index = lds_phi(2*lt) + constant(j) once 2*TPB is a multiple of 16
+template <int LOGB>
+__host__ __device__ constexpr u32 lds_voff(int j) {
+    return 2u * BlockCfg<LOGB>::TPB * (u32)j + 2u * ((2u * BlockCfg<LOGB>::TPB * (u32)j) >> 4);
+}
+
 template <int LOGB>
 __device__ __forceinline__ void lds_put_vectors(const u64x2 (&v)[8], u64 *__restrict__ lds, u32 lt) {
+    if constexpr (BlockCfg<LOGB>::TPB >= 8) {
+        u64 *__restrict__ base = lds + lds_phi(2 * lt);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) *reinterpret_cast<u64x2 *>(lds + lds_phi(2 * (lt + BlockCfg<LOGB>::TPB * j))) = v[j];
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<u64x2 *>(base + lds_voff<LOGB>(j)) = v[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<u64x2 *>(lds + lds_phi(2 * (lt + BlockCfg<LOGB>::TPB * j))) = v[j];
+    }
 }
 
 template <int LOGB>
 __device__ __forceinline__ void lds_get_vectors(u64x2 (&v)[8], const u64 *__restrict__ lds, u32 lt) {
+    if constexpr (BlockCfg<LOGB>::TPB >= 8) {
+        const u64 *__restrict__ base = lds + lds_phi(2 * lt);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const u64x2 *>(lds + lds_phi(2 * (lt + BlockCfg<LOGB>::TPB * j)));
+        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const u64x2 *>(base + lds_voff<LOGB>(j));
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const u64x2 *>(lds + lds_phi(2 * (lt + BlockCfg<LOGB>::TPB * j)));
+    }
 }
 
 #endif  // __HIPCC__

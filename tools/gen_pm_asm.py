@@ -97,6 +97,36 @@ def inv_seq(t, s):
     return seq
 
 
+def canon_seq(t, s):
+    """any 64-bit x -> [0, q): fold (x mod~ q < 2^K + 2^31 < 2q), then subtract q unless that borrows"""
+    A, E, C, cy = t["A"], t["E"], t["C"], t["cy"]
+    return [
+        f"v_lshrrev_b32 v{E[0]}, %[sh], %[x1{s}]",
+        f"v_and_b32 v{C[1]}, %[m], %[x1{s}]",
+        f"v_mov_b32 v{C[0]}, %[x0{s}]",
+        f"v_mad_u64_u32 {pair(C)}, {cy}, v{E[0]}, %[c], {pair(C)}",
+        f"v_lshl_add_u64 {pair(A)}, {pair(C)}, 0, %[negq]",              # A = X - q (negative iff X < q: X < 2q < 2^63)
+        f"v_cmp_gt_i32_e64 {cy}, 0, v{A[1]}",
+        f"v_cndmask_b32_e64 %[o0{s}], v{A[0]}, v{C[0]}, {cy}",
+        f"v_cndmask_b32_e64 %[o1{s}], v{A[1]}, v{C[1]}, {cy}",
+    ]
+
+
+def gen_canon(ways):
+    sfx = ["a", "b"][:ways]
+    sets = SETS[:ways]
+    lines = interleave([canon_seq(t, s) for t, s in zip(sets, sfx)])
+    outs, ins = [], []
+    for s in sfx:
+        outs += [f'[o0{s}] "=&v"(o0{s})', f'[o1{s}] "=&v"(o1{s})']
+    if ways == 2:
+        outs += ['[cyb] "=&s"(cyb)']
+    for s in sfx:
+        ins += [f'[x0{s}] "v"((u32)x{s})', f'[x1{s}] "v"((u32)(x{s} >> 32))']
+    ins += ['[sh] "v"(ar.vsh)', '[m] "v"(ar.vmask)', '[c] "s"(ar.c)', '[negq] "s"(0ull - ar.q)']
+    return emit_asm(lines, outs, ins, clobbers_of(sets, ["A", "E", "C"]), indent="    ")
+
+
 def interleave(seqs):
     out = []
     for i in range(max(len(q) for q in seqs)):
@@ -211,6 +241,17 @@ def main():
         src += "    if constexpr (UNI) {\n" + gen_inv(ways, True) + "    } else {\n" + gen_inv(ways, False) + "    }\n"
         for s in ["a", "b"][:ways]:
             src += f"    x{s} = xo{s};\n    y{s} = yo{s};\n"
+        src += "}\n\n"
+    for ways in (1, 2):
+        args = ", ".join(f"u64 &x{s}" for s in ["a", "b"][:ways])
+        src += (f"// any 64-bit value -> canonical residue in [0, q)\ntemplate <class A>\n__device__ __forceinline__ void "
+                f"pm_canon{ways}(const A &ar, {args}) {{\n")
+        src += "    u32 " + ", ".join(f"o0{s}, o1{s}" for s in ["a", "b"][:ways]) + ";\n"
+        if ways == 2:
+            src += "    u64 cyb;\n"
+        src += gen_canon(ways)
+        for s in ["a", "b"][:ways]:
+            src += f"    x{s} = ((u64)o1{s} << 32) | o0{s};\n"
         src += "}\n\n"
     src += "}  // namespace pfhe\n"
     with open(OUT, "w") as f:
