@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Copies the summaries of a tools/profile_round2.sh run (gpurun_out/TAG/) into profiles/ under the prefix TAG:
+bench line, kernel trace of the same bench command grouped by kernel and grid size, HBM-counter summary, utilisation
+counters of the NTT kernels, and the external product's kernel breakdown + counters at the bench shape."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02_a"
+# (run on the GPU box, where only gpurun_out/ travels back: the summaries go to gpurun_out/TAG/summaries/ and are copied
+# into profiles/ by hand afterwards:  cp gpurun_out/TAG/summaries/* profiles/)
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(src, "summaries")
+os.makedirs(dst, exist_ok=True)
+
+
+def short(n):
+    return n.replace("void ", "").replace("pfhe::(anonymous namespace)::", "").replace("pfhe::", "").split("(")[0]
+
+
+def grid_of(r):
+    return int(r.get("Grid_Size", r.get("Grid_Size_X", 0)))
+
+
+def newest(pattern):
+    f = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+    return f[-1] if f else None
+
+
+# ---- bench line + kernel trace of the same command
+b = json.loads(open(src + "/bench.json").read().strip().splitlines()[-1])
+json.dump(b, open(f"{dst}/{tag}_bench.json", "w"), indent=1)
+tr, st = newest(src + "/trace_bench/**/*_kernel_trace.csv"), newest(src + "/trace_bench/**/*_kernel_stats.csv")
+d = collections.defaultdict(list)
+for r in csv.DictReader(open(tr)):
+    d[(short(r["Kernel_Name"]), grid_of(r))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+lines = ["rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --ext-total 0   (grouped by kernel and grid size:",
+         "the timed steps launch the two passes per 1/12-batch tile on two streams, the roofline leg launches full-size passes)",
+         f"{'kernel':64s} {'grid':>10s} {'n':>4s} {'avg ms':>8s} {'min ms':>8s} {'max ms':>8s}"]
+out = []
+for (k, g), v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
+    if k.startswith("__amd"):
+        continue
+    lines.append(f"{k:64s} {g:10d} {len(v):4d} {sum(v) / len(v) / 1e6:8.3f} {min(v) / 1e6:8.3f} {max(v) / 1e6:8.3f}")
+    out.append({"kernel": k, "grid": g, "launches": len(v), "avg_ms": sum(v) / len(v) / 1e6})
+open(f"{dst}/{tag}_bench_kernel_trace.txt", "w").write("\n".join(lines) + "\n")
+json.dump(out, open(f"{dst}/{tag}_bench_kernel_trace.json", "w"), indent=1)
+shutil.copy(st, f"{dst}/{tag}_bench_kernel_stats.csv")
+for ext in ("txt", "json"):
+    if os.path.exists(f"{src}/rocprof.{ext}"):
+        shutil.copy(f"{src}/rocprof.{ext}", f"{dst}/{tag}_rocprof.{ext}")
+
+
+def counter_table(prefix, title):
+    table = collections.defaultdict(dict)
+    for dpath in sorted(glob.glob(f"{src}/{prefix}*/")):
+        c = os.path.basename(dpath.rstrip("/"))[len(prefix):]
+        f = newest(dpath + "/**/*counter_collection.csv")
+        if not f:
+            continue
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            acc[(short(r["Kernel_Name"]), grid_of(r))].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            table[k][c] = (sum(v) / len(v), len(v))
+    cols = sorted({c for v in table.values() for c in v})
+    rows = [title, f"{'kernel':60s} {'grid':>10s} {'n':>5s} " + " ".join(f"{c:>16s}" for c in cols)]
+    for k in sorted(table, key=lambda k: (k[0], -k[1])):
+        if k[0].startswith("__amd") or "fill" in k[0]:
+            continue
+        nlaunch = max(n for _, n in table[k].values())
+        rows.append(f"{k[0]:60s} {k[1]:10d} {nlaunch:5d} " + " ".join(f"{table[k].get(c, (float('nan'), 0))[0]:16.2f}" for c in cols))
+    return rows
+
+
+open(f"{dst}/{tag}_pmc_utilisation.txt", "w").write("\n".join(counter_table(
+    "util_", "rocprofv3 --pmc <one counter per pass> -- python3 tools/profile_ntt.py (PFHE_PROFILE_BATCH=2048); averages over launches")) + "\n")
+# ---- external product at the bench shape
+ep = ["tools/perf_extprod.py (batch 1024, default chunk of 64 ciphertexts): " + " | ".join(
+    l.strip() for l in open(src + "/ep.log") if "ext-products" in l)]
+stf = newest(src + "/ep_trace/**/*_kernel_stats.csv")
+if stf:
+    ep.append("rocprofv3 --kernel-trace --stats (same command):")
+    for r in csv.DictReader(open(stf)):
+        ep.append(f"  {short(r['Name']):58s} calls {int(r['Calls']):5d}  avg {float(r['AverageNs']) / 1e3:9.1f} us  {float(r['Percentage']):6.2f} %")
+ep += counter_table("ep_", "rocprofv3 --pmc <one counter per pass> -- python3 tools/perf_extprod.py (FETCH_SIZE / WRITE_SIZE in KiB as "
+                    "reported: reads = 2 x FETCH_SIZE on gfx950)")
+open(f"{dst}/{tag}_extprod_pmc.txt", "w").write("\n".join(ep) + "\n")
+print("\n".join(lines[:10]))
+print("\n".join(ep[:14]))
