@@ -164,11 +164,12 @@ constexpr bool kBlockLeadBarrier = true;
 constexpr bool kBlockLeadBarrier = false;
 #endif
 
-template <class A, int LOGB, bool INV, bool MUL>
+template <class A, int LOGB, bool INV, bool MUL, int LOGE = 4>
 __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L,
                                                 u32 log_n, u64 total_blocks, u32 lazy, const u64 *__restrict__ mul,
                                                 u64 mul_polys, u64 *__restrict__ lds_raw) {
-    using Cfg = BlockCfg<LOGB>;
+    using Cfg = BlockCfg<LOGB, LOGE>;
+    constexpr int NV = Cfg::E / 2;  // 16-byte vectors per thread
     const u32 tid = threadIdx.x;
     const u32 sub = Cfg::BPW == 1 ? 0u : tid / Cfg::TPB;
     const u32 lt = Cfg::BPW == 1 ? tid : tid % Cfg::TPB;
@@ -187,13 +188,13 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
 
     // all global traffic as 16-byte vectors in natural order (1 KiB per wave instruction), staged
     // through LDS into / out of the register layouts of the first / last register pass
-    u64x2 io[8];
+    u64x2 io[NV];
     PFHE_STAMP(0);
     if (valid) {
-        load_block_vectors<LOGB>(io, gptr, lt);
+        load_block_vectors<LOGB, LOGE>(io, gptr, lt);
     } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) io[j] = u64x2{0, 0};
+        for (int j = 0; j < NV; ++j) io[j] = u64x2{0, 0};
     }
     if constexpr (MUL) {  // fused pointwise product (DcrtPolynomial::mul_assign) on the way in
         // The multiplicand is one RNS polynomial (mul_polys == L, indexed by the limb) or one polynomial per data
@@ -201,16 +202,16 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
         // `valid` branch on purpose: inside it, the zero high half of the zero-extended 32-bit constant c was
         // defined in the branch, reached the rest of the kernel as a phi the compiler could not fold, and every
         // multiplication by c in the transform became two (5.3 instead of 4.2 ms per 12 288 transforms).
-        u64x2 mv[8];
+        u64x2 mv[NV];
         if (valid) {
             const u64 mpoly = mul_polys == (u64)L ? (u64)limb : pid;
-            load_block_vectors<LOGB>(mv, mul + mpoly * n + eblk, lt);
+            load_block_vectors<LOGB, LOGE>(mv, mul + mpoly * n + eblk, lt);
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) mv[j] = u64x2{0, 0};
+            for (int j = 0; j < NV; ++j) mv[j] = u64x2{0, 0};
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NV; ++j) {
             io[j].x = ar.mul_any(io[j].x, mv[j].x);
             io[j].y = ar.mul_any(io[j].y, mv[j].y);
         }
@@ -219,32 +220,46 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PFHE_STAMP(1);  // global loads landed
 #endif
-    lds_put_vectors<LOGB>(io, lds, lt);
+    lds_put_vectors<LOGB, LOGE>(io, lds, lt);
     __syncthreads();
     PFHE_STAMP(2);  // staged
-    u64 x[16];
+    u64 x[Cfg::E];
     if constexpr (!INV) {
-        lds_get_layout<LOGB - 4>(x, lds, lt);
-        block_forward_core<A, LOGB, kBlockLeadBarrier>(ar, x, lds, n, eblk, lt, lazy != 0);
+        lds_get_layout<LOGB - LOGE, LOGE>(x, lds, lt);
+        block_forward_core<A, LOGB, kBlockLeadBarrier, LOGE>(ar, x, lds, n, eblk, lt, lazy != 0);
         PFHE_STAMP(8);  // compute done (stamps 3..7 inside the core)
         if constexpr (kBlockLeadBarrier) __syncthreads();  // else: the write-back reuses the slots each thread read last
-        lds_put_layout<0>(x, lds, lt);
+        lds_put_layout<0, LOGE>(x, lds, lt);
     } else {
-        lds_get_layout<0>(x, lds, lt);
-        block_inverse_core<A, LOGB, kBlockLeadBarrier>(ar, x, lds, n, eblk, lt, log_n == LOGB, lazy != 0);
+        lds_get_layout<0, LOGE>(x, lds, lt);
+        block_inverse_core<A, LOGB, kBlockLeadBarrier, LOGE>(ar, x, lds, n, eblk, lt, log_n == LOGB, lazy != 0);
         if constexpr (kBlockLeadBarrier) __syncthreads();
-        lds_put_layout<LOGB - 4>(x, lds, lt);
+        lds_put_layout<LOGB - LOGE, LOGE>(x, lds, lt);
     }
     __syncthreads();
     PFHE_STAMP(9);
-    lds_get_vectors<LOGB>(io, lds, lt);
-    if (valid) store_block_vectors<LOGB>(io, gptr, lt);
+    lds_get_vectors<LOGB, LOGE>(io, lds, lt);
+    if (valid) store_block_vectors<LOGB, LOGE>(io, gptr, lt);
 #ifdef PFHE_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     PFHE_STAMP(10);
 }
 
+
+// 8 coefficients per thread: registers for seven waves per SIMD (LDS then allows 32 waves per CU with 2^12-word blocks)
+#ifndef PFHE_BLOCK8_WAVES_ATTR
+#define PFHE_BLOCK8_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(6, 8)))
+#endif
+template <int LOGB>
+constexpr int kBlock8Threads = BlockCfg<(LOGB <= 13 ? LOGB : 13), 3>::THREADS;
+template <class A, int LOGB, bool INV, bool MUL = false>
+__global__ __launch_bounds__(kBlock8Threads<LOGB>) PFHE_BLOCK8_WAVES_ATTR void ntt_block8_kernel(
+    u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L, u32 log_n, u64 total_blocks, u32 lazy,
+    const u64 *__restrict__ mul, u64 mul_polys) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds_raw[];
+    block_pass_body<A, LOGB, INV, MUL, 3>(data, primes, L, log_n, total_blocks, lazy, mul, mul_polys, lds_raw);
+}
 
 template <class A, int LOGB, bool INV, bool MUL = false>
 __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) PFHE_BLOCK_WAVES_ATTR void ntt_block_kernel(
@@ -259,10 +274,25 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) PFHE_BLOCK_WAVES_ATTR void
 // ------------------------------------------------------------------------------------------
 namespace {
 
+// Blocks that take the 8-coefficients-per-thread form (twice the threads, half the registers each: 76-80 registers
+// and six waves per SIMD for the pseudo-Mersenne kernels, eight for the generic ones).  Off by default (build with
+// -DPFHE_BLOCK8 to try it): measured 3.28 ms (forward) / 3.23 ms (inverse) per 12 288 blocks-of-2^12 passes against
+// 3.20 / 3.03-3.12 ms for the 16-coefficient form — the block pass is bound by VALU issue, not by latency, and the
+// extra exchange costs more than the occupancy returns.
+template <class A, int LOGB>
+constexpr bool use_block8() {
+#ifdef PFHE_BLOCK8
+    return !A::kPacked && LOGB == kTwoPassBlockLog;
+#else
+    return false;
+#endif
+}
+
 template <class A, int LOGB, bool INV, bool MUL = false>
 int launch_block(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys, bool lazy, hipStream_t s,
                  const u64 *mul = nullptr, u64 mul_polys = 0) {
-    using Cfg = BlockCfg<LOGB>;
+    constexpr int LOGE = use_block8<A, LOGB>() ? 3 : 4;
+    using Cfg = BlockCfg<LOGB, LOGE>;
     const u64 total_blocks = npolys << (log_n - LOGB);
     const u64 grid = (total_blocks + Cfg::BPW - 1) / Cfg::BPW;
     if (grid == 0) return PFHE_OK;
@@ -271,7 +301,9 @@ int launch_block(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys
         return PFHE_ERR_BAD_LENGTH;
     }
     constexpr size_t lds_bytes = (size_t)Cfg::BPW * Cfg::LDS_WORDS * sizeof(u64);
-    auto kern = ntt_block_kernel<A, LOGB, INV, MUL>;
+    void (*kern)(u64 *, const NttPrime *, u32, u32, u64, u32, const u64 *, u64);
+    if constexpr (LOGE == 3) kern = ntt_block8_kernel<A, LOGB, INV, MUL>;
+    else kern = ntt_block_kernel<A, LOGB, INV, MUL>;
     if (lds_bytes > 64 * 1024) {
         static thread_local bool configured[64] = {};
         int dev = 0;

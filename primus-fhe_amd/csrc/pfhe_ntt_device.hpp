@@ -553,11 +553,18 @@ __device__ __forceinline__ void strided_inverse_regs(const A &ar, u64 (&x)[1 << 
     }
 }
 
-template <int LOGB>
+// A block pass owns blocks of B = 2^LOGB coefficients; every thread keeps E = 2^LOGE of them in registers and runs LOGE
+// radix-2 stages per register pass.  LOGE = 4 (16 coefficients, 4 stages) is the general form; LOGE = 3 halves the
+// registers a thread needs and doubles the threads per block: more resident waves per SIMD to hide the LDS / twiddle /
+// barrier latencies behind, at the price of one more exchange per 12 stages.
+template <int LOGB, int LOGE = 4>
 struct BlockCfg {
     static_assert(LOGB >= 4 && LOGB <= 14, "block pass handles 2^4 .. 2^14 coefficients");
+    static_assert(LOGE == 3 || LOGE == 4, "8 or 16 coefficients per thread");
     static constexpr int B = 1 << LOGB;
-    static constexpr int TPB = B / 16;                     // threads per block of coefficients
+    static constexpr int E = 1 << LOGE;                    // coefficients per thread
+    static constexpr int TPB = B >> LOGE;                  // threads per block of coefficients
+    static_assert(TPB <= 1024, "a block must fit one workgroup");
 // smallest workgroup: one wave.  Small workgroups put more independent workgroups on a CU (LDS is
 // what limits residency), which overlaps their load / compute / store phases better: measured
 // +2..9 % for N = 2^8..2^11 against 256-thread workgroups (tools/build_variant.sh -DPFHE_MIN_WG=256).
@@ -573,13 +580,13 @@ struct BlockCfg {
 // keeps 16-byte alignment and de-phases the 128-byte rows read by the pos = 0 register pass.
 __device__ __forceinline__ u32 lds_phi(u32 e) { return e + ((e >> 4) << 1); }
 
-// block-local element index of register k of thread lt when register bits sit at [POS+3 : POS]
-template <int POS>
+// block-local element index of register k of thread lt when register bits sit at [POS+LOGE-1 : POS]
+template <int POS, int LOGE = 4>
 __device__ __forceinline__ u32 layout(u32 lt, int k) {
     if constexpr (POS == 0) {
-        return (lt << 4) | (u32)k;
+        return (lt << LOGE) | (u32)k;
     } else {
-        return ((lt >> POS) << (POS + 4)) | ((u32)k << POS) | (lt & ((1u << POS) - 1));
+        return ((lt >> POS) << (POS + LOGE)) | ((u32)k << POS) | (lt & ((1u << POS) - 1));
     }
 }
 
@@ -592,77 +599,59 @@ __device__ __forceinline__ u32 maybe_uniform(u32 v) {
     }
 }
 
-// chunks of a forward register pass in execution order (software-pipelined twiddle loads): stage JHI, JHI-1, ... as
-// wholes, the 8-twiddle stage 0 (when it is part of the pass) as two halves
-__host__ __device__ constexpr int fwd_chunk_j(int c, int jhi, int jlo) { return (jlo == 0 && c >= jhi) ? 0 : jhi - c; }
-__host__ __device__ constexpr int fwd_chunk_u0(int c, int jhi, int jlo) { return (jlo == 0 && c >= jhi) ? (c - jhi) * 4 : 0; }
-__host__ __device__ constexpr int fwd_chunk_u1(int c, int jhi, int jlo) {
-    return (jlo == 0 && c >= jhi) ? (c - jhi) * 4 + 4 : (16 >> (fwd_chunk_j(c, jhi, jlo) + 1));
+// Entry of the lane-ordered tables (NttPrime::fwd_last / inv_last, built for groups of 16 coefficients) for the stage at
+// distance 2^j, twiddle u of the thread whose first coefficient is element e0 (a multiple of 2^LOGE): the group of 16 is
+// g16 = e0 >> 4, and a thread of 8 coefficients owns half of its twiddles (h = bit 3 of e0 selects which).
+template <int LOGE>
+__device__ __forceinline__ u32 last_table_off(u32 n, u32 e0, int j, int u) {
+    constexpr int S = 4 - LOGE;
+    const u32 g = e0 >> LOGE, h = g & ((1u << S) - 1), g16 = g >> S;
+    const u32 uu = (h << (LOGE - 1 - j)) + (u32)u;
+    return (((8u >> j) - 1) + uu) * (n >> 4) + g16;
 }
 
 // forward stages on register bits JHI..JLO (element bits POS+JHI .. POS+JLO); twiddle of the
 // butterfly at global element E, distance 2^p: fwd[(N + E) >> (p + 1)]
-template <class A, int POS, int JHI, int JLO, bool UNIFORM>
-__device__ __forceinline__ void fwd_regpass(const A &ar, u64 (&x)[16], u32 n_plus_e, u32 n) {
+template <class A, int POS, int JHI, int JLO, bool UNIFORM, int LOGE = 4>
+__device__ __forceinline__ void fwd_regpass(const A &ar, u64 (&x)[1 << LOGE], u32 n_plus_e, u32 n) {
+    constexpr int E = 1 << LOGE;
 #pragma unroll
     for (int j = JHI; j >= JLO; --j) {
         const u32 base = maybe_uniform<POS, UNIFORM>(n_plus_e >> (POS + j + 1));
-        // POS == 0: every lane has twiddles of its own; the lane-ordered tables make the wave's loads contiguous
-        const u32 last_off = (((8u >> j) - 1) * (n >> 4)) + ((n_plus_e - n) >> 4);
         constexpr bool kUni = UNIFORM && POS >= 6;  // maybe_uniform: the twiddle sits in scalar registers
-        typename A::Tw w[8];
+        typename A::Tw w[E / 2];
+        // POS == 0: every lane has twiddles of its own; the lane-ordered tables make the wave's loads contiguous
         const auto load_tw = [&](int u) {
-            if constexpr (POS == 0 && A::kLastTables) w[u] = ar.fwd_tw_last(last_off + (u32)u * (n >> 4));
+            if constexpr (POS == 0 && A::kLastTables) w[u] = ar.fwd_tw_last(last_table_off<LOGE>(n, n_plus_e - n, j, u));
             else w[u] = ar.fwd_tw(base + u);
         };
+        const int ntw = E >> (j + 1);  // twiddles of this stage
 #if !defined(PFHE_NO_ASM_BFLY_PAIRS) && !defined(PFHE_NO_ASM_BFLY)
         if constexpr (A::kWide) {
             // two butterflies per asm block (independent instruction streams interleaved): butterfly b of the stage
-            // has u = b >> j, v = b & (2^j - 1)
-            if constexpr (kUni) {
+            // has u = b >> j, v = b & (2^j - 1).  Per-lane twiddles (four registers each) are loaded at most four at a
+            // time: the eight of the last stage of a 16-coefficient thread at once cost 32 registers at the tightest
+            // point of the kernel.
+            const int group = (kUni || ntw <= 4) ? ntw : 4;
 #pragma unroll
-                for (int u = 0; u < (16 >> (j + 1)); ++u) load_tw(u);
+            for (int u0 = 0; u0 < ntw; u0 += group) {
 #pragma unroll
-                for (int b = 0; b < 8; b += 2) {
+                for (int u = u0; u < u0 + group; ++u) load_tw(u);
+#pragma unroll
+                for (int b = u0 << j; b < ((u0 + group) << j); b += 2) {
                     const int ua = b >> j, va = b & ((1 << j) - 1), ub = (b + 1) >> j, vb = (b + 1) & ((1 << j) - 1);
                     const int a0 = (ua << (j + 1)) | va, a1 = a0 | (1 << j), b0 = (ub << (j + 1)) | vb, b1 = b0 | (1 << j);
-                    if ((POS + j) & 1) pm_fwd_bfly2<true, true>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
-                    else pm_fwd_bfly2<false, true>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
+                    if ((POS + j) & 1) pm_fwd_bfly2<true, kUni>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
+                    else pm_fwd_bfly2<false, kUni>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
                 }
             }
-#ifndef PFHE_PIPELINED_TWIDDLES
-            else {
-                if (j == 0) {  // the eight twiddles of the last stage in two halves (32 registers at once otherwise)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                        for (int u = 4 * h; u < 4 * h + 4; ++u) load_tw(u);
-#pragma unroll
-                        for (int b = 4 * h; b < 4 * h + 4; b += 2) {
-                            if ((POS + j) & 1) pm_fwd_bfly2<true, false>(ar, x[2 * b], x[2 * b + 1], w[b], x[2 * b + 2], x[2 * b + 3], w[b + 1]);
-                            else pm_fwd_bfly2<false, false>(ar, x[2 * b], x[2 * b + 1], w[b], x[2 * b + 2], x[2 * b + 3], w[b + 1]);
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < (16 >> (j + 1)); ++u) load_tw(u);
-#pragma unroll
-                    for (int b = 0; b < 8; b += 2) {
-                        const int ua = b >> j, va = b & ((1 << j) - 1), ub = (b + 1) >> j, vb = (b + 1) & ((1 << j) - 1);
-                        const int a0 = (ua << (j + 1)) | va, a1 = a0 | (1 << j), b0 = (ub << (j + 1)) | vb, b1 = b0 | (1 << j);
-                        if ((POS + j) & 1) pm_fwd_bfly2<true, false>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
-                        else pm_fwd_bfly2<false, false>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
-                    }
-                }
-            }
-#endif
-            continue;  // (PFHE_PIPELINED_TWIDDLES: per-lane twiddles take the software-pipelined form below the loop)
+            continue;
         }
 #endif
 #pragma unroll
-        for (int u = 0; u < (16 >> (j + 1)); ++u) load_tw(u);
+        for (int u = 0; u < ntw; ++u) load_tw(u);
 #pragma unroll
-        for (int u = 0; u < (16 >> (j + 1)); ++u) {
+        for (int u = 0; u < ntw; ++u) {
 #pragma unroll
             for (int v = 0; v < (1 << j); ++v) {
                 const int k0 = (u << (j + 1)) | v, k1 = k0 | (1 << j);
@@ -671,72 +660,34 @@ __device__ __forceinline__ void fwd_regpass(const A &ar, u64 (&x)[16], u32 n_plu
             }
         }
     }
-#if !defined(PFHE_NO_ASM_BFLY_PAIRS) && !defined(PFHE_NO_ASM_BFLY) && defined(PFHE_PIPELINED_TWIDDLES)
-    if constexpr (A::kWide && !(UNIFORM && POS >= 6)) {
-        // Per-lane twiddles (vector registers, four per twiddle).  Left alone the compiler issues all fifteen loads of
-        // the pass up front: 60 registers.  Here the loads of the NEXT chunk (a stage, or half of the 8-twiddle last
-        // stage) are issued just before the butterflies of the current one and scheduling barriers keep them
-        // there: at most 8 twiddles are live, which lets the block pass fit 96 registers (five waves per SIMD: four of
-        // its own and one of the streaming pass beside it).
-        typename A::Tw tw[4][8];
-        const auto load_chunk = [&](int j, int u0, int u1) {
-            const u32 base = n_plus_e >> (POS + j + 1);
-            const u32 last_off = (((8u >> j) - 1) * (n >> 4)) + ((n_plus_e - n) >> 4);
-#pragma unroll
-            for (int u = u0; u < u1; ++u) {
-                if constexpr (POS == 0 && A::kLastTables) tw[j][u] = ar.fwd_tw_last(last_off + (u32)u * (n >> 4));
-                else tw[j][u] = ar.fwd_tw(base + u);
-            }
-        };
-        const auto run_chunk = [&](int j, int u0, int u1) {
-#pragma unroll
-            for (int b = u0 << j; b < (u1 << j); b += 2) {
-                const int ua = b >> j, va = b & ((1 << j) - 1), ub = (b + 1) >> j, vb = (b + 1) & ((1 << j) - 1);
-                const int a0 = (ua << (j + 1)) | va, a1 = a0 | (1 << j), b0 = (ub << (j + 1)) | vb, b1 = b0 | (1 << j);
-                if ((POS + j) & 1) pm_fwd_bfly2<true, false>(ar, x[a0], x[a1], tw[j][ua], x[b0], x[b1], tw[j][ub]);
-                else pm_fwd_bfly2<false, false>(ar, x[a0], x[a1], tw[j][ua], x[b0], x[b1], tw[j][ub]);
-            }
-        };
-        // chunks in execution order: stage j as a whole, the last stage (j == 0) in two halves
-        constexpr int kChunks = (JHI - JLO + 1) + (JLO == 0 ? 1 : 0);
-        load_chunk(fwd_chunk_j(0, JHI, JLO), fwd_chunk_u0(0, JHI, JLO), fwd_chunk_u1(0, JHI, JLO));
-#pragma unroll
-        for (int c = 0; c < kChunks; ++c) {
-            if (c + 1 < kChunks)
-                load_chunk(fwd_chunk_j(c + 1, JHI, JLO), fwd_chunk_u0(c + 1, JHI, JLO), fwd_chunk_u1(c + 1, JHI, JLO));
-            __builtin_amdgcn_sched_barrier(0);
-            run_chunk(fwd_chunk_j(c, JHI, JLO), fwd_chunk_u0(c, JHI, JLO), fwd_chunk_u1(c, JHI, JLO));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-#endif
 }
 
 // inverse stages on register bits JLO..JHI: inv[1 + N - (N >> p) + (E >> (p + 1))]; when
 // `final_stage` the top stage (j == JHI) is the last stage of the whole transform.
-template <class A, int POS, int JLO, int JHI, bool UNIFORM>
-__device__ __forceinline__ void inv_regpass(const A &ar, u64 (&x)[16], u32 n, u32 e_abs, bool final_stage,
+template <class A, int POS, int JLO, int JHI, bool UNIFORM, int LOGE = 4>
+__device__ __forceinline__ void inv_regpass(const A &ar, u64 (&x)[1 << LOGE], u32 n, u32 e_abs, bool final_stage,
                                             bool lazy) {
+    constexpr int E = 1 << LOGE;
 #pragma unroll
     for (int j = JLO; j <= JHI; ++j) {
         const u32 p = POS + j;
         if (j == JHI && final_stage) {
 #pragma unroll
-            for (int v = 0; v < 8; ++v) inv_final_bfly(ar, x[v], x[v | 8], lazy);
+            for (int v = 0; v < E / 2; ++v) inv_final_bfly(ar, x[v], x[v | (E / 2)], lazy);
         } else {
             const u32 base = maybe_uniform<POS, UNIFORM>(1 + n - (n >> p) + (e_abs >> (p + 1)));
-            const u32 last_off = (((8u >> j) - 1) * (n >> 4)) + (e_abs >> 4);  // POS == 0: lane-ordered tables
             constexpr bool kUni = UNIFORM && POS >= 6;
-            typename A::Tw w[8];
+            typename A::Tw w[E / 2];
+            const int ntw = E >> (j + 1);
 #pragma unroll
-            for (int u = 0; u < (16 >> (j + 1)); ++u) {
-                if constexpr (POS == 0 && A::kLastTables) w[u] = ar.inv_tw_last(last_off + (u32)u * (n >> 4));
+            for (int u = 0; u < ntw; ++u) {
+                if constexpr (POS == 0 && A::kLastTables) w[u] = ar.inv_tw_last(last_table_off<LOGE>(n, e_abs, j, u));  // lane-ordered
                 else w[u] = ar.inv_tw(base + u);
             }
 #if !defined(PFHE_NO_ASM_BFLY_PAIRS) && !defined(PFHE_NO_ASM_BFLY)
             if constexpr (A::kWide) {  // two butterflies per asm block, as in fwd_regpass
 #pragma unroll
-                for (int b = 0; b < 8; b += 2) {
+                for (int b = 0; b < E / 2; b += 2) {
                     const int ua = b >> j, va = b & ((1 << j) - 1), ub = (b + 1) >> j, vb = (b + 1) & ((1 << j) - 1);
                     const int a0 = (ua << (j + 1)) | va, a1 = a0 | (1 << j), b0 = (ub << (j + 1)) | vb, b1 = b0 | (1 << j);
                     pm_inv_bfly2<kUni>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
@@ -745,7 +696,7 @@ __device__ __forceinline__ void inv_regpass(const A &ar, u64 (&x)[16], u32 n, u3
             }
 #endif
 #pragma unroll
-            for (int u = 0; u < (16 >> (j + 1)); ++u) {
+            for (int u = 0; u < ntw; ++u) {
 #pragma unroll
                 for (int v = 0; v < (1 << j); ++v) {
                     const int k0 = (u << (j + 1)) | v, k1 = k0 | (1 << j);
@@ -765,18 +716,18 @@ __host__ __device__ constexpr u32 lds_koff(int k) {
     return ((u32)k << POS) + 2u * (((u32)k << POS) >> 4);
 }
 
-template <int POS>
-__device__ __forceinline__ void lds_get_layout(u64 (&x)[16], const u64 *__restrict__ lds, u32 lt) {
-    const u64 *__restrict__ base = lds + lds_phi(layout<POS>(lt, 0));
+template <int POS, int LOGE = 4>
+__device__ __forceinline__ void lds_get_layout(u64 (&x)[1 << LOGE], const u64 *__restrict__ lds, u32 lt) {
+    const u64 *__restrict__ base = lds + lds_phi(layout<POS, LOGE>(lt, 0));
 #pragma unroll
-    for (int k = 0; k < 16; ++k) x[k] = base[lds_koff<POS>(k)];
+    for (int k = 0; k < (1 << LOGE); ++k) x[k] = base[lds_koff<POS>(k)];
 }
 
-template <int POS>
-__device__ __forceinline__ void lds_put_layout(const u64 (&x)[16], u64 *__restrict__ lds, u32 lt) {
-    u64 *__restrict__ base = lds + lds_phi(layout<POS>(lt, 0));
+template <int POS, int LOGE = 4>
+__device__ __forceinline__ void lds_put_layout(const u64 (&x)[1 << LOGE], u64 *__restrict__ lds, u32 lt) {
+    u64 *__restrict__ base = lds + lds_phi(layout<POS, LOGE>(lt, 0));
 #pragma unroll
-    for (int k = 0; k < 16; ++k) base[lds_koff<POS>(k)] = x[k];
+    for (int k = 0; k < (1 << LOGE); ++k) base[lds_koff<POS>(k)] = x[k];
 }
 
 // registers (layout FROM) -> LDS -> registers (layout TO).
@@ -786,15 +737,15 @@ __device__ __forceinline__ void lds_put_layout(const u64 (&x)[16], u64 *__restri
 // The threads that trade words in one exchange have ids inside one aligned block of 2^max(FROM, TO) threads; up to
 // 2^6 that is a single wave, whose LDS accesses execute in program order: no workgroup barrier between the
 // writes and the reads either (PFHE_NO_WAVE_LOCAL_EXCHANGE restores both barriers everywhere).
-template <int FROM, int TO, bool FIRST>
-__device__ __forceinline__ void lds_exchange(u64 (&x)[16], u64 *__restrict__ lds, u32 lt) {
+template <int FROM, int TO, bool FIRST, int LOGE = 4>
+__device__ __forceinline__ void lds_exchange(u64 (&x)[1 << LOGE], u64 *__restrict__ lds, u32 lt) {
 #ifdef PFHE_NO_WAVE_LOCAL_EXCHANGE
     constexpr bool kLead = true, kWaveLocal = false;
 #else
     constexpr bool kLead = FIRST, kWaveLocal = (FROM > TO ? FROM : TO) <= 6;
 #endif
     if constexpr (kLead) __syncthreads();
-    lds_put_layout<FROM>(x, lds, lt);
+    lds_put_layout<FROM, LOGE>(x, lds, lt);
     if constexpr (kWaveLocal) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -802,132 +753,134 @@ __device__ __forceinline__ void lds_exchange(u64 (&x)[16], u64 *__restrict__ lds
     } else {
         __syncthreads();
     }
-    lds_get_layout<TO>(x, lds, lt);
+    lds_get_layout<TO, LOGE>(x, lds, lt);
 }
 
-template <class A, int LOGB, int POS, bool FIRST = false>
-__device__ __forceinline__ void fwd_chain(const A &ar, u64 (&x)[16], u64 *__restrict__ lds, u32 n, u32 eblk, u32 lt) {
-    constexpr bool UNI = BlockCfg<LOGB>::TPB >= 64;  // a wave never straddles two blocks
+template <class A, int LOGB, int POS, bool FIRST = false, int LOGE = 4>
+__device__ __forceinline__ void fwd_chain(const A &ar, u64 (&x)[1 << LOGE], u64 *__restrict__ lds, u32 n, u32 eblk, u32 lt) {
+    constexpr bool UNI = BlockCfg<LOGB, LOGE>::TPB >= 64;  // a wave never straddles two blocks
     if constexpr (POS > 0) {
-        constexpr int NPOS = POS >= 4 ? POS - 4 : 0;
-        constexpr int JHI = POS >= 4 ? 3 : POS - 1;
-        lds_exchange<POS, NPOS, FIRST>(x, lds, lt);
+        constexpr int NPOS = POS >= LOGE ? POS - LOGE : 0;
+        constexpr int JHI = POS >= LOGE ? LOGE - 1 : POS - 1;
+        lds_exchange<POS, NPOS, FIRST, LOGE>(x, lds, lt);
 #ifdef PFHE_STAMPS
         PFHE_STAMP(NPOS == 0 ? 6 : 4);
 #endif
-        fwd_regpass<A, NPOS, JHI, 0, UNI>(ar, x, n + eblk + layout<NPOS>(lt, 0), n);
+        fwd_regpass<A, NPOS, JHI, 0, UNI, LOGE>(ar, x, n + eblk + layout<NPOS, LOGE>(lt, 0), n);
 #ifdef PFHE_STAMPS
         PFHE_STAMP(NPOS == 0 ? 7 : 5);
 #endif
-        fwd_chain<A, LOGB, NPOS>(ar, x, lds, n, eblk, lt);
+        fwd_chain<A, LOGB, NPOS, false, LOGE>(ar, x, lds, n, eblk, lt);
     }
 }
 
-// forward compute core: x holds layout<LOGB-4> on entry and layout<0> (canonical unless lazy) on exit
-// LEAD = false: the caller filled x by lds_get_layout<LOGB-4> from this LDS region (so the first exchange, too,
+// forward compute core: x holds layout<LOGB-LOGE> on entry and layout<0> (canonical unless lazy) on exit
+// LEAD = false: the caller filled x by lds_get_layout<LOGB-LOGE> from this LDS region (so the first exchange, too,
 // only overwrites slots its own thread read last) and needs no barrier in front of it.
-template <class A, int LOGB, bool LEAD = true>
-__device__ __forceinline__ void block_forward_core(const A &ar, u64 (&x)[16], u64 *__restrict__ lds, u32 n,
+template <class A, int LOGB, bool LEAD = true, int LOGE = 4>
+__device__ __forceinline__ void block_forward_core(const A &ar, u64 (&x)[1 << LOGE], u64 *__restrict__ lds, u32 n,
                                                    u32 eblk, u32 lt, bool lazy) {
-    constexpr int POS0 = LOGB - 4;
-    constexpr bool UNI = BlockCfg<LOGB>::TPB >= 64;  // a wave never straddles two blocks
-    fwd_regpass<A, POS0, 3, 0, UNI>(ar, x, n + eblk + layout<POS0>(lt, 0), n);
+    constexpr int POS0 = LOGB - LOGE, E = 1 << LOGE;
+    constexpr bool UNI = BlockCfg<LOGB, LOGE>::TPB >= 64;  // a wave never straddles two blocks
+    fwd_regpass<A, POS0, LOGE - 1, 0, UNI, LOGE>(ar, x, n + eblk + layout<POS0, LOGE>(lt, 0), n);
 #ifdef PFHE_STAMPS
     PFHE_STAMP(3);
 #endif
-    fwd_chain<A, LOGB, POS0, LEAD>(ar, x, lds, n, eblk, lt);
+    fwd_chain<A, LOGB, POS0, LEAD, LOGE>(ar, x, lds, n, eblk, lt);
     if constexpr (A::kPacked) {  // distance-1 stage between the halves of each word
 #pragma unroll
-        for (int k = 0; k < 16; ++k) x[k] = ar.fwd_intra(x[k], n + eblk + layout<0>(lt, k));
+        for (int k = 0; k < E; ++k) x[k] = ar.fwd_intra(x[k], n + eblk + layout<0, LOGE>(lt, k));
     }
     if constexpr (A::kWide) {
 #if !defined(PFHE_NO_ASM_BFLY)
         if (!lazy) {  // one uniform branch for the whole thread, two elements per asm block
 #pragma unroll
-            for (int k = 0; k < 16; k += 2) pm_canon2(ar, x[k], x[k + 1]);
+            for (int k = 0; k < E; k += 2) pm_canon2(ar, x[k], x[k + 1]);
         } else
 #endif
         {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) x[k] = fwd_finish(ar, x[k], lazy);
+            for (int k = 0; k < E; ++k) x[k] = fwd_finish(ar, x[k], lazy);
         }
     } else if (!lazy) {  // [0,4q) -> [0,q): scalar/transform.rs:104-116
 #pragma unroll
-        for (int k = 0; k < 16; ++k) x[k] = ar.reduce_4q(x[k]);
+        for (int k = 0; k < E; ++k) x[k] = ar.reduce_4q(x[k]);
     }
 }
 
-template <class A, int LOGB, int POS, bool FIRST = false>
-__device__ __forceinline__ void inv_chain(const A &ar, u64 (&x)[16], u64 *__restrict__ lds, u32 n, u32 eblk, u32 lt,
+template <class A, int LOGB, int POS, bool FIRST = false, int LOGE = 4>
+__device__ __forceinline__ void inv_chain(const A &ar, u64 (&x)[1 << LOGE], u64 *__restrict__ lds, u32 n, u32 eblk, u32 lt,
                                           bool final_block, bool lazy) {
-    constexpr bool UNI = BlockCfg<LOGB>::TPB >= 64;  // a wave never straddles two blocks
-    constexpr int DONE = POS + 4;  // element bits already processed
+    constexpr bool UNI = BlockCfg<LOGB, LOGE>::TPB >= 64;  // a wave never straddles two blocks
+    constexpr int DONE = POS + LOGE;  // element bits already processed
     if constexpr (DONE < LOGB) {
-        constexpr int NPOS = DONE <= LOGB - 4 ? DONE : LOGB - 4;
+        constexpr int NPOS = DONE <= LOGB - LOGE ? DONE : LOGB - LOGE;
         constexpr int JLO = DONE - NPOS;
-        constexpr bool LAST = NPOS + 4 >= LOGB;
-        lds_exchange<POS, NPOS, FIRST>(x, lds, lt);
-        inv_regpass<A, NPOS, JLO, 3, UNI>(ar, x, n, eblk + layout<NPOS>(lt, 0), LAST && final_block, lazy);
-        inv_chain<A, LOGB, NPOS>(ar, x, lds, n, eblk, lt, final_block, lazy);
+        constexpr bool LAST = NPOS + LOGE >= LOGB;
+        lds_exchange<POS, NPOS, FIRST, LOGE>(x, lds, lt);
+        inv_regpass<A, NPOS, JLO, LOGE - 1, UNI, LOGE>(ar, x, n, eblk + layout<NPOS, LOGE>(lt, 0), LAST && final_block, lazy);
+        inv_chain<A, LOGB, NPOS, false, LOGE>(ar, x, lds, n, eblk, lt, final_block, lazy);
     }
 }
 
-// inverse compute core: x holds layout<0> on entry and layout<LOGB-4> on exit
-template <class A, int LOGB, bool LEAD = true>
-__device__ __forceinline__ void block_inverse_core(const A &ar, u64 (&x)[16], u64 *__restrict__ lds, u32 n,
+// inverse compute core: x holds layout<0> on entry and layout<LOGB-LOGE> on exit
+template <class A, int LOGB, bool LEAD = true, int LOGE = 4>
+__device__ __forceinline__ void block_inverse_core(const A &ar, u64 (&x)[1 << LOGE], u64 *__restrict__ lds, u32 n,
                                                    u32 eblk, u32 lt, bool final_block, bool lazy) {
-    constexpr bool UNI = BlockCfg<LOGB>::TPB >= 64;  // a wave never straddles two blocks
+    constexpr bool UNI = BlockCfg<LOGB, LOGE>::TPB >= 64;  // a wave never straddles two blocks
     if constexpr (A::kPacked) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) x[k] = ar.inv_intra(x[k], n, eblk + layout<0>(lt, k));
+        for (int k = 0; k < (1 << LOGE); ++k) x[k] = ar.inv_intra(x[k], n, eblk + layout<0, LOGE>(lt, k));
     }
-    inv_regpass<A, 0, 0, 3, UNI>(ar, x, n, eblk + layout<0>(lt, 0), LOGB == 4 && final_block, lazy);
-    inv_chain<A, LOGB, 0, LEAD>(ar, x, lds, n, eblk, lt, final_block, lazy);
+    inv_regpass<A, 0, 0, LOGE - 1, UNI, LOGE>(ar, x, n, eblk + layout<0, LOGE>(lt, 0), LOGB == LOGE && final_block, lazy);
+    inv_chain<A, LOGB, 0, LEAD, LOGE>(ar, x, lds, n, eblk, lt, final_block, lazy);
 }
 
-// ---- coalesced block I/O: 8 x 16-byte vectors per thread in natural order (vector v = elements
+// ---- coalesced block I/O: E/2 16-byte vectors per thread in natural order (vector v = elements
 //      2v, 2v+1), one full KiB per wave instruction, staged through LDS ----
-template <int LOGB>
-__device__ __forceinline__ void load_block_vectors(u64x2 (&v)[8], const u64 *gptr, u32 lt) {
+template <int LOGB, int LOGE = 4>
+__device__ __forceinline__ void load_block_vectors(u64x2 (&v)[1 << (LOGE - 1)], const u64 *gptr, u32 lt) {
     const GCVec2Ptr p = (GCVec2Ptr)(const void *)gptr;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = p[lt + BlockCfg<LOGB>::TPB * j];
+    for (int j = 0; j < (1 << (LOGE - 1)); ++j) v[j] = p[lt + BlockCfg<LOGB, LOGE>::TPB * j];
 }
 
-template <int LOGB>
-__device__ __forceinline__ void store_block_vectors(const u64x2 (&v)[8], u64 *gptr, u32 lt) {
+template <int LOGB, int LOGE = 4>
+__device__ __forceinline__ void store_block_vectors(const u64x2 (&v)[1 << (LOGE - 1)], u64 *gptr, u32 lt) {
     const GVec2Ptr p = (GVec2Ptr)(void *)gptr;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) p[lt + BlockCfg<LOGB>::TPB * j] = v[j];
+    for (int j = 0; j < (1 << (LOGE - 1)); ++j) p[lt + BlockCfg<LOGB, LOGE>::TPB * j] = v[j];
 }
 
 // vector v = lt + TPB*j holds elements 2v, 2v+1: padded index = lds_phi(2*lt) + constant(j) once 2*TPB is a multiple of 16
-template <int LOGB>
+template <int LOGB, int LOGE = 4>
 __host__ __device__ constexpr u32 lds_voff(int j) {
-    return 2u * BlockCfg<LOGB>::TPB * (u32)j + 2u * ((2u * BlockCfg<LOGB>::TPB * (u32)j) >> 4);
+    return 2u * BlockCfg<LOGB, LOGE>::TPB * (u32)j + 2u * ((2u * BlockCfg<LOGB, LOGE>::TPB * (u32)j) >> 4);
 }
 
-template <int LOGB>
-__device__ __forceinline__ void lds_put_vectors(const u64x2 (&v)[8], u64 *__restrict__ lds, u32 lt) {
-    if constexpr (BlockCfg<LOGB>::TPB >= 8) {
+template <int LOGB, int LOGE = 4>
+__device__ __forceinline__ void lds_put_vectors(const u64x2 (&v)[1 << (LOGE - 1)], u64 *__restrict__ lds, u32 lt) {
+    constexpr int NV = 1 << (LOGE - 1), TPB = BlockCfg<LOGB, LOGE>::TPB;
+    if constexpr (TPB >= 8) {
         u64 *__restrict__ base = lds + lds_phi(2 * lt);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) *reinterpret_cast<u64x2 *>(base + lds_voff<LOGB>(j)) = v[j];
+        for (int j = 0; j < NV; ++j) *reinterpret_cast<u64x2 *>(base + lds_voff<LOGB, LOGE>(j)) = v[j];
     } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) *reinterpret_cast<u64x2 *>(lds + lds_phi(2 * (lt + BlockCfg<LOGB>::TPB * j))) = v[j];
+        for (int j = 0; j < NV; ++j) *reinterpret_cast<u64x2 *>(lds + lds_phi(2 * (lt + TPB * j))) = v[j];
     }
 }
 
-template <int LOGB>
-__device__ __forceinline__ void lds_get_vectors(u64x2 (&v)[8], const u64 *__restrict__ lds, u32 lt) {
-    if constexpr (BlockCfg<LOGB>::TPB >= 8) {
+template <int LOGB, int LOGE = 4>
+__device__ __forceinline__ void lds_get_vectors(u64x2 (&v)[1 << (LOGE - 1)], const u64 *__restrict__ lds, u32 lt) {
+    constexpr int NV = 1 << (LOGE - 1), TPB = BlockCfg<LOGB, LOGE>::TPB;
+    if constexpr (TPB >= 8) {
         const u64 *__restrict__ base = lds + lds_phi(2 * lt);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const u64x2 *>(base + lds_voff<LOGB>(j));
+        for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const u64x2 *>(base + lds_voff<LOGB, LOGE>(j));
     } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const u64x2 *>(lds + lds_phi(2 * (lt + BlockCfg<LOGB>::TPB * j)));
+        for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const u64x2 *>(lds + lds_phi(2 * (lt + TPB * j)));
     }
 }
 
