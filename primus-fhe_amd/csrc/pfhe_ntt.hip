@@ -131,13 +131,16 @@ __device__ __forceinline__ void strided_pass_body(u64 *__restrict__ data, const 
     }
 }
 
-// 128 registers at most: a SIMD's 512 then hold three block-pass waves (128 each) AND one wave of this kernel, which is
-// what lets the two-stream transform overlap the streaming pass with the computing one (at 136 the mix did not fit)
-// VEC == 1 is the LIGHT form (at most 96 registers): PFHE_LIGHT_STRIDED selects it for the strided pass that runs
-// beside a block pass in the two-stream transform.  Measured: no gain (5.41 vs 5.37 ms per step) — it only fits next to
-// four block-pass waves when those are squeezed to 96 registers, which costs the block pass more than the overlap returns.
+// Register budget: left to the compiler (134-136 registers for the two-column form, three waves per SIMD).  Capping
+// it at 128 so that a wave fits beside three block-pass waves costs 4-16 spilled registers, i.e. scratch traffic on an
+// HBM-bound kernel (6.34 / 7.5 GiB moved per 6 GiB launch, forward / inverse): 2.17 -> 2.22 ms and 2.18 -> 2.31 ms, for
+// no better overlap.  VEC == 1 is the LIGHT form (at most 96 registers) that PFHE_LIGHT_STRIDED selects for the strided
+// pass running beside a block pass in the two-stream transform; measured: no gain (5.41 vs 5.37 ms per step).
+#ifndef PFHE_STRIDED_MIN_WAVES
+#define PFHE_STRIDED_MIN_WAVES 1
+#endif
 template <class A, int K, int VEC, bool INV, bool FINAL>
-__global__ __launch_bounds__(256, K <= 4 ? (VEC == 1 ? 5 : 4) : 1) void ntt_strided_kernel(u64 *__restrict__ data,
+__global__ __launch_bounds__(256, K <= 4 ? (VEC == 1 ? 5 : PFHE_STRIDED_MIN_WAVES) : 1) void ntt_strided_kernel(u64 *__restrict__ data,
                                                           const NttPrime *__restrict__ primes, u32 L,
                                                           u32 log_n, u32 log_s, u64 total_threads, u32 lazy) {
     strided_pass_body<A, K, VEC, INV, FINAL>(data, primes, L, log_n, log_s, (u64)blockIdx.x * blockDim.x + threadIdx.x,
