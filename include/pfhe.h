@@ -367,7 +367,9 @@ typedef struct pfhe_extprod_plan pfhe_extprod_plan;
  * &mut DcrtGlevContext) — glwe/crt.rs:200-212, context/glev.rs:4-68.  The plan borrows `table`
  * (which must outlive it) and owns device scratch for `chunk` ciphertexts (0 = default: about 1 GiB of digit polynomials
  * per buffer, at least 64 and at most 65536 ciphertexts):
- * one buffer of chunk*(k+1)*ell*L*N words (+ chunk*(k+1)*ell*N int32).  Like `&mut DcrtGlevContext` it must not be used concurrently. */
+ * one buffer of chunk*(k+1)*ell*L*N words (+ chunk*(k+1)*ell*N int32).  Like `&mut DcrtGlevContext` it must not be used concurrently —
+ * and it is bound to ONE stream at a time: calls on two different streams share the digit buffers with no cross-stream
+ * dependency, so let the first stream finish (or record / wait an event) before using the plan on another. */
 int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *base, const pfhe_basis *basis,
                              size_t glwe_dimension, size_t chunk, pfhe_extprod_plan **out);
 void pfhe_extprod_plan_destroy(pfhe_extprod_plan *plan);

@@ -394,9 +394,13 @@ int pfhe_dcrt_mul_monomial_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev,
         set_last_error("monomial degree must be below 2N");
         return PFHE_ERR_BAD_ARGUMENT;
     }
-    if (len && a_dev == out_dev) {
-        set_last_error("mul_monomial_to needs distinct buffers; use mul_monomial_assign for the in-place form");
-        return PFHE_ERR_BAD_ARGUMENT;
+    // the rotation reads in[(j - r) mod N] while other threads write out[j]: ANY overlap of the two ranges is a race
+    if (len) {
+        const uintptr_t a0 = (uintptr_t)a_dev, o0 = (uintptr_t)out_dev, bytes = (uintptr_t)len * sizeof(u64);
+        if (a0 < o0 + bytes && o0 < a0 + bytes) {
+            set_last_error("mul_monomial_to needs non-overlapping buffers; use mul_monomial_assign for the in-place form");
+            return PFHE_ERR_BAD_ARGUMENT;
+        }
     }
     return monomial_to(t, (const u64 *)a_dev, r, (u64 *)out_dev, len, (hipStream_t)stream);
     PFHE_GUARD_END

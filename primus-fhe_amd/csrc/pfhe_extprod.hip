@@ -38,8 +38,14 @@ __device__ __forceinline__ u64 mac(const BarrettMac &m, u64 acc, u64 d, u64 k) {
 #ifndef PFHE_MULACC_MIN_WG
 #define PFHE_MULACC_MIN_WG 2  // resident workgroups per CU the register allocation is sized for (tuning switch)
 #endif
-template <class A, int NC>
-__global__ __launch_bounds__(256, PFHE_MULACC_MIN_WG) void gadget_block_mulacc_kernel(const u64 *__restrict__ digits,
+// LOGE: 4 = 256 threads with 16 coefficients each, 3 = 512 threads with 8 each.  The accumulators (NC 64-bit words per
+// coefficient) live in registers for the whole loop over the terms: with 16 coefficients per thread they are 64 registers
+// on top of the transform's ~106 and only two workgroups (two waves per SIMD) fit a CU; with 8 they are 32 on top of ~80.
+#ifndef PFHE_MULACC8_MIN_WAVES
+#define PFHE_MULACC8_MIN_WAVES 4
+#endif
+template <class A, int NC, int LOGE = 4>
+__global__ __launch_bounds__(LOGE == 3 ? 512 : 256, LOGE == 3 ? PFHE_MULACC8_MIN_WAVES : PFHE_MULACC_MIN_WG) void gadget_block_mulacc_kernel(const u64 *__restrict__ digits,
                                                                   const u64 *__restrict__ ggsw, u64 ggsw_stride,
                                                                   u64 *__restrict__ result,
                                                                   const NttPrime *__restrict__ primes, u32 L, u32 log_n,
@@ -65,37 +71,38 @@ __global__ __launch_bounds__(256, PFHE_MULACC_MIN_WG) void gadget_block_mulacc_k
     const u64 *__restrict__ key = ggsw + e * ggsw_stride + limb_off;
     u64 *__restrict__ out = result + e * NC * W + limb_off;
 
-    u64x2 acc[NC][8];
+    constexpr int NV = 1 << (LOGE - 1);  // 16-byte vectors per thread
+    u64x2 acc[NC][NV];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         if (accumulate) {
-            load_block_vectors<LOGB>(acc[c], out + (u64)c * W, lt);
+            load_block_vectors<LOGB, LOGE>(acc[c], out + (u64)c * W, lt);
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[c][j] = u64x2{0, 0};
+            for (int j = 0; j < NV; ++j) acc[c][j] = u64x2{0, 0};
         }
     }
 
     for (u32 ij = 0; ij < terms; ++ij) {
-        u64x2 io[8];
-        load_block_vectors<LOGB>(io, dg + (u64)ij * W, lt);
+        u64x2 io[NV];
+        load_block_vectors<LOGB, LOGE>(io, dg + (u64)ij * W, lt);
         // (no barrier: these are the slots this thread read with lds_get_vectors at the end of the previous iteration)
-        lds_put_vectors<LOGB>(io, lds, lt);
+        lds_put_vectors<LOGB, LOGE>(io, lds, lt);
         __syncthreads();
-        u64 x[16];
-        lds_get_layout<LOGB - 4>(x, lds, lt);
+        u64 x[1 << LOGE];
+        lds_get_layout<LOGB - LOGE, LOGE>(x, lds, lt);
         // (no barrier in front of the first exchange or of the write-back: in both a thread overwrites exactly the
         // LDS slots it read last — pfhe_ntt_device.hpp, lds_exchange)
-        block_forward_core<A, LOGB, false>(ar, x, lds, n, eblk, lt, /*lazy=*/true);  // digit_hat mod~ q
-        lds_put_layout<0>(x, lds, lt);
+        block_forward_core<A, LOGB, false, LOGE>(ar, x, lds, n, eblk, lt, /*lazy=*/true);  // digit_hat mod~ q
+        lds_put_layout<0, LOGE>(x, lds, lt);
         __syncthreads();
-        lds_get_vectors<LOGB>(io, lds, lt);  // natural order again: same positions as the key vectors
+        lds_get_vectors<LOGB, LOGE>(io, lds, lt);  // natural order again: same positions as the key vectors
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            u64x2 kv[8];
-            load_block_vectors<LOGB>(kv, key + ((u64)ij * NC + c) * W, lt);
+            u64x2 kv[NV];
+            load_block_vectors<LOGB, LOGE>(kv, key + ((u64)ij * NC + c) * W, lt);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < NV; ++j) {
                 if constexpr (std::is_same<A, PmArith>::value) {
                     acc[c][j].x = mac(ar, acc[c][j].x, io[j].x, kv[j].x);
                     acc[c][j].y = mac(ar, acc[c][j].y, io[j].y, kv[j].y);
@@ -116,12 +123,12 @@ __global__ __launch_bounds__(256, PFHE_MULACC_MIN_WG) void gadget_block_mulacc_k
     for (int c = 0; c < NC; ++c) {
         if constexpr (std::is_same<A, PmArith>::value) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {  // fold the pending terms, then [0, 2^K + 2^(K-9)) -> canonical
+            for (int j = 0; j < NV; ++j) {  // fold the pending terms, then [0, 2^K + 2^(K-9)) -> canonical
                 acc[c][j].x = csub(ar.reduce_x(acc[c][j].x), ar.q);
                 acc[c][j].y = csub(ar.reduce_x(acc[c][j].y), ar.q);
             }
         }
-        store_block_vectors<LOGB>(acc[c], out + (u64)c * W, lt);
+        store_block_vectors<LOGB, LOGE>(acc[c], out + (u64)c * W, lt);
     }
 }
 
@@ -461,8 +468,13 @@ int gadget_block_mulacc_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u
     constexpr size_t lds_bytes = (size_t)Cfg::LDS_WORDS * sizeof(u64);
     const u64 stride = ggsw_shared ? 0ull : ggsw_words;
     if (pm) {
+#ifndef PFHE_MULACC_16
+        hipLaunchKernelGGL((gadget_block_mulacc_kernel<PmArith, 2, 3>), dim3((u32)total_blocks), dim3(512), lds_bytes, s,
+                           digits, ggsw, stride, result, primes, L, log_n, terms, total_blocks, accumulate ? 1u : 0u);
+#else
         hipLaunchKernelGGL((gadget_block_mulacc_kernel<PmArith, 2>), dim3((u32)total_blocks), dim3(256), lds_bytes, s,
                            digits, ggsw, stride, result, primes, L, log_n, terms, total_blocks, accumulate ? 1u : 0u);
+#endif
     } else {
         hipLaunchKernelGGL((gadget_block_mulacc_kernel<ShoupArith, 2>), dim3((u32)total_blocks), dim3(256), lds_bytes, s,
                            digits, ggsw, stride, result, primes, L, log_n, terms, total_blocks, accumulate ? 1u : 0u);

@@ -57,7 +57,9 @@ __device__ __forceinline__ Bar load_bar(const NttPrime *__restrict__ primes, u32
 // PM: every modulus is pseudo-Mersenne (q = 2^K - c): the folding multiply of PmArith replaces the 128-bit Barrett
 // reduction (a third of the instructions); both return the canonical residue.
 template <bool HAS_C, bool PAIR, bool PM>
-__global__ __launch_bounds__(kPwThreads) void pointwise_kernel(u64 *out, const u64 *a, const u64 *__restrict__ b,
+// (no __restrict__ on the data pointers: out may be a and/or c, and b may be a or out — mul_assign(a, a) squares in
+// place; every word is read before the same thread writes it)
+__global__ __launch_bounds__(kPwThreads) void pointwise_kernel(u64 *out, const u64 *a, const u64 *b,
                                                                const u64 *c, const NttPrime *__restrict__ primes,
                                                                u32 L, u32 log_n, u64 len, u64 len_b, u64 group_words) {
     constexpr u64 V = PAIR ? 2 : 1;
