@@ -182,8 +182,25 @@ def pmc_traffic(kernel: str, batch: int):
             rows = json.load(open(path))["kernels"]
         except Exception:
             continue
-        want = "ntt_block_kernel" if "block" in kernel else "ntt_strided_kernel"
+        want = "ntt_pipe_kernel" if "pipe" in kernel else "ntt_block_kernel" if "block" in kernel else "ntt_strided_kernel"
         inv = "inv" in kernel
+        if want == "ntt_pipe_kernel":  # <A, INV, MUL>: tiles + 1 launches per transform, three grid sizes
+            sel = []
+            for r in rows:
+                k = r["kernel"]
+                if want not in k or r.get("hbm_bytes_per_launch") is None or "<" not in k or not r.get("launches"):
+                    continue
+                targs = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]
+                if (targs[1] == "true") == inv and targs[2] == "false":
+                    sel.append(r)
+            tile_units = -(-batch // 12)
+            if sel and max(r["grid_size"] for r in sel) == tile_units * 3 * 16 * 256:
+                launches = sum(r["launches"] for r in sel)
+                return {"bytes_per_launch": sum(r["hbm_bytes_per_launch"] * r["launches"] for r in sel) / launches,
+                        "source": os.path.basename(path),
+                        "method": "2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes (MI355X_MICROARCH.md, HBM), "
+                                  "averaged over the %d launches profiled" % launches}
+            continue
         best = None
         for r in rows:
             k = r["kernel"]
@@ -361,16 +378,46 @@ def main():
         alg_bytes = 16 * n * batch * L  # each pass reads and writes every coefficient once
         achieved = alg_bytes / (dom[1] * 1e-3) / 1e9
         pmc = pmc_traffic(dom[0], batch)
-        result["roofline"] = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                              # HBM bytes per launch of this kernel from the committed PMC passes (null if none match)
-                              "traffic": pmc["bytes_per_launch"] if pmc else None,
-                              "traffic_unit": "bytes per launch",
-                              "traffic_source": (pmc["source"] + ": " + pmc["method"]) if pmc else None,
-                              "avg_launch_ms": dom[1], "algorithmic_bytes_per_launch": alg_bytes,
-                              "note": "fraction of the HBM roofline as the metric asks; the kernel's own limit is the "
-                                      "integer ALU and its LDS / twiddle traffic (profiles/r02_*), not HBM"}
+        standalone = {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                      # HBM bytes per launch of this kernel from the committed PMC passes (null if none match)
+                      "traffic": pmc["bytes_per_launch"] if pmc else None,
+                      "traffic_unit": "bytes per launch",
+                      "traffic_source": (pmc["source"] + ": " + pmc["method"]) if pmc else None,
+                      "avg_launch_ms": dom[1], "algorithmic_bytes_per_launch": alg_bytes,
+                      "note": "fraction of the HBM roofline as the metric asks; the kernel's own limit is the "
+                              "integer ALU and its LDS / twiddle traffic (profiles/r02_*), not HBM"}
         result["kernels_ms"] = {k: v for k, v in per_pass}
+        form, launches = table.transform_form(words)
+        if form.startswith("ntt_pipe_kernel"):
+            # The timed step is tiles + 1 back-to-back launches of ONE kernel (block pass of tile k-1 and strided pass of
+            # tile k in each workgroup): time them as the step does, HIP events on the launch stream.  One launch's
+            # algorithmic bytes = the transform's 16*N bytes per limb-polynomial over the launches (each coefficient is
+            # read once and written once by the TRANSFORM; the two-pass plan moves it twice, which `traffic` shows).
+            check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(x.data_ptr()), words, mods.ctypes.data_as(u64p), L, n, 5, None))
+            table.transform_dev(x)
+            reps = max(3, args.steps)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(reps):
+                table.transform_dev(x)
+            e1.record(stream)
+            e1.synchronize()
+            ms_launch = e0.elapsed_time(e1) / reps / launches
+            achieved_p = alg_bytes / launches / (ms_launch * 1e-3) / 1e9
+            pmc_p = pmc_traffic(form, batch)
+            result["roofline"] = {"bound": "hbm", "kernel": form, "achieved": achieved_p, "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": achieved_p / HBM_PEAK_GBS,
+                                  "traffic": pmc_p["bytes_per_launch"] if pmc_p else None,
+                                  "traffic_unit": "bytes per launch",
+                                  "traffic_source": (pmc_p["source"] + ": " + pmc_p["method"]) if pmc_p else None,
+                                  "avg_launch_ms": ms_launch, "launches_per_step": launches,
+                                  "algorithmic_bytes_per_launch": alg_bytes / launches,
+                                  "note": "the step's only kernel; it moves every coefficient twice (two-pass plan), so "
+                                          "its HBM floor is 2x the algorithmic bytes; stand-alone passes in roofline_passes"}
+            result["roofline_passes"] = standalone
+        else:
+            result["roofline"] = standalone
         # the single-pass loops above left x in an arbitrary state: restore canonical residues
         check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(x.data_ptr()), words, mods.ctypes.data_as(u64p), L, n, 5, None))
         # ---- the inverse transform at the same shape (U64DcrtTable::inverse_transform_slice, prime64/table.rs:560) ----

@@ -151,6 +151,7 @@ def _declare(lib: C.CDLL) -> None:
     sig("pfhe_dcrt_transform_num_passes", ci, vp)
     sig("pfhe_dcrt_transform_pass_name", C.c_char_p, vp, ci, ci)
     sig("pfhe_dcrt_transform_pass_dev", ci, vp, vp, sz, ci, ci, ci, vp)
+    sig("pfhe_dcrt_transform_form", ci, vp, sz, ci, C.c_char_p, sz, C.POINTER(ci))
 
     for pre in ("pfhe_ntt_", "pfhe_dcrt_"):
         sig(pre + "mul_to_dev", ci, vp, vp, sz, vp, sz, vp, vp)

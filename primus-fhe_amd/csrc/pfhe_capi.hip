@@ -749,6 +749,14 @@ const char *pfhe_dcrt_transform_pass_name(const pfhe_dcrt *table, int inverse, i
     return buf;
 }
 
+int pfhe_dcrt_transform_form(const pfhe_dcrt *table, size_t len, int inverse, char *name, size_t cap, int *launches) {
+    if (!table || !name || cap == 0 || !launches) return PFHE_ERR_BAD_ARGUMENT;
+    const TableSet &t = *table->t;
+    if (len % (t.n * t.L) != 0) return PFHE_ERR_BAD_LENGTH;
+    *launches = ntt_transform_form(t.L, t.log_n, t.pm, len / t.n, inverse != 0, t.tune, name, cap);
+    return PFHE_OK;
+}
+
 int pfhe_dcrt_transform_pass_dev(const pfhe_dcrt *table, uint64_t *poly_dev, size_t len, int inverse, int index,
                                  int lazy, void *stream) {
     PFHE_GUARD_BEGIN

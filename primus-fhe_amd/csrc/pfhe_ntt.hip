@@ -167,16 +167,22 @@ constexpr bool kBlockLeadBarrier = true;
 constexpr bool kBlockLeadBarrier = false;
 #endif
 
-template <class A, int LOGB, bool INV, bool MUL, int LOGE = 4>
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+// after_stage runs once the block's own global loads have landed in LDS (the pipelined kernel issues the loads of its
+// strided chunk there, so that they are in flight during the block's stages and do not delay the block's first wait)
+template <class A, int LOGB, bool INV, bool MUL, int LOGE = 4, class Hook = NoHook>
 __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L,
                                                 u32 log_n, u64 total_blocks, u32 lazy, const u64 *__restrict__ mul,
-                                                u64 mul_polys, u64 *__restrict__ lds_raw) {
+                                                u64 mul_polys, u64 *__restrict__ lds_raw, u64 first_block,
+                                                Hook after_stage = Hook()) {
     using Cfg = BlockCfg<LOGB, LOGE>;
     constexpr int NV = Cfg::E / 2;  // 16-byte vectors per thread
     const u32 tid = threadIdx.x;
     const u32 sub = Cfg::BPW == 1 ? 0u : tid / Cfg::TPB;
     const u32 lt = Cfg::BPW == 1 ? tid : tid % Cfg::TPB;
-    u64 blk = (u64)blockIdx.x * Cfg::BPW + sub;
+    u64 blk = first_block * Cfg::BPW + sub;
     const bool valid = blk < total_blocks;
     if (!valid) blk = 0;
     const u32 log_nb = log_n - LOGB;  // blocks per polynomial
@@ -226,6 +232,7 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
     lds_put_vectors<LOGB, LOGE>(io, lds, lt);
     __syncthreads();
     PFHE_STAMP(2);  // staged
+    after_stage();
     u64 x[Cfg::E];
     if constexpr (!INV) {
         lds_get_layout<LOGB - LOGE, LOGE>(x, lds, lt);
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(kBlock8Threads<LOGB>) PFHE_BLOCK8_WAVES_ATTR void n
     u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L, u32 log_n, u64 total_blocks, u32 lazy,
     const u64 *__restrict__ mul, u64 mul_polys) {
     extern __shared__ __attribute__((aligned(16))) u64 lds_raw[];
-    block_pass_body<A, LOGB, INV, MUL, 3>(data, primes, L, log_n, total_blocks, lazy, mul, mul_polys, lds_raw);
+    block_pass_body<A, LOGB, INV, MUL, 3>(data, primes, L, log_n, total_blocks, lazy, mul, mul_polys, lds_raw, blockIdx.x);
 }
 
 template <class A, int LOGB, bool INV, bool MUL = false>
@@ -269,7 +276,52 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) PFHE_BLOCK_WAVES_ATTR void
     u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L, u32 log_n, u64 total_blocks, u32 lazy,
     const u64 *__restrict__ mul, u64 mul_polys) {
     extern __shared__ __attribute__((aligned(16))) u64 lds_raw[];
-    block_pass_body<A, LOGB, INV, MUL>(data, primes, L, log_n, total_blocks, lazy, mul, mul_polys, lds_raw);
+    block_pass_body<A, LOGB, INV, MUL>(data, primes, L, log_n, total_blocks, lazy, mul, mul_polys, lds_raw, blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------
+// Pipelined two-pass transform, N = 2^16 (4 strided stages + blocks of 2^12): ONE kernel per tile boundary.  Workgroup
+// i runs the block pass on block i of tile A and the strided pass on chunk i (256 columns x 16 rows) of tile B, with
+// the strided chunk's loads issued right after the block's own loads have landed and consumed after the block's twelve
+// stages: the HBM latency of the strided pass hides behind the block pass's arithmetic INSIDE each wave, instead of
+// relying on two kernels of different register footprints sharing a SIMD.  Forward: A = tile k-1, B = tile k
+// (strided first); inverse: A = tile k, B = tile k-1 (block first).  Both tiles start at a multiple of L polynomials,
+// so block i and chunk i belong to the same limb (16 blocks and 16 chunks per limb-polynomial).
+// ------------------------------------------------------------------------------------------
+#ifndef PFHE_PIPE_WAVES_ATTR
+#define PFHE_PIPE_WAVES_ATTR  // left to the compiler: 142-145 registers, three waves per SIMD, no spills (waves_per_eu(3,3): 160-168, 8 spilled)
+#endif
+template <class A, bool INV, bool MUL>
+__global__ __launch_bounds__(256) PFHE_PIPE_WAVES_ATTR void ntt_pipe_kernel(
+    u64 *__restrict__ blk_data, u64 blk_total, u64 *__restrict__ str_data, u64 str_total,
+    const NttPrime *__restrict__ primes, u32 L, u32 lazy, const u64 *__restrict__ mul, u64 mul_polys) {
+    constexpr int LOGB = 12, K = 4;
+    constexpr u32 log_n = 16, n = 1u << log_n;
+    extern __shared__ __attribute__((aligned(16))) u64 lds_raw[];
+    const u64 chunk = blockIdx.x;
+    const bool has_str = chunk < str_total;
+    // chunk -> (limb-polynomial, 256 columns): thread t owns column (chunk % 16) * 256 + t, rows k * 4096
+    u64 *__restrict__ sp = str_data + (chunk >> 4) * n + ((chunk & 15) << 8) + threadIdx.x;
+    u64 sx[1 << K][1];
+    const auto issue = [&]() {
+        if (has_str) {
+#pragma unroll
+            for (int k = 0; k < (1 << K); ++k) sx[k][0] = __builtin_nontemporal_load(sp + ((u64)k << LOGB));
+        }
+    };
+    if (chunk < blk_total) {
+        block_pass_body<A, LOGB, INV, MUL>(blk_data, primes, L, log_n, blk_total, INV ? 0u : lazy, mul, mul_polys, lds_raw,
+                                           chunk, issue);
+    } else {
+        issue();
+    }
+    if (has_str) {
+        const A ar(primes + (chunk >> 4) % L);
+        if constexpr (!INV) strided_forward_regs<A, K, 1>(ar, sx, n, 0u, LOGB);
+        else strided_inverse_regs<A, K, 1, true>(ar, sx, n, 0u, LOGB, lazy != 0);  // the only strided pass: final stage
+#pragma unroll
+        for (int k = 0; k < (1 << K); ++k) sp[(u64)k << LOGB] = sx[k][0];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -426,6 +478,8 @@ NttTuning NttTuning::from_env() {
     t.light_strided = std::getenv("PFHE_LIGHT_STRIDED") != nullptr;
     t.max_single_pass_log = env_int("PFHE_MAX_SINGLE_PASS_LOG", 9, (int)kMaxSinglePassLog);
     t.block_log = env_int("PFHE_BLOCK_LOG", 8, 12);
+    t.pipelined = std::getenv("PFHE_DISABLE_PIPELINED") == nullptr;
+    t.pipelined_min_mb = env_int("PFHE_PIPELINED_MIN_MB", 1, 1 << 20);
     return t;
 }
 
@@ -514,6 +568,11 @@ namespace {
 #endif
 constexpr int kOverlapTiles = PFHE_OVERLAP_TILES_DEFAULT;
 constexpr u64 kOverlapMinBytes = 512ull << 20;  // below this the extra launches do not pay
+// pipelined form: from 256 MiB of data (2^16-point transforms: 512 limb-polynomials), tiles of at least 96 MiB
+// (measured: 384 MiB 0.395 -> 0.369 ms with 4 tiles, 1.5 GiB 1.448 -> 1.395 ms with 12, 6 GiB 5.23 -> 5.15 ms with 12;
+// 96 MiB 0.087 -> 0.096 ms, so smaller batches keep the two plain launches)
+constexpr u64 kPipelinedMinBytes = 256ull << 20;
+constexpr u64 kPipelinedTileBytes = 96ull << 20;
 
 struct OverlapCtx {
     hipStream_t a = nullptr, b = nullptr;
@@ -602,10 +661,95 @@ void release_overlap_ctx(int dev, OverlapCtx *c) {
 
 }  // namespace
 
+// the pipelined form of the two-pass transform (ntt_pipe_kernel): tiles + 1 launches on the caller's stream
+template <class A>
+static int transform_pipelined(const NttPrime *primes, u32 L, u64 *data, u64 npolys, bool inverse, bool lazy,
+                               hipStream_t s, int tiles, const u64 *mul, u64 mul_polys) {
+    constexpr u32 log_n = 16;
+    constexpr size_t lds_bytes = (size_t)BlockCfg<12>::LDS_WORDS * sizeof(u64);
+    const u64 units = npolys / L;
+    for (int k = 0; k <= tiles; ++k) {
+        // forward: strided pass of tile k, block pass of tile k-1; inverse: block pass of tile k, strided pass of tile k-1
+        const int kb = inverse ? k : k - 1, ks = inverse ? k - 1 : k;
+        u64 *bptr = nullptr, *sptr = nullptr;
+        const u64 *mptr = nullptr;
+        u64 bt = 0, st = 0, mp = 0;
+        if (kb >= 0 && kb < tiles) {
+            const u64 u0 = units * kb / tiles, u1 = units * (kb + 1) / tiles;
+            bptr = data + ((u0 * L) << log_n);
+            bt = ((u1 - u0) * L) << (log_n - 12);
+            // a per-element multiplicand is tiled like the data; a shared one (one unit of L) is not
+            if (mul) {
+                mptr = mul_polys == npolys ? mul + ((u0 * L) << log_n) : mul;
+                mp = mul_polys == npolys ? (u1 - u0) * L : mul_polys;
+            }
+        }
+        if (ks >= 0 && ks < tiles) {
+            const u64 u0 = units * ks / tiles, u1 = units * (ks + 1) / tiles;
+            sptr = data + ((u0 * L) << log_n);
+            st = ((u1 - u0) * L) << 4;
+        }
+        const u64 grid = bt > st ? bt : st;
+        if (grid == 0) continue;
+        if (grid > 0x7fffffffull) {
+            set_last_error("batch too large for one launch");
+            return PFHE_ERR_BAD_LENGTH;
+        }
+        if (inverse && mul)
+            hipLaunchKernelGGL((ntt_pipe_kernel<A, true, true>), dim3((u32)grid), dim3(256), lds_bytes, s, bptr, bt, sptr, st,
+                               primes, L, lazy ? 1u : 0u, mptr, mp);
+        else if (inverse)
+            hipLaunchKernelGGL((ntt_pipe_kernel<A, true, false>), dim3((u32)grid), dim3(256), lds_bytes, s, bptr, bt, sptr, st,
+                               primes, L, lazy ? 1u : 0u, mptr, mp);
+        else
+            hipLaunchKernelGGL((ntt_pipe_kernel<A, false, false>), dim3((u32)grid), dim3(256), lds_bytes, s, bptr, bt, sptr,
+                               st, primes, L, lazy ? 1u : 0u, mptr, mp);
+        PFHE_HIP(hipGetLastError());
+    }
+    return PFHE_OK;
+}
+
+// tiles of the pipelined form for this batch, 0 when the batch does not take it
+static int pipelined_tiles(u32 L, u32 log_n, int pm, u64 npolys, bool inverse, bool has_mul, const NttTuning &tune) {
+    const u64 bytes = (npolys << log_n) * sizeof(u64);
+    if (!(tune.pipelined && log_n == 16 && ntt_num_passes(log_n, pm, tune) == 2 && pm != kArithB32 &&
+          (!has_mul || inverse) && npolys % L == 0 && make_ntt_plan(log_n, pm, tune).block_log == 12 &&
+          bytes >= (tune.pipelined_min_mb ? (u64)tune.pipelined_min_mb << 20 : kPipelinedMinBytes)))
+        return 0;
+    int pt = tune.overlap_tiles ? tune.overlap_tiles : kOverlapTiles;
+    if (!tune.overlap_tiles && (u64)pt > bytes / kPipelinedTileBytes) pt = (int)(bytes / kPipelinedTileBytes);
+    if (pt < 2) pt = 2;
+    if ((u64)pt > npolys / L) pt = (int)(npolys / L);
+    return pt;
+}
+
+// how transform() will run a batch: kernel (or form) name and the number of kernel launches
+int ntt_transform_form(u32 L, u32 log_n, int arith, u64 npolys, bool inverse, const NttTuning &tune, char *buf, size_t cap) {
+    const int pt = pipelined_tiles(L, log_n, arith, npolys, inverse, false, tune);
+    if (pt >= 1) {
+        std::snprintf(buf, cap, "ntt_pipe_kernel<%s>", inverse ? "inv" : "fwd");
+        return pt + 1;
+    }
+    const int passes = ntt_num_passes(log_n, arith, tune);
+    int tiles = tune.overlap_tiles ? tune.overlap_tiles : kOverlapTiles;
+    if ((u64)tiles * L > npolys) tiles = (int)(npolys / L);
+    const bool two_stream = arith != kArithB32 && passes == 2 && (!inverse || tune.overlap_inverse) &&
+                            (npolys << log_n) * sizeof(u64) >= kOverlapMinBytes && tiles >= 2 && tune.overlap;
+    std::snprintf(buf, cap, two_stream ? "two-stream tiled passes" : "plain passes");
+    return two_stream ? passes * tiles : passes;
+}
+
 static int transform(const NttPrime *primes, u32 L, u32 log_n, int pm, u64 *data, u64 npolys, bool inverse,
                      bool lazy, hipStream_t s, const NttTuning &tune, const u64 *mul = nullptr, u64 mul_polys = 0) {
     const int passes = ntt_num_passes(log_n, pm, tune);
     const u64 bytes = (npolys << log_n) * sizeof(u64);
+    {
+        const int pt = pipelined_tiles(L, log_n, pm, npolys, inverse, mul != nullptr, tune);
+        if (pt >= 1)
+            return pm == kArithPm
+                       ? transform_pipelined<PmArith>(primes, L, data, npolys, inverse, lazy, s, pt, mul, mul_polys)
+                       : transform_pipelined<ShoupArith>(primes, L, data, npolys, inverse, lazy, s, pt, mul, mul_polys);
+    }
     int dev = 0;
     // (the u32 tables do not gain from the overlap: measured 3.40 ms vs 3.15 ms without, N = 2^16)
     // (the inverse direction, block pass first, measures 2 % slower tiled than as two full-size launches: 5.98 vs

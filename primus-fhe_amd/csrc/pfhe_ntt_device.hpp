@@ -30,6 +30,8 @@ struct NttTuning {
     bool light_strided = false;    // PFHE_LIGHT_STRIDED: the tiled transform runs the one-column strided pass beside the block pass
     int max_single_pass_log = 0;   // PFHE_MAX_SINGLE_PASS_LOG (0: built-in default)
     int block_log = 0;             // PFHE_BLOCK_LOG: block size under strided passes (0: built-in default)
+    bool pipelined = true;         // PFHE_DISABLE_PIPELINED clears it: N = 2^16 runs as tiles + 1 launches of ntt_pipe_kernel on the caller's stream
+    int pipelined_min_mb = 0;      // PFHE_PIPELINED_MIN_MB: smallest batch (MiB of data) that takes the pipelined form (0: built-in default)
     static NttTuning from_env();
 };
 NttPlan make_ntt_plan(u32 log_n, int arith = 0, const NttTuning &tune = NttTuning());  // arith: see kArith* below
@@ -41,6 +43,8 @@ NttPlan make_ntt_plan(u32 log_n, int arith = 0, const NttTuning &tune = NttTunin
 enum : int { kArithShoup = 0, kArithPm = 1, kArithB32 = 2 };
 int ntt_forward_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, bool lazy,
                     hipStream_t s, const NttTuning &tune = NttTuning());
+// the form a transform of npolys limb-polynomials takes (kernel or form name into buf) and its number of launches
+int ntt_transform_form(u32 L, u32 log_n, int arith, u64 npolys, bool inverse, const NttTuning &tune, char *buf, size_t cap);
 int ntt_inverse_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, bool lazy,
                     hipStream_t s, const NttTuning &tune = NttTuning());
 // inverse transform of data (*) mul, the pointwise product fused into the loads of the first

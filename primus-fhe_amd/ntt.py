@@ -211,6 +211,12 @@ class U64DcrtTable:
         check(lib().pfhe_dcrt_add_dcrt_glwe_mul_dcrt_polynomial_assign_dev(self._h, pc, pa, na, pb, nb, glwe_polys,
                                                                            _stream(stream)))
 
+    def transform_form(self, words: int, inverse: bool = False):
+        """(name, launches): how transform_dev / inverse_transform_dev will run `words` words of data."""
+        buf, k = C.create_string_buffer(96), C.c_int(0)
+        check(lib().pfhe_dcrt_transform_form(self._h, words, int(inverse), buf, len(buf), C.byref(k)))
+        return buf.value.decode(), int(k.value)
+
     def fill_uniform_dev(self, dst, seed: int, stream=None):
         """Synthetic residues (bench / test input): uniform in [0, q_limb) from SplitMix64(seed)."""
         p, n = _dev(dst)

@@ -50,13 +50,17 @@ def test_external_product_and_ntt_in_a_graph(pf, chunk, batch):
         assert torch.equal(out, ref)
 
 
-def test_large_batch_transform_in_a_graph(pf):
-    """>= 512 MiB: the two passes run tile by tile on two pooled internal streams."""
+@pytest.mark.parametrize("pipelined", [True, False])
+def test_large_batch_transform_in_a_graph(pf, pipelined, monkeypatch):
+    """>= 256 MiB: the pipelined form launches its tiles on the capturing stream itself (captured as is); without it
+    the two-stream form must notice the capture and fall back to two plain launches."""
     import ctypes as C
     import torch
     from primus_fhe_amd._lib import check, u64p
     log_n, batch = 16, 352
     n, L = 1 << log_n, 3
+    if not pipelined:
+        monkeypatch.setenv("PFHE_DISABLE_PIPELINED", "1")  # switches are read when a table is created
     t = pf.U64DcrtTable(log_n, Q61)
     mods = np.array(Q61, np.uint64)
     x = torch.empty(batch * L * n, dtype=torch.int64, device="cuda")

@@ -270,12 +270,21 @@ def test_two_stream_overlap_path_matches_oracle(pf, orc, monkeypatch):
     d.transform_dev(x)
     y = x.clone()  # ordered after the join on the same (current) stream
     got = to_host(y)
-    monkeypatch.setenv("PFHE_DISABLE_OVERLAP", "1")  # switches are read when a table is created
+    # three forms of the same transform (switches are read when a table is created): pipelined single-stream (the
+    # default at this size), two-stream tiled, two plain launches
+    monkeypatch.setenv("PFHE_DISABLE_PIPELINED", "1")
+    d2 = pf.U64DcrtTable(log_n, Q61)
+    monkeypatch.setenv("PFHE_DISABLE_OVERLAP", "1")
     d1 = pf.U64DcrtTable(log_n, Q61)
     monkeypatch.delenv("PFHE_DISABLE_OVERLAP")
-    x1 = to_dev(a)
-    d1.transform_dev(x1)
-    assert np.array_equal(got, to_host(x1))
+    monkeypatch.delenv("PFHE_DISABLE_PIPELINED")
+    for other in (d2, d1):
+        x1 = to_dev(a)
+        other.transform_dev(x1)
+        z = x1.clone()
+        assert np.array_equal(got, to_host(z))
+        other.inverse_transform_dev(x1)
+        assert np.array_equal(to_host(x1), a)
     for e in (0, 123, batch - 1):
         ref = a[e * L * n:(e + 1) * L * n].copy()
         o.transform_slice(ref)
@@ -438,12 +447,15 @@ def test_fused_polymul_large_batch_tiled_path(pf, orc, shared):
     a, bh = fill(batch * W, 11), fill(W if shared else batch * W, 12)
     fused = a.clone()
     d.mul_dcrt_polynomial_dev(fused, bh)
-    # the inverse direction is not tiled by default: exercise its tiling too (switches are read at table creation)
+    # d runs the pipelined form; the two-stream form does not tile the inverse direction by default: exercise its
+    # tiling too (switches are read at table creation)
     os.environ["PFHE_OVERLAP_INVERSE"] = "1"
+    os.environ["PFHE_DISABLE_PIPELINED"] = "1"
     try:
         d_tiled = pf.U64DcrtTable(log_n, Q61)
     finally:
         del os.environ["PFHE_OVERLAP_INVERSE"]
+        del os.environ["PFHE_DISABLE_PIPELINED"]
     tiled = a.clone()
     d_tiled.mul_dcrt_polynomial_dev(tiled, bh)
     inv_tiled = a.clone()
@@ -453,10 +465,14 @@ def test_fused_polymul_large_batch_tiled_path(pf, orc, shared):
     d.inverse_transform_dev(inv_plain)
     assert torch.equal(inv_plain, inv_tiled)
     os.environ["PFHE_DISABLE_FUSED_POLYMUL"] = "1"
+    os.environ["PFHE_DISABLE_PIPELINED"] = "1"
+    os.environ["PFHE_DISABLE_OVERLAP"] = "1"
     try:
         d_plain = pf.U64DcrtTable(log_n, Q61)
     finally:
         del os.environ["PFHE_DISABLE_FUSED_POLYMUL"]
+        del os.environ["PFHE_DISABLE_PIPELINED"]
+        del os.environ["PFHE_DISABLE_OVERLAP"]
     plain = a.clone()
     d_plain.mul_dcrt_polynomial_dev(plain, bh)
     assert torch.equal(fused, plain)
@@ -554,6 +570,24 @@ def test_handles_release_their_device_memory(pf):
     assert free0 - free1 < 64 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 50 create/destroy cycles"
 
 
+def test_transform_form_reports_the_launch_plan(pf, monkeypatch):
+    """pfhe_dcrt_transform_form: what bench.py's roofline object is built from."""
+    n, L = 1 << 16, 3
+    t = pf.U64DcrtTable(16, Q61)
+    assert t.transform_form(4096 * L * n) == ("ntt_pipe_kernel<fwd>", 13)
+    assert t.transform_form(4096 * L * n, inverse=True) == ("ntt_pipe_kernel<inv>", 13)
+    assert t.transform_form(256 * L * n) == ("ntt_pipe_kernel<fwd>", 5)      # 384 MiB: 4 tiles of 96 MiB
+    assert t.transform_form(64 * L * n) == ("plain passes", 2)
+    assert pf.U64DcrtTable(12, [Q61[0]]).transform_form(1 << 12) == ("plain passes", 1)
+    monkeypatch.setenv("PFHE_DISABLE_PIPELINED", "1")
+    t2 = pf.U64DcrtTable(16, Q61)
+    assert t2.transform_form(4096 * L * n) == ("two-stream tiled passes", 24)
+    assert t2.transform_form(4096 * L * n, inverse=True) == ("plain passes", 2)
+    with pytest.raises(pf.PfheError) as e:
+        t.transform_form(5)
+    assert e.value.kind == "BadLength"
+
+
 @pytest.mark.gpu
 def test_overlap_context_creation_failure_is_clean():
     """The two-stream transform falls back to one stream when its streams / events cannot be created, and the
@@ -572,7 +606,7 @@ t = pf.U64DcrtTable(log_n, Q61)
 x = torch.empty(batch * 3 << log_n, dtype=torch.int64, device="cuda")
 t.fill_uniform_dev(x, 5)
 ref = x.clone()
-os.environ["PFHE_DISABLE_OVERLAP"] = "1"
+os.environ["PFHE_DISABLE_OVERLAP"] = "1"   # (PFHE_DISABLE_PIPELINED is set for the whole process: two-stream form)
 t1 = pf.U64DcrtTable(log_n, Q61)
 t1.transform_dev(ref)
 def rounds(k):
@@ -590,7 +624,7 @@ assert free0 - free1 < (16 << 20), (free0, free1)
 print("ok")
 """
     for fail_after in (0, 3, 7):
-        env = dict(os.environ, PFHE_TEST_FAIL_OVERLAP_CTX=str(fail_after))
+        env = dict(os.environ, PFHE_TEST_FAIL_OVERLAP_CTX=str(fail_after), PFHE_DISABLE_PIPELINED="1")
         env.pop("PFHE_DISABLE_OVERLAP", None)
         r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

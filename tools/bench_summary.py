@@ -8,6 +8,9 @@ print(f"headline: {d['value'] / 1e6:.3f} M NTT/s  {d['ms_per_step']:.3f} ms/step
 if "roofline" in d:
     r = d["roofline"]
     print(f"roofline: {r['kernel']}  {r['avg_launch_ms']:.3f} ms  {r['achieved']:.0f} GB/s  frac {r['frac']:.3f}")
+    if "roofline_passes" in d:
+        r = d["roofline_passes"]
+        print(f"stand-alone: {r['kernel']}  {r['avg_launch_ms']:.3f} ms  {r['achieved']:.0f} GB/s  frac {r['frac']:.3f}")
     print("kernels_ms:", {k: round(v, 3) for k, v in d.get("kernels_ms", {}).items()})
 for k in ("intt", "ntt_generic_prime", "polymul", "ntt_u32"):
     if k in d:

@@ -13,9 +13,9 @@ import ctypes as C
 import os
 import sys
 
-# one launch per pass over the whole batch (no two-stream tiling), so that per-launch counters refer
-# to the same launch shape as bench.py's per-kernel timing leg
-os.environ.setdefault("PFHE_DISABLE_OVERLAP", "1")
+# t runs the default form (large batches of N = 2^16: ntt_pipe_kernel, tiles + 1 launches); t_plain runs one launch per
+# pass over the whole batch, so that per-launch counters refer to the same launch shape as bench.py's per-kernel
+# timing leg
 
 import numpy as np
 
@@ -29,6 +29,9 @@ Q61 = [2305843009211596801, 2305843009210023937, 2305843009208713217]
 batch = int(os.environ.get("PFHE_PROFILE_BATCH", "4096"))
 n, L = 1 << 16, 3
 t = p.U64DcrtTable(16, Q61)
+os.environ["PFHE_DISABLE_OVERLAP"] = os.environ["PFHE_DISABLE_PIPELINED"] = "1"  # (read when a table is created)
+t_plain = p.U64DcrtTable(16, Q61)
+del os.environ["PFHE_DISABLE_OVERLAP"], os.environ["PFHE_DISABLE_PIPELINED"]
 words = batch * L * n
 x = torch.empty(words, dtype=torch.int64, device="cuda")
 mods = np.array(Q61, np.uint64)
@@ -36,8 +39,11 @@ check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(x.data_ptr()), words, mods.cty
 b = x[:L * n].clone()
 for _ in range(3):
     t.transform_dev(x)
-t.mul_assign_dev(x, b)
 t.inverse_transform_dev(x)
+for _ in range(3):
+    t_plain.transform_dev(x)
+t.mul_assign_dev(x, b)
+t_plain.inverse_transform_dev(x)
 base = p.RNSBase(Q61)
 ctx = p.DcrtGlevContext(t, base, p.BigUintApproxSignedBasis(base, 30), 1, 8)
 ep = min(64, batch // 2)
@@ -47,6 +53,7 @@ out = torch.empty(ep * 2 * L * n, dtype=torch.int64, device="cuda")
 p.mul_dcrt_ggsw_to_dev(x[:ep * 2 * L * n], ggsw, out, ctx, into_coeff_form=True)
 # fused product inside the inverse transform (config 3), shared multiplicand
 t.mul_dcrt_polynomial_dev(x, b)
+t_plain.mul_dcrt_polynomial_dev(x, b)
 # u32 tables at the same shape (three 30-bit primes): 2 forward + 1 inverse
 t32 = p.U32DcrtTable(16, [1073479681, 1071513601, 1070727169])
 x32 = x.view(torch.int32)[:words]
