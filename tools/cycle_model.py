@@ -4,7 +4,8 @@ assembly of csrc/pfhe_ntt.hip, priced with the per-wave-instruction issue costs 
 (profiles/r02_microbench5_instruction_costs.txt, 4 waves per SIMD), against the measured kernel durations.
 
 The three kernels are straight-line code per workgroup (no loops: every stage is unrolled), so static counts are
-dynamic counts; the few instructions on not-taken paths (`valid` guards) are counted too (< 1 %).
+dynamic counts; the few instructions on not-taken paths (`valid` guards) are counted too (< 1 %).  The backward jumps
+the pipelined kernel shows are the block layout of its `valid` / `has_str` guards (each executed once), not loops.
 
     python tools/cycle_model.py [--ms block=3.19,strided=2.16,pipe=0.397] > profiles/r02_cycle_model.txt
 """
@@ -68,12 +69,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ms", default="", help="measured durations, e.g. block=3.19,strided=2.16,pipe=0.397")
     ap.add_argument("--clock-ghz", type=float, default=2.4)
+    ap.add_argument("--clocks", default="", help="sustained shader clock per kernel in GHz (tools/microbench8_clock.hip), "
+                                                 "e.g. block=2.10,strided=2.21,pipe=1.98")
     args = ap.parse_args()
     measured = dict((k, float(v)) for k, v in (kv.split("=") for kv in args.ms.split(",") if kv))
+    clocks = dict((k, float(v)) for k, v in (kv.split("=") for kv in args.clocks.split(",") if kv))
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function",
                            "-fno-gpu-rdc", "-S", "--cuda-device-only", "-o", ASM, SRC], stderr=subprocess.DEVNULL)
     txt = open(ASM).read()
     polys = 4096 * 3
+    isa = {}
     print("Static cycle model, N = 2^16, 3 x 61-bit pseudo-Mersenne primes, 4096 RNS polynomials (12 288 limb transforms)")
     print(f"costs (cycles per wave-instruction at 4 waves/SIMD, microbench5): {COST};  {args.clock_ghz} GHz, 256 CUs x 4 SIMDs\n")
     for key, (mangled, title) in KERNELS.items():
@@ -115,12 +120,27 @@ def main():
         print(f"{title}\n  VALU instructions per wave: {valu}  "
               + "  ".join(f"{k} {v}" for k, v in sorted(cls.items())) + f"   -> {cycles:.0f} issue cycles per wave")
         print("  top ops: " + ", ".join(f"{o} {c}" for o, c in ops.most_common(9)))
-        print("  other:   " + ", ".join(f"{k} {v}" for k, v in sorted(other.items())) + f";  backward branches (loops): {back}")
-        line = f"  {waves} waves = {per_simd:.0f} per SIMD -> VALU issue floor {ms:.3f} ms per {polys} limb transforms"
+        print("  other:   " + ", ".join(f"{k} {v}" for k, v in sorted(other.items())) + f";  backward jumps: {back}")
+        line = f"  {waves} waves = {per_simd:.0f} per SIMD -> VALU issue floor {ms:.3f} ms per {polys} limb transforms at {args.clock_ghz} GHz"
+        if key in clocks:
+            ms = ms * args.clock_ghz / clocks[key]
+            line += f", {ms:.3f} ms at the sustained {clocks[key]} GHz"
         if key in measured:
-            tot = measured[key] * (12 if key == "pipe" else 1)
+            tot = measured[key] * (13 if key == "pipe" else 1)
             line += f";  measured {tot:.3f} ms -> {ms / tot:.0%} of the time is VALU issue at these costs"
         print(line + "\n")
+        if key == "block":
+            app = [i for i, l in enumerate(body) if "#ASMSTART" in l]
+            noapp = [i for i, l in enumerate(body) if "#ASMEND" in l]
+            for a0 in app:  # the first asm block that is a butterfly (the short ones are register pins)
+                e0 = min(e for e in noapp if e > a0)
+                if e0 - a0 > 20:
+                    isa[key] = [l.rstrip() for l in body[a0:e0 + 1]]
+                    break
+    if "block" in isa:
+        print("ISA listing: the first asm block of the block pass as compiled (two interleaved forward butterflies, uniform\n"
+              "twiddles in SGPRs, WITH the fold of x = 18 instructions each (the 14-instruction form lacks the first four); generator: tools/gen_pm_asm.py; all variants: primus-fhe_amd/csrc/pfhe_pm_asm.hpp)")
+        print("\n".join(isa["block"]) + "\n")
     print("HBM floor of the two-pass plan: 2 x 12.885 GB read+written; at the 6.0 TB/s this chip sustains for streaming read+write "
           "(strided pass alone: 2.16 ms per 12.885 GB) = 4.3 ms per step.")
 
