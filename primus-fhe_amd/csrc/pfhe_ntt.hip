@@ -195,9 +195,41 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
     u64 *__restrict__ gptr = data + pid * n + eblk;
     u64 *__restrict__ lds = lds_raw + (size_t)sub * Cfg::LDS_WORDS;
 
+    // Forward direction: the first register pass wants register k of thread lt = element (k << POS0) + lt, which 8-byte
+    // loads deliver directly (a wave instruction reads 512 contiguous bytes): no staging through LDS, one barrier and 24
+    // LDS instructions fewer, and the first butterflies start when their own operands have landed.  Only inside the
+    // pipelined kernel (Hook given), where it measures 5.15 against 5.19 ms per 12 288 transforms; stand-alone it is
+    // neutral at 2^12 (3.22 ms either way) and slower for blocks of 2^14 (0.365 vs 0.357 ms per 4096) and for the u32
+    // tables (3.10 vs 2.94 ms).  The mirror image, 8-byte stores after the last INVERSE pass, pays everywhere it was
+    // measured (2^16 inverse 5.08 vs 5.20 ms, 2^14 inverse 0.381 vs 0.412 ms) and is the default below.
+    constexpr bool kDirectLoad = !INV && !MUL && Cfg::BPW == 1 && (LOGB - LOGE) >= 6 && !kBlockLeadBarrier &&
+                                 !std::is_same<Hook, NoHook>::value
+#ifdef PFHE_STAGED_BLOCK_LOADS
+                                 && false
+#endif
+        ;
+    u64x2 io[NV];
+    u64 x[Cfg::E];
+    if constexpr (kDirectLoad) {
+        PFHE_STAMP(0);
+#pragma unroll
+        for (int k = 0; k < Cfg::E; ++k)
+            x[k] = valid ? __builtin_nontemporal_load(gptr + ((u32)k << (LOGB - LOGE)) + lt) : 0ull;
+        PFHE_STAMP(1);
+        PFHE_STAMP(2);
+        after_stage();
+        block_forward_core<A, LOGB, false, LOGE>(ar, x, lds, n, eblk, lt, lazy != 0);
+        PFHE_STAMP(8);
+        lds_put_layout<0, LOGE>(x, lds, lt);
+        __syncthreads();
+        PFHE_STAMP(9);
+        lds_get_vectors<LOGB, LOGE>(io, lds, lt);
+        if (valid) store_block_vectors<LOGB, LOGE>(io, gptr, lt);
+        PFHE_STAMP(10);
+        return;
+    }
     // all global traffic as 16-byte vectors in natural order (1 KiB per wave instruction), staged
     // through LDS into / out of the register layouts of the first / last register pass
-    u64x2 io[NV];
     PFHE_STAMP(0);
     if (valid) {
         load_block_vectors<LOGB, LOGE>(io, gptr, lt);
@@ -233,7 +265,6 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
     __syncthreads();
     PFHE_STAMP(2);  // staged
     after_stage();
-    u64 x[Cfg::E];
     if constexpr (!INV) {
         lds_get_layout<LOGB - LOGE, LOGE>(x, lds, lt);
         block_forward_core<A, LOGB, kBlockLeadBarrier, LOGE>(ar, x, lds, n, eblk, lt, lazy != 0);
@@ -243,6 +274,21 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
     } else {
         lds_get_layout<0, LOGE>(x, lds, lt);
         block_inverse_core<A, LOGB, kBlockLeadBarrier, LOGE>(ar, x, lds, n, eblk, lt, log_n == LOGB, lazy != 0);
+        // mirror of the forward direction's direct loads: the last inverse pass leaves register k of thread lt =
+        // element (k << POS0) + lt, stored as 8-byte words (512 contiguous bytes per wave instruction)
+        constexpr bool kDirectStore = Cfg::BPW == 1 && (LOGB - LOGE) >= 6 && !kBlockLeadBarrier && !A::kPacked
+#ifdef PFHE_STAGED_BLOCK_STORES
+                                      && false
+#endif
+            ;
+        if constexpr (kDirectStore) {
+            if (valid) {
+#pragma unroll
+                for (int k = 0; k < Cfg::E; ++k) gptr[((u32)k << (LOGB - LOGE)) + lt] = x[k];
+            }
+            PFHE_STAMP(10);
+            return;
+        }
         if constexpr (kBlockLeadBarrier) __syncthreads();
         lds_put_layout<LOGB - LOGE, LOGE>(x, lds, lt);
     }

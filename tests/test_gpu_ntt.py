@@ -570,6 +570,44 @@ def test_handles_release_their_device_memory(pf):
     assert free0 - free1 < 64 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 50 create/destroy cycles"
 
 
+@pytest.mark.parametrize("q", [Q61[1], 4611686018425815041])  # pseudo-Mersenne arithmetic / generic (Shoup) arithmetic
+def test_pipelined_form_single_modulus_lazy_and_ragged_tiles(pf, orc, q):
+    """The pipelined form behind U64NttTable (L = 1) at a batch that does not divide into equal tiles: canonical and
+    lazy outputs, forward and inverse, against the oracle on the elements either side of every tile boundary."""
+    import torch
+    log_n, batch = 16, 523  # 523 * 512 KiB = 261.5 MiB -> 2 tiles of 261 and 262 polynomials
+    n = 1 << log_n
+    d, o = pf.U64NttTable(log_n, q), orc.U64NttTable(log_n, q)
+    rng = np.random.default_rng(5)
+    a = rand_mod(rng, q, n * batch)
+    probe = [0, 1, 260, 261, 262, 522]
+
+    def expect(fn, src):
+        out = {}
+        for e in probe:
+            r = src[e * n:(e + 1) * n].copy()
+            fn(r)
+            out[e] = r
+        return out
+
+    x = to_dev(a)
+    d.transform_dev(x)
+    fwd = to_host(x.clone())
+    for e, r in expect(o.transform_slice, a).items():
+        assert np.array_equal(fwd[e * n:(e + 1) * n], r), e
+    xl = to_dev(a)
+    d.transform_dev(xl, lazy=True)
+    lz = to_host(xl.clone())
+    assert int(lz.max()) < 4 * q and np.array_equal(lz % np.uint64(q), fwd)
+    xi = to_dev(fwd)  # the lazy inverse takes [0, 2q): the canonical spectrum
+    d.inverse_transform_dev(xi, lazy=True)
+    li = to_host(xi.clone())
+    assert int(li.max()) < 2 * q and np.array_equal(li % np.uint64(q), a)
+    d.inverse_transform_dev(x)
+    assert np.array_equal(to_host(x), a)
+    del xl
+
+
 def test_transform_form_reports_the_launch_plan(pf, monkeypatch):
     """pfhe_dcrt_transform_form: what bench.py's roofline object is built from."""
     n, L = 1 << 16, 3
