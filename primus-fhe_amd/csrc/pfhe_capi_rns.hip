@@ -572,12 +572,12 @@ int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *rns, const 
     p->rns = rns->h.dev;
     p->basis = basis->h.dev;
     p->k = (u32)glwe_dimension;
-    // default: about 1 GiB of digit polynomials per buffer, at least 64 ciphertexts — 64 is the measured
-    // optimum at N = 2^16, 3 limbs (16: 26.5 ms, 32: 25.7, 64: 24.7, 128: 24.8 per 1024 products); small
-    // rings need many more ciphertexts per launch to amortise the launches
+    // default: about 2 GiB of digit polynomials per buffer, at least 128 ciphertexts — measured at N = 2^16, 3 limbs
+    // with today's kernels (ms per 1024 products): 32: 21.7, 64: 21.2, 128: 20.8, 256: 20.9, 1024: 20.8 (round 1, slower
+    // kernels: 64 was the optimum); small rings need many more ciphertexts per launch to amortise the launches
     if (chunk == 0) {
         const size_t per_ct = (size_t)(glwe_dimension + 1) * p->basis.ell * t->L * t->n * sizeof(u64);
-        chunk = std::max<size_t>(64, std::min<size_t>(65536, ((size_t)1 << 30) / per_ct));
+        chunk = std::max<size_t>(128, std::min<size_t>(65536, ((size_t)2 << 30) / per_ct));
     }
     p->chunk = chunk;
     p->digits_words = p->chunk * (p->k + 1) * p->basis.ell * t->L * t->n;

@@ -20,6 +20,13 @@ struct RnsDev {
     u64 inv_punct[kMaxLimbs], inv_punct_p[kMaxLimbs];  // (Q/q_i)^-1 mod q_i and its Shoup quotient
     u64 punct[kMaxLimbs][kMaxLimbs];                    // Q/q_i, little-endian limbs
     u64 Q[kMaxLimbs];                                   // product of all moduli
+    // Mixed-radix (Garner) form of the same CRT lift for bases of 2 or 3 moduli with max q < 2 min q (every prime of
+    // the BASELINE configs): x = v0 + q0*v1 + q0*q1*v2 with v_i < q_i needs 1 / 3 modular products and 1 / 3 widening
+    // ones instead of L Shoup products, L*value_len widening ones and L compare-and-subtract passes over value_len
+    // limbs; the result is the same integer in [0, Q).  garner = 0: the general form below it.
+    u32 garner, pad2_;
+    u64 g_inv[3][2], g_inv_p[3][2];  // g_inv[i][j] = q_j^-1 mod q_i (j < i) and its Shoup quotient
+    u64 g_prod[2];                   // q0*q1, little-endian
 };
 
 // BigUintApproxSignedBasis<u64> constants (primus_decompose/src/big_integer/basis.rs:17-211).

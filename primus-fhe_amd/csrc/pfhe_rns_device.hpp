@@ -7,9 +7,42 @@
 
 namespace pfhe {
 
+// Mixed-radix form of the CRT lift (RnsDev::garner): digits v0 = r0, v1 = (r1 - v0) / q0 mod q1,
+// v2 = ((r2 - v0) / q0 - v1) / q1 mod q2, then x = v0 + q0*v1 + q0*q1*v2 < Q — no comparison with Q, no subtraction.
+template <int LEN>
+__device__ __forceinline__ void compose_garner(const RnsDev &R, const u64 *r, u64 (&v)[LEN]) {
+    typedef unsigned __int128 u128;
+    const u64 v0 = r[0];
+    // (max q < 2 min q: one conditional subtraction reduces a digit into another modulus' range)
+    u64 t = sub_mod(r[1], reduce_once(v0, R.q[1]), R.q[1]);
+    const u64 v1 = mul_shoup(t, R.g_inv[1][0], R.g_inv_p[1][0], R.q[1]);
+    u128 lo = (u128)R.q[0] * v1 + v0;  // < q0*q1 < 2^124
+    u64 w2 = 0;
+    if (R.L == 3) {
+        t = sub_mod(r[2], reduce_once(v0, R.q[2]), R.q[2]);
+        t = mul_shoup(t, R.g_inv[2][0], R.g_inv_p[2][0], R.q[2]);
+        t = sub_mod(t, reduce_once(v1, R.q[2]), R.q[2]);
+        const u64 v2 = mul_shoup(t, R.g_inv[2][1], R.g_inv_p[2][1], R.q[2]);
+        const u128 m0 = (u128)R.g_prod[0] * v2, m1 = (u128)R.g_prod[1] * v2;
+        const u128 s0 = (u128)(u64)lo + (u64)m0;
+        const u128 s1 = (u128)(u64)(lo >> 64) + (u64)(m0 >> 64) + (u64)m1 + (u64)(s0 >> 64);
+        lo = ((u128)(u64)s1 << 64) | (u64)s0;
+        w2 = (u64)(m1 >> 64) + (u64)(s1 >> 64);
+    }
+    v[0] = (u64)lo;
+    if constexpr (LEN > 1) v[1] = (u64)(lo >> 64);
+    if constexpr (LEN > 2) v[2] = w2;
+#pragma unroll
+    for (int j = 3; j < LEN; ++j) v[j] = 0;
+}
+
 // v (LEN limbs, canonical in [0,Q)) = CRT lift of residues r[0..L)  — base.rs:609-633.
 template <int LEN>
 __device__ __forceinline__ void compose(const RnsDev &R, const u64 *r, u64 (&v)[LEN]) {
+    if (R.garner) {
+        compose_garner<LEN>(R, r, v);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < LEN; ++j) v[j] = 0;
     for (u32 i = 0; i < R.L; ++i) {

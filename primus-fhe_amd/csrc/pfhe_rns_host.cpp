@@ -3,6 +3,7 @@
 // Computes what RNSBase::new (primus_rns/src/base.rs:79-117) and
 // BigUintApproxSignedBasis::new (primus_decompose/src/big_integer/basis.rs:40-211) compute.
 #include <algorithm>
+#include <cstdlib>
 
 #include "pfhe_rns.hpp"
 
@@ -124,6 +125,23 @@ int build_rns(const u64 *moduli, size_t count, RnsHost &out) {
         const u64 inv = inv_mod(big_mod_u64(P, moduli[i]), moduli[i]);
         d.inv_punct[i] = inv;
         d.inv_punct_p[i] = (u64)(((u128)inv << 64) / moduli[i]);
+    }
+    u64 qmin = moduli[0], qmax = moduli[0];
+    for (size_t i = 1; i < count; ++i) {
+        qmin = std::min(qmin, moduli[i]);
+        qmax = std::max(qmax, moduli[i]);
+    }
+    if ((count == 2 || count == 3) && qmax < 2 * qmin && std::getenv("PFHE_DISABLE_GARNER") == nullptr) {
+        d.garner = 1;
+        for (size_t i = 1; i < count; ++i)
+            for (size_t j = 0; j < i; ++j) {
+                const u64 inv = inv_mod(moduli[j] % moduli[i], moduli[i]);
+                d.g_inv[i][j] = inv;
+                d.g_inv_p[i][j] = (u64)(((u128)inv << 64) / moduli[i]);
+            }
+        const u128 p01 = (u128)moduli[0] * moduli[1];
+        d.g_prod[0] = (u64)p01;
+        d.g_prod[1] = (u64)(p01 >> 64);
     }
     out.dev = d;
     out.moduli.assign(moduli, moduli + count);

@@ -79,6 +79,39 @@ def test_compose_matches_oracle(pf, orc, moduli, count):
     assert e.value.kind == "BadLength"
 
 
+@pytest.mark.parametrize("moduli", [
+    [134215681, 134176769],                                # L = 2, one limb
+    Q61[:2],                                               # L = 2, two limbs
+    [137438822401, 137438814209, 137438773249],            # L = 3, two limbs
+    Q61,                                                   # L = 3, three limbs
+    [2305843009213317121, 1152921504606584833, 2305843009211596801],  # 61 / 60 / 61 bits: max > 2 min, general form
+    [1125899906826241, 2305843009211596801],               # 50 / 61 bits: the general form only
+    [3, 5, 7], [2, 3],
+])
+def test_compose_mixed_radix_form_equals_general_form(pf, moduli, monkeypatch):
+    """The mixed-radix (Garner) lift that bases of 2-3 similar moduli take against the general form (switch read when the
+    base is created) and against Python big integers, incl. the extreme residues."""
+    count = 4096
+    rng = np.random.default_rng(len(moduli) * 1000 + moduli[0] % 997)
+    res = np.concatenate([rng.integers(0, m, count, dtype=np.uint64) for m in moduli])
+    for i, m in enumerate(moduli):  # all-zero, all-maximal and mixed extreme columns
+        res[i * count + 0] = 0
+        res[i * count + 1] = m - 1
+        res[i * count + 2] = (m - 1) if i % 2 else 0
+        res[i * count + 3] = 0 if i % 2 else (m - 1)
+    base = pf.RNSBase(moduli)
+    monkeypatch.setenv("PFHE_DISABLE_GARNER", "1")
+    general = pf.RNSBase(moduli)
+    monkeypatch.delenv("PFHE_DISABLE_GARNER")
+    L = base.big_uint_value_len()
+    a, b = np.empty(count * L, np.uint64), np.empty(count * L, np.uint64)
+    base.compose_multiple_values_to(res, a, count)
+    general.compose_multiple_values_to(res, b, count)
+    assert np.array_equal(a, b)
+    for c in list(range(8)) + [count - 1]:
+        assert limbs_to_int(a[c * L:(c + 1) * L]) == crt_compose([int(res[i * count + c]) for i in range(len(moduli))], moduli)
+
+
 @pytest.mark.parametrize("moduli,log_basis,rev", [
     (Q61, 30, None), (Q61, 30, 4), (Q61, 61, None), (Q61, 1, None), (Q61, 7, None),
     ([134215681, 134176769], 7, None), ([134215681, 134176769], 6, None), (Q61[:2], 13, 5),

@@ -81,7 +81,7 @@ def counter_table(prefix, title):
 open(f"{dst}/{tag}_pmc_utilisation.txt", "w").write("\n".join(counter_table(
     "util_", "rocprofv3 --pmc <one counter per pass> -- python3 tools/profile_ntt.py (PFHE_PROFILE_BATCH=2048); averages over launches")) + "\n")
 # ---- external product at the bench shape
-ep = ["tools/perf_extprod.py (batch 1024, default chunk of 64 ciphertexts): " + " | ".join(
+ep = ["tools/perf_extprod.py (batch 1024, default chunk of 128 ciphertexts): " + " | ".join(
     l.strip() for l in open(src + "/ep.log") if "ext-products" in l)]
 stf = newest(src + "/ep_trace/**/*_kernel_stats.csv")
 if stf:
