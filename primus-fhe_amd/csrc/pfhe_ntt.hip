@@ -203,7 +203,7 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
     // tables (3.10 vs 2.94 ms).  The mirror image, 8-byte stores after the last INVERSE pass, pays everywhere it was
     // measured (2^16 inverse 5.08 vs 5.20 ms, 2^14 inverse 0.381 vs 0.412 ms) and is the default below.
     constexpr bool kDirectLoad = !INV && !MUL && Cfg::BPW == 1 && (LOGB - LOGE) >= 6 && !kBlockLeadBarrier &&
-                                 !std::is_same<Hook, NoHook>::value
+                                 !std::is_same<Hook, NoHook>::value && !A::kPacked
 #ifdef PFHE_STAGED_BLOCK_LOADS
                                  && false
 #endif
@@ -337,17 +337,19 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) PFHE_BLOCK_WAVES_ATTR void
 #ifndef PFHE_PIPE_WAVES_ATTR
 #define PFHE_PIPE_WAVES_ATTR  // left to the compiler: 142-145 registers, three waves per SIMD, no spills (waves_per_eu(3,3): 160-168, 8 spilled)
 #endif
-template <class A, bool INV, bool MUL>
-__global__ __launch_bounds__(256) PFHE_PIPE_WAVES_ATTR void ntt_pipe_kernel(
+template <class A, int LOGB, bool INV, bool MUL>
+__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) PFHE_PIPE_WAVES_ATTR void ntt_pipe_kernel(
     u64 *__restrict__ blk_data, u64 blk_total, u64 *__restrict__ str_data, u64 str_total,
     const NttPrime *__restrict__ primes, u32 L, u32 lazy, const u64 *__restrict__ mul, u64 mul_polys) {
-    constexpr int LOGB = 12, K = 4;
-    constexpr u32 log_n = 16, n = 1u << log_n;
+    // words per polynomial = 2^K blocks of 2^LOGB = 16 chunks of TPB columns: block i and chunk i share their limb
+    constexpr int K = 4, TPB = BlockCfg<LOGB>::TPB;
+    static_assert(BlockCfg<LOGB>::BPW == 1 && (1 << LOGB) / TPB == (1 << K), "16 blocks and 16 chunks per polynomial");
+    constexpr u32 log_n = LOGB + K, n = 1u << log_n;
     extern __shared__ __attribute__((aligned(16))) u64 lds_raw[];
     const u64 chunk = blockIdx.x;
     const bool has_str = chunk < str_total;
-    // chunk -> (limb-polynomial, 256 columns): thread t owns column (chunk % 16) * 256 + t, rows k * 4096
-    u64 *__restrict__ sp = str_data + (chunk >> 4) * n + ((chunk & 15) << 8) + threadIdx.x;
+    // chunk -> (limb-polynomial, TPB columns): thread t owns column (chunk % 16) * TPB + t, rows k * 2^LOGB
+    u64 *__restrict__ sp = str_data + (chunk >> 4) * n + (chunk & 15) * TPB + threadIdx.x;
     u64 sx[1 << K][1];
     const auto issue = [&]() {
         if (has_str) {
@@ -708,11 +710,12 @@ void release_overlap_ctx(int dev, OverlapCtx *c) {
 }  // namespace
 
 // the pipelined form of the two-pass transform (ntt_pipe_kernel): tiles + 1 launches on the caller's stream
-template <class A>
+template <class A, int LOGB>
 static int transform_pipelined(const NttPrime *primes, u32 L, u64 *data, u64 npolys, bool inverse, bool lazy,
                                hipStream_t s, int tiles, const u64 *mul, u64 mul_polys) {
-    constexpr u32 log_n = 16;
-    constexpr size_t lds_bytes = (size_t)BlockCfg<12>::LDS_WORDS * sizeof(u64);
+    constexpr u32 log_n = LOGB + 4;
+    constexpr size_t lds_bytes = (size_t)BlockCfg<LOGB>::LDS_WORDS * sizeof(u64);
+    constexpr u32 threads = BlockCfg<LOGB>::THREADS;
     const u64 units = npolys / L;
     for (int k = 0; k <= tiles; ++k) {
         // forward: strided pass of tile k, block pass of tile k-1; inverse: block pass of tile k, strided pass of tile k-1
@@ -723,7 +726,7 @@ static int transform_pipelined(const NttPrime *primes, u32 L, u64 *data, u64 npo
         if (kb >= 0 && kb < tiles) {
             const u64 u0 = units * kb / tiles, u1 = units * (kb + 1) / tiles;
             bptr = data + ((u0 * L) << log_n);
-            bt = ((u1 - u0) * L) << (log_n - 12);
+            bt = ((u1 - u0) * L) << 4;
             // a per-element multiplicand is tiled like the data; a shared one (one unit of L) is not
             if (mul) {
                 mptr = mul_polys == npolys ? mul + ((u0 * L) << log_n) : mul;
@@ -741,15 +744,20 @@ static int transform_pipelined(const NttPrime *primes, u32 L, u64 *data, u64 npo
             set_last_error("batch too large for one launch");
             return PFHE_ERR_BAD_LENGTH;
         }
-        if (inverse && mul)
-            hipLaunchKernelGGL((ntt_pipe_kernel<A, true, true>), dim3((u32)grid), dim3(256), lds_bytes, s, bptr, bt, sptr, st,
-                               primes, L, lazy ? 1u : 0u, mptr, mp);
-        else if (inverse)
-            hipLaunchKernelGGL((ntt_pipe_kernel<A, true, false>), dim3((u32)grid), dim3(256), lds_bytes, s, bptr, bt, sptr, st,
-                               primes, L, lazy ? 1u : 0u, mptr, mp);
+        if constexpr (!A::kPacked) {
+            if (inverse && mul) {
+                hipLaunchKernelGGL((ntt_pipe_kernel<A, LOGB, true, true>), dim3((u32)grid), dim3(threads), lds_bytes, s, bptr,
+                                   bt, sptr, st, primes, L, lazy ? 1u : 0u, mptr, mp);
+                PFHE_HIP(hipGetLastError());
+                continue;
+            }
+        }
+        if (inverse)
+            hipLaunchKernelGGL((ntt_pipe_kernel<A, LOGB, true, false>), dim3((u32)grid), dim3(threads), lds_bytes, s, bptr, bt,
+                               sptr, st, primes, L, lazy ? 1u : 0u, mptr, mp);
         else
-            hipLaunchKernelGGL((ntt_pipe_kernel<A, false, false>), dim3((u32)grid), dim3(256), lds_bytes, s, bptr, bt, sptr,
-                               st, primes, L, lazy ? 1u : 0u, mptr, mp);
+            hipLaunchKernelGGL((ntt_pipe_kernel<A, LOGB, false, false>), dim3((u32)grid), dim3(threads), lds_bytes, s, bptr, bt,
+                               sptr, st, primes, L, lazy ? 1u : 0u, mptr, mp);
         PFHE_HIP(hipGetLastError());
     }
     return PFHE_OK;
@@ -758,8 +766,11 @@ static int transform_pipelined(const NttPrime *primes, u32 L, u64 *data, u64 npo
 // tiles of the pipelined form for this batch, 0 when the batch does not take it
 static int pipelined_tiles(u32 L, u32 log_n, int pm, u64 npolys, bool inverse, bool has_mul, const NttTuning &tune) {
     const u64 bytes = (npolys << log_n) * sizeof(u64);
-    if (!(tune.pipelined && log_n == 16 && ntt_num_passes(log_n, pm, tune) == 2 && pm != kArithB32 &&
-          (!has_mul || inverse) && npolys % L == 0 && make_ntt_plan(log_n, pm, tune).block_log == 12 &&
+    // 64-bit tables, N = 2^16 = 2^4 x 2^12.  (The u32 tables' 2^15 words = 2^4 x 2^11 fit the same kernel template; measured
+    // 2.858 ms against 2.866-2.874 ms for their two plain launches per 12 288 transforms: not instantiated.)
+    const bool shape = pm != kArithB32 && log_n == 16 && make_ntt_plan(log_n, pm, tune).block_log == 12;
+    if (!(tune.pipelined && shape && ntt_num_passes(log_n, pm, tune) == 2 &&
+          (!has_mul || inverse) && npolys % L == 0 &&
           bytes >= (tune.pipelined_min_mb ? (u64)tune.pipelined_min_mb << 20 : kPipelinedMinBytes)))
         return 0;
     int pt = tune.overlap_tiles ? tune.overlap_tiles : kOverlapTiles;
@@ -793,8 +804,8 @@ static int transform(const NttPrime *primes, u32 L, u32 log_n, int pm, u64 *data
         const int pt = pipelined_tiles(L, log_n, pm, npolys, inverse, mul != nullptr, tune);
         if (pt >= 1)
             return pm == kArithPm
-                       ? transform_pipelined<PmArith>(primes, L, data, npolys, inverse, lazy, s, pt, mul, mul_polys)
-                       : transform_pipelined<ShoupArith>(primes, L, data, npolys, inverse, lazy, s, pt, mul, mul_polys);
+                       ? transform_pipelined<PmArith, 12>(primes, L, data, npolys, inverse, lazy, s, pt, mul, mul_polys)
+                       : transform_pipelined<ShoupArith, 12>(primes, L, data, npolys, inverse, lazy, s, pt, mul, mul_polys);
     }
     int dev = 0;
     // (the u32 tables do not gain from the overlap: measured 3.40 ms vs 3.15 ms without, N = 2^16)

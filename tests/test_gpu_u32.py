@@ -152,16 +152,26 @@ def test_u32_monomials(pf, orc, log_n):
         t.transform_monomial(q, 1, out)
 
 
-def test_u32_full_batch_round_trip_properties(pf, orc):
-    """N = 2^16, 3 primes, 1024 RNS polynomials (768 MiB): round trip + linearity + oracle spot checks."""
+def test_u32_full_batch_round_trip_properties(pf, orc, monkeypatch):
+    """N = 2^16, 3 primes, 1024 RNS polynomials (768 MiB): round trip + oracle spot checks; the transform switches
+    that 64-bit tables react to at this size must not change a u32 table's results."""
     import torch
     log_n, batch = 16, 1024
     n, L = 1 << log_n, 3
     t, o = pf.U32DcrtTable(log_n, Q30), orc.U32DcrtTable(log_n, Q30)
+    monkeypatch.setenv("PFHE_DISABLE_PIPELINED", "1")
+    t_plain = pf.U32DcrtTable(log_n, Q30)
+    monkeypatch.delenv("PFHE_DISABLE_PIPELINED")
     x = torch.empty(batch * L * n, dtype=torch.int32, device="cuda")
     t.fill_uniform_dev(x, 0x5EED_0000_0000_0032)
     orig = x.clone()
     t.transform_dev(x)
+    y = orig.clone()
+    t_plain.transform_dev(y)
+    assert torch.equal(x, y)
+    t_plain.inverse_transform_dev(y)
+    assert torch.equal(y, orig)
+    del y
     for e in (0, 511, 1023):
         s = slice(e * L * n, (e + 1) * L * n)
         ref = to_host32(orig[s]).copy(); o.transform_slice(ref)
