@@ -306,7 +306,7 @@ def main():
         "value": world * ep_batch / dte, "unit": "RLWE external products/s (CrtGlwe x DcrtGgsw -> coefficient form), "
                                                  "whole job", "n_gpus": world,
         "batch_per_gpu": ep_batch, "ms_per_batch": dte * 1e3, "gadget": {"log_basis": 30, "ell": 6, "k": 1},
-        "ggsw": "one shared 36 MiB DcrtGgsw per GPU", "chunk": args.ext_chunk or "default (64 at this shape)",
+        "ggsw": "one shared 36 MiB DcrtGgsw per GPU", "chunk": args.ext_chunk or "default (128 at this shape)",
         "hbm_roofline_frac": ep_batch / dte * 96 * n / (HBM_PEAK_GBS * 1e9),
         "limb_ntts_per_product": 42}
     # kernel groups of the product, HIP events on the launch stream (rank 0): which one dominates, and its share of
