@@ -182,16 +182,17 @@ def pmc_traffic(kernel: str, batch: int):
             rows = json.load(open(path))["kernels"]
         except Exception:
             continue
-        want = "ntt_pipe_kernel" if "pipe" in kernel else "ntt_block_kernel" if "block" in kernel else "ntt_strided_kernel"
+        want = ("ntt_pipe_" if "pipe" in kernel else "ntt_block_kernel" if "block" in kernel else "ntt_strided_kernel")
         inv = "inv" in kernel
-        if want == "ntt_pipe_kernel":  # <A, INV, MUL>: tiles + 1 launches per transform, three grid sizes
+        if want == "ntt_pipe_":  # ntt_pipe_fwd_kernel<A, LOGB> / ntt_pipe_inv_kernel<A, LOGB, MUL>: tiles + 1 launches
             sel = []
             for r in rows:
                 k = r["kernel"]
-                if want not in k or r.get("hbm_bytes_per_launch") is None or "<" not in k or not r.get("launches"):
+                if (("ntt_pipe_inv_kernel" if inv else "ntt_pipe_fwd_kernel") not in k or "<" not in k
+                        or r.get("hbm_bytes_per_launch") is None or not r.get("launches")):
                     continue
                 targs = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]
-                if (targs[1] == "true") == inv and targs[2] == "false":
+                if targs[0] == "PmArith" and (not inv or targs[2] == "false"):
                     sel.append(r)
             tile_units = -(-batch // 12)
             if sel and max(r["grid_size"] for r in sel) == tile_units * 3 * 16 * 256:
@@ -389,7 +390,7 @@ def main():
                               "integer ALU and its LDS / twiddle traffic (profiles/r02_*), not HBM"}
         result["kernels_ms"] = {k: v for k, v in per_pass}
         form, launches = table.transform_form(words)
-        if form.startswith("ntt_pipe_kernel"):
+        if form.startswith("ntt_pipe_"):
             # The timed step is tiles + 1 back-to-back launches of ONE kernel (block pass of tile k-1 and strided pass of
             # tile k in each workgroup): time them as the step does, HIP events on the launch stream.  One launch's
             # algorithmic bytes = the transform's 16*N bytes per limb-polynomial over the launches (each coefficient is

@@ -421,7 +421,7 @@ const char *pfhe_dcrt_transform_pass_name(const pfhe_dcrt *table, int inverse, i
 int pfhe_dcrt_transform_pass_dev(const pfhe_dcrt *table, uint64_t *poly_dev, size_t len, int inverse,
                                  int index, int lazy, void *stream);
 /* How pfhe_dcrt_transform_dev / pfhe_dcrt_inverse_transform_dev will run `len` words: the kernel (or form) name and
- * the number of kernel launches.  Large batches of N = 2^16 run as tiles + 1 launches of ntt_pipe_kernel (block pass of
+ * the number of kernel launches.  Large batches of N = 2^16 run as tiles + 1 launches of ntt_pipe_{fwd,inv}_kernel (block pass of
  * one tile and strided pass of the next in each workgroup), not as the per-pass kernels above. */
 int pfhe_dcrt_transform_form(const pfhe_dcrt *table, size_t len, int inverse, char *name, size_t cap,
                              int *launches);

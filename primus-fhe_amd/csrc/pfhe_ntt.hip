@@ -217,8 +217,12 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
             x[k] = valid ? __builtin_nontemporal_load(gptr + ((u32)k << (LOGB - LOGE)) + lt) : 0ull;
         PFHE_STAMP(1);
         PFHE_STAMP(2);
+#ifdef PFHE_PIPE_LATE_LOADS
+        block_forward_core<A, LOGB, false, LOGE, Hook>(ar, x, lds, n, eblk, lt, lazy != 0, after_stage);
+#else
         after_stage();
         block_forward_core<A, LOGB, false, LOGE>(ar, x, lds, n, eblk, lt, lazy != 0);
+#endif
         PFHE_STAMP(8);
         lds_put_layout<0, LOGE>(x, lds, lt);
         __syncthreads();
@@ -334,11 +338,14 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) PFHE_BLOCK_WAVES_ATTR void
 // (strided first); inverse: A = tile k, B = tile k-1 (block first).  Both tiles start at a multiple of L polynomials,
 // so block i and chunk i belong to the same limb (16 blocks and 16 chunks per limb-polynomial).
 // ------------------------------------------------------------------------------------------
-#ifndef PFHE_PIPE_WAVES_ATTR
-#define PFHE_PIPE_WAVES_ATTR  // left to the compiler: 142-145 registers, three waves per SIMD, no spills (waves_per_eu(3,3): 160-168, 8 spilled)
+// Register budgets: the forward instantiations fit 124 registers without spilling when told to aim for four waves per
+// SIMD (5.00-5.01 against 5.06 ms per 12 288 transforms); the inverse ones spill 6 there (5.42 against 5.00 ms) and are
+// left to the compiler: 142 registers, three waves per SIMD.
+#ifndef PFHE_PIPE_FWD_WAVES_ATTR
+#define PFHE_PIPE_FWD_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
 template <class A, int LOGB, bool INV, bool MUL>
-__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) PFHE_PIPE_WAVES_ATTR void ntt_pipe_kernel(
+__device__ __forceinline__ void ntt_pipe_body(
     u64 *__restrict__ blk_data, u64 blk_total, u64 *__restrict__ str_data, u64 str_total,
     const NttPrime *__restrict__ primes, u32 L, u32 lazy, const u64 *__restrict__ mul, u64 mul_polys) {
     // words per polynomial = 2^K blocks of 2^LOGB = 16 chunks of TPB columns: block i and chunk i share their limb
@@ -370,6 +377,19 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) PFHE_PIPE_WAVES_ATTR void 
 #pragma unroll
         for (int k = 0; k < (1 << K); ++k) sp[(u64)k << LOGB] = sx[k][0];
     }
+}
+
+template <class A, int LOGB>
+__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) PFHE_PIPE_FWD_WAVES_ATTR void ntt_pipe_fwd_kernel(
+    u64 *__restrict__ blk_data, u64 blk_total, u64 *__restrict__ str_data, u64 str_total,
+    const NttPrime *__restrict__ primes, u32 L, u32 lazy) {
+    ntt_pipe_body<A, LOGB, false, false>(blk_data, blk_total, str_data, str_total, primes, L, lazy, nullptr, 0);
+}
+template <class A, int LOGB, bool MUL>
+__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) void ntt_pipe_inv_kernel(
+    u64 *__restrict__ blk_data, u64 blk_total, u64 *__restrict__ str_data, u64 str_total,
+    const NttPrime *__restrict__ primes, u32 L, u32 lazy, const u64 *__restrict__ mul, u64 mul_polys) {
+    ntt_pipe_body<A, LOGB, true, MUL>(blk_data, blk_total, str_data, str_total, primes, L, lazy, mul, mul_polys);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -709,7 +729,7 @@ void release_overlap_ctx(int dev, OverlapCtx *c) {
 
 }  // namespace
 
-// the pipelined form of the two-pass transform (ntt_pipe_kernel): tiles + 1 launches on the caller's stream
+// the pipelined form of the two-pass transform (ntt_pipe_{fwd,inv}_kernel): tiles + 1 launches on the caller's stream
 template <class A, int LOGB>
 static int transform_pipelined(const NttPrime *primes, u32 L, u64 *data, u64 npolys, bool inverse, bool lazy,
                                hipStream_t s, int tiles, const u64 *mul, u64 mul_polys) {
@@ -746,18 +766,18 @@ static int transform_pipelined(const NttPrime *primes, u32 L, u64 *data, u64 npo
         }
         if constexpr (!A::kPacked) {
             if (inverse && mul) {
-                hipLaunchKernelGGL((ntt_pipe_kernel<A, LOGB, true, true>), dim3((u32)grid), dim3(threads), lds_bytes, s, bptr,
-                                   bt, sptr, st, primes, L, lazy ? 1u : 0u, mptr, mp);
+                hipLaunchKernelGGL((ntt_pipe_inv_kernel<A, LOGB, true>), dim3((u32)grid), dim3(threads), lds_bytes, s, bptr, bt,
+                                   sptr, st, primes, L, lazy ? 1u : 0u, mptr, mp);
                 PFHE_HIP(hipGetLastError());
                 continue;
             }
         }
         if (inverse)
-            hipLaunchKernelGGL((ntt_pipe_kernel<A, LOGB, true, false>), dim3((u32)grid), dim3(threads), lds_bytes, s, bptr, bt,
+            hipLaunchKernelGGL((ntt_pipe_inv_kernel<A, LOGB, false>), dim3((u32)grid), dim3(threads), lds_bytes, s, bptr, bt,
                                sptr, st, primes, L, lazy ? 1u : 0u, mptr, mp);
         else
-            hipLaunchKernelGGL((ntt_pipe_kernel<A, LOGB, false, false>), dim3((u32)grid), dim3(threads), lds_bytes, s, bptr, bt,
-                               sptr, st, primes, L, lazy ? 1u : 0u, mptr, mp);
+            hipLaunchKernelGGL((ntt_pipe_fwd_kernel<A, LOGB>), dim3((u32)grid), dim3(threads), lds_bytes, s, bptr, bt, sptr, st,
+                               primes, L, lazy ? 1u : 0u);
         PFHE_HIP(hipGetLastError());
     }
     return PFHE_OK;
@@ -784,7 +804,7 @@ static int pipelined_tiles(u32 L, u32 log_n, int pm, u64 npolys, bool inverse, b
 int ntt_transform_form(u32 L, u32 log_n, int arith, u64 npolys, bool inverse, const NttTuning &tune, char *buf, size_t cap) {
     const int pt = pipelined_tiles(L, log_n, arith, npolys, inverse, false, tune);
     if (pt >= 1) {
-        std::snprintf(buf, cap, "ntt_pipe_kernel<%s>", inverse ? "inv" : "fwd");
+        std::snprintf(buf, cap, inverse ? "ntt_pipe_inv_kernel" : "ntt_pipe_fwd_kernel");
         return pt + 1;
     }
     const int passes = ntt_num_passes(log_n, arith, tune);

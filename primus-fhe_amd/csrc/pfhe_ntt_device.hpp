@@ -760,8 +760,13 @@ __device__ __forceinline__ void lds_exchange(u64 (&x)[1 << LOGE], u64 *__restric
     lds_get_layout<TO, LOGE>(x, lds, lt);
 }
 
-template <class A, int LOGB, int POS, bool FIRST = false, int LOGE = 4>
-__device__ __forceinline__ void fwd_chain(const A &ar, u64 (&x)[1 << LOGE], u64 *__restrict__ lds, u32 n, u32 eblk, u32 lt) {
+struct NoLateHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+// before_last runs in front of the last register pass (the pipelined kernel may issue its strided chunk's loads there)
+template <class A, int LOGB, int POS, bool FIRST = false, int LOGE = 4, class Late = NoLateHook>
+__device__ __forceinline__ void fwd_chain(const A &ar, u64 (&x)[1 << LOGE], u64 *__restrict__ lds, u32 n, u32 eblk, u32 lt,
+                                          Late before_last = Late()) {
     constexpr bool UNI = BlockCfg<LOGB, LOGE>::TPB >= 64;  // a wave never straddles two blocks
     if constexpr (POS > 0) {
         constexpr int NPOS = POS >= LOGE ? POS - LOGE : 0;
@@ -770,27 +775,28 @@ __device__ __forceinline__ void fwd_chain(const A &ar, u64 (&x)[1 << LOGE], u64 
 #ifdef PFHE_STAMPS
         PFHE_STAMP(NPOS == 0 ? 6 : 4);
 #endif
+        if constexpr (NPOS == 0) before_last();
         fwd_regpass<A, NPOS, JHI, 0, UNI, LOGE>(ar, x, n + eblk + layout<NPOS, LOGE>(lt, 0), n);
 #ifdef PFHE_STAMPS
         PFHE_STAMP(NPOS == 0 ? 7 : 5);
 #endif
-        fwd_chain<A, LOGB, NPOS, false, LOGE>(ar, x, lds, n, eblk, lt);
+        fwd_chain<A, LOGB, NPOS, false, LOGE, Late>(ar, x, lds, n, eblk, lt, before_last);
     }
 }
 
 // forward compute core: x holds layout<LOGB-LOGE> on entry and layout<0> (canonical unless lazy) on exit
 // LEAD = false: the caller filled x by lds_get_layout<LOGB-LOGE> from this LDS region (so the first exchange, too,
 // only overwrites slots its own thread read last) and needs no barrier in front of it.
-template <class A, int LOGB, bool LEAD = true, int LOGE = 4>
+template <class A, int LOGB, bool LEAD = true, int LOGE = 4, class Late = NoLateHook>
 __device__ __forceinline__ void block_forward_core(const A &ar, u64 (&x)[1 << LOGE], u64 *__restrict__ lds, u32 n,
-                                                   u32 eblk, u32 lt, bool lazy) {
+                                                   u32 eblk, u32 lt, bool lazy, Late before_last = Late()) {
     constexpr int POS0 = LOGB - LOGE, E = 1 << LOGE;
     constexpr bool UNI = BlockCfg<LOGB, LOGE>::TPB >= 64;  // a wave never straddles two blocks
     fwd_regpass<A, POS0, LOGE - 1, 0, UNI, LOGE>(ar, x, n + eblk + layout<POS0, LOGE>(lt, 0), n);
 #ifdef PFHE_STAMPS
     PFHE_STAMP(3);
 #endif
-    fwd_chain<A, LOGB, POS0, LEAD, LOGE>(ar, x, lds, n, eblk, lt);
+    fwd_chain<A, LOGB, POS0, LEAD, LOGE, Late>(ar, x, lds, n, eblk, lt, before_last);
     if constexpr (A::kPacked) {  // distance-1 stage between the halves of each word
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = ar.fwd_intra(x[k], n + eblk + layout<0, LOGE>(lt, k));

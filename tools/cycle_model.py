@@ -32,7 +32,7 @@ COST = {"half": 2.51, "half_sgpr": 4.28, "full": 4.28, "carry": 4.41}
 KERNELS = {
     "block": ("ntt_block_kernelINS_7PmArithELi12ELb0ELb0E", "block pass, forward (12 stages on 2^12 coefficients)"),
     "strided": ("ntt_strided_kernelINS_7PmArithELi4ELi2ELb0ELb0E", "strided pass, forward (4 stages, 2 columns per thread)"),
-    "pipe": ("ntt_pipe_kernelINS_7PmArithELb0ELb0E", "pipelined kernel, forward (block pass + one-column strided pass)"),
+    "pipe": ("ntt_pipe_fwd_kernelINS_7PmArithELi12E", "pipelined kernel, forward (block pass + one-column strided pass)"),
 }
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Forward / inverse RNS NTT at the bench shape: two-stream tiled transform against the pipelined single-stream form
-(PFHE_PIPELINED, ntt_pipe_kernel) for several tile counts.  Switches are read when a table is created."""
+(PFHE_PIPELINED, ntt_pipe_{fwd,inv}_kernel) for several tile counts.  Switches are read when a table is created."""
 import ctypes as C
 import os
 import sys

@@ -13,7 +13,7 @@ import ctypes as C
 import os
 import sys
 
-# t runs the default form (large batches of N = 2^16: ntt_pipe_kernel, tiles + 1 launches); t_plain runs one launch per
+# t runs the default form (large batches of N = 2^16: ntt_pipe_{fwd,inv}_kernel, tiles + 1 launches); t_plain runs one launch per
 # pass over the whole batch, so that per-launch counters refer to the same launch shape as bench.py's per-kernel
 # timing leg
 
