@@ -217,12 +217,9 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
             x[k] = valid ? __builtin_nontemporal_load(gptr + ((u32)k << (LOGB - LOGE)) + lt) : 0ull;
         PFHE_STAMP(1);
         PFHE_STAMP(2);
-#ifdef PFHE_PIPE_LATE_LOADS
-        block_forward_core<A, LOGB, false, LOGE, Hook>(ar, x, lds, n, eblk, lt, lazy != 0, after_stage);
-#else
+        // (forward: issuing them in front of the last register pass instead — the per-lane-twiddle one — costs 152 registers)
         after_stage();
         block_forward_core<A, LOGB, false, LOGE>(ar, x, lds, n, eblk, lt, lazy != 0);
-#endif
         PFHE_STAMP(8);
         lds_put_layout<0, LOGE>(x, lds, lt);
         __syncthreads();
@@ -268,7 +265,11 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
     lds_put_vectors<LOGB, LOGE>(io, lds, lt);
     __syncthreads();
     PFHE_STAMP(2);  // staged
-    after_stage();
+    // (inverse: the hook runs in front of the LAST register pass instead — uniform twiddles, the fewest live registers —
+    // so that the pipelined kernel's 32 registers of prefetched strided data do not sit through the per-lane-twiddle
+    // passes: 128 registers without spills, four waves per SIMD; 4.98 against 5.05 ms per 12 288 inverse transforms,
+    // 10.33 against 10.64 ms for NTT -> mul -> INTT)
+    if constexpr (!INV) after_stage();
     if constexpr (!INV) {
         lds_get_layout<LOGB - LOGE, LOGE>(x, lds, lt);
         block_forward_core<A, LOGB, kBlockLeadBarrier, LOGE>(ar, x, lds, n, eblk, lt, lazy != 0);
@@ -277,7 +278,7 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
         lds_put_layout<0, LOGE>(x, lds, lt);
     } else {
         lds_get_layout<0, LOGE>(x, lds, lt);
-        block_inverse_core<A, LOGB, kBlockLeadBarrier, LOGE>(ar, x, lds, n, eblk, lt, log_n == LOGB, lazy != 0);
+        block_inverse_core<A, LOGB, kBlockLeadBarrier, LOGE, Hook>(ar, x, lds, n, eblk, lt, log_n == LOGB, lazy != 0, after_stage);
         // mirror of the forward direction's direct loads: the last inverse pass leaves register k of thread lt =
         // element (k << POS0) + lt, stored as 8-byte words (512 contiguous bytes per wave instruction)
         constexpr bool kDirectStore = Cfg::BPW == 1 && (LOGB - LOGE) >= 6 && !kBlockLeadBarrier && !A::kPacked
@@ -338,9 +339,10 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) PFHE_BLOCK_WAVES_ATTR void
 // (strided first); inverse: A = tile k, B = tile k-1 (block first).  Both tiles start at a multiple of L polynomials,
 // so block i and chunk i belong to the same limb (16 blocks and 16 chunks per limb-polynomial).
 // ------------------------------------------------------------------------------------------
-// Register budgets: the forward instantiations fit 124 registers without spilling when told to aim for four waves per
-// SIMD (5.00-5.01 against 5.06 ms per 12 288 transforms); the inverse ones spill 6 there (5.42 against 5.00 ms) and are
-// left to the compiler: 142 registers, three waves per SIMD.
+// Register budgets: both directions run at four waves per SIMD without spilling — the forward instantiations in 124
+// registers (5.00-5.01 against 5.06 ms per 12 288 transforms at three waves), the inverse ones in 128 once the strided
+// chunk's loads are issued in front of the block pass's LAST register pass (block_pass_body; issued after the staging
+// they spill 6 registers there: 5.42 ms).
 #ifndef PFHE_PIPE_FWD_WAVES_ATTR
 #define PFHE_PIPE_FWD_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
@@ -385,8 +387,11 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) PFHE_PIPE_FWD_WAVES_ATTR v
     const NttPrime *__restrict__ primes, u32 L, u32 lazy) {
     ntt_pipe_body<A, LOGB, false, false>(blk_data, blk_total, str_data, str_total, primes, L, lazy, nullptr, 0);
 }
+#ifndef PFHE_PIPE_INV_WAVES_ATTR
+#define PFHE_PIPE_INV_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
 template <class A, int LOGB, bool MUL>
-__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) void ntt_pipe_inv_kernel(
+__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) PFHE_PIPE_INV_WAVES_ATTR void ntt_pipe_inv_kernel(
     u64 *__restrict__ blk_data, u64 blk_total, u64 *__restrict__ str_data, u64 str_total,
     const NttPrime *__restrict__ primes, u32 L, u32 lazy, const u64 *__restrict__ mul, u64 mul_polys) {
     ntt_pipe_body<A, LOGB, true, MUL>(blk_data, blk_total, str_data, str_total, primes, L, lazy, mul, mul_polys);

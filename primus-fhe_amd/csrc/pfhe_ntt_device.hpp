@@ -818,9 +818,10 @@ __device__ __forceinline__ void block_forward_core(const A &ar, u64 (&x)[1 << LO
     }
 }
 
-template <class A, int LOGB, int POS, bool FIRST = false, int LOGE = 4>
+// before_last runs in front of the last register pass (uniform twiddles: the pass with the fewest live registers)
+template <class A, int LOGB, int POS, bool FIRST = false, int LOGE = 4, class Late = NoLateHook>
 __device__ __forceinline__ void inv_chain(const A &ar, u64 (&x)[1 << LOGE], u64 *__restrict__ lds, u32 n, u32 eblk, u32 lt,
-                                          bool final_block, bool lazy) {
+                                          bool final_block, bool lazy, Late before_last = Late()) {
     constexpr bool UNI = BlockCfg<LOGB, LOGE>::TPB >= 64;  // a wave never straddles two blocks
     constexpr int DONE = POS + LOGE;  // element bits already processed
     if constexpr (DONE < LOGB) {
@@ -828,22 +829,24 @@ __device__ __forceinline__ void inv_chain(const A &ar, u64 (&x)[1 << LOGE], u64 
         constexpr int JLO = DONE - NPOS;
         constexpr bool LAST = NPOS + LOGE >= LOGB;
         lds_exchange<POS, NPOS, FIRST, LOGE>(x, lds, lt);
+        if constexpr (LAST) before_last();
         inv_regpass<A, NPOS, JLO, LOGE - 1, UNI, LOGE>(ar, x, n, eblk + layout<NPOS, LOGE>(lt, 0), LAST && final_block, lazy);
-        inv_chain<A, LOGB, NPOS, false, LOGE>(ar, x, lds, n, eblk, lt, final_block, lazy);
+        inv_chain<A, LOGB, NPOS, false, LOGE, Late>(ar, x, lds, n, eblk, lt, final_block, lazy, before_last);
     }
 }
 
 // inverse compute core: x holds layout<0> on entry and layout<LOGB-LOGE> on exit
-template <class A, int LOGB, bool LEAD = true, int LOGE = 4>
+// before_last: see inv_chain
+template <class A, int LOGB, bool LEAD = true, int LOGE = 4, class Late = NoLateHook>
 __device__ __forceinline__ void block_inverse_core(const A &ar, u64 (&x)[1 << LOGE], u64 *__restrict__ lds, u32 n,
-                                                   u32 eblk, u32 lt, bool final_block, bool lazy) {
+                                                   u32 eblk, u32 lt, bool final_block, bool lazy, Late before_last = Late()) {
     constexpr bool UNI = BlockCfg<LOGB, LOGE>::TPB >= 64;  // a wave never straddles two blocks
     if constexpr (A::kPacked) {
 #pragma unroll
         for (int k = 0; k < (1 << LOGE); ++k) x[k] = ar.inv_intra(x[k], n, eblk + layout<0, LOGE>(lt, k));
     }
     inv_regpass<A, 0, 0, LOGE - 1, UNI, LOGE>(ar, x, n, eblk + layout<0, LOGE>(lt, 0), LOGB == LOGE && final_block, lazy);
-    inv_chain<A, LOGB, 0, LEAD, LOGE>(ar, x, lds, n, eblk, lt, final_block, lazy);
+    inv_chain<A, LOGB, 0, LEAD, LOGE, Late>(ar, x, lds, n, eblk, lt, final_block, lazy, before_last);
 }
 
 // ---- coalesced block I/O: E/2 16-byte vectors per thread in natural order (vector v = elements
