@@ -85,15 +85,26 @@ __global__ __launch_bounds__(LOGE == 3 ? 512 : 256, LOGE == 3 ? PFHE_MULACC8_MIN
 
     for (u32 ij = 0; ij < terms; ++ij) {
         u64x2 io[NV];
+        u64 x[1 << LOGE];
+#ifndef PFHE_MULACC_STAGED_LOADS
+        // (19.4-19.6 against 19.9 ms per 1024 products with the staged 16-byte loads of the #else branch)
+        // the first register pass wants register k = element (k << POS0) + lt: 8-byte loads deliver it without staging
+        // (512 contiguous bytes per wave instruction); the first exchange then needs its leading barrier, because other
+        // threads may still be reading the previous term's natural-order image
+#pragma unroll
+        for (int k = 0; k < (1 << LOGE); ++k)
+            x[k] = __builtin_nontemporal_load(dg + (u64)ij * W + ((u32)k << (LOGB - LOGE)) + lt);
+        block_forward_core<A, LOGB, true, LOGE>(ar, x, lds, n, eblk, lt, /*lazy=*/true);  // digit_hat mod~ q
+#else
         load_block_vectors<LOGB, LOGE>(io, dg + (u64)ij * W, lt);
         // (no barrier: these are the slots this thread read with lds_get_vectors at the end of the previous iteration)
         lds_put_vectors<LOGB, LOGE>(io, lds, lt);
         __syncthreads();
-        u64 x[1 << LOGE];
         lds_get_layout<LOGB - LOGE, LOGE>(x, lds, lt);
         // (no barrier in front of the first exchange or of the write-back: in both a thread overwrites exactly the
         // LDS slots it read last — pfhe_ntt_device.hpp, lds_exchange)
         block_forward_core<A, LOGB, false, LOGE>(ar, x, lds, n, eblk, lt, /*lazy=*/true);  // digit_hat mod~ q
+#endif
         lds_put_layout<0, LOGE>(x, lds, lt);
         __syncthreads();
         lds_get_vectors<LOGB, LOGE>(io, lds, lt);  // natural order again: same positions as the key vectors
