@@ -72,6 +72,9 @@ __global__ __launch_bounds__(LOGE == 3 ? 512 : 256, LOGE == 3 ? PFHE_MULACC8_MIN
     u64 *__restrict__ out = result + e * NC * W + limb_off;
 
     constexpr int NV = 1 << (LOGE - 1);  // 16-byte vectors per thread
+    // (accumulators in the layout the transform ends in, the key read as each thread's own run of 16-byte pieces and ONE
+    // transposition per output at the end instead of one per term: 20.1 against 19.5 ms per 1024 products — the key
+    // reads, 64 pieces 64 bytes apart per wave instruction, cost more than the LDS trips they save)
     u64x2 acc[NC][NV];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
