@@ -7,7 +7,7 @@ The three kernels are straight-line code per workgroup (no loops: every stage is
 dynamic counts; the few instructions on not-taken paths (`valid` guards) are counted too (< 1 %).  The backward jumps
 the pipelined kernel shows are the block layout of its `valid` / `has_str` guards (each executed once), not loops.
 
-    python tools/cycle_model.py [--ms block=3.19,strided=2.16,pipe=0.397] > profiles/r02_cycle_model.txt
+    python tools/cycle_model.py [--ms block=3.17,strided=2.18,pipe=0.563 --clocks block=2.10,strided=2.21,pipe=1.98] > profiles/r02_cycle_model.txt
 """
 import argparse
 import collections
@@ -69,6 +69,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ms", default="", help="measured durations, e.g. block=3.19,strided=2.16,pipe=0.397")
     ap.add_argument("--clock-ghz", type=float, default=2.4)
+    ap.add_argument("--pipe-launches", type=int, default=9, help="launches of the pipelined kernel per transform (tiles + 1)")
     ap.add_argument("--clocks", default="", help="sustained shader clock per kernel in GHz (tools/microbench8_clock.hip), "
                                                  "e.g. block=2.10,strided=2.21,pipe=1.98")
     args = ap.parse_args()
@@ -126,7 +127,7 @@ def main():
             ms = ms * args.clock_ghz / clocks[key]
             line += f", {ms:.3f} ms at the sustained {clocks[key]} GHz"
         if key in measured:
-            tot = measured[key] * (13 if key == "pipe" else 1)
+            tot = measured[key] * (args.pipe_launches if key == "pipe" else 1)
             line += f";  measured {tot:.3f} ms -> {ms / tot:.0%} of the time is VALU issue at these costs"
         print(line + "\n")
         if key == "block":
