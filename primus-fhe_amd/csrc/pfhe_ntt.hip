@@ -355,6 +355,9 @@ __device__ __forceinline__ void ntt_pipe_body(
     static_assert(BlockCfg<LOGB>::BPW == 1 && (1 << LOGB) / TPB == (1 << K), "16 blocks and 16 chunks per polynomial");
     constexpr u32 log_n = LOGB + K, n = 1u << log_n;
     extern __shared__ __attribute__((aligned(16))) u64 lds_raw[];
+#ifdef PFHE_STAMPS_FULL_ONLY  // diagnostic build (tools/stamps_pipe.py): only launches with both parts run, so that the
+    if (blk_total == 0 || str_total == 0) return;  // stamps of one full launch survive (results are wrong in this build)
+#endif
     const u64 chunk = blockIdx.x;
     const bool has_str = chunk < str_total;
     // chunk -> (limb-polynomial, TPB columns): thread t owns column (chunk % 16) * TPB + t, rows k * 2^LOGB
@@ -374,10 +377,19 @@ __device__ __forceinline__ void ntt_pipe_body(
     }
     if (has_str) {
         const A ar(primes + (chunk >> 4) % L);
+#ifdef PFHE_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PFHE_STAMP(11);  // the block's stores and the strided chunk's loads have landed
+#endif
         if constexpr (!INV) strided_forward_regs<A, K, 1>(ar, sx, n, 0u, LOGB);
         else strided_inverse_regs<A, K, 1, true>(ar, sx, n, 0u, LOGB, lazy != 0);  // the only strided pass: final stage
+        PFHE_STAMP(12);
 #pragma unroll
         for (int k = 0; k < (1 << K); ++k) sp[(u64)k << LOGB] = sx[k][0];
+#ifdef PFHE_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PFHE_STAMP(13);
+#endif
     }
 }
 

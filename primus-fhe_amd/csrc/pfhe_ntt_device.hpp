@@ -75,7 +75,7 @@ int ntt_pass_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data,
 // Diagnostic build (tools/build_variant.sh stamps -DPFHE_STAMPS): wave 0 of the first workgroups stamps s_memtime at
 // the phase boundaries of the block pass into a device array read back by pfhe_debug_read_stamps.  Never in the
 // product build: the stamps cost ~10 % of the wave's cycles.
-constexpr int kStampSlots = 12, kStampWgs = 1 << 16;
+constexpr int kStampSlots = 14, kStampWgs = 1 << 16;
 static __device__ u64 g_stamps[kStampWgs][kStampSlots];
 #define PFHE_STAMP(i)                                                                          \
     do {                                                                                       \
