@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256, 4) void digits_strided_kernel(const NttPrime *
         strided_forward_regs<A, K, 1>(ar, x, n, 0u, log_s);
         u64 *__restrict__ dst = out + (pl * L + i) * n + col;
 #pragma unroll
-        for (int k = 0; k < RK; ++k) dst[(u64)k << log_s] = x[k][0];
+        for (int k = 0; k < RK; ++k) gstore<true>(dst + ((u64)k << log_s), x[k][0]);
     }
 }
 

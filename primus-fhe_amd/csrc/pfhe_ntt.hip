@@ -124,9 +124,9 @@ __device__ __forceinline__ void strided_pass_body(u64 *__restrict__ data, const 
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         if constexpr (VEC == 2) {
-            *reinterpret_cast<u64x2 *>(ptr + ((u64)k << log_s)) = u64x2{x[k][0], x[k][1]};
+            gstore<false>(reinterpret_cast<u64x2 *>(ptr + ((u64)k << log_s)), u64x2{x[k][0], x[k][1]});
         } else {
-            ptr[(u64)k << log_s] = x[k][0];
+            gstore<false>(ptr + ((u64)k << log_s), x[k][0]);
         }
     }
 }
@@ -178,6 +178,7 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
                                                 u64 mul_polys, u64 *__restrict__ lds_raw, u64 first_block,
                                                 Hook after_stage = Hook()) {
     using Cfg = BlockCfg<LOGB, LOGE>;
+    constexpr bool kNt = !std::is_same<Hook, NoHook>::value;  // the pipelined kernel (large batches): non-temporal stores
     constexpr int NV = Cfg::E / 2;  // 16-byte vectors per thread
     const u32 tid = threadIdx.x;
     const u32 sub = Cfg::BPW == 1 ? 0u : tid / Cfg::TPB;
@@ -225,7 +226,7 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
         __syncthreads();
         PFHE_STAMP(9);
         lds_get_vectors<LOGB, LOGE>(io, lds, lt);
-        if (valid) store_block_vectors<LOGB, LOGE>(io, gptr, lt);
+        if (valid) store_block_vectors<LOGB, LOGE, kNt>(io, gptr, lt);
         PFHE_STAMP(10);
         return;
     }
@@ -233,7 +234,7 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
     // through LDS into / out of the register layouts of the first / last register pass
     PFHE_STAMP(0);
     if (valid) {
-        load_block_vectors<LOGB, LOGE>(io, gptr, lt);
+        load_block_vectors<LOGB, LOGE, kNt>(io, gptr, lt);
     } else {
 #pragma unroll
         for (int j = 0; j < NV; ++j) io[j] = u64x2{0, 0};
@@ -247,7 +248,7 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
         u64x2 mv[NV];
         if (valid) {
             const u64 mpoly = mul_polys == (u64)L ? (u64)limb : pid;
-            load_block_vectors<LOGB, LOGE>(mv, mul + mpoly * n + eblk, lt);
+            load_block_vectors<LOGB, LOGE, kNt>(mv, mul + mpoly * n + eblk, lt);
         } else {
 #pragma unroll
             for (int j = 0; j < NV; ++j) mv[j] = u64x2{0, 0};
@@ -289,7 +290,7 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
         if constexpr (kDirectStore) {
             if (valid) {
 #pragma unroll
-                for (int k = 0; k < Cfg::E; ++k) gptr[((u32)k << (LOGB - LOGE)) + lt] = x[k];
+                for (int k = 0; k < Cfg::E; ++k) gstore<kNt>(gptr + ((u32)k << (LOGB - LOGE)) + lt, x[k]);
             }
             PFHE_STAMP(10);
             return;
@@ -300,7 +301,7 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
     __syncthreads();
     PFHE_STAMP(9);
     lds_get_vectors<LOGB, LOGE>(io, lds, lt);
-    if (valid) store_block_vectors<LOGB, LOGE>(io, gptr, lt);
+    if (valid) store_block_vectors<LOGB, LOGE, kNt>(io, gptr, lt);
 #ifdef PFHE_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -385,7 +386,7 @@ __device__ __forceinline__ void ntt_pipe_body(
         else strided_inverse_regs<A, K, 1, true>(ar, sx, n, 0u, LOGB, lazy != 0);  // the only strided pass: final stage
         PFHE_STAMP(12);
 #pragma unroll
-        for (int k = 0; k < (1 << K); ++k) sp[(u64)k << LOGB] = sx[k][0];
+        for (int k = 0; k < (1 << K); ++k) gstore<true>(sp + ((u64)k << LOGB), sx[k][0]);
 #ifdef PFHE_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PFHE_STAMP(13);

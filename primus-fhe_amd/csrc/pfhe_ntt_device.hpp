@@ -851,18 +851,53 @@ __device__ __forceinline__ void block_inverse_core(const A &ar, u64 (&x)[1 << LO
 
 // ---- coalesced block I/O: E/2 16-byte vectors per thread in natural order (vector v = elements
 //      2v, 2v+1), one full KiB per wave instruction, staged through LDS ----
-template <int LOGB, int LOGE = 4>
+template <int LOGB, int LOGE = 4, bool NT = false>
 __device__ __forceinline__ void load_block_vectors(u64x2 (&v)[1 << (LOGE - 1)], const u64 *gptr, u32 lt) {
     const GCVec2Ptr p = (GCVec2Ptr)(const void *)gptr;
 #pragma unroll
-    for (int j = 0; j < (1 << (LOGE - 1)); ++j) v[j] = p[lt + BlockCfg<LOGB, LOGE>::TPB * j];
+    for (int j = 0; j < (1 << (LOGE - 1)); ++j) {
+#ifndef PFHE_PLAIN_STORES
+        if constexpr (NT) {  // read-once data of a large batch
+            v[j] = __builtin_nontemporal_load(p + lt + BlockCfg<LOGB, LOGE>::TPB * j);
+            continue;
+        }
+#endif
+        v[j] = p[lt + BlockCfg<LOGB, LOGE>::TPB * j];
+    }
 }
 
-template <int LOGB, int LOGE = 4>
+// Global store of transform output, non-temporal where NT: the kernels of LARGE batches (the pipelined transform, the
+// external product's digit polynomials) write every word once and read it again only in a later launch, long after it
+// has left the caches.  Measured against plain stores (-DPFHE_PLAIN_STORES), 12 288 limb-polynomials of 2^16: strided
+// pass 2.09 vs 2.19 ms (6.2 vs 5.9 TB/s), forward transform 4.87 vs 5.06 ms, inverse 4.83 vs 4.99 ms, NTT -> mul -> INTT
+// 10.06 vs 10.33 ms, external product 52.4 vs 51.9 k/s.  Small batches, whose intermediate the next pass finds in the
+// Infinity Cache, keep plain stores (192 MiB: 0.181 ms plain, 0.190 ms non-temporal).
+template <bool NT, class T>
+__device__ __forceinline__ void gstore(T *p, T v) {
+#ifndef PFHE_PLAIN_STORES
+    if constexpr (NT) {
+        __builtin_nontemporal_store(v, p);
+        return;
+    }
+#endif
+    *p = v;
+}
+// (a per-launch choice — `if (flag) non-temporal else plain` — does not survive the compiler: it merges the two stores
+// into a plain one; the choice is a template parameter of the kernels that run large batches only)
+
+template <int LOGB, int LOGE = 4, bool NT = false>
 __device__ __forceinline__ void store_block_vectors(const u64x2 (&v)[1 << (LOGE - 1)], u64 *gptr, u32 lt) {
     const GVec2Ptr p = (GVec2Ptr)(void *)gptr;
 #pragma unroll
-    for (int j = 0; j < (1 << (LOGE - 1)); ++j) p[lt + BlockCfg<LOGB, LOGE>::TPB * j] = v[j];
+    for (int j = 0; j < (1 << (LOGE - 1)); ++j) {
+#ifndef PFHE_PLAIN_STORES
+        if constexpr (NT) {
+            __builtin_nontemporal_store(v[j], p + lt + BlockCfg<LOGB, LOGE>::TPB * j);
+            continue;
+        }
+#endif
+        p[lt + BlockCfg<LOGB, LOGE>::TPB * j] = v[j];
+    }
 }
 
 // vector v = lt + TPB*j holds elements 2v, 2v+1: padded index = lds_phi(2*lt) + constant(j) once 2*TPB is a multiple of 16
