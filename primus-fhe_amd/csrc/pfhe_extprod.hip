@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void gadget_signed_digits_kernel(RnsDev R, Bas
     } else {
         u64 r[2][kMaxLimbs];
         for (u32 i = 0; i < R.L; ++i) {
-            const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(crt + (poly * R.L + i) * n + t);
+            const u64x2 w = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(crt + (poly * R.L + i) * n + t));  // read once
             r[0][i] = w.x;
             r[1][i] = w.y;
         }
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256, 4) void digits_strided_kernel(const NttPrime *
     const int *__restrict__ src = dig + pl * n + col;
     int d[RK];
 #pragma unroll
-    for (int k = 0; k < RK; ++k) d[k] = src[(u64)k << log_s];
+    for (int k = 0; k < RK; ++k) d[k] = __builtin_nontemporal_load(src + ((u64)k << log_s));  // read once
 #pragma unroll 1
     for (u32 i = 0; i < L; ++i) {
         const A ar(primes + i);
