@@ -75,7 +75,7 @@ __global__ void ntt_tiny_kernel(u64 *__restrict__ data, const NttPrime *__restri
 //   inverse: stages with butterfly distance S ... S*2^(K-1); FINAL marks that the top stage is
 //            the last stage of the whole transform (fused N^-1 scaling, table.rs:283-318).
 // ------------------------------------------------------------------------------------------
-template <class A, int K, int VEC, bool INV, bool FINAL>
+template <class A, int K, int VEC, bool INV, bool FINAL, bool NT = false>
 __device__ __forceinline__ void strided_pass_body(u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L,
                                                   u32 log_n, u32 log_s, u64 gid, u64 total_threads, u32 lazy) {
     constexpr int R = 1 << K;
@@ -124,9 +124,9 @@ __device__ __forceinline__ void strided_pass_body(u64 *__restrict__ data, const 
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         if constexpr (VEC == 2) {
-            gstore<false>(reinterpret_cast<u64x2 *>(ptr + ((u64)k << log_s)), u64x2{x[k][0], x[k][1]});
+            gstore<NT>(reinterpret_cast<u64x2 *>(ptr + ((u64)k << log_s)), u64x2{x[k][0], x[k][1]});
         } else {
-            gstore<false>(ptr + ((u64)k << log_s), x[k][0]);
+            gstore<NT>(ptr + ((u64)k << log_s), x[k][0]);
         }
     }
 }
@@ -139,12 +139,13 @@ __device__ __forceinline__ void strided_pass_body(u64 *__restrict__ data, const 
 #ifndef PFHE_STRIDED_MIN_WAVES
 #define PFHE_STRIDED_MIN_WAVES 1
 #endif
-template <class A, int K, int VEC, bool INV, bool FINAL>
+// NT: non-temporal stores (launch_strided picks it for batches of at least kNtMinBytes)
+template <class A, int K, int VEC, bool INV, bool FINAL, bool NT = false>
 __global__ __launch_bounds__(256, K <= 4 ? (VEC == 1 ? 5 : PFHE_STRIDED_MIN_WAVES) : 1) void ntt_strided_kernel(u64 *__restrict__ data,
                                                           const NttPrime *__restrict__ primes, u32 L,
                                                           u32 log_n, u32 log_s, u64 total_threads, u32 lazy) {
-    strided_pass_body<A, K, VEC, INV, FINAL>(data, primes, L, log_n, log_s, (u64)blockIdx.x * blockDim.x + threadIdx.x,
-                                             total_threads, lazy);
+    strided_pass_body<A, K, VEC, INV, FINAL, NT>(data, primes, L, log_n, log_s,
+                                                 (u64)blockIdx.x * blockDim.x + threadIdx.x, total_threads, lazy);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -172,13 +173,15 @@ struct NoHook {
 };
 // after_stage runs once the block's own global loads have landed in LDS (the pipelined kernel issues the loads of its
 // strided chunk there, so that they are in flight during the block's stages and do not delay the block's first wait)
-template <class A, int LOGB, bool INV, bool MUL, int LOGE = 4, class Hook = NoHook>
+template <class A, int LOGB, bool INV, bool MUL, int LOGE = 4, class Hook = NoHook, bool NTIO = false>
 __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L,
                                                 u32 log_n, u64 total_blocks, u32 lazy, const u64 *__restrict__ mul,
                                                 u64 mul_polys, u64 *__restrict__ lds_raw, u64 first_block,
                                                 Hook after_stage = Hook()) {
     using Cfg = BlockCfg<LOGB, LOGE>;
-    constexpr bool kNt = !std::is_same<Hook, NoHook>::value;  // the pipelined kernel (large batches): non-temporal stores
+    // non-temporal stores and staged loads: the pipelined kernel (large batches only) and the NT instantiations that
+    // launch_block picks for batches of at least kNtMinBytes
+    constexpr bool kNt = !std::is_same<Hook, NoHook>::value || NTIO;
     constexpr int NV = Cfg::E / 2;  // 16-byte vectors per thread
     const u32 tid = threadIdx.x;
     const u32 sub = Cfg::BPW == 1 ? 0u : tid / Cfg::TPB;
@@ -323,12 +326,13 @@ __global__ __launch_bounds__(kBlock8Threads<LOGB>) PFHE_BLOCK8_WAVES_ATTR void n
     block_pass_body<A, LOGB, INV, MUL, 3>(data, primes, L, log_n, total_blocks, lazy, mul, mul_polys, lds_raw, blockIdx.x);
 }
 
-template <class A, int LOGB, bool INV, bool MUL = false>
+template <class A, int LOGB, bool INV, bool MUL = false, bool NT = false>
 __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) PFHE_BLOCK_WAVES_ATTR void ntt_block_kernel(
     u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L, u32 log_n, u64 total_blocks, u32 lazy,
     const u64 *__restrict__ mul, u64 mul_polys) {
     extern __shared__ __attribute__((aligned(16))) u64 lds_raw[];
-    block_pass_body<A, LOGB, INV, MUL>(data, primes, L, log_n, total_blocks, lazy, mul, mul_polys, lds_raw, blockIdx.x);
+    block_pass_body<A, LOGB, INV, MUL, 4, NoHook, NT>(data, primes, L, log_n, total_blocks, lazy, mul, mul_polys, lds_raw,
+                                                      blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -429,9 +433,15 @@ constexpr bool use_block8() {
 #endif
 }
 
-template <class A, int LOGB, bool INV, bool MUL = false>
-int launch_block(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys, bool lazy, hipStream_t s,
-                 const u64 *mul = nullptr, u64 mul_polys = 0) {
+// Large batches take the instantiations with non-temporal stores / staged loads (pfhe_ntt_device.hpp, gstore): measured
+// at 4096 polynomials, block pass of 2^12: 3.18 vs 3.25 ms; N = 2^13: 0.48 vs 0.51 ms; N = 2^14 inverse 0.370 vs 0.392 ms;
+// u32 tables 2.90 vs 2.96 ms; strided pass 2.09 vs 2.19 ms.  Small batches, which the next kernel finds in the Infinity
+// Cache, keep the plain forms (192 MiB, two passes: 0.181 ms plain, 0.190 ms non-temporal).
+constexpr u64 kNtMinBytes = 256ull << 20;
+
+template <class A, int LOGB, bool INV, bool MUL, bool NT>
+int launch_block_impl(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys, bool lazy, hipStream_t s,
+                      const u64 *mul, u64 mul_polys) {
     constexpr int LOGE = use_block8<A, LOGB>() ? 3 : 4;
     using Cfg = BlockCfg<LOGB, LOGE>;
     const u64 total_blocks = npolys << (log_n - LOGB);
@@ -444,7 +454,7 @@ int launch_block(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys
     constexpr size_t lds_bytes = (size_t)Cfg::BPW * Cfg::LDS_WORDS * sizeof(u64);
     void (*kern)(u64 *, const NttPrime *, u32, u32, u64, u32, const u64 *, u64);
     if constexpr (LOGE == 3) kern = ntt_block8_kernel<A, LOGB, INV, MUL>;
-    else kern = ntt_block_kernel<A, LOGB, INV, MUL>;
+    else kern = ntt_block_kernel<A, LOGB, INV, MUL, NT>;
     if (lds_bytes > 64 * 1024) {
         static thread_local bool configured[64] = {};
         int dev = 0;
@@ -459,6 +469,16 @@ int launch_block(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys
                        total_blocks, lazy ? 1u : 0u, mul, mul_polys);
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
+}
+
+template <class A, int LOGB, bool INV, bool MUL = false>
+int launch_block(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys, bool lazy, hipStream_t s,
+                 const u64 *mul = nullptr, u64 mul_polys = 0) {
+    if constexpr (LOGB >= 11) {
+        if ((npolys << log_n) * sizeof(u64) >= kNtMinBytes)
+            return launch_block_impl<A, LOGB, INV, MUL, true>(data, primes, L, log_n, npolys, lazy, s, mul, mul_polys);
+    }
+    return launch_block_impl<A, LOGB, INV, MUL, false>(data, primes, L, log_n, npolys, lazy, s, mul, mul_polys);
 }
 
 template <class A, bool INV, bool MUL = false>
@@ -486,8 +506,12 @@ int launch_strided(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u32 log_
         set_last_error("batch too large for one launch");
         return PFHE_ERR_BAD_LENGTH;
     }
-    hipLaunchKernelGGL((ntt_strided_kernel<A, K, VEC, INV, FINAL>), dim3((u32)grid), dim3(256), 0, s, data, primes,
-                       L, log_n, log_s, total, lazy ? 1u : 0u);
+    if (K >= 3 && (npolys << log_n) * sizeof(u64) >= kNtMinBytes)
+        hipLaunchKernelGGL((ntt_strided_kernel<A, K, VEC, INV, FINAL, (K >= 3)>), dim3((u32)grid), dim3(256), 0, s, data,
+                           primes, L, log_n, log_s, total, lazy ? 1u : 0u);
+    else
+        hipLaunchKernelGGL((ntt_strided_kernel<A, K, VEC, INV, FINAL>), dim3((u32)grid), dim3(256), 0, s, data, primes,
+                           L, log_n, log_s, total, lazy ? 1u : 0u);
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
 }
