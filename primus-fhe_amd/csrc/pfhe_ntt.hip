@@ -590,6 +590,7 @@ NttTuning NttTuning::from_env() {
     t.block_log = env_int("PFHE_BLOCK_LOG", 8, 12);
     t.pipelined = std::getenv("PFHE_DISABLE_PIPELINED") == nullptr;
     t.pipelined_min_mb = env_int("PFHE_PIPELINED_MIN_MB", 1, 1 << 20);
+    t.pipe_ramp = env_int("PFHE_PIPE_RAMP", 1, 32);
     return t;
 }
 
@@ -775,11 +776,30 @@ void release_overlap_ctx(int dev, OverlapCtx *c) {
 // the pipelined form of the two-pass transform (ntt_pipe_{fwd,inv}_kernel): tiles + 1 launches on the caller's stream
 template <class A, int LOGB>
 static int transform_pipelined(const NttPrime *primes, u32 L, u64 *data, u64 npolys, bool inverse, bool lazy,
-                               hipStream_t s, int tiles, const u64 *mul, u64 mul_polys) {
+                               hipStream_t s, int tiles, int ramp, const u64 *mul, u64 mul_polys) {
+    if (tiles > 64) tiles = 64;
     constexpr u32 log_n = LOGB + 4;
     constexpr size_t lds_bytes = (size_t)BlockCfg<LOGB>::LDS_WORDS * sizeof(u64);
     constexpr u32 threads = BlockCfg<LOGB>::THREADS;
     const u64 units = npolys / L;
+    // tile boundaries: weights ramp up 1, 2, ... ramp and down again (ramp 1 = equal tiles).  The first and the last
+    // launch run only one pass's worth of work (nothing to overlap with); a ramp makes those two small, and the
+    // surplus of the larger neighbour in the launches between runs beside paired workgroups.
+    u64 cum[66];
+    {
+        u64 wsum = 0, w[65];
+        for (int k = 0; k < tiles; ++k) {
+            const int up = k + 1, down = tiles - k;
+            w[k] = (u64)std::min(std::min(up, down), ramp < 1 ? 1 : ramp);
+            wsum += w[k];
+        }
+        u64 acc = 0;
+        cum[0] = 0;
+        for (int k = 0; k < tiles; ++k) {
+            acc += w[k];
+            cum[k + 1] = units * acc / wsum;
+        }
+    }
     for (int k = 0; k <= tiles; ++k) {
         // forward: strided pass of tile k, block pass of tile k-1; inverse: block pass of tile k, strided pass of tile k-1
         const int kb = inverse ? k : k - 1, ks = inverse ? k - 1 : k;
@@ -787,7 +807,7 @@ static int transform_pipelined(const NttPrime *primes, u32 L, u64 *data, u64 npo
         const u64 *mptr = nullptr;
         u64 bt = 0, st = 0, mp = 0;
         if (kb >= 0 && kb < tiles) {
-            const u64 u0 = units * kb / tiles, u1 = units * (kb + 1) / tiles;
+            const u64 u0 = cum[kb], u1 = cum[kb + 1];
             bptr = data + ((u0 * L) << log_n);
             bt = ((u1 - u0) * L) << 4;
             // a per-element multiplicand is tiled like the data; a shared one (one unit of L) is not
@@ -797,7 +817,7 @@ static int transform_pipelined(const NttPrime *primes, u32 L, u64 *data, u64 npo
             }
         }
         if (ks >= 0 && ks < tiles) {
-            const u64 u0 = units * ks / tiles, u1 = units * (ks + 1) / tiles;
+            const u64 u0 = cum[ks], u1 = cum[ks + 1];
             sptr = data + ((u0 * L) << log_n);
             st = ((u1 - u0) * L) << 4;
         }
@@ -867,8 +887,9 @@ static int transform(const NttPrime *primes, u32 L, u32 log_n, int pm, u64 *data
         const int pt = pipelined_tiles(L, log_n, pm, npolys, inverse, mul != nullptr, tune);
         if (pt >= 1)
             return pm == kArithPm
-                       ? transform_pipelined<PmArith, 12>(primes, L, data, npolys, inverse, lazy, s, pt, mul, mul_polys)
-                       : transform_pipelined<ShoupArith, 12>(primes, L, data, npolys, inverse, lazy, s, pt, mul, mul_polys);
+                       ? transform_pipelined<PmArith, 12>(primes, L, data, npolys, inverse, lazy, s, pt, tune.pipe_ramp, mul, mul_polys)
+                       : transform_pipelined<ShoupArith, 12>(primes, L, data, npolys, inverse, lazy, s, pt, tune.pipe_ramp, mul,
+                                                             mul_polys);
     }
     int dev = 0;
     // (the u32 tables do not gain from the overlap: measured 3.40 ms vs 3.15 ms without, N = 2^16)
