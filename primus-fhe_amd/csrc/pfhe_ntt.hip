@@ -415,83 +415,6 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) PFHE_PIPE_INV_WAVES_ATTR v
 }
 
 // ------------------------------------------------------------------------------------------
-// EXPERIMENT (PFHE_TEAM=1 at table creation; forward, N = 2^16): one persistent launch in which the intermediate of
-// the two-pass plan is handed from the strided pass to the block pass through the XCD's L2 instead of HBM.  Workgroups
-// read HW_REG_XCC_ID and take tickets from THEIR XCD's queue; limb-polynomial p belongs to XCD p % 8.  Ticket t of a
-// queue: phase t / 16 (even: strided chunk t % 16 of the XCD's m-th polynomial, m = phase / 2; odd: block t % 16 of its
-// (m - lag)-th polynomial), so a block ticket only ever waits for strided tickets that were handed out earlier, to
-// workgroups that are running: no co-residency assumption, no deadlock; the wait is bounded anyway and raises
-// ctl->error.  Hand-off: plain stores (they stay in the XCD's L2 and are written through), every storing wave's
-// s_waitcnt vmcnt(0), workgroup barrier, one agent-scope atomic add to done[p]; the consumer polls done[p] and reads the
-// block with non-temporal loads, which bypass the (never refreshed) L1 and are served by the same L2.  This relies on
-// same-XCD L2 behaviour that MI355X_MICROARCH.md describes but HIP does not promise; results are checked bit for bit.
-// ------------------------------------------------------------------------------------------
-struct TeamCtl {
-    u32 ticket[8];
-    u32 error;
-    u32 pad[7];
-    u32 done[1];  // [npolys]
-};
-struct TeamHook {
-    __device__ __forceinline__ void operator()() const {}
-};
-template <class A>
-__global__ __launch_bounds__(256) PFHE_BLOCK_WAVES_ATTR void ntt_team_fwd_kernel(u64 *__restrict__ data,
-                                                                                const NttPrime *__restrict__ primes, u32 L,
-                                                                                u64 npolys, u32 lazy, u32 lag,
-                                                                                TeamCtl *__restrict__ ctl) {
-    constexpr int LOGB = 12, K = 4;
-    constexpr u32 log_n = 16, n = 1u << log_n;
-    extern __shared__ __attribute__((aligned(16))) u64 lds_raw[];
-    u32 *__restrict__ bcast = reinterpret_cast<u32 *>(lds_raw + BlockCfg<LOGB>::LDS_WORDS);
-    u32 xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
-    xcc &= 7u;
-    const u64 mine = npolys > xcc ? (npolys - xcc + 7) / 8 : 0;  // polynomials of this XCD
-    const u64 tickets = 32 * (mine + lag);
-    for (;;) {
-        __syncthreads();  // the previous iteration's readers of bcast / of the LDS image are done
-        if (threadIdx.x == 0) bcast[0] = atomicAdd(&ctl->ticket[xcc], 1u);
-        __syncthreads();
-        const u32 t = bcast[0];
-        if (t >= tickets) break;
-        const u32 phase = t >> 4, part = t & 15;
-        const u64 m = phase >> 1;
-        if ((phase & 1) == 0) {
-            if (m >= mine) continue;
-            const u64 p = m * 8 + xcc;
-            const A ar(primes + p % L);
-            u64 *__restrict__ sp = data + p * n + part * 256 + threadIdx.x;
-            u64 sx[1 << K][1];
-#pragma unroll
-            for (int k = 0; k < (1 << K); ++k) sx[k][0] = __builtin_nontemporal_load(sp + ((u64)k << LOGB));
-            strided_forward_regs<A, K, 1>(ar, sx, n, 0u, LOGB);
-#pragma unroll
-            for (int k = 0; k < (1 << K); ++k) sp[(u64)k << LOGB] = sx[k][0];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_fetch_add(&ctl->done[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            if (m < lag || m - lag >= mine) continue;
-            const u64 p = (m - lag) * 8 + xcc;
-            if (threadIdx.x == 0) {
-                u32 spins = 0;
-                while (__hip_atomic_load(&ctl->done[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 16u) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1u << 22)) {  // bounded: a lost hand-off is an error, never a hang
-                        __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                }
-            }
-            __syncthreads();
-            block_pass_body<A, LOGB, false, false, 4, TeamHook>(data, primes, L, log_n, npolys << 4, lazy, nullptr, 0, lds_raw,
-                                                                p * 16 + part, TeamHook());
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // host-side planner / launchers
 // ------------------------------------------------------------------------------------------
 namespace {
@@ -668,9 +591,6 @@ NttTuning NttTuning::from_env() {
     t.pipelined = std::getenv("PFHE_DISABLE_PIPELINED") == nullptr;
     t.pipelined_min_mb = env_int("PFHE_PIPELINED_MIN_MB", 1, 1 << 20);
     t.pipe_ramp = env_int("PFHE_PIPE_RAMP", 1, 32);
-    t.team = std::getenv("PFHE_TEAM") != nullptr;
-    t.team_lag = env_int("PFHE_TEAM_LAG", 1, 64);
-    t.team_wgs = env_int("PFHE_TEAM_WGS", 1, 4);
     return t;
 }
 
@@ -926,34 +846,6 @@ static int transform_pipelined(const NttPrime *primes, u32 L, u64 *data, u64 npo
     return PFHE_OK;
 }
 
-// EXPERIMENT: see ntt_team_fwd_kernel
-template <class A>
-static int transform_team(const NttPrime *primes, u32 L, u64 *data, u64 npolys, bool lazy, hipStream_t s, int lag, int wgs) {
-    static std::mutex mu;
-    static TeamCtl *ctl[64] = {};
-    static u64 cap[64] = {};
-    int dev = 0;
-    PFHE_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) return PFHE_ERR_UNSUPPORTED;
-    {
-        std::lock_guard<std::mutex> lock(mu);
-        if (cap[dev] < npolys) {
-            if (ctl[dev]) (void)hipFree(ctl[dev]);
-            PFHE_HIP(hipMalloc(reinterpret_cast<void **>(&ctl[dev]), sizeof(TeamCtl) + npolys * sizeof(u32)));
-            cap[dev] = npolys;
-        }
-    }
-    PFHE_HIP(hipMemsetAsync(ctl[dev], 0, sizeof(TeamCtl) + npolys * sizeof(u32), s));
-    hipDeviceProp_t prop;
-    PFHE_HIP(hipGetDeviceProperties(&prop, dev));
-    const u32 grid = (u32)prop.multiProcessorCount * (u32)wgs;
-    const size_t lds_bytes = (size_t)BlockCfg<12>::LDS_WORDS * sizeof(u64) + 16;
-    hipLaunchKernelGGL((ntt_team_fwd_kernel<A>), dim3(grid), dim3(256), lds_bytes, s, data, primes, L, npolys, lazy ? 1u : 0u,
-                       (u32)lag, ctl[dev]);
-    PFHE_HIP(hipGetLastError());
-    return PFHE_OK;
-}
-
 // tiles of the pipelined form for this batch, 0 when the batch does not take it
 static int pipelined_tiles(u32 L, u32 log_n, int pm, u64 npolys, bool inverse, bool has_mul, const NttTuning &tune) {
     const u64 bytes = (npolys << log_n) * sizeof(u64);
@@ -991,12 +883,6 @@ static int transform(const NttPrime *primes, u32 L, u32 log_n, int pm, u64 *data
                      bool lazy, hipStream_t s, const NttTuning &tune, const u64 *mul = nullptr, u64 mul_polys = 0) {
     const int passes = ntt_num_passes(log_n, pm, tune);
     const u64 bytes = (npolys << log_n) * sizeof(u64);
-    if (tune.team && !inverse && mul == nullptr && log_n == 16 && pm != kArithB32 && passes == 2 &&
-        make_ntt_plan(log_n, pm, tune).block_log == 12 && bytes >= kPipelinedMinBytes && !stream_is_capturing(s)) {
-        const int lag = tune.team_lag ? tune.team_lag : 3, wgs = tune.team_wgs ? tune.team_wgs : 4;
-        return pm == kArithPm ? transform_team<PmArith>(primes, L, data, npolys, lazy, s, lag, wgs)
-                              : transform_team<ShoupArith>(primes, L, data, npolys, lazy, s, lag, wgs);
-    }
     {
         const int pt = pipelined_tiles(L, log_n, pm, npolys, inverse, mul != nullptr, tune);
         if (pt >= 1)

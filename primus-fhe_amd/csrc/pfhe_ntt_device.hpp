@@ -31,8 +31,6 @@ struct NttTuning {
     int max_single_pass_log = 0;   // PFHE_MAX_SINGLE_PASS_LOG (0: built-in default)
     int block_log = 0;             // PFHE_BLOCK_LOG: block size under strided passes (0: built-in default)
     bool pipelined = true;         // PFHE_DISABLE_PIPELINED clears it: N = 2^16 runs as tiles + 1 launches of ntt_pipe_kernel on the caller's stream
-    bool team = false;             // PFHE_TEAM (experiment): forward N = 2^16 as one persistent launch with an L2 hand-off
-    int team_lag = 0, team_wgs = 0;  // PFHE_TEAM_LAG (polynomials between a strided and its block phase), PFHE_TEAM_WGS (per CU)
     int pipe_ramp = 0;             // PFHE_PIPE_RAMP: tile weights of the pipelined form ramp 1..ramp..1 (0 / 1: equal tiles)
     int pipelined_min_mb = 0;      // PFHE_PIPELINED_MIN_MB: smallest batch (MiB of data) that takes the pipelined form (0: built-in default)
     static NttTuning from_env();
