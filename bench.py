@@ -415,7 +415,9 @@ def main():
                                   "avg_launch_ms": ms_launch, "launches_per_step": launches,
                                   "algorithmic_bytes_per_launch": alg_bytes / launches,
                                   "note": "the step's only kernel; it moves every coefficient twice (two-pass plan), so "
-                                          "its HBM floor is 2x the algorithmic bytes; stand-alone passes in roofline_passes"}
+                                          "its HBM floor is 2x the algorithmic bytes; it runs AT the 1400 W package power cap "
+                                          "with the shader clock throttled to ~1.9 GHz (profiles/r02_power_probe.txt); "
+                                          "stand-alone passes in roofline_passes"}
             result["roofline_passes"] = standalone
         else:
             result["roofline"] = standalone
