@@ -608,6 +608,37 @@ def test_pipelined_form_single_modulus_lazy_and_ragged_tiles(pf, orc, q):
     del xl
 
 
+@pytest.mark.parametrize("L,batch,tiles,ramp", [(3, 171, 0, 0), (3, 173, 5, 0), (1, 513, 3, 0), (1, 700, 7, 3), (3, 352, 64, 4),
+                                                (2, 257, 0, 2)])
+def test_pipelined_form_tile_arithmetic(pf, L, batch, tiles, ramp, monkeypatch):
+    """Odd batch sizes, tile counts that do not divide them, more tiles than is sensible, ramped tile sizes: the
+    pipelined form must equal the two plain launches bit for bit, forward and inverse (switches are read when a table
+    is created)."""
+    import torch
+    log_n = 16
+    n = 1 << log_n
+    moduli = Q61[:L]
+    if tiles:
+        monkeypatch.setenv("PFHE_OVERLAP_TILES", str(tiles))
+    if ramp:
+        monkeypatch.setenv("PFHE_PIPE_RAMP", str(ramp))
+    t = pf.U64DcrtTable(log_n, moduli)
+    name, launches = t.transform_form(batch * L * n)
+    assert name == "ntt_pipe_fwd_kernel" and launches >= 3
+    monkeypatch.setenv("PFHE_DISABLE_PIPELINED", "1")
+    monkeypatch.setenv("PFHE_DISABLE_OVERLAP", "1")
+    plain = pf.U64DcrtTable(log_n, moduli)
+    assert plain.transform_form(batch * L * n) == ("plain passes", 2)
+    x = _fill(pf, batch * L * n, moduli, n, 1234 + batch)
+    y = x.clone()
+    t.transform_dev(x)
+    plain.transform_dev(y)
+    assert torch.equal(x, y)
+    t.inverse_transform_dev(x)
+    plain.inverse_transform_dev(y)
+    assert torch.equal(x, y)
+
+
 def test_transform_form_reports_the_launch_plan(pf, monkeypatch):
     """pfhe_dcrt_transform_form: what bench.py's roofline object is built from."""
     n, L = 1 << 16, 3
