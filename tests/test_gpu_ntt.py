@@ -689,11 +689,15 @@ def rounds(k):
 rounds(5)                       # torch's caching allocator settles (clone, comparison workspaces)
 free0 = rounds(5)
 free1 = rounds(40)
-assert free0 - free1 < (16 << 20), (free0, free1)
+assert os.environ.get("PFHE_TEST_LEAK_CHECK") == "0" or free0 - free1 < (16 << 20), (free0, free1)
 print("ok")
 """
+    # under xdist other workers allocate device memory while the child measures it: keep the functional check
+    # (results equal the single-stream path's), drop the free-memory comparison
+    leak_check = "0" if os.environ.get("PYTEST_XDIST_WORKER") else "1"
     for fail_after in (0, 3, 7):
-        env = dict(os.environ, PFHE_TEST_FAIL_OVERLAP_CTX=str(fail_after), PFHE_DISABLE_PIPELINED="1")
+        env = dict(os.environ, PFHE_TEST_FAIL_OVERLAP_CTX=str(fail_after), PFHE_DISABLE_PIPELINED="1",
+                   PFHE_TEST_LEAK_CHECK=leak_check)
         env.pop("PFHE_DISABLE_OVERLAP", None)
         r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600,
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -13,8 +13,10 @@ Cost model (tools/microbench5.hip, MI355X, 4 waves per SIMD, cycles per wave-ins
 mov/lshrrev with VGPR or inline operands 2.3; everything else 4.2 (v_mad_u64_u32, v_lshl_add_u64, v_alignbit_b32,
 shifts left, min/max, any 32-bit op with an SGPR operand), v_add_co / v_addc_co 4.4.
 
-    forward, no fold : 5 mad + mov + addc + alignbit + and + 3 lshl_add_u64 + 2 not          = 14 instr, 51 cycles
-    forward, fold    : + lshrrev + and + mov + mad                                           = 18 instr, 62 cycles
+    forward, no fold : 5 mad + mov + addc + alignbit + and + 2 lshl_add_u64 + sub_co + subb  = 13 instr, 51 cycles
+    forward, fold    : + lshrrev + and + mov + mad                                           = 17 instr, 62 cycles
+    (until late in round 2 the tail was not, not, 2 x lshl_add_u64: 14 / 18 instructions for the same cycles — but the
+    kernels run at the package power cap, where an instruction less is worth more than its issue slot)
     inverse          : lshl_add_u64 + (lshrrev, and, mad) + lshl_add_u64 + sub_co + subb + multiply (10) = 18 instr
 
 Run from the repository root:  python tools/gen_pm_asm.py
@@ -34,6 +36,11 @@ SETS = [dict(A=(2, 3), B=(4, 5), E=(6, 7), C=(8, 9), cy="vcc"),
 if os.environ.get("PM_ASM_HIGH_TEMPS"):  # experiment: the first placement tried (forces 128 registers on every kernel)
     SETS = [dict(A=(120, 121), B=(122, 123), E=(124, 125), C=(126, 127), cy="vcc"),
             dict(A=(112, 113), B=(114, 115), E=(116, 117), C=(118, 119), cy="%[cyb]")]
+
+
+# forward y' = X + 3q - T as a 64-bit borrow chain into two 32-bit outputs (3 instructions) instead of not, not, two 64-bit
+# adds (4): one instruction fewer per butterfly (1846 -> 1742 in the block pass); PM_ASM_NOT_ADD=1 restores the old tail
+SUBC = not os.environ.get("PM_ASM_NOT_ADD")
 
 
 def pair(p):
@@ -72,6 +79,14 @@ def fwd_seq(t, s, fold):
     else:
         X = f"%[x{s}]"
     seq += mul_seq(t, s, f"%[y0{s}]", f"%[y1{s}]")
+    if SUBC:
+        seq += [
+            f"v_lshl_add_u64 %[xo{s}], {X}, 0, {pair(A)}",                 # x' = X + T
+            f"v_lshl_add_u64 {pair(B)}, {X}, 0, %[q3]",                    # X + 3q
+            f"v_sub_co_u32_e64 %[yo0{s}], {cy}, v{B[0]}, v{A[0]}",
+            f"v_subb_co_u32_e64 %[yo1{s}], {cy}, v{B[1]}, v{A[1]}, {cy}",  # y' = X + 3q - T, as two halves
+        ]
+        return seq
     seq += [
         f"v_lshl_add_u64 %[xo{s}], {X}, 0, {pair(A)}",                     # x' = X + T
         f"v_not_b32 v{A[0]}, v{A[0]}",
@@ -157,7 +172,10 @@ def gen_fwd(ways, fold, uni):
     lines = interleave([fwd_seq(t, s, fold) for t, s in zip(sets, sfx)])
     outs, ins = [], []
     for s in sfx:
-        outs += [f'[xo{s}] "=&v"(xo{s})', f'[yo{s}] "=&v"(yo{s})']
+        if SUBC:
+            outs += [f'[xo{s}] "=&v"(xo{s})', f'[yo0{s}] "=&v"(yo0{s})', f'[yo1{s}] "=&v"(yo1{s})']
+        else:
+            outs += [f'[xo{s}] "=&v"(xo{s})', f'[yo{s}] "=&v"(yo{s})']
     if ways == 2:
         outs += ['[cyb] "=&s"(cyb)']
     for s in sfx:
@@ -168,7 +186,8 @@ def gen_fwd(ways, fold, uni):
         ins += [f'[y0{s}] "v"((u32)y{s})', f'[y1{s}] "v"((u32)(y{s} >> 32))']
         ins += [f'[w0{s}] "{tc}"((u32)w{s}.w)', f'[w1{s}] "{tc}"((u32)(w{s}.w >> 32))',
                 f'[v0{s}] "{tc}"((u32)w{s}.w2)', f'[v1{s}] "{tc}"((u32)(w{s}.w2 >> 32))']
-    ins += ['[sh1] "s"(ar.sh + 1)', '[m1] "v"(ar.vmask1)', '[c2] "s"(ar.c2)', '[q3p1] "s"(ar.q3 + 1)']
+    ins += ['[sh1] "s"(ar.sh + 1)', '[m1] "v"(ar.vmask1)', '[c2] "s"(ar.c2)',
+            '[q3] "s"(ar.q3)' if SUBC else '[q3p1] "s"(ar.q3 + 1)']
     if fold:
         ins += ['[sh] "v"(ar.vsh)', '[m] "v"(ar.vmask)', '[c] "s"(ar.c)']
     keys = ["A", "B", "E"] + (["C"] if fold else [])
@@ -218,6 +237,8 @@ def main():
         src += (f"template <bool FOLD, bool UNI, class A, class TW>\n__device__ __forceinline__ void pm_fwd_bfly{ways}"
                 f"(const A &ar, {args}) {{\n")
         src += "    " + ", ".join(f"u64 xo{s}, yo{s}" for s in ["a", "b"][:ways]).replace(", u64", "; u64") + ";\n"
+        if SUBC:
+            src += "    u32 " + ", ".join(f"yo0{s}, yo1{s}" for s in ["a", "b"][:ways]) + ";\n"
         if ways == 2:
             src += "    u64 cyb;\n"
         first = True
@@ -229,7 +250,10 @@ def main():
                 first = False
         src = src.rstrip() + "\n"
         for s in ["a", "b"][:ways]:
-            src += f"    x{s} = xo{s};\n    y{s} = yo{s};\n"
+            if SUBC:
+                src += f"    x{s} = xo{s};\n    y{s} = ((u64)yo1{s} << 32) | yo0{s};\n    (void)yo{s};\n"
+            else:
+                src += f"    x{s} = xo{s};\n    y{s} = yo{s};\n"
         src += "}\n\n"
     for ways in (1, 2):
         args = ", ".join(f"u64 &x{s}, u64 &y{s}, TW w{s}" for s in ["a", "b"][:ways])
