@@ -194,7 +194,7 @@ def pmc_traffic(kernel: str, batch: int):
                 targs = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]
                 if targs[0] == "PmArith" and (not inv or targs[2] == "false"):
                     sel.append(r)
-            tile_units = -(-batch // 8)
+            tile_units = -(-batch // 24)
             if sel and max(r["grid_size"] for r in sel) == tile_units * 3 * 16 * 256:
                 launches = sum(r["launches"] for r in sel)
                 return {"bytes_per_launch": sum(r["hbm_bytes_per_launch"] * r["launches"] for r in sel) / launches,

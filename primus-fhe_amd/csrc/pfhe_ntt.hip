@@ -168,6 +168,13 @@ constexpr bool kBlockLeadBarrier = true;
 constexpr bool kBlockLeadBarrier = false;
 #endif
 
+// Stores of the pipelined kernels' INTERMEDIATE (strided pass -> block pass of the next launch; inverse: the other way
+// round): non-temporal, or plain so that tiles small enough stay in the 256 MiB Infinity Cache until they are read.
+#ifdef PFHE_PIPE_NT_INTERMEDIATE
+constexpr bool kPipeIntermediateNt = true;
+#else
+constexpr bool kPipeIntermediateNt = false;
+#endif
 struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
@@ -218,7 +225,11 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
         PFHE_STAMP(0);
 #pragma unroll
         for (int k = 0; k < Cfg::E; ++k)
+#ifdef PFHE_PIPE_PLAIN_BLOCK_LOADS  // experiment (with PFHE_PIPE_STRIDED_PLAIN): plain loads of the intermediate
+            x[k] = valid ? gptr[((u32)k << (LOGB - LOGE)) + lt] : 0ull;
+#else
             x[k] = valid ? __builtin_nontemporal_load(gptr + ((u32)k << (LOGB - LOGE)) + lt) : 0ull;
+#endif
         PFHE_STAMP(1);
         PFHE_STAMP(2);
         // (forward: issuing them in front of the last register pass instead — the per-lane-twiddle one — costs 152 registers)
@@ -293,7 +304,10 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
         if constexpr (kDirectStore) {
             if (valid) {
 #pragma unroll
-                for (int k = 0; k < Cfg::E; ++k) gstore<kNt>(gptr + ((u32)k << (LOGB - LOGE)) + lt, x[k]);
+                // (inside the pipelined inverse kernel this is the INTERMEDIATE: see kPipeIntermediateNt)
+                for (int k = 0; k < Cfg::E; ++k)
+                    gstore<(kNt && (std::is_same<Hook, NoHook>::value || kPipeIntermediateNt))>(
+                        gptr + ((u32)k << (LOGB - LOGE)) + lt, x[k]);
             }
             PFHE_STAMP(10);
             return;
@@ -390,7 +404,8 @@ __device__ __forceinline__ void ntt_pipe_body(
         else strided_inverse_regs<A, K, 1, true>(ar, sx, n, 0u, LOGB, lazy != 0);  // the only strided pass: final stage
         PFHE_STAMP(12);
 #pragma unroll
-        for (int k = 0; k < (1 << K); ++k) gstore<true>(sp + ((u64)k << LOGB), sx[k][0]);
+        // forward: this is the intermediate (kPipeIntermediateNt); inverse: the final output (always non-temporal)
+        for (int k = 0; k < (1 << K); ++k) gstore<(INV || kPipeIntermediateNt)>(sp + ((u64)k << LOGB), sx[k][0]);
 #ifdef PFHE_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PFHE_STAMP(13);
@@ -679,12 +694,15 @@ namespace {
 #endif
 constexpr int kOverlapTiles = PFHE_OVERLAP_TILES_DEFAULT;
 constexpr u64 kOverlapMinBytes = 512ull << 20;  // below this the extra launches do not pay
-// pipelined form: from 256 MiB of data (2^16-point transforms: 512 limb-polynomials), tiles of at least 96 MiB
-// (measured: 384 MiB 0.395 -> 0.369 ms with 4 tiles, 1.5 GiB 1.448 -> 1.395 ms with 12, 6 GiB 5.23 -> 5.15 ms with 12;
-// 96 MiB 0.087 -> 0.096 ms, so smaller batches keep the two plain launches)
+// pipelined form: from 256 MiB of data (2^16-point transforms: 512 limb-polynomials), tiles of 256 MiB = the Infinity
+// Cache, whose share of the intermediate (plain stores, kPipeIntermediateNt) the next launch then reads on-die.  Measured,
+// forward / inverse ms per 6 GiB: 24 tiles 4.60-4.63 / 4.61-4.63, 20 tiles 4.83 / 4.80, 32 tiles 4.68 / 4.68, against
+// 4.72 / 4.64 for 8 tiles with a non-temporal intermediate; 3 GiB: 12 tiles 2.34 ms (8: 2.46); 1.5 GiB: 6 tiles 1.22 ms
+// (12: 1.26); 384 MiB 0.395 -> 0.37 ms against the two plain launches; 96 MiB 0.087 -> 0.096 ms, so smaller batches
+// keep those.
 constexpr u64 kPipelinedMinBytes = 256ull << 20;
-constexpr u64 kPipelinedTileBytes = 96ull << 20;
-constexpr int kPipelinedTiles = 8;  // 6 GiB, forward / inverse ms: 8 tiles 5.05 / 4.94, 12: 5.06 / 4.98, 16: 5.10 / 5.02, 24: 5.17 / 5.10
+constexpr u64 kPipelinedTileBytes = 256ull << 20;
+constexpr int kPipelinedMaxTiles = 64;
 
 struct OverlapCtx {
     hipStream_t a = nullptr, b = nullptr;
@@ -856,8 +874,8 @@ static int pipelined_tiles(u32 L, u32 log_n, int pm, u64 npolys, bool inverse, b
           (!has_mul || inverse) && npolys % L == 0 &&
           bytes >= (tune.pipelined_min_mb ? (u64)tune.pipelined_min_mb << 20 : kPipelinedMinBytes)))
         return 0;
-    int pt = tune.overlap_tiles ? tune.overlap_tiles : kPipelinedTiles;
-    if (!tune.overlap_tiles && (u64)pt > bytes / kPipelinedTileBytes) pt = (int)(bytes / kPipelinedTileBytes);
+    int pt = tune.overlap_tiles ? tune.overlap_tiles
+                                : (int)std::min<u64>((bytes + kPipelinedTileBytes / 2) / kPipelinedTileBytes, (u64)kPipelinedMaxTiles);
     if (pt < 2) pt = 2;
     if ((u64)pt > npolys / L) pt = (int)(npolys / L);
     return pt;

@@ -643,9 +643,9 @@ def test_transform_form_reports_the_launch_plan(pf, monkeypatch):
     """pfhe_dcrt_transform_form: what bench.py's roofline object is built from."""
     n, L = 1 << 16, 3
     t = pf.U64DcrtTable(16, Q61)
-    assert t.transform_form(4096 * L * n) == ("ntt_pipe_fwd_kernel", 9)
-    assert t.transform_form(4096 * L * n, inverse=True) == ("ntt_pipe_inv_kernel", 9)
-    assert t.transform_form(256 * L * n) == ("ntt_pipe_fwd_kernel", 5)      # 384 MiB: 4 tiles of 96 MiB
+    assert t.transform_form(4096 * L * n) == ("ntt_pipe_fwd_kernel", 25)
+    assert t.transform_form(4096 * L * n, inverse=True) == ("ntt_pipe_inv_kernel", 25)
+    assert t.transform_form(256 * L * n) == ("ntt_pipe_fwd_kernel", 3)      # 384 MiB: 2 tiles
     assert t.transform_form(64 * L * n) == ("plain passes", 2)
     assert pf.U64DcrtTable(12, [Q61[0]]).transform_form(1 << 12) == ("plain passes", 1)
     monkeypatch.setenv("PFHE_DISABLE_PIPELINED", "1")
