@@ -40,7 +40,7 @@ d = collections.defaultdict(list)
 for r in csv.DictReader(open(tr)):
     d[(short(r["Kernel_Name"]), grid_of(r))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 lines = ["rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --ext-total 0   (grouped by kernel and grid size:",
-         "the timed steps are 9 launches (8 tiles + 1) of ntt_pipe_fwd_kernel per transform, the stand-alone leg launches full-size passes)",
+         "the timed steps are 25 launches (24 tiles of 256 MiB + 1) of ntt_pipe_fwd_kernel per transform, the stand-alone leg launches full-size passes)",
          f"{'kernel':64s} {'grid':>10s} {'n':>4s} {'avg ms':>8s} {'min ms':>8s} {'max ms':>8s}"]
 out = []
 for (k, g), v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
