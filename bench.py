@@ -35,6 +35,7 @@ if ROOT not in sys.path:
 
 Q61 = [2305843009211596801, 2305843009210023937, 2305843009208713217]
 LOG_N = 16
+SEED_NTT, SEED_CONFIG5, SEED_GGSW = 0x5EED000000000003, 0x5EED000000000005, 99
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
 
 
@@ -51,6 +52,10 @@ def parse_args():
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for the timing barrier "
                     "(nccl = RCCL; gloo + --one-device lets two ranks share one GPU for a plumbing check)")
     ap.add_argument("--one-device", action="store_true", help="debug: every rank uses cuda:0")
+    ap.add_argument("--dump-dir", default="", help="parity aid for tests/test_gpu_shard.py: every rank writes the HIP "
+                    "outputs of its shard (one forward NTT of its RNS polynomials, its config-5 products) as "
+                    "rank<r>.npz into this directory; small --batch / --ext-total only")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py spawns the ranks itself")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -229,11 +234,43 @@ def pmc_traffic(kernel: str, batch: int):
     return None
 
 
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` outside a launcher: start N fresh rank processes (one per GPU, the
+    environment torch.distributed.run would give them) and relay rank 0's JSON line.  Decided before
+    anything in this process touches the GPU; the parent never initialises HIP and never execs."""
+    import socket
+    import subprocess
+
+    if not args.one_device:
+        import torch
+        have = torch.cuda.device_count()  # counting devices does not initialise the GPU
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (use --one-device --dist-backend gloo for a "
+                             "plumbing check on one GPU)" % (args.gpus, have))
+    port = args.master_port
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [pr.wait() for pr in procs]
+    return max((abs(rc) for rc in rcs), default=0)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     import torch
 
@@ -256,13 +293,17 @@ def main():
 
     n, L, batch = 1 << LOG_N, 3, args.batch
     words = batch * L * n
+    dump = {}
     table = p.U64DcrtTable(LOG_N, Q61, device=local_rank)
-    x = torch.empty(words, dtype=torch.int64, device="cuda")
+    ep_batch = min(args.ext_batch, batch)
+    xbuf = torch.empty(max(words, ep_batch * 2 * L * n), dtype=torch.int64, device="cuda")  # also the config-4 input
+    x = xbuf[:words]
     mods = np.array(Q61, np.uint64)
-    check(p.lib().pfhe_fill_uniform_dev(local_rank, C.c_void_p(x.data_ptr()), words, mods.ctypes.data_as(u64p), L, n,
-                                        0x5EED000000000003 + rank, None))
+    from primus_fhe_amd.shard import fill_job_shard, timed_steps
 
-    from primus_fhe_amd.shard import timed_steps
+    # rank r owns RNS polynomials [r*batch, (r+1)*batch) of a job of world*batch: its input depends on the position
+    # in the job only, so the union over ranks is the same job whatever the world size
+    fill_job_shard(p.lib(), local_rank, x.data_ptr(), rank * batch, batch, L * n, Q61, n, SEED_NTT)
 
     def step():
         # forward transform of a canonical batch; the output of one step (canonical, bit-reversed
@@ -288,17 +329,16 @@ def main():
     # ---- config 4 / 5: RNS gadget external product, k=1, logB=30 (ell=6), batch 1024 per GPU, one shared
     #      GGSW replicated per device; every rank runs it, the rate is aggregated over ranks (weak scaling,
     #      no collective on the data path) ----
-    ep_batch = min(args.ext_batch, batch)
     base = p.RNSBase(Q61, device=local_rank)
     basis = p.BigUintApproxSignedBasis(base, 30)
     ctx = p.DcrtGlevContext(table, base, basis, 1, args.ext_chunk)
     glwe_words, ggsw_words = ep_batch * 2 * L * n, ctx.ggsw_len()
-    check(p.lib().pfhe_fill_uniform_dev(local_rank, C.c_void_p(x.data_ptr()), glwe_words, mods.ctypes.data_as(u64p), L, n,
+    check(p.lib().pfhe_fill_uniform_dev(local_rank, C.c_void_p(xbuf.data_ptr()), glwe_words, mods.ctypes.data_as(u64p), L, n,
                                         0x5EED000000000004 + rank, None))
-    glwe = x[:glwe_words]                           # canonical residues: a valid CrtGlwe batch
+    glwe = xbuf[:glwe_words]                           # canonical residues: a valid CrtGlwe batch
     ggsw = torch.empty(ggsw_words, dtype=torch.int64, device="cuda")
     check(p.lib().pfhe_fill_uniform_dev(local_rank, C.c_void_p(ggsw.data_ptr()), ggsw_words, mods.ctypes.data_as(u64p), L,
-                                        n, 99, None))
+                                        n, SEED_GGSW, None))
     out = torch.empty(glwe_words, dtype=torch.int64, device="cuda")
     ep_steps = max(2, args.steps // 3)
     dte = timed_steps(lambda: p.mul_dcrt_ggsw_to_dev(glwe, ggsw, out, ctx, into_coeff_form=True), ep_steps, 1,
@@ -339,8 +379,7 @@ def main():
         b5, e5 = shard_range(args.ext_total, world, rank)
         mine = e5 - b5
         g5 = torch.empty(max(1, mine) * 2 * L * n, dtype=torch.int64, device="cuda")
-        check(p.lib().pfhe_fill_uniform_dev(local_rank, C.c_void_p(g5.data_ptr()), g5.numel(), mods.ctypes.data_as(u64p), L,
-                                            n, 0x5EED000000000005 + b5, None))
+        fill_job_shard(p.lib(), local_rank, g5.data_ptr(), b5, mine, 2 * L * n, Q61, n, SEED_CONFIG5)
         o5 = torch.empty_like(g5)
 
         def run_shard(begin, end):
@@ -354,11 +393,23 @@ def main():
                             "no collective on the data path)",
                     "hbm_roofline_frac": leg["value"] / world * 96 * n / (HBM_PEAK_GBS * 1e9)})
         result["external_product_config5"] = leg
+        if args.dump_dir:
+            dump["config5_range"] = np.array([b5, e5])
+            dump["config5_out"] = o5[:mine * 2 * L * n].cpu().numpy().view(np.uint64)
         del g5, o5
     del ggsw, ctx
+    if args.dump_dir:
+        if batch > 64 or args.ext_total > 64:
+            raise SystemExit("--dump-dir is for small parity runs (--batch, --ext-total <= 64)")
+        fill_job_shard(p.lib(), local_rank, x.data_ptr(), rank * batch, batch, L * n, Q61, n, SEED_NTT)
+        table.transform_dev(x)
+        dump["ntt_range"] = np.array([rank * batch, (rank + 1) * batch])
+        dump["ntt_out"] = x.cpu().numpy().view(np.uint64)
+        os.makedirs(args.dump_dir, exist_ok=True)
+        np.savez(os.path.join(args.dump_dir, "rank%d.npz" % rank), **dump)
 
-    if rank == 0 and world == 1:
-        # ---- per-kernel timing (HIP events on the launch stream) for the roofline object ----
+    if rank == 0 and not args.dump_dir:
+        # ---- per-kernel timing (HIP events on the launch stream) for the roofline object: rank 0's GPU, any N ----
         npass = p.lib().pfhe_dcrt_transform_num_passes(table._h)
         stream = torch.cuda.current_stream()
         per_pass = []
@@ -421,6 +472,7 @@ def main():
             result["roofline_passes"] = standalone
         else:
             result["roofline"] = standalone
+    if rank == 0 and world == 1 and not args.dump_dir:
         # the single-pass loops above left x in an arbitrary state: restore canonical residues
         check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(x.data_ptr()), words, mods.ctypes.data_as(u64p), L, n, 5, None))
         # ---- the inverse transform at the same shape (U64DcrtTable::inverse_transform_slice, prime64/table.rs:560) ----

@@ -29,6 +29,7 @@ struct pfhe_extprod_plan {
     bool pipeline = false;
     // PFHE_DISABLE_SMALL_EXTPROD / _FUSED_EXTPROD / _FUSED_DECOMPOSE, read at plan creation
     bool use_small = true, use_fused = true, use_fused_decompose = true;
+    bool use_fused_tail = true;  // PFHE_DISABLE_FUSED_TAIL clears it (the parity tests compare both forms)
     // measurement aid (pfhe_extprod_profile_dev): when non-null, run_product records an event before the
     // decomposition, between the decomposition and the transform / multiply-accumulate, and after it, per chunk
     std::vector<hipEvent_t> *prof = nullptr;
@@ -84,13 +85,14 @@ int plan_check(const pfhe_extprod_plan *p) {
 // rows == k+1 without `accumulate` gives CrtGlwe::mul_dcrt_ggsw_to (glwe/crt.rs:200-227).
 // Chunks of ciphertexts run one after the other on the caller's stream, or (plan created under
 // PFHE_EXTPROD_PIPELINE) software-pipelined over the plan's two streams and two digit buffers.
-// `into_coeff`: the caller wants coefficient-form output; *coeff_done reports whether this function already
-// produced it (small-ring kernel) or the caller still has to run the inverse transform.
+// `into_coeff`: the caller wants coefficient-form output; *coeff_passes reports how many passes of the inverse
+// transform this function already ran on the result: -1 = all of them (small-ring kernel), 1 = the block pass
+// (fused into the multiply-accumulate kernel; the caller runs the remaining strided pass), 0 = none.
 // `big_input`: the input polynomials are BigUintPolynomials (value_len limbs per coefficient) instead of CRT ones.
 int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 *keys, bool keys_shared, u64 *result,
-                u64 batch, bool accumulate, hipStream_t s, bool into_coeff = false, bool *coeff_done = nullptr,
+                u64 batch, bool accumulate, hipStream_t s, bool into_coeff = false, int *coeff_passes = nullptr,
                 bool big_input = false) {
-    if (coeff_done) *coeff_done = false;
+    if (coeff_passes) *coeff_passes = 0;
     const TableSet &t = *p->table;
     const u64 W = (u64)t.L * t.n;
     RnsDev rns = p->rns;
@@ -112,7 +114,7 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
                                        keys + (keys_shared ? 0 : done * key_words), keys_shared,
                                        result + done * (p->k + 1) * W, cur, accumulate, into_coeff, s));
         }
-        if (coeff_done) *coeff_done = into_coeff;
+        if (coeff_passes) *coeff_passes = into_coeff ? -1 : 0;
         return PFHE_OK;
     }
     const bool single = !p->pipeline || batch <= p->chunk || stream_is_capturing(s);
@@ -120,6 +122,9 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
     const bool fused = gadget_fused_supported(t.log_n, p->k) && p->use_fused &&
                        ((std::min<u64>(batch, p->chunk) * t.L) << (t.log_n - 12)) >= 256;
     const int passes = ntt_num_passes(t.log_n, t.pm, t.tune);
+    // coefficient-form output: the inverse transform's block pass runs inside the fused kernel, on the accumulators
+    const bool inv_tail = fused && into_coeff && !accumulate && coeff_passes != nullptr && passes == 2 && p->use_fused_tail;
+    if (inv_tail) *coeff_passes = 1;
     const bool fused_decompose = gadget_decompose_strided_supported(t.log_n, p->rns.value_len) &&
                                  p->use_fused_decompose;
     if (!single) {
@@ -172,7 +177,7 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
         if (fused) {
             PFHE_TRY(gadget_block_mulacc_dev(t.primes_dev, t.L, t.log_n, t.pm, p->k, rows * ell, dg,
                                              keys + (keys_shared ? 0 : done * key_words), keys_shared,
-                                             result + done * (p->k + 1) * W, cur, accumulate, sb));
+                                             result + done * (p->k + 1) * W, cur, accumulate, sb, inv_tail));
         } else {
             PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.pm, dg, npolys, false, passes - 1, false, sb, nullptr, 0, t.tune));
         }
@@ -588,6 +593,7 @@ int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *rns, const 
     p->use_small = std::getenv("PFHE_DISABLE_SMALL_EXTPROD") == nullptr;
     p->use_fused = std::getenv("PFHE_DISABLE_FUSED_EXTPROD") == nullptr;
     p->use_fused_decompose = std::getenv("PFHE_DISABLE_FUSED_DECOMPOSE") == nullptr;
+    p->use_fused_tail = std::getenv("PFHE_DISABLE_FUSED_TAIL") == nullptr;
     for (int i = 0; i < 2; ++i) {
         void *d = nullptr;
         if (i == 0 || p->pipeline) PFHE_HIP(hipMalloc(&d, p->digits_words * sizeof(u64)));
@@ -641,12 +647,15 @@ int pfhe_extprod_mul_dcrt_ggsw_to_dev(pfhe_extprod_plan *plan, const uint64_t *c
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
     const bool shared = len_ggsw == ggsw && batch > 1 ? true : (len_ggsw == ggsw);
     // result.set_zero() (glwe/crt.rs:217) is implied: the first accumulation overwrites
-    bool coeff_done = false;
+    int coeff_passes = 0;
     PFHE_TRY(run_product(plan, (const u64 *)crt_glwe_dev, plan->k + 1, (const u64 *)dcrt_ggsw_dev, shared,
-                         (u64 *)result_dev, batch, false, (hipStream_t)stream, into_coeff_form != 0, &coeff_done));
-    if (into_coeff_form && !coeff_done)  // DcrtGlwe::into_coeff_form, macros/mod.rs:901-911
+                         (u64 *)result_dev, batch, false, (hipStream_t)stream, into_coeff_form != 0, &coeff_passes));
+    if (into_coeff_form && coeff_passes == 0)  // DcrtGlwe::into_coeff_form, macros/mod.rs:901-911
         PFHE_TRY(ntt_inverse_dev(t.primes_dev, t.L, t.log_n, t.pm, (u64 *)result_dev, batch * (plan->k + 1) * t.L, false,
                                  (hipStream_t)stream, t.tune));
+    for (int i = coeff_passes; into_coeff_form && i > 0 && i < ntt_num_passes(t.log_n, t.pm, t.tune); ++i)
+        PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.pm, (u64 *)result_dev, batch * (plan->k + 1) * t.L, true, i,
+                              false, (hipStream_t)stream, nullptr, 0, t.tune));
     return PFHE_OK;
     PFHE_GUARD_END
 }

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(LOGE == 3 ? 512 : 256, LOGE == 3 ? PFHE_MULACC8_MIN
                                                                   const u64 *__restrict__ ggsw, u64 ggsw_stride,
                                                                   u64 *__restrict__ result,
                                                                   const NttPrime *__restrict__ primes, u32 L, u32 log_n,
-                                                                  u32 terms, u64 total_blocks, u32 accumulate) {
+                                                                  u32 terms, u64 total_blocks, u32 accumulate, u32 inv_tail) {
     constexpr int LOGB = 12;
     extern __shared__ __attribute__((aligned(16))) u64 lds[];
     const u32 lt = threadIdx.x;
@@ -75,46 +75,40 @@ __global__ __launch_bounds__(LOGE == 3 ? 512 : 256, LOGE == 3 ? PFHE_MULACC8_MIN
     // (accumulators in the layout the transform ends in, the key read as each thread's own run of 16-byte pieces and ONE
     // transposition per output at the end instead of one per term: 20.1 against 19.5 ms per 1024 products — the key
     // reads, 64 pieces 64 bytes apart per wave instruction, cost more than the LDS trips they save)
+    // The accumulators start at zero; an accumulating call adds the previous result in the epilogue.  (Loading it in
+    // front of the loop made the compiler park all 32 accumulator registers in scratch on the way into the loop — one
+    // 148-byte store per lane, 432 MiB per launch of 128 ciphertexts, reloaded only on the never-taken zero-terms path.)
     u64x2 acc[NC][NV];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        if (accumulate) {
-            load_block_vectors<LOGB, LOGE>(acc[c], out + (u64)c * W, lt);
-        } else {
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
-            for (int j = 0; j < NV; ++j) acc[c][j] = u64x2{0, 0};
-        }
-    }
+        for (int j = 0; j < NV; ++j) acc[c][j] = u64x2{0, 0};
 
-    for (u32 ij = 0; ij < terms; ++ij) {
+    u32 ij = 0;
+    do {  // terms >= 1 (checked on the host): no zero-trip path to keep the initial values alive for
         u64x2 io[NV];
         u64 x[1 << LOGE];
-#ifndef PFHE_MULACC_STAGED_LOADS
-        // (19.4-19.6 against 19.9 ms per 1024 products with the staged 16-byte loads of the #else branch)
+        // Per-term opaque copy of the thread id: every address of the body (digit and key vectors, LDS layouts, the
+        // lane-ordered twiddle entries) is recomputed from it each term — a few dozen instructions against the ~1500 of
+        // a term — instead of being hoisted out of the loop as an invariant, where the 64-bit addresses alone held 30
+        // registers across the loop and pushed 17 into scratch.
+        u32 ltl = lt;
+        asm volatile("" : "+v"(ltl));
         // the first register pass wants register k = element (k << POS0) + lt: 8-byte loads deliver it without staging
-        // (512 contiguous bytes per wave instruction); the first exchange then needs its leading barrier, because other
-        // threads may still be reading the previous term's natural-order image
+        // (512 contiguous bytes per wave instruction; 19.4-19.6 against 19.9 ms per 1024 products with staged 16-byte
+        // loads); the first exchange then needs its leading barrier, because other threads may still be reading the
+        // previous term's natural-order image
 #pragma unroll
         for (int k = 0; k < (1 << LOGE); ++k)
-            x[k] = __builtin_nontemporal_load(dg + (u64)ij * W + ((u32)k << (LOGB - LOGE)) + lt);
-        block_forward_core<A, LOGB, true, LOGE>(ar, x, lds, n, eblk, lt, /*lazy=*/true);  // digit_hat mod~ q
-#else
-        load_block_vectors<LOGB, LOGE>(io, dg + (u64)ij * W, lt);
-        // (no barrier: these are the slots this thread read with lds_get_vectors at the end of the previous iteration)
-        lds_put_vectors<LOGB, LOGE>(io, lds, lt);
+            x[k] = __builtin_nontemporal_load(dg + (u64)ij * W + ((u32)k << (LOGB - LOGE)) + ltl);
+        block_forward_core<A, LOGB, true, LOGE>(ar, x, lds, n, eblk, ltl, /*lazy=*/true);  // digit_hat mod~ q
+        lds_put_layout<0, LOGE>(x, lds, ltl);
         __syncthreads();
-        lds_get_layout<LOGB - LOGE, LOGE>(x, lds, lt);
-        // (no barrier in front of the first exchange or of the write-back: in both a thread overwrites exactly the
-        // LDS slots it read last — pfhe_ntt_device.hpp, lds_exchange)
-        block_forward_core<A, LOGB, false, LOGE>(ar, x, lds, n, eblk, lt, /*lazy=*/true);  // digit_hat mod~ q
-#endif
-        lds_put_layout<0, LOGE>(x, lds, lt);
-        __syncthreads();
-        lds_get_vectors<LOGB, LOGE>(io, lds, lt);  // natural order again: same positions as the key vectors
+        lds_get_vectors<LOGB, LOGE>(io, lds, ltl);  // natural order again: same positions as the key vectors
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             u64x2 kv[NV];
-            load_block_vectors<LOGB, LOGE>(kv, key + ((u64)ij * NC + c) * W, lt);
+            load_block_vectors<LOGB, LOGE>(kv, key + ((u64)ij * NC + c) * W, ltl);
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 if constexpr (std::is_same<A, PmArith>::value) {
@@ -132,18 +126,66 @@ __global__ __launch_bounds__(LOGE == 3 ? 512 : 256, LOGE == 3 ? PFHE_MULACC8_MIN
                 }
             }
         }
-    }
+    } while (++ij < terms);
+    // The epilogue's addresses, too, are computed from an opaque copy of the thread id (one per component): they cannot
+    // be hoisted above the loop or above the previous component's inverse pass.
+    // explicit instantiation per component (the body may contain a whole inverse block pass, which the compiler
+    // does not unroll a loop around; a runtime-indexed accumulator array would live in scratch)
+    auto epilogue = [&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        u64 *__restrict__ oc = out + (u64)c * W;
+        u32 lte = lt;
+        asm volatile("" : "+v"(lte));
+        if (accumulate) {  // DcrtGlwe::add_dcrt_glev_mul_crt_poly_assign: acc += previous result (canonical)
+            u64x2 old[NV];
+            load_block_vectors<LOGB, LOGE>(old, oc, lte);
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        if constexpr (std::is_same<A, PmArith>::value) {
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {  // fold the pending terms, then [0, 2^K + 2^(K-9)) -> canonical
-                acc[c][j].x = csub(ar.reduce_x(acc[c][j].x), ar.q);
-                acc[c][j].y = csub(ar.reduce_x(acc[c][j].y), ar.q);
+            for (int j = 0; j < NV; ++j) {
+                if constexpr (std::is_same<A, PmArith>::value) {
+                    // pending terms < 5.5 * 2^K, old < 2^K: the sum fits 64 bits and is folded below
+                    acc[c][j].x += old[j].x;
+                    acc[c][j].y += old[j].y;
+                } else {
+                    acc[c][j].x = csub(acc[c][j].x + old[j].x, P->q);
+                    acc[c][j].y = csub(acc[c][j].y + old[j].y, P->q);
+                }
             }
         }
-        store_block_vectors<LOGB, LOGE>(acc[c], out + (u64)c * W, lt);
-    }
+        if (inv_tail) {
+            // DcrtGlwe::into_coeff_form (macros/mod.rs:901-911), first pass: the inverse transform's block pass runs on the
+            // accumulators while they are on chip; what is stored is the intermediate the inverse strided pass expects
+            // (exactly what ntt_block_kernel<12, inverse> would have left in place).  Its butterflies take any
+            // representative below 3 * 2^K, so the fold alone is enough.
+            if constexpr (std::is_same<A, PmArith>::value) {
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    acc[c][j].x = ar.reduce_x(acc[c][j].x);
+                    acc[c][j].y = ar.reduce_x(acc[c][j].y);
+                }
+            }
+            u64 y[1 << LOGE];
+            __syncthreads();  // other threads may still be reading the previous image (last term / previous component)
+            lds_put_vectors<LOGB, LOGE>(acc[c], lds, lte);
+            __syncthreads();
+            lds_get_layout<0, LOGE>(y, lds, lte);
+            block_inverse_core<A, LOGB, false, LOGE>(ar, y, lds, n, eblk, lte, /*final_block=*/false, /*lazy=*/false);
+#pragma unroll
+            for (int k = 0; k < (1 << LOGE); ++k) gstore<true>(oc + ((u32)k << (LOGB - LOGE)) + lte, y[k]);
+        } else {
+            if constexpr (std::is_same<A, PmArith>::value) {
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {  // fold the pending terms, then [0, 2^K + 2^31) -> canonical
+                    acc[c][j].x = csub(ar.reduce_x(acc[c][j].x), ar.q);
+                    acc[c][j].y = csub(ar.reduce_x(acc[c][j].y), ar.q);
+                }
+            }
+            store_block_vectors<LOGB, LOGE>(acc[c], oc, lte);
+        }
+    };
+    epilogue(std::integral_constant<int, 0>{});
+    if constexpr (NC > 1) epilogue(std::integral_constant<int, 1>{});
+    if constexpr (NC > 2) epilogue(std::integral_constant<int, 2>{});
+    static_assert(NC <= 3, "add an epilogue call per component");
 }
 
 // ------------------------------------------------------------------------------------------
@@ -472,8 +514,8 @@ bool gadget_fused_supported(u32 log_n, u32 k) { return k == 1 && make_ntt_plan(l
 
 int gadget_block_mulacc_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u32 k, u32 terms, const u64 *digits,
                             const u64 *ggsw, bool ggsw_shared, u64 *result, u64 batch, bool accumulate,
-                            hipStream_t s) {
-    if (!gadget_fused_supported(log_n, k)) return PFHE_ERR_UNSUPPORTED;
+                            hipStream_t s, bool inv_tail) {
+    if (!gadget_fused_supported(log_n, k) || terms == 0 || (inv_tail && accumulate)) return PFHE_ERR_UNSUPPORTED;
     using Cfg = BlockCfg<12>;
     const u64 total_blocks = (batch * L) << (log_n - 12);
     if (total_blocks == 0) return PFHE_OK;
@@ -482,16 +524,15 @@ int gadget_block_mulacc_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u
     constexpr size_t lds_bytes = (size_t)Cfg::LDS_WORDS * sizeof(u64);
     const u64 stride = ggsw_shared ? 0ull : ggsw_words;
     if (pm) {
-#ifndef PFHE_MULACC_16
+        // 512 threads x 8 coefficients: 32 accumulator registers, four waves per SIMD (the 256 x 16 form holds 64 and
+        // fits two: 48.0 -> 49.0 k products/s when it was replaced)
         hipLaunchKernelGGL((gadget_block_mulacc_kernel<PmArith, 2, 3>), dim3((u32)total_blocks), dim3(512), lds_bytes, s,
-                           digits, ggsw, stride, result, primes, L, log_n, terms, total_blocks, accumulate ? 1u : 0u);
-#else
-        hipLaunchKernelGGL((gadget_block_mulacc_kernel<PmArith, 2>), dim3((u32)total_blocks), dim3(256), lds_bytes, s,
-                           digits, ggsw, stride, result, primes, L, log_n, terms, total_blocks, accumulate ? 1u : 0u);
-#endif
+                           digits, ggsw, stride, result, primes, L, log_n, terms, total_blocks, accumulate ? 1u : 0u,
+                           inv_tail ? 1u : 0u);
     } else {
         hipLaunchKernelGGL((gadget_block_mulacc_kernel<ShoupArith, 2>), dim3((u32)total_blocks), dim3(256), lds_bytes, s,
-                           digits, ggsw, stride, result, primes, L, log_n, terms, total_blocks, accumulate ? 1u : 0u);
+                           digits, ggsw, stride, result, primes, L, log_n, terms, total_blocks, accumulate ? 1u : 0u,
+                           inv_tail ? 1u : 0u);
     }
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;

@@ -92,9 +92,11 @@ bool gadget_split_decompose_supported(u32 log_n, u32 value_len, u32 log_basis);
 int gadget_decompose_strided_dev(const RnsDev &r, const BasisDev &b, const NttPrime *primes, u32 log_n, bool pm,
                                  const u64 *crt_polys, u64 *digits, u64 npolys, hipStream_t s,
                                  int *sdigits = nullptr);
+// inv_tail (not with accumulate): the kernel also runs the block pass of the INVERSE transform on its result blocks
+// before storing them; the caller finishes with the inverse transform's strided pass (ntt_pass_dev, inverse, index 1).
 int gadget_block_mulacc_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u32 k, u32 terms, const u64 *digits,
                             const u64 *ggsw, bool ggsw_shared, u64 *result, u64 batch, bool accumulate,
-                            hipStream_t s);
+                            hipStream_t s, bool inv_tail = false);
 
 // Small rings (N = 2^10..2^12): digit extraction to int32 + ONE kernel for transforms, multiply-accumulate and
 // (optionally) the inverse transforms (pfhe_extprod.hip, extprod_small_kernel).

@@ -20,6 +20,34 @@ def shard_range(total: int, world: int, rank: int) -> tuple[int, int]:
     return begin, begin + base + (1 if rank < extra else 0)
 
 
+_SPLITMIX_GAMMA = 0x9E3779B97F4A7C15
+
+
+def job_seed(seed: int, word_offset: int) -> int:
+    """Seed under which pfhe_fill_uniform_dev writes, at word 0 of a buffer, what it would have written at word
+    `word_offset` of a buffer filled with `seed`: the fill is counter-based (word i = splitmix64(seed, i) scaled into
+    [0, q_r)), so a shard of a job's synthetic input depends only on its position in the job, not on how the job is
+    split over the ranks.  `word_offset` must be a multiple of one RNS polynomial (L * N words)."""
+    return (seed + word_offset * _SPLITMIX_GAMMA) & 0xFFFFFFFFFFFFFFFF
+
+
+def fill_job_shard(lib, device: int, dst_ptr: int, begin_unit: int, units: int, unit_words: int, moduli, poly_len: int,
+                   seed: int, stream=None) -> None:
+    """Synthetic input of units [begin_unit, begin_unit + units) of a job whose unit (ciphertext, RNS polynomial) is
+    `unit_words` words, written to device memory at dst_ptr.  Identical to the same units of the job filled in one go."""
+    import ctypes as C
+
+    import numpy as np
+    mods = np.ascontiguousarray(moduli, dtype=np.uint64)
+    if unit_words % (len(mods) * poly_len):
+        raise ValueError("a unit must be whole RNS polynomials")
+    rc = lib.pfhe_fill_uniform_dev(device, C.c_void_p(dst_ptr), units * unit_words,
+                                   mods.ctypes.data_as(C.POINTER(C.c_uint64)), len(mods), poly_len,
+                                   job_seed(seed, begin_unit * unit_words), stream)
+    if rc != 0:
+        raise RuntimeError("pfhe_fill_uniform_dev failed: %d" % rc)
+
+
 def timed_steps(step, steps: int, warmup: int, sync, dist=None, device=None):
     """Contract of bench.py: W untimed steps, then exactly K steps bracketed by barrier + sync on
     both sides; returns the MAX over ranks of the elapsed seconds."""

@@ -46,3 +46,20 @@ def splitmix_rns(case_id: int, moduli, n: int, batch: int = 1) -> np.ndarray:
 
 def digest(words: np.ndarray) -> str:
     return hashlib.sha256(np.ascontiguousarray(words, dtype="<u8").tobytes()).hexdigest()
+
+
+def _mulhi64(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    m = np.uint64(0xFFFFFFFF)
+    s = np.uint64(32)
+    a0, a1, b0, b1 = a & m, a >> s, b & m, b >> s
+    with np.errstate(over="ignore"):
+        mid = (a0 * b0 >> s) + (a1 * b0 & m) + (a0 * b1 & m)
+        return a1 * b1 + (a1 * b0 >> s) + (a0 * b1 >> s) + (mid >> s)
+
+
+def fill_uniform_words(seed: int, start: int, count: int, moduli, poly_len: int) -> np.ndarray:
+    """Host model of pfhe_fill_uniform_dev (include/pfhe.h): words start .. start+count of a buffer filled with `seed`,
+    word i = floor(splitmix64(seed, i) * q / 2^64) with q = moduli[(i / poly_len) % len(moduli)]."""
+    i = np.arange(start, start + count, dtype=np.uint64)
+    q = np.asarray(moduli, dtype=np.uint64)[(i // np.uint64(poly_len)) % np.uint64(len(moduli))]
+    return _mulhi64(splitmix_words(seed, start, count), q)

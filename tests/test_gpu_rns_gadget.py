@@ -427,3 +427,41 @@ def test_config4_full_batch_every_ciphertext(pf, orc):
     with ThreadPoolExecutor(usable_cores()) as ex:
         ok = list(ex.map(one, range(batch)))
     assert all(ok), [e for e, v in enumerate(ok) if not v][:10]
+
+
+@pytest.mark.parametrize("log_n,batch,shared,generic", [
+    (13, 48, True, False), (15, 12, False, False), (16, 8, True, False), (16, 7, False, True), (17, 3, True, False),
+])
+def test_fused_inverse_tail_equals_separate_inverse(pf, orc, log_n, batch, shared, generic, monkeypatch):
+    """Coefficient-form output of the fused path (two-pass rings, k = 1): the multiply-accumulate kernel runs the inverse
+    transform's block pass on its accumulators and a strided pass finishes (DcrtGlwe::into_coeff_form,
+    macros/mod.rs:901-911).  Same words as the plan created under PFHE_DISABLE_FUSED_TAIL (separate inverse transform)
+    and as the oracle; pseudo-Mersenne and generic-prime arithmetic, shared and per-ciphertext keys."""
+    import torch
+    k = 1
+    rng = np.random.default_rng(1000 + log_n + batch)
+    otable, glwe, ggsw, exp = make_case(orc, rng, log_n, k, Q61, 30, None, batch if log_n <= 13 else 2, shared)
+    n = 1 << log_n
+    if generic:
+        monkeypatch.setenv("PFHE_DISABLE_PM", "1")
+    table, base = pf.U64DcrtTable(log_n, Q61), pf.RNSBase(Q61)
+    monkeypatch.delenv("PFHE_DISABLE_PM", raising=False)
+    basis = pf.BigUintApproxSignedBasis(base, 30)
+    ell = basis.decompose_length()
+    ctx = pf.DcrtGlevContext(table, base, basis, k)
+    monkeypatch.setenv("PFHE_DISABLE_FUSED_TAIL", "1")
+    ctx_sep = pf.DcrtGlevContext(table, base, basis, k)
+    monkeypatch.delenv("PFHE_DISABLE_FUSED_TAIL")
+    G, K = ctx.glwe_len(), ctx.ggsw_len()
+    # the first ciphertexts are the oracle's case; the rest of the batch (enough to take the fused kernels) is random
+    oc = glwe.size // G
+    more = batch - oc
+    full_g = np.concatenate([glwe, rand_rns(rng, Q61, n, more * (k + 1))]) if more else glwe
+    full_k = ggsw if shared or not more else np.concatenate([ggsw, rand_rns(rng, Q61, n, more * (k + 1) * ell * (k + 1))])
+    dg, dk = to_dev(full_g), to_dev(full_k)
+    fused, sep = torch.zeros_like(dg), torch.zeros_like(dg)
+    pf.mul_dcrt_ggsw_to_dev(dg, dk, fused, ctx, into_coeff_form=True)
+    pf.mul_dcrt_ggsw_to_dev(dg, dk, sep, ctx_sep, into_coeff_form=True)
+    assert torch.equal(fused, sep)
+    otable.inverse_transform_slice(exp)
+    assert np.array_equal(to_host(fused[:oc * G]), exp)

@@ -101,3 +101,52 @@ def test_two_rank_gloo_sharding_matches_unsharded():
     assert ok
     assert sorted(ranges) == [(0, 4), (4, 7)]
     assert dt > 0 and ncalls == 3  # 1 warm-up + exactly 2 timed steps
+
+
+def test_job_seed_makes_shard_input_position_only():
+    """A shard's synthetic input filled with job_seed(seed, offset) at word 0 is the job's input at `offset`."""
+    from golden_inputs import fill_uniform_words
+    from primus_fhe_amd.shard import job_seed
+    moduli, n, unit = [2305843009211596801, 2305843009210023937, 97], 16, 2 * 3 * 16
+    job = fill_uniform_words(0x5EED000000000005, 0, 7 * unit, moduli, n)
+    for b, e in ((0, 4), (4, 7), (2, 3)):
+        shard = fill_uniform_words(job_seed(0x5EED000000000005, b * unit), 0, (e - b) * unit, moduli, n)
+        assert np.array_equal(shard, job[b * unit:e * unit])
+
+
+def test_bench_gpus_flag_spawns_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` with no launcher environment starts N rank processes itself:
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* per child, the same argv, only rank 0's stdout relayed."""
+    import subprocess
+    import types
+
+    import bench
+    started = []
+
+    class FakeProc:
+        def __init__(self, argv, env=None, stdout=None):
+            started.append((argv, env, stdout))
+
+        def wait(self):
+            return 0
+
+    monkeypatch.setattr(subprocess, "Popen", FakeProc)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--one-device", "--steps", "2"])
+    args = types.SimpleNamespace(gpus=4, one_device=True, master_port=0)
+    assert bench.spawn_ranks(args) == 0
+    assert len(started) == 4
+    ports = {env["MASTER_PORT"] for _, env, _ in started}
+    assert len(ports) == 1
+    for r, (argv, env, stdout) in enumerate(started):
+        assert argv[1].endswith("bench.py") and argv[2:] == ["--gpus", "4", "--one-device", "--steps", "2"]
+        assert (env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"], env["MASTER_ADDR"]) == (str(r), str(r), "4", "127.0.0.1")
+        assert (stdout is None) == (r == 0)
+
+
+def test_bench_rejects_world_size_mismatch(monkeypatch):
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    with pytest.raises(SystemExit) as ei:
+        bench.main()
+    assert "WORLD_SIZE" in str(ei.value)
