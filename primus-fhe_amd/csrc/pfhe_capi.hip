@@ -79,6 +79,7 @@ int make_table_set(u32 log_n, const u64 *moduli, size_t count, int device, std::
     ts->primes.resize(count);
     ts->tune = NttTuning::from_env();
     ts->fused_polymul = std::getenv("PFHE_DISABLE_FUSED_POLYMUL") == nullptr;
+    ts->fused_polymul_mid = std::getenv("PFHE_DISABLE_POLYMUL_MID") == nullptr;
     ts->monomial_inplace = std::getenv("PFHE_DISABLE_MONOMIAL_INPLACE") == nullptr;
     const size_t bytes = ts->n * sizeof(ulonglong2);
     bool all_pm = std::getenv("PFHE_DISABLE_PM") == nullptr;  // tuning switch: force the generic path
@@ -788,6 +789,14 @@ int pfhe_dcrt_mul_dcrt_polynomial_dev(const pfhe_dcrt *table, uint64_t *crt_poly
     if (len_b != len && len_b != t.n * t.L) {
         set_last_error("multiplicand must have the same length or exactly one polynomial");
         return PFHE_ERR_BAD_LENGTH;
+    }
+    if (len != 0 && t.fused_polymul && t.fused_polymul_mid) {
+        // forward block pass -> product -> inverse block pass in one kernel, between the strided passes
+        DeviceGuard g(t.device);
+        if (!g.ok) return PFHE_ERR_NO_DEVICE;
+        const int rc = ntt_polymul_dev(t.primes_dev, t.L, t.log_n, t.pm, (u64 *)crt_poly_dev, len / t.n,
+                                       (const u64 *)dcrt_poly_dev, len_b / t.n, (hipStream_t)stream, t.tune);
+        if (rc != PFHE_ERR_UNSUPPORTED) return rc;
     }
     PFHE_TRY(transform_dev(t, (u64 *)crt_poly_dev, len, false, false, (hipStream_t)stream));
     if (t.log_n >= 4 && len != 0 && t.fused_polymul) {

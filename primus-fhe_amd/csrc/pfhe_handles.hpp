@@ -18,6 +18,7 @@ struct TableSet {
     // tuning switches, read from the environment once, when the handle is created
     NttTuning tune;
     bool fused_polymul = true;             // cleared by PFHE_DISABLE_FUSED_POLYMUL
+    bool fused_polymul_mid = true;         // cleared by PFHE_DISABLE_POLYMUL_MID: NTT -> mul -> INTT block passes in one kernel
     bool monomial_inplace = true;          // cleared by PFHE_DISABLE_MONOMIAL_INPLACE
     std::vector<NttPrime> primes;          // host copies (device pointers inside)
     const NttPrime *primes_dev = nullptr;  // the same array on the device

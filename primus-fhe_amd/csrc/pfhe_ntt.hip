@@ -430,6 +430,157 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) PFHE_PIPE_INV_WAVES_ATTR v
 }
 
 // ------------------------------------------------------------------------------------------
+// NTT -> pointwise product -> INTT on one block (CrtRlwe::mul_dcrt_polynomial_to, primus_lattice/src/rlwe/crt.rs:42-65,
+// + DcrtPolynomial::into_coeff_form, macros/mod.rs:901-911): the forward transform's block pass, the product and the
+// inverse transform's block pass all act on the same contiguous block of 2^LOGB coefficients, so ONE workgroup runs all
+// three while the block is on chip.  For N = 2^LOGB (single-pass rings, 2^10 .. 2^14) that is the whole product with one
+// HBM read and one write per coefficient; for two-pass rings it sits between the two strided passes: 3 HBM round trips
+// (48*N bytes per limb-polynomial) instead of the 4 of transform + fused inverse-mul.
+// The forward half leaves lazy values (one fold), the product takes any representative below 2^63 and a canonical
+// multiplicand and returns [0, 2q), which the inverse butterflies accept: the canonical final output is the reference's.
+// Hooks (pipelined form): after_load runs once the block's own loads are issued and consumed by the first stages;
+// mid runs while the block sits in LDS between the halves (no block registers live); late runs in front of the inverse
+// half's last register pass (the pass with the fewest live registers).
+// ------------------------------------------------------------------------------------------
+// An opaque copy of the thread id (no instruction): addresses computed from it cannot be hoisted above this point, so
+// the address registers of a later phase are not live through an earlier one.
+__device__ __forceinline__ u32 opaque_tid() {
+    u32 t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
+// gptr / mptr: this block of the data and of the multiplicand; ar: the arithmetic of the block's limb
+template <class A, int LOGB, class HookA = NoHook, class HookM = NoHook, class HookL = NoLateHook, bool NT = false>
+__device__ __forceinline__ void block_mid_body(const A &ar, u64 *__restrict__ gptr, const u64 *__restrict__ mptr, bool valid,
+                                               u32 n, u32 eblk, bool final_block, u64 *__restrict__ lds,
+                                               HookA after_load = HookA(), HookM mid = HookM(), HookL late = HookL()) {
+    using Cfg = BlockCfg<LOGB>;
+    static_assert(Cfg::BPW == 1 && LOGB - 4 >= 6, "one block per workgroup, whole waves per register layout");
+    constexpr int NV = Cfg::E / 2, POS0 = LOGB - 4;
+    u64 x[Cfg::E];
+    {
+        const u32 lt = opaque_tid();
+        // register k of thread lt = element (k << POS0) + lt: 8-byte loads, 512 contiguous bytes per wave instruction
+#pragma unroll
+        for (int k = 0; k < Cfg::E; ++k) x[k] = valid ? __builtin_nontemporal_load(gptr + ((u32)k << POS0) + lt) : 0ull;
+        after_load();
+        block_forward_core<A, LOGB, false>(ar, x, lds, n, eblk, lt, /*lazy=*/true);
+        lds_put_layout<0>(x, lds, lt);
+    }
+    {
+        const u32 lt = opaque_tid();
+        u64x2 io[NV], mv[NV];
+        if (valid) {  // natural order, 1 KiB per wave instruction
+            load_block_vectors<LOGB, 4, NT>(mv, mptr, lt);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) mv[j] = u64x2{0, 0};
+        }
+        __syncthreads();
+        lds_get_vectors<LOGB>(io, lds, lt);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {  // (outside any `valid` branch: see the note in block_pass_body)
+            io[j].x = ar.mul_any(io[j].x, mv[j].x);
+            io[j].y = ar.mul_any(io[j].y, mv[j].y);
+        }
+        lds_put_vectors<LOGB>(io, lds, lt);  // the slots this thread just read
+    }
+    mid();
+    __syncthreads();
+    {
+        const u32 lt = opaque_tid();
+        lds_get_layout<0>(x, lds, lt);
+        block_inverse_core<A, LOGB, false, 4, HookL>(ar, x, lds, n, eblk, lt, final_block, /*lazy=*/false, late);
+    }
+    if (valid) {
+        const u32 lt = opaque_tid();
+#pragma unroll
+        for (int k = 0; k < Cfg::E; ++k) gstore<NT>(gptr + ((u32)k << POS0) + lt, x[k]);
+    }
+}
+
+template <class A, int LOGB, bool NT>
+__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_block_mid_kernel(
+    u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L, u32 log_n, u64 total_blocks,
+    const u64 *__restrict__ mul, u64 mul_polys) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds_raw[];
+    u64 blk = blockIdx.x;
+    const bool valid = blk < total_blocks;
+    if (!valid) blk = 0;
+    const u32 log_nb = log_n - LOGB;
+    const u64 pid = blk >> log_nb;
+    const u32 limb = (u32)(pid % L);
+    const u32 eblk = (u32)(blk & ((1ull << log_nb) - 1)) << LOGB;
+    const u32 n = 1u << log_n;
+    // The multiplicand is one RNS polynomial (mul_polys == L, indexed by the limb) or one polynomial per data polynomial
+    const u64 mpoly = mul_polys == (u64)L ? (u64)limb : pid;
+    const A ar(primes + limb);
+    block_mid_body<A, LOGB, NoHook, NoHook, NoLateHook, NT>(ar, data + pid * n + eblk, mul + mpoly * n + eblk, valid, n, eblk,
+                                                            log_n == LOGB, lds_raw);
+}
+
+// Pipelined form for N = 2^16 (4 strided stages, blocks of 2^12), large batches: launch k runs, in workgroup i, the
+// middle kernel on block i of tile k-1, the FORWARD strided pass on chunk i (256 columns x 16 rows) of tile k and the
+// INVERSE (final) strided pass on chunk i of tile k-2.  The forward chunk's loads are in flight during the block's
+// forward half and consumed while the block sits in LDS between the halves; the inverse chunk's loads are issued in
+// front of the inverse half's last register pass and consumed after the block's stores.  One set of 32 registers
+// serves both chunks.
+template <class A, int LOGB>
+__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_pipe_mid_kernel(
+    u64 *__restrict__ mid_data, u64 mid_total, u64 *__restrict__ sf_data, u64 sf_total, u64 *__restrict__ si_data,
+    u64 si_total, const NttPrime *__restrict__ primes, u32 L, const u64 *__restrict__ mul, u64 mul_polys) {
+    constexpr int K = 4, TPB = BlockCfg<LOGB>::TPB;
+    static_assert((1 << LOGB) / TPB == (1 << K), "16 blocks and 16 chunks per polynomial");
+    constexpr u32 log_n = LOGB + K, n = 1u << log_n;
+    extern __shared__ __attribute__((aligned(16))) u64 lds_raw[];
+    const u64 chunk = blockIdx.x;
+    const bool has_sf = chunk < sf_total, has_si = chunk < si_total;
+    const u64 cbase = (chunk >> 4) * n + (chunk & 15) * TPB;  // wave-uniform
+    const A ars(primes + (chunk >> 4) % L);  // tiles start at multiples of L polynomials: one limb for all three roles
+    u64 sx[1 << K][1];
+    const auto issue_f = [&]() {
+        if (has_sf) {
+            const u64 *__restrict__ sp = sf_data + cbase + opaque_tid();
+#pragma unroll
+            for (int k = 0; k < (1 << K); ++k) sx[k][0] = __builtin_nontemporal_load(sp + ((u64)k << LOGB));
+        }
+    };
+    const auto finish_f = [&]() {
+        if (has_sf) {
+            strided_forward_regs<A, K, 1>(ars, sx, n, 0u, LOGB);
+            u64 *__restrict__ sp = sf_data + cbase + opaque_tid();
+#pragma unroll
+            for (int k = 0; k < (1 << K); ++k) gstore<kPipeIntermediateNt>(sp + ((u64)k << LOGB), sx[k][0]);
+        }
+    };
+    const auto issue_i = [&]() {
+        if (has_si) {
+            const u64 *__restrict__ sp = si_data + cbase + opaque_tid();
+#pragma unroll
+            for (int k = 0; k < (1 << K); ++k) sx[k][0] = sp[(u64)k << LOGB];  // intermediate: plain (Infinity Cache)
+        }
+    };
+    if (chunk < mid_total) {
+        const u64 pid = chunk >> 4;
+        const u32 eblk = (u32)(chunk & 15) << LOGB;
+        const u64 mpoly = mul_polys == (u64)L ? pid % L : pid;
+        block_mid_body<A, LOGB>(ars, mid_data + pid * n + eblk, mul + mpoly * n + eblk, true, n, eblk, false, lds_raw, issue_f,
+                                finish_f, issue_i);
+    } else {
+        issue_f();
+        finish_f();
+        issue_i();
+    }
+    if (has_si) {
+        strided_inverse_regs<A, K, 1, true>(ars, sx, n, 0u, LOGB, /*lazy=*/false);
+        u64 *__restrict__ sp = si_data + cbase + opaque_tid();
+#pragma unroll
+        for (int k = 0; k < (1 << K); ++k) gstore<true>(sp + ((u64)k << LOGB), sx[k][0]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host-side planner / launchers
 // ------------------------------------------------------------------------------------------
 namespace {
@@ -978,6 +1129,96 @@ int ntt_inverse_mul_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64
     if (mul == nullptr || mul_polys == 0 || mul_polys % L != 0 || (mul_polys != npolys && mul_polys != L))
         return PFHE_ERR_BAD_ARGUMENT;
     return transform(primes, L, log_n, arith, data, npolys, true, false, s, tune, mul, mul_polys);
+}
+
+
+// NTT -> product -> INTT with the middle kernel (see block_mid_body).  PFHE_ERR_UNSUPPORTED when the shape does not
+// take it (the caller falls back to transform + fused inverse-mul).
+template <class A>
+static int polymul_impl(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, const u64 *mul,
+                        u64 mul_polys, hipStream_t s, const NttTuning &tune) {
+    const NttPlan plan = make_ntt_plan(log_n, arith, tune);
+    if (plan.tiny || plan.n_strided > 1 || plan.block_log < 10) return PFHE_ERR_UNSUPPORTED;
+    const bool large = (npolys << log_n) * sizeof(u64) >= kNtMinBytes;
+    const auto launch_mid = [&](auto logb_c, u64 *ptr, u64 np, const u64 *mptr, u64 mp) -> int {
+        constexpr int LOGB = decltype(logb_c)::value;
+        using Cfg = BlockCfg<LOGB>;
+        const u64 total_blocks = np << (log_n - LOGB);
+        if (total_blocks == 0) return PFHE_OK;
+        if (total_blocks > 0x7fffffffull) {
+            set_last_error("batch too large for one launch");
+            return PFHE_ERR_BAD_LENGTH;
+        }
+        constexpr size_t lds_bytes = (size_t)Cfg::LDS_WORDS * sizeof(u64);
+        void (*kern)(u64 *, const NttPrime *, u32, u32, u64, const u64 *, u64) =
+            large ? ntt_block_mid_kernel<A, LOGB, true> : ntt_block_mid_kernel<A, LOGB, false>;
+        if (lds_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)lds_bytes);
+            if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute", __FILE__, __LINE__);
+        }
+        hipLaunchKernelGGL(kern, dim3((u32)total_blocks), dim3(Cfg::THREADS), lds_bytes, s, ptr, primes, L, log_n,
+                           total_blocks, mptr, mp);
+        PFHE_HIP(hipGetLastError());
+        return PFHE_OK;
+    };
+    if (plan.n_strided == 0) {  // single-pass rings: the middle kernel is the whole product
+        switch (plan.block_log) {
+#define PFHE_CASE(B) \
+    case B: return launch_mid(std::integral_constant<int, B>{}, data, npolys, mul, mul_polys);
+            PFHE_CASE(10) PFHE_CASE(11) PFHE_CASE(12) PFHE_CASE(13) PFHE_CASE(14)
+#undef PFHE_CASE
+        }
+        return PFHE_ERR_UNSUPPORTED;
+    }
+    if (plan.block_log != 12) return PFHE_ERR_UNSUPPORTED;
+    const int pt = pipelined_tiles(L, log_n, arith, npolys, true, true, tune);
+    if (pt >= 1) {
+        constexpr size_t lds_bytes = (size_t)BlockCfg<12>::LDS_WORDS * sizeof(u64);
+        const int tiles = pt > kPipelinedMaxTiles ? kPipelinedMaxTiles : pt;
+        const u64 units = npolys / L;
+        for (int k = 0; k <= tiles + 1; ++k) {
+            // launch k: forward strided pass of tile k, middle kernel on tile k-1, inverse strided pass of tile k-2
+            u64 *ptr[3] = {nullptr, nullptr, nullptr};
+            u64 tot[3] = {0, 0, 0};
+            const u64 *mptr = nullptr;
+            u64 mp = 0;
+            for (int role = 0; role < 3; ++role) {
+                const int kt = k - role;
+                if (kt < 0 || kt >= tiles) continue;
+                const u64 u0 = units * (u64)kt / (u64)tiles, u1 = units * (u64)(kt + 1) / (u64)tiles;
+                ptr[role] = data + ((u0 * L) << log_n);
+                tot[role] = ((u1 - u0) * L) << 4;
+                if (role == 1) {  // a per-element multiplicand is tiled like the data; a shared one (one unit of L) is not
+                    mptr = mul_polys == npolys ? mul + ((u0 * L) << log_n) : mul;
+                    mp = mul_polys == npolys ? (u1 - u0) * L : mul_polys;
+                }
+            }
+            const u64 grid = std::max(tot[0], std::max(tot[1], tot[2]));
+            if (grid == 0) continue;
+            if (grid > 0x7fffffffull) {
+                set_last_error("batch too large for one launch");
+                return PFHE_ERR_BAD_LENGTH;
+            }
+            hipLaunchKernelGGL((ntt_pipe_mid_kernel<A, 12>), dim3((u32)grid), dim3(BlockCfg<12>::THREADS), lds_bytes, s, ptr[1],
+                               tot[1], ptr[0], tot[0], ptr[2], tot[2], primes, L, mptr, mp);
+            PFHE_HIP(hipGetLastError());
+        }
+        return PFHE_OK;
+    }
+    PFHE_TRY(ntt_pass_dev(primes, L, log_n, arith, data, npolys, false, 0, false, s, nullptr, 0, tune));
+    PFHE_TRY(launch_mid(std::integral_constant<int, 12>{}, data, npolys, mul, mul_polys));
+    return ntt_pass_dev(primes, L, log_n, arith, data, npolys, true, 1, false, s, nullptr, 0, tune);
+}
+
+int ntt_polymul_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, const u64 *mul,
+                    u64 mul_polys, hipStream_t s, const NttTuning &tune) {
+    if (mul == nullptr || mul_polys == 0 || mul_polys % L != 0 || (mul_polys != npolys && mul_polys != L))
+        return PFHE_ERR_BAD_ARGUMENT;
+    if (arith == kArithB32) return PFHE_ERR_UNSUPPORTED;
+    if (npolys == 0) return PFHE_OK;
+    return arith == kArithPm ? polymul_impl<PmArith>(primes, L, log_n, arith, data, npolys, mul, mul_polys, s, tune)
+                             : polymul_impl<ShoupArith>(primes, L, log_n, arith, data, npolys, mul, mul_polys, s, tune);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -53,6 +53,11 @@ int ntt_inverse_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *da
 // 64-bit policies only.
 int ntt_inverse_mul_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, const u64 *mul,
                         u64 mul_polys, hipStream_t s, const NttTuning &tune = NttTuning());
+// data <- INTT(NTT(data) (*) mul) with the forward block pass, the product and the inverse block pass fused in one kernel
+// (one HBM round trip for N <= 2^14, three for two-pass rings).  PFHE_ERR_UNSUPPORTED: shape not covered, use
+// ntt_forward_dev + ntt_inverse_mul_dev.  64-bit policies only.
+int ntt_polymul_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, const u64 *mul,
+                    u64 mul_polys, hipStream_t s, const NttTuning &tune = NttTuning());
 // U32NttTable / U32DcrtTable transforms (log_n = log2 of the polynomial length in coefficients)
 int ntt32_transform_dev(const NttPrime *primes, u32 L, u32 log_n, u32 *data, u64 npolys, bool inverse, bool lazy,
                         hipStream_t s, const NttTuning &tune = NttTuning());
@@ -772,6 +777,7 @@ __device__ __forceinline__ void fwd_chain(const A &ar, u64 (&x)[1 << LOGE], u64 
     if constexpr (POS > 0) {
         constexpr int NPOS = POS >= LOGE ? POS - LOGE : 0;
         constexpr int JHI = POS >= LOGE ? LOGE - 1 : POS - 1;
+        asm volatile("" : "+v"(lt));  // this pass's LDS and twiddle addresses are computed here, not hoisted to the kernel's top
         lds_exchange<POS, NPOS, FIRST, LOGE>(x, lds, lt);
 #ifdef PFHE_STAMPS
         PFHE_STAMP(NPOS == 0 ? 6 : 4);
@@ -829,6 +835,7 @@ __device__ __forceinline__ void inv_chain(const A &ar, u64 (&x)[1 << LOGE], u64 
         constexpr int NPOS = DONE <= LOGB - LOGE ? DONE : LOGB - LOGE;
         constexpr int JLO = DONE - NPOS;
         constexpr bool LAST = NPOS + LOGE >= LOGB;
+        asm volatile("" : "+v"(lt));  // see fwd_chain
         lds_exchange<POS, NPOS, FIRST, LOGE>(x, lds, lt);
         if constexpr (LAST) before_last();
         inv_regpass<A, NPOS, JLO, LOGE - 1, UNI, LOGE>(ar, x, n, eblk + layout<NPOS, LOGE>(lt, 0), LAST && final_block, lazy);

@@ -476,6 +476,16 @@ def test_fused_polymul_large_batch_tiled_path(pf, orc, shared):
     plain = a.clone()
     d_plain.mul_dcrt_polynomial_dev(plain, bh)
     assert torch.equal(fused, plain)
+    # d fuses forward block pass -> product -> inverse block pass in one kernel (three HBM passes); the four-pass form
+    # (forward transform, then the product on the loads of the inverse transform's block pass) stays as the fallback
+    os.environ["PFHE_DISABLE_POLYMUL_MID"] = "1"
+    try:
+        d_four = pf.U64DcrtTable(log_n, Q61)
+    finally:
+        del os.environ["PFHE_DISABLE_POLYMUL_MID"]
+    four = a.clone()
+    d_four.mul_dcrt_polynomial_dev(four, bh)
+    assert torch.equal(fused, four)
     for e in (0, 179, 359):
         x = to_host(a[e * W:(e + 1) * W]).copy()
         o.transform_slice(x)
@@ -742,6 +752,37 @@ def test_config3_full_batch_every_element(pf, orc):
         ref = to_host(x[s0 * W:(s0 + slab) * W]).copy()
         oracle_map(o.inverse_transform_slice, ref, W)
         assert np.array_equal(to_host(orig[s0 * W:(s0 + slab) * W]), ref), s0
+
+
+@pytest.mark.parametrize("shared", [True, False])
+def test_config3_polymul_full_batch_every_element(pf, orc, shared):
+    """BASELINE config 3 at its full batch: NTT -> pointwise product -> INTT of all 4096 RNS polynomials (the pipelined
+    three-pass form: tiles + 2 launches of ntt_pipe_mid_kernel), EVERY limb polynomial compared with the oracle
+    (transform_slice, DcrtPolynomial::mul_assign, inverse_transform_slice), shared and per-element multiplicand."""
+    import torch
+    from gpu_util import oracle_map
+    log_n, batch = 16, 4096
+    n, L = 1 << log_n, 3
+    W = L * n
+    d, o = pf.U64DcrtTable(log_n, Q61), orc.U64DcrtTable(log_n, Q61)
+    x = _fill(pf, batch * W, Q61, n, 0x5EED000000000003)
+    bh = _fill(pf, W if shared else batch * W, Q61, n, 77)
+    orig = x.clone()
+    d.mul_dcrt_polynomial_dev(x, bh)
+    torch.cuda.synchronize()
+    hb = to_host(bh)
+    slab = 256
+    for s0 in range(0, batch, slab):
+        ref = to_host(orig[s0 * W:(s0 + slab) * W]).copy()
+        oracle_map(o.transform_slice, ref, W)
+        if shared:
+            oracle_map(lambda c: [o.mul_assign(c[i:i + W], hb) for i in range(0, c.size, W)], ref, W)
+        else:
+            mb = hb[s0 * W:(s0 + slab) * W]
+            for i in range(slab):
+                o.mul_assign(ref[i * W:(i + 1) * W], mb[i * W:(i + 1) * W])
+        oracle_map(o.inverse_transform_slice, ref, W)
+        assert np.array_equal(to_host(x[s0 * W:(s0 + slab) * W]), ref), s0
 
 
 def test_config2_full_batch(pf, orc):
