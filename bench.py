@@ -125,6 +125,31 @@ def cpu_baseline(seconds: float):
         "sample": f"{done} forward limb-NTTs of N=2^16 (61-bit primes), oracle "
                   f"{'AVX-512 DQ' if avx512 else 'scalar'} Harvey path, {cores} threads, {dt:.1f} s",
     }
+    # the reference's own criterion case (benches/bench_u64.rs:8,117-130: q = 1125899906826241 < 2^50, N = 4096), where an
+    # AVX-512 IFMA host takes the BIT_SHIFT = 52 rung (prime64/table.rs:166-186): restated in the oracle as well
+    try:
+        q50, ln50 = 1125899906826241, 12
+        t50 = oracle.U64NttTable(ln50, q50)
+        ifma = bool(oracle.lib().orc_avx512_ifma_available())
+        b50 = [rng.integers(0, q50, (1 << ln50) * 512, dtype=np.uint64) for _ in range(cores)]
+
+        def w50(i, shift):
+            t50.transform_batch_avx512(b50[i], shift=shift)
+            return 512
+
+        rates = {}
+        for label, shift in ((("ifma", 52),) if ifma else ()) + ((("dq", 64),) if avx512 else ()):
+            t0 = time.perf_counter()
+            d = 0
+            with ThreadPoolExecutor(cores) as ex:
+                while time.perf_counter() - t0 < 0.5:
+                    d += sum(ex.map(lambda i: w50(i, shift), range(cores)))
+            rates[label] = d / (time.perf_counter() - t0)
+        out["reference_bench_case"] = {
+            "workload": "forward NTT, N = 4096, q = 1125899906826241 (primus_ntt/benches/bench_u64.rs:8)", "cores": cores,
+            "unit": "NTT/s", "backend_the_reference_dispatches_to": "ifma" if ifma else ("dq" if avx512 else "scalar"), **rates}
+    except Exception as e:
+        out["reference_bench_case"] = {"error": str(e)[:200]}
     # RLWE external product at the config-4 shape (one ciphertext per task, one shared GGSW): the oracle's
     # restatement of CrtGlwe::mul_dcrt_ggsw_to with its forward transforms on the vector backend when present
     try:

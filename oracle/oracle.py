@@ -82,6 +82,10 @@ def _load(path: str | None = None) -> C.CDLL:
     sig("orc_get_vector_backend", ci)
     sig("orc_u64_ntt_forward_avx512", ci, vp, _u64p, ci)
     sig("orc_u64_ntt_inverse_avx512", ci, vp, _u64p, ci)
+    sig("orc_avx512_ifma_available", ci)
+    sig("orc_u64_ntt_forward_avx512_shift", ci, vp, _u64p, ci, ci)
+    sig("orc_u64_ntt_inverse_avx512_shift", ci, vp, _u64p, ci, ci)
+    sig("orc_u64_ntt_forward_avx512_batch", ci, vp, _u64p, sz, ci, ci)
     sig("orc_u64_ntt_transform_monomial", None, vp, u64, sz, _u64p)
     sig("orc_u64_ntt_transform_coeff_one_monomial", None, vp, sz, _u64p)
     sig("orc_u64_ntt_transform_coeff_minus_one_monomial", None, vp, sz, _u64p)
@@ -274,23 +278,31 @@ class U64NttTable:
     def lazy_transform_slice(self, a): self._each(lib().orc_u64_ntt_lazy_transform_slice, a)
     def lazy_inverse_transform_slice(self, a): self._each(lib().orc_u64_ntt_lazy_inverse_transform_slice, a)
 
-    def transform_slice_avx512(self, a, lazy: bool = False):
-        """Forward transform through the AVX-512 DQ backend (prime64/avx512/); raises when unavailable."""
+    def transform_slice_avx512(self, a, lazy: bool = False, shift: int = 0):
+        """Forward transform through the AVX-512 backend (prime64/avx512/): shift 64 = DQ rung, 52 = IFMA rung
+        (q < 2^50), 0 = the reference's dispatch (table.rs:166-232); raises when unavailable."""
         assert a.size % self.n == 0
         flat = a.reshape(-1)
         base = flat.ctypes.data
         for i in range(flat.size // self.n):
-            rc = lib().orc_u64_ntt_forward_avx512(self._h, C.cast(base + 8 * self.n * i, _u64p), int(lazy))
+            rc = lib().orc_u64_ntt_forward_avx512_shift(self._h, C.cast(base + 8 * self.n * i, _u64p), int(lazy), shift)
             if rc:
                 raise OracleError(rc)
 
-    def inverse_transform_slice_avx512(self, a, lazy: bool = False):
-        """Inverse transform through the AVX-512 DQ backend (prime64/avx512/transform.rs:205); raises when unavailable."""
+    def transform_batch_avx512(self, a, lazy: bool = False, shift: int = 0):
+        """Every polynomial of `a` forward-transformed inside ONE foreign call (no per-polynomial Python dispatch)."""
+        assert a.size % self.n == 0
+        rc = lib().orc_u64_ntt_forward_avx512_batch(self._h, _p(a.reshape(-1)), a.size // self.n, int(lazy), shift)
+        if rc:
+            raise OracleError(rc)
+
+    def inverse_transform_slice_avx512(self, a, lazy: bool = False, shift: int = 0):
+        """Inverse transform through the AVX-512 backend (prime64/avx512/transform.rs:205); shift as above."""
         assert a.size % self.n == 0
         flat = a.reshape(-1)
         base = flat.ctypes.data
         for i in range(flat.size // self.n):
-            rc = lib().orc_u64_ntt_inverse_avx512(self._h, C.cast(base + 8 * self.n * i, _u64p), int(lazy))
+            rc = lib().orc_u64_ntt_inverse_avx512_shift(self._h, C.cast(base + 8 * self.n * i, _u64p), int(lazy), shift)
             if rc:
                 raise OracleError(rc)
 

@@ -36,6 +36,7 @@ uint64_t orc_shoup_quotient(uint64_t w, uint64_t q) {
 static uint64_t multiply_factor_quotient(uint64_t w, uint32_t shift, uint64_t q) {
     return (uint64_t)((((u128)w) << shift) / q);
 }
+uint64_t orc_multiply_factor_quotient(uint64_t w, uint32_t shift, uint64_t q) { return multiply_factor_quotient(w, shift, q); }
 
 /* arithmetic.rs:32-35  Barrett-64 lazy multiply, result in [0, 2q) */
 uint64_t orc_mul_mod_lazy(uint64_t y, uint64_t w, uint64_t w_precon, uint64_t q) {
@@ -239,8 +240,8 @@ struct orc_u64_ntt {
     uint64_t root, inv_root;
     uint64_t inv_n, inv_n_precon32, inv_n_precon64;
     uint64_t inv_n_w, inv_n_w_precon32, inv_n_w_precon64;
-    uint64_t *roots, *roots_precon32, *roots_precon64;
-    uint64_t *inv_roots, *inv_roots_precon32, *inv_roots_precon64;
+    uint64_t *roots, *roots_precon32, *roots_precon64, *roots_precon52;
+    uint64_t *inv_roots, *inv_roots_precon32, *inv_roots_precon64, *inv_roots_precon52;
     uint64_t *ordinal_roots; /* 2n */
     size_t *rev;             /* reverse_lsbs, n */
 };
@@ -290,6 +291,14 @@ int orc_u64_ntt_new(uint32_t log_n, uint64_t q, orc_u64_ntt **out) {
         t->roots_precon64[i] = orc_shoup_quotient(t->roots[i], q);
         t->inv_roots_precon64[i] = orc_shoup_quotient(t->inv_roots[i], q);
     }
+    if (q < (1ull << 50)) { /* Barrett-52 preconditioners of the IFMA rung (table.rs:98-110, precompute.rs:37-45) */
+        t->roots_precon52 = (uint64_t *)malloc(n * sizeof(uint64_t));
+        t->inv_roots_precon52 = (uint64_t *)malloc(n * sizeof(uint64_t));
+        for (size_t i = 0; i < n; ++i) {
+            t->roots_precon52[i] = multiply_factor_quotient(t->roots[i], 52, q);
+            t->inv_roots_precon52[i] = multiply_factor_quotient(t->inv_roots[i], 52, q);
+        }
+    }
     if (t->low_q) {
         t->roots_precon32 = (uint64_t *)malloc(n * sizeof(uint64_t));
         t->inv_roots_precon32 = (uint64_t *)malloc(n * sizeof(uint64_t));
@@ -314,8 +323,8 @@ int orc_u64_ntt_new(uint32_t log_n, uint64_t q, orc_u64_ntt **out) {
 
 void orc_u64_ntt_free(orc_u64_ntt *t) {
     if (!t) return;
-    free(t->roots); free(t->roots_precon32); free(t->roots_precon64);
-    free(t->inv_roots); free(t->inv_roots_precon32); free(t->inv_roots_precon64);
+    free(t->roots); free(t->roots_precon32); free(t->roots_precon64); free(t->roots_precon52);
+    free(t->inv_roots); free(t->inv_roots_precon32); free(t->inv_roots_precon64); free(t->inv_roots_precon52);
     free(t->ordinal_roots); free(t->rev);
     free(t);
 }
@@ -330,6 +339,8 @@ const uint64_t *orc_u64_ntt_roots(const orc_u64_ntt *t) { return t->roots; }
 const uint64_t *orc_u64_ntt_roots_precon64(const orc_u64_ntt *t) { return t->roots_precon64; }
 const uint64_t *orc_u64_ntt_inv_roots(const orc_u64_ntt *t) { return t->inv_roots; }
 const uint64_t *orc_u64_ntt_inv_roots_precon64(const orc_u64_ntt *t) { return t->inv_roots_precon64; }
+const uint64_t *orc_u64_ntt_roots_precon52(const orc_u64_ntt *t) { return t->roots_precon52; }
+const uint64_t *orc_u64_ntt_inv_roots_precon52(const orc_u64_ntt *t) { return t->inv_roots_precon52; }
 const uint64_t *orc_u64_ntt_ordinal_roots(const orc_u64_ntt *t) { return t->ordinal_roots; }
 
 static uint32_t pick_shift(const orc_u64_ntt *t, uint32_t bit_shift) {

@@ -51,6 +51,8 @@ enum orc_status {
 uint64_t orc_reduce_once(uint64_t x, uint64_t q);
 uint64_t orc_reduce_twice(uint64_t x, uint64_t q, uint64_t two_q);
 uint64_t orc_shoup_quotient(uint64_t w, uint64_t q);
+/* MultiplyFactor::new(w, shift, q).quotient() = floor(w * 2^shift / q) (primus_factor/src/mul_factor/mod.rs:18) */
+uint64_t orc_multiply_factor_quotient(uint64_t w, uint32_t shift, uint64_t q);
 uint64_t orc_mul_mod_lazy(uint64_t y, uint64_t w, uint64_t w_precon, uint64_t q);
 uint64_t orc_mul_mod_lazy32(uint64_t y, uint64_t w, uint64_t w_precon32, uint64_t q);
 uint64_t orc_shoup_mul(uint64_t w, uint64_t w_precon, uint64_t b, uint64_t q);
@@ -92,6 +94,8 @@ uint64_t orc_u64_ntt_inv_n(const orc_u64_ntt *t);
 uint64_t orc_u64_ntt_inv_n_w(const orc_u64_ntt *t);
 const uint64_t *orc_u64_ntt_roots(const orc_u64_ntt *t);
 const uint64_t *orc_u64_ntt_roots_precon64(const orc_u64_ntt *t);
+const uint64_t *orc_u64_ntt_roots_precon52(const orc_u64_ntt *t);     /* null unless q < 2^50 */
+const uint64_t *orc_u64_ntt_inv_roots_precon52(const orc_u64_ntt *t); /* null unless q < 2^50 */
 const uint64_t *orc_u64_ntt_inv_roots(const orc_u64_ntt *t);
 const uint64_t *orc_u64_ntt_inv_roots_precon64(const orc_u64_ntt *t);
 const uint64_t *orc_u64_ntt_ordinal_roots(const orc_u64_ntt *t);
@@ -131,8 +135,14 @@ int orc_avx512_available(void);
  * AVX-512 backend when the host has one (bench.py's cpu_baseline only) */
 void orc_set_vector_backend(int on);
 int orc_get_vector_backend(void);
+/* dispatch as the reference does (table.rs:166-302): IFMA (BIT_SHIFT = 52) when the CPU has it and q < 2^50, else DQ */
 int orc_u64_ntt_forward_avx512(const orc_u64_ntt *t, uint64_t *values, int lazy);
 int orc_u64_ntt_inverse_avx512(const orc_u64_ntt *t, uint64_t *values, int lazy);
+/* shift = 64 forces the DQ rung, 52 the IFMA rung (ORC_ERR_BAD_ARG when the CPU lacks it or q >= 2^50), 0 dispatches */
+int orc_avx512_ifma_available(void);
+int orc_u64_ntt_forward_avx512_shift(const orc_u64_ntt *t, uint64_t *values, int lazy, int shift);
+int orc_u64_ntt_inverse_avx512_shift(const orc_u64_ntt *t, uint64_t *values, int lazy, int shift);
+int orc_u64_ntt_forward_avx512_batch(const orc_u64_ntt *t, uint64_t *values, size_t count, int lazy, int shift);
 
 /* ---------------- U32NttTable (prime32/table.rs, prime32/scalar/) ---------------- */
 typedef struct orc_u32_ntt orc_u32_ntt;

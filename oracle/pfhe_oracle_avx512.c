@@ -17,6 +17,8 @@
  * loaded twiddles instead); the arithmetic per butterfly is the same.  Canonical outputs are
  * identical to the scalar path's (tests/test_oracle_avx512.py); it exists so that bench.py's
  * cpu_baseline is not handicapped against what the real reference would run on this host.
+ * The body (pfhe_oracle_avx512_impl.h) is compiled twice: BIT_SHIFT = 64 (DQ) and BIT_SHIFT = 52 (IFMA, q < 2^50:
+ * butterfly.rs:30-35,97-102, utils/arithmetic.rs:62-75,141-165, transform.rs:388-397).
  */
 #include <immintrin.h>
 #include <stddef.h>
@@ -24,245 +26,64 @@
 
 #include "pfhe_oracle.h"
 
-#define TGT __attribute__((target("avx512f,avx512dq")))
-
 int orc_avx512_available(void) {
     __builtin_cpu_init();
     return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq");
 }
 
-TGT static inline __m512i small_mod(__m512i x, __m512i m) { return _mm512_min_epu64(x, _mm512_sub_epi64(x, m)); }
-
-/* utils/arithmetic.rs:94-127: high 64 bits of x*y without the lo*lo partial product (error <= 1) */
-TGT static inline __m512i mulhi_approx(__m512i x, __m512i y) {
-    const __m512i lo_mask = _mm512_set1_epi64(0xFFFFFFFFll);
-    const __m512i x_hi = _mm512_shuffle_epi32(x, (_MM_PERM_ENUM)0xB1), y_hi = _mm512_shuffle_epi32(y, (_MM_PERM_ENUM)0xB1);
-    const __m512i z_lo_hi = _mm512_mul_epu32(x, y_hi), z_hi_lo = _mm512_mul_epu32(x_hi, y), z_hi_hi = _mm512_mul_epu32(x_hi, y_hi);
-    const __m512i sum_lo = _mm512_and_si512(z_lo_hi, lo_mask), sum_mid = _mm512_srli_epi64(z_lo_hi, 32);
-    const __m512i sum_mid2 = _mm512_add_epi64(z_hi_lo, sum_lo);
-    return _mm512_add_epi64(_mm512_add_epi64(z_hi_hi, sum_mid), _mm512_srli_epi64(sum_mid2, 32));
+int orc_avx512_ifma_available(void) {
+    return orc_avx512_available() && __builtin_cpu_supports("avx512ifma");
 }
 
-/* butterfly.rs:10-57, BIT_SHIFT = 64 */
-TGT static inline void fwd_bfly(__m512i *x, __m512i *y, __m512i w, __m512i wp, __m512i neg_q, __m512i two_q) {
-    *x = small_mod(*x, two_q);
-    const __m512i qh = mulhi_approx(wp, *y);
-    __m512i t = _mm512_add_epi64(_mm512_mullo_epi64(w, *y), _mm512_mullo_epi64(qh, neg_q)); /* [0,4q) */
-    t = small_mod(t, two_q);
-    *y = _mm512_add_epi64(*x, _mm512_sub_epi64(two_q, t));
-    *x = _mm512_add_epi64(*x, t);
+/* BIT_SHIFT = 64 */
+#define S52 0
+#define FN(name) name##_dq
+#define TGT __attribute__((target("avx512f,avx512dq")))
+#define AVAILABLE orc_avx512_available
+#include "pfhe_oracle_avx512_impl.h"
+#undef S52
+#undef FN
+#undef TGT
+#undef AVAILABLE
+
+/* BIT_SHIFT = 52 (IFMA) */
+#define S52 1
+#define FN(name) name##_ifma
+#define TGT __attribute__((target("avx512f,avx512dq,avx512ifma")))
+#define AVAILABLE orc_avx512_ifma_available
+#include "pfhe_oracle_avx512_impl.h"
+#undef S52
+#undef FN
+#undef TGT
+#undef AVAILABLE
+
+/* the reference's ladder (table.rs:166-232 forward, :236-302 inverse): IFMA when the CPU has it and q < 2^50, else DQ
+ * (the 32-bit rung for q < 2^30 is the scalar Barrett-32 path's domain in this restatement) */
+static int pick_ifma(const orc_u64_ntt *t, int shift) {
+    if (shift == 52) return 1;
+    if (shift == 64) return 0;
+    return orc_avx512_ifma_available() && orc_u64_ntt_modulus(t) < (1ull << 50) && orc_u64_ntt_roots_precon52(t) != 0;
 }
 
-/* one stage with butterfly distance t >= 8 over `n` values whose first group uses roots[ri0] */
-TGT static void stage_t8(uint64_t *v, size_t n, size_t t, const uint64_t *w, const uint64_t *wp, size_t ri0,
-                         __m512i neg_q, __m512i two_q) {
-    size_t ri = ri0;
-    for (size_t c = 0; c < n; c += 2 * t, ++ri) {
-        const __m512i vw = _mm512_set1_epi64((long long)w[ri]), vwp = _mm512_set1_epi64((long long)wp[ri]);
-        for (size_t j = 0; j < t; j += 8) {
-            __m512i x = _mm512_loadu_si512(v + c + j), y = _mm512_loadu_si512(v + c + j + t);
-            fwd_bfly(&x, &y, vw, vwp, neg_q, two_q);
-            _mm512_storeu_si512(v + c + j, x);
-            _mm512_storeu_si512(v + c + j + t, y);
-        }
-    }
+int orc_u64_ntt_forward_avx512_shift(const orc_u64_ntt *t, uint64_t *values, int lazy, int shift) {
+    return pick_ifma(t, shift) ? orc_u64_ntt_forward_avx512_ifma(t, values, lazy) : orc_u64_ntt_forward_avx512_dq(t, values, lazy);
+}
+int orc_u64_ntt_inverse_avx512_shift(const orc_u64_ntt *t, uint64_t *values, int lazy, int shift) {
+    return pick_ifma(t, shift) ? orc_u64_ntt_inverse_avx512_ifma(t, values, lazy) : orc_u64_ntt_inverse_avx512_dq(t, values, lazy);
+}
+int orc_u64_ntt_forward_avx512(const orc_u64_ntt *t, uint64_t *values, int lazy) {
+    return orc_u64_ntt_forward_avx512_shift(t, values, lazy, 0);
+}
+int orc_u64_ntt_inverse_avx512(const orc_u64_ntt *t, uint64_t *values, int lazy) {
+    return orc_u64_ntt_inverse_avx512_shift(t, values, lazy, 0);
 }
 
-/* the last three stages (distances 4, 2, 1) on 16 consecutive values at a time; `m4` = number of
- * distance-4 groups in this sub-transform, whose roots start at roots[ri4] (then 2*ri4, 4*ri4) */
-TGT static void stages_t4_t2_t1(uint64_t *v, size_t n, const uint64_t *w, const uint64_t *wp, size_t ri4,
-                                __m512i neg_q, __m512i two_q, __m512i q, int canonical) {
-    const __m512i ix4 = _mm512_setr_epi64(0, 1, 2, 3, 8, 9, 10, 11), iy4 = _mm512_setr_epi64(4, 5, 6, 7, 12, 13, 14, 15);
-    const __m512i iw4 = _mm512_setr_epi64(0, 0, 0, 0, 1, 1, 1, 1);
-    const __m512i ix2 = _mm512_setr_epi64(0, 1, 4, 5, 8, 9, 12, 13), iy2 = _mm512_setr_epi64(2, 3, 6, 7, 10, 11, 14, 15);
-    const __m512i iw2 = _mm512_setr_epi64(0, 0, 1, 1, 2, 2, 3, 3);
-    const __m512i oa2 = _mm512_setr_epi64(0, 1, 8, 9, 2, 3, 10, 11), ob2 = _mm512_setr_epi64(4, 5, 12, 13, 6, 7, 14, 15);
-    const __m512i ix1 = _mm512_setr_epi64(0, 2, 4, 6, 8, 10, 12, 14), iy1 = _mm512_setr_epi64(1, 3, 5, 7, 9, 11, 13, 15);
-    const __m512i oa1 = _mm512_setr_epi64(0, 8, 1, 9, 2, 10, 3, 11), ob1 = _mm512_setr_epi64(4, 12, 5, 13, 6, 14, 7, 15);
-    size_t r4 = ri4, r2 = 2 * ri4, r1 = 4 * ri4;
-    for (size_t c = 0; c < n; c += 16, r4 += 2, r2 += 4, r1 += 8) {
-        __m512i a = _mm512_loadu_si512(v + c), b = _mm512_loadu_si512(v + c + 8);
-        /* distance 4 */
-        __m512i x = _mm512_permutex2var_epi64(a, ix4, b), y = _mm512_permutex2var_epi64(a, iy4, b);
-        __m512i vw = _mm512_permutexvar_epi64(iw4, _mm512_maskz_loadu_epi64(0x03, w + r4));
-        __m512i vp = _mm512_permutexvar_epi64(iw4, _mm512_maskz_loadu_epi64(0x03, wp + r4));
-        fwd_bfly(&x, &y, vw, vp, neg_q, two_q);
-        a = _mm512_permutex2var_epi64(x, ix4, y); /* [X0-3, Y0-3] */
-        b = _mm512_permutex2var_epi64(x, iy4, y); /* [X4-7, Y4-7] */
-        /* distance 2 */
-        x = _mm512_permutex2var_epi64(a, ix2, b);
-        y = _mm512_permutex2var_epi64(a, iy2, b);
-        vw = _mm512_permutexvar_epi64(iw2, _mm512_maskz_loadu_epi64(0x0F, w + r2));
-        vp = _mm512_permutexvar_epi64(iw2, _mm512_maskz_loadu_epi64(0x0F, wp + r2));
-        fwd_bfly(&x, &y, vw, vp, neg_q, two_q);
-        a = _mm512_permutex2var_epi64(x, oa2, y);
-        b = _mm512_permutex2var_epi64(x, ob2, y);
-        /* distance 1 */
-        x = _mm512_permutex2var_epi64(a, ix1, b);
-        y = _mm512_permutex2var_epi64(a, iy1, b);
-        vw = _mm512_loadu_si512(w + r1);
-        vp = _mm512_loadu_si512(wp + r1);
-        fwd_bfly(&x, &y, vw, vp, neg_q, two_q);
-        if (canonical) { /* [0,4q) -> [0,q) */
-            x = small_mod(small_mod(x, two_q), q);
-            y = small_mod(small_mod(y, two_q), q);
-        }
-        _mm512_storeu_si512(v + c, _mm512_permutex2var_epi64(x, oa1, y));
-        _mm512_storeu_si512(v + c + 8, _mm512_permutex2var_epi64(x, ob1, y));
-    }
-}
-
-/* transform.rs:13-260: sub-transform of `n` values whose first stage (distance n/2) has its single
- * group at roots[ri]; the following stage's groups start at roots[2*ri], and so on */
-TGT static void forward_rec(uint64_t *v, size_t n, const uint64_t *w, const uint64_t *wp, size_t ri, __m512i neg_q,
-                            __m512i two_q, __m512i q, int canonical) {
-    if (n > 1024) { /* depth-first: one stage, then the two halves */
-        stage_t8(v, n, n >> 1, w, wp, ri, neg_q, two_q);
-        forward_rec(v, n >> 1, w, wp, 2 * ri, neg_q, two_q, q, canonical);
-        forward_rec(v + (n >> 1), n >> 1, w, wp, 2 * ri + 1, neg_q, two_q, q, canonical);
-        return;
-    }
-    size_t t = n >> 1, r = ri;
-    for (; t >= 8; t >>= 1, r <<= 1) stage_t8(v, n, t, w, wp, r, neg_q, two_q);
-    stages_t4_t2_t1(v, n, w, wp, r, neg_q, two_q, q, canonical);
-}
-
-/* U64NttTable::transform_slice / lazy_transform_slice through the AVX-512 backend (n >= 16) */
-TGT int orc_u64_ntt_forward_avx512(const orc_u64_ntt *t, uint64_t *values, int lazy) {
+/* `count` consecutive polynomials in one call (bench.py's CPU legs: keeps the Python dispatch out of the timing) */
+int orc_u64_ntt_forward_avx512_batch(const orc_u64_ntt *t, uint64_t *values, size_t count, int lazy, int shift) {
     const size_t n = orc_u64_ntt_n(t);
-    if (n < 16 || !orc_avx512_available()) return ORC_ERR_BAD_ARG;
-    const uint64_t qv = orc_u64_ntt_modulus(t);
-    const __m512i q = _mm512_set1_epi64((long long)qv), two_q = _mm512_set1_epi64((long long)(qv << 1));
-    const __m512i neg_q = _mm512_set1_epi64(-(long long)qv);
-    forward_rec(values, n, orc_u64_ntt_roots(t), orc_u64_ntt_roots_precon64(t), 1, neg_q, two_q, q, !lazy);
-    return ORC_OK;
-}
-
-/* ------------------------------------------------------------------------------------------------
- * inverse transform — prime64/avx512/transform.rs:205-423 with BIT_SHIFT = 64, input_mod_factor = 1
- * (table.rs:257-272).  Twiddle of the stage with `m` groups over the whole transform: inv_roots[1 + N - 2m + g]
- * (the reference reaches the same entries by walking w_idx with its per-depth deltas).
- * ------------------------------------------------------------------------------------------------ */
-
-/* utils/arithmetic.rs:19-60: exact high 64 bits of x*y */
-TGT static inline __m512i mulhi_exact(__m512i x, __m512i y) {
-    const __m512i lo_mask = _mm512_set1_epi64(0xFFFFFFFFll);
-    const __m512i x_hi = _mm512_shuffle_epi32(x, (_MM_PERM_ENUM)0xB1), y_hi = _mm512_shuffle_epi32(y, (_MM_PERM_ENUM)0xB1);
-    const __m512i z_lo_lo = _mm512_mul_epu32(x, y), z_lo_hi = _mm512_mul_epu32(x, y_hi);
-    const __m512i z_hi_lo = _mm512_mul_epu32(x_hi, y), z_hi_hi = _mm512_mul_epu32(x_hi, y_hi);
-    const __m512i sum_tmp = _mm512_add_epi64(z_lo_hi, _mm512_srli_epi64(z_lo_lo, 32));
-    const __m512i sum_lo = _mm512_and_si512(sum_tmp, lo_mask), sum_mid = _mm512_srli_epi64(sum_tmp, 32);
-    const __m512i sum_mid2 = _mm512_add_epi64(z_hi_lo, sum_lo);
-    return _mm512_add_epi64(_mm512_add_epi64(z_hi_hi, sum_mid), _mm512_srli_epi64(sum_mid2, 32));
-}
-
-/* butterfly.rs:58-117, BIT_SHIFT = 64: X' = X + Y mod 2q, Y' = W * (X - Y + 2q) mod~ q in [0,2q) */
-TGT static inline void inv_bfly(__m512i *x, __m512i *y, __m512i w, __m512i wp, __m512i neg_q, __m512i two_q,
-                                int input_less_than_mod) {
-    const __m512i y_minus_2q = _mm512_sub_epi64(*y, two_q);
-    const __m512i t = _mm512_sub_epi64(*x, y_minus_2q);
-    if (input_less_than_mod) {
-        *x = _mm512_add_epi64(*x, *y);
-    } else {
-        *x = _mm512_add_epi64(*x, y_minus_2q);
-        const __mmask8 neg = _mm512_movepi64_mask(*x);
-        *x = _mm512_mask_add_epi64(*x, neg, *x, two_q);
-    }
-    const __m512i qh = mulhi_approx(wp, t);
-    *y = small_mod(_mm512_add_epi64(_mm512_mullo_epi64(w, t), _mm512_mullo_epi64(qh, neg_q)), two_q);
-}
-
-/* stages at distances 1, 2, 4 on 16 consecutive values at a time (stages.rs: inv_t1, inv_t2, inv_t4).
- * r1 / r2 / r4: index of the first twiddle of this sub-transform's distance-1 / 2 / 4 stage. */
-TGT static void inv_stages_t1_t2_t4(uint64_t *v, size_t n, const uint64_t *w, const uint64_t *wp, size_t r1, size_t r2,
-                                    size_t r4, __m512i neg_q, __m512i two_q, int input_less_than_mod) {
-    const __m512i even = _mm512_setr_epi64(0, 2, 4, 6, 8, 10, 12, 14), odd = _mm512_setr_epi64(1, 3, 5, 7, 9, 11, 13, 15);
-    /* after distance 1: X[k] = element 2k, Y[k] = element 2k+1; distance-2 operands: elements {0,1,4,5,8,9,12,13} and
-     * {2,3,6,7,10,11,14,15} */
-    const __m512i x2i = _mm512_setr_epi64(0, 8, 2, 10, 4, 12, 6, 14), y2i = _mm512_setr_epi64(1, 9, 3, 11, 5, 13, 7, 15);
-    const __m512i iw2 = _mm512_setr_epi64(0, 0, 1, 1, 2, 2, 3, 3);
-    /* after distance 2: x lanes = elements {0,1,4,5,8,9,12,13}, y lanes = {2,3,6,7,10,11,14,15}; distance-4 operands:
-     * elements {0,1,2,3,8,9,10,11} and {4,5,6,7,12,13,14,15} */
-    const __m512i x4i = _mm512_setr_epi64(0, 1, 8, 9, 4, 5, 12, 13), y4i = _mm512_setr_epi64(2, 3, 10, 11, 6, 7, 14, 15);
-    const __m512i iw4 = _mm512_setr_epi64(0, 0, 0, 0, 1, 1, 1, 1);
-    /* after distance 4: x lanes = elements {0..3, 8..11}, y lanes = {4..7, 12..15} */
-    const __m512i oa = _mm512_setr_epi64(0, 1, 2, 3, 8, 9, 10, 11), ob = _mm512_setr_epi64(4, 5, 6, 7, 12, 13, 14, 15);
-    for (size_t c = 0; c < n; c += 16, r1 += 8, r2 += 4, r4 += 2) {
-        const __m512i a = _mm512_loadu_si512(v + c), b = _mm512_loadu_si512(v + c + 8);
-        __m512i x = _mm512_permutex2var_epi64(a, even, b), y = _mm512_permutex2var_epi64(a, odd, b);
-        inv_bfly(&x, &y, _mm512_loadu_si512(w + r1), _mm512_loadu_si512(wp + r1), neg_q, two_q, input_less_than_mod);
-        __m512i x2 = _mm512_permutex2var_epi64(x, x2i, y), y2 = _mm512_permutex2var_epi64(x, y2i, y);
-        inv_bfly(&x2, &y2, _mm512_permutexvar_epi64(iw2, _mm512_maskz_loadu_epi64(0x0F, w + r2)),
-                 _mm512_permutexvar_epi64(iw2, _mm512_maskz_loadu_epi64(0x0F, wp + r2)), neg_q, two_q, 0);
-        __m512i x4 = _mm512_permutex2var_epi64(x2, x4i, y2), y4 = _mm512_permutex2var_epi64(x2, y4i, y2);
-        inv_bfly(&x4, &y4, _mm512_permutexvar_epi64(iw4, _mm512_maskz_loadu_epi64(0x03, w + r4)),
-                 _mm512_permutexvar_epi64(iw4, _mm512_maskz_loadu_epi64(0x03, wp + r4)), neg_q, two_q, 0);
-        _mm512_storeu_si512(v + c, _mm512_permutex2var_epi64(x4, oa, y4));
-        _mm512_storeu_si512(v + c + 8, _mm512_permutex2var_epi64(x4, ob, y4));
-    }
-}
-
-/* one stage with butterfly distance t >= 8 (stages.rs: inv_t8); the first group uses inv_roots[ri0] */
-TGT static void inv_stage_t8(uint64_t *v, size_t n, size_t t, const uint64_t *w, const uint64_t *wp, size_t ri0,
-                             __m512i neg_q, __m512i two_q) {
-    size_t ri = ri0;
-    for (size_t c = 0; c < n; c += 2 * t, ++ri) {
-        const __m512i vw = _mm512_set1_epi64((long long)w[ri]), vwp = _mm512_set1_epi64((long long)wp[ri]);
-        for (size_t j = 0; j < t; j += 8) {
-            __m512i x = _mm512_loadu_si512(v + c + j), y = _mm512_loadu_si512(v + c + j + t);
-            inv_bfly(&x, &y, vw, vwp, neg_q, two_q, 0);
-            _mm512_storeu_si512(v + c + j, x);
-            _mm512_storeu_si512(v + c + j + t, y);
-        }
-    }
-}
-
-/* transform.rs:237-334: the sub-transform over the n values starting at element `e0` of a transform of big_n points
- * runs its stages at distances 1 .. n/4 and leaves its own last stage (distance n/2) to its caller: above 1024 points
- * the caller recurses into the two halves and then runs THEIR last stage (distance n/4 here, two groups) in one sweep;
- * the last stage of the whole transform is the fused loop of orc_u64_ntt_inverse_avx512.
- * Index of the first twiddle of the stage at distance t: 1 + N - N/t + e0/(2t). */
-TGT static void inverse_rec(uint64_t *v, size_t n, size_t big_n, size_t e0, const uint64_t *w, const uint64_t *wp,
-                            __m512i neg_q, __m512i two_q, int depth0) {
-#define RI(t) (1 + big_n - big_n / (t) + e0 / (2 * (t)))
-    if (n <= 1024) { /* breadth-first; inputs are below q only for the very first stage of an undivided transform */
-        inv_stages_t1_t2_t4(v, n, w, wp, RI(1), RI(2), RI(4), neg_q, two_q, depth0);
-        for (size_t t = 8; 4 * t <= n; t <<= 1) inv_stage_t8(v, n, t, w, wp, RI(t), neg_q, two_q);
-        return;
-    }
-    inverse_rec(v, n >> 1, big_n, e0, w, wp, neg_q, two_q, 0);
-    inverse_rec(v + (n >> 1), n >> 1, big_n, e0 + (n >> 1), w, wp, neg_q, two_q, 0);
-    inv_stage_t8(v, n, n >> 2, w, wp, RI(n >> 2), neg_q, two_q);
-#undef RI
-}
-
-/* U64NttTable::inverse_transform_slice / lazy_inverse_transform_slice through the AVX-512 backend (n >= 16) */
-TGT int orc_u64_ntt_inverse_avx512(const orc_u64_ntt *t, uint64_t *values, int lazy) {
-    const size_t n = orc_u64_ntt_n(t);
-    if (n < 16 || !orc_avx512_available()) return ORC_ERR_BAD_ARG;
-    const uint64_t qv = orc_u64_ntt_modulus(t);
-    const __m512i q = _mm512_set1_epi64((long long)qv), two_q = _mm512_set1_epi64((long long)(qv << 1));
-    const __m512i neg_q = _mm512_set1_epi64(-(long long)qv);
-    inverse_rec(values, n, n, 0, orc_u64_ntt_inv_roots(t), orc_u64_ntt_inv_roots_precon64(t), neg_q, two_q, 1);
-    /* transform.rs:336-421: final stage with N^-1 (x half) and N^-1 * w (y half), exact quotients */
-    const uint64_t inv_n = orc_u64_ntt_inv_n(t), inv_n_w = orc_u64_ntt_inv_n_w(t);
-    const __m512i v_inv_n = _mm512_set1_epi64((long long)inv_n), v_inv_n_w = _mm512_set1_epi64((long long)inv_n_w);
-    const __m512i v_inv_n_p = _mm512_set1_epi64((long long)orc_shoup_quotient(inv_n, qv));
-    const __m512i v_inv_n_w_p = _mm512_set1_epi64((long long)orc_shoup_quotient(inv_n_w, qv));
-    const size_t h = n >> 1;
-    for (size_t j = 0; j < h; j += 8) {
-        __m512i x = _mm512_loadu_si512(values + j), y = _mm512_loadu_si512(values + j + h);
-        const __m512i y_minus_2q = _mm512_sub_epi64(y, two_q);
-        const __m512i s = small_mod(_mm512_add_epi64(x, y), two_q);
-        const __m512i d = _mm512_sub_epi64(x, y_minus_2q);
-        x = _mm512_add_epi64(_mm512_mullo_epi64(v_inv_n, s), _mm512_mullo_epi64(mulhi_exact(v_inv_n_p, s), neg_q));
-        y = _mm512_add_epi64(_mm512_mullo_epi64(v_inv_n_w, d), _mm512_mullo_epi64(mulhi_exact(v_inv_n_w_p, d), neg_q));
-        if (!lazy) {
-            x = small_mod(x, q);
-            y = small_mod(y, q);
-        }
-        _mm512_storeu_si512(values + j, x);
-        _mm512_storeu_si512(values + j + h, y);
+    for (size_t i = 0; i < count; ++i) {
+        const int rc = orc_u64_ntt_forward_avx512_shift(t, values + i * n, lazy, shift);
+        if (rc) return rc;
     }
     return ORC_OK;
 }

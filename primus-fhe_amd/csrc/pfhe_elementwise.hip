@@ -31,31 +31,15 @@ constexpr int kMaxEwLimbs = 8;
 // workgroups as there are vectors (the dispatcher then walks memory in address order) with non-temporal loads and
 // stores streams at 6.3 TB/s; the usual "8 workgroups per CU + grid-stride loop, 4 vectors in flight per thread"
 // reaches 4.8 TB/s (5.3 TB/s with non-temporal accesses).  The grid-stride loop remains for > 2^31 workgroups.
-#ifndef PFHE_EW_UNROLL
-#define PFHE_EW_UNROLL 1
-#endif
-#ifndef PFHE_EW_WG_PER_CU
-#define PFHE_EW_WG_PER_CU (1u << 22)
-#endif
-#ifndef PFHE_EW_CACHED
-#define PFHE_EW_NT
-#define PFHE_EW_NT_STORE
-#endif
+constexpr int kEwUnroll = 1;                // vectors per thread and iteration
+constexpr unsigned kEwWgPerCu = 1u << 22;   // workgroups per CU before the grid-stride loop takes over
 
 using ew_vec = __attribute__((__vector_size__(2 * sizeof(u64)))) u64;
 __device__ __forceinline__ ew_vec ew_load(const u64 *p) {
-#ifdef PFHE_EW_NT
     return __builtin_nontemporal_load(reinterpret_cast<const ew_vec *>(p));
-#else
-    return *reinterpret_cast<const ew_vec *>(p);
-#endif
 }
 __device__ __forceinline__ void ew_store(u64 *p, ew_vec v) {
-#ifdef PFHE_EW_NT_STORE
     __builtin_nontemporal_store(v, reinterpret_cast<ew_vec *>(p));
-#else
-    *reinterpret_cast<ew_vec *>(p) = v;
-#endif
 }
 
 enum EwOp : int { kAdd, kSub, kNeg, kMulScalar, kAddMulScalar, kMulFactor, kAddMulFactor };
@@ -92,7 +76,7 @@ __global__ __launch_bounds__(kEwThreads) void elementwise_kernel(u64 *out, const
                                                                  const NttPrime *__restrict__ primes, u32 L, u32 log_n,
                                                                  u64 len, EwScalars sc) {
     constexpr u64 V = PAIR ? 2 : 1;
-    constexpr int UNROLL = PFHE_EW_UNROLL;
+    constexpr int UNROLL = kEwUnroll;
     const u64 nvec = len / V;
     const u64 tile = (u64)gridDim.x * blockDim.x;
     for (u64 v0 = (u64)blockIdx.x * blockDim.x + threadIdx.x; v0 < nvec; v0 += tile * UNROLL) {
@@ -230,7 +214,7 @@ __global__ __launch_bounds__(kEwThreads) void inv_kernel(u64 *out, const u64 *in
 
 u32 ew_grid(u64 items) {
     u64 g = (items + kEwThreads - 1) / kEwThreads;
-    const u64 cap = std::min<u64>(256ull * PFHE_EW_WG_PER_CU, 0x7fffffffull);  // grid-stride beyond that
+    const u64 cap = std::min<u64>(256ull * kEwWgPerCu, 0x7fffffffull);  // grid-stride beyond that
     if (g > cap) g = cap;
     if (g == 0) g = 1;
     return (u32)g;
@@ -241,7 +225,7 @@ int launch_elementwise(const TableSet &t, u64 *out, const u64 *a, const u64 *b, 
                        hipStream_t s) {
     if (len == 0) return PFHE_OK;
     const bool pair = t.log_n >= 1;
-    const u64 items = ((pair ? len / 2 : len) + PFHE_EW_UNROLL - 1) / PFHE_EW_UNROLL;
+    const u64 items = ((pair ? len / 2 : len) + kEwUnroll - 1) / kEwUnroll;
     const dim3 g(ew_grid(items)), th(kEwThreads);
     if (pair) hipLaunchKernelGGL((elementwise_kernel<OP, true>), g, th, 0, s, out, a, b, t.primes_dev, t.L, t.log_n, len, sc);
     else hipLaunchKernelGGL((elementwise_kernel<OP, false>), g, th, 0, s, out, a, b, t.primes_dev, t.L, t.log_n, len, sc);

@@ -35,17 +35,13 @@ __device__ __forceinline__ u64 mac(const BarrettMac &m, u64 acc, u64 d, u64 k) {
     return mul_add_mod_barrett(d, k, acc, m.q, m.lo, m.hi);
 }
 
-#ifndef PFHE_MULACC_MIN_WG
-#define PFHE_MULACC_MIN_WG 2  // resident workgroups per CU the register allocation is sized for (tuning switch)
-#endif
+constexpr int kMulaccMinWg = 2;  // resident workgroups per CU the 256-thread form's register allocation is sized for
 // LOGE: 4 = 256 threads with 16 coefficients each, 3 = 512 threads with 8 each.  The accumulators (NC 64-bit words per
 // coefficient) live in registers for the whole loop over the terms: with 16 coefficients per thread they are 64 registers
 // on top of the transform's ~106 and only two workgroups (two waves per SIMD) fit a CU; with 8 they are 32 on top of ~80.
-#ifndef PFHE_MULACC8_MIN_WAVES
-#define PFHE_MULACC8_MIN_WAVES 4
-#endif
+constexpr int kMulacc8MinWaves = 4;
 template <class A, int NC, int LOGE = 4>
-__global__ __launch_bounds__(LOGE == 3 ? 512 : 256, LOGE == 3 ? PFHE_MULACC8_MIN_WAVES : PFHE_MULACC_MIN_WG) void gadget_block_mulacc_kernel(const u64 *__restrict__ digits,
+__global__ __launch_bounds__(LOGE == 3 ? 512 : 256, LOGE == 3 ? kMulacc8MinWaves : kMulaccMinWg) void gadget_block_mulacc_kernel(const u64 *__restrict__ digits,
                                                                   const u64 *__restrict__ ggsw, u64 ggsw_stride,
                                                                   u64 *__restrict__ result,
                                                                   const NttPrime *__restrict__ primes, u32 L, u32 log_n,
@@ -385,8 +381,6 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_wave
     const NttPrime *__restrict__ P = primes + r;
     const A ar(P);
     const u64 W = (u64)L * n;
-    const int *__restrict__ dg = sdigits + e * rows * ell * n + lt;
-    const u64 *__restrict__ key = ggsw + e * ggsw_stride + (u64)r * n + lt * 16;
     u64 *__restrict__ out = result + e * NC * W + (u64)r * n;
 
     u64 acc[NC][16];  // NTT-domain positions lt*16 .. lt*16+15 (register layout <0>)
@@ -408,16 +402,17 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_wave
     const u32 terms = rows * ell;
     for (u32 ij = 0; ij < terms; ++ij) {
         u64 x[16];
+        const u32 ltl = opaque_tid();  // per-term addresses are recomputed, not carried around the loop (see gadget_block_mulacc_kernel)
 #pragma unroll
         for (int k = 0; k < 16; ++k) {  // centred lift (base.rs:279-312) of the balanced digit
-            const int d = dg[(u64)ij * n + (u32)k * Cfg::TPB];
+            const int d = (sdigits + e * rows * ell * n + ltl)[(u64)ij * n + (u32)k * Cfg::TPB];
             x[k] = d < 0 ? ar.q + (u64)(long long)d : (u64)d;
         }
-        block_forward_core<A, LOGB>(ar, x, lds, n, 0u, lt, /*lazy=*/true);
+        block_forward_core<A, LOGB>(ar, x, lds, n, 0u, ltl, /*lazy=*/true);
         const bool fold_now = (ij % kPmMacFoldEvery) == kPmMacFoldEvery - 1;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const GCVec2Ptr kp = (GCVec2Ptr)(const void *)(key + ((u64)ij * NC + c) * W);
+            const GCVec2Ptr kp = (GCVec2Ptr)(const void *)(ggsw + e * ggsw_stride + (u64)r * n + ltl * 16 + ((u64)ij * NC + c) * W);
 #pragma unroll
             for (int v = 0; v < 8; ++v) {
                 const u64x2 kv = kp[v];
@@ -441,18 +436,19 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_wave
     auto epilogue = [&](auto cc) {
         constexpr int c = decltype(cc)::value;
         u64 y[16];
+        const u32 lte = opaque_tid();
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             if constexpr (std::is_same<A, PmArith>::value) y[k] = csub(ar.reduce_x(acc[c][k]), ar.q);
             else y[k] = acc[c][k];
         }
         if (into_coeff) {
-            block_inverse_core<A, LOGB>(ar, y, lds, n, 0u, lt, /*final_block=*/true, /*lazy=*/false);
-            u64 *__restrict__ o = out + (u64)c * W + lt;  // register layout <LOGB-4>: element lt + k * TPB
+            block_inverse_core<A, LOGB>(ar, y, lds, n, 0u, lte, /*final_block=*/true, /*lazy=*/false);
+            u64 *__restrict__ o = out + (u64)c * W + lte;  // register layout <LOGB-4>: element lt + k * TPB
 #pragma unroll
             for (int k = 0; k < 16; ++k) o[(u32)k * Cfg::TPB] = y[k];
         } else {
-            const GVec2Ptr o = (GVec2Ptr)(void *)(out + (u64)c * W + lt * 16);
+            const GVec2Ptr o = (GVec2Ptr)(void *)(out + (u64)c * W + lte * 16);
 #pragma unroll
             for (int v = 0; v < 8; ++v) o[v] = u64x2{y[2 * v], y[2 * v + 1]};
         }

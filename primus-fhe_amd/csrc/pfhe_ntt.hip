@@ -96,7 +96,6 @@ __device__ __forceinline__ void strided_pass_body(u64 *__restrict__ data, const 
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         // streaming (non-temporal) loads: this pass reads every word exactly once; 2.27 -> 2.16 ms per launch
-#ifndef PFHE_PLAIN_STRIDED_LOADS
         if constexpr (VEC == 2) {
             const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(ptr + ((u64)k << log_s)));
             x[k][0] = v.x;
@@ -104,15 +103,6 @@ __device__ __forceinline__ void strided_pass_body(u64 *__restrict__ data, const 
         } else {
             x[k][0] = __builtin_nontemporal_load(ptr + ((u64)k << log_s));
         }
-#else
-        if constexpr (VEC == 2) {
-            const u64x2 v = *reinterpret_cast<const u64x2 *>(ptr + ((u64)k << log_s));
-            x[k][0] = v.x;
-            x[k][1] = v.y;
-        } else {
-            x[k][0] = ptr[(u64)k << log_s];
-        }
-#endif
     }
 
     if constexpr (!INV) {
@@ -136,12 +126,10 @@ __device__ __forceinline__ void strided_pass_body(u64 *__restrict__ data, const 
 // HBM-bound kernel (6.34 / 7.5 GiB moved per 6 GiB launch, forward / inverse): 2.17 -> 2.22 ms and 2.18 -> 2.31 ms, for
 // no better overlap.  VEC == 1 is the LIGHT form (at most 96 registers) that PFHE_LIGHT_STRIDED selects for the strided
 // pass running beside a block pass in the two-stream transform; measured: no gain (5.41 vs 5.37 ms per step).
-#ifndef PFHE_STRIDED_MIN_WAVES
-#define PFHE_STRIDED_MIN_WAVES 1
-#endif
+constexpr int kStridedMinWaves = 1;
 // NT: non-temporal stores (launch_strided picks it for batches of at least kNtMinBytes)
 template <class A, int K, int VEC, bool INV, bool FINAL, bool NT = false>
-__global__ __launch_bounds__(256, K <= 4 ? (VEC == 1 ? 5 : PFHE_STRIDED_MIN_WAVES) : 1) void ntt_strided_kernel(u64 *__restrict__ data,
+__global__ __launch_bounds__(256, K <= 4 ? (VEC == 1 ? 5 : kStridedMinWaves) : 1) void ntt_strided_kernel(u64 *__restrict__ data,
                                                           const NttPrime *__restrict__ primes, u32 L,
                                                           u32 log_n, u32 log_s, u64 total_threads, u32 lazy) {
     strided_pass_body<A, K, VEC, INV, FINAL, NT>(data, primes, L, log_n, log_s,
@@ -157,24 +145,12 @@ __global__ __launch_bounds__(256, K <= 4 ? (VEC == 1 ? 5 : PFHE_STRIDED_MIN_WAVE
 //            the fused N^-1 / N^-1*w scaling (scalar/transform.rs:283-318).
 // ------------------------------------------------------------------------------------------
 // LDS limits the block pass to four waves per SIMD; telling the compiler so makes it spend registers on
-// instruction-level parallelism instead of chasing a higher occupancy it cannot get (1-3 % measured)
-#ifndef PFHE_BLOCK_WAVES_ATTR
-#define PFHE_BLOCK_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4, 4), amdgpu_num_vgpr(104)))
-#endif
-// x is filled from the staging region by lds_get_layout, so the first exchange needs no barrier in front of it
-#ifdef PFHE_BLOCK_LEAD_BARRIER
-constexpr bool kBlockLeadBarrier = true;
-#else
-constexpr bool kBlockLeadBarrier = false;
-#endif
+// instruction-level parallelism instead of chasing a higher occupancy it cannot get (1-3 % measured).
+// (x is filled from the staging region by lds_get_layout, so the first exchange needs no barrier in front of it.)
 
 // Stores of the pipelined kernels' INTERMEDIATE (strided pass -> block pass of the next launch; inverse: the other way
 // round): non-temporal, or plain so that tiles small enough stay in the 256 MiB Infinity Cache until they are read.
-#ifdef PFHE_PIPE_NT_INTERMEDIATE
-constexpr bool kPipeIntermediateNt = true;
-#else
 constexpr bool kPipeIntermediateNt = false;
-#endif
 struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
@@ -213,40 +189,26 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
     // neutral at 2^12 (3.22 ms either way) and slower for blocks of 2^14 (0.365 vs 0.357 ms per 4096) and for the u32
     // tables (3.10 vs 2.94 ms).  The mirror image, 8-byte stores after the last INVERSE pass, pays everywhere it was
     // measured (2^16 inverse 5.08 vs 5.20 ms, 2^14 inverse 0.381 vs 0.412 ms) and is the default below.
-    constexpr bool kDirectLoad = !INV && !MUL && Cfg::BPW == 1 && (LOGB - LOGE) >= 6 && !kBlockLeadBarrier &&
+    constexpr bool kDirectLoad = !INV && !MUL && Cfg::BPW == 1 && (LOGB - LOGE) >= 6 &&
                                  !std::is_same<Hook, NoHook>::value && !A::kPacked
-#ifdef PFHE_STAGED_BLOCK_LOADS
-                                 && false
-#endif
         ;
     u64x2 io[NV];
     u64 x[Cfg::E];
     if constexpr (kDirectLoad) {
-        PFHE_STAMP(0);
 #pragma unroll
         for (int k = 0; k < Cfg::E; ++k)
-#ifdef PFHE_PIPE_PLAIN_BLOCK_LOADS  // experiment (with PFHE_PIPE_STRIDED_PLAIN): plain loads of the intermediate
-            x[k] = valid ? gptr[((u32)k << (LOGB - LOGE)) + lt] : 0ull;
-#else
             x[k] = valid ? __builtin_nontemporal_load(gptr + ((u32)k << (LOGB - LOGE)) + lt) : 0ull;
-#endif
-        PFHE_STAMP(1);
-        PFHE_STAMP(2);
         // (forward: issuing them in front of the last register pass instead — the per-lane-twiddle one — costs 152 registers)
         after_stage();
         block_forward_core<A, LOGB, false, LOGE>(ar, x, lds, n, eblk, lt, lazy != 0);
-        PFHE_STAMP(8);
         lds_put_layout<0, LOGE>(x, lds, lt);
         __syncthreads();
-        PFHE_STAMP(9);
         lds_get_vectors<LOGB, LOGE>(io, lds, lt);
         if (valid) store_block_vectors<LOGB, LOGE, kNt>(io, gptr, lt);
-        PFHE_STAMP(10);
         return;
     }
     // all global traffic as 16-byte vectors in natural order (1 KiB per wave instruction), staged
     // through LDS into / out of the register layouts of the first / last register pass
-    PFHE_STAMP(0);
     if (valid) {
         load_block_vectors<LOGB, LOGE, kNt>(io, gptr, lt);
     } else {
@@ -273,13 +235,8 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
             io[j].y = ar.mul_any(io[j].y, mv[j].y);
         }
     }
-#ifdef PFHE_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PFHE_STAMP(1);  // global loads landed
-#endif
     lds_put_vectors<LOGB, LOGE>(io, lds, lt);
     __syncthreads();
-    PFHE_STAMP(2);  // staged
     // (inverse: the hook runs in front of the LAST register pass instead — uniform twiddles, the fewest live registers —
     // so that the pipelined kernel's 32 registers of prefetched strided data do not sit through the per-lane-twiddle
     // passes: 128 registers without spills, four waves per SIMD; 4.98 against 5.05 ms per 12 288 inverse transforms,
@@ -287,19 +244,14 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
     if constexpr (!INV) after_stage();
     if constexpr (!INV) {
         lds_get_layout<LOGB - LOGE, LOGE>(x, lds, lt);
-        block_forward_core<A, LOGB, kBlockLeadBarrier, LOGE>(ar, x, lds, n, eblk, lt, lazy != 0);
-        PFHE_STAMP(8);  // compute done (stamps 3..7 inside the core)
-        if constexpr (kBlockLeadBarrier) __syncthreads();  // else: the write-back reuses the slots each thread read last
+        block_forward_core<A, LOGB, false, LOGE>(ar, x, lds, n, eblk, lt, lazy != 0);
         lds_put_layout<0, LOGE>(x, lds, lt);
     } else {
         lds_get_layout<0, LOGE>(x, lds, lt);
-        block_inverse_core<A, LOGB, kBlockLeadBarrier, LOGE, Hook>(ar, x, lds, n, eblk, lt, log_n == LOGB, lazy != 0, after_stage);
+        block_inverse_core<A, LOGB, false, LOGE, Hook>(ar, x, lds, n, eblk, lt, log_n == LOGB, lazy != 0, after_stage);
         // mirror of the forward direction's direct loads: the last inverse pass leaves register k of thread lt =
         // element (k << POS0) + lt, stored as 8-byte words (512 contiguous bytes per wave instruction)
-        constexpr bool kDirectStore = Cfg::BPW == 1 && (LOGB - LOGE) >= 6 && !kBlockLeadBarrier && !A::kPacked
-#ifdef PFHE_STAGED_BLOCK_STORES
-                                      && false
-#endif
+        constexpr bool kDirectStore = Cfg::BPW == 1 && (LOGB - LOGE) >= 6 && !A::kPacked
             ;
         if constexpr (kDirectStore) {
             if (valid) {
@@ -309,44 +261,150 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
                     gstore<(kNt && (std::is_same<Hook, NoHook>::value || kPipeIntermediateNt))>(
                         gptr + ((u32)k << (LOGB - LOGE)) + lt, x[k]);
             }
-            PFHE_STAMP(10);
             return;
         }
-        if constexpr (kBlockLeadBarrier) __syncthreads();
         lds_put_layout<LOGB - LOGE, LOGE>(x, lds, lt);
     }
     __syncthreads();
-    PFHE_STAMP(9);
     lds_get_vectors<LOGB, LOGE>(io, lds, lt);
     if (valid) store_block_vectors<LOGB, LOGE, kNt>(io, gptr, lt);
-#ifdef PFHE_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    PFHE_STAMP(10);
 }
 
 
-// 8 coefficients per thread: registers for seven waves per SIMD (LDS then allows 32 waves per CU with 2^12-word blocks)
-#ifndef PFHE_BLOCK8_WAVES_ATTR
-#define PFHE_BLOCK8_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(6, 8)))
-#endif
-template <int LOGB>
-constexpr int kBlock8Threads = BlockCfg<(LOGB <= 13 ? LOGB : 13), 3>::THREADS;
-template <class A, int LOGB, bool INV, bool MUL = false>
-__global__ __launch_bounds__(kBlock8Threads<LOGB>) PFHE_BLOCK8_WAVES_ATTR void ntt_block8_kernel(
-    u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L, u32 log_n, u64 total_blocks, u32 lazy,
-    const u64 *__restrict__ mul, u64 mul_polys) {
-    extern __shared__ __attribute__((aligned(16))) u64 lds_raw[];
-    block_pass_body<A, LOGB, INV, MUL, 3>(data, primes, L, log_n, total_blocks, lazy, mul, mul_polys, lds_raw, blockIdx.x);
-}
-
+// Three register budgets, by block size (the attributes do not take template arguments, hence three kernels):
+//   2^10 .. 2^12: four waves per SIMD (LDS) and at most 104 registers — measured on the 2^12 pass under the strided passes;
+//   2^13, 2^14:   four waves per SIMD (one or two workgroups of 512 / 1024 threads per CU), registers left to the compiler;
+//   below 2^10:   several polynomials per wave, the primes are per-lane values in VGPRs: no cap at all (the 104-register
+//                 cap cost these kernels 20-84 bytes of scratch per lane).
 template <class A, int LOGB, bool INV, bool MUL = false, bool NT = false>
-__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) PFHE_BLOCK_WAVES_ATTR void ntt_block_kernel(
+__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4), amdgpu_num_vgpr(104))) void ntt_block_kernel(
     u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L, u32 log_n, u64 total_blocks, u32 lazy,
     const u64 *__restrict__ mul, u64 mul_polys) {
+    static_assert(LOGB >= 10 && LOGB <= 12, "the capped form is for blocks of 2^10 .. 2^12");
     extern __shared__ __attribute__((aligned(16))) u64 lds_raw[];
     block_pass_body<A, LOGB, INV, MUL, 4, NoHook, NT>(data, primes, L, log_n, total_blocks, lazy, mul, mul_polys, lds_raw,
                                                       blockIdx.x);
+}
+template <class A, int LOGB, bool INV, bool MUL = false, bool NT = false>
+__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_block_big_kernel(
+    u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L, u32 log_n, u64 total_blocks, u32 lazy,
+    const u64 *__restrict__ mul, u64 mul_polys) {
+    static_assert(LOGB >= 13, "blocks of 2^13 and 2^14");
+    extern __shared__ __attribute__((aligned(16))) u64 lds_raw[];
+    block_pass_body<A, LOGB, INV, MUL, 4, NoHook, NT>(data, primes, L, log_n, total_blocks, lazy, mul, mul_polys, lds_raw,
+                                                      blockIdx.x);
+}
+template <class A, int LOGB, bool INV, bool MUL = false, bool NT = false>
+__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) void ntt_block_small_kernel(
+    u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L, u32 log_n, u64 total_blocks, u32 lazy,
+    const u64 *__restrict__ mul, u64 mul_polys) {
+    static_assert(LOGB < 10, "blocks below 2^10");
+    extern __shared__ __attribute__((aligned(16))) u64 lds_raw[];
+    block_pass_body<A, LOGB, INV, MUL, 4, NoHook, NT>(data, primes, L, log_n, total_blocks, lazy, mul, mul_polys, lds_raw,
+                                                      blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------
+// Persistent single-pass transform for N = 2^13 / 2^14 (BASELINE config 2).  A polynomial of 2^14 words fills a CU's LDS
+// (144 KiB): one 1024-thread workgroup per CU, whose sixteen waves would all wait for their loads at the same time, then
+// all compute, then all store.  Here a workgroup stays resident and walks over polynomials p, p + G, p + 2G, ...; the loads
+// of the NEXT polynomial are issued in front of the current one's LAST register pass (forward: two stages for 2^14, per-lane
+// twiddles four at a time; inverse: the pass with wave-uniform twiddles) into a second set of 32 registers and land during
+// that pass and the write-back, so only the first polynomial of a workgroup is waited for with nothing else to do.
+// Forward: 8-byte loads deliver the first register layout directly (register k of thread lt = element (k << POS0) + lt);
+// inverse: natural-order 16-byte vectors, staged through LDS into layout 0, and direct 8-byte stores at the end.
+// ------------------------------------------------------------------------------------------
+constexpr int kPersistInvHook = 1;  // passes before the last one at which the inverse direction issues its prefetch (0: 0.332 ms, 1: 0.315 ms per 4096)
+template <class A, int LOGB, bool INV>
+__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_persist_kernel(
+    u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L, u64 npolys, u32 lazy) {
+    using Cfg = BlockCfg<LOGB>;
+    static_assert(Cfg::BPW == 1 && LOGB - 4 >= 6, "one polynomial per workgroup, whole waves per register layout");
+    constexpr int NV = Cfg::E / 2, POS0 = LOGB - 4;
+    constexpr u32 n = 1u << LOGB;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    u64 p = blockIdx.x;
+    if (p >= npolys) return;
+    const u64 stride = gridDim.x;
+    if constexpr (!INV) {
+        u64 x[Cfg::E], xn[Cfg::E];
+        {
+            const u64 *__restrict__ g = data + p * n + threadIdx.x;
+#pragma unroll
+            for (int k = 0; k < Cfg::E; ++k) x[k] = __builtin_nontemporal_load(g + ((u32)k << POS0));
+        }
+        while (true) {
+            const u64 pn = p + stride;
+            const bool more = pn < npolys;
+            const A ar(primes + p % L);
+            const auto prefetch = [&]() {
+                if (more) {
+                    const u64 *__restrict__ g = data + pn * n + opaque_tid();
+#pragma unroll
+                    for (int k = 0; k < Cfg::E; ++k) xn[k] = __builtin_nontemporal_load(g + ((u32)k << POS0));
+                } else {  // a dead value: the old contents must not count as live
+#pragma unroll
+                    for (int k = 0; k < Cfg::E; ++k) xn[k] = 0;
+                }
+            };
+            {
+                const u32 lt = opaque_tid();
+                // (leading barrier of the first exchange: the previous polynomial's write-back may still be read)
+                // The next polynomial's loads go out AFTER the last register pass: in front of it (per-lane twiddles) the
+                // 32 extra registers cost 12-26 spilled ones and the kernel loses to the plain one (0.402 vs 0.356 ms).
+                block_forward_core<A, LOGB, true>(ar, x, lds, n, 0u, lt, lazy != 0);
+                prefetch();
+                lds_put_layout<0>(x, lds, lt);
+            }
+            __syncthreads();
+            {
+                const u32 lt = opaque_tid();
+                u64x2 io[NV];
+                lds_get_vectors<LOGB>(io, lds, lt);
+                store_block_vectors<LOGB, 4, true>(io, data + p * n, lt);
+            }
+            if (!more) break;
+#pragma unroll
+            for (int k = 0; k < Cfg::E; ++k) x[k] = xn[k];
+            p = pn;
+        }
+    } else {
+        u64x2 io[NV], ion[NV];
+        load_block_vectors<LOGB, 4, true>(io, data + p * n, threadIdx.x);
+        bool first = true;
+        while (true) {
+            const u64 pn = p + stride;
+            const bool more = pn < npolys;
+            const A ar(primes + p % L);
+            const auto prefetch = [&]() {
+                if (more) {
+                    load_block_vectors<LOGB, 4, true>(ion, data + pn * n, opaque_tid());
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) ion[j] = u64x2{0, 0};
+                }
+            };
+            u64 x[Cfg::E];
+            {
+                const u32 lt = opaque_tid();
+                if (!first) __syncthreads();  // the previous polynomial's last exchange may still be read
+                lds_put_vectors<LOGB>(io, lds, lt);
+                __syncthreads();
+                lds_get_layout<0>(x, lds, lt);
+                block_inverse_core<A, LOGB, false, 4, decltype(prefetch), kPersistInvHook>(ar, x, lds, n, 0u, lt, true, lazy != 0, prefetch);
+            }
+            {
+                u64 *__restrict__ g = data + p * n + opaque_tid();
+#pragma unroll
+                for (int k = 0; k < Cfg::E; ++k) gstore<true>(g + ((u32)k << POS0), x[k]);
+            }
+            if (!more) break;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) io[j] = ion[j];
+            p = pn;
+            first = false;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -362,9 +420,6 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) PFHE_BLOCK_WAVES_ATTR void
 // registers (5.00-5.01 against 5.06 ms per 12 288 transforms at three waves), the inverse ones in 128 once the strided
 // chunk's loads are issued in front of the block pass's LAST register pass (block_pass_body; issued after the staging
 // they spill 6 registers there: 5.42 ms).
-#ifndef PFHE_PIPE_FWD_WAVES_ATTR
-#define PFHE_PIPE_FWD_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
-#endif
 template <class A, int LOGB, bool INV, bool MUL>
 __device__ __forceinline__ void ntt_pipe_body(
     u64 *__restrict__ blk_data, u64 blk_total, u64 *__restrict__ str_data, u64 str_total,
@@ -374,9 +429,6 @@ __device__ __forceinline__ void ntt_pipe_body(
     static_assert(BlockCfg<LOGB>::BPW == 1 && (1 << LOGB) / TPB == (1 << K), "16 blocks and 16 chunks per polynomial");
     constexpr u32 log_n = LOGB + K, n = 1u << log_n;
     extern __shared__ __attribute__((aligned(16))) u64 lds_raw[];
-#ifdef PFHE_STAMPS_FULL_ONLY  // diagnostic build (tools/stamps_pipe.py): only launches with both parts run, so that the
-    if (blk_total == 0 || str_total == 0) return;  // stamps of one full launch survive (results are wrong in this build)
-#endif
     const u64 chunk = blockIdx.x;
     const bool has_str = chunk < str_total;
     // chunk -> (limb-polynomial, TPB columns): thread t owns column (chunk % 16) * TPB + t, rows k * 2^LOGB
@@ -396,34 +448,22 @@ __device__ __forceinline__ void ntt_pipe_body(
     }
     if (has_str) {
         const A ar(primes + (chunk >> 4) % L);
-#ifdef PFHE_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        PFHE_STAMP(11);  // the block's stores and the strided chunk's loads have landed
-#endif
         if constexpr (!INV) strided_forward_regs<A, K, 1>(ar, sx, n, 0u, LOGB);
         else strided_inverse_regs<A, K, 1, true>(ar, sx, n, 0u, LOGB, lazy != 0);  // the only strided pass: final stage
-        PFHE_STAMP(12);
 #pragma unroll
         // forward: this is the intermediate (kPipeIntermediateNt); inverse: the final output (always non-temporal)
         for (int k = 0; k < (1 << K); ++k) gstore<(INV || kPipeIntermediateNt)>(sp + ((u64)k << LOGB), sx[k][0]);
-#ifdef PFHE_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        PFHE_STAMP(13);
-#endif
     }
 }
 
 template <class A, int LOGB>
-__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) PFHE_PIPE_FWD_WAVES_ATTR void ntt_pipe_fwd_kernel(
+__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_pipe_fwd_kernel(
     u64 *__restrict__ blk_data, u64 blk_total, u64 *__restrict__ str_data, u64 str_total,
     const NttPrime *__restrict__ primes, u32 L, u32 lazy) {
     ntt_pipe_body<A, LOGB, false, false>(blk_data, blk_total, str_data, str_total, primes, L, lazy, nullptr, 0);
 }
-#ifndef PFHE_PIPE_INV_WAVES_ATTR
-#define PFHE_PIPE_INV_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
-#endif
 template <class A, int LOGB, bool MUL>
-__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) PFHE_PIPE_INV_WAVES_ATTR void ntt_pipe_inv_kernel(
+__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_pipe_inv_kernel(
     u64 *__restrict__ blk_data, u64 blk_total, u64 *__restrict__ str_data, u64 str_total,
     const NttPrime *__restrict__ primes, u32 L, u32 lazy, const u64 *__restrict__ mul, u64 mul_polys) {
     ntt_pipe_body<A, LOGB, true, MUL>(blk_data, blk_total, str_data, str_total, primes, L, lazy, mul, mul_polys);
@@ -442,14 +482,6 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) PFHE_PIPE_INV_WAVES_ATTR v
 // mid runs while the block sits in LDS between the halves (no block registers live); late runs in front of the inverse
 // half's last register pass (the pass with the fewest live registers).
 // ------------------------------------------------------------------------------------------
-// An opaque copy of the thread id (no instruction): addresses computed from it cannot be hoisted above this point, so
-// the address registers of a later phase are not live through an earlier one.
-__device__ __forceinline__ u32 opaque_tid() {
-    u32 t = threadIdx.x;
-    asm volatile("" : "+v"(t));
-    return t;
-}
-
 // gptr / mptr: this block of the data and of the multiplicand; ar: the arithmetic of the block's limb
 template <class A, int LOGB, class HookA = NoHook, class HookM = NoHook, class HookL = NoLateHook, bool NT = false>
 __device__ __forceinline__ void block_mid_body(const A &ar, u64 *__restrict__ gptr, const u64 *__restrict__ mptr, bool valid,
@@ -585,20 +617,6 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_wave
 // ------------------------------------------------------------------------------------------
 namespace {
 
-// Blocks that take the 8-coefficients-per-thread form (twice the threads, half the registers each: 76-80 registers
-// and six waves per SIMD for the pseudo-Mersenne kernels, eight for the generic ones).  Off by default (build with
-// -DPFHE_BLOCK8 to try it): measured 3.28 ms (forward) / 3.23 ms (inverse) per 12 288 blocks-of-2^12 passes against
-// 3.20 / 3.03-3.12 ms for the 16-coefficient form — the block pass is bound by VALU issue, not by latency, and the
-// extra exchange costs more than the occupancy returns.
-template <class A, int LOGB>
-constexpr bool use_block8() {
-#ifdef PFHE_BLOCK8
-    return !A::kPacked && LOGB == kTwoPassBlockLog;
-#else
-    return false;
-#endif
-}
-
 // Large batches take the instantiations with non-temporal stores / staged loads (pfhe_ntt_device.hpp, gstore): measured
 // at 4096 polynomials, block pass of 2^12: 3.18 vs 3.25 ms; N = 2^13: 0.48 vs 0.51 ms; N = 2^14 inverse 0.370 vs 0.392 ms;
 // u32 tables 2.90 vs 2.96 ms; strided pass 2.09 vs 2.19 ms.  Small batches, which the next kernel finds in the Infinity
@@ -608,8 +626,7 @@ constexpr u64 kNtMinBytes = 256ull << 20;
 template <class A, int LOGB, bool INV, bool MUL, bool NT>
 int launch_block_impl(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys, bool lazy, hipStream_t s,
                       const u64 *mul, u64 mul_polys) {
-    constexpr int LOGE = use_block8<A, LOGB>() ? 3 : 4;
-    using Cfg = BlockCfg<LOGB, LOGE>;
+    using Cfg = BlockCfg<LOGB>;
     const u64 total_blocks = npolys << (log_n - LOGB);
     const u64 grid = (total_blocks + Cfg::BPW - 1) / Cfg::BPW;
     if (grid == 0) return PFHE_OK;
@@ -619,8 +636,9 @@ int launch_block_impl(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 n
     }
     constexpr size_t lds_bytes = (size_t)Cfg::BPW * Cfg::LDS_WORDS * sizeof(u64);
     void (*kern)(u64 *, const NttPrime *, u32, u32, u64, u32, const u64 *, u64);
-    if constexpr (LOGE == 3) kern = ntt_block8_kernel<A, LOGB, INV, MUL>;
-    else kern = ntt_block_kernel<A, LOGB, INV, MUL, NT>;
+    if constexpr (LOGB >= 13) kern = ntt_block_big_kernel<A, LOGB, INV, MUL, NT>;
+    else if constexpr (LOGB >= 10) kern = ntt_block_kernel<A, LOGB, INV, MUL, NT>;
+    else kern = ntt_block_small_kernel<A, LOGB, INV, MUL, NT>;
     if (lds_bytes > 64 * 1024) {
         static thread_local bool configured[64] = {};
         int dev = 0;
@@ -637,9 +655,50 @@ int launch_block_impl(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 n
     return PFHE_OK;
 }
 
+// CUs of the current device (cached per device)
+static int device_cu_count() {
+    static thread_local int cached[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cached[dev] = v;
+    }
+    return cached[dev];
+}
+
+// persistent single-pass form (ntt_persist_kernel): N = 2^13 / 2^14, at least two polynomials per resident workgroup
+template <class A, int LOGB, bool INV>
+int launch_persist(u64 *data, const NttPrime *primes, u32 L, u64 npolys, bool lazy, hipStream_t s, u64 resident) {
+    using Cfg = BlockCfg<LOGB>;
+    constexpr size_t lds_bytes = (size_t)Cfg::LDS_WORDS * sizeof(u64);
+    void (*kern)(u64 *, const NttPrime *, u32, u64, u32) = ntt_persist_kernel<A, LOGB, INV>;
+    static thread_local bool configured[64] = {};
+    int dev = 0;
+    PFHE_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !configured[dev]) {
+        PFHE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds_bytes));
+        configured[dev] = true;
+    }
+    // equal shares: every workgroup walks ceil(npolys / grid) polynomials, give or take one
+    const u64 rounds = (npolys + resident - 1) / resident;
+    const u64 grid = (npolys + rounds - 1) / rounds;
+    hipLaunchKernelGGL(kern, dim3((u32)grid), dim3(Cfg::THREADS), lds_bytes, s, data, primes, L, npolys, lazy ? 1u : 0u);
+    PFHE_HIP(hipGetLastError());
+    return PFHE_OK;
+}
+
 template <class A, int LOGB, bool INV, bool MUL = false>
 int launch_block(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys, bool lazy, hipStream_t s,
-                 const u64 *mul = nullptr, u64 mul_polys = 0) {
+                 const u64 *mul = nullptr, u64 mul_polys = 0, bool persist = true) {
+    // (N = 2^13, two workgroups per CU, measures slower in this form: 0.33 vs 0.29-0.32 ms per 8192 polynomials)
+    if constexpr (LOGB == 14 && !MUL && !A::kPacked) {
+        const u64 resident = (u64)device_cu_count();
+        if (persist && log_n == LOGB && npolys >= 2 * resident)
+            return launch_persist<A, LOGB, INV>(data, primes, L, npolys, lazy, s, resident);
+    }
     if constexpr (LOGB >= 11) {
         if ((npolys << log_n) * sizeof(u64) >= kNtMinBytes)
             return launch_block_impl<A, LOGB, INV, MUL, true>(data, primes, L, log_n, npolys, lazy, s, mul, mul_polys);
@@ -649,11 +708,11 @@ int launch_block(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys
 
 template <class A, bool INV, bool MUL = false>
 int dispatch_block(int logb, u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys, bool lazy,
-                   hipStream_t s, const u64 *mul = nullptr, u64 mul_polys = 0) {
+                   hipStream_t s, const u64 *mul = nullptr, u64 mul_polys = 0, bool persist = true) {
     switch (logb) {
 #define PFHE_CASE(B) \
     case B:          \
-        return launch_block<A, B, INV, MUL>(data, primes, L, log_n, npolys, lazy, s, mul, mul_polys);
+        return launch_block<A, B, INV, MUL>(data, primes, L, log_n, npolys, lazy, s, mul, mul_polys, persist);
         PFHE_CASE(4) PFHE_CASE(5) PFHE_CASE(6) PFHE_CASE(7) PFHE_CASE(8) PFHE_CASE(9) PFHE_CASE(10)
         PFHE_CASE(11) PFHE_CASE(12) PFHE_CASE(13) PFHE_CASE(14)
 #undef PFHE_CASE
@@ -713,7 +772,7 @@ int launch_tiny(bool inverse, const NttPrime *primes, u32 L, u32 log_n, u64 *dat
 // then strided passes, the last of which carries the fused final stage)
 template <class A>
 int run_pass(const NttPlan &plan, const NttPrime *primes, u32 L, u32 log_n, u64 *data, u64 npolys, bool inverse,
-             int index, bool lazy, hipStream_t s, const u64 *mul, u64 mul_polys, bool vec1) {
+             int index, bool lazy, hipStream_t s, const u64 *mul, u64 mul_polys, bool vec1, bool persist) {
     const int block_at = inverse ? 0 : plan.n_strided;
     if (mul != nullptr) {
         if constexpr (A::kPacked) {
@@ -724,8 +783,8 @@ int run_pass(const NttPlan &plan, const NttPrime *primes, u32 L, u32 log_n, u64 
         }
     }
     if (index == block_at) {
-        return inverse ? dispatch_block<A, true>(plan.block_log, data, primes, L, log_n, npolys, lazy, s)
-                       : dispatch_block<A, false>(plan.block_log, data, primes, L, log_n, npolys, lazy, s);
+        return inverse ? dispatch_block<A, true>(plan.block_log, data, primes, L, log_n, npolys, lazy, s, nullptr, 0, persist)
+                       : dispatch_block<A, false>(plan.block_log, data, primes, L, log_n, npolys, lazy, s, nullptr, 0, persist);
     }
     const int i = inverse ? plan.n_strided - index : index;  // index into plan.strided (forward order)
     u32 log_s = log_n;
@@ -757,15 +816,10 @@ NttTuning NttTuning::from_env() {
     t.pipelined = std::getenv("PFHE_DISABLE_PIPELINED") == nullptr;
     t.pipelined_min_mb = env_int("PFHE_PIPELINED_MIN_MB", 1, 1 << 20);
     t.pipe_ramp = env_int("PFHE_PIPE_RAMP", 1, 32);
+    t.persist = std::getenv("PFHE_DISABLE_PERSIST") == nullptr;
     return t;
 }
 
-#ifdef PFHE_STAMPS
-extern "C" int pfhe_debug_read_stamps(unsigned long long *out, size_t wgs) {
-    if (wgs > (size_t)kStampWgs) wgs = kStampWgs;
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), wgs * kStampSlots * sizeof(u64)) == hipSuccess ? 0 : 35;
-}
-#endif
 
 NttPlan make_ntt_plan(u32 log_n, int arith, const NttTuning &tune) {
     NttPlan p;
@@ -822,12 +876,12 @@ int ntt_pass_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data,
     const bool v1 = tune.strided_vec1;
     if (arith == kArithB32) {
         if (plan.tiny) return PFHE_ERR_UNSUPPORTED;  // N <= 16 is served by ntt32_tiny_kernel
-        return run_pass<B32Arith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys, v1);
+        return run_pass<B32Arith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys, v1, false);
     }
     if (plan.tiny) return mul ? PFHE_ERR_UNSUPPORTED : launch_tiny(inverse, primes, L, log_n, data, npolys, lazy, s);
     return arith == kArithPm
-               ? run_pass<PmArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys, v1)
-               : run_pass<ShoupArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys, v1);
+               ? run_pass<PmArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys, v1, tune.persist)
+               : run_pass<ShoupArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys, v1, tune.persist);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -840,10 +894,7 @@ int ntt_pass_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data,
 // ------------------------------------------------------------------------------------------
 namespace {
 
-#ifndef PFHE_OVERLAP_TILES_DEFAULT
-#define PFHE_OVERLAP_TILES_DEFAULT 12  // 8: 5.67 ms, 12: 5.60 ms, 16: 5.61 ms per 12 288 NTTs of 2^16
-#endif
-constexpr int kOverlapTiles = PFHE_OVERLAP_TILES_DEFAULT;
+constexpr int kOverlapTiles = 12;  // 8: 5.67 ms, 12: 5.60 ms, 16: 5.61 ms per 12 288 NTTs of 2^16
 constexpr u64 kOverlapMinBytes = 512ull << 20;  // below this the extra launches do not pay
 // pipelined form: from 256 MiB of data (2^16-point transforms: 512 limb-polynomials), tiles of 256 MiB = the Infinity
 // Cache, whose share of the intermediate (plain stores, kPipeIntermediateNt) the next launch then reads on-die.  Measured,

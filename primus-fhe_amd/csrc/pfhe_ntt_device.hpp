@@ -32,6 +32,7 @@ struct NttTuning {
     int block_log = 0;             // PFHE_BLOCK_LOG: block size under strided passes (0: built-in default)
     bool pipelined = true;         // PFHE_DISABLE_PIPELINED clears it: N = 2^16 runs as tiles + 1 launches of ntt_pipe_kernel on the caller's stream
     int pipe_ramp = 0;             // PFHE_PIPE_RAMP: tile weights of the pipelined form ramp 1..ramp..1 (0 / 1: equal tiles)
+    bool persist = true;           // PFHE_DISABLE_PERSIST clears it: N = 2^13 / 2^14 batches run ntt_persist_kernel (resident workgroups that prefetch their next polynomial)
     int pipelined_min_mb = 0;      // PFHE_PIPELINED_MIN_MB: smallest batch (MiB of data) that takes the pipelined form (0: built-in default)
     static NttTuning from_env();
 };
@@ -77,22 +78,6 @@ int ntt_pass_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data,
 #error "libpfhe_hip is written for wave64 targets (gfx950)"
 #endif
 
-#ifdef PFHE_STAMPS
-// Diagnostic build (tools/build_variant.sh stamps -DPFHE_STAMPS): wave 0 of the first workgroups stamps s_memtime at
-// the phase boundaries of the block pass into a device array read back by pfhe_debug_read_stamps.  Never in the
-// product build: the stamps cost ~10 % of the wave's cycles.
-constexpr int kStampSlots = 14, kStampWgs = 1 << 16;
-static __device__ u64 g_stamps[kStampWgs][kStampSlots];
-#define PFHE_STAMP(i)                                                                          \
-    do {                                                                                       \
-        if (threadIdx.x == 0 && blockIdx.x < kStampWgs) g_stamps[blockIdx.x][i] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
-#else
-#define PFHE_STAMP(i) \
-    do {              \
-    } while (0)
-#endif
-
 // Tables are reached through pointers stored in NttPrime, which the compiler would treat as
 // generic (flat) pointers: flat loads tick both vmcnt and lgkmcnt and serialise against LDS
 // traffic.  Reading through explicit global-address-space pointers yields plain global_load.
@@ -105,9 +90,16 @@ typedef const u64 __attribute__((address_space(1))) *GCWordPtr;
 // while a kernel runs.
 typedef const u64x2 __attribute__((address_space(4))) *CCVec2Ptr;
 
+// An opaque copy of the thread id (no instruction): addresses computed from it cannot be hoisted above this point, so
+// the address registers of a later phase are not live through an earlier one.
+__device__ __forceinline__ u32 opaque_tid() {
+    u32 t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
 // x mod m for x < 2m, using the borrow of the subtraction as the select condition
 __device__ __forceinline__ u64 csub(u64 x, u64 m) {
-#ifndef PFHE_NO_CSUB_ASM
     // four instructions (subtract with borrow, two selects on the borrow); the compiler's lowering of the
     // overflow intrinsic compares separately and takes five: -2 % VALU instructions in the pseudo-Mersenne block
     // pass, -6 % in the Shoup one (4.57 -> 4.39 ms per 12 288 NTTs)
@@ -119,11 +111,6 @@ __device__ __forceinline__ u64 csub(u64 x, u64 m) {
         : "v"(x0), "v"(x1), "v"(m0), "v"(m1)
         : "vcc");
     return ((u64)d1 << 32) | d0;
-#else
-    u64 d;
-    const bool borrow = __builtin_usubll_overflow(x, m, &d);
-    return borrow ? x : d;
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -230,9 +217,6 @@ struct PmArith {
         asm volatile("" : "+v"(vsh), "+v"(vmask), "+v"(vmask1));  // as uniform values they would live in SGPRs
     }
     __device__ __forceinline__ Tw fwd_tw(u32 i) const {
-#ifdef PFHE_EXPERIMENT_CONST_TW  // timing experiment only (wrong results): what do the twiddle loads cost?
-        return inv_n;
-#endif
         const u64x2 v = fwd[i];
         return Tw{v.x, v.y};
     }
@@ -281,9 +265,7 @@ struct PmArith {
         // mad(w0,y1,0); mad(w1,y0,.); 64-bit add of (lo >> 32) — one more instruction per product than
         // feeding (lo >> 32) to the first multiply-add.  PFHE_NO_MID_BARRIER restores the compiler's form;
         // a volatile barrier also pins the schedule and is 6 % slower.
-#ifndef PFHE_NO_MID_BARRIER
         asm("" : "+v"(mid));
-#endif
         mid += (u64)w1 * y0;
         const u64 hi = (u64)w1 * y1 + (mid >> 32);
         const u32 l0 = (u32)lo, l1 = (u32)mid, h0 = (u32)hi, h1 = (u32)(hi >> 32);
@@ -424,21 +406,10 @@ struct B32Arith {
 // even register bits (so its last stage folds, whatever follows).
 template <bool FOLD = true, bool UNI = false, class A>
 __device__ __forceinline__ void fwd_bfly(const A &ar, u64 &x, u64 &y, typename A::Tw w) {
-#ifdef PFHE_EXPERIMENT_NO_BFLY  // data-movement skeleton (tuning experiments only; results are wrong)
-    x ^= w.w;
-    return;
-#endif
     if constexpr (A::kPacked) {
         ar.fwd_bfly(x, y, w);
     } else if constexpr (A::kWide) {
-#ifndef PFHE_NO_ASM_BFLY
         pm_fwd_bfly1<FOLD, UNI>(ar, x, y, w);
-#else
-        const u64 tx = FOLD ? ar.reduce_x(x) : x;
-        const u64 t = ar.mul_lazy(y, w);
-        x = tx + t;
-        y = sub_u64(tx + ar.q3, t);
-#endif
     } else {
         const u64 tx = ar.reduce_x(x);
         const u64 t = ar.mul_lazy(y, w);
@@ -454,10 +425,8 @@ __device__ __forceinline__ void inv_bfly(const A &ar, u64 &x, u64 &y, typename A
     if constexpr (A::kPacked) {
         ar.inv_bfly(x, y, w);
     } else if constexpr (A::kWide) {
-#ifndef PFHE_NO_ASM_BFLY
         pm_inv_bfly1<UNI>(ar, x, y, w);
         return;
-#endif
         const u64 tx = x + y;
         const u64 ty = sub_u64(x + ar.q3, y);
         x = ar.reduce_x(tx);
@@ -577,11 +546,9 @@ struct BlockCfg {
     static_assert(TPB <= 1024, "a block must fit one workgroup");
 // smallest workgroup: one wave.  Small workgroups put more independent workgroups on a CU (LDS is
 // what limits residency), which overlaps their load / compute / store phases better: measured
-// +2..9 % for N = 2^8..2^11 against 256-thread workgroups (tools/build_variant.sh -DPFHE_MIN_WG=256).
-#ifndef PFHE_MIN_WG
-#define PFHE_MIN_WG 64
-#endif
-    static constexpr int THREADS = TPB > PFHE_MIN_WG ? TPB : PFHE_MIN_WG;  // workgroup size
+// +2..9 % for N = 2^8..2^11 against 256-thread workgroups (measured with a 256-thread minimum).
+    static constexpr int kMinWg = 64;
+    static constexpr int THREADS = TPB > kMinWg ? TPB : kMinWg;  // workgroup size
     static constexpr int BPW = THREADS / TPB;              // coefficient blocks per workgroup
     static constexpr int LDS_WORDS = B + B / 8;            // 16 words + 2 words of padding
 };
@@ -636,7 +603,6 @@ __device__ __forceinline__ void fwd_regpass(const A &ar, u64 (&x)[1 << LOGE], u3
             else w[u] = ar.fwd_tw(base + u);
         };
         const int ntw = E >> (j + 1);  // twiddles of this stage
-#if !defined(PFHE_NO_ASM_BFLY_PAIRS) && !defined(PFHE_NO_ASM_BFLY)
         if constexpr (A::kWide) {
             // two butterflies per asm block (independent instruction streams interleaved): butterfly b of the stage
             // has u = b >> j, v = b & (2^j - 1).  Per-lane twiddles (four registers each) are loaded at most four at a
@@ -657,7 +623,6 @@ __device__ __forceinline__ void fwd_regpass(const A &ar, u64 (&x)[1 << LOGE], u3
             }
             continue;
         }
-#endif
 #pragma unroll
         for (int u = 0; u < ntw; ++u) load_tw(u);
 #pragma unroll
@@ -694,7 +659,6 @@ __device__ __forceinline__ void inv_regpass(const A &ar, u64 (&x)[1 << LOGE], u3
                 if constexpr (POS == 0 && A::kLastTables) w[u] = ar.inv_tw_last(last_table_off<LOGE>(n, e_abs, j, u));  // lane-ordered
                 else w[u] = ar.inv_tw(base + u);
             }
-#if !defined(PFHE_NO_ASM_BFLY_PAIRS) && !defined(PFHE_NO_ASM_BFLY)
             if constexpr (A::kWide) {  // two butterflies per asm block, as in fwd_regpass
 #pragma unroll
                 for (int b = 0; b < E / 2; b += 2) {
@@ -704,7 +668,6 @@ __device__ __forceinline__ void inv_regpass(const A &ar, u64 (&x)[1 << LOGE], u3
                 }
                 continue;
             }
-#endif
 #pragma unroll
             for (int u = 0; u < ntw; ++u) {
 #pragma unroll
@@ -749,11 +712,7 @@ __device__ __forceinline__ void lds_put_layout(const u64 (&x)[1 << LOGE], u64 *_
 // writes and the reads either (PFHE_NO_WAVE_LOCAL_EXCHANGE restores both barriers everywhere).
 template <int FROM, int TO, bool FIRST, int LOGE = 4>
 __device__ __forceinline__ void lds_exchange(u64 (&x)[1 << LOGE], u64 *__restrict__ lds, u32 lt) {
-#ifdef PFHE_NO_WAVE_LOCAL_EXCHANGE
-    constexpr bool kLead = true, kWaveLocal = false;
-#else
     constexpr bool kLead = FIRST, kWaveLocal = (FROM > TO ? FROM : TO) <= 6;
-#endif
     if constexpr (kLead) __syncthreads();
     lds_put_layout<FROM, LOGE>(x, lds, lt);
     if constexpr (kWaveLocal) {
@@ -779,14 +738,8 @@ __device__ __forceinline__ void fwd_chain(const A &ar, u64 (&x)[1 << LOGE], u64 
         constexpr int JHI = POS >= LOGE ? LOGE - 1 : POS - 1;
         asm volatile("" : "+v"(lt));  // this pass's LDS and twiddle addresses are computed here, not hoisted to the kernel's top
         lds_exchange<POS, NPOS, FIRST, LOGE>(x, lds, lt);
-#ifdef PFHE_STAMPS
-        PFHE_STAMP(NPOS == 0 ? 6 : 4);
-#endif
         if constexpr (NPOS == 0) before_last();
         fwd_regpass<A, NPOS, JHI, 0, UNI, LOGE>(ar, x, n + eblk + layout<NPOS, LOGE>(lt, 0), n);
-#ifdef PFHE_STAMPS
-        PFHE_STAMP(NPOS == 0 ? 7 : 5);
-#endif
         fwd_chain<A, LOGB, NPOS, false, LOGE, Late>(ar, x, lds, n, eblk, lt, before_last);
     }
 }
@@ -800,21 +753,16 @@ __device__ __forceinline__ void block_forward_core(const A &ar, u64 (&x)[1 << LO
     constexpr int POS0 = LOGB - LOGE, E = 1 << LOGE;
     constexpr bool UNI = BlockCfg<LOGB, LOGE>::TPB >= 64;  // a wave never straddles two blocks
     fwd_regpass<A, POS0, LOGE - 1, 0, UNI, LOGE>(ar, x, n + eblk + layout<POS0, LOGE>(lt, 0), n);
-#ifdef PFHE_STAMPS
-    PFHE_STAMP(3);
-#endif
     fwd_chain<A, LOGB, POS0, LEAD, LOGE, Late>(ar, x, lds, n, eblk, lt, before_last);
     if constexpr (A::kPacked) {  // distance-1 stage between the halves of each word
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = ar.fwd_intra(x[k], n + eblk + layout<0, LOGE>(lt, k));
     }
     if constexpr (A::kWide) {
-#if !defined(PFHE_NO_ASM_BFLY)
         if (!lazy) {  // one uniform branch for the whole thread, two elements per asm block
 #pragma unroll
             for (int k = 0; k < E; k += 2) pm_canon2(ar, x[k], x[k + 1]);
         } else
-#endif
         {
 #pragma unroll
             for (int k = 0; k < E; ++k) x[k] = fwd_finish(ar, x[k], lazy);
@@ -826,7 +774,8 @@ __device__ __forceinline__ void block_forward_core(const A &ar, u64 (&x)[1 << LO
 }
 
 // before_last runs in front of the last register pass (uniform twiddles: the pass with the fewest live registers)
-template <class A, int LOGB, int POS, bool FIRST = false, int LOGE = 4, class Late = NoLateHook>
+// HOOK_AT: the hook runs in front of the pass that has HOOK_AT more passes after it (0: the last pass)
+template <class A, int LOGB, int POS, bool FIRST = false, int LOGE = 4, class Late = NoLateHook, int HOOK_AT = 0>
 __device__ __forceinline__ void inv_chain(const A &ar, u64 (&x)[1 << LOGE], u64 *__restrict__ lds, u32 n, u32 eblk, u32 lt,
                                           bool final_block, bool lazy, Late before_last = Late()) {
     constexpr bool UNI = BlockCfg<LOGB, LOGE>::TPB >= 64;  // a wave never straddles two blocks
@@ -837,15 +786,17 @@ __device__ __forceinline__ void inv_chain(const A &ar, u64 (&x)[1 << LOGE], u64 
         constexpr bool LAST = NPOS + LOGE >= LOGB;
         asm volatile("" : "+v"(lt));  // see fwd_chain
         lds_exchange<POS, NPOS, FIRST, LOGE>(x, lds, lt);
-        if constexpr (LAST) before_last();
+        // passes still to come after this one: ceil((LOGB - (NPOS + LOGE)) / LOGE)
+        constexpr int AFTER = (LOGB - NPOS - LOGE + LOGE - 1) / LOGE;
+        if constexpr (AFTER == HOOK_AT) before_last();
         inv_regpass<A, NPOS, JLO, LOGE - 1, UNI, LOGE>(ar, x, n, eblk + layout<NPOS, LOGE>(lt, 0), LAST && final_block, lazy);
-        inv_chain<A, LOGB, NPOS, false, LOGE, Late>(ar, x, lds, n, eblk, lt, final_block, lazy, before_last);
+        inv_chain<A, LOGB, NPOS, false, LOGE, Late, HOOK_AT>(ar, x, lds, n, eblk, lt, final_block, lazy, before_last);
     }
 }
 
 // inverse compute core: x holds layout<0> on entry and layout<LOGB-LOGE> on exit
 // before_last: see inv_chain
-template <class A, int LOGB, bool LEAD = true, int LOGE = 4, class Late = NoLateHook>
+template <class A, int LOGB, bool LEAD = true, int LOGE = 4, class Late = NoLateHook, int HOOK_AT = 0>
 __device__ __forceinline__ void block_inverse_core(const A &ar, u64 (&x)[1 << LOGE], u64 *__restrict__ lds, u32 n,
                                                    u32 eblk, u32 lt, bool final_block, bool lazy, Late before_last = Late()) {
     constexpr bool UNI = BlockCfg<LOGB, LOGE>::TPB >= 64;  // a wave never straddles two blocks
@@ -854,7 +805,7 @@ __device__ __forceinline__ void block_inverse_core(const A &ar, u64 (&x)[1 << LO
         for (int k = 0; k < (1 << LOGE); ++k) x[k] = ar.inv_intra(x[k], n, eblk + layout<0, LOGE>(lt, k));
     }
     inv_regpass<A, 0, 0, LOGE - 1, UNI, LOGE>(ar, x, n, eblk + layout<0, LOGE>(lt, 0), LOGB == LOGE && final_block, lazy);
-    inv_chain<A, LOGB, 0, LEAD, LOGE, Late>(ar, x, lds, n, eblk, lt, final_block, lazy, before_last);
+    inv_chain<A, LOGB, 0, LEAD, LOGE, Late, HOOK_AT>(ar, x, lds, n, eblk, lt, final_block, lazy, before_last);
 }
 
 // ---- coalesced block I/O: E/2 16-byte vectors per thread in natural order (vector v = elements
@@ -864,12 +815,10 @@ __device__ __forceinline__ void load_block_vectors(u64x2 (&v)[1 << (LOGE - 1)], 
     const GCVec2Ptr p = (GCVec2Ptr)(const void *)gptr;
 #pragma unroll
     for (int j = 0; j < (1 << (LOGE - 1)); ++j) {
-#ifndef PFHE_PLAIN_STORES
         if constexpr (NT) {  // read-once data of a large batch
             v[j] = __builtin_nontemporal_load(p + lt + BlockCfg<LOGB, LOGE>::TPB * j);
             continue;
         }
-#endif
         v[j] = p[lt + BlockCfg<LOGB, LOGE>::TPB * j];
     }
 }
@@ -882,12 +831,10 @@ __device__ __forceinline__ void load_block_vectors(u64x2 (&v)[1 << (LOGE - 1)], 
 // Infinity Cache, keep plain stores (192 MiB: 0.181 ms plain, 0.190 ms non-temporal).
 template <bool NT, class T>
 __device__ __forceinline__ void gstore(T *p, T v) {
-#ifndef PFHE_PLAIN_STORES
     if constexpr (NT) {
         __builtin_nontemporal_store(v, p);
         return;
     }
-#endif
     *p = v;
 }
 // (a per-launch choice — `if (flag) non-temporal else plain` — does not survive the compiler: it merges the two stores
@@ -898,12 +845,10 @@ __device__ __forceinline__ void store_block_vectors(const u64x2 (&v)[1 << (LOGE 
     const GVec2Ptr p = (GVec2Ptr)(void *)gptr;
 #pragma unroll
     for (int j = 0; j < (1 << (LOGE - 1)); ++j) {
-#ifndef PFHE_PLAIN_STORES
         if constexpr (NT) {
             __builtin_nontemporal_store(v[j], p + lt + BlockCfg<LOGB, LOGE>::TPB * j);
             continue;
         }
-#endif
         p[lt + BlockCfg<LOGB, LOGE>::TPB * j] = v[j];
     }
 }

@@ -18,27 +18,14 @@ namespace {
 constexpr int kPwThreads = 256;
 // Launch shape as in pfhe_elementwise.hip: one vector per thread, one workgroup per 256 vectors (no grid-stride
 // below 2^31 workgroups), non-temporal streams: mul_assign with a per-element multiplicand 4.10 -> 3.24 ms on 6 GiB.
-#ifndef PFHE_PW_UNROLL
-#define PFHE_PW_UNROLL 1
-#endif
-#ifndef PFHE_PW_CACHED
-#define PFHE_PW_NT
-#endif
+constexpr int kPwUnroll = 1;  // vectors per thread and iteration
 
 using pw_vec = __attribute__((__vector_size__(2 * sizeof(u64)))) u64;
 __device__ __forceinline__ pw_vec pw_load(const u64 *p) {
-#ifdef PFHE_PW_NT
     return __builtin_nontemporal_load(reinterpret_cast<const pw_vec *>(p));
-#else
-    return *reinterpret_cast<const pw_vec *>(p);
-#endif
 }
 __device__ __forceinline__ void pw_store(u64 *p, pw_vec v) {
-#ifdef PFHE_PW_NT
     __builtin_nontemporal_store(v, reinterpret_cast<pw_vec *>(p));
-#else
-    *reinterpret_cast<pw_vec *>(p) = v;
-#endif
 }
 
 struct Bar {
@@ -63,7 +50,7 @@ __global__ __launch_bounds__(kPwThreads) void pointwise_kernel(u64 *out, const u
                                                                const u64 *c, const NttPrime *__restrict__ primes,
                                                                u32 L, u32 log_n, u64 len, u64 len_b, u64 group_words) {
     constexpr u64 V = PAIR ? 2 : 1;
-    constexpr int UNROLL = PFHE_PW_UNROLL;
+    constexpr int UNROLL = kPwUnroll;
     const u64 nvec = len / V;
     const bool shared_b = len_b != len;
     const u32 group_units = group_words ? (u32)(group_words >> log_n) / L : 1;
@@ -227,10 +214,8 @@ __global__ __launch_bounds__(kPwThreads) void monomial_kernel(u64 *__restrict__ 
 
 u32 grid_for(u64 work_items) {
     u64 g = (work_items + kPwThreads - 1) / kPwThreads;
-#ifndef PFHE_PW_WG_PER_CU
-#define PFHE_PW_WG_PER_CU (1u << 22)
-#endif
-    const u64 cap = 256ull * PFHE_PW_WG_PER_CU < 0x7fffffffull ? 256ull * PFHE_PW_WG_PER_CU : 0x7fffffffull;  // grid-stride beyond that
+    constexpr unsigned long long kPwWgPerCu = 1ull << 22;
+    const u64 cap = 256ull * kPwWgPerCu < 0x7fffffffull ? 256ull * kPwWgPerCu : 0x7fffffffull;  // grid-stride beyond that
     if (g > cap) g = cap;
     if (g == 0) g = 1;
     return (u32)g;
@@ -242,7 +227,7 @@ int pointwise_dev(u64 *out, const u64 *a, const u64 *b, const u64 *c, const NttP
                   u64 len, u64 len_b, hipStream_t s, u64 group_words, bool pm) {
     if (len == 0) return PFHE_OK;
     const bool pair = log_n >= 1 && (len % 2 == 0) && (len_b % 2 == 0);
-    const u64 items = ((pair ? len / 2 : len) + PFHE_PW_UNROLL - 1) / PFHE_PW_UNROLL;  // vectors per thread and iteration
+    const u64 items = ((pair ? len / 2 : len) + kPwUnroll - 1) / kPwUnroll;  // vectors per thread and iteration
     const dim3 g(grid_for(items ? items : 1)), t(kPwThreads);
 #define PFHE_PW_LAUNCH(HAS_C, PAIR, PM)                                                                               \
     hipLaunchKernelGGL((pointwise_kernel<HAS_C, PAIR, PM>), g, t, 0, s, out, a, b, c, primes, L, log_n, len, len_b, \

@@ -68,3 +68,46 @@ def test_avx512_rejects_tiny_transforms(orc):
     t = orc.U64NttTable(3, 97)
     with pytest.raises(orc.OracleError):
         t.transform_slice_avx512(np.zeros(8, np.uint64))
+
+
+Q50 = 1125899906826241  # the reference's own bench prime (benches/bench_u64.rs:8), below 2^50: the IFMA rung
+
+
+@pytest.mark.parametrize("log_n,q", [(4, Q50), (5, 1125899906629633), (10, 562949953392641), (12, Q50), (13, 132120577),
+                                     (16, 1125899903827969)])
+def test_avx512_ifma_rung_equals_scalar(orc, log_n, q):
+    """BIT_SHIFT = 52 (prime64/avx512 with vpmadd52, q < 2^50: internal.rs:12,24,28; table.rs:166-186,236-256): canonical
+    outputs identical to the scalar path and to the DQ rung, lazy outputs in range and equal mod q, round trip."""
+    if not orc.lib().orc_avx512_ifma_available():
+        pytest.skip("host has no AVX-512 IFMA")
+    rng = np.random.default_rng(200 + log_n)
+    t = orc.U64NttTable(log_n, q)
+    a = rng.integers(0, q, 3 << log_n, dtype=np.uint64)
+    a[:4] = [0, q - 1, 1, q // 2]
+    ref = a.copy(); t.transform_slice(ref)
+    for shift in (52, 64, 0):
+        got = a.copy(); t.transform_slice_avx512(got, shift=shift)
+        assert np.array_equal(got, ref), shift
+    lz = rng.integers(0, 4 * q, 1 << log_n, dtype=np.uint64)
+    can = (lz % np.uint64(q)).copy(); t.transform_slice(can)
+    t.transform_slice_avx512(lz, lazy=True, shift=52)
+    assert lz.max() < 4 * q and np.array_equal(lz % np.uint64(q), can)
+    iref = a.copy(); t.inverse_transform_slice(iref)
+    for shift in (52, 64, 0):
+        got = a.copy(); t.inverse_transform_slice_avx512(got, shift=shift)
+        assert np.array_equal(got, iref), shift
+    il = a.copy(); t.inverse_transform_slice_avx512(il, lazy=True, shift=52)
+    assert il.max() < 2 * q and np.array_equal(il % np.uint64(q), iref)
+    rt = a.copy(); t.transform_slice_avx512(rt, shift=52); t.inverse_transform_slice_avx512(rt, shift=52)
+    assert np.array_equal(rt, a)
+
+
+def test_avx512_ifma_rejects_wide_moduli(orc):
+    """The IFMA rung is for q < 2^50 (MAX_FWD_IFMA_MODULUS); a 61-bit prime must not take it."""
+    if not orc.lib().orc_avx512_ifma_available():
+        pytest.skip("host has no AVX-512 IFMA")
+    t = orc.U64NttTable(8, Q61[0])
+    with pytest.raises(orc.OracleError):
+        t.transform_slice_avx512(np.zeros(256, np.uint64), shift=52)
+    with pytest.raises(orc.OracleError):
+        t.inverse_transform_slice_avx512(np.zeros(256, np.uint64), shift=52)

@@ -22,10 +22,10 @@ mods = np.array([q], np.uint64)
 check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(x.data_ptr()), x.numel(), mods.ctypes.data_as(u64p), 1, n, 2, None))
 stream = torch.cuda.current_stream()
 for name, fn in (("forward", t.transform_dev), ("inverse", t.inverse_transform_dev)):
-    for _ in range(3):
+    for _ in range(int(os.environ.get("WARM", "600"))):  # ~0.25 s: the shader clock needs that long to settle
         fn(x)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 20
+    reps = int(os.environ.get("REPS", "200"))
     e0.record(stream)
     for _ in range(reps):
         fn(x)
