@@ -202,6 +202,19 @@ def cpu_baseline(seconds: float):
     return out
 
 
+def extprod_traffic():
+    """Whole-product HBM bytes per external product from the newest committed counter passes
+    (profiles/*_extprod_traffic.json, written by tools/collect_profiles2.py), or None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_extprod_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            return {"bytes_per_product": float(d["bytes_per_product"]), "source": os.path.basename(path), "method": d["method"]}
+        except Exception:
+            continue
+    return None
+
+
 def pmc_traffic(kernel: str, batch: int):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 +
     WRITE_SIZE, separate --pmc runs of tools/profile_ntt.py at this shape; profiles/*_rocprof.json).
@@ -385,16 +398,25 @@ def main():
             mac_bytes = ep_batch * (2 * 6 * L + 2 * L) * n * 8  # transformed digits read + result written (key: L2)
             dec_bytes = ep_batch * (2 * L + 2 * 6 * L) * n * 8  # CRT polynomials read + strided-pass digits written
             dom_bytes = mac_bytes if ms_mac >= ms_dec else dec_bytes
+            traffic = extprod_traffic()
             result["external_product"]["roofline"] = {
-                "bound": "hbm", "kernel": "gadget_block_mulacc_kernel (block pass of the digits' transform + multiply-accumulate)"
+                "bound": "hbm", "kernel": "gadget_block_mulacc_kernel (block pass of the digits' transform + multiply-accumulate"
+                                          " + inverse block pass of the result)"
                 if ms_mac >= ms_dec else "gadget_signed_digits_kernel + digits_strided_kernel",
                 "avg_launch_ms": dom_ms / max(1, launches), "launches_per_batch": launches,
                 "ms_per_batch": {"digits_and_strided_pass": ms_dec, "block_pass_and_multiply_accumulate": ms_mac},
                 "achieved": dom_bytes / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_batch": dom_bytes, "traffic": None,
-                "note": "the kernel runs 12 block transforms per output block: bound by the integer ALU "
-                        "(profiles/r02_extprod_pmc.txt), not by HBM"}
+                "algorithmic_bytes_per_batch": dom_bytes,
+                # whole product, every kernel: HBM bytes per product from the committed counter passes x this batch
+                "traffic": traffic["bytes_per_product"] * ep_batch if traffic else None,
+                "traffic_unit": "bytes per batch of %d products, all kernels of the product (coefficient form)" % ep_batch,
+                "traffic_source": (traffic["source"] + ": " + traffic["method"]) if traffic else None,
+                "traffic_vs_algorithmic": traffic["bytes_per_product"] / (96 * n) if traffic else None,
+                "note": "the kernel runs 12 forward block transforms + 72 multiply-accumulates per word + 2 inverse block "
+                        "transforms per output block: VALUBusy 80+ % AND ~11x the product's algorithmic bytes in flight "
+                        "(the 36 half-transformed digit polynomials are written and read once): loaded on both units "
+                        "(profiles/r03_*_extprod_pmc.txt)"}
         except Exception as e:  # measurement aid only
             result["external_product"]["roofline"] = {"error": str(e)[:200]}
     del out

@@ -385,9 +385,11 @@ int pfhe_extprod_mul_dcrt_ggsw_to_dev(pfhe_extprod_plan *plan, const uint64_t *c
                                       size_t len_glwe, const uint64_t *dcrt_ggsw_dev, size_t len_ggsw,
                                       uint64_t *result_dev, size_t len_result, int into_coeff_form,
                                       void *stream);
-/* Measurement aid (bench.py, tools/): the same product (NTT-form output) with HIP events between its kernel groups
- * on `stream`; waits for the stream.  ms_out[0] = digit extraction + lifting strided pass, ms_out[1] = block pass of the
- * digits' transform + multiply-accumulate, both summed over the *launches_out chunks.  Not a reference interface. */
+/* Measurement aid (bench.py, tools/): the same product (coefficient-form output) with HIP events between its kernel
+ * groups on `stream`; waits for the stream.  ms_out[0] = digit extraction + lifting strided pass, ms_out[1] = block pass of
+ * the digits' transform + multiply-accumulate (+ the inverse transform's block pass, fused into the same kernel), both
+ * summed over the *launches_out chunks; the inverse transform's strided pass runs after the last event.  Not a reference
+ * interface. */
 int pfhe_extprod_profile_dev(pfhe_extprod_plan *plan, const uint64_t *crt_glwe_dev, size_t len_glwe,
                              const uint64_t *dcrt_ggsw_dev, size_t len_ggsw, uint64_t *result_dev, size_t len_result,
                              double *ms_out, size_t *launches_out, void *stream);

@@ -274,11 +274,9 @@ int monomial(const TableSet &t, u64 coeff, size_t degree, u64 *values, size_t le
         set_last_error("monomial output must be exactly one polynomial");
         return PFHE_ERR_BAD_LENGTH;
     }
-    if (t.L > kMaxMonomialLimbs) {
-        set_last_error("monomial transforms support at most 16 moduli");
-        return PFHE_ERR_UNSUPPORTED;
-    }
-    MonomialScalars sc{};
+    // the per-limb scalars travel by value as kernel arguments (no staging buffer: the device form is capturable), at most
+    // kMaxMonomialLimbs of them per launch; wider bases take one launch per group of limbs
+    std::vector<MonomialScalars> groups((t.L + kMaxMonomialLimbs - 1) / kMaxMonomialLimbs);
     for (u32 i = 0; i < t.L; ++i) {
         const u64 q = t.primes[i].q;
         const u64 ci = minus_one ? q - 1 : coeff;
@@ -286,17 +284,25 @@ int monomial(const TableSet &t, u64 coeff, size_t degree, u64 *values, size_t le
             set_last_error("monomial coefficient must be reduced modulo every modulus");
             return PFHE_ERR_BAD_ARGUMENT;
         }
-        sc.value[i] = ci;
-        sc.quotient[i] = (u64)(((unsigned __int128)ci << 64) / q);
+        MonomialScalars &sc = groups[i / kMaxMonomialLimbs];
+        sc.value[i % kMaxMonomialLimbs] = ci;
+        sc.quotient[i % kMaxMonomialLimbs] = (u64)(((unsigned __int128)ci << 64) / q);
     }
     DeviceGuard g(t.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
     const u64 deg = (u64)degree & (2 * (u64)t.n - 1);
-    if (!host)  // device output: one launch on the caller's stream, nothing else (capturable)
-        return monomial_dev(values, t.primes_dev, t.L, t.log_n, deg, sc, s);
+    const auto run = [&](u64 *out) -> int {
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            const u32 l0 = (u32)gi * kMaxMonomialLimbs, lg = std::min<u32>(kMaxMonomialLimbs, t.L - l0);
+            PFHE_TRY(monomial_dev(out + (size_t)l0 * t.n, t.primes_dev + l0, lg, t.log_n, deg, groups[gi], s));
+        }
+        return PFHE_OK;
+    };
+    if (!host)  // device output: launches on the caller's stream, nothing else (capturable)
+        return run(values);
     void *out_dev = nullptr;
     PFHE_HIP(hipMalloc(&out_dev, len * sizeof(u64)));
-    int rc = monomial_dev(static_cast<u64 *>(out_dev), t.primes_dev, t.L, t.log_n, deg, sc, s);
+    int rc = run(static_cast<u64 *>(out_dev));
     hipError_t e = hipSuccess;
     if (rc == PFHE_OK) e = hipMemcpyAsync(values, out_dev, len * sizeof(u64), hipMemcpyDeviceToHost, s);
     if (rc == PFHE_OK && e == hipSuccess) e = hipStreamSynchronize(s);

@@ -672,8 +672,10 @@ int pfhe_extprod_profile_dev(pfhe_extprod_plan *plan, const uint64_t *crt_glwe_d
     }
     std::vector<hipEvent_t> ev;
     plan->prof = &ev;
+    // coefficient-form output, as bench.py times it: the second group includes the inverse block pass fused into the
+    // multiply-accumulate kernel; the final strided inverse pass runs after the last stamp
     int rc = pfhe_extprod_mul_dcrt_ggsw_to_dev(plan, crt_glwe_dev, len_glwe, dcrt_ggsw_dev, len_ggsw, result_dev,
-                                               len_result, 0, stream);
+                                               len_result, 1, stream);
     plan->prof = nullptr;
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     ms_out[0] = ms_out[1] = 0.0;

@@ -1079,6 +1079,7 @@ static int pipelined_tiles(u32 L, u32 log_n, int pm, u64 npolys, bool inverse, b
     int pt = tune.overlap_tiles ? tune.overlap_tiles
                                 : (int)std::min<u64>((bytes + kPipelinedTileBytes / 2) / kPipelinedTileBytes, (u64)kPipelinedMaxTiles);
     if (pt < 2) pt = 2;
+    if (pt > kPipelinedMaxTiles) pt = kPipelinedMaxTiles;  // what transform_pipelined runs (its launch count is reported)
     if ((u64)pt > npolys / L) pt = (int)(npolys / L);
     return pt;
 }

@@ -154,6 +154,7 @@ int make_table_set32(u32 log_n, const u32 *moduli, size_t count, int device, std
     ts->log_n = log_n;
     ts->n = (size_t)1 << log_n;
     ts->L = (u32)count;
+    ts->tune = NttTuning::from_env();  // u32 tables read the tuning switches at creation too
     ts->primes.resize(count);
     const size_t n = ts->n;
     std::vector<u64> packed(n);
@@ -266,11 +267,8 @@ int monomial32(const TableSet &t, u32 coeff, size_t degree, u32 *values, size_t 
         set_last_error("monomial output must be exactly one polynomial");
         return PFHE_ERR_BAD_LENGTH;
     }
-    if (t.L > kMaxMonomialLimbs) {
-        set_last_error("monomial transforms support at most 16 moduli");
-        return PFHE_ERR_UNSUPPORTED;
-    }
-    MonomialScalars sc{};
+    // scalars by value, at most kMaxMonomialLimbs per launch; wider bases take one launch per group of limbs
+    std::vector<MonomialScalars> groups((t.L + kMaxMonomialLimbs - 1) / kMaxMonomialLimbs);
     for (u32 i = 0; i < t.L; ++i) {
         const u32 q = (u32)t.primes[i].q;
         const u32 ci = minus_one ? q - 1 : coeff;
@@ -278,17 +276,21 @@ int monomial32(const TableSet &t, u32 coeff, size_t degree, u32 *values, size_t 
             set_last_error("monomial coefficient must be reduced modulo every modulus");
             return PFHE_ERR_BAD_ARGUMENT;
         }
-        sc.value[i] = ci;
+        groups[i / kMaxMonomialLimbs].value[i % kMaxMonomialLimbs] = ci;
     }
     DeviceGuard g(t.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
     const u64 deg = (u64)degree & (2 * (u64)t.n - 1);
     void *out_dev = values;
     if (host) PFHE_HIP(hipMalloc(&out_dev, len * sizeof(u32)));
-    hipLaunchKernelGGL(monomial32_kernel, dim3(grid_for(len)), dim3(kThreads), 0, s, static_cast<u32 *>(out_dev),
-                       t.primes_dev, t.L, t.log_n, deg, sc);
-    hipError_t e = hipGetLastError();
-    if (host) {  // the device form is this one launch (capturable); only the host form copies back and waits
+    hipError_t e = hipSuccess;
+    for (size_t gi = 0; gi < groups.size() && e == hipSuccess; ++gi) {
+        const u32 l0 = (u32)gi * kMaxMonomialLimbs, lg = std::min<u32>(kMaxMonomialLimbs, t.L - l0);
+        hipLaunchKernelGGL(monomial32_kernel, dim3(grid_for((size_t)lg * t.n)), dim3(kThreads), 0, s,
+                           static_cast<u32 *>(out_dev) + (size_t)l0 * t.n, t.primes_dev + l0, lg, t.log_n, deg, groups[gi]);
+        e = hipGetLastError();
+    }
+    if (host) {  // the device form is these launches (capturable); only the host form copies back and waits
         if (e == hipSuccess) e = hipMemcpyAsync(values, out_dev, len * sizeof(u32), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         (void)hipFree(out_dev);

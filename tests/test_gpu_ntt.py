@@ -804,3 +804,53 @@ def test_config2_full_batch(pf, orc):
     assert torch.equal(x, orig)
     oracle_map(o.inverse_transform_slice, inv, n)
     assert np.array_equal(inv, to_host(orig))
+
+
+WIDE40 = [1099511628161, 1099511629121, 1099511629889, 1099511630209, 1099511630593, 1099511630849, 1099511631937,
+          1099511633153, 1099511634113, 1099511635009, 1099511636161, 1099511638529, 1099511639297, 1099511640001,
+          1099511641153, 1099511641729, 1099511643137, 1099511643521]  # 18 primes = 1 mod 64
+
+
+def test_monomials_of_a_wide_rns_base(pf, orc):
+    """DcrtTable::transform_monomial / coeff_one / coeff_minus_one (dcrt/mod.rs:105-134) with more moduli than one launch
+    carries scalars for (16): the limbs are served in groups."""
+    log_n = 4
+    n = 1 << log_n
+    d = pf.U64DcrtTable(log_n, WIDE40)
+    tabs = [orc.U64NttTable(log_n, q) for q in WIDE40]
+    out = np.empty(len(WIDE40) * n, np.uint64)
+    for degree in (0, 1, n - 1, n + 3):
+        d.transform_monomial(5, degree, out)
+        assert np.array_equal(out, np.concatenate([t.transform_monomial(5, degree) for t in tabs])), degree
+        d.transform_coeff_minus_one_monomial(degree, out)
+        assert np.array_equal(out, np.concatenate([t.transform_coeff_minus_one_monomial(degree) for t in tabs]))
+        d.transform_coeff_one_monomial(degree, out)
+        assert np.array_equal(out, np.concatenate([t.transform_coeff_one_monomial(degree) for t in tabs]))
+
+
+@pytest.mark.parametrize("log_n", [4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("lazy", [False, True])
+def test_dcrt_small_rings_with_per_lane_primes(pf, orc, log_n, lazy):
+    """Block passes below 2^10 hold several polynomials per wave, so the prime (q, c, K) is a per-lane value in the asm
+    butterflies (pfhe_pm_asm.hpp): forward and inverse DCRT transforms of three pseudo-Mersenne limbs, batch 8, against
+    the oracle for every small size."""
+    rng = np.random.default_rng(70 + log_n)
+    n, batch = 1 << log_n, 8
+    d, o = pf.U64DcrtTable(log_n, Q61), orc.U64DcrtTable(log_n, Q61)
+    a = rand_rns(rng, Q61, n, batch)
+    fwd, exp = to_dev(a), a.copy()
+    o.transform_slice(exp)
+    if lazy:
+        d.transform_dev(fwd, lazy=True)
+        got = to_host(fwd)
+        qs = np.tile(np.repeat(np.array(Q61, np.uint64), n), batch)
+        assert np.all(got < 4 * qs) and np.array_equal(got % qs, exp)
+        inv = to_dev(exp)
+        d.inverse_transform_dev(inv, lazy=True)
+        gi = to_host(inv)
+        assert np.all(gi < 2 * qs) and np.array_equal(gi % qs, a)
+    else:
+        d.transform_dev(fwd)
+        assert np.array_equal(to_host(fwd), exp)
+        d.inverse_transform_dev(fwd)
+        assert np.array_equal(to_host(fwd), a)

@@ -11,7 +11,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02_a"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03_a"
 # (run on the GPU box, where only gpurun_out/ travels back: the summaries go to gpurun_out/TAG/summaries/ and are copied
 # into profiles/ by hand afterwards:  cp gpurun_out/TAG/summaries/* profiles/)
 src = os.path.join(ROOT, "gpurun_out", tag)
@@ -90,6 +90,30 @@ if stf:
         ep.append(f"  {short(r['Name']):58s} calls {int(r['Calls']):5d}  avg {float(r['AverageNs']) / 1e3:9.1f} us  {float(r['Percentage']):6.2f} %")
 ep += counter_table("ep_", "rocprofv3 --pmc <one counter per pass> -- python3 tools/perf_extprod.py (FETCH_SIZE / WRITE_SIZE in KiB as "
                     "reported: reads = 2 x FETCH_SIZE on gfx950)")
+# whole-product HBM traffic: every launch of the COEFF_ONLY counter passes (4 products of batch 1024, coefficient form),
+# 2 x FETCH_SIZE + WRITE_SIZE (KiB as reported; gfx950 correction of MI355X_MICROARCH.md), summed and divided by the products
+def counter_sum(name):
+    f = newest(f"{src}/ep_{name}/**/*counter_collection.csv")
+    per = collections.defaultdict(float)
+    if f:
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if not (k.startswith("__amd") or "fill" in k):
+                per[k] += float(r["Counter_Value"])
+    return per
+
+
+fe, wr = counter_sum("FETCH_SIZE"), counter_sum("WRITE_SIZE")
+if fe and wr:
+    products = 4 * int(os.environ.get("BATCH", "1024"))
+    per_kernel = {k: (2 * fe.get(k, 0.0) + wr.get(k, 0.0)) * 1024 / products for k in sorted(set(fe) | set(wr))}
+    traffic = {"products": products, "form": "CrtGlwe x DcrtGgsw -> coefficient form, batch 1024, default chunk",
+               "method": "sum over every kernel launch of 2*FETCH_SIZE + WRITE_SIZE (separate --pmc passes, KiB), / products",
+               "bytes_per_product": sum(per_kernel.values()), "bytes_per_product_by_kernel": per_kernel,
+               "algorithmic_bytes_per_product": 96 * 65536}
+    json.dump(traffic, open(f"{dst}/{tag}_extprod_traffic.json", "w"), indent=1)
+    ep.append("whole product: %.1f MB moved per product (algorithmic 6.29 MB): " % (traffic["bytes_per_product"] / 1e6) +
+              ", ".join("%s %.1f" % (k, v / 1e6) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1])))
 open(f"{dst}/{tag}_extprod_pmc.txt", "w").write("\n".join(ep) + "\n")
 print("\n".join(lines[:10]))
 print("\n".join(ep[:14]))

@@ -31,7 +31,8 @@ def fill(words, seed):
 
 glwe, ggsw = fill(batch * 2 * L * n, 1), fill(ctx.ggsw_len(), 2)
 out = torch.empty_like(glwe)
-for coeff in (False, True):
+# COEFF_ONLY=1: only the coefficient-form product (counter passes: every launch then belongs to that form)
+for coeff in ((True,) if os.environ.get("COEFF_ONLY") else (False, True)):
     p.mul_dcrt_ggsw_to_dev(glwe, ggsw, out, ctx, into_coeff_form=coeff)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
