@@ -83,11 +83,14 @@ int make_table_set(u32 log_n, const u64 *moduli, size_t count, int device, std::
     ts->monomial_inplace = std::getenv("PFHE_DISABLE_MONOMIAL_INPLACE") == nullptr;
     const size_t bytes = ts->n * sizeof(ulonglong2);
     bool all_pm = std::getenv("PFHE_DISABLE_PM") == nullptr;  // tuning switch: force the generic path
+    bool all_mont = std::getenv("PFHE_DISABLE_MONT") == nullptr;  // tuning switch: generic primes keep the Shoup transforms
     for (size_t i = 0; i < count; ++i) {
         u32 pk = 0;
         u64 pc = 0;
         if (!pm_shape(host[i].q, pk, pc)) all_pm = false;
+        if (!mont_shape(host[i].q)) all_mont = false;
     }
+    const bool use_mont = !all_pm && all_mont && log_n >= 4;
     const auto upload = [&](const void *src, size_t nbytes, const void **dst) -> int {
         void *d = nullptr;
         PFHE_HIP(hipMalloc(&d, nbytes));
@@ -152,6 +155,34 @@ int make_table_set(u32 log_n, const u64 *moduli, size_t count, int device, std::
             if (all_pm && log_n >= 4) last_order(fw, iw, fl, il);
         }
         if (!all_pm && log_n >= 4) last_order(host[i].fwd, host[i].inv, fl, il);
+        if (use_mont) {
+            // {w * 2^32 mod q, w * 2^64 mod q}: the one-word Montgomery product of MontArith (pfhe_mont_asm.hpp)
+            const u64 q = P.q;
+            const auto mform = [&](u64 w) {
+                const u64 a = (u64)(((unsigned __int128)w << 32) % q);
+                return ulonglong2{a, (u64)(((unsigned __int128)a << 32) % q)};
+            };
+            std::vector<ulonglong2> fm(ts->n), im(ts->n), flm, ilm;
+            for (size_t k = 0; k < ts->n; ++k) {
+                fm[k] = mform(host[i].fwd[k].x);
+                im[k] = mform(host[i].inv[k].x);
+            }
+            last_order(fm, im, flm, ilm);
+            const void *a = nullptr, *b = nullptr, *c = nullptr, *d = nullptr;
+            PFHE_TRY(upload(fm.data(), bytes, &a));
+            PFHE_TRY(upload(im.data(), bytes, &b));
+            PFHE_TRY(upload(flm.data(), flm.size() * sizeof(ulonglong2), &c));
+            PFHE_TRY(upload(ilm.data(), ilm.size() * sizeof(ulonglong2), &d));
+            P.fwd_m = static_cast<const ulonglong2 *>(a);
+            P.inv_m = static_cast<const ulonglong2 *>(b);
+            P.fwd_last_m = static_cast<const ulonglong2 *>(c);
+            P.inv_last_m = static_cast<const ulonglong2 *>(d);
+            const ulonglong2 nm = mform(P.inv_n), nwm = mform(P.inv_n_w);
+            P.inv_n_m = nm.x, P.inv_n_m2 = nm.y, P.inv_n_w_m = nwm.x, P.inv_n_w_m2 = nwm.y;
+            u32 inv = 1;  // Newton: q^-1 mod 2^32
+            for (int it = 0; it < 5; ++it) inv *= 2u - (u32)q * inv;
+            P.qinv32 = 0u - inv;
+        }
         if (!fl.empty()) {
             const void *flp = nullptr, *ilp = nullptr;
             PFHE_TRY(upload(fl.data(), fl.size() * sizeof(ulonglong2), &flp));
@@ -163,6 +194,7 @@ int make_table_set(u32 log_n, const u64 *moduli, size_t count, int device, std::
         ts->inv_roots.push_back(host[i].inv_root);
     }
     ts->pm = all_pm;
+    ts->ntt_arith = all_pm ? kArithPm : (use_mont ? kArithMont : kArithShoup);
     void *pd = nullptr;
     PFHE_HIP(hipMalloc(&pd, count * sizeof(NttPrime)));
     ts->allocations.push_back(pd);
@@ -197,8 +229,8 @@ int transform_dev(const TableSet &t, u64 *data, size_t len, bool inverse, bool l
     DeviceGuard g(t.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
     const u64 npolys = units * t.L;
-    return inverse ? ntt_inverse_dev(t.primes_dev, t.L, t.log_n, t.pm, data, npolys, lazy, s, t.tune)
-                   : ntt_forward_dev(t.primes_dev, t.L, t.log_n, t.pm, data, npolys, lazy, s, t.tune);
+    return inverse ? ntt_inverse_dev(t.primes_dev, t.L, t.log_n, t.ntt_arith, data, npolys, lazy, s, t.tune)
+                   : ntt_forward_dev(t.primes_dev, t.L, t.log_n, t.ntt_arith, data, npolys, lazy, s, t.tune);
 }
 
 // host-pointer wrapper: stage through a temporary device buffer
@@ -746,13 +778,13 @@ int pfhe_dcrt_glwe_mul_dcrt_polynomial_to_dev(const pfhe_dcrt *table, const uint
 }
 
 int pfhe_dcrt_transform_num_passes(const pfhe_dcrt *table) {
-    return table ? ntt_num_passes(table->t->log_n, table->t->pm, table->t->tune) : 0;
+    return table ? ntt_num_passes(table->t->log_n, table->t->ntt_arith, table->t->tune) : 0;
 }
 
 const char *pfhe_dcrt_transform_pass_name(const pfhe_dcrt *table, int inverse, int index) {
     static thread_local char buf[96];
     buf[0] = 0;
-    if (table) ntt_pass_name(table->t->log_n, inverse != 0, index, buf, sizeof buf, table->t->pm, table->t->tune);
+    if (table) ntt_pass_name(table->t->log_n, inverse != 0, index, buf, sizeof buf, table->t->ntt_arith, table->t->tune);
     return buf;
 }
 
@@ -760,7 +792,7 @@ int pfhe_dcrt_transform_form(const pfhe_dcrt *table, size_t len, int inverse, ch
     if (!table || !name || cap == 0 || !launches) return PFHE_ERR_BAD_ARGUMENT;
     const TableSet &t = *table->t;
     if (len % (t.n * t.L) != 0) return PFHE_ERR_BAD_LENGTH;
-    *launches = ntt_transform_form(t.L, t.log_n, t.pm, len / t.n, inverse != 0, t.tune, name, cap);
+    *launches = ntt_transform_form(t.L, t.log_n, t.ntt_arith, len / t.n, inverse != 0, t.tune, name, cap);
     return PFHE_OK;
 }
 
@@ -773,7 +805,7 @@ int pfhe_dcrt_transform_pass_dev(const pfhe_dcrt *table, uint64_t *poly_dev, siz
     if (len % (t.n * t.L) != 0) return PFHE_ERR_BAD_LENGTH;
     DeviceGuard g(t.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    return ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.pm, (u64 *)poly_dev, len / t.n, inverse != 0, index,
+    return ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.ntt_arith, (u64 *)poly_dev, len / t.n, inverse != 0, index,
                         lazy != 0, (hipStream_t)stream, nullptr, 0, t.tune);
     PFHE_GUARD_END
 }
@@ -800,7 +832,7 @@ int pfhe_dcrt_mul_dcrt_polynomial_dev(const pfhe_dcrt *table, uint64_t *crt_poly
         // forward block pass -> product -> inverse block pass in one kernel, between the strided passes
         DeviceGuard g(t.device);
         if (!g.ok) return PFHE_ERR_NO_DEVICE;
-        const int rc = ntt_polymul_dev(t.primes_dev, t.L, t.log_n, t.pm, (u64 *)crt_poly_dev, len / t.n,
+        const int rc = ntt_polymul_dev(t.primes_dev, t.L, t.log_n, t.ntt_arith, (u64 *)crt_poly_dev, len / t.n,
                                        (const u64 *)dcrt_poly_dev, len_b / t.n, (hipStream_t)stream, t.tune);
         if (rc != PFHE_ERR_UNSUPPORTED) return rc;
     }
@@ -809,7 +841,7 @@ int pfhe_dcrt_mul_dcrt_polynomial_dev(const pfhe_dcrt *table, uint64_t *crt_poly
         // the pointwise product rides on the loads of the inverse transform's first pass
         DeviceGuard g(t.device);
         if (!g.ok) return PFHE_ERR_NO_DEVICE;
-        return ntt_inverse_mul_dev(t.primes_dev, t.L, t.log_n, t.pm, (u64 *)crt_poly_dev, len / t.n,
+        return ntt_inverse_mul_dev(t.primes_dev, t.L, t.log_n, t.ntt_arith, (u64 *)crt_poly_dev, len / t.n,
                                    (const u64 *)dcrt_poly_dev, len_b / t.n, (hipStream_t)stream, t.tune);
     }
     PFHE_TRY(pointwise(t, 0, (u64 *)crt_poly_dev, nullptr, len, (const u64 *)dcrt_poly_dev, len_b,

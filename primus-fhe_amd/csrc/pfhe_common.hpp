@@ -88,7 +88,18 @@ struct NttPrime {
     // kind the arithmetic policy in use wants ({w, Shoup quotient} or {w, w * 2^32 mod q}); null for N < 16.
     const ulonglong2 *fwd_last;
     const ulonglong2 *inv_last;
+    // Montgomery-form twiddles of the generic-prime transforms (MontArith; null unless the table takes that path):
+    // {w * 2^32 mod q, w * 2^64 mod q}, same indexing as fwd / inv, and their lane-ordered copies
+    const ulonglong2 *fwd_m;
+    const ulonglong2 *inv_m;
+    const ulonglong2 *fwd_last_m;
+    const ulonglong2 *inv_last_m;
+    u64 inv_n_m, inv_n_m2, inv_n_w_m, inv_n_w_m2;  // N^-1 and N^-1 * w in the same form
+    u32 qinv32, mont_pad;                          // -q^-1 mod 2^32
 };
+
+// MontArith covers primes below 2^61 (lazy values stay below 8q <= 2^64)
+inline bool mont_shape(u64 q) { return (q & 1) && q < (1ull << 61); }
 
 // q = 2^K - c qualifies for PmArith when 40 <= K <= 61 and c < 2^(K-33)
 inline bool pm_shape(u64 q, u32 &k, u64 &c) {

@@ -15,6 +15,7 @@ struct TableSet {
     size_t n = 1;
     u32 L = 0;
     bool pm = false;                       // every prime has the pseudo-Mersenne shape
+    int ntt_arith = 0;                     // policy of the plain transforms: kArithPm, kArithMont (generic primes below 2^61) or kArithShoup
     // tuning switches, read from the environment once, when the handle is created
     NttTuning tune;
     bool fused_polymul = true;             // cleared by PFHE_DISABLE_FUSED_POLYMUL

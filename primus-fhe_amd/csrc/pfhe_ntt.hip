@@ -879,6 +879,8 @@ int ntt_pass_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data,
         return run_pass<B32Arith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys, v1, false);
     }
     if (plan.tiny) return mul ? PFHE_ERR_UNSUPPORTED : launch_tiny(inverse, primes, L, log_n, data, npolys, lazy, s);
+    if (arith == kArithMont)
+        return run_pass<MontArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys, v1, tune.persist);
     return arith == kArithPm
                ? run_pass<PmArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys, v1, tune.persist)
                : run_pass<ShoupArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys, v1, tune.persist);
@@ -1106,6 +1108,8 @@ static int transform(const NttPrime *primes, u32 L, u32 log_n, int pm, u64 *data
     const u64 bytes = (npolys << log_n) * sizeof(u64);
     {
         const int pt = pipelined_tiles(L, log_n, pm, npolys, inverse, mul != nullptr, tune);
+        if (pt >= 1 && pm == kArithMont)
+            return transform_pipelined<MontArith, 12>(primes, L, data, npolys, inverse, lazy, s, pt, tune.pipe_ramp, mul, mul_polys);
         if (pt >= 1)
             return pm == kArithPm
                        ? transform_pipelined<PmArith, 12>(primes, L, data, npolys, inverse, lazy, s, pt, tune.pipe_ramp, mul, mul_polys)
@@ -1269,6 +1273,7 @@ int ntt_polymul_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *da
         return PFHE_ERR_BAD_ARGUMENT;
     if (arith == kArithB32) return PFHE_ERR_UNSUPPORTED;
     if (npolys == 0) return PFHE_OK;
+    if (arith == kArithMont) return polymul_impl<MontArith>(primes, L, log_n, arith, data, npolys, mul, mul_polys, s, tune);
     return arith == kArithPm ? polymul_impl<PmArith>(primes, L, log_n, arith, data, npolys, mul, mul_polys, s, tune)
                              : polymul_impl<ShoupArith>(primes, L, log_n, arith, data, npolys, mul, mul_polys, s, tune);
 }

@@ -4,6 +4,7 @@
 #include "pfhe_common.hpp"
 #include "pfhe_modmath.hpp"
 #if defined(__HIPCC__)
+#include "pfhe_mont_asm.hpp"
 #include "pfhe_pm_asm.hpp"
 #endif
 
@@ -38,11 +39,12 @@ struct NttTuning {
 };
 NttPlan make_ntt_plan(u32 log_n, int arith = 0, const NttTuning &tune = NttTuning());  // arith: see kArith* below
 
-// `arith` selects the arithmetic policy: kArithShoup (any q < 2^62), kArithPm (every prime of the
+// `arith` selects the arithmetic policy: kArithShoup (any q < 2^62), kArithMont (every prime below 2^61: the
+// transforms of generic primes, NttPrime::fwd_m), kArithPm (every prime of the
 // table has the pseudo-Mersenne shape, NttPrime::pm_k) or kArithB32 (32-bit tables: `data` holds
 // pairs of u32 coefficients and log_n counts 64-bit WORDS, i.e. log2(N) - 1).  A bool converts to
 // the first two.
-enum : int { kArithShoup = 0, kArithPm = 1, kArithB32 = 2 };
+enum : int { kArithShoup = 0, kArithPm = 1, kArithB32 = 2, kArithMont = 3 };
 int ntt_forward_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, bool lazy,
                     hipStream_t s, const NttTuning &tune = NttTuning());
 // the form a transform of npolys limb-polynomials takes (kernel or form name into buf) and its number of launches
@@ -168,6 +170,7 @@ struct ShoupArith {
     __device__ __forceinline__ u64 reduce_4q(u64 x) const { return csub(csub(x, two_q), q); }  // [0,4q) -> [0,q)
     static constexpr bool kPacked = false;
     static constexpr bool kWide = false;
+    static constexpr bool kMont = false;
 };
 
 // v_mad_u64_u32 with its carry-out kept (an SGPR pair: one bit per lane), and the add-with-carry that consumes it.
@@ -294,6 +297,68 @@ struct PmArith {
     // "wide" lazy domain: butterfly values are arbitrary 64-bit representatives bounded by the analysis at
     // fwd_bfly / inv_bfly below, not the reference's [0,4q) / [0,2q)
     static constexpr bool kWide = true;
+    static constexpr bool kMont = false;
+};
+
+
+// MontArith — any odd prime q < 2^61 (the transforms of tables whose primes are not all pseudo-Mersenne): one-word
+//   Montgomery reduction with a split multiplicand.  Twiddles are stored as {wm = w*2^32 mod q, wm2 = w*2^64 mod q}
+//   (NttPrime::fwd_m / inv_m); T = (y0*wm + y1*wm2 + m*q) / 2^32 == y*w (mod q), T < 3q for ANY 64-bit y, with
+//   m = (low word of the sum) * (-q^-1 mod 2^32): seven 32 x 32 multiplies where the reference's Shoup product
+//   (shoup_factor/mod.rs:124-131) takes ten.  Lazy domain [0, 8q) inside 64 bits: see pfhe_mont_asm.hpp.  Exact
+//   integer arithmetic: canonical outputs are the Shoup path's, lazy outputs agree mod q and honour the reference's
+//   [0,4q) / [0,2q) contracts.  Products of two data words keep the Barrett form (mul_any).
+struct MontArith {
+    struct Tw {
+        u64 w, w2;
+    };
+    u64 q, two_q, q3, q4;
+    CCVec2Ptr fwd, inv;
+    GCVec2Ptr fwd_last, inv_last;
+    Tw inv_n, inv_n_w;
+    u64 bar_lo, bar_hi;
+    u32 qinv;          // -q^-1 mod 2^32
+    u32 vq4_0, vq4_1;  // halves of 4q held in VGPRs (operands of the borrow chains in pfhe_mont_asm.hpp)
+
+    __device__ __forceinline__ explicit MontArith(const NttPrime *__restrict__ P)
+        : q(P->q), two_q(P->two_q), q3(P->q3), q4(P->q << 2), fwd((CCVec2Ptr)(const void *)P->fwd_m),
+          inv((CCVec2Ptr)(const void *)P->inv_m), fwd_last((GCVec2Ptr)(const void *)P->fwd_last_m),
+          inv_last((GCVec2Ptr)(const void *)P->inv_last_m), inv_n{P->inv_n_m, P->inv_n_m2},
+          inv_n_w{P->inv_n_w_m, P->inv_n_w_m2}, bar_lo(P->bar_lo), bar_hi(P->bar_hi), qinv(P->qinv32),
+          vq4_0((u32)(P->q << 2)), vq4_1((u32)((P->q << 2) >> 32)) {
+        asm volatile("" : "+v"(vq4_0), "+v"(vq4_1));  // as uniform values they would live in SGPRs
+    }
+    static constexpr bool kLastTables = true;
+    static constexpr bool kPacked = false;
+    static constexpr bool kWide = false;
+    static constexpr bool kMont = true;
+    __device__ __forceinline__ Tw fwd_tw(u32 i) const {
+        const u64x2 v = fwd[i];
+        return Tw{v.x, v.y};
+    }
+    __device__ __forceinline__ Tw inv_tw(u32 i) const {
+        const u64x2 v = inv[i];
+        return Tw{v.x, v.y};
+    }
+    __device__ __forceinline__ Tw fwd_tw_last(u32 off) const {
+        const u64x2 v = fwd_last[off];
+        return Tw{v.x, v.y};
+    }
+    __device__ __forceinline__ Tw inv_tw_last(u32 off) const {
+        const u64x2 v = inv_last[off];
+        return Tw{v.x, v.y};
+    }
+    __device__ __forceinline__ Tw tw_inv_n() const { return inv_n; }
+    __device__ __forceinline__ Tw tw_inv_n_w() const { return inv_n_w; }
+#if defined(__HIPCC__)
+    __device__ __forceinline__ u64 mul_lazy(u64 y, Tw t) const { return mont_mul1<false>(*this, y, t); }  // [0, 3q); twiddle operands in VGPRs: also right when the prime is a per-lane value
+#endif
+    __device__ __forceinline__ u64 mul_any(u64 a, u64 b) const { return mul_mod_barrett(a, b, q, bar_lo, bar_hi); }
+    __device__ __forceinline__ u64 reduce_x(u64 x) const { return csub(x, q4); }                     // [0,8q) -> [0,4q)
+    __device__ __forceinline__ u64 reduce_2q(u64 x) const { return csub(x, q); }
+    __device__ __forceinline__ u64 canon3(u64 x) const { return csub(csub(x, two_q), q); }            // [0,4q) -> [0,q)
+    __device__ __forceinline__ u64 canon(u64 x) const { return canon3(csub(x, q4)); }                 // [0,8q) -> [0,q)
+    __device__ __forceinline__ u64 reduce_4q(u64 x) const { return canon(x); }
 };
 
 // B32Arith — the u32 tables (U32NttTable, q < 2^30): a 64-bit word carries the two adjacent
@@ -315,6 +380,7 @@ struct B32Arith {
     Tw inv_n, inv_n_w;
     static constexpr bool kPacked = true;
     static constexpr bool kWide = false;
+    static constexpr bool kMont = false;
     static constexpr bool kLastTables = false;
 
     __device__ __forceinline__ explicit B32Arith(const NttPrime *__restrict__ P)
@@ -410,6 +476,8 @@ __device__ __forceinline__ void fwd_bfly(const A &ar, u64 &x, u64 &y, typename A
         ar.fwd_bfly(x, y, w);
     } else if constexpr (A::kWide) {
         pm_fwd_bfly1<FOLD, UNI>(ar, x, y, w);
+    } else if constexpr (A::kMont) {
+        mont_fwd_bfly1<UNI>(ar, x, y, w);  // (reduces x at every stage: below 8q in, below 7q out)
     } else {
         const u64 tx = ar.reduce_x(x);
         const u64 t = ar.mul_lazy(y, w);
@@ -426,11 +494,8 @@ __device__ __forceinline__ void inv_bfly(const A &ar, u64 &x, u64 &y, typename A
         ar.inv_bfly(x, y, w);
     } else if constexpr (A::kWide) {
         pm_inv_bfly1<UNI>(ar, x, y, w);
-        return;
-        const u64 tx = x + y;
-        const u64 ty = sub_u64(x + ar.q3, y);
-        x = ar.reduce_x(tx);
-        y = ar.mul_lazy(ty, w);
+    } else if constexpr (A::kMont) {
+        mont_inv_bfly1<UNI>(ar, x, y, w);  // inputs below 4q: x' < 4q, y' < 3q
     } else {
         const u64 tx = x + y;
         const u64 ty = x + ar.two_q - y;
@@ -452,6 +517,14 @@ __device__ __forceinline__ void inv_final_bfly(const A &ar, u64 &x, u64 &y, bool
         // lazy results must honour the reference's [0,2q) contract: one fold (< U + 2^31 < 2q)
         x = lazy ? ar.reduce_x(rx) : ar.canon(rx);
         y = lazy ? ar.reduce_x(ry) : ar.canon(ry);
+    } else if constexpr (A::kMont) {
+        const u64 tx = x + y;  // inputs below 4q; the product takes any 64-bit value
+        const u64 ty = sub_u64(x + ar.q4, y);
+        const u64 rx = ar.mul_lazy(tx, ar.tw_inv_n());    // [0, 3q)
+        const u64 ry = ar.mul_lazy(ty, ar.tw_inv_n_w());
+        // lazy: the reference's [0,2q) contract (one conditional subtraction of 2q); else canonical
+        x = lazy ? csub(rx, ar.two_q) : ar.canon3(rx);
+        y = lazy ? csub(ry, ar.two_q) : ar.canon3(ry);
     } else {
         const u64 tx = ar.reduce_x(x + y);
         const u64 ty = x + ar.two_q - y;
@@ -470,7 +543,7 @@ __device__ __forceinline__ void inv_final_bfly(const A &ar, u64 &x, u64 &y, bool
 // (scalar/transform.rs:104-116)
 template <class A>
 __device__ __forceinline__ u64 fwd_finish(const A &ar, u64 x, bool lazy) {
-    if constexpr (A::kWide) {
+    if constexpr (A::kWide || A::kMont) {  // Mont: below 7q -> [0,4q) or [0,q)
         return lazy ? ar.reduce_x(x) : ar.canon(x);
     } else {
         return lazy ? x : ar.reduce_4q(x);
@@ -603,7 +676,7 @@ __device__ __forceinline__ void fwd_regpass(const A &ar, u64 (&x)[1 << LOGE], u3
             else w[u] = ar.fwd_tw(base + u);
         };
         const int ntw = E >> (j + 1);  // twiddles of this stage
-        if constexpr (A::kWide) {
+        if constexpr (A::kWide || A::kMont) {
             // two butterflies per asm block (independent instruction streams interleaved): butterfly b of the stage
             // has u = b >> j, v = b & (2^j - 1).  Per-lane twiddles (four registers each) are loaded at most four at a
             // time: the eight of the last stage of a 16-coefficient thread at once cost 32 registers at the tightest
@@ -617,7 +690,8 @@ __device__ __forceinline__ void fwd_regpass(const A &ar, u64 (&x)[1 << LOGE], u3
                 for (int b = u0 << j; b < ((u0 + group) << j); b += 2) {
                     const int ua = b >> j, va = b & ((1 << j) - 1), ub = (b + 1) >> j, vb = (b + 1) & ((1 << j) - 1);
                     const int a0 = (ua << (j + 1)) | va, a1 = a0 | (1 << j), b0 = (ub << (j + 1)) | vb, b1 = b0 | (1 << j);
-                    if ((POS + j) & 1) pm_fwd_bfly2<true, kUni>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
+                    if constexpr (A::kMont) mont_fwd_bfly2<kUni>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
+                    else if ((POS + j) & 1) pm_fwd_bfly2<true, kUni>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
                     else pm_fwd_bfly2<false, kUni>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
                 }
             }
@@ -659,12 +733,13 @@ __device__ __forceinline__ void inv_regpass(const A &ar, u64 (&x)[1 << LOGE], u3
                 if constexpr (POS == 0 && A::kLastTables) w[u] = ar.inv_tw_last(last_table_off<LOGE>(n, e_abs, j, u));  // lane-ordered
                 else w[u] = ar.inv_tw(base + u);
             }
-            if constexpr (A::kWide) {  // two butterflies per asm block, as in fwd_regpass
+            if constexpr (A::kWide || A::kMont) {  // two butterflies per asm block, as in fwd_regpass
 #pragma unroll
                 for (int b = 0; b < E / 2; b += 2) {
                     const int ua = b >> j, va = b & ((1 << j) - 1), ub = (b + 1) >> j, vb = (b + 1) & ((1 << j) - 1);
                     const int a0 = (ua << (j + 1)) | va, a1 = a0 | (1 << j), b0 = (ub << (j + 1)) | vb, b1 = b0 | (1 << j);
-                    pm_inv_bfly2<kUni>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
+                    if constexpr (A::kMont) mont_inv_bfly2<kUni>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
+                    else pm_inv_bfly2<kUni>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
                 }
                 continue;
             }
@@ -767,6 +842,9 @@ __device__ __forceinline__ void block_forward_core(const A &ar, u64 (&x)[1 << LO
 #pragma unroll
             for (int k = 0; k < E; ++k) x[k] = fwd_finish(ar, x[k], lazy);
         }
+    } else if constexpr (A::kMont) {  // below 7q -> [0,4q) (lazy contract) or [0,q)
+#pragma unroll
+        for (int k = 0; k < E; ++k) x[k] = fwd_finish(ar, x[k], lazy);
     } else if (!lazy) {  // [0,4q) -> [0,q): scalar/transform.rs:104-116
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = ar.reduce_4q(x[k]);

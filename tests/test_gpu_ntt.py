@@ -854,3 +854,82 @@ def test_dcrt_small_rings_with_per_lane_primes(pf, orc, log_n, lazy):
         assert np.array_equal(to_host(fwd), exp)
         d.inverse_transform_dev(fwd)
         assert np.array_equal(to_host(fwd), a)
+
+
+# generic NTT-friendly primes (= 1 mod 2^18, NOT of pseudo-Mersenne shape), 61 / 61 / 59 / 45 / 33 bits: the domain of the
+# Montgomery-form transforms (MontArith, q < 2^61)
+GENERIC = [1635294906373636097, 1220953465133989889, 387168985270714369, 27672964759553, 7717519361]
+
+
+@pytest.mark.parametrize("log_n,moduli,batch", [
+    (4, GENERIC[:3], 5), (5, GENERIC[1:4], 8), (7, GENERIC[:1], 3), (9, GENERIC[2:5], 4), (10, GENERIC[:2], 3),
+    (12, GENERIC[3:], 2), (13, GENERIC[:2], 2), (14, GENERIC[1:2], 2), (15, GENERIC[:2], 2), (16, GENERIC[:3], 2),
+    (17, GENERIC[4:], 1),
+])
+def test_generic_primes_montgomery_transforms(pf, orc, log_n, moduli, batch, monkeypatch):
+    """Tables whose primes are below 2^61 but not pseudo-Mersenne run their transforms in Montgomery form (MontArith: 7
+    multiplies per twiddle product instead of Shoup's 10): canonical outputs equal the oracle's and the Shoup path's
+    (PFHE_DISABLE_MONT), lazy outputs honour [0,4q) / [0,2q) and agree mod q, for every plan shape; the fused
+    NTT -> product -> INTT too."""
+    rng = np.random.default_rng(900 + log_n)
+    n, L = 1 << log_n, len(moduli)
+    d, o = pf.U64DcrtTable(log_n, moduli), orc.U64DcrtTable(log_n, moduli)
+    monkeypatch.setenv("PFHE_DISABLE_MONT", "1")
+    d_shoup = pf.U64DcrtTable(log_n, moduli)
+    monkeypatch.delenv("PFHE_DISABLE_MONT")
+    a = rand_rns(rng, moduli, n, batch)
+    a[:L * n:n] = [q - 1 for q in moduli]  # extreme residues in the first polynomial
+    exp = a.copy(); o.transform_slice(exp)
+    x, xs = to_dev(a), to_dev(a)
+    d.transform_dev(x); d_shoup.transform_dev(xs)
+    assert np.array_equal(to_host(x), exp) and np.array_equal(to_host(xs), exp)
+    d.inverse_transform_dev(x)
+    assert np.array_equal(to_host(x), a)
+    qs = np.tile(np.repeat(np.array(moduli, np.uint64), n), batch)
+    lz = to_dev((a + qs * rng.integers(0, 4, a.size).astype(np.uint64)))  # lazy inputs in [0,4q)
+    d.transform_dev(lz, lazy=True)
+    got = to_host(lz)
+    assert np.all(got < 4 * qs) and np.array_equal(got % qs, exp)
+    li = to_dev(exp)
+    d.inverse_transform_dev(li, lazy=True)
+    gi = to_host(li)
+    assert np.all(gi < 2 * qs) and np.array_equal(gi % qs, a)
+    # NTT -> product -> INTT (shared multiplicand)
+    bh = rand_rns(rng, moduli, n, 1)
+    pe = exp.copy()
+    for i in range(batch):
+        o.mul_assign(pe[i * L * n:(i + 1) * L * n], bh)
+    o.inverse_transform_slice(pe)
+    pa = to_dev(a)
+    d.mul_dcrt_polynomial_dev(pa, to_dev(bh))
+    assert np.array_equal(to_host(pa), pe)
+
+
+def test_generic_primes_large_batch_pipelined(pf, orc):
+    """The pipelined forms (tiles + 1 launches) with Montgomery-form butterflies: 540 MiB of 61-bit generic primes, forward,
+    inverse and the three-pass product, against the Shoup path on the whole batch and the oracle on three elements."""
+    import os
+    import torch
+    log_n, batch = 16, 360
+    mods = GENERIC[:3]
+    n, L = 1 << log_n, 3
+    W = L * n
+    d, o = pf.U64DcrtTable(log_n, mods), orc.U64DcrtTable(log_n, mods)
+    os.environ["PFHE_DISABLE_MONT"] = "1"
+    try:
+        ds = pf.U64DcrtTable(log_n, mods)
+    finally:
+        del os.environ["PFHE_DISABLE_MONT"]
+    a = _fill(pf, batch * W, mods, n, 21)
+    bh = _fill(pf, W, mods, n, 22)
+    f1, f2 = a.clone(), a.clone()
+    d.transform_dev(f1); ds.transform_dev(f2)
+    assert torch.equal(f1, f2)
+    for e in (0, 177, 359):
+        x = to_host(a[e * W:(e + 1) * W]).copy(); o.transform_slice(x)
+        assert np.array_equal(to_host(f1[e * W:(e + 1) * W]), x)
+    d.inverse_transform_dev(f1)
+    assert torch.equal(f1, a)
+    p1, p2 = a.clone(), a.clone()
+    d.mul_dcrt_polynomial_dev(p1, bh); ds.mul_dcrt_polynomial_dev(p2, bh)
+    assert torch.equal(p1, p2)

@@ -17,6 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 ALLOWED = {
     "ntt_strided_kernel<B32Arith, 4, 1": 12,      # one-column strided pass of the u32 tables (tuning switch PFHE_STRIDED_VEC1)
     "ntt_pipe_mid_kernel<PmArith": 12,            # three roles in 128 registers
+    "ntt_pipe_mid_kernel<MontArith": 20,
     "extprod_small_kernel<PmArith": 12,           # small rings, two waves per SIMD by design
     "gadget_decompose_strided_kernel": 528,       # fallback for digits wider than 32 bits: indexed local arrays
 }
