@@ -24,7 +24,6 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
-#include <mutex>
 #include <vector>
 
 #include "pfhe_common.hpp"
@@ -124,8 +123,7 @@ __device__ __forceinline__ void strided_pass_body(u64 *__restrict__ data, const 
 // Register budget: left to the compiler (134-136 registers for the two-column form, three waves per SIMD).  Capping
 // it at 128 so that a wave fits beside three block-pass waves costs 4-16 spilled registers, i.e. scratch traffic on an
 // HBM-bound kernel (6.34 / 7.5 GiB moved per 6 GiB launch, forward / inverse): 2.17 -> 2.22 ms and 2.18 -> 2.31 ms, for
-// no better overlap.  VEC == 1 is the LIGHT form (at most 96 registers) that PFHE_LIGHT_STRIDED selects for the strided
-// pass running beside a block pass in the two-stream transform; measured: no gain (5.41 vs 5.37 ms per step).
+// no better overlap.  VEC == 1 (PFHE_STRIDED_VEC1) is the one-column form, at most 96 registers.
 constexpr int kStridedMinWaves = 1;
 // NT: non-temporal stores (launch_strided picks it for batches of at least kNtMinBytes)
 template <class A, int K, int VEC, bool INV, bool FINAL, bool NT = false>
@@ -806,11 +804,8 @@ static int env_int(const char *name, int lo, int hi) {
 
 NttTuning NttTuning::from_env() {
     NttTuning t;
-    t.overlap = std::getenv("PFHE_DISABLE_OVERLAP") == nullptr;
-    t.overlap_inverse = std::getenv("PFHE_OVERLAP_INVERSE") != nullptr;
-    t.overlap_tiles = env_int("PFHE_OVERLAP_TILES", 2, 4096);
+    t.pipe_tiles = env_int("PFHE_PIPE_TILES", 2, 4096);
     t.strided_vec1 = std::getenv("PFHE_STRIDED_VEC1") != nullptr;
-    t.light_strided = std::getenv("PFHE_LIGHT_STRIDED") != nullptr;
     t.max_single_pass_log = env_int("PFHE_MAX_SINGLE_PASS_LOG", 9, (int)kMaxSinglePassLog);
     t.block_log = env_int("PFHE_BLOCK_LOG", 8, 12);
     t.pipelined = std::getenv("PFHE_DISABLE_PIPELINED") == nullptr;
@@ -886,113 +881,19 @@ int ntt_pass_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data,
                : run_pass<ShoupArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys, v1, tune.persist);
 }
 
-// ------------------------------------------------------------------------------------------
-// Two-stream overlap for two-pass transforms of large batches.  The strided pass is HBM-bound
-// (its VALU is half idle) and the block pass is VALU-bound (its memory pipe is mostly idle):
-// the batch is cut into tiles and the strided pass of tile k+1 runs on a second stream while the
-// block pass of tile k runs on the first, so the two kinds of workgroups share the CUs.
-// Measured on MI355X at N = 2^16, 12 288 polynomials: 6.34 ms -> 5.76 ms with 8 tiles (first measurement; today
-// 5.93 ms as two full-size launches, 5.60 ms with 12 tiles).
-// ------------------------------------------------------------------------------------------
-namespace {
-
-constexpr int kOverlapTiles = 12;  // 8: 5.67 ms, 12: 5.60 ms, 16: 5.61 ms per 12 288 NTTs of 2^16
-constexpr u64 kOverlapMinBytes = 512ull << 20;  // below this the extra launches do not pay
 // pipelined form: from 256 MiB of data (2^16-point transforms: 512 limb-polynomials), tiles of 256 MiB = the Infinity
 // Cache, whose share of the intermediate (plain stores, kPipeIntermediateNt) the next launch then reads on-die.  Measured,
 // forward / inverse ms per 6 GiB: 24 tiles 4.60-4.63 / 4.61-4.63, 20 tiles 4.83 / 4.80, 32 tiles 4.68 / 4.68, against
 // 4.72 / 4.64 for 8 tiles with a non-temporal intermediate; 3 GiB: 12 tiles 2.34 ms (8: 2.46); 1.5 GiB: 6 tiles 1.22 ms
 // (12: 1.26); 384 MiB 0.395 -> 0.37 ms against the two plain launches; 96 MiB 0.087 -> 0.096 ms, so smaller batches
 // keep those.
+// (Until round 3 other two-pass rings — N = 2^15, 2^17 — ran their passes tiled on two internal streams; with today's
+// kernels that form measures slower than two full-size launches, 5.08 vs 4.93 ms at 2^15 and 5.13 vs 5.11 ms at 2^17 per
+// 6 GiB, and it is gone: every transform runs on the caller's stream only.)
+namespace {
 constexpr u64 kPipelinedMinBytes = 256ull << 20;
 constexpr u64 kPipelinedTileBytes = 256ull << 20;
 constexpr int kPipelinedMaxTiles = 64;
-
-struct OverlapCtx {
-    hipStream_t a = nullptr, b = nullptr;
-    hipEvent_t fork = nullptr, join_a = nullptr, join_b = nullptr, done = nullptr;
-    std::vector<hipEvent_t> tile;
-    bool done_recorded = false;  // `done` marks the end of the last user's work on streams a and b
-    ~OverlapCtx() {
-        for (hipEvent_t e : tile)
-            if (e) (void)hipEventDestroy(e);
-        for (hipEvent_t e : {fork, join_a, join_b, done})
-            if (e) (void)hipEventDestroy(e);
-        if (a) (void)hipStreamDestroy(a);
-        if (b) (void)hipStreamDestroy(b);
-    }
-};
-
-std::mutex g_overlap_mutex;
-std::vector<OverlapCtx *> g_overlap_free[64];
-
-// PFHE_TEST_FAIL_OVERLAP_CTX (read once): fail the creation after N successful HIP objects, to exercise the
-// clean-up path (tests/test_gpu_ntt.py); never set in production
-int overlap_fail_after() {
-    static const int v = [] {
-        const char *e = std::getenv("PFHE_TEST_FAIL_OVERLAP_CTX");
-        return e ? std::atoi(e) : -1;
-    }();
-    return v;
-}
-
-OverlapCtx *acquire_overlap_ctx(int dev, int tiles) {
-    OverlapCtx *c = nullptr;
-    {
-        std::lock_guard<std::mutex> lock(g_overlap_mutex);
-        // A context returns to the free list while its streams may still be busy.  Prefer one whose last user has
-        // finished (another caller stream would otherwise queue silently behind that work); with several busy ones
-        // around, create a new context rather than wait, up to a small pool.
-        auto &fl = g_overlap_free[dev];
-        for (size_t i = fl.size(); i-- > 0;) {
-            if (!fl[i]->done_recorded || hipEventQuery(fl[i]->done) == hipSuccess) {
-                c = fl[i];
-                fl.erase(fl.begin() + (long)i);
-                break;
-            }
-        }
-        (void)hipGetLastError();  // hipEventQuery reports "not ready" as an error code
-        if (!c && fl.size() >= 8) {
-            c = fl.back();
-            fl.pop_back();
-        }
-    }
-    int made = 0;
-    const int fail_after = overlap_fail_after();
-    const auto ok_stream = [&](hipStream_t *st) {
-        if (fail_after >= 0 && made >= fail_after) return false;
-        ++made;
-        return hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess;
-    };
-    const auto ok_event = [&](hipEvent_t *ev) {
-        if (fail_after >= 0 && made >= fail_after) return false;
-        ++made;
-        return hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
-    };
-    bool ok = true;
-    if (!c) {
-        c = new OverlapCtx();
-        ok = ok_stream(&c->a) && ok_stream(&c->b) && ok_event(&c->fork) && ok_event(&c->join_a) && ok_event(&c->join_b) &&
-             ok_event(&c->done);
-    }
-    while (ok && (int)c->tile.size() < tiles) {
-        hipEvent_t ev = nullptr;
-        ok = ok_event(&ev);
-        if (ok) c->tile.push_back(ev);
-    }
-    if (!ok) {
-        (void)hipGetLastError();
-        delete c;  // the destructor releases whatever was created; the caller falls back to one stream
-        return nullptr;
-    }
-    return c;
-}
-
-void release_overlap_ctx(int dev, OverlapCtx *c) {
-    std::lock_guard<std::mutex> lock(g_overlap_mutex);
-    g_overlap_free[dev].push_back(c);
-}
-
 }  // namespace
 
 // the pipelined form of the two-pass transform (ntt_pipe_{fwd,inv}_kernel): tiles + 1 launches on the caller's stream
@@ -1078,7 +979,7 @@ static int pipelined_tiles(u32 L, u32 log_n, int pm, u64 npolys, bool inverse, b
           (!has_mul || inverse) && npolys % L == 0 &&
           bytes >= (tune.pipelined_min_mb ? (u64)tune.pipelined_min_mb << 20 : kPipelinedMinBytes)))
         return 0;
-    int pt = tune.overlap_tiles ? tune.overlap_tiles
+    int pt = tune.pipe_tiles ? tune.pipe_tiles
                                 : (int)std::min<u64>((bytes + kPipelinedTileBytes / 2) / kPipelinedTileBytes, (u64)kPipelinedMaxTiles);
     if (pt < 2) pt = 2;
     if (pt > kPipelinedMaxTiles) pt = kPipelinedMaxTiles;  // what transform_pipelined runs (its launch count is reported)
@@ -1093,19 +994,13 @@ int ntt_transform_form(u32 L, u32 log_n, int arith, u64 npolys, bool inverse, co
         std::snprintf(buf, cap, inverse ? "ntt_pipe_inv_kernel" : "ntt_pipe_fwd_kernel");
         return pt + 1;
     }
-    const int passes = ntt_num_passes(log_n, arith, tune);
-    int tiles = tune.overlap_tiles ? tune.overlap_tiles : kOverlapTiles;
-    if ((u64)tiles * L > npolys) tiles = (int)(npolys / L);
-    const bool two_stream = arith != kArithB32 && passes == 2 && (!inverse || tune.overlap_inverse) &&
-                            (npolys << log_n) * sizeof(u64) >= kOverlapMinBytes && tiles >= 2 && tune.overlap;
-    std::snprintf(buf, cap, two_stream ? "two-stream tiled passes" : "plain passes");
-    return two_stream ? passes * tiles : passes;
+    std::snprintf(buf, cap, "plain passes");
+    return ntt_num_passes(log_n, arith, tune);
 }
 
 static int transform(const NttPrime *primes, u32 L, u32 log_n, int pm, u64 *data, u64 npolys, bool inverse,
                      bool lazy, hipStream_t s, const NttTuning &tune, const u64 *mul = nullptr, u64 mul_polys = 0) {
     const int passes = ntt_num_passes(log_n, pm, tune);
-    const u64 bytes = (npolys << log_n) * sizeof(u64);
     {
         const int pt = pipelined_tiles(L, log_n, pm, npolys, inverse, mul != nullptr, tune);
         if (pt >= 1 && pm == kArithMont)
@@ -1116,58 +1011,10 @@ static int transform(const NttPrime *primes, u32 L, u32 log_n, int pm, u64 *data
                        : transform_pipelined<ShoupArith, 12>(primes, L, data, npolys, inverse, lazy, s, pt, tune.pipe_ramp, mul,
                                                              mul_polys);
     }
-    int dev = 0;
-    // (the u32 tables do not gain from the overlap: measured 3.40 ms vs 3.15 ms without, N = 2^16)
-    // (the inverse direction, block pass first, measures 2 % slower tiled than as two full-size launches: 5.98 vs
-    // 5.85 ms; PFHE_OVERLAP_INVERSE=1 at table creation tiles it anyway)
-    int tiles = tune.overlap_tiles ? tune.overlap_tiles : kOverlapTiles;
-    if ((u64)tiles * L > npolys) tiles = (int)(npolys / L);
-    const bool overlap = pm != kArithB32 && passes == 2 && (!inverse || tune.overlap_inverse) && bytes >= kOverlapMinBytes &&
-                         tiles >= 2 && tune.overlap && !stream_is_capturing(s) && hipGetDevice(&dev) == hipSuccess &&
-                         dev >= 0 && dev < 64;
-    OverlapCtx *c = overlap ? acquire_overlap_ctx(dev, tiles) : nullptr;
-    if (!c) {
-        for (int i = 0; i < passes; ++i)
-            PFHE_TRY(ntt_pass_dev(primes, L, log_n, pm, data, npolys, inverse, i, lazy, s, i == 0 ? mul : nullptr,
-                                  mul_polys, tune));
-        return PFHE_OK;
-    }
-    // tiles are whole multiples of L polynomials so that the limb of a polynomial (index % L) is
-    // unchanged inside a tile
-    const u64 units = npolys / L;
-    int rc = PFHE_OK;
-    NttTuning light = tune;  // the strided pass that runs beside a block pass takes its 64-register form
-    light.strided_vec1 = tune.light_strided;
-    hipError_t e = hipEventRecord(c->fork, s);
-    if (e == hipSuccess) e = hipStreamWaitEvent(c->a, c->fork, 0);
-    if (e == hipSuccess) e = hipStreamWaitEvent(c->b, c->fork, 0);
-    for (int k = 0; k < tiles && rc == PFHE_OK && e == hipSuccess; ++k) {
-        const u64 u0 = units * k / tiles, u1 = units * (k + 1) / tiles;
-        if (u1 == u0) continue;
-        u64 *ptr = data + ((u0 * L) << log_n);
-        const u64 np = (u1 - u0) * L;
-        // a per-element multiplicand is tiled like the data; a shared one (one unit of L) is not
-        const u64 *mptr = mul == nullptr ? nullptr : (mul_polys == npolys ? mul + ((u0 * L) << log_n) : mul);
-        rc = ntt_pass_dev(primes, L, log_n, pm, ptr, np, inverse, 0, lazy, c->a, mptr,
-                          mul_polys == npolys ? np : mul_polys, inverse ? tune : light);
-        if (rc != PFHE_OK) break;
-        e = hipEventRecord(c->tile[k], c->a);
-        if (e == hipSuccess) e = hipStreamWaitEvent(c->b, c->tile[k], 0);
-        if (e != hipSuccess) break;
-        rc = ntt_pass_dev(primes, L, log_n, pm, ptr, np, inverse, 1, lazy, c->b, nullptr, 0, inverse ? light : tune);
-    }
-    // join: everything later on the caller's stream waits for both internal streams
-    if (e == hipSuccess) e = hipEventRecord(c->join_a, c->a);
-    if (e == hipSuccess) e = hipEventRecord(c->join_b, c->b);
-    if (e == hipSuccess) e = hipStreamWaitEvent(s, c->join_a, 0);
-    if (e == hipSuccess) e = hipStreamWaitEvent(s, c->join_b, 0);
-    if (e == hipSuccess) {
-        e = hipEventRecord(c->done, s);
-        c->done_recorded = e == hipSuccess;
-    }
-    release_overlap_ctx(dev, c);
-    if (e != hipSuccess) return hip_fail(e, "two-stream transform", __FILE__, __LINE__);
-    return rc;
+    // one launch per pass on the caller's stream
+    for (int i = 0; i < passes; ++i)
+        PFHE_TRY(ntt_pass_dev(primes, L, log_n, pm, data, npolys, inverse, i, lazy, s, i == 0 ? mul : nullptr, mul_polys, tune));
+    return PFHE_OK;
 }
 
 int ntt_forward_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, bool lazy,

@@ -24,11 +24,8 @@ struct NttPlan {
 // created (NttTuning::from_env), and travel inside the handle: nothing on the launch path calls getenv, and two
 // tables created under different settings keep their own.
 struct NttTuning {
-    bool overlap = true;           // PFHE_DISABLE_OVERLAP clears it: two-pass transforms of big batches run tiled on two streams
-    bool overlap_inverse = false;  // PFHE_OVERLAP_INVERSE: tile the inverse direction too
-    int overlap_tiles = 0;         // PFHE_OVERLAP_TILES (0: built-in default)
+    int pipe_tiles = 0;            // PFHE_PIPE_TILES: tiles of the pipelined form (0: built-in default, batch / 256 MiB)
     bool strided_vec1 = false;     // PFHE_STRIDED_VEC1: one column per thread in the 4-stage strided pass (64 registers)
-    bool light_strided = false;    // PFHE_LIGHT_STRIDED: the tiled transform runs the one-column strided pass beside the block pass
     int max_single_pass_log = 0;   // PFHE_MAX_SINGLE_PASS_LOG (0: built-in default)
     int block_log = 0;             // PFHE_BLOCK_LOG: block size under strided passes (0: built-in default)
     bool pipelined = true;         // PFHE_DISABLE_PIPELINED clears it: N = 2^16 runs as tiles + 1 launches of ntt_pipe_kernel on the caller's stream

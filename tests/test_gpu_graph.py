@@ -53,7 +53,7 @@ def test_external_product_and_ntt_in_a_graph(pf, chunk, batch):
 @pytest.mark.parametrize("pipelined", [True, False])
 def test_large_batch_transform_in_a_graph(pf, pipelined, monkeypatch):
     """>= 256 MiB: the pipelined form launches its tiles on the capturing stream itself (captured as is); without it
-    the two-stream form must notice the capture and fall back to two plain launches."""
+    the transform is two plain launches on that stream."""
     import ctypes as C
     import torch
     from primus_fhe_amd._lib import check, u64p

@@ -256,9 +256,9 @@ def test_pseudo_mersenne_path_equals_generic_path(pf, orc, q, log_n, monkeypatch
     assert np.array_equal(outs[0], outs[1])
 
 
-def test_two_stream_overlap_path_matches_oracle(pf, orc, monkeypatch):
-    """Batches >= 512 MiB of a two-pass transform are tiled over two internal HIP streams
-    (pfhe_ntt.hip `transform`); results must equal the single-stream path and the oracle, and work
+def test_large_batch_forms_match_oracle(pf, orc, monkeypatch):
+    """Batches >= 256 MiB of N = 2^16 run as tiles + 1 launches of the pipelined kernel on the caller's stream
+    (pfhe_ntt.hip `transform`); results must equal the two plain launches and the oracle, and work
     queued on the caller's stream afterwards must see the finished data."""
     import torch
     log_n, batch = 16, 352  # 352 * 3 * 512 KiB = 528 MiB
@@ -270,15 +270,12 @@ def test_two_stream_overlap_path_matches_oracle(pf, orc, monkeypatch):
     d.transform_dev(x)
     y = x.clone()  # ordered after the join on the same (current) stream
     got = to_host(y)
-    # three forms of the same transform (switches are read when a table is created): pipelined single-stream (the
-    # default at this size), two-stream tiled, two plain launches
+    # two forms of the same transform (switches are read when a table is created): pipelined (the default at this
+    # size) and one launch per pass
     monkeypatch.setenv("PFHE_DISABLE_PIPELINED", "1")
-    d2 = pf.U64DcrtTable(log_n, Q61)
-    monkeypatch.setenv("PFHE_DISABLE_OVERLAP", "1")
     d1 = pf.U64DcrtTable(log_n, Q61)
-    monkeypatch.delenv("PFHE_DISABLE_OVERLAP")
     monkeypatch.delenv("PFHE_DISABLE_PIPELINED")
-    for other in (d2, d1):
+    for other in (d1,):
         x1 = to_dev(a)
         other.transform_dev(x1)
         z = x1.clone()
@@ -426,9 +423,9 @@ def test_add_dcrt_glwe_mul_dcrt_polynomial_assign(pf, orc, log_n, moduli, k, bat
 
 @pytest.mark.parametrize("shared", [True, False])
 def test_fused_polymul_large_batch_tiled_path(pf, orc, shared):
-    """Batches >= 512 MiB run the two transform passes per tile on two streams; the fused product must
-    follow the tiling of a per-element multiplicand.  Compared with the unfused kernels on the whole
-    batch and with the oracle on three elements."""
+    """Batches >= 256 MiB run the pipelined forms (tiles + 2 launches of the three-pass product); the product must
+    follow the tiling of a per-element multiplicand.  Compared with the plain three-pass, four-pass and unfused forms on
+    the whole batch and with the oracle on three elements."""
     import os
     import torch
     log_n, batch = 16, 360  # 360 x 3 x 512 KiB = 540 MiB
@@ -447,14 +444,11 @@ def test_fused_polymul_large_batch_tiled_path(pf, orc, shared):
     a, bh = fill(batch * W, 11), fill(W if shared else batch * W, 12)
     fused = a.clone()
     d.mul_dcrt_polynomial_dev(fused, bh)
-    # d runs the pipelined form; the two-stream form does not tile the inverse direction by default: exercise its
-    # tiling too (switches are read at table creation)
-    os.environ["PFHE_OVERLAP_INVERSE"] = "1"
+    # d runs the pipelined forms; d_tiled one launch per pass (switches are read at table creation)
     os.environ["PFHE_DISABLE_PIPELINED"] = "1"
     try:
         d_tiled = pf.U64DcrtTable(log_n, Q61)
     finally:
-        del os.environ["PFHE_OVERLAP_INVERSE"]
         del os.environ["PFHE_DISABLE_PIPELINED"]
     tiled = a.clone()
     d_tiled.mul_dcrt_polynomial_dev(tiled, bh)
@@ -466,13 +460,11 @@ def test_fused_polymul_large_batch_tiled_path(pf, orc, shared):
     assert torch.equal(inv_plain, inv_tiled)
     os.environ["PFHE_DISABLE_FUSED_POLYMUL"] = "1"
     os.environ["PFHE_DISABLE_PIPELINED"] = "1"
-    os.environ["PFHE_DISABLE_OVERLAP"] = "1"
     try:
         d_plain = pf.U64DcrtTable(log_n, Q61)
     finally:
         del os.environ["PFHE_DISABLE_FUSED_POLYMUL"]
         del os.environ["PFHE_DISABLE_PIPELINED"]
-        del os.environ["PFHE_DISABLE_OVERLAP"]
     plain = a.clone()
     d_plain.mul_dcrt_polynomial_dev(plain, bh)
     assert torch.equal(fused, plain)
@@ -629,14 +621,13 @@ def test_pipelined_form_tile_arithmetic(pf, L, batch, tiles, ramp, monkeypatch):
     n = 1 << log_n
     moduli = Q61[:L]
     if tiles:
-        monkeypatch.setenv("PFHE_OVERLAP_TILES", str(tiles))
+        monkeypatch.setenv("PFHE_PIPE_TILES", str(tiles))
     if ramp:
         monkeypatch.setenv("PFHE_PIPE_RAMP", str(ramp))
     t = pf.U64DcrtTable(log_n, moduli)
     name, launches = t.transform_form(batch * L * n)
     assert name == "ntt_pipe_fwd_kernel" and launches >= 3
     monkeypatch.setenv("PFHE_DISABLE_PIPELINED", "1")
-    monkeypatch.setenv("PFHE_DISABLE_OVERLAP", "1")
     plain = pf.U64DcrtTable(log_n, moduli)
     assert plain.transform_form(batch * L * n) == ("plain passes", 2)
     x = _fill(pf, batch * L * n, moduli, n, 1234 + batch)
@@ -660,58 +651,11 @@ def test_transform_form_reports_the_launch_plan(pf, monkeypatch):
     assert pf.U64DcrtTable(12, [Q61[0]]).transform_form(1 << 12) == ("plain passes", 1)
     monkeypatch.setenv("PFHE_DISABLE_PIPELINED", "1")
     t2 = pf.U64DcrtTable(16, Q61)
-    assert t2.transform_form(4096 * L * n) == ("two-stream tiled passes", 24)
+    assert t2.transform_form(4096 * L * n) == ("plain passes", 2)
     assert t2.transform_form(4096 * L * n, inverse=True) == ("plain passes", 2)
     with pytest.raises(pf.PfheError) as e:
         t.transform_form(5)
     assert e.value.kind == "BadLength"
-
-
-@pytest.mark.gpu
-def test_overlap_context_creation_failure_is_clean():
-    """The two-stream transform falls back to one stream when its streams / events cannot be created, and the
-    partially built context is destroyed (PFHE_TEST_FAIL_OVERLAP_CTX=N fails the N+1-th HIP object; the switch is
-    read once per process, hence the subprocess).  Results must equal the single-stream path's."""
-    import subprocess
-    import sys
-    script = r"""
-import os, sys
-sys.path.insert(0, os.getcwd())
-import numpy as np, torch
-import primus_fhe_amd as pf
-Q61 = [2305843009211596801, 2305843009210023937, 2305843009208713217]
-log_n, batch = 16, 352
-t = pf.U64DcrtTable(log_n, Q61)
-x = torch.empty(batch * 3 << log_n, dtype=torch.int64, device="cuda")
-t.fill_uniform_dev(x, 5)
-ref = x.clone()
-os.environ["PFHE_DISABLE_OVERLAP"] = "1"   # (PFHE_DISABLE_PIPELINED is set for the whole process: two-stream form)
-t1 = pf.U64DcrtTable(log_n, Q61)
-t1.transform_dev(ref)
-def rounds(k):
-    for _ in range(k):
-        y = x.clone()
-        t.transform_dev(y)      # context creation fails every time: single-stream fallback
-        assert torch.equal(y, ref)
-        del y
-    torch.cuda.synchronize()
-    return torch.cuda.mem_get_info()[0]
-rounds(5)                       # torch's caching allocator settles (clone, comparison workspaces)
-free0 = rounds(5)
-free1 = rounds(40)
-assert os.environ.get("PFHE_TEST_LEAK_CHECK") == "0" or free0 - free1 < (16 << 20), (free0, free1)
-print("ok")
-"""
-    # under xdist other workers allocate device memory while the child measures it: keep the functional check
-    # (results equal the single-stream path's), drop the free-memory comparison
-    leak_check = "0" if os.environ.get("PYTEST_XDIST_WORKER") else "1"
-    for fail_after in (0, 3, 7):
-        env = dict(os.environ, PFHE_TEST_FAIL_OVERLAP_CTX=str(fail_after), PFHE_DISABLE_PIPELINED="1",
-                   PFHE_TEST_LEAK_CHECK=leak_check)
-        env.pop("PFHE_DISABLE_OVERLAP", None)
-        r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600,
-                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        assert r.returncode == 0 and "ok" in r.stdout, (fail_after, r.stdout[-500:], r.stderr[-2000:])
 
 
 def _fill(pf, words, moduli, n, seed):

@@ -29,9 +29,9 @@ Q61 = [2305843009211596801, 2305843009210023937, 2305843009208713217]
 batch = int(os.environ.get("PFHE_PROFILE_BATCH", "4096"))
 n, L = 1 << 16, 3
 t = p.U64DcrtTable(16, Q61)
-os.environ["PFHE_DISABLE_OVERLAP"] = os.environ["PFHE_DISABLE_PIPELINED"] = "1"  # (read when a table is created)
+os.environ["PFHE_DISABLE_PIPELINED"] = "1"  # (read when a table is created)
 t_plain = p.U64DcrtTable(16, Q61)
-del os.environ["PFHE_DISABLE_OVERLAP"], os.environ["PFHE_DISABLE_PIPELINED"]
+del os.environ["PFHE_DISABLE_PIPELINED"]
 words = batch * L * n
 x = torch.empty(words, dtype=torch.int64, device="cuda")
 mods = np.array(Q61, np.uint64)
