@@ -1055,10 +1055,16 @@ static int polymul_impl(const NttPrime *primes, u32 L, u32 log_n, int arith, u64
         constexpr size_t lds_bytes = (size_t)Cfg::LDS_WORDS * sizeof(u64);
         void (*kern)(u64 *, const NttPrime *, u32, u32, u64, const u64 *, u64) =
             large ? ntt_block_mid_kernel<A, LOGB, true> : ntt_block_mid_kernel<A, LOGB, false>;
-        if (lds_bytes > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)lds_bytes);
-            if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute", __FILE__, __LINE__);
+        if (lds_bytes > 64 * 1024) {  // once per device and instantiation (both NT forms)
+            static thread_local bool configured[64][2] = {};
+            int dev = 0;
+            PFHE_HIP(hipGetDevice(&dev));
+            if (dev < 0 || dev >= 64 || !configured[dev][large ? 1 : 0]) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute", __FILE__, __LINE__);
+                if (dev >= 0 && dev < 64) configured[dev][large ? 1 : 0] = true;
+            }
         }
         hipLaunchKernelGGL(kern, dim3((u32)total_blocks), dim3(Cfg::THREADS), lds_bytes, s, ptr, primes, L, log_n,
                            total_blocks, mptr, mp);

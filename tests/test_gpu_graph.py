@@ -160,3 +160,68 @@ def test_monomial_transforms_in_a_graph(pf):
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy().view(np.uint64), exp)
     assert np.array_equal(out32.cpu().numpy().view(np.uint32), exp32)
+
+
+def test_round3_kernels_first_called_inside_a_capture(pf):
+    """The persistent N = 2^14 kernel (sets its dynamic-LDS attribute and reads the CU count on first use), the three-pass
+    product's middle kernel and the external product's fused inverse tail, each called for the FIRST time inside a
+    capture (fresh primes, so no earlier test has configured these instantiations): capture must succeed and the replay must
+    equal the eager result."""
+    import torch
+    rng = np.random.default_rng(31)
+    s = torch.cuda.Stream()
+    # --- N = 2^14: 600 polynomials >= two per resident workgroup on a 256-CU part: ntt_persist_kernel, both directions
+    q14 = Q61[1]
+    t14 = pf.U64NttTable(14, q14)
+    x = to_dev(rng.integers(0, q14, 600 << 14, dtype=np.uint64))
+    orig = x.clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        t14.transform_dev(x, stream=s)
+        t14.inverse_transform_dev(x, stream=s)
+    x.copy_(orig + 0)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(x, orig)  # forward then inverse = identity
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=s):
+        t14.transform_dev(x, stream=s)
+    g2.replay()
+    torch.cuda.synchronize()
+    y = orig.clone()
+    t14.transform_dev(y)
+    assert torch.equal(x, y)
+    # --- N = 2^13 (one launch of the middle kernel) and N = 2^16 (strided, middle, strided) products
+    for log_n, batch in ((13, 5), (16, 3)):
+        n = 1 << log_n
+        d = pf.U64DcrtTable(log_n, Q61[:2])
+        a = to_dev(rand_rns(rng, Q61[:2], n, batch))
+        bh = to_dev(rand_rns(rng, Q61[:2], n, 1))
+        keep = a.clone()
+        gp = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gp, stream=s):
+            d.mul_dcrt_polynomial_dev(a, bh, stream=s)
+        a.copy_(keep)
+        gp.replay()
+        torch.cuda.synchronize()
+        ref = keep.clone()
+        d.mul_dcrt_polynomial_dev(ref, bh)
+        assert torch.equal(a, ref)
+    # --- external product at N = 2^16, coefficient form (fused inverse tail + one strided pass), batch 8
+    log_n, k, batch = 16, 1, 8
+    n = 1 << log_n
+    t, base = pf.U64DcrtTable(log_n, Q61), pf.RNSBase(Q61)
+    basis = pf.BigUintApproxSignedBasis(base, 30)
+    ctx = pf.DcrtGlevContext(t, base, basis, k)
+    dg = to_dev(rand_rns(rng, Q61, n, batch * (k + 1)))
+    dk = to_dev(rand_rns(rng, Q61, n, (k + 1) * basis.decompose_length() * (k + 1)))
+    out = torch.zeros_like(dg)
+    ge = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(ge, stream=s):
+        pf.mul_dcrt_ggsw_to_dev(dg, dk, out, ctx, into_coeff_form=True, stream=s)
+    out.zero_()
+    ge.replay()
+    torch.cuda.synchronize()
+    ref = torch.zeros_like(dg)
+    pf.mul_dcrt_ggsw_to_dev(dg, dk, ref, ctx, into_coeff_form=True)
+    assert torch.equal(out, ref)
