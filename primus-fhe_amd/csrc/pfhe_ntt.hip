@@ -550,6 +550,79 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_wave
                                                             log_n == LOGB, lds_raw);
 }
 
+// Persistent form of the middle kernel for N = 2^14 (one 1024-thread workgroup per CU, see ntt_persist_kernel): a resident
+// workgroup walks over polynomials and issues the next one's loads in front of the inverse half's second-to-last register
+// pass (wave-uniform twiddles from there on), so that only its first polynomial is waited for with nothing else to do.
+template <class A, int LOGB>
+__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_persist_mid_kernel(
+    u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L, u64 npolys, const u64 *__restrict__ mul, u64 mul_polys) {
+    using Cfg = BlockCfg<LOGB>;
+    static_assert(Cfg::BPW == 1 && LOGB - 4 >= 6, "one polynomial per workgroup, whole waves per register layout");
+    constexpr int NV = Cfg::E / 2, POS0 = LOGB - 4;
+    constexpr u32 n = 1u << LOGB;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    u64 p = blockIdx.x;
+    if (p >= npolys) return;
+    const u64 stride = gridDim.x;
+    u64 x[Cfg::E], xn[Cfg::E];
+    {
+        const u64 *__restrict__ g = data + p * n + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < Cfg::E; ++k) x[k] = __builtin_nontemporal_load(g + ((u32)k << POS0));
+    }
+    while (true) {
+        const u64 pn = p + stride;
+        const bool more = pn < npolys;
+        const u32 limb = (u32)(p % L);
+        const A ar(primes + limb);
+        const auto prefetch = [&]() {
+            if (more) {
+                const u64 *__restrict__ g = data + pn * n + opaque_tid();
+#pragma unroll
+                for (int k = 0; k < Cfg::E; ++k) xn[k] = __builtin_nontemporal_load(g + ((u32)k << POS0));
+            } else {  // a dead value: the old contents must not count as live
+#pragma unroll
+                for (int k = 0; k < Cfg::E; ++k) xn[k] = 0;
+            }
+        };
+        {
+            const u32 lt = opaque_tid();
+            // (leading barrier of the first exchange: the previous polynomial's last exchange may still be read)
+            block_forward_core<A, LOGB, true>(ar, x, lds, n, 0u, lt, /*lazy=*/true);
+            lds_put_layout<0>(x, lds, lt);
+        }
+        {
+            const u32 lt = opaque_tid();
+            u64x2 io[NV], mv[NV];
+            const u64 mpoly = mul_polys == (u64)L ? (u64)limb : p;
+            load_block_vectors<LOGB, 4, false>(mv, mul + mpoly * n, lt);
+            __syncthreads();
+            lds_get_vectors<LOGB>(io, lds, lt);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                io[j].x = ar.mul_any(io[j].x, mv[j].x);
+                io[j].y = ar.mul_any(io[j].y, mv[j].y);
+            }
+            lds_put_vectors<LOGB>(io, lds, lt);  // the slots this thread just read
+        }
+        __syncthreads();
+        {
+            const u32 lt = opaque_tid();
+            lds_get_layout<0>(x, lds, lt);
+            block_inverse_core<A, LOGB, false, 4, decltype(prefetch), kPersistInvHook>(ar, x, lds, n, 0u, lt, true, false, prefetch);
+        }
+        {
+            u64 *__restrict__ g = data + p * n + opaque_tid();
+#pragma unroll
+            for (int k = 0; k < Cfg::E; ++k) gstore<true>(g + ((u32)k << POS0), x[k]);
+        }
+        if (!more) break;
+#pragma unroll
+        for (int k = 0; k < Cfg::E; ++k) x[k] = xn[k];
+        p = pn;
+    }
+}
+
 // Pipelined form for N = 2^16 (4 strided stages, blocks of 2^12), large batches: launch k runs, in workgroup i, the
 // middle kernel on block i of tile k-1, the FORWARD strided pass on chunk i (256 columns x 16 rows) of tile k and the
 // INVERSE (final) strided pass on chunk i of tile k-2.  The forward chunk's loads are in flight during the block's
@@ -1071,6 +1144,28 @@ static int polymul_impl(const NttPrime *primes, u32 L, u32 log_n, int arith, u64
         PFHE_HIP(hipGetLastError());
         return PFHE_OK;
     };
+    if (plan.n_strided == 0 && plan.block_log == 14 && tune.persist) {
+        // N = 2^14: resident workgroups that prefetch their next polynomial (ntt_persist_mid_kernel)
+        const u64 resident = (u64)device_cu_count();
+        if (npolys >= 2 * resident) {
+            using Cfg = BlockCfg<14>;
+            constexpr size_t lds_bytes = (size_t)Cfg::LDS_WORDS * sizeof(u64);
+            void (*kern)(u64 *, const NttPrime *, u32, u64, const u64 *, u64) = ntt_persist_mid_kernel<A, 14>;
+            static thread_local bool configured[64] = {};
+            int dev = 0;
+            PFHE_HIP(hipGetDevice(&dev));
+            if (dev < 0 || dev >= 64 || !configured[dev]) {
+                PFHE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)lds_bytes));
+                if (dev >= 0 && dev < 64) configured[dev] = true;
+            }
+            const u64 rounds = (npolys + resident - 1) / resident;
+            const u64 grid = (npolys + rounds - 1) / rounds;
+            hipLaunchKernelGGL(kern, dim3((u32)grid), dim3(Cfg::THREADS), lds_bytes, s, data, primes, L, npolys, mul, mul_polys);
+            PFHE_HIP(hipGetLastError());
+            return PFHE_OK;
+        }
+    }
     if (plan.n_strided == 0) {  // single-pass rings: the middle kernel is the whole product
         switch (plan.block_log) {
 #define PFHE_CASE(B) \

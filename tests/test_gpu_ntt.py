@@ -877,3 +877,36 @@ def test_generic_primes_large_batch_pipelined(pf, orc):
     p1, p2 = a.clone(), a.clone()
     d.mul_dcrt_polynomial_dev(p1, bh); ds.mul_dcrt_polynomial_dev(p2, bh)
     assert torch.equal(p1, p2)
+
+
+@pytest.mark.parametrize("moduli,shared", [(Q61[:1], True), (Q61[:2], False), (GENERIC[:1], True)])
+def test_polymul_2p14_resident_workgroups(pf, orc, moduli, shared, monkeypatch):
+    """N = 2^14 batches of at least two polynomials per CU take ntt_persist_mid_kernel (resident workgroups that prefetch
+    their next polynomial): same words as one workgroup per polynomial (PFHE_DISABLE_PERSIST) on the whole batch, and the
+    oracle on the first, a middle and the last element; pseudo-Mersenne and Montgomery arithmetic, ragged shares (601)."""
+    import torch
+    log_n, units = 14, 601
+    n, L = 1 << log_n, len(moduli)
+    W = L * n
+    d, o = pf.U64DcrtTable(log_n, moduli), orc.U64DcrtTable(log_n, moduli)
+    monkeypatch.setenv("PFHE_DISABLE_PERSIST", "1")
+    d1 = pf.U64DcrtTable(log_n, moduli)
+    monkeypatch.delenv("PFHE_DISABLE_PERSIST")
+    a = _fill(pf, units * W, moduli, n, 141)
+    bh = _fill(pf, W if shared else units * W, moduli, n, 142)
+    x, y = a.clone(), a.clone()
+    d.mul_dcrt_polynomial_dev(x, bh)
+    d1.mul_dcrt_polynomial_dev(y, bh)
+    assert torch.equal(x, y)
+    for e in (0, 300, units - 1):
+        r = to_host(a[e * W:(e + 1) * W]).copy()
+        o.transform_slice(r)
+        o.mul_assign(r, to_host(bh[:W] if shared else bh[e * W:(e + 1) * W]).copy())
+        o.inverse_transform_slice(r)
+        assert np.array_equal(to_host(x[e * W:(e + 1) * W]), r), e
+    # the transforms alone, both directions, same comparison
+    f, f1 = a.clone(), a.clone()
+    d.transform_dev(f); d1.transform_dev(f1)
+    assert torch.equal(f, f1)
+    d.inverse_transform_dev(f)
+    assert torch.equal(f, a)

@@ -1,4 +1,4 @@
-"""NTT -> product -> INTT at the bench shape (N = 2^16, 3 primes, batch 4096), per tuning environment.
+"""NTT -> product -> INTT at the bench shape (N = 2^LOG_N [16], 3 primes, 6 GiB batch), per tuning environment.
 Usage: python tools/perf_polymul.py [ENV=VAL,ENV=VAL ...]   (one table per argument; switches are read at table creation)"""
 import os
 import sys
@@ -9,7 +9,8 @@ import torch
 import primus_fhe_amd as p
 
 Q61 = [2305843009211596801, 2305843009210023937, 2305843009208713217]
-log_n, L, batch = 16, 3, int(os.environ.get("BATCH", "4096"))
+log_n = int(os.environ.get("LOG_N", "16"))
+L, batch = 3, int(os.environ.get("BATCH", str(4096 << (16 - log_n))))
 n = 1 << log_n
 x = torch.empty(batch * L * n, dtype=torch.int64, device="cuda")
 b = torch.empty(L * n, dtype=torch.int64, device="cuda")
