@@ -12,6 +12,9 @@ if "roofline" in d:
         r = d["roofline_passes"]
         print(f"stand-alone: {r['kernel']}  {r['avg_launch_ms']:.3f} ms  {r['achieved']:.0f} GB/s  frac {r['frac']:.3f}")
     print("kernels_ms:", {k: round(v, 3) for k, v in d.get("kernels_ms", {}).items()})
+if "sustained" in d:
+    u = d["sustained"]
+    print(f"sustained: {u['value'] / 1e6:.3f} M NTT/s  {u['ms_per_step']:.3f} ms/step over {u['seconds']:.1f} s  frac {u['hbm_roofline_frac']:.3f}")
 for k in ("intt", "ntt_generic_prime", "polymul", "ntt_u32"):
     if k in d:
         print(f"{k}: {d[k]['value'] / 1e3:.1f} k/s  {d[k]['ms_per_batch']:.3f} ms  frac {d[k]['hbm_roofline_frac']:.3f}")
