@@ -340,6 +340,8 @@ const uint64_t *orc_u64_ntt_roots_precon64(const orc_u64_ntt *t) { return t->roo
 const uint64_t *orc_u64_ntt_inv_roots(const orc_u64_ntt *t) { return t->inv_roots; }
 const uint64_t *orc_u64_ntt_inv_roots_precon64(const orc_u64_ntt *t) { return t->inv_roots_precon64; }
 const uint64_t *orc_u64_ntt_roots_precon52(const orc_u64_ntt *t) { return t->roots_precon52; }
+const uint64_t *orc_u64_ntt_roots_precon32(const orc_u64_ntt *t) { return t->roots_precon32; }
+const uint64_t *orc_u64_ntt_inv_roots_precon32(const orc_u64_ntt *t) { return t->inv_roots_precon32; }
 const uint64_t *orc_u64_ntt_inv_roots_precon52(const orc_u64_ntt *t) { return t->inv_roots_precon52; }
 const uint64_t *orc_u64_ntt_ordinal_roots(const orc_u64_ntt *t) { return t->ordinal_roots; }
 

@@ -94,6 +94,8 @@ uint64_t orc_u64_ntt_inv_n(const orc_u64_ntt *t);
 uint64_t orc_u64_ntt_inv_n_w(const orc_u64_ntt *t);
 const uint64_t *orc_u64_ntt_roots(const orc_u64_ntt *t);
 const uint64_t *orc_u64_ntt_roots_precon64(const orc_u64_ntt *t);
+const uint64_t *orc_u64_ntt_roots_precon32(const orc_u64_ntt *t);     /* null unless q < 2^30 */
+const uint64_t *orc_u64_ntt_inv_roots_precon32(const orc_u64_ntt *t);
 const uint64_t *orc_u64_ntt_roots_precon52(const orc_u64_ntt *t);     /* null unless q < 2^50 */
 const uint64_t *orc_u64_ntt_inv_roots_precon52(const orc_u64_ntt *t); /* null unless q < 2^50 */
 const uint64_t *orc_u64_ntt_inv_roots(const orc_u64_ntt *t);
@@ -138,7 +140,8 @@ int orc_get_vector_backend(void);
 /* dispatch as the reference does (table.rs:166-302): IFMA (BIT_SHIFT = 52) when the CPU has it and q < 2^50, else DQ */
 int orc_u64_ntt_forward_avx512(const orc_u64_ntt *t, uint64_t *values, int lazy);
 int orc_u64_ntt_inverse_avx512(const orc_u64_ntt *t, uint64_t *values, int lazy);
-/* shift = 64 forces the DQ rung, 52 the IFMA rung (ORC_ERR_BAD_ARG when the CPU lacks it or q >= 2^50), 0 dispatches */
+/* shift = 64 / 32 force the DQ rungs (32: q < 2^30), 52 the IFMA rung (q < 2^50; ORC_ERR_BAD_ARG when the CPU lacks it or
+ * the modulus is too wide), 0 dispatches */
 int orc_avx512_ifma_available(void);
 int orc_u64_ntt_forward_avx512_shift(const orc_u64_ntt *t, uint64_t *values, int lazy, int shift);
 int orc_u64_ntt_inverse_avx512_shift(const orc_u64_ntt *t, uint64_t *values, int lazy, int shift);

@@ -36,40 +36,59 @@ int orc_avx512_ifma_available(void) {
 }
 
 /* BIT_SHIFT = 64 */
-#define S52 0
+#define SHIFTV 64
 #define FN(name) name##_dq
 #define TGT __attribute__((target("avx512f,avx512dq")))
 #define AVAILABLE orc_avx512_available
 #include "pfhe_oracle_avx512_impl.h"
-#undef S52
+#undef SHIFTV
+#undef FN
+#undef TGT
+#undef AVAILABLE
+
+/* BIT_SHIFT = 32 (q < 2^30) */
+#define SHIFTV 32
+#define FN(name) name##_dq32
+#define TGT __attribute__((target("avx512f,avx512dq")))
+#define AVAILABLE orc_avx512_available
+#include "pfhe_oracle_avx512_impl.h"
+#undef SHIFTV
 #undef FN
 #undef TGT
 #undef AVAILABLE
 
 /* BIT_SHIFT = 52 (IFMA) */
-#define S52 1
+#define SHIFTV 52
 #define FN(name) name##_ifma
 #define TGT __attribute__((target("avx512f,avx512dq,avx512ifma")))
 #define AVAILABLE orc_avx512_ifma_available
 #include "pfhe_oracle_avx512_impl.h"
-#undef S52
+#undef SHIFTV
 #undef FN
 #undef TGT
 #undef AVAILABLE
 
-/* the reference's ladder (table.rs:166-232 forward, :236-302 inverse): IFMA when the CPU has it and q < 2^50, else DQ
- * (the 32-bit rung for q < 2^30 is the scalar Barrett-32 path's domain in this restatement) */
-static int pick_ifma(const orc_u64_ntt *t, int shift) {
-    if (shift == 52) return 1;
-    if (shift == 64) return 0;
-    return orc_avx512_ifma_available() && orc_u64_ntt_modulus(t) < (1ull << 50) && orc_u64_ntt_roots_precon52(t) != 0;
+/* the reference's ladder (table.rs:166-232 forward, :236-302 inverse): IFMA (52) when the CPU has it and q < 2^50, else
+ * the DQ backend with 32-bit preconditioners for q < 2^30 and 64-bit ones otherwise */
+static int pick_shift(const orc_u64_ntt *t, int shift) {
+    if (shift == 52 || shift == 64 || shift == 32) return shift;
+    if (orc_avx512_ifma_available() && orc_u64_ntt_modulus(t) < (1ull << 50) && orc_u64_ntt_roots_precon52(t) != 0) return 52;
+    return orc_u64_ntt_modulus(t) < (1ull << 30) && orc_u64_ntt_roots_precon32(t) != 0 ? 32 : 64;
 }
 
 int orc_u64_ntt_forward_avx512_shift(const orc_u64_ntt *t, uint64_t *values, int lazy, int shift) {
-    return pick_ifma(t, shift) ? orc_u64_ntt_forward_avx512_ifma(t, values, lazy) : orc_u64_ntt_forward_avx512_dq(t, values, lazy);
+    switch (pick_shift(t, shift)) {
+        case 52: return orc_u64_ntt_forward_avx512_ifma(t, values, lazy);
+        case 32: return orc_u64_ntt_forward_avx512_dq32(t, values, lazy);
+        default: return orc_u64_ntt_forward_avx512_dq(t, values, lazy);
+    }
 }
 int orc_u64_ntt_inverse_avx512_shift(const orc_u64_ntt *t, uint64_t *values, int lazy, int shift) {
-    return pick_ifma(t, shift) ? orc_u64_ntt_inverse_avx512_ifma(t, values, lazy) : orc_u64_ntt_inverse_avx512_dq(t, values, lazy);
+    switch (pick_shift(t, shift)) {
+        case 52: return orc_u64_ntt_inverse_avx512_ifma(t, values, lazy);
+        case 32: return orc_u64_ntt_inverse_avx512_dq32(t, values, lazy);
+        default: return orc_u64_ntt_inverse_avx512_dq(t, values, lazy);
+    }
 }
 int orc_u64_ntt_forward_avx512(const orc_u64_ntt *t, uint64_t *values, int lazy) {
     return orc_u64_ntt_forward_avx512_shift(t, values, lazy, 0);

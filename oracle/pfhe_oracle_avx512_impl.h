@@ -1,7 +1,8 @@
 /*
  * pfhe_oracle_avx512_impl.h — body of the AVX-512 restatement, included twice by pfhe_oracle_avx512.c:
- *   S52 = 0: BIT_SHIFT = 64 (AVX-512 DQ, approximate 64-bit quotients, any q < 2^62)
- *   S52 = 1: BIT_SHIFT = 52 (AVX-512 IFMA, vpmadd52 products, q < 2^50: internal.rs:12,24,28; table.rs:166-186,236-256)
+ *   SHIFTV = 64: BIT_SHIFT = 64 (AVX-512 DQ, approximate 64-bit quotients, any q < 2^62)
+ *   SHIFTV = 52: BIT_SHIFT = 52 (AVX-512 IFMA, vpmadd52 products, q < 2^50: internal.rs:12,24,28; table.rs:166-186,236-256)
+ *   SHIFTV = 32: BIT_SHIFT = 32 (AVX-512 DQ, 64-bit products of 32-bit operands, q < 2^30: internal.rs:16; table.rs:188-200)
  * FN(name) appends the variant's suffix, TGT carries its target attribute, AVAILABLE() its CPU check.
  * TEST / BENCH INFRASTRUCTURE ONLY (see pfhe_oracle.h).
  */
@@ -20,11 +21,14 @@ TGT static inline __m512i FN(mulhi_approx)(__m512i x, __m512i y) {
 /* butterfly.rs:10-57, BIT_SHIFT = 64 */
 TGT static inline void FN(fwd_bfly)(__m512i *x, __m512i *y, __m512i w, __m512i wp, __m512i neg_q, __m512i two_q) {
     *x = FN(small_mod)(*x, two_q);
-#if S52 /* butterfly.rs:30-35: exact 52-bit quotient, T in [0,2q) without a correction */
+#if SHIFTV == 52 /* butterfly.rs:30-35: exact 52-bit quotient, T in [0,2q) without a correction */
     const __m512i z = _mm512_setzero_si512();
     const __m512i qh = _mm512_madd52hi_epu64(z, wp, *y);
     const __m512i t = _mm512_and_si512(_mm512_madd52lo_epu64(_mm512_madd52lo_epu64(z, w, *y), qh, neg_q),
                                        _mm512_set1_epi64((1ll << 52) - 1));
+#elif SHIFTV == 32 /* butterfly.rs:23-29: q < 2^30, y < 4q < 2^32: the quotient is the high half of a 64-bit product */
+    const __m512i qh = _mm512_srli_epi64(_mm512_mullo_epi64(wp, *y), 32);
+    const __m512i t = _mm512_add_epi64(_mm512_mullo_epi64(w, *y), _mm512_mullo_epi64(qh, neg_q));
 #else
     const __m512i qh = FN(mulhi_approx)(wp, *y);
     __m512i t = _mm512_add_epi64(_mm512_mullo_epi64(w, *y), _mm512_mullo_epi64(qh, neg_q)); /* [0,4q) */
@@ -113,11 +117,13 @@ TGT int FN(orc_u64_ntt_forward_avx512)(const orc_u64_ntt *t, uint64_t *values, i
     const size_t n = orc_u64_ntt_n(t);
     if (n < 16 || !AVAILABLE()) return ORC_ERR_BAD_ARG;
     const uint64_t qv = orc_u64_ntt_modulus(t);
-    if (S52 && (qv >= (1ull << 50) || !orc_u64_ntt_roots_precon52(t))) return ORC_ERR_BAD_ARG; /* internal.rs:24 */
+    if (SHIFTV == 52 && (qv >= (1ull << 50) || !orc_u64_ntt_roots_precon52(t))) return ORC_ERR_BAD_ARG; /* internal.rs:24 */
+    if (SHIFTV == 32 && (qv >= (1ull << 30) || !orc_u64_ntt_roots_precon32(t))) return ORC_ERR_BAD_ARG; /* internal.rs:16 */
     const __m512i q = _mm512_set1_epi64((long long)qv), two_q = _mm512_set1_epi64((long long)(qv << 1));
     const __m512i neg_q = _mm512_set1_epi64(-(long long)qv);
-    FN(forward_rec)(values, n, orc_u64_ntt_roots(t), S52 ? orc_u64_ntt_roots_precon52(t) : orc_u64_ntt_roots_precon64(t), 1,
-                    neg_q, two_q, q, !lazy);
+    FN(forward_rec)(values, n, orc_u64_ntt_roots(t),
+                    SHIFTV == 52 ? orc_u64_ntt_roots_precon52(t) : SHIFTV == 32 ? orc_u64_ntt_roots_precon32(t) : orc_u64_ntt_roots_precon64(t),
+                    1, neg_q, two_q, q, !lazy);
     return ORC_OK;
 }
 
@@ -151,10 +157,13 @@ TGT static inline void FN(inv_bfly)(__m512i *x, __m512i *y, __m512i w, __m512i w
         const __mmask8 neg = _mm512_movepi64_mask(*x);
         *x = _mm512_mask_add_epi64(*x, neg, *x, two_q);
     }
-#if S52 /* butterfly.rs:97-102 */
+#if SHIFTV == 52 /* butterfly.rs:97-102 */
     const __m512i z = _mm512_setzero_si512();
     const __m512i qh = _mm512_madd52hi_epu64(z, wp, t);
     *y = _mm512_and_si512(_mm512_madd52lo_epu64(_mm512_madd52lo_epu64(z, qh, neg_q), w, t), _mm512_set1_epi64((1ll << 52) - 1));
+#elif SHIFTV == 32 /* butterfly.rs:90-96 */
+    const __m512i qh = _mm512_srli_epi64(_mm512_mullo_epi64(wp, t), 32);
+    *y = _mm512_add_epi64(_mm512_mullo_epi64(qh, neg_q), _mm512_mullo_epi64(w, t));
 #else
     const __m512i qh = FN(mulhi_approx)(wp, t);
     *y = FN(small_mod)(_mm512_add_epi64(_mm512_mullo_epi64(w, t), _mm512_mullo_epi64(qh, neg_q)), two_q);
@@ -230,27 +239,32 @@ TGT int FN(orc_u64_ntt_inverse_avx512)(const orc_u64_ntt *t, uint64_t *values, i
     const size_t n = orc_u64_ntt_n(t);
     if (n < 16 || !AVAILABLE()) return ORC_ERR_BAD_ARG;
     const uint64_t qv = orc_u64_ntt_modulus(t);
-    if (S52 && (qv >= (1ull << 50) || !orc_u64_ntt_inv_roots_precon52(t))) return ORC_ERR_BAD_ARG; /* internal.rs:28 */
+    if (SHIFTV == 52 && (qv >= (1ull << 50) || !orc_u64_ntt_inv_roots_precon52(t))) return ORC_ERR_BAD_ARG; /* internal.rs:28 */
+    if (SHIFTV == 32 && (qv >= (1ull << 30) || !orc_u64_ntt_inv_roots_precon32(t))) return ORC_ERR_BAD_ARG; /* this restatement keeps the forward bound for both directions (the table holds 32-bit preconditioners for q < 2^30 only) */
     const __m512i q = _mm512_set1_epi64((long long)qv), two_q = _mm512_set1_epi64((long long)(qv << 1));
     const __m512i neg_q = _mm512_set1_epi64(-(long long)qv);
     FN(inverse_rec)(values, n, n, 0, orc_u64_ntt_inv_roots(t),
-                    S52 ? orc_u64_ntt_inv_roots_precon52(t) : orc_u64_ntt_inv_roots_precon64(t), neg_q, two_q, 1);
+                    SHIFTV == 52 ? orc_u64_ntt_inv_roots_precon52(t) : SHIFTV == 32 ? orc_u64_ntt_inv_roots_precon32(t) : orc_u64_ntt_inv_roots_precon64(t),
+                    neg_q, two_q, 1);
     /* transform.rs:336-421: final stage with N^-1 (x half) and N^-1 * w (y half), exact quotients */
     const uint64_t inv_n = orc_u64_ntt_inv_n(t), inv_n_w = orc_u64_ntt_inv_n_w(t);
     const __m512i v_inv_n = _mm512_set1_epi64((long long)inv_n), v_inv_n_w = _mm512_set1_epi64((long long)inv_n_w);
     /* MultiplyFactor::new(value, BIT_SHIFT, q).quotient() = floor(value * 2^BIT_SHIFT / q), transform.rs:344-348 */
-    const __m512i v_inv_n_p = _mm512_set1_epi64((long long)(S52 ? orc_multiply_factor_quotient(inv_n, 52, qv) : orc_shoup_quotient(inv_n, qv)));
-    const __m512i v_inv_n_w_p = _mm512_set1_epi64((long long)(S52 ? orc_multiply_factor_quotient(inv_n_w, 52, qv) : orc_shoup_quotient(inv_n_w, qv)));
+    const __m512i v_inv_n_p = _mm512_set1_epi64((long long)(SHIFTV == 64 ? orc_shoup_quotient(inv_n, qv) : orc_multiply_factor_quotient(inv_n, SHIFTV, qv)));
+    const __m512i v_inv_n_w_p = _mm512_set1_epi64((long long)(SHIFTV == 64 ? orc_shoup_quotient(inv_n_w, qv) : orc_multiply_factor_quotient(inv_n_w, SHIFTV, qv)));
     const size_t h = n >> 1;
     for (size_t j = 0; j < h; j += 8) {
         __m512i x = _mm512_loadu_si512(values + j), y = _mm512_loadu_si512(values + j + h);
         const __m512i y_minus_2q = _mm512_sub_epi64(y, two_q);
         const __m512i s = FN(small_mod)(_mm512_add_epi64(x, y), two_q);
         const __m512i d = _mm512_sub_epi64(x, y_minus_2q);
-#if S52 /* transform.rs:388-397 */
+#if SHIFTV == 52 /* transform.rs:388-397 */
         const __m512i z = _mm512_setzero_si512(), m52 = _mm512_set1_epi64((1ll << 52) - 1);
         x = _mm512_and_si512(_mm512_madd52lo_epu64(_mm512_madd52lo_epu64(z, v_inv_n, s), _mm512_madd52hi_epu64(z, v_inv_n_p, s), neg_q), m52);
         y = _mm512_and_si512(_mm512_madd52lo_epu64(_mm512_madd52lo_epu64(z, v_inv_n_w, d), _mm512_madd52hi_epu64(z, v_inv_n_w_p, d), neg_q), m52);
+#elif SHIFTV == 32 /* transform.rs:375-387 */
+        x = _mm512_add_epi64(_mm512_mullo_epi64(v_inv_n, s), _mm512_mullo_epi64(_mm512_srli_epi64(_mm512_mullo_epi64(v_inv_n_p, s), 32), neg_q));
+        y = _mm512_add_epi64(_mm512_mullo_epi64(v_inv_n_w, d), _mm512_mullo_epi64(_mm512_srli_epi64(_mm512_mullo_epi64(v_inv_n_w_p, d), 32), neg_q));
 #else
         x = _mm512_add_epi64(_mm512_mullo_epi64(v_inv_n, s), _mm512_mullo_epi64(FN(mulhi_exact)(v_inv_n_p, s), neg_q));
         y = _mm512_add_epi64(_mm512_mullo_epi64(v_inv_n_w, d), _mm512_mullo_epi64(FN(mulhi_exact)(v_inv_n_w_p, d), neg_q));

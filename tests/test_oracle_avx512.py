@@ -111,3 +111,32 @@ def test_avx512_ifma_rejects_wide_moduli(orc):
         t.transform_slice_avx512(np.zeros(256, np.uint64), shift=52)
     with pytest.raises(orc.OracleError):
         t.inverse_transform_slice_avx512(np.zeros(256, np.uint64), shift=52)
+
+
+@pytest.mark.parametrize("log_n,q", [(4, 132120577), (8, 536813569), (10, 1073479681), (13, 132120577), (16, 1071513601)])
+def test_avx512_32bit_rung_equals_scalar(orc, log_n, q):
+    """BIT_SHIFT = 32 (q < 2^30: prime64/avx512 butterfly.rs:23-29,90-96, transform.rs:375-387; table.rs:188-200): canonical
+    outputs identical to the scalar path (which takes its own Barrett-32 butterflies for these primes) and to the other
+    rungs, lazy outputs in range and equal mod q."""
+    if not orc.lib().orc_avx512_available():
+        pytest.skip("host has no AVX-512 DQ")
+    rng = np.random.default_rng(300 + log_n)
+    t = orc.U64NttTable(log_n, q)
+    a = rng.integers(0, q, 3 << log_n, dtype=np.uint64)
+    a[:4] = [0, q - 1, 1, q // 2]
+    ref = a.copy(); t.transform_slice(ref)
+    iref = a.copy(); t.inverse_transform_slice(iref)
+    shifts = (32, 64, 0) + ((52,) if orc.lib().orc_avx512_ifma_available() else ())
+    for shift in shifts:
+        got = a.copy(); t.transform_slice_avx512(got, shift=shift)
+        assert np.array_equal(got, ref), shift
+        got = a.copy(); t.inverse_transform_slice_avx512(got, shift=shift)
+        assert np.array_equal(got, iref), shift
+    lz = rng.integers(0, 4 * q, 1 << log_n, dtype=np.uint64)
+    can = (lz % np.uint64(q)).copy(); t.transform_slice(can)
+    t.transform_slice_avx512(lz, lazy=True, shift=32)
+    assert lz.max() < 4 * q and np.array_equal(lz % np.uint64(q), can)
+    il = a.copy(); t.inverse_transform_slice_avx512(il, lazy=True, shift=32)
+    assert il.max() < 2 * q and np.array_equal(il % np.uint64(q), iref)
+    with pytest.raises(orc.OracleError):
+        orc.U64NttTable(8, Q61[0]).transform_slice_avx512(np.zeros(256, np.uint64), shift=32)
