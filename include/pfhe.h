@@ -169,6 +169,11 @@ int pfhe_dcrt_transform_coeff_one_monomial(const pfhe_dcrt *table, size_t degree
                                            size_t len);
 int pfhe_dcrt_transform_coeff_minus_one_monomial(const pfhe_dcrt *table, size_t degree,
                                                  uint64_t *values, size_t len);
+/* device-pointer variants of the three monomial transforms: launches on `stream` only (the per-limb coefficients
+ * travel as kernel arguments), no allocation or synchronisation — capturable into a HIP graph (a CMUX / blind-rotate
+ * loop builds X^d in NTT form every step).  minus_one != 0 selects -X^degree (coeff is then ignored). */
+int pfhe_dcrt_transform_monomial_dev(const pfhe_dcrt *table, uint64_t coeff, size_t degree,
+                                     uint64_t *values_dev, size_t len, int minus_one, void *stream);
 int pfhe_dcrt_transform_dev(const pfhe_dcrt *table, uint64_t *poly_dev, size_t len, int lazy,
                             void *stream);
 int pfhe_dcrt_inverse_transform_dev(const pfhe_dcrt *table, uint64_t *poly_dev, size_t len,

@@ -104,6 +104,11 @@ class U64DcrtTable {
     void transform_monomial(uint64_t coeff, size_t degree, uint64_t *values, size_t len) const {
         check(pfhe_dcrt_transform_monomial(h_, coeff, degree, values, len));
     }
+    // device-pointer form (launches on `stream` only: capturable); minus_one selects -X^degree
+    void transform_monomial_dev(uint64_t coeff, size_t degree, uint64_t *values_dev, size_t len, bool minus_one = false,
+                                void *stream = nullptr) const {
+        check(pfhe_dcrt_transform_monomial_dev(h_, coeff, degree, values_dev, len, minus_one ? 1 : 0, stream));
+    }
     void transform_dev(uint64_t *poly_dev, size_t len, bool lazy = false, void *stream = nullptr) const {
         check(pfhe_dcrt_transform_dev(h_, poly_dev, len, lazy, stream));
     }

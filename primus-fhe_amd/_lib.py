@@ -91,6 +91,7 @@ def _declare(lib: C.CDLL) -> None:
     sig("pfhe_dcrt_transform_monomial", ci, vp, u64, sz, vp, sz)
     sig("pfhe_dcrt_transform_coeff_one_monomial", ci, vp, sz, vp, sz)
     sig("pfhe_dcrt_transform_coeff_minus_one_monomial", ci, vp, sz, vp, sz)
+    sig("pfhe_dcrt_transform_monomial_dev", ci, vp, u64, sz, vp, sz, ci, vp)
     sig("pfhe_dcrt_transform_dev", ci, vp, vp, sz, ci, vp)
     sig("pfhe_dcrt_inverse_transform_dev", ci, vp, vp, sz, ci, vp)
     sig("pfhe_dcrt_mul_assign_dev", ci, vp, vp, sz, vp, sz, vp)

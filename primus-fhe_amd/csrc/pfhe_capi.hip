@@ -629,6 +629,16 @@ int pfhe_dcrt_transform_coeff_minus_one_monomial(const pfhe_dcrt *table, size_t 
     PFHE_GUARD_END
 }
 
+int pfhe_dcrt_transform_monomial_dev(const pfhe_dcrt *table, uint64_t coeff, size_t degree, uint64_t *values_dev,
+                                     size_t len, int minus_one, void *stream) {
+    PFHE_GUARD_BEGIN
+    if (!table) return PFHE_ERR_BAD_ARGUMENT;
+    PFHE_REQUIRE_ALIGNED(values_dev);
+    return monomial(*table->t, minus_one ? 0 : coeff, degree, (u64 *)values_dev, len, false, (hipStream_t)stream,
+                    minus_one != 0);
+    PFHE_GUARD_END
+}
+
 int pfhe_dcrt_transform_dev(const pfhe_dcrt *table, uint64_t *poly_dev, size_t len, int lazy, void *stream) {
     PFHE_GUARD_BEGIN
     if (!table) return PFHE_ERR_BAD_ARGUMENT;

@@ -168,6 +168,18 @@ class U64DcrtTable:
         """-X^degree: q_i - 1 in limb i (primus_ntt/src/dcrt/mod.rs:124-134)."""
         check(lib().pfhe_dcrt_transform_coeff_minus_one_monomial(self._h, degree, *_host(values)))
 
+    def transform_monomial_dev(self, coeff: int, degree: int, values, stream=None):
+        """DcrtTable::transform_monomial into device memory: launches only, capturable."""
+        p, n = _dev(values)
+        check(lib().pfhe_dcrt_transform_monomial_dev(self._h, coeff, degree, p, n, 0, _stream(stream)))
+
+    def transform_coeff_one_monomial_dev(self, degree: int, values, stream=None):
+        self.transform_monomial_dev(1, degree, values, stream)
+
+    def transform_coeff_minus_one_monomial_dev(self, degree: int, values, stream=None):
+        p, n = _dev(values)
+        check(lib().pfhe_dcrt_transform_monomial_dev(self._h, 0, degree, p, n, 1, _stream(stream)))
+
     def transform_dev(self, poly, lazy: bool = False, stream=None):
         p, n = _dev(poly)
         check(lib().pfhe_dcrt_transform_dev(self._h, p, n, int(lazy), _stream(stream)))

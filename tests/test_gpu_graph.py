@@ -160,6 +160,24 @@ def test_monomial_transforms_in_a_graph(pf):
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy().view(np.uint64), exp)
     assert np.array_equal(out32.cpu().numpy().view(np.uint32), exp32)
+    # DcrtTable forms (dcrt/mod.rs:105-134), three limbs, c * X^d / X^d / -X^d
+    d = pf.U64DcrtTable(log_n, Q61)
+    outs = [torch.zeros(3 * n, dtype=torch.int64, device="cuda") for _ in range(3)]
+    exps = [np.zeros(3 * n, np.uint64) for _ in range(3)]
+    d.transform_monomial(9, 2 * n - 5, exps[0])
+    d.transform_coeff_one_monomial(77, exps[1])
+    d.transform_coeff_minus_one_monomial(n + 1, exps[2])
+    gd = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gd, stream=s):
+        d.transform_monomial_dev(9, 2 * n - 5, outs[0], stream=s)
+        d.transform_coeff_one_monomial_dev(77, outs[1], stream=s)
+        d.transform_coeff_minus_one_monomial_dev(n + 1, outs[2], stream=s)
+    for o in outs:
+        o.zero_()
+    gd.replay()
+    torch.cuda.synchronize()
+    for o, e in zip(outs, exps):
+        assert np.array_equal(o.cpu().numpy().view(np.uint64), e)
 
 
 def test_round3_kernels_first_called_inside_a_capture(pf):
