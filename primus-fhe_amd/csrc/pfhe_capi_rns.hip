@@ -30,6 +30,7 @@ struct pfhe_extprod_plan {
     // PFHE_DISABLE_SMALL_EXTPROD / _FUSED_EXTPROD / _FUSED_DECOMPOSE, read at plan creation
     bool use_small = true, use_fused = true, use_fused_decompose = true;
     bool use_fused_tail = true;  // PFHE_DISABLE_FUSED_TAIL clears it (the parity tests compare both forms)
+    u64 fused_min_wgs = 160;     // workgroups a call must offer before the fused block + multiply-accumulate kernel is taken (PFHE_FUSED_MIN_WGS; N = 2^16, 3 limbs, coefficient form: 1 / 2 / 4 / 5 ciphertexts take 97 / 121 / 165 / 190 us unfused and 141 / 144 / 158 / 164 us fused)
     // measurement aid (pfhe_extprod_profile_dev): when non-null, run_product records an event before the
     // decomposition, between the decomposition and the transform / multiply-accumulate, and after it, per chunk
     std::vector<hipEvent_t> *prof = nullptr;
@@ -120,7 +121,7 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
     const bool single = !p->pipeline || batch <= p->chunk || stream_is_capturing(s);
     hipStream_t sa = single ? s : p->sa, sb = single ? s : p->sb;
     const bool fused = gadget_fused_supported(t.log_n, p->k) && p->use_fused &&
-                       ((std::min<u64>(batch, p->chunk) * t.L) << (t.log_n - 12)) >= 256;
+                       ((std::min<u64>(batch, p->chunk) * t.L) << (t.log_n - 12)) >= p->fused_min_wgs;
     const int passes = ntt_num_passes(t.log_n, t.pm, t.tune);
     // coefficient-form output: the inverse transform's block pass runs inside the fused kernel, on the accumulators
     const bool inv_tail = fused && into_coeff && !accumulate && coeff_passes != nullptr && passes == 2 && p->use_fused_tail;
@@ -594,6 +595,7 @@ int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *rns, const 
     p->use_fused = std::getenv("PFHE_DISABLE_FUSED_EXTPROD") == nullptr;
     p->use_fused_decompose = std::getenv("PFHE_DISABLE_FUSED_DECOMPOSE") == nullptr;
     p->use_fused_tail = std::getenv("PFHE_DISABLE_FUSED_TAIL") == nullptr;
+    if (const char *e = std::getenv("PFHE_FUSED_MIN_WGS")) p->fused_min_wgs = (u64)std::max(1, std::atoi(e));
     for (int i = 0; i < 2; ++i) {
         void *d = nullptr;
         if (i == 0 || p->pipeline) PFHE_HIP(hipMalloc(&d, p->digits_words * sizeof(u64)));
