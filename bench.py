@@ -296,8 +296,24 @@ def spawn_ranks(args) -> int:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rcs = [pr.wait() for pr in procs]
-    return max((abs(rc) for rc in rcs), default=0)
+    # a rank that dies leaves the others waiting at a barrier: end them (by PID, never by pattern) instead of hanging
+    rcs = [None] * len(procs)
+    while any(rc is None for rc in rcs):
+        for i, pr in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = pr.poll()
+        if any(rc not in (None, 0) for rc in rcs):
+            for i, pr in enumerate(procs):
+                if rcs[i] is None:
+                    pr.terminate()
+                    try:
+                        rcs[i] = pr.wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        pr.kill()
+                        rcs[i] = pr.wait()
+            break
+        time.sleep(0.2)
+    return max((abs(rc) for rc in rcs if rc is not None), default=0)
 
 
 def main():

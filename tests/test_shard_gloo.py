@@ -127,7 +127,10 @@ def test_bench_gpus_flag_spawns_one_rank_per_gpu(monkeypatch):
         def __init__(self, argv, env=None, stdout=None):
             started.append((argv, env, stdout))
 
-        def wait(self):
+        def wait(self, timeout=None):
+            return 0
+
+        def poll(self):
             return 0
 
     monkeypatch.setattr(subprocess, "Popen", FakeProc)
@@ -150,3 +153,37 @@ def test_bench_rejects_world_size_mismatch(monkeypatch):
     with pytest.raises(SystemExit) as ei:
         bench.main()
     assert "WORLD_SIZE" in str(ei.value)
+
+
+def test_bench_spawner_ends_the_other_ranks_when_one_dies(monkeypatch):
+    """A rank that exits non-zero must not leave its peers waiting at a barrier: the launcher terminates them (by handle)
+    and returns the failing code."""
+    import subprocess
+    import types
+
+    import bench
+
+    class P:
+        def __init__(self, rc):
+            self.rc, self.terminated = rc, False
+
+        def poll(self):
+            return self.rc
+
+        def terminate(self):
+            self.terminated = True
+            self.rc = -15
+
+        def wait(self, timeout=None):
+            return self.rc
+
+        def kill(self):
+            self.rc = -9
+
+    procs = [P(None), P(3), P(None)]
+    it = iter(procs)
+    monkeypatch.setattr(subprocess, "Popen", lambda *a, **k: next(it))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "3", "--one-device"])
+    rc = bench.spawn_ranks(types.SimpleNamespace(gpus=3, one_device=True, master_port=0))
+    assert rc == 15 or rc == 3
+    assert procs[0].terminated and procs[2].terminated and not procs[1].terminated
