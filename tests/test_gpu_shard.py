@@ -143,3 +143,23 @@ def test_config5_job_of_8192_ciphertexts_sharded_eight_ways(orc):
             exp = _oracle_product(orc, o, obase, obasis, gin, kh)
             got = to_host(os_[(ct - b) * W:(ct - b + 1) * W])
             assert np.array_equal(got, exp), "ciphertext %d (rank %d) != oracle" % (ct, rk)
+
+
+def test_bench_under_the_launcher_with_rccl(tmp_path):
+    """The driver's form: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` over RCCL (backend "nccl").
+    One GPU here, so N = 1 with --force-dist: the process group is initialised on the device, the timing barrier and the
+    max-over-ranks all-reduce run through RCCL, and the JSON line comes out of rank 0."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "2",
+           "--warmup", "1", "--batch", "16", "--ext-batch", "4", "--ext-total", "8", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["external_product_config5"]["batch_total"] == 8
+    assert "roofline" in line
