@@ -910,3 +910,48 @@ def test_polymul_2p14_resident_workgroups(pf, orc, moduli, shared, monkeypatch):
     assert torch.equal(f, f1)
     d.inverse_transform_dev(f)
     assert torch.equal(f, a)
+
+
+@pytest.mark.parametrize("env,log_n,batch", [
+    ({"PFHE_MAX_SINGLE_PASS_LOG": "9"}, 10, 5),     # 1 strided stage + blocks of 2^9
+    ({"PFHE_MAX_SINGLE_PASS_LOG": "9"}, 13, 3),     # blocks of 2^12 below N = 2^14's single-pass limit
+    ({"PFHE_BLOCK_LOG": "8"}, 16, 2),               # blocks of 2^8: two strided passes of 4 stages
+    ({"PFHE_BLOCK_LOG": "10"}, 17, 1),              # 7 strided stages in two passes (4 + 3)
+    ({"PFHE_STRIDED_VEC1": "1"}, 16, 2),            # one column per thread in the strided pass
+    ({"PFHE_PIPELINED_MIN_MB": "1"}, 16, 4),        # the pipelined kernel on a 6 MiB batch
+    ({"PFHE_PIPELINED_MIN_MB": "1", "PFHE_PIPE_TILES": "3"}, 16, 5),
+])
+@pytest.mark.parametrize("generic", [False, True])
+def test_plan_tuning_switches_change_the_plan_not_the_words(pf, orc, env, log_n, batch, generic, monkeypatch):
+    """Every plan switch NttTuning::from_env reads (at table creation) against the oracle: forward, inverse, lazy forward and
+    the polynomial product, pseudo-Mersenne and generic-prime (Montgomery) arithmetic.  The switches only choose how the
+    stages are split over launches."""
+    n = 1 << log_n
+    moduli = Q61[:2]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    if generic:
+        monkeypatch.setenv("PFHE_DISABLE_PM", "1")
+    d = pf.U64DcrtTable(log_n, moduli)
+    o = orc.U64DcrtTable(log_n, moduli)
+    rng = np.random.default_rng(77 + log_n + batch)
+    a, bh = rand_rns(rng, moduli, n, batch), rand_rns(rng, moduli, n, 1)
+    fwd = a.copy()
+    o.transform_slice(fwd)
+    x = to_dev(a)
+    d.transform_dev(x)
+    assert np.array_equal(to_host(x), fwd)
+    d.inverse_transform_dev(x)
+    assert np.array_equal(to_host(x), a)
+    d.transform_dev(x, lazy=True)
+    qs = np.repeat(np.tile(np.array(moduli, np.uint64), batch), n)
+    lz = to_host(x)
+    assert (lz < 4 * qs).all() and np.array_equal(lz % qs, fwd)
+    exp = fwd.copy()
+    W = len(moduli) * n
+    for e in range(batch):
+        o.mul_assign(exp[e * W:(e + 1) * W], bh)
+    o.inverse_transform_slice(exp)
+    y = to_dev(a)
+    d.mul_dcrt_polynomial_dev(y, to_dev(bh))
+    assert np.array_equal(to_host(y), exp)

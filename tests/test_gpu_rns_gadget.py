@@ -465,3 +465,26 @@ def test_fused_inverse_tail_equals_separate_inverse(pf, orc, log_n, batch, share
     assert torch.equal(fused, sep)
     otable.inverse_transform_slice(exp)
     assert np.array_equal(to_host(fused[:oc * G]), exp)
+
+
+@pytest.mark.parametrize("min_wgs,log_n", [("1", 16), ("100000", 16), ("1", 13)])
+def test_fused_kernel_threshold_switch(pf, orc, min_wgs, log_n, monkeypatch):
+    """PFHE_FUSED_MIN_WGS (read at plan creation) moves the batch size from which the fused block pass + multiply-accumulate
+    kernel is taken: one ciphertext through the fused kernel, a batch through the separate kernels — the oracle's words
+    either way, NTT form and coefficient form."""
+    k, batch = 1, (1 if min_wgs == "1" else 12)
+    rng = np.random.default_rng(9090 + log_n + batch)
+    otable, glwe, ggsw, exp = make_case(orc, rng, log_n, k, Q61, 30, None, 1, True)
+    n = 1 << log_n
+    table, base = pf.U64DcrtTable(log_n, Q61), pf.RNSBase(Q61)
+    basis = pf.BigUintApproxSignedBasis(base, 30)
+    monkeypatch.setenv("PFHE_FUSED_MIN_WGS", min_wgs)
+    ctx = pf.DcrtGlevContext(table, base, basis, k)
+    G = ctx.glwe_len()
+    full = np.concatenate([glwe, rand_rns(rng, Q61, n, (batch - 1) * (k + 1))]) if batch > 1 else glwe
+    out = np.empty_like(full)
+    pf.mul_dcrt_ggsw_to(full, ggsw, out, ctx)
+    assert np.array_equal(out[:G], exp)
+    pf.mul_dcrt_ggsw_to(full, ggsw, out, ctx, into_coeff_form=True)
+    otable.inverse_transform_slice(exp)
+    assert np.array_equal(out[:G], exp)
