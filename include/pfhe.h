@@ -71,6 +71,15 @@ int pfhe_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t byte
 int pfhe_memcpy_d2d(int device, void *dst_dev, const void *src_dev, size_t bytes, void *stream);
 int pfhe_memset_dev(int device, void *dst_dev, int byte, size_t bytes, void *stream);
 int pfhe_stream_synchronize(int device, void *stream);
+/* Host-pointer entry points (`*_slice`, `*_to` without `_dev`) behave like the reference's `&self, &mut [T]` methods
+ * (table.rs:541-563: in place, no allocation per call): each call borrows a staging context — private stream, cached
+ * device arena, pinned bounce buffer — from a per-device pool and returns it, so calls of a size seen before allocate
+ * nothing and any number of threads may call through one handle concurrently (NttTable: Send + Sync).
+ * pfhe_debug_alloc_count: device / pinned allocation and free calls the library has made since it was loaded (a
+ * steady-state loop must not move it).  pfhe_staging_release: frees the idle contexts of `device` (-1: all devices),
+ * returns their number. */
+uint64_t pfhe_debug_alloc_count(void);
+int pfhe_staging_release(int device);
 /* Synthetic data: word i of the buffer = floor(splitmix64(seed, i) * q / 2^64), i.e. uniform in
  * [0,q) (per-modulus uniform sampling as primus_distr/src/common.rs:244-263).  Modulus-major RNS
  * layout when `moduli_count` > 1: word i uses moduli[(i / poly_len) % moduli_count]. */

@@ -59,6 +59,8 @@ def _declare(lib: C.CDLL) -> None:
     sig("pfhe_memcpy_d2d", ci, ci, vp, vp, sz, vp)
     sig("pfhe_memset_dev", ci, ci, vp, ci, sz, vp)
     sig("pfhe_stream_synchronize", ci, ci, vp)
+    sig("pfhe_debug_alloc_count", u64)
+    sig("pfhe_staging_release", ci, ci)
     sig("pfhe_fill_uniform_dev", ci, ci, vp, sz, u64p, sz, sz, u64, vp)
 
     sig("pfhe_ntt_create", ci, u32, u64, ci, C.POINTER(vp))

@@ -12,6 +12,7 @@
 #include "pfhe_handles.hpp"
 #include "pfhe_ntt_device.hpp"
 #include "pfhe_pointwise.hpp"
+#include "pfhe_staging.hpp"
 
 namespace pfhe {
 
@@ -56,7 +57,7 @@ static int check_device(int device) {
 
 TableSet::~TableSet() {
     DeviceGuard g(device);
-    for (void *p : allocations) (void)hipFree(p);
+    for (void *p : allocations) (void)counted_free(p);
 }
 
 // Builds host tables for every modulus, uploads them, and fills `out`.
@@ -93,7 +94,7 @@ int make_table_set(u32 log_n, const u64 *moduli, size_t count, int device, std::
     const bool use_mont = !all_pm && all_mont && log_n >= 4;
     const auto upload = [&](const void *src, size_t nbytes, const void **dst) -> int {
         void *d = nullptr;
-        PFHE_HIP(hipMalloc(&d, nbytes));
+        PFHE_HIP(counted_malloc(&d, nbytes));
         ts->allocations.push_back(d);
         PFHE_HIP(hipMemcpy(d, src, nbytes, hipMemcpyHostToDevice));
         *dst = d;
@@ -196,12 +197,12 @@ int make_table_set(u32 log_n, const u64 *moduli, size_t count, int device, std::
     ts->pm = all_pm;
     ts->ntt_arith = all_pm ? kArithPm : (use_mont ? kArithMont : kArithShoup);
     void *pd = nullptr;
-    PFHE_HIP(hipMalloc(&pd, count * sizeof(NttPrime)));
+    PFHE_HIP(counted_malloc(&pd, count * sizeof(NttPrime)));
     ts->allocations.push_back(pd);
     PFHE_HIP(hipMemcpy(pd, ts->primes.data(), count * sizeof(NttPrime), hipMemcpyHostToDevice));
     ts->primes_dev = static_cast<const NttPrime *>(pd);
     void *md = nullptr;
-    PFHE_HIP(hipMalloc(&md, count * sizeof(u64)));
+    PFHE_HIP(counted_malloc(&md, count * sizeof(u64)));
     ts->allocations.push_back(md);
     std::vector<u64> mods(moduli, moduli + count);
     PFHE_HIP(hipMemcpy(md, mods.data(), count * sizeof(u64), hipMemcpyHostToDevice));
@@ -233,31 +234,46 @@ int transform_dev(const TableSet &t, u64 *data, size_t len, bool inverse, bool l
                    : ntt_forward_dev(t.primes_dev, t.L, t.log_n, t.ntt_arith, data, npolys, lazy, s, t.tune);
 }
 
-// host-pointer wrapper: stage through a temporary device buffer
-template <class F>
-static int with_staged(const TableSet &t, u64 *host, size_t len, bool copy_in, F &&f) {
+// Host-pointer form of the transforms (table.rs:541-563 takes `&mut [T]` in place): the slice is staged through a
+// pooled context (pfhe_staging.hpp: no allocation in steady state) and pinned in place for the call.  Polynomials are
+// independent, so a long slice is cut into pieces of whole units and pipelined over the context's two streams: one
+// carries the copies in, the other waits for each piece, transforms it and copies it back — the copy back of piece i
+// overlaps the copy in of piece i + 1 (the link is full duplex).
+size_t stage_chunk_bytes() {
+    static const size_t v = [] {
+        const char *e = std::getenv("PFHE_STAGE_CHUNK");
+        const unsigned long long x = e && *e ? std::strtoull(e, nullptr, 10) : 0ull;
+        return x ? (size_t)x : (size_t)8 << 20;
+    }();
+    return v;
+}
+
+int transform_host(const TableSet &t, u64 *host, size_t len, bool inverse, bool lazy) {
     if (!host && len) return PFHE_ERR_BAD_ARGUMENT;
     u64 units = 0;
     PFHE_TRY(check_len(t, len, units));
     if (len == 0) return PFHE_OK;
     DeviceGuard g(t.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    void *d = nullptr;
-    PFHE_HIP(hipMalloc(&d, len * sizeof(u64)));
-    int rc = PFHE_OK;
-    hipError_t e = hipSuccess;
-    if (copy_in) e = hipMemcpy(d, host, len * sizeof(u64), hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        rc = f(static_cast<u64 *>(d));
-        if (rc == PFHE_OK) e = hipMemcpy(host, d, len * sizeof(u64), hipMemcpyDeviceToHost);  // syncs
+    HostStage st(t.device);
+    if (!st.ok()) return PFHE_ERR_HIP;
+    void *dv = nullptr;
+    PFHE_TRY(st.alloc(len * sizeof(u64), &dv));
+    u64 *d = static_cast<u64 *>(dv);
+    const size_t unit = t.n * t.L;
+    const bool pinned = st.pin(host, len * sizeof(u64));
+    // pageable copies block the calling thread: nothing to pipeline, one piece
+    const size_t per = pinned ? std::max<size_t>(1, stage_chunk_bytes() / (unit * sizeof(u64))) : (size_t)units;
+    const bool pipelined = per < units;
+    const hipStream_t s_in = st.stream(), s_run = pipelined ? st.stream2() : st.stream();
+    for (u64 u0 = 0; u0 < units; u0 += per) {
+        const size_t words = (size_t)std::min<u64>(per, units - u0) * unit, off = (size_t)u0 * unit;
+        PFHE_TRY(st.copy_in(d + off, host + off, words * sizeof(u64), s_in));
+        if (pipelined) PFHE_TRY(st.order(s_in, s_run));
+        PFHE_TRY(transform_dev(t, d + off, words, inverse, lazy, s_run));
+        PFHE_TRY(st.download(host + off, d + off, words * sizeof(u64), s_run));
     }
-    (void)hipFree(d);
-    if (e != hipSuccess) return hip_fail(e, "staged copy", __FILE__, __LINE__);
-    return rc;
-}
-
-int transform_host(const TableSet &t, u64 *host, size_t len, bool inverse, bool lazy) {
-    return with_staged(t, host, len, true, [&](u64 *d) { return transform_dev(t, d, len, inverse, lazy, nullptr); });
+    return st.finish();
 }
 
 int pointwise(const TableSet &t, int mode, u64 *acc, const u64 *a, size_t len_a, const u64 *b, size_t len_b,
@@ -332,15 +348,15 @@ int monomial(const TableSet &t, u64 coeff, size_t degree, u64 *values, size_t le
     };
     if (!host)  // device output: launches on the caller's stream, nothing else (capturable)
         return run(values);
+    // host output: the caller's stream is not involved (pooled staging context, no allocation in steady state)
+    HostStage st(t.device);
+    if (!st.ok()) return PFHE_ERR_HIP;
     void *out_dev = nullptr;
-    PFHE_HIP(hipMalloc(&out_dev, len * sizeof(u64)));
-    int rc = run(static_cast<u64 *>(out_dev));
-    hipError_t e = hipSuccess;
-    if (rc == PFHE_OK) e = hipMemcpyAsync(values, out_dev, len * sizeof(u64), hipMemcpyDeviceToHost, s);
-    if (rc == PFHE_OK && e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(out_dev);
-    if (e != hipSuccess) return hip_fail(e, "monomial transform", __FILE__, __LINE__);
-    return rc;
+    PFHE_TRY(st.alloc(len * sizeof(u64), &out_dev));
+    s = st.stream();
+    PFHE_TRY(run(static_cast<u64 *>(out_dev)));
+    PFHE_TRY(st.download(values, out_dev, len * sizeof(u64)));
+    return st.finish();
 }
 
 }  // namespace pfhe
@@ -397,13 +413,16 @@ int pfhe_device_count(int *count) {
     return PFHE_OK;
 }
 
+uint64_t pfhe_debug_alloc_count(void) { return alloc_event_count(); }
+int pfhe_staging_release(int device) { return staging_release(device); }
+
 int pfhe_device_malloc(int device, size_t bytes, void **out) {
     if (!out) return PFHE_ERR_BAD_ARGUMENT;
     *out = nullptr;
     PFHE_TRY(check_device(device));
     DeviceGuard g(device);
     if (bytes == 0) return PFHE_OK;
-    PFHE_HIP(hipMalloc(out, bytes));
+    PFHE_HIP(counted_malloc(out, bytes));
     return PFHE_OK;
 }
 
@@ -411,7 +430,7 @@ int pfhe_device_free(int device, void *ptr) {
     if (!ptr) return PFHE_OK;
     PFHE_TRY(check_device(device));
     DeviceGuard g(device);
-    PFHE_HIP(hipFree(ptr));
+    PFHE_HIP(counted_free(ptr));
     return PFHE_OK;
 }
 
@@ -467,17 +486,14 @@ int pfhe_fill_uniform_dev(int device, uint64_t *dst, size_t len, const uint64_t 
     if (!dst || !moduli || moduli_count == 0 || poly_len == 0) return PFHE_ERR_BAD_ARGUMENT;
     PFHE_TRY(check_device(device));
     DeviceGuard g(device);
+    HostStage st(device);  // the modulus list travels through a pooled staging context (no allocation per call)
+    if (!st.ok()) return PFHE_ERR_HIP;
     void *md = nullptr;
-    PFHE_HIP(hipMalloc(&md, moduli_count * sizeof(u64)));
-    hipError_t e = hipMemcpy(md, moduli, moduli_count * sizeof(u64), hipMemcpyHostToDevice);
-    int rc = PFHE_OK;
-    if (e == hipSuccess) {
-        rc = fill_uniform_dev((u64 *)dst, len, (const u64 *)md, moduli_count, poly_len, seed, (hipStream_t)stream);
-        e = hipStreamSynchronize((hipStream_t)stream);
-    }
-    (void)hipFree(md);
-    if (e != hipSuccess) return hip_fail(e, "fill_uniform", __FILE__, __LINE__);
-    return rc;
+    PFHE_TRY(st.upload(moduli, moduli_count * sizeof(u64), &md));
+    PFHE_TRY(st.finish());
+    PFHE_TRY(fill_uniform_dev((u64 *)dst, len, (const u64 *)md, moduli_count, poly_len, seed, (hipStream_t)stream));
+    PFHE_HIP(hipStreamSynchronize((hipStream_t)stream));  // the list must outlive the kernel
+    return PFHE_OK;
     PFHE_GUARD_END
 }
 

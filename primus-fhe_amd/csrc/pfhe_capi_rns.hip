@@ -9,6 +9,7 @@
 #include "pfhe_capi_internal.hpp"
 #include "pfhe_ntt_device.hpp"
 #include "pfhe_rns.hpp"
+#include "pfhe_staging.hpp"
 
 using namespace pfhe;
 
@@ -46,8 +47,8 @@ struct pfhe_extprod_plan {
         if (sa) (void)hipStreamSynchronize(sa);
         if (sb) (void)hipStreamSynchronize(sb);
         for (u64 *d : digits)
-            if (d) (void)hipFree(d);
-        if (sdigits) (void)hipFree(sdigits);
+            if (d) (void)counted_free(d);
+        if (sdigits) (void)counted_free(sdigits);
         for (hipEvent_t e : {fork, join_a, join_b, produced[0], produced[1], consumed[0], consumed[1]})
             if (e) (void)hipEventDestroy(e);
         if (sa) (void)hipStreamDestroy(sa);
@@ -56,26 +57,6 @@ struct pfhe_extprod_plan {
 };
 
 namespace {
-
-// temporary device buffers for the host-pointer convenience entry points
-struct Staging {
-    std::vector<void *> bufs;
-    ~Staging() {
-        for (void *p : bufs) (void)hipFree(p);
-    }
-    int alloc(size_t bytes, void **out) {
-        *out = nullptr;
-        if (bytes == 0) bytes = 8;
-        PFHE_HIP(hipMalloc(out, bytes));
-        bufs.push_back(*out);
-        return PFHE_OK;
-    }
-    int upload(const void *host, size_t bytes, void **out) {
-        PFHE_TRY(alloc(bytes, out));
-        if (bytes) PFHE_HIP(hipMemcpy(*out, host, bytes, hipMemcpyHostToDevice));
-        return PFHE_OK;
-    }
-};
 
 int plan_check(const pfhe_extprod_plan *p) {
     if (!p || !p->table) return PFHE_ERR_BAD_ARGUMENT;
@@ -261,13 +242,14 @@ int pfhe_rns_compose_multiple_values_to(const pfhe_rns *r, const uint64_t *multi
     if (value_count == 0) return PFHE_OK;
     DeviceGuard g(r->h.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    Staging st;
+    HostStage st(r->h.device);  // pooled staging context: no allocation in steady state
+    if (!st.ok()) return PFHE_ERR_HIP;
     void *in = nullptr, *o = nullptr;
     PFHE_TRY(st.upload(multi_residues, len_in * 8, &in));
     PFHE_TRY(st.alloc(len_out * 8, &o));
-    PFHE_TRY(rns_compose_dev(r->h.dev, (const u64 *)in, (u64 *)o, value_count, nullptr));
-    PFHE_HIP(hipMemcpy(big_uint_values, o, len_out * 8, hipMemcpyDeviceToHost));
-    return PFHE_OK;
+    PFHE_TRY(rns_compose_dev(r->h.dev, (const u64 *)in, (u64 *)o, value_count, st.stream()));
+    PFHE_TRY(st.download(big_uint_values, o, len_out * 8));
+    return st.finish();
     PFHE_GUARD_END
 }
 
@@ -299,14 +281,15 @@ int pfhe_rns_wrapping_decompose_small_values_to(const pfhe_rns *r, const uint64_
     if (value_count == 0) return PFHE_OK;
     DeviceGuard g(r->h.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    Staging st;
+    HostStage st(r->h.device);  // pooled staging context: no allocation in steady state
+    if (!st.ok()) return PFHE_ERR_HIP;
     void *in = nullptr, *o = nullptr;
     PFHE_TRY(st.upload(small_values, value_count * 8, &in));
     PFHE_TRY(st.alloc(len_out * 8, &o));
     PFHE_TRY(pfhe_rns_wrapping_decompose_small_values_to_dev(r, (const uint64_t *)in, value_count, (uint64_t *)o,
-                                                             len_out, small_value_modulus, nullptr));
-    PFHE_HIP(hipMemcpy(multi_residues, o, len_out * 8, hipMemcpyDeviceToHost));
-    return PFHE_OK;
+                                                             len_out, small_value_modulus, st.stream()));
+    PFHE_TRY(st.download(multi_residues, o, len_out * 8));
+    return st.finish();
     PFHE_GUARD_END
 }
 
@@ -357,14 +340,15 @@ static int add_scaled_host(const pfhe_rns *r, const uint64_t *small_values, size
     if (value_count == 0) return PFHE_OK;
     DeviceGuard g(r->h.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    Staging st;
+    HostStage st(r->h.device);  // pooled staging context: no allocation in steady state
+    if (!st.ok()) return PFHE_ERR_HIP;
     void *in = nullptr, *a = nullptr;
     PFHE_TRY(st.upload(small_values, value_count * 8, &in));
     PFHE_TRY(st.upload(acc, len_acc * 8, &a));
     PFHE_TRY(add_scaled_common(r, (const uint64_t *)in, value_count, (uint64_t *)a, len_acc, small_value_modulus, centred,
-                               factors, nullptr));
-    PFHE_HIP(hipMemcpy(acc, a, len_acc * 8, hipMemcpyDeviceToHost));
-    return PFHE_OK;
+                               factors, st.stream()));
+    PFHE_TRY(st.download(acc, a, len_acc * 8));
+    return st.finish();
 }
 
 int pfhe_rns_add_wrapping_decompose_small_values_scaled(const pfhe_rns *r, const uint64_t *small_values,
@@ -434,14 +418,15 @@ int pfhe_basis_init_value_carry_slice_inplace(const pfhe_basis *b, uint64_t *val
     if (count == 0) return PFHE_OK;
     DeviceGuard g(b->h.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    Staging st;
+    HostStage st(b->h.device);  // pooled staging context: no allocation in steady state
+    if (!st.ok()) return PFHE_ERR_HIP;
     void *v = nullptr, *c = nullptr;
     PFHE_TRY(st.upload(values, len * 8, &v));
     PFHE_TRY(st.alloc(count, &c));
-    PFHE_TRY(basis_init_value_carry_dev(b->h.dev, (u64 *)v, (unsigned char *)c, count, nullptr));
-    PFHE_HIP(hipMemcpy(values, v, len * 8, hipMemcpyDeviceToHost));
-    PFHE_HIP(hipMemcpy(carries, c, count, hipMemcpyDeviceToHost));
-    return PFHE_OK;
+    PFHE_TRY(basis_init_value_carry_dev(b->h.dev, (u64 *)v, (unsigned char *)c, count, st.stream()));
+    PFHE_TRY(st.download(values, v, len * 8));
+    PFHE_TRY(st.download(carries, c, count));
+    return st.finish();
     PFHE_GUARD_END
 }
 
@@ -468,16 +453,17 @@ int pfhe_basis_unsigned_decompose_slice_to(const pfhe_basis *b, size_t level, co
     if (count == 0) return PFHE_OK;
     DeviceGuard g(b->h.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    Staging st;
+    HostStage st(b->h.device);  // pooled staging context: no allocation in steady state
+    if (!st.ok()) return PFHE_ERR_HIP;
     void *v = nullptr, *d = nullptr, *c = nullptr;
     PFHE_TRY(st.upload(values, len * 8, &v));
     PFHE_TRY(st.alloc(count * 8, &d));
     PFHE_TRY(st.upload(carries, count, &c));
     PFHE_TRY(basis_unsigned_decompose_dev(b->h.dev, (u32)level, (const u64 *)v, (u64 *)d, (unsigned char *)c, count,
-                                          nullptr));
-    PFHE_HIP(hipMemcpy(digits, d, count * 8, hipMemcpyDeviceToHost));
-    PFHE_HIP(hipMemcpy(carries, c, count, hipMemcpyDeviceToHost));
-    return PFHE_OK;
+                                          st.stream()));
+    PFHE_TRY(st.download(digits, d, count * 8));
+    PFHE_TRY(st.download(carries, c, count));
+    return st.finish();
     PFHE_GUARD_END
 }
 
@@ -533,16 +519,17 @@ int pfhe_basis_decompose_slice_to(const pfhe_basis *b, size_t level, const uint6
     if (count == 0) return PFHE_OK;
     DeviceGuard g(b->h.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    Staging st;
+    HostStage st(b->h.device);  // pooled staging context: no allocation in steady state
+    if (!st.ok()) return PFHE_ERR_HIP;
     void *v = nullptr, *d = nullptr, *c = nullptr;
     PFHE_TRY(st.upload(values, len * 8, &v));
     PFHE_TRY(st.alloc(len * 8, &d));
     PFHE_TRY(st.upload(carries, count, &c));
     PFHE_TRY(basis_signed_decompose_dev(b->h.rns, b->h.dev, (u32)level, (const u64 *)v, (u64 *)d, (unsigned char *)c, count,
-                                        nullptr));
-    PFHE_HIP(hipMemcpy(decomposed, d, len * 8, hipMemcpyDeviceToHost));
-    PFHE_HIP(hipMemcpy(carries, c, count, hipMemcpyDeviceToHost));
-    return PFHE_OK;
+                                        st.stream()));
+    PFHE_TRY(st.download(decomposed, d, len * 8));
+    PFHE_TRY(st.download(carries, c, count));
+    return st.finish();
     PFHE_GUARD_END
 }
 
@@ -598,7 +585,7 @@ int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *rns, const 
     if (const char *e = std::getenv("PFHE_FUSED_MIN_WGS")) p->fused_min_wgs = (u64)std::max(1, std::atoi(e));
     for (int i = 0; i < 2; ++i) {
         void *d = nullptr;
-        if (i == 0 || p->pipeline) PFHE_HIP(hipMalloc(&d, p->digits_words * sizeof(u64)));
+        if (i == 0 || p->pipeline) PFHE_HIP(counted_malloc(&d, p->digits_words * sizeof(u64)));
         p->digits[i] = (u64 *)d;
         PFHE_HIP(hipEventCreateWithFlags(&p->produced[i], hipEventDisableTiming));
         PFHE_HIP(hipEventCreateWithFlags(&p->consumed[i], hipEventDisableTiming));
@@ -607,7 +594,7 @@ int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *rns, const 
          std::getenv("PFHE_DISABLE_SPLIT_DECOMPOSE") == nullptr) ||
         extprod_small_supported(t->log_n, p->k, p->rns.value_len, p->basis.log_basis)) {
         void *d = nullptr;
-        PFHE_HIP(hipMalloc(&d, p->chunk * (p->k + 1) * p->basis.ell * t->n * sizeof(int)));
+        PFHE_HIP(counted_malloc(&d, p->chunk * (p->k + 1) * p->basis.ell * t->n * sizeof(int)));
         p->sdigits = (int *)d;
     }
     PFHE_HIP(hipStreamCreateWithFlags(&p->sa, hipStreamNonBlocking));
@@ -797,15 +784,16 @@ int pfhe_extprod_mul_dcrt_ggsw_to(pfhe_extprod_plan *plan, const uint64_t *crt_g
     if ((!crt_glwe || !dcrt_ggsw || !result) && len_glwe) return PFHE_ERR_BAD_ARGUMENT;
     DeviceGuard g(plan->table->device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    Staging st;
+    HostStage st(plan->table->device);  // pooled staging context: no allocation in steady state
+    if (!st.ok()) return PFHE_ERR_HIP;
     void *a = nullptr, *k = nullptr, *r = nullptr;
     PFHE_TRY(st.upload(crt_glwe, len_glwe * 8, &a));
     PFHE_TRY(st.upload(dcrt_ggsw, len_ggsw * 8, &k));
     PFHE_TRY(st.alloc(len_result * 8, &r));
     PFHE_TRY(pfhe_extprod_mul_dcrt_ggsw_to_dev(plan, (const uint64_t *)a, len_glwe, (const uint64_t *)k, len_ggsw,
-                                               (uint64_t *)r, len_result, into_coeff_form, nullptr));
-    if (len_result) PFHE_HIP(hipMemcpy(result, r, len_result * 8, hipMemcpyDeviceToHost));
-    return PFHE_OK;
+                                               (uint64_t *)r, len_result, into_coeff_form, st.stream()));
+    PFHE_TRY(st.download(result, r, len_result * 8));
+    return st.finish();
     PFHE_GUARD_END
 }
 

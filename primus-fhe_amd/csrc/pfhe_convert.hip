@@ -18,6 +18,7 @@
 #include "pfhe_capi_internal.hpp"
 #include "pfhe_modmath.hpp"
 #include "pfhe_rns.hpp"
+#include "pfhe_staging.hpp"
 
 namespace pfhe {
 
@@ -249,22 +250,17 @@ static int conv_host(const pfhe_conv *c, const uint64_t *in, size_t len_in, uint
     if (poly_length == 0) return PFHE_OK;
     DeviceGuard g(c->device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    HostStage st(c->device);  // pooled staging context: no allocation in steady state
+    if (!st.ok()) return PFHE_ERR_HIP;
     void *din = nullptr, *dout = nullptr;
-    PFHE_HIP(hipMalloc(&din, len_in * 8));
-    hipError_t e = hipMalloc(&dout, len_out * 8);
-    int rc = PFHE_OK;
-    if (e == hipSuccess) e = hipMemcpy(din, in, len_in * 8, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        rc = exact ? pfhe_conv_exact_convert_array_dev(c, (const uint64_t *)din, len_in, (uint64_t *)dout, len_out,
-                                                       poly_length, nullptr)
+    PFHE_TRY(st.upload(in, len_in * 8, &din));
+    PFHE_TRY(st.alloc(len_out * 8, &dout));
+    PFHE_TRY(exact ? pfhe_conv_exact_convert_array_dev(c, (const uint64_t *)din, len_in, (uint64_t *)dout, len_out,
+                                                       poly_length, st.stream())
                    : pfhe_conv_fast_convert_array_dev(c, (const uint64_t *)din, len_in, (uint64_t *)dout, len_out,
-                                                      poly_length, nullptr);
-        if (rc == PFHE_OK) e = hipMemcpy(out, dout, len_out * 8, hipMemcpyDeviceToHost);
-    }
-    (void)hipFree(din);
-    if (dout) (void)hipFree(dout);
-    if (e != hipSuccess) return hip_fail(e, "base conversion staging", __FILE__, __LINE__);
-    return rc;
+                                                      poly_length, st.stream()));
+    PFHE_TRY(st.download(out, dout, len_out * 8));
+    return st.finish();
 }
 
 int pfhe_conv_fast_convert_array(const pfhe_conv *c, const uint64_t *crt_poly_in, size_t len_in, uint64_t *crt_poly_out,
@@ -308,20 +304,15 @@ int pfhe_rns_decompose_big_uint_values_to(const pfhe_rns *r, const uint64_t *big
     if (value_count == 0) return PFHE_OK;
     DeviceGuard g(r->h.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    HostStage st(r->h.device);
+    if (!st.ok()) return PFHE_ERR_HIP;
     void *din = nullptr, *dout = nullptr;
-    PFHE_HIP(hipMalloc(&din, len_in * 8));
-    hipError_t e = hipMalloc(&dout, len_out * 8);
-    int rc = PFHE_OK;
-    if (e == hipSuccess) e = hipMemcpy(din, big_uint_values, len_in * 8, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        rc = pfhe_rns_decompose_big_uint_values_to_dev(r, (const uint64_t *)din, len_in, (uint64_t *)dout, len_out,
-                                                       value_count, nullptr);
-        if (rc == PFHE_OK) e = hipMemcpy(multi_residues, dout, len_out * 8, hipMemcpyDeviceToHost);
-    }
-    (void)hipFree(din);
-    if (dout) (void)hipFree(dout);
-    if (e != hipSuccess) return hip_fail(e, "decompose staging", __FILE__, __LINE__);
-    return rc;
+    PFHE_TRY(st.upload(big_uint_values, len_in * 8, &din));
+    PFHE_TRY(st.alloc(len_out * 8, &dout));
+    PFHE_TRY(pfhe_rns_decompose_big_uint_values_to_dev(r, (const uint64_t *)din, len_in, (uint64_t *)dout, len_out,
+                                                       value_count, st.stream()));
+    PFHE_TRY(st.download(multi_residues, dout, len_out * 8));
+    return st.finish();
     PFHE_GUARD_END
 }
 

@@ -19,6 +19,7 @@
 
 #include "pfhe_capi_internal.hpp"
 #include "pfhe_modmath.hpp"
+#include "pfhe_staging.hpp"
 #include "../../include/pfhe.h"
 
 namespace pfhe {
@@ -430,7 +431,7 @@ int pfhe_dcrt_mul_monomial_assign_dev(const pfhe_dcrt *table, uint64_t *data_dev
     const size_t tile = std::max<size_t>(unit, (((size_t)1 << 27) / unit) * unit);  // words
     const size_t scratch_words = std::min(tile, len);
     u64 *scratch = nullptr;
-    PFHE_HIP(hipMallocAsync((void **)&scratch, scratch_words * sizeof(u64), s));
+    PFHE_HIP(counted_malloc_async((void **)&scratch, scratch_words * sizeof(u64), s));
     int st = PFHE_OK;
     for (size_t off = 0; off < len && st == PFHE_OK; off += tile) {
         const size_t w = std::min(tile, len - off);
@@ -438,7 +439,7 @@ int pfhe_dcrt_mul_monomial_assign_dev(const pfhe_dcrt *table, uint64_t *data_dev
         if (st == PFHE_OK && hipMemcpyAsync(data_dev + off, scratch, w * sizeof(u64), hipMemcpyDeviceToDevice, s) != hipSuccess)
             st = PFHE_ERR_HIP;
     }
-    (void)hipFreeAsync(scratch, s);
+    (void)counted_free_async(scratch, s);
     return st;
     PFHE_GUARD_END
 }
@@ -456,7 +457,7 @@ int pfhe_dcrt_inv_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, uint64_t
         return PFHE_ERR_UNSUPPORTED;
     }
     unsigned int *flag = nullptr;
-    PFHE_HIP(hipMallocAsync((void **)&flag, sizeof(unsigned int), s));
+    PFHE_HIP(counted_malloc_async((void **)&flag, sizeof(unsigned int), s));
     PFHE_HIP(hipMemsetAsync(flag, 0, sizeof(unsigned int), s));
     const dim3 th(kEwThreads);
     if (t.log_n >= 4) {
@@ -470,7 +471,7 @@ int pfhe_dcrt_inv_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, uint64_t
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(&host_flag, flag, sizeof(unsigned int), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFreeAsync(flag, s);
+    (void)counted_free_async(flag, s);
     PFHE_HIP(e);
     if (host_flag) {
         set_last_error("an element has no inverse (zero residue)");

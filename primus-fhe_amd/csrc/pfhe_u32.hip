@@ -8,6 +8,7 @@
 // streaming kernels on u32 data (pointwise products, monomial transforms, synthetic fill) and the
 // extern "C" entry points.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -18,6 +19,7 @@
 #include "pfhe_modmath.hpp"
 #include "pfhe_ntt_device.hpp"
 #include "pfhe_pointwise.hpp"
+#include "pfhe_staging.hpp"
 
 namespace pfhe {
 
@@ -173,7 +175,7 @@ int make_table_set32(u32 log_n, const u32 *moduli, size_t count, int device, std
             const auto &src = dir == 0 ? host[i].fwd : host[i].inv;
             for (size_t k = 0; k < n; ++k) packed[k] = src[k].x | (((src[k].x << 32) / q) << 32);
             void *d = nullptr;
-            PFHE_HIP(hipMalloc(&d, n * sizeof(u64)));
+            PFHE_HIP(counted_malloc(&d, n * sizeof(u64)));
             ts->allocations.push_back(d);
             PFHE_HIP(hipMemcpy(d, packed.data(), n * sizeof(u64), hipMemcpyHostToDevice));
             // the word kernels index the inverse table in units of words: bias it by N/2 entries
@@ -184,7 +186,7 @@ int make_table_set32(u32 log_n, const u32 *moduli, size_t count, int device, std
         ts->inv_roots.push_back(host[i].inv_root);
     }
     void *pd = nullptr;
-    PFHE_HIP(hipMalloc(&pd, count * sizeof(NttPrime)));
+    PFHE_HIP(counted_malloc(&pd, count * sizeof(NttPrime)));
     ts->allocations.push_back(pd);
     PFHE_HIP(hipMemcpy(pd, ts->primes.data(), count * sizeof(NttPrime), hipMemcpyHostToDevice));
     ts->primes_dev = static_cast<const NttPrime *>(pd);
@@ -204,30 +206,33 @@ int transform32_dev(const TableSet &t, u32 *data, size_t len, bool inverse, bool
     return ntt32_transform_dev(t.primes_dev, t.L, t.log_n, data, units * t.L, inverse, lazy, s, t.tune);
 }
 
-template <class F>
-int with_staged32(const TableSet &t, u32 *host, size_t len, bool copy_in, F &&f) {
+// host-pointer form: pooled staging context, slice pinned in place, pieces of whole units pipelined over its two
+// streams (see transform_host in pfhe_capi.hip)
+int transform32_host(const TableSet &t, u32 *host, size_t len, bool inverse, bool lazy) {
     if (!host && len) return PFHE_ERR_BAD_ARGUMENT;
     u64 units = 0;
     PFHE_TRY(check_len32(t, len, units));
     if (len == 0) return PFHE_OK;
     DeviceGuard g(t.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    void *d = nullptr;
-    PFHE_HIP(hipMalloc(&d, len * sizeof(u32)));
-    int rc = PFHE_OK;
-    hipError_t e = hipSuccess;
-    if (copy_in) e = hipMemcpy(d, host, len * sizeof(u32), hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        rc = f(static_cast<u32 *>(d));
-        if (rc == PFHE_OK) e = hipMemcpy(host, d, len * sizeof(u32), hipMemcpyDeviceToHost);
+    HostStage st(t.device);
+    if (!st.ok()) return PFHE_ERR_HIP;
+    void *dv = nullptr;
+    PFHE_TRY(st.alloc(len * sizeof(u32), &dv));
+    u32 *d = static_cast<u32 *>(dv);
+    const size_t unit = t.n * t.L;
+    const bool pinned = st.pin(host, len * sizeof(u32));
+    const size_t per = pinned ? std::max<size_t>(1, stage_chunk_bytes() / (unit * sizeof(u32))) : (size_t)units;
+    const bool pipelined = per < units;
+    const hipStream_t s_in = st.stream(), s_run = pipelined ? st.stream2() : st.stream();
+    for (u64 u0 = 0; u0 < units; u0 += per) {
+        const size_t words = (size_t)std::min<u64>(per, units - u0) * unit, off = (size_t)u0 * unit;
+        PFHE_TRY(st.copy_in(d + off, host + off, words * sizeof(u32), s_in));
+        if (pipelined) PFHE_TRY(st.order(s_in, s_run));
+        PFHE_TRY(transform32_dev(t, d + off, words, inverse, lazy, s_run));
+        PFHE_TRY(st.download(host + off, d + off, words * sizeof(u32), s_run));
     }
-    (void)hipFree(d);
-    if (e != hipSuccess) return hip_fail(e, "staged copy", __FILE__, __LINE__);
-    return rc;
-}
-
-int transform32_host(const TableSet &t, u32 *host, size_t len, bool inverse, bool lazy) {
-    return with_staged32(t, host, len, true, [&](u32 *d) { return transform32_dev(t, d, len, inverse, lazy, nullptr); });
+    return st.finish();
 }
 
 int pointwise32(const TableSet &t, int mode, u32 *acc, const u32 *a, size_t len_a, const u32 *b, size_t len_b,
@@ -282,7 +287,13 @@ int monomial32(const TableSet &t, u32 coeff, size_t degree, u32 *values, size_t 
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
     const u64 deg = (u64)degree & (2 * (u64)t.n - 1);
     void *out_dev = values;
-    if (host) PFHE_HIP(hipMalloc(&out_dev, len * sizeof(u32)));
+    std::unique_ptr<HostStage> st;
+    if (host) {  // pooled staging context: no allocation in steady state, the caller's stream is not involved
+        st = std::make_unique<HostStage>(t.device);
+        if (!st->ok()) return PFHE_ERR_HIP;
+        PFHE_TRY(st->alloc(len * sizeof(u32), &out_dev));
+        s = st->stream();
+    }
     hipError_t e = hipSuccess;
     for (size_t gi = 0; gi < groups.size() && e == hipSuccess; ++gi) {
         const u32 l0 = (u32)gi * kMaxMonomialLimbs, lg = std::min<u32>(kMaxMonomialLimbs, t.L - l0);
@@ -290,10 +301,9 @@ int monomial32(const TableSet &t, u32 coeff, size_t degree, u32 *values, size_t 
                            static_cast<u32 *>(out_dev) + (size_t)l0 * t.n, t.primes_dev + l0, lg, t.log_n, deg, groups[gi]);
         e = hipGetLastError();
     }
-    if (host) {  // the device form is these launches (capturable); only the host form copies back and waits
-        if (e == hipSuccess) e = hipMemcpyAsync(values, out_dev, len * sizeof(u32), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        (void)hipFree(out_dev);
+    if (host && e == hipSuccess) {  // the device form is these launches (capturable); only the host form copies back and waits
+        PFHE_TRY(st->download(values, out_dev, len * sizeof(u32)));
+        return st->finish();
     }
     if (e != hipSuccess) return hip_fail(e, "monomial transform", __FILE__, __LINE__);
     return PFHE_OK;

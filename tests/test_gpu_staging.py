@@ -1,0 +1,142 @@
+"""Host-pointer (`*_slice`, `*_to`) entry points: the reference's methods take `&self, &mut [T]` and allocate nothing
+per call (primus_ntt/src/ntt/prime64/table.rs:541-563, SURVEY §8b "no hidden allocation per call").  The C ABI's
+host-pointer forms stage through a per-device pool of contexts (csrc/pfhe_staging.hpp): steady-state calls must not
+allocate, concurrent callers must not share a context, long slices are cut into pieces, and every result stays
+bit-exact."""
+import threading
+
+import numpy as np
+import pytest
+
+from gpu_util import rand_mod, rand_rns
+from pyref import Q61, Q62
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pf():
+    import primus_fhe_amd as p
+    return p
+
+
+def alloc_count(pf):
+    return int(pf.lib().pfhe_debug_alloc_count())
+
+
+def test_steady_state_slice_calls_do_not_allocate(pf, orc):
+    log_n = 16
+    n = 1 << log_n
+    t, o = pf.U64NttTable(log_n, Q61[0]), orc.U64NttTable(log_n, Q61[0])
+    d, od = pf.U64DcrtTable(log_n, Q61), orc.U64DcrtTable(log_n, Q61)
+    rng = np.random.default_rng(5)
+    a = rand_mod(rng, Q61[0], n)
+    r = rand_rns(rng, Q61, n, 2)
+    ref_a = a.copy(); o.transform_slice(ref_a)
+    ref_r = r.copy(); od.transform_slice(ref_r)
+    # warm-up: the pool grows to the largest call
+    x = r.copy(); d.transform_slice(x); d.inverse_transform_slice(x)
+    x = a.copy(); t.transform_slice(x)
+    before = alloc_count(pf)
+    for _ in range(100):
+        x = a.copy()
+        t.transform_slice(x)
+        assert np.array_equal(x, ref_a)
+        t.inverse_transform_slice(x)
+        assert np.array_equal(x, a)
+    for _ in range(10):
+        y = r.copy()
+        d.transform_slice(y)
+        assert np.array_equal(y, ref_r)
+        d.lazy_inverse_transform_slice(y)
+        assert np.array_equal(y % np.tile(np.repeat(np.array(Q61, dtype=np.uint64), n), 2), r)
+    assert alloc_count(pf) == before, "host-pointer calls allocated in steady state"
+
+
+def test_steady_state_u32_converter_and_rns_calls_do_not_allocate(pf, orc):
+    q30 = [1073479681, 1071513601, 1070727169]
+    log_n = 13
+    n = 1 << log_n
+    rng = np.random.default_rng(6)
+    d32, o32 = pf.U32DcrtTable(log_n, q30), orc.U32DcrtTable(log_n, q30)
+    a32 = np.concatenate([rng.integers(0, q, n, dtype=np.uint64).astype(np.uint32) for q in q30])
+    ref32 = a32.copy(); o32.transform_slice(ref32)
+    base, obase = pf.RNSBase(Q61), orc.RNSBase(Q61)
+    res = rand_rns(rng, Q61, n, 1)
+    ref_big = obase.compose_multiple_values_to(res, n)
+
+    def once():
+        x = a32.copy(); d32.transform_slice(x)
+        assert np.array_equal(x, ref32)
+        big = np.empty(n * base.big_uint_value_len(), np.uint64)
+        base.compose_multiple_values_to(res, big, n)
+        assert np.array_equal(big, ref_big)
+
+    once()
+    before = alloc_count(pf)
+    for _ in range(20):
+        once()
+    assert alloc_count(pf) == before
+
+
+def test_long_slice_is_cut_into_pieces_and_stays_exact(pf, orc):
+    """47 RNS polynomials of 2^14 (17.6 MiB) exceed one piece (PFHE_STAGE_CHUNK, 8 MiB by default): the slice is pinned in
+    place, one stream copies the pieces in, the other transforms each and copies it back; ragged last piece."""
+    log_n, batch = 14, 47
+    n = 1 << log_n
+    d, o = pf.U64DcrtTable(log_n, Q61), orc.U64DcrtTable(log_n, Q61)
+    rng = np.random.default_rng(7)
+    a = rand_rns(rng, Q61, n, batch)
+    assert a.nbytes > (16 << 20)
+    ref = a.copy(); o.transform_slice(ref)
+    x = a.copy(); d.transform_slice(x)
+    assert np.array_equal(x, ref)
+    d.inverse_transform_slice(x)
+    assert np.array_equal(x, a)
+
+
+def test_concurrent_host_slice_callers_get_their_own_context(pf, orc):
+    """NttTable: Send + Sync (ntt/mod.rs:16): four host threads call transform_slice on one table at once."""
+    log_n = 15
+    n = 1 << log_n
+    t, o = pf.U64NttTable(log_n, Q62), orc.U64NttTable(log_n, Q62)
+    rng = np.random.default_rng(8)
+    inputs = [rand_mod(rng, Q62, n * (i + 1)) for i in range(4)]
+    refs = []
+    for a in inputs:
+        r = a.copy(); o.transform_slice(r); refs.append(r)
+    errors = []
+
+    def worker(i):
+        try:
+            for _ in range(25):
+                x = inputs[i].copy()
+                t.transform_slice(x)
+                if not np.array_equal(x, refs[i]):
+                    raise AssertionError(f"thread {i}: forward mismatch")
+                t.inverse_transform_slice(x)
+                if not np.array_equal(x, inputs[i]):
+                    raise AssertionError(f"thread {i}: round trip mismatch")
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    [th.start() for th in threads]
+    [th.join() for th in threads]
+    assert not errors, errors
+    # one thread now: every call takes the context on top of the pool, which grows to the largest slice once
+    [worker(i) for i in range(4)]
+    before = alloc_count(pf)
+    [worker(i) for i in range(4)]
+    assert not errors and alloc_count(pf) == before
+
+
+def test_staging_release_returns_the_pool(pf):
+    t = pf.U64NttTable(12, Q61[0])
+    x = np.arange(1 << 12, dtype=np.uint64)
+    t.transform_slice(x)
+    assert pf.lib().pfhe_staging_release(-1) >= 1
+    before = alloc_count(pf)
+    t.inverse_transform_slice(x)   # the pool grows again
+    assert np.array_equal(x, np.arange(1 << 12, dtype=np.uint64))
+    assert alloc_count(pf) > before
