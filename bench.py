@@ -41,7 +41,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 
 def parse_args():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="GPUs (= ranks) of one node; default: WORLD_SIZE when a launcher "
+                    "set it, else 1")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="RNS polynomials per GPU (default: BASELINE config 3')")
@@ -52,6 +53,8 @@ def parse_args():
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for the timing barrier "
                     "(nccl = RCCL; gloo + --one-device lets two ranks share one GPU for a plumbing check)")
     ap.add_argument("--one-device", action="store_true", help="debug: every rank uses cuda:0")
+    ap.add_argument("--skip-device-check", action="store_true", help="when bench.py spawns the ranks itself: do not count "
+                    "the visible GPUs first (a rank whose GPU is missing fails by itself and ends its peers)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank (test aid: "
                     "exercises the RCCL barrier / max-reduce on a 1-GPU box)")
     ap.add_argument("--dump-dir", default="", help="parity aid for tests/test_gpu_shard.py: every rank writes the HIP "
@@ -60,7 +63,10 @@ def parse_args():
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when bench.py spawns the ranks itself")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.gpus is None:  # `torchrun --nproc-per-node N bench.py` without --gpus
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
+    return args
 
 
 def cpu_baseline(seconds: float):
@@ -204,14 +210,57 @@ def cpu_baseline(seconds: float):
     return out
 
 
+def git_blob_hash(path: str) -> str:
+    """The id `git hash-object` gives the file: names the exact committed profile a traffic figure was read from."""
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+_BUILT_KERNELS = None
+
+
+def built_vgprs(kernel: str):
+    """vgpr_count of `kernel` in the libpfhe_hip.so this run loads (its code objects' metadata), or None."""
+    global _BUILT_KERNELS
+    if _BUILT_KERNELS is None:
+        try:
+            import primus_fhe_amd as p
+            from primus_fhe_amd._codeobj import kernel_resources
+            _BUILT_KERNELS = kernel_resources(p.library_path())
+        except Exception:
+            _BUILT_KERNELS = {}
+    r = _BUILT_KERNELS.get(kernel)
+    return None if r is None else (r["vgpr"] or 0) + (r["agpr"] or 0)
+
+
+def provenance(path: str, profiled: dict):
+    """A committed counter profile describes the kernels it was taken on.  Its figures are reported only when every
+    kernel it covers still has, in the library being timed, the register count the profiler recorded (rocprofv3's
+    VGPR_Count column, rounded to the allocation granule of 8 as the code object's .vgpr_count is not): a changed kernel
+    makes the profile stale and the traffic null.  Returns (fields for the JSON line, ok)."""
+    rows = {}
+    ok = bool(profiled)
+    for k, v in (profiled or {}).items():
+        now = built_vgprs(k)
+        rows[k] = {"profiled_vgpr_count": v, "built_vgpr_count": now}
+        if v is None or now is None or -(-now // 8) * 8 != -(-v // 8) * 8:
+            ok = False
+    return {"profile": os.path.basename(path), "profile_git_blob": git_blob_hash(path), "kernels_checked": rows,
+            "profile_matches_build": ok}, ok
+
+
 def extprod_traffic():
     """Whole-product HBM bytes per external product from the newest committed counter passes
-    (profiles/*_extprod_traffic.json, written by tools/collect_profiles2.py), or None."""
+    (profiles/*_extprod_traffic.json, written by tools/collect_profiles2.py) — or None when there is none, or when the
+    kernels it was taken on are not the ones in the library being timed (provenance)."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_extprod_traffic.json")), reverse=True):
         try:
             d = json.load(open(path))
-            return {"bytes_per_product": float(d["bytes_per_product"]), "source": os.path.basename(path), "method": d["method"]}
+            prov, ok = provenance(path, d.get("vgpr_count_by_kernel"))
+            return {"bytes_per_product": float(d["bytes_per_product"]) if ok else None, "source": os.path.basename(path),
+                    "method": d["method"], "provenance": prov}
         except Exception:
             continue
     return None
@@ -220,7 +269,9 @@ def extprod_traffic():
 def pmc_traffic(kernel: str, batch: int):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 +
     WRITE_SIZE, separate --pmc runs of tools/profile_ntt.py at this shape; profiles/*_rocprof.json).
-    bench.py cannot collect counters itself; null when no matching profile is committed."""
+    bench.py cannot collect counters itself: the figure is READ FROM A COMMITTED PROFILE, named in `traffic_source` with its
+    git blob id, and is null when no profile of this launch shape is committed or when the profiled kernel's register
+    count differs from the one in the library being timed (provenance)."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof.json")), reverse=True):
         try:
@@ -242,8 +293,9 @@ def pmc_traffic(kernel: str, batch: int):
             tile_units = -(-batch // 24)
             if sel and max(r["grid_size"] for r in sel) == tile_units * 3 * 16 * 256:
                 launches = sum(r["launches"] for r in sel)
-                return {"bytes_per_launch": sum(r["hbm_bytes_per_launch"] * r["launches"] for r in sel) / launches,
-                        "source": os.path.basename(path),
+                prov, ok = provenance(path, {r["kernel"]: r.get("vgpr_count") for r in sel})
+                return {"bytes_per_launch": sum(r["hbm_bytes_per_launch"] * r["launches"] for r in sel) / launches if ok else None,
+                        "source": os.path.basename(path), "provenance": prov,
                         "method": "2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes (MI355X_MICROARCH.md, HBM), "
                                   "averaged over the %d launches profiled" % launches}
             continue
@@ -269,21 +321,24 @@ def pmc_traffic(kernel: str, batch: int):
         # strided pass = N/32 threads per polynomial
         want_grid = batch * 3 * ((1 << LOG_N) // 16 if "block" in want else (1 << LOG_N) // 32)
         if best and best["grid_size"] == want_grid:
-            return {"bytes_per_launch": best["hbm_bytes_per_launch"], "source": os.path.basename(path),
+            prov, ok = provenance(path, {best["kernel"]: best.get("vgpr_count")})
+            return {"bytes_per_launch": best["hbm_bytes_per_launch"] if ok else None, "source": os.path.basename(path),
+                    "provenance": prov,
                     "method": "2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes (MI355X_MICROARCH.md, HBM)"}
     return None
 
 
 def spawn_ranks(args) -> int:
     """`python bench.py --gpus N` outside a launcher: start N fresh rank processes (one per GPU, the
-    environment torch.distributed.run would give them) and relay rank 0's JSON line.  Decided before
-    anything in this process touches the GPU; the parent never initialises HIP and never execs."""
+    environment torch.distributed.run would give them) and relay rank 0's JSON line.  The parent never execs and runs
+    no GPU work; counting the visible devices (skipped under --skip-device-check or --one-device) may initialise the HIP
+    runtime in the parent, which is harmless because every rank is a fresh child process."""
     import socket
     import subprocess
 
-    if not args.one_device:
+    if not args.one_device and not args.skip_device_check:
         import torch
-        have = torch.cuda.device_count()  # counting devices does not initialise the GPU
+        have = torch.cuda.device_count()  # (falls back to hipGetDeviceCount when amdsmi is unavailable)
         if have < args.gpus:
             raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (use --one-device --dist-backend gloo for a "
                              "plumbing check on one GPU)" % (args.gpus, have))
@@ -430,10 +485,11 @@ def main():
                 "frac": dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_batch": dom_bytes,
                 # whole product, every kernel: HBM bytes per product from the committed counter passes x this batch
-                "traffic": traffic["bytes_per_product"] * ep_batch if traffic else None,
+                "traffic": traffic["bytes_per_product"] * ep_batch if traffic and traffic["bytes_per_product"] else None,
                 "traffic_unit": "bytes per batch of %d products, all kernels of the product (coefficient form)" % ep_batch,
-                "traffic_source": (traffic["source"] + ": " + traffic["method"]) if traffic else None,
-                "traffic_vs_algorithmic": traffic["bytes_per_product"] / (96 * n) if traffic else None,
+                "traffic_source": ("from committed profile " + traffic["source"] + ": " + traffic["method"]) if traffic else None,
+                "traffic_provenance": traffic["provenance"] if traffic else None,
+                "traffic_vs_algorithmic": traffic["bytes_per_product"] / (96 * n) if traffic and traffic["bytes_per_product"] else None,
                 "note": "the kernel runs 12 forward block transforms + 72 multiply-accumulates per word + 2 inverse block "
                         "transforms per output block: VALUBusy 80+ % AND ~11x the product's algorithmic bytes in flight "
                         "(the 36 half-transformed digit polynomials are written and read once): loaded on both units "
@@ -503,7 +559,8 @@ def main():
                       # HBM bytes per launch of this kernel from the committed PMC passes (null if none match)
                       "traffic": pmc["bytes_per_launch"] if pmc else None,
                       "traffic_unit": "bytes per launch",
-                      "traffic_source": (pmc["source"] + ": " + pmc["method"]) if pmc else None,
+                      "traffic_source": ("from committed profile " + pmc["source"] + ": " + pmc["method"]) if pmc else None,
+                      "traffic_provenance": pmc["provenance"] if pmc else None,
                       "avg_launch_ms": dom[1], "algorithmic_bytes_per_launch": alg_bytes,
                       "note": "fraction of the HBM roofline as the metric asks; the kernel's own limit is the "
                               "integer ALU and its LDS / twiddle traffic (profiles/r02_*), not HBM"}
@@ -530,7 +587,8 @@ def main():
                                   "unit": "GB/s", "frac": achieved_p / HBM_PEAK_GBS,
                                   "traffic": pmc_p["bytes_per_launch"] if pmc_p else None,
                                   "traffic_unit": "bytes per launch",
-                                  "traffic_source": (pmc_p["source"] + ": " + pmc_p["method"]) if pmc_p else None,
+                                  "traffic_source": ("from committed profile " + pmc_p["source"] + ": " + pmc_p["method"]) if pmc_p else None,
+                                  "traffic_provenance": pmc_p["provenance"] if pmc_p else None,
                                   "avg_launch_ms": ms_launch, "launches_per_step": launches,
                                   "algorithmic_bytes_per_launch": alg_bytes / launches,
                                   "note": "the step's only kernel; it moves every coefficient twice (two-pass plan), so "

@@ -37,7 +37,8 @@ struct pfhe_extprod_plan {
     std::vector<hipEvent_t> *prof = nullptr;
     u64 *digits[2] = {nullptr, nullptr};
     size_t digits_words = 0;  // per buffer
-    int *sdigits = nullptr;   // compact signed digits of one chunk (chunk * (k+1) * ell * N int32), or null
+    void *sdigits = nullptr;  // compact signed digits of one chunk (chunk * (k+1) * ell * N words of sdigit_bytes: int32 when log_basis <= 31, else int64), or null
+    size_t sdigit_bytes = 0;
     hipStream_t sa = nullptr, sb = nullptr;
     hipEvent_t fork = nullptr, join_a = nullptr, join_b = nullptr;
     hipEvent_t produced[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
@@ -91,8 +92,8 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
         batch * t.L >= 1024 && p->use_small) {
         for (u64 done = 0; done < batch; done += p->chunk) {
             const u64 cur = std::min<u64>(p->chunk, batch - done);
-            PFHE_TRY(gadget_signed_digits_dev(rns, p->basis, t.log_n, crt_polys + done * rows * in_words, p->sdigits, cur * rows, s));
-            PFHE_TRY(extprod_small_dev(t.primes_dev, t.L, t.log_n, t.pm, p->k, rows, ell, p->sdigits,
+            PFHE_TRY(gadget_signed_digits_dev(rns, p->basis, t.log_n, crt_polys + done * rows * in_words, (int *)p->sdigits, cur * rows, s));
+            PFHE_TRY(extprod_small_dev(t.primes_dev, t.L, t.log_n, t.pm, p->k, rows, ell, (const int *)p->sdigits,
                                        keys + (keys_shared ? 0 : done * key_words), keys_shared,
                                        result + done * (p->k + 1) * W, cur, accumulate, into_coeff, s));
         }
@@ -103,12 +104,17 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
     hipStream_t sa = single ? s : p->sa, sb = single ? s : p->sb;
     const bool fused = gadget_fused_supported(t.log_n, p->k) && p->use_fused &&
                        ((std::min<u64>(batch, p->chunk) * t.L) << (t.log_n - 12)) >= p->fused_min_wgs;
-    const int passes = ntt_num_passes(t.log_n, t.pm, t.tune);
+    const int passes = ntt_num_passes(t.log_n, t.ntt_arith, t.tune);
+    // Arithmetic of the plain transform passes in here.  The gadget kernels embed Shoup or pseudo-Mersenne butterflies
+    // (selector t.pm); generic primes below 2^61 have the cheaper Montgomery-form transforms (t.ntt_arith), whose
+    // passes may FOLLOW a Shoup pass (they accept values below 8q) but must not precede one (they leave values below
+    // 7q where the Shoup butterflies expect [0, 4q)): so the last digit pass and the result's inverse passes take
+    // t.ntt_arith, and the leading digit passes do unless the fused multiply-accumulate kernel consumes their output.
     // coefficient-form output: the inverse transform's block pass runs inside the fused kernel, on the accumulators
     const bool inv_tail = fused && into_coeff && !accumulate && coeff_passes != nullptr && passes == 2 && p->use_fused_tail;
     if (inv_tail) *coeff_passes = 1;
     const bool fused_decompose = gadget_decompose_strided_supported(t.log_n, p->rns.value_len) &&
-                                 p->use_fused_decompose;
+                                 p->use_fused_decompose && p->sdigits != nullptr;
     if (!single) {
         PFHE_HIP(hipEventRecord(p->fork, s));
         PFHE_HIP(hipStreamWaitEvent(sa, p->fork, 0));
@@ -150,7 +156,8 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
         } else {
             PFHE_TRY(gadget_decompose_dev(rns, p->basis, t.log_n, crt_polys + done * rows * in_words, dg, cur * rows, sa));
             for (int i = 0; i < passes - 1; ++i)
-                PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.pm, dg, npolys, false, i, false, sa, nullptr, 0, t.tune));
+                PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, fused ? (int)t.pm : t.ntt_arith, dg, npolys, false, i, false, sa,
+                                      nullptr, 0, t.tune));
         }
         if (!single) PFHE_HIP(hipEventRecord(p->produced[buf], sa));
         PFHE_TRY(stamp(sa));
@@ -161,7 +168,8 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
                                              keys + (keys_shared ? 0 : done * key_words), keys_shared,
                                              result + done * (p->k + 1) * W, cur, accumulate, sb, inv_tail));
         } else {
-            PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.pm, dg, npolys, false, passes - 1, false, sb, nullptr, 0, t.tune));
+            PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.ntt_arith, dg, npolys, false, passes - 1, false, sb, nullptr, 0,
+                                  t.tune));
         }
         if (!single) PFHE_HIP(hipEventRecord(p->consumed[buf], sb));
         PFHE_TRY(stamp(sb));
@@ -590,12 +598,12 @@ int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *rns, const 
         PFHE_HIP(hipEventCreateWithFlags(&p->produced[i], hipEventDisableTiming));
         PFHE_HIP(hipEventCreateWithFlags(&p->consumed[i], hipEventDisableTiming));
     }
-    if ((gadget_split_decompose_supported(t->log_n, p->rns.value_len, p->basis.log_basis) &&
-         std::getenv("PFHE_DISABLE_SPLIT_DECOMPOSE") == nullptr) ||
+    if ((gadget_decompose_strided_supported(t->log_n, p->rns.value_len) && p->use_fused_decompose) ||
         extprod_small_supported(t->log_n, p->k, p->rns.value_len, p->basis.log_basis)) {
         void *d = nullptr;
-        PFHE_HIP(counted_malloc(&d, p->chunk * (p->k + 1) * p->basis.ell * t->n * sizeof(int)));
-        p->sdigits = (int *)d;
+        p->sdigit_bytes = gadget_digit_bytes(p->basis.log_basis);
+        PFHE_HIP(counted_malloc(&d, p->chunk * (p->k + 1) * p->basis.ell * t->n * p->sdigit_bytes));
+        p->sdigits = d;
     }
     PFHE_HIP(hipStreamCreateWithFlags(&p->sa, hipStreamNonBlocking));
     PFHE_HIP(hipStreamCreateWithFlags(&p->sb, hipStreamNonBlocking));
@@ -610,7 +618,7 @@ int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *rns, const 
 void pfhe_extprod_plan_destroy(pfhe_extprod_plan *p) { delete p; }
 size_t pfhe_extprod_plan_scratch_bytes(const pfhe_extprod_plan *p) {
     if (!p) return 0;
-    return (p->pipeline ? 2 : 1) * p->digits_words * 8 + (p->sdigits ? p->chunk * (p->k + 1) * p->basis.ell * p->table->n * sizeof(int) : 0);
+    return (p->pipeline ? 2 : 1) * p->digits_words * 8 + (p->sdigits ? p->chunk * (p->k + 1) * p->basis.ell * p->table->n * p->sdigit_bytes : 0);
 }
 
 int pfhe_extprod_mul_dcrt_ggsw_to_dev(pfhe_extprod_plan *plan, const uint64_t *crt_glwe_dev, size_t len_glwe,
@@ -640,10 +648,10 @@ int pfhe_extprod_mul_dcrt_ggsw_to_dev(pfhe_extprod_plan *plan, const uint64_t *c
     PFHE_TRY(run_product(plan, (const u64 *)crt_glwe_dev, plan->k + 1, (const u64 *)dcrt_ggsw_dev, shared,
                          (u64 *)result_dev, batch, false, (hipStream_t)stream, into_coeff_form != 0, &coeff_passes));
     if (into_coeff_form && coeff_passes == 0)  // DcrtGlwe::into_coeff_form, macros/mod.rs:901-911
-        PFHE_TRY(ntt_inverse_dev(t.primes_dev, t.L, t.log_n, t.pm, (u64 *)result_dev, batch * (plan->k + 1) * t.L, false,
+        PFHE_TRY(ntt_inverse_dev(t.primes_dev, t.L, t.log_n, t.ntt_arith, (u64 *)result_dev, batch * (plan->k + 1) * t.L, false,
                                  (hipStream_t)stream, t.tune));
-    for (int i = coeff_passes; into_coeff_form && i > 0 && i < ntt_num_passes(t.log_n, t.pm, t.tune); ++i)
-        PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.pm, (u64 *)result_dev, batch * (plan->k + 1) * t.L, true, i,
+    for (int i = coeff_passes; into_coeff_form && i > 0 && i < ntt_num_passes(t.log_n, t.ntt_arith, t.tune); ++i)
+        PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.ntt_arith, (u64 *)result_dev, batch * (plan->k + 1) * t.L, true, i,
                               false, (hipStream_t)stream, nullptr, 0, t.tune));
     return PFHE_OK;
     PFHE_GUARD_END

@@ -185,86 +185,22 @@ __global__ __launch_bounds__(LOGE == 3 ? 512 : 256, LOGE == 3 ? kMulacc8MinWaves
 }
 
 // ------------------------------------------------------------------------------------------
-// Steps (1)-(4) of glwe/dcrt.rs:219-244 fused with the FIRST (strided) pass of the forward
-// transform: a thread owns one column t of one input CRT polynomial, i.e. the 2^K coefficients
-// t + S*k (S = N / 2^K) that a strided-pass thread would own.  It CRT-composes them once, then for
-// every gadget level and every limb produces the 2^K centred digit residues in registers, runs the
-// K radix-2 stages on them and stores the result where the strided pass would have stored it.  The
-// coefficient-domain digit polynomials (8*ell*L*N bytes per input polynomial) are never written.
+// Steps (1)-(4) of glwe/dcrt.rs:219-244 fused with the FIRST (strided) pass of the forward transform, as two kernels:
+//   gadget_signed_digits_kernel: steps (1)-(3), two coefficients per thread: CRT-compose, carry init, all ell BALANCED
+//     digits written as DT = int32 (log_basis <= 31) or int64 ([poly][level][N]: 4*ell*N or 8*ell*N bytes per input
+//     polynomial — the centred lift (4) of a signed digit d is d or q_i + d, so the limb copies are not materialised);
+//   digits_strided_kernel: step (4) + the strided pass of (5): a thread owns one column of one (polynomial, level),
+//     reads its 2^K digits once, and for every limb lifts them, runs the K stages in registers and stores where the
+//     strided pass would have stored.  The coefficient-domain digit polynomials (8*ell*L*N bytes per input polynomial)
+//     are never written.
+// (Until round 3 digits wider than 32 bits took a single kernel that kept 2^K composed big integers per thread alive
+// across all levels: 234 VGPRs at 3 limbs and 528 bytes of scratch per lane at 4.  The digit width is now a template
+// parameter of the two kernels and that kernel is gone.)
 // ------------------------------------------------------------------------------------------
-template <class A, int LEN, int K>
-__global__ __launch_bounds__(256) void gadget_decompose_strided_kernel(RnsDev R, BasisDev B, const NttPrime *__restrict__ primes,
-                                                                      u32 log_n, const u64 *__restrict__ crt,
-                                                                      u64 *__restrict__ out, u64 total_threads) {
-    constexpr int RK = 1 << K;
-    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total_threads) return;
-    const u32 log_s = log_n - K;
-    const u32 n = 1u << log_n;
-    const u32 col = (u32)(gid & ((1ull << log_s) - 1));
-    const u64 poly = gid >> log_s;
-    const u64 *__restrict__ in = crt + poly * R.L * n + col;
-
-    // (1) compose + (2) carry init, one big integer per owned coefficient
-    u64 v[RK][LEN];
-    u32 carries = 0;
-#pragma unroll
-    for (int k = 0; k < RK; ++k) {
-        if (R.big_input) {
-            const u64 *__restrict__ big = crt + (poly * n + col + ((u64)k << log_s)) * LEN;
-#pragma unroll
-            for (int j = 0; j < LEN; ++j) v[k][j] = big[j];
-        } else {
-            u64 r[kMaxLimbs];
-            for (u32 i = 0; i < R.L; ++i) r[i] = in[(u64)i * n + ((u64)k << log_s)];
-            compose<LEN>(R, r, v[k]);
-        }
-        carries |= init_value_carry<LEN>(B, v[k]) << k;
-    }
-    const u64 half = (B.basis + 1) / 2;
-    u64 *__restrict__ o = out + poly * B.ell * R.L * n + col;
-#pragma unroll 1
-    for (u32 j = 0; j < B.ell; ++j) {
-        // (3) digit j of every owned coefficient
-        u64 u[RK];
-#pragma unroll
-        for (int k = 0; k < RK; ++k) {
-            const u64 temp = window<LEN>(v[k], B.drop_bits + j * B.log_basis, B.basis_minus_one, B.log_basis) +
-                             ((carries >> k) & 1u);
-            const u32 cbit = (temp & B.carry_mask) != 0;
-            carries = (carries & ~(1u << k)) | (cbit << k);
-            u[k] = temp & B.basis_minus_one;
-        }
-#pragma unroll 1
-        for (u32 i = 0; i < R.L; ++i) {
-            // (4) centred lift into limb i, then the strided pass of that limb's transform
-            const A ar(primes + i);
-            u64 x[RK][1];
-#pragma unroll
-            for (int k = 0; k < RK; ++k) x[k][0] = (B.basis != 2 && u[k] >= half) ? R.q[i] - B.basis + u[k] : u[k];
-            strided_forward_regs<A, K, 1>(ar, x, n, 0u, log_s);
-            u64 *__restrict__ dst = o + ((u64)j * R.L + i) * n;
-#pragma unroll
-            for (int k = 0; k < RK; ++k) dst[(u64)k << log_s] = x[k][0];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Split form of the same steps, used when the digits fit 32 bits (log_basis <= 31).  The fused kernel
-// above keeps 2^K composed big integers per thread alive across all levels (234 VGPRs at 3 limbs,
-// K = 4: two waves per SIMD); splitting lets the arithmetic-heavy part run at four.
-//   gadget_signed_digits_kernel: steps (1)-(3), one thread per coefficient, all ell BALANCED digits
-//     written as int32 ([poly][level][N], 4*ell*N bytes per input polynomial — the centred lift (4)
-//     of a signed digit d is d or q_i + d, so the limb copies need not be materialised);
-//   digits_strided_kernel: step (4) + the strided pass of (5): a thread owns one column of one
-//     (polynomial, level), reads its 2^K digits once, and for every limb lifts them, runs the K stages
-//     in registers and stores where the strided pass would have stored.
-// ------------------------------------------------------------------------------------------
-// Two adjacent coefficients per thread: 16-byte loads of the residues, 8-byte stores of the digit pairs.
-template <int LEN>
+// Two adjacent coefficients per thread: 16-byte loads of the residues, one store of the digit pair.
+template <int LEN, class DT = int>
 __global__ __launch_bounds__(256) void gadget_signed_digits_kernel(RnsDev R, BasisDev B, u32 log_n,
-                                                                  const u64 *__restrict__ crt, int *__restrict__ out,
+                                                                  const u64 *__restrict__ crt, DT *__restrict__ out,
                                                                   u64 total_pairs) {
     const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total_pairs) return;
@@ -289,23 +225,24 @@ __global__ __launch_bounds__(256) void gadget_signed_digits_kernel(RnsDev R, Bas
     }
     u32 carry[2] = {init_value_carry<LEN>(B, v[0]), init_value_carry<LEN>(B, v[1])};
     const u64 half = (B.basis + 1) / 2;
-    int *__restrict__ o = out + poly * B.ell * n + t;
+    DT *__restrict__ o = out + poly * B.ell * n + t;
+    typedef DT DT2 __attribute__((ext_vector_type(2)));
     for (u32 j = 0; j < B.ell; ++j) {
-        int d[2];
+        DT d[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const u64 temp = window<LEN>(v[e], B.drop_bits + j * B.log_basis, B.basis_minus_one, B.log_basis) + carry[e];
             carry[e] = (temp & B.carry_mask) != 0;
             const u64 u = temp & B.basis_minus_one;
-            d[e] = (B.basis != 2 && u >= half) ? (int)((long long)u - (long long)B.basis) : (int)u;
+            d[e] = (B.basis != 2 && u >= half) ? (DT)((long long)u - (long long)B.basis) : (DT)u;
         }
-        *reinterpret_cast<int2 *>(o + (u64)j * n) = int2{d[0], d[1]};
+        *reinterpret_cast<DT2 *>(o + (u64)j * n) = DT2{d[0], d[1]};
     }
 }
 
-template <class A, int K>
+template <class A, int K, class DT = int>
 __global__ __launch_bounds__(256, 4) void digits_strided_kernel(const NttPrime *__restrict__ primes, u32 L, u32 log_n,
-                                                               const int *__restrict__ dig, u64 *__restrict__ out,
+                                                               const DT *__restrict__ dig, u64 *__restrict__ out,
                                                                u64 total_threads) {
     constexpr int RK = 1 << K;
     const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -314,8 +251,8 @@ __global__ __launch_bounds__(256, 4) void digits_strided_kernel(const NttPrime *
     const u32 n = 1u << log_n;
     const u32 col = (u32)(gid & ((1ull << log_s) - 1));
     const u64 pl = gid >> log_s;  // (input polynomial, level)
-    const int *__restrict__ src = dig + pl * n + col;
-    int d[RK];
+    const DT *__restrict__ src = dig + pl * n + col;
+    DT d[RK];
 #pragma unroll
     for (int k = 0; k < RK; ++k) d[k] = __builtin_nontemporal_load(src + ((u64)k << log_s));  // read once
 #pragma unroll 1
@@ -332,15 +269,15 @@ __global__ __launch_bounds__(256, 4) void digits_strided_kernel(const NttPrime *
     }
 }
 
-template <class A, int K>
+template <class A, int K, class DT>
 int launch_digits_strided(const RnsDev &r, const BasisDev &b, const NttPrime *primes, u32 log_n, const u64 *crt,
-                          int *sdigits, u64 *digits, u64 npolys, hipStream_t s) {
+                          DT *sdigits, u64 *digits, u64 npolys, hipStream_t s) {
     const u64 coeffs = (npolys << log_n) / 2;  // two coefficients per thread (N >= 2^9 on this path)
     const u32 g1 = (u32)((coeffs + 255) / 256);
     switch (r.value_len) {
 #define PFHE_CASE(LEN)                                                                                        \
     case LEN:                                                                                                 \
-        hipLaunchKernelGGL((gadget_signed_digits_kernel<LEN>), dim3(g1), dim3(256), 0, s, r, b, log_n, crt, sdigits, \
+        hipLaunchKernelGGL((gadget_signed_digits_kernel<LEN, DT>), dim3(g1), dim3(256), 0, s, r, b, log_n, crt, sdigits, \
                            coeffs);                                                                           \
         break;
         PFHE_CASE(1) PFHE_CASE(2) PFHE_CASE(3) PFHE_CASE(4)
@@ -349,8 +286,8 @@ int launch_digits_strided(const RnsDev &r, const BasisDev &b, const NttPrime *pr
     }
     PFHE_HIP(hipGetLastError());
     const u64 total = (npolys * b.ell) << (log_n - K);
-    hipLaunchKernelGGL((digits_strided_kernel<A, K>), dim3((u32)((total + 255) / 256)), dim3(256), 0, s, primes, r.L,
-                       log_n, sdigits, digits, total);
+    hipLaunchKernelGGL((digits_strided_kernel<A, K, DT>), dim3((u32)((total + 255) / 256)), dim3(256), 0, s, primes, r.L,
+                       log_n, (const DT *)sdigits, digits, total);
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
 }
@@ -485,25 +422,6 @@ int dispatch_extprod_small(u32 log_n, const int *sdigits, const u64 *ggsw, u64 s
     return PFHE_ERR_UNSUPPORTED;
 }
 
-template <class A, int K>
-int launch_decompose_strided(const RnsDev &r, const BasisDev &b, const NttPrime *primes, u32 log_n, const u64 *crt,
-                             u64 *digits, u64 npolys, hipStream_t s) {
-    const u64 total = npolys << (log_n - K);
-    const u32 grid = (u32)((total + 255) / 256);
-    switch (r.value_len) {
-#define PFHE_CASE(LEN)                                                                                          \
-    case LEN:                                                                                                   \
-        hipLaunchKernelGGL((gadget_decompose_strided_kernel<A, LEN, K>), dim3(grid), dim3(256), 0, s, r, b, primes, \
-                           log_n, crt, digits, total);                                                          \
-        break;
-        PFHE_CASE(1) PFHE_CASE(2) PFHE_CASE(3) PFHE_CASE(4)
-#undef PFHE_CASE
-        default: return PFHE_ERR_UNSUPPORTED;
-    }
-    PFHE_HIP(hipGetLastError());
-    return PFHE_OK;
-}
-
 }  // namespace
 
 bool gadget_fused_supported(u32 log_n, u32 k) { return k == 1 && make_ntt_plan(log_n).block_log == 12; }
@@ -583,30 +501,28 @@ int extprod_small_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u32 k, 
     return PFHE_ERR_UNSUPPORTED;
 }
 
-// int32 digits: |digit| <= 2^(log_basis - 1)
-bool gadget_split_decompose_supported(u32 log_n, u32 value_len, u32 log_basis) {
-    return gadget_decompose_strided_supported(log_n, value_len) && log_basis <= 31;
+// balanced digits are stored as int32 when log_basis <= 31 (|digit| <= 2^(log_basis - 1)), else as int64
+size_t gadget_digit_bytes(u32 log_basis) { return log_basis <= 31 ? sizeof(int) : sizeof(long long); }
+
+template <class A, int K>
+static int digits_strided_by_width(const RnsDev &r, const BasisDev &b, const NttPrime *primes, u32 log_n, const u64 *crt_polys,
+                                   void *sdigits, u64 *digits, u64 npolys, hipStream_t s) {
+    return b.log_basis <= 31
+               ? launch_digits_strided<A, K, int>(r, b, primes, log_n, crt_polys, (int *)sdigits, digits, npolys, s)
+               : launch_digits_strided<A, K, long long>(r, b, primes, log_n, crt_polys, (long long *)sdigits, digits, npolys, s);
 }
 
 int gadget_decompose_strided_dev(const RnsDev &r, const BasisDev &b, const NttPrime *primes, u32 log_n, bool pm,
-                                 const u64 *crt_polys, u64 *digits, u64 npolys, hipStream_t s, int *sdigits) {
-    if (!gadget_decompose_strided_supported(log_n, r.value_len)) return PFHE_ERR_UNSUPPORTED;
+                                 const u64 *crt_polys, u64 *digits, u64 npolys, hipStream_t s, void *sdigits) {
+    if (!gadget_decompose_strided_supported(log_n, r.value_len) || sdigits == nullptr) return PFHE_ERR_UNSUPPORTED;
     if (npolys == 0) return PFHE_OK;
     const int k = make_ntt_plan(log_n).strided[0];
-    if (sdigits != nullptr && gadget_split_decompose_supported(log_n, r.value_len, b.log_basis)) {
-        if (pm) {
-            return k == 4 ? launch_digits_strided<PmArith, 4>(r, b, primes, log_n, crt_polys, sdigits, digits, npolys, s)
-                          : launch_digits_strided<PmArith, 3>(r, b, primes, log_n, crt_polys, sdigits, digits, npolys, s);
-        }
-        return k == 4 ? launch_digits_strided<ShoupArith, 4>(r, b, primes, log_n, crt_polys, sdigits, digits, npolys, s)
-                      : launch_digits_strided<ShoupArith, 3>(r, b, primes, log_n, crt_polys, sdigits, digits, npolys, s);
-    }
     if (pm) {
-        return k == 4 ? launch_decompose_strided<PmArith, 4>(r, b, primes, log_n, crt_polys, digits, npolys, s)
-                      : launch_decompose_strided<PmArith, 3>(r, b, primes, log_n, crt_polys, digits, npolys, s);
+        return k == 4 ? digits_strided_by_width<PmArith, 4>(r, b, primes, log_n, crt_polys, sdigits, digits, npolys, s)
+                      : digits_strided_by_width<PmArith, 3>(r, b, primes, log_n, crt_polys, sdigits, digits, npolys, s);
     }
-    return k == 4 ? launch_decompose_strided<ShoupArith, 4>(r, b, primes, log_n, crt_polys, digits, npolys, s)
-                  : launch_decompose_strided<ShoupArith, 3>(r, b, primes, log_n, crt_polys, digits, npolys, s);
+    return k == 4 ? digits_strided_by_width<ShoupArith, 4>(r, b, primes, log_n, crt_polys, sdigits, digits, npolys, s)
+                  : digits_strided_by_width<ShoupArith, 3>(r, b, primes, log_n, crt_polys, sdigits, digits, npolys, s);
 }
 
 }  // namespace pfhe

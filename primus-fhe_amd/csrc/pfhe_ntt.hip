@@ -481,7 +481,9 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_wave
 // half's last register pass (the pass with the fewest live registers).
 // ------------------------------------------------------------------------------------------
 // gptr / mptr: this block of the data and of the multiplicand; ar: the arithmetic of the block's limb
-template <class A, int LOGB, class HookA = NoHook, class HookM = NoHook, class HookL = NoLateHook, bool NT = false>
+// NT: non-temporal data loads / stores (large batches); MNT: non-temporal loads of the multiplicand too — only when it is
+// per-element (read once); a multiplicand shared by the batch is re-read by every workgroup and must stay cacheable.
+template <class A, int LOGB, class HookA = NoHook, class HookM = NoHook, class HookL = NoLateHook, bool NT = false, bool MNT = false>
 __device__ __forceinline__ void block_mid_body(const A &ar, u64 *__restrict__ gptr, const u64 *__restrict__ mptr, bool valid,
                                                u32 n, u32 eblk, bool final_block, u64 *__restrict__ lds,
                                                HookA after_load = HookA(), HookM mid = HookM(), HookL late = HookL()) {
@@ -502,7 +504,7 @@ __device__ __forceinline__ void block_mid_body(const A &ar, u64 *__restrict__ gp
         const u32 lt = opaque_tid();
         u64x2 io[NV], mv[NV];
         if (valid) {  // natural order, 1 KiB per wave instruction
-            load_block_vectors<LOGB, 4, NT>(mv, mptr, lt);
+            load_block_vectors<LOGB, 4, MNT>(mv, mptr, lt);
         } else {
 #pragma unroll
             for (int j = 0; j < NV; ++j) mv[j] = u64x2{0, 0};
@@ -530,7 +532,7 @@ __device__ __forceinline__ void block_mid_body(const A &ar, u64 *__restrict__ gp
     }
 }
 
-template <class A, int LOGB, bool NT>
+template <class A, int LOGB, bool NT, bool MNT = false>
 __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_block_mid_kernel(
     u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L, u32 log_n, u64 total_blocks,
     const u64 *__restrict__ mul, u64 mul_polys) {
@@ -546,8 +548,8 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_wave
     // The multiplicand is one RNS polynomial (mul_polys == L, indexed by the limb) or one polynomial per data polynomial
     const u64 mpoly = mul_polys == (u64)L ? (u64)limb : pid;
     const A ar(primes + limb);
-    block_mid_body<A, LOGB, NoHook, NoHook, NoLateHook, NT>(ar, data + pid * n + eblk, mul + mpoly * n + eblk, valid, n, eblk,
-                                                            log_n == LOGB, lds_raw);
+    block_mid_body<A, LOGB, NoHook, NoHook, NoLateHook, NT, MNT>(ar, data + pid * n + eblk, mul + mpoly * n + eblk, valid, n,
+                                                                 eblk, log_n == LOGB, lds_raw);
 }
 
 // Persistent form of the middle kernel for N = 2^14 (one 1024-thread workgroup per CU, see ntt_persist_kernel): a resident
@@ -714,10 +716,11 @@ int launch_block_impl(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 n
         static thread_local bool configured[64] = {};
         int dev = 0;
         PFHE_HIP(hipGetDevice(&dev));
-        if (dev < 64 && !configured[dev]) {
+        const bool cached = dev >= 0 && dev < 64;  // outside the cache: set on every launch
+        if (!cached || !configured[dev]) {
             PFHE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            configured[dev] = true;
+            if (cached) configured[dev] = true;
         }
     }
     hipLaunchKernelGGL(kern, dim3((u32)grid), dim3(Cfg::THREADS), lds_bytes, s, data, primes, L, log_n,
@@ -748,10 +751,12 @@ int launch_persist(u64 *data, const NttPrime *primes, u32 L, u64 npolys, bool la
     static thread_local bool configured[64] = {};
     int dev = 0;
     PFHE_HIP(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && !configured[dev]) {
+    // (a device index outside the cache sets the attribute on every launch, as polymul_impl does)
+    const bool cached = dev >= 0 && dev < 64;
+    if (!cached || !configured[dev]) {
         PFHE_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes));
-        configured[dev] = true;
+        if (cached) configured[dev] = true;
     }
     // equal shares: every workgroup walks ceil(npolys / grid) polynomials, give or take one
     const u64 rounds = (npolys + resident - 1) / resident;
@@ -1126,17 +1131,20 @@ static int polymul_impl(const NttPrime *primes, u32 L, u32 log_n, int arith, u64
             return PFHE_ERR_BAD_LENGTH;
         }
         constexpr size_t lds_bytes = (size_t)Cfg::LDS_WORDS * sizeof(u64);
+        // a per-element multiplicand of a large batch is read once (non-temporal); a shared one stays cacheable
+        const int form = !large ? 0 : (mp == np ? 2 : 1);
         void (*kern)(u64 *, const NttPrime *, u32, u32, u64, const u64 *, u64) =
-            large ? ntt_block_mid_kernel<A, LOGB, true> : ntt_block_mid_kernel<A, LOGB, false>;
-        if (lds_bytes > 64 * 1024) {  // once per device and instantiation (both NT forms)
-            static thread_local bool configured[64][2] = {};
+            form == 0 ? ntt_block_mid_kernel<A, LOGB, false> : form == 1 ? ntt_block_mid_kernel<A, LOGB, true, false>
+                                                                          : ntt_block_mid_kernel<A, LOGB, true, true>;
+        if (lds_bytes > 64 * 1024) {  // once per device and instantiation
+            static thread_local bool configured[64][3] = {};
             int dev = 0;
             PFHE_HIP(hipGetDevice(&dev));
-            if (dev < 0 || dev >= 64 || !configured[dev][large ? 1 : 0]) {
+            if (dev < 0 || dev >= 64 || !configured[dev][form]) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
                 if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute", __FILE__, __LINE__);
-                if (dev >= 0 && dev < 64) configured[dev][large ? 1 : 0] = true;
+                if (dev >= 0 && dev < 64) configured[dev][form] = true;
             }
         }
         hipLaunchKernelGGL(kern, dim3((u32)total_blocks), dim3(Cfg::THREADS), lds_bytes, s, ptr, primes, L, log_n,

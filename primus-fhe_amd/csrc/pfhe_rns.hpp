@@ -86,12 +86,11 @@ int gadget_mulacc_dev(const NttPrime *primes, u32 L, u32 log_n, u32 k, u32 rows,
 bool gadget_fused_supported(u32 log_n, u32 k);
 // Steps (1)-(4) fused with the first (strided) pass of the forward transform (pfhe_extprod.hip).
 bool gadget_decompose_strided_supported(u32 log_n, u32 value_len);
-// `sdigits` (optional): scratch of npolys * ell * N int32 words; when given and the digits fit 32 bits the
-// work is split into a compact signed-digit kernel + a lifting strided pass (better occupancy).
-bool gadget_split_decompose_supported(u32 log_n, u32 value_len, u32 log_basis);
+// `sdigits`: scratch of npolys * ell * N balanced digits of gadget_digit_bytes(log_basis) bytes each (int32 when
+// log_basis <= 31, else int64): a compact signed-digit kernel + a lifting strided pass.
+size_t gadget_digit_bytes(u32 log_basis);
 int gadget_decompose_strided_dev(const RnsDev &r, const BasisDev &b, const NttPrime *primes, u32 log_n, bool pm,
-                                 const u64 *crt_polys, u64 *digits, u64 npolys, hipStream_t s,
-                                 int *sdigits = nullptr);
+                                 const u64 *crt_polys, u64 *digits, u64 npolys, hipStream_t s, void *sdigits);
 // inv_tail (not with accumulate): the kernel also runs the block pass of the INVERSE transform on its result blocks
 // before storing them; the caller finishes with the inverse transform's strided pass (ntt_pass_dev, inverse, index 1).
 int gadget_block_mulacc_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u32 k, u32 terms, const u64 *digits,

@@ -183,6 +183,10 @@ def make_case(orc, rng, log_n, k, moduli, log_basis, rev, batch, shared):
     (3, 1, Q61, 30, None, 1, True, 0), (4, 1, Q61, 30, None, 5, True, 2), (4, 1, Q61, 30, None, 5, False, 3),
     (6, 2, Q61[:2], 20, 3, 3, True, 1), (10, 1, [134215681, 134176769], 7, None, 2, False, 0),
     (12, 1, Q61, 30, None, 3, True, 2), (13, 1, Q61, 13, None, 1, True, 0),
+    # digits wider than 32 bits on two-pass rings: the int64 instantiations of the digit kernels (log B = 40: ell = 4,
+    # 45: ell = 4, 61: ell = 3), and on a single-pass ring (unfused kernels)
+    (15, 1, Q61, 40, None, 2, True, 0), (16, 1, Q61, 45, None, 2, False, 1), (16, 1, Q61, 60, None, 1, True, 0),
+    (12, 1, Q61, 33, None, 2, True, 0),
 ])
 def test_external_product_matches_oracle(pf, orc, log_n, k, moduli, log_basis, rev, batch, shared, chunk):
     """CrtGlwe::mul_dcrt_ggsw_to (glwe/crt.rs:200-227), batched, shared or per-ciphertext GGSW."""
@@ -201,6 +205,34 @@ def test_external_product_matches_oracle(pf, orc, log_n, k, moduli, log_basis, r
     with pytest.raises(pf.PfheError) as e:
         pf.mul_dcrt_ggsw_to(glwe, ggsw[:-1].copy(), out, ctx)
     assert e.value.kind == "BadLength"
+
+
+@pytest.mark.parametrize("log_basis", [31, 32, 50])
+def test_wide_digits_generic_primes_and_unfused_path(pf, orc, log_basis, monkeypatch):
+    """The digit width is a template parameter of gadget_signed_digits_kernel / digits_strided_kernel (int32 up to
+    log B = 31, int64 beyond: big_integer/common.rs:132-140 allows any log B < 64).  Generic-prime (Shoup / Montgomery)
+    tables and the plan without the fused decomposition must give the oracle's words on either side of the switch."""
+    log_n, k, batch = 16, 1, 2
+    rng = np.random.default_rng(log_basis)
+    otable, glwe, ggsw, exp = make_case(orc, rng, log_n, k, Q61, log_basis, None, batch, True)
+    monkeypatch.setenv("PFHE_DISABLE_PM", "1")
+    table, base = pf.U64DcrtTable(log_n, Q61), pf.RNSBase(Q61)
+    monkeypatch.delenv("PFHE_DISABLE_PM")
+    basis = pf.BigUintApproxSignedBasis(base, log_basis)
+    ctx = pf.DcrtGlevContext(table, base, basis, k)
+    monkeypatch.setenv("PFHE_DISABLE_FUSED_DECOMPOSE", "1")
+    ctx_unfused = pf.DcrtGlevContext(pf.U64DcrtTable(log_n, Q61), base, basis, k)
+    monkeypatch.delenv("PFHE_DISABLE_FUSED_DECOMPOSE")
+    assert ctx.scratch_bytes() > ctx_unfused.scratch_bytes()   # the digit buffer exists only for the split kernels
+    out = np.empty_like(glwe)
+    for c in (ctx, ctx_unfused):
+        pf.mul_dcrt_ggsw_to(glwe, ggsw, out, c)
+        assert np.array_equal(out, exp)
+    e2 = exp.copy()
+    otable.inverse_transform_slice(e2)
+    for c in (ctx, ctx_unfused):
+        pf.mul_dcrt_ggsw_to(glwe, ggsw, out, c, into_coeff_form=True)
+        assert np.array_equal(out, e2)
 
 
 def test_external_product_equals_schoolbook(pf, orc):

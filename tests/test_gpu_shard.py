@@ -1,7 +1,7 @@
 """BASELINE config 5 on the hardware there is (one GPU): the sharded external-product job through the HIP library.
 
-* two ranks on ONE device, started by bench.py's own `--gpus 2` entry (gloo barrier): the union of the ranks' HIP
-  outputs equals the unsharded HIP output and the oracle, bit for bit (ragged split);
+* two and EIGHT ranks on ONE device, started by bench.py's own `--gpus N` entry (gloo barrier): the union of the ranks'
+  HIP outputs equals the unsharded HIP output and the oracle, bit for bit (ragged splits);
 * the full 8192-ciphertext job on one GPU, unsharded and as the eight `shard_range(8192, 8, r)` pieces, with oracle
   checks on the ciphertexts either side of every shard boundary.
 
@@ -47,40 +47,51 @@ def _oracle_product(orc, o, obase, obasis, glwe, ggsw):
     return r
 
 
-def test_two_ranks_one_device_through_bench_entry(tmp_path, orc):
+@pytest.mark.parametrize("world,batch,total,extra", [
+    (2, 3, 5, []),                          # ragged: 3 + 2
+    (8, 2, 13, ["--skip-device-check"]),    # BASELINE config 5's world size: eight rank processes, ragged 2,2,2,2,2,1,1,1
+])
+def test_ranks_on_one_device_through_bench_entry(tmp_path, orc, world, batch, total, extra):
+    """`bench.py --gpus N` exactly as the driver's launcher would run the N ranks — N real processes, rendezvous on
+    127.0.0.1, barrier + max-reduce (gloo), N dumps — on the one device there is.  The union of the ranks' HIP outputs
+    must equal the unsharded HIP result and the oracle."""
     import torch
 
     import primus_fhe_amd as p
     from primus_fhe_amd.shard import fill_job_shard, shard_range
 
-    batch, total = 3, 5  # per-rank RNS polynomials of the NTT leg; ciphertexts of the config-5 job (ragged: 3 + 2)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-device", "--dist-backend", "gloo",
+    # batch: per-rank RNS polynomials of the NTT leg; total: ciphertexts of the config-5 job
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--one-device", "--dist-backend", "gloo",
            "--batch", str(batch), "--ext-batch", "2", "--ext-total", str(total), "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline", "--dump-dir", str(tmp_path)]
+           "--no-cpu-baseline", "--dump-dir", str(tmp_path)] + extra
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0
+    assert line["n_gpus"] == world and line["steps"] == 2 and line["value"] > 0
     c5 = line["external_product_config5"]
-    assert c5["n_gpus"] == 2 and c5["batch_total"] == total and c5["scaling"] == "strong"
-    assert line["external_product"]["n_gpus"] == 2
+    assert c5["n_gpus"] == world and c5["batch_total"] == total and c5["scaling"] == "strong"
+    assert line["external_product"]["n_gpus"] == world
 
-    dumps = [np.load(os.path.join(tmp_path, "rank%d.npz" % rk)) for rk in range(2)]
-    assert [tuple(d["config5_range"]) for d in dumps] == [shard_range(total, 2, rk) for rk in range(2)] == [(0, 3), (3, 5)]
-    assert [tuple(d["ntt_range"]) for d in dumps] == [(0, batch), (batch, 2 * batch)]
+    dumps = [np.load(os.path.join(tmp_path, "rank%d.npz" % rk)) for rk in range(world)]
+    ranges = [tuple(int(v) for v in d["config5_range"]) for d in dumps]
+    assert ranges == [shard_range(total, world, rk) for rk in range(world)]
+    assert ranges[0][0] == 0 and ranges[-1][1] == total and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    if world == 2:
+        assert ranges == [(0, 3), (3, 5)]
+    assert [tuple(d["ntt_range"]) for d in dumps] == [(rk * batch, (rk + 1) * batch) for rk in range(world)]
     ntt_union = np.concatenate([d["ntt_out"] for d in dumps])
     c5_union = np.concatenate([d["config5_out"] for d in dumps])
 
     bench, table, ctx = _setup(p)
     L, W = 3, 2 * 3 * N
-    # ---- NTT leg: the job of 2*batch RNS polynomials, unsharded on the HIP path, and the oracle on the host model
+    # ---- NTT leg: the job of world*batch RNS polynomials, unsharded on the HIP path, and the oracle on the host model
     #      of the synthetic input (which also pins pfhe_fill_uniform_dev's position-only seeding) ----
-    x = torch.empty(2 * batch * L * N, dtype=torch.int64, device="cuda")
-    fill_job_shard(p.lib(), 0, x.data_ptr(), 0, 2 * batch, L * N, bench.Q61, N, bench.SEED_NTT)
-    host_in = fill_uniform_words(bench.SEED_NTT, 0, 2 * batch * L * N, bench.Q61, N)
+    x = torch.empty(world * batch * L * N, dtype=torch.int64, device="cuda")
+    fill_job_shard(p.lib(), 0, x.data_ptr(), 0, world * batch, L * N, bench.Q61, N, bench.SEED_NTT)
+    host_in = fill_uniform_words(bench.SEED_NTT, 0, world * batch * L * N, bench.Q61, N)
     assert np.array_equal(to_host(x), host_in)
     table.transform_dev(x)
     assert np.array_equal(ntt_union, to_host(x)), "union of the ranks' NTT shards != unsharded HIP transform"

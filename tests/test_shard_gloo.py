@@ -155,6 +155,44 @@ def test_bench_rejects_world_size_mismatch(monkeypatch):
     assert "WORLD_SIZE" in str(ei.value)
 
 
+def test_bench_gpus_defaults_to_the_launchers_world_size(monkeypatch):
+    """`torchrun --nproc-per-node N bench.py` without --gpus: the launcher's WORLD_SIZE is the number of GPUs
+    (ADVICE r3); without a launcher the default is one."""
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2"])
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    assert bench.parse_args().gpus == 4
+    monkeypatch.delenv("WORLD_SIZE")
+    assert bench.parse_args().gpus == 1
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--skip-device-check"])
+    a = bench.parse_args()
+    assert a.gpus == 8 and a.skip_device_check
+
+
+def test_traffic_figures_carry_their_provenance():
+    """roofline.traffic is read from a committed profile: the line names the file, its git blob id and the register
+    counts it was taken at, and is null when the library being timed has different kernels."""
+    import subprocess
+
+    import bench
+    import primus_fhe_amd as p
+    if not os.path.exists(p.library_path()):
+        pytest.skip("libpfhe_hip.so not built")
+    from primus_fhe_amd._codeobj import kernel_resources
+    res = kernel_resources(p.library_path())
+    assert res["ntt_pipe_fwd_kernel<PmArith, 12>"]["vgpr"] <= 128 and res["ntt_pipe_fwd_kernel<PmArith, 12>"]["scratch"] == 0
+    path = os.path.join(ROOT, "profiles", "r03_d_rocprof.json")
+    blob = subprocess.run(["git", "hash-object", path], capture_output=True, text=True, cwd=ROOT).stdout.strip()
+    assert bench.git_blob_hash(path) == blob
+    built = bench.built_vgprs("ntt_pipe_fwd_kernel<PmArith, 12>")
+    prov, ok = bench.provenance(path, {"ntt_pipe_fwd_kernel<PmArith, 12>": built})
+    assert ok and prov["profile_git_blob"] == blob
+    prov, ok = bench.provenance(path, {"ntt_pipe_fwd_kernel<PmArith, 12>": built + 16})
+    assert not ok and not prov["profile_matches_build"]
+    assert not bench.provenance(path, {"ntt_pipe_fwd_kernel<PmArith, 12>": None})[1]   # a profile without register counts
+    assert not bench.provenance(path, {})[1]
+
+
 def test_bench_spawner_ends_the_other_ranks_when_one_dies(monkeypatch):
     """A rank that exits non-zero must not leave its peers waiting at a barrier: the launcher terminates them (by handle)
     and returns the failing code."""

@@ -92,6 +92,9 @@ ep += counter_table("ep_", "rocprofv3 --pmc <one counter per pass> -- python3 to
                     "reported: reads = 2 x FETCH_SIZE on gfx950)")
 # whole-product HBM traffic: every launch of the COEFF_ONLY counter passes (4 products of batch 1024, coefficient form),
 # 2 x FETCH_SIZE + WRITE_SIZE (KiB as reported; gfx950 correction of MI355X_MICROARCH.md), summed and divided by the products
+ep_vgpr = {}
+
+
 def counter_sum(name):
     f = newest(f"{src}/ep_{name}/**/*counter_collection.csv")
     per = collections.defaultdict(float)
@@ -100,6 +103,8 @@ def counter_sum(name):
             k = short(r["Kernel_Name"])
             if not (k.startswith("__amd") or "fill" in k):
                 per[k] += float(r["Counter_Value"])
+                if r.get("VGPR_Count"):
+                    ep_vgpr[k] = int(r["VGPR_Count"]) + int(r.get("Accum_VGPR_Count") or 0)
     return per
 
 
@@ -110,6 +115,7 @@ if fe and wr:
     traffic = {"products": products, "form": "CrtGlwe x DcrtGgsw -> coefficient form, batch 1024, default chunk",
                "method": "sum over every kernel launch of 2*FETCH_SIZE + WRITE_SIZE (separate --pmc passes, KiB), / products",
                "bytes_per_product": sum(per_kernel.values()), "bytes_per_product_by_kernel": per_kernel,
+               "vgpr_count_by_kernel": ep_vgpr,
                "algorithmic_bytes_per_product": 96 * 65536}
     json.dump(traffic, open(f"{dst}/{tag}_extprod_traffic.json", "w"), indent=1)
     ep.append("whole product: %.1f MB moved per product (algorithmic 6.29 MB): " % (traffic["bytes_per_product"] / 1e6) +

@@ -37,7 +37,10 @@ def main():
         key = (short(r["Kernel_Name"]), int(r["Grid_Size"]) if "Grid_Size" in r else int(r.get("Grid_Size_X", 0)))
         dur[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     traffic = collections.defaultdict(lambda: {"fetch_kib": [], "write_kib": []})
+    vgpr = {}  # registers of the code object the counters were taken on (bench.py checks them against the build it times)
     for r in fetch:
+        if r.get("VGPR_Count"):
+            vgpr[short(r["Kernel_Name"])] = int(r["VGPR_Count"]) + int(r.get("Accum_VGPR_Count") or 0)
         traffic[(short(r["Kernel_Name"]), int(r["Grid_Size"]))]["fetch_kib"].append(float(r["Counter_Value"]))
     for r in write:
         traffic[(short(r["Kernel_Name"]), int(r["Grid_Size"]))]["write_kib"].append(float(r["Counter_Value"]))
@@ -48,7 +51,7 @@ def main():
             continue
         f = sum(t["fetch_kib"]) / len(t["fetch_kib"]) if t["fetch_kib"] else None
         w = sum(t["write_kib"]) / len(t["write_kib"]) if t["write_kib"] else None
-        row = {"kernel": key[0], "grid_size": key[1], "launches": len(d),
+        row = {"kernel": key[0], "grid_size": key[1], "launches": len(d), "vgpr_count": vgpr.get(key[0]),
                "avg_ms": sum(d) / len(d) / 1e6 if d else None,
                "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
                "read_bytes_corrected": None if f is None else 2 * f * 1024,
