@@ -77,6 +77,11 @@ struct NttPrime {
     u64 pm_c;
     const u64 *fwd_w;        // device: u32 tables only ({w, floor(w*2^32/q)} packed in one word, pfhe_u32.hip)
     const u64 *inv_w;
+    const u64 *fwd_wn;       // device: u32 tables only: fwd_w with the twiddle negated, {2^32 - w, floor(w*2^32/q)} (B32Arith::mul1_neg)
+    // u32 tables: lane-ordered copies (see fwd_last below) for the register pass at word distances 8..1 and the
+    // intra-word stage: 31 * (N/32) entries (15 + 16 per group of 16 words), forward ones negated; null for N < 32
+    const u64 *fwd_last_w;
+    const u64 *inv_last_w;
     const ulonglong2 *fwd_p; // device, N entries {w, w*2^32 mod q}: twiddles of the pseudo-Mersenne path, same
     const ulonglong2 *inv_p; // indexing as fwd / inv (null when the prime does not qualify)
     u64 inv_n_2, inv_n_w_2;  // inv_n * 2^32 mod q, inv_n_w * 2^32 mod q

@@ -1252,10 +1252,10 @@ __global__ void ntt32_tiny_kernel(u32 *__restrict__ data, const NttPrime *__rest
             for (u32 e = 0; e < n; ++e) {
                 if (e & (1u << p)) continue;
                 const u32 f = e | (1u << p);
-                const B32Arith::Tw w = ar.fwd_tw((n + e) >> (p + 1));
-                const u32 tx = B32Arith::once(x[e], two_q), t = ar.mul1(x[f], w);
-                x[e] = tx + t;
-                x[f] = tx + two_q - t;
+                const B32Arith::Tw wn = ar.fwd_tw((n + e) >> (p + 1));  // negated twiddle (NttPrime::fwd_wn)
+                const u32 tx = B32Arith::once(x[e], two_q), tn = ar.mul1_neg(x[f], wn);
+                x[e] = tx - tn;
+                x[f] = tx + two_q + tn;
             }
         }
         if (!lazy)

@@ -373,27 +373,42 @@ struct B32Arith {
     };
     u32 q, two_q32;
     u64 two_q;  // 2q in both halves
-    GCWordPtr fwd, inv;
+    GCWordPtr fwd, inv, fwd_last, inv_last;
     Tw inv_n, inv_n_w;
     static constexpr bool kPacked = true;
     static constexpr bool kWide = false;
     static constexpr bool kMont = false;
-    static constexpr bool kLastTables = false;
+    // lane-ordered twiddles of the last register pass and of the intra-word stage (NttPrime::fwd_last_w / inv_last_w)
+    static constexpr bool kLastTables = true;
 
     __device__ __forceinline__ explicit B32Arith(const NttPrime *__restrict__ P)
         : q((u32)P->q), two_q32((u32)P->two_q), two_q(P->two_q | (P->two_q << 32)),
-          fwd((GCWordPtr)(const void *)P->fwd_w), inv((GCWordPtr)(const void *)P->inv_w),
+          fwd((GCWordPtr)(const void *)P->fwd_wn), inv((GCWordPtr)(const void *)P->inv_w),
+          fwd_last((GCWordPtr)(const void *)P->fwd_last_w), inv_last((GCWordPtr)(const void *)P->inv_last_w),
           inv_n{(u32)P->inv_n, (u32)P->inv_n_p}, inv_n_w{(u32)P->inv_n_w, (u32)P->inv_n_w_p} {}
     static __device__ __forceinline__ Tw unpack(u64 v) { return Tw{(u32)v, (u32)(v >> 32)}; }
     static __device__ __forceinline__ u64 pack(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
+    // forward twiddles come from the NEGATED table (NttPrime::fwd_wn: {2^32 - w, floor(w*2^32/q)}): see mul1_neg
     __device__ __forceinline__ Tw fwd_tw(u32 i) const { return unpack(fwd[i]); }
     __device__ __forceinline__ Tw inv_tw(u32 i) const { return unpack(inv[i]); }
+    __device__ __forceinline__ Tw fwd_tw_last(u32 off) const { return unpack(fwd_last[off]); }
+    __device__ __forceinline__ Tw inv_tw_last(u32 off) const { return unpack(inv_last[off]); }
     __device__ __forceinline__ Tw tw_inv_n() const { return inv_n; }
     __device__ __forceinline__ Tw tw_inv_n_w() const { return inv_n_w; }
+    // low word of a*b + c in ONE instruction (v_mad_u64_u32): the compiler, asked for 32 bits of that sum, emits
+    // v_mul_lo_u32 + v_add_u32; passing the 64-bit product y*w as the addend makes the whole lazy product three
+    // instructions (v_mul_hi_u32, v_mad_u64_u32, v_mad_u64_u32) instead of four
+    static __device__ __forceinline__ u32 mad_lo(u32 a, u32 b, u64 c) {
+        u64 d, carry;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
+        return (u32)d;
+    }
     // arithmetic.rs:16-20: w*y - q*floor(y*w'/2^32), wrapping, in [0,2q)
-    // (v_mad_u64_u32 forms of this product were measured and are not faster: on gfx950 v_mul_lo_u32 /
-    // v_mul_hi_u32 issue in ~1.5 full-rate slots, tools/microbench4.hip)
-    __device__ __forceinline__ u32 mul1(u32 y, Tw t) const { return t.w * y - q * __umulhi(y, t.wp); }
+    __device__ __forceinline__ u32 mul1(u32 y, Tw t) const { return mad_lo(__umulhi(y, t.wp), 0u - q, (u64)y * t.w); }
+    // the same product NEGATED, q*floor(y*w'/2^32) - w*y (wrapping), from a twiddle stored as 2^32 - w: a forward
+    // butterfly then is x' = tx - tn, y' = tx + 2q + tn (one v_sub_u32 and one v_add3_u32) — seven instructions per
+    // coefficient butterfly where the compiler's form of arithmetic.rs:43-59 took ten
+    __device__ __forceinline__ u32 mul1_neg(u32 y, Tw tn) const { return mad_lo(__umulhi(y, tn.wp), q, (u64)y * tn.w); }
     static __device__ __forceinline__ u32 once(u32 x, u32 m) { return min(x, x - m); }  // arithmetic.rs:3-6
     __device__ __forceinline__ u64 mul_lazy(u64 y, Tw t) const { return pack(mul1((u32)y, t), mul1((u32)(y >> 32), t)); }
     __device__ __forceinline__ u64 reduce_x(u64 x) const { return pack(once((u32)x, two_q32), once((u32)(x >> 32), two_q32)); }
@@ -401,10 +416,10 @@ struct B32Arith {
     __device__ __forceinline__ u64 reduce_4q(u64 x) const { return reduce_2q(reduce_x(x)); }
 
     // butterflies on both halves with 32-bit operations only (no 64-bit carries)
-    __device__ __forceinline__ void fwd1(u32 &x, u32 &y, Tw w) const {
-        const u32 tx = once(x, two_q32), t = mul1(y, w);
-        x = tx + t;
-        y = tx + two_q32 - t;
+    __device__ __forceinline__ void fwd1(u32 &x, u32 &y, Tw wn) const {
+        const u32 tx = once(x, two_q32), tn = mul1_neg(y, wn);
+        x = tx - tn;
+        y = tx + two_q32 + tn;
     }
     __device__ __forceinline__ void inv1(u32 &x, u32 &y, Tw w) const {
         const u32 tx = x + y, ty = x + two_q32 - y;
@@ -444,14 +459,16 @@ struct B32Arith {
     }
 
     // distance-1 stage, forward: word at word index i uses roots[N/2 + i] (n = N/2 words)
-    __device__ __forceinline__ u64 fwd_intra(u64 x, u32 n_plus_i) const {
-        const Tw w = fwd_tw(n_plus_i);
-        const u32 tx = once((u32)x, two_q32), t = mul1((u32)(x >> 32), w);
-        return pack(tx + t, tx + two_q32 - t);
+    __device__ __forceinline__ u64 fwd_intra(u64 x, u32 n_plus_i) const { return fwd_intra_tw(x, fwd_tw(n_plus_i)); }
+    __device__ __forceinline__ u64 fwd_intra_tw(u64 x, Tw wn) const {
+        const u32 tx = once((u32)x, two_q32), tn = mul1_neg((u32)(x >> 32), wn);
+        return pack(tx - tn, tx + two_q32 + tn);
     }
     // distance-1 stage, inverse: inv_roots[1 + i]; `inv` is biased by n words
     __device__ __forceinline__ u64 inv_intra(u64 x, u32 n, u32 i) const {
-        const Tw w = unpack(inv[(long)(1 + i) - (long)n]);
+        return inv_intra_tw(x, unpack(inv[(long)(1 + i) - (long)n]));
+    }
+    __device__ __forceinline__ u64 inv_intra_tw(u64 x, Tw w) const {
         const u32 a = (u32)x, b = (u32)(x >> 32);
         return pack(once(a + b, two_q32), mul1(a + two_q32 - b, w));
     }
@@ -827,8 +844,14 @@ __device__ __forceinline__ void block_forward_core(const A &ar, u64 (&x)[1 << LO
     fwd_regpass<A, POS0, LOGE - 1, 0, UNI, LOGE>(ar, x, n + eblk + layout<POS0, LOGE>(lt, 0), n);
     fwd_chain<A, LOGB, POS0, LEAD, LOGE, Late>(ar, x, lds, n, eblk, lt, before_last);
     if constexpr (A::kPacked) {  // distance-1 stage between the halves of each word
+        if constexpr (LOGE == 4) {  // lane-ordered twiddles: slot 15 + k of group (eblk >> 4) + lt
+            const u32 off0 = 15u * (n >> 4) + (eblk >> 4) + lt;
 #pragma unroll
-        for (int k = 0; k < E; ++k) x[k] = ar.fwd_intra(x[k], n + eblk + layout<0, LOGE>(lt, k));
+            for (int k = 0; k < E; ++k) x[k] = ar.fwd_intra_tw(x[k], ar.fwd_tw_last(off0 + (u32)k * (n >> 4)));
+        } else {
+#pragma unroll
+            for (int k = 0; k < E; ++k) x[k] = ar.fwd_intra(x[k], n + eblk + layout<0, LOGE>(lt, k));
+        }
     }
     if constexpr (A::kWide) {
         if (!lazy) {  // one uniform branch for the whole thread, two elements per asm block
@@ -876,8 +899,14 @@ __device__ __forceinline__ void block_inverse_core(const A &ar, u64 (&x)[1 << LO
                                                    u32 eblk, u32 lt, bool final_block, bool lazy, Late before_last = Late()) {
     constexpr bool UNI = BlockCfg<LOGB, LOGE>::TPB >= 64;  // a wave never straddles two blocks
     if constexpr (A::kPacked) {
+        if constexpr (LOGE == 4) {  // lane-ordered twiddles, as in block_forward_core
+            const u32 off0 = 15u * (n >> 4) + (eblk >> 4) + lt;
 #pragma unroll
-        for (int k = 0; k < (1 << LOGE); ++k) x[k] = ar.inv_intra(x[k], n, eblk + layout<0, LOGE>(lt, k));
+            for (int k = 0; k < (1 << LOGE); ++k) x[k] = ar.inv_intra_tw(x[k], ar.inv_tw_last(off0 + (u32)k * (n >> 4)));
+        } else {
+#pragma unroll
+            for (int k = 0; k < (1 << LOGE); ++k) x[k] = ar.inv_intra(x[k], n, eblk + layout<0, LOGE>(lt, k));
+        }
     }
     inv_regpass<A, 0, 0, LOGE - 1, UNI, LOGE>(ar, x, n, eblk + layout<0, LOGE>(lt, 0), LOGB == LOGE && final_block, lazy);
     inv_chain<A, LOGB, 0, LEAD, LOGE, Late, HOOK_AT>(ar, x, lds, n, eblk, lt, final_block, lazy, before_last);

@@ -159,7 +159,6 @@ int make_table_set32(u32 log_n, const u32 *moduli, size_t count, int device, std
     ts->tune = NttTuning::from_env();  // u32 tables read the tuning switches at creation too
     ts->primes.resize(count);
     const size_t n = ts->n;
-    std::vector<u64> packed(n);
     for (size_t i = 0; i < count; ++i) {
         const u64 q = host[i].q;
         NttPrime &P = ts->primes[i];
@@ -171,16 +170,52 @@ int make_table_set32(u32 log_n, const u32 *moduli, size_t count, int device, std
         P.inv_n_w = host[i].inv_n_w;
         P.inv_n_w_p = (host[i].inv_n_w << 32) / q;
         P.bar_lo = (u64)(((unsigned __int128)1 << 64) / q);
-        for (int dir = 0; dir < 2; ++dir) {
-            const auto &src = dir == 0 ? host[i].fwd : host[i].inv;
-            for (size_t k = 0; k < n; ++k) packed[k] = src[k].x | (((src[k].x << 32) / q) << 32);
+        const auto upload = [&](const std::vector<u64> &v, const u64 **dst) -> int {
             void *d = nullptr;
-            PFHE_HIP(counted_malloc(&d, n * sizeof(u64)));
+            PFHE_HIP(counted_malloc(&d, v.size() * sizeof(u64)));
             ts->allocations.push_back(d);
-            PFHE_HIP(hipMemcpy(d, packed.data(), n * sizeof(u64), hipMemcpyHostToDevice));
-            // the word kernels index the inverse table in units of words: bias it by N/2 entries
-            if (dir == 0) P.fwd_w = static_cast<const u64 *>(d);
-            else P.inv_w = static_cast<const u64 *>(d) + n / 2;
+            PFHE_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(u64), hipMemcpyHostToDevice));
+            *dst = static_cast<const u64 *>(d);
+            return PFHE_OK;
+        };
+        const auto pack_of = [&](const std::vector<ulonglong2> &src, bool negate) {
+            std::vector<u64> v(n);
+            for (size_t k = 0; k < n; ++k)
+                v[k] = (negate ? (u64)(u32)(0u - (u32)src[k].x) : src[k].x) | (((src[k].x << 32) / q) << 32);
+            return v;
+        };
+        // forward, inverse, forward with the twiddle negated (B32Arith::mul1_neg)
+        const std::vector<u64> pf = pack_of(host[i].fwd, false), pi = pack_of(host[i].inv, false), pn = pack_of(host[i].fwd, true);
+        const u64 *dinv = nullptr;
+        PFHE_TRY(upload(pf, &P.fwd_w));
+        PFHE_TRY(upload(pi, &dinv));
+        P.inv_w = dinv + n / 2;  // the word kernels index the inverse table in units of words: biased by N/2 entries
+        PFHE_TRY(upload(pn, &P.fwd_wn));
+        // Lane-ordered copies for the register pass in which a thread owns 16 consecutive WORDS (stages at word
+        // distances 8, 4, 2, 1: 15 twiddles per group of 16 words, as NttPrime::fwd_last) plus the intra-word stage (one
+        // twiddle per word: 16 more): entry (slot * G + g) belongs to group g, so the 64 lanes of a wave — 64
+        // consecutive groups — load 64 consecutive entries instead of 64 separate lines (the gathers kept the u32 block
+        // pass at 3.6 TB/s whatever its instruction count).  Word units: nw = N/2 words per polynomial.
+        const size_t nw = n / 2;
+        if (nw >= 16) {
+            const size_t G = nw / 16;
+            std::vector<u64> fl(31 * G), il(31 * G);
+            for (int j = 3; j >= 0; --j) {
+                const size_t per = (size_t)8 >> j;
+                for (size_t u = 0; u < per; ++u)
+                    for (size_t g2 = 0; g2 < G; ++g2) {
+                        const size_t off = (per - 1 + u) * G + g2;
+                        fl[off] = pn[(nw >> (j + 1)) + g2 * per + u];
+                        il[off] = pi[nw + 1 + nw - (nw >> j) + g2 * per + u];
+                    }
+            }
+            for (size_t k = 0; k < 16; ++k)
+                for (size_t g2 = 0; g2 < G; ++g2) {
+                    fl[(15 + k) * G + g2] = pn[nw + 16 * g2 + k];  // fwd_intra: roots[N/2 + word]
+                    il[(15 + k) * G + g2] = pi[1 + 16 * g2 + k];   // inv_intra: inv_roots[1 + word]
+                }
+            PFHE_TRY(upload(fl, &P.fwd_last_w));
+            PFHE_TRY(upload(il, &P.inv_last_w));
         }
         ts->roots.push_back(host[i].root);
         ts->inv_roots.push_back(host[i].inv_root);
