@@ -261,6 +261,25 @@ int transform_host(const TableSet &t, u64 *host, size_t len, bool inverse, bool 
     PFHE_TRY(st.alloc(len * sizeof(u64), &dv));
     u64 *d = static_cast<u64 *>(dv);
     const size_t unit = t.n * t.L;
+    // A slice of at most one piece is not copied at all: it is pinned in place and the kernels read and write it over the
+    // link themselves (first pass host -> device scratch, last pass device scratch -> host; single-pass rings in place on
+    // the mapped memory).  Two kernel launches and one synchronisation instead of copy, two kernels, copy:
+    // 2^16-point transform 60 -> 45 us (tools/perf_host_slice.py); PFHE_STAGE_ZERO_COPY=0 keeps the copies.
+    static const bool zero_copy = [] {
+        const char *e = std::getenv("PFHE_STAGE_ZERO_COPY");
+        return !(e && *e == '0');
+    }();
+    if (zero_copy && len * sizeof(u64) <= stage_chunk_bytes()) {
+        if (u64 *mapped = static_cast<u64 *>(st.map(host, len * sizeof(u64)))) {
+            const int rc = ntt_transform_through_dev(t.primes_dev, t.L, t.log_n, t.ntt_arith, mapped, d, units * t.L, inverse, lazy,
+                                                     st.stream(), t.tune);
+            if (rc != PFHE_ERR_UNSUPPORTED) {
+                st.touch();
+                PFHE_TRY(rc);
+                return st.finish();
+            }
+        }
+    }
     const bool pinned = st.pin(host, len * sizeof(u64));
     // pageable copies block the calling thread: nothing to pipeline, one piece
     const size_t per = pinned ? std::max<size_t>(1, stage_chunk_bytes() / (unit * sizeof(u64))) : (size_t)units;

@@ -74,8 +74,10 @@ __global__ void ntt_tiny_kernel(u64 *__restrict__ data, const NttPrime *__restri
 //   inverse: stages with butterfly distance S ... S*2^(K-1); FINAL marks that the top stage is
 //            the last stage of the whole transform (fused N^-1 scaling, table.rs:283-318).
 // ------------------------------------------------------------------------------------------
+// `src`: where the pass reads (the in-place kernels pass `data` itself, which the compiler sees as the same pointer; the
+// out-of-place kernels of the host-pointer path read pinned host memory and write device memory, or the reverse).
 template <class A, int K, int VEC, bool INV, bool FINAL, bool NT = false>
-__device__ __forceinline__ void strided_pass_body(u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L,
+__device__ __forceinline__ void strided_pass_body(u64 *__restrict__ data, const u64 *src, const NttPrime *__restrict__ primes, u32 L,
                                                   u32 log_n, u32 log_s, u64 gid, u64 total_threads, u32 lazy) {
     constexpr int R = 1 << K;
     if (gid >= total_threads) return;
@@ -89,18 +91,20 @@ __device__ __forceinline__ void strided_pass_body(u64 *__restrict__ data, const 
     const A ar(primes + pid_lo % L);
     const u32 n = 1u << log_n;
     const u32 ebase = hi << (log_s + K);  // element index of register 0, column 0
-    u64 *__restrict__ ptr = data + (u64)pid_lo * n + ebase + (u64)col * VEC;
+    const u64 word0 = (u64)pid_lo * n + ebase + (u64)col * VEC;
+    u64 *__restrict__ ptr = data + word0;
+    const u64 *sptr = src + word0;
 
     u64 x[R][VEC];
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         // streaming (non-temporal) loads: this pass reads every word exactly once; 2.27 -> 2.16 ms per launch
         if constexpr (VEC == 2) {
-            const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(ptr + ((u64)k << log_s)));
+            const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(sptr + ((u64)k << log_s)));
             x[k][0] = v.x;
             x[k][1] = v.y;
         } else {
-            x[k][0] = __builtin_nontemporal_load(ptr + ((u64)k << log_s));
+            x[k][0] = __builtin_nontemporal_load(sptr + ((u64)k << log_s));
         }
     }
 
@@ -130,8 +134,16 @@ template <class A, int K, int VEC, bool INV, bool FINAL, bool NT = false>
 __global__ __launch_bounds__(256, K <= 4 ? (VEC == 1 ? 5 : kStridedMinWaves) : 1) void ntt_strided_kernel(u64 *__restrict__ data,
                                                           const NttPrime *__restrict__ primes, u32 L,
                                                           u32 log_n, u32 log_s, u64 total_threads, u32 lazy) {
-    strided_pass_body<A, K, VEC, INV, FINAL, NT>(data, primes, L, log_n, log_s,
+    strided_pass_body<A, K, VEC, INV, FINAL, NT>(data, data, primes, L, log_n, log_s,
                                                  (u64)blockIdx.x * blockDim.x + threadIdx.x, total_threads, lazy);
+}
+// out-of-place form (host-pointer path, ntt_transform_through_dev): plain stores
+template <class A, int K, int VEC, bool INV, bool FINAL>
+__global__ __launch_bounds__(256) void ntt_strided_oop_kernel(u64 *__restrict__ dst, const u64 *__restrict__ src,
+                                                              const NttPrime *__restrict__ primes, u32 L, u32 log_n, u32 log_s,
+                                                              u64 total_threads, u32 lazy) {
+    strided_pass_body<A, K, VEC, INV, FINAL, false>(dst, src, primes, L, log_n, log_s,
+                                                    (u64)blockIdx.x * blockDim.x + threadIdx.x, total_threads, lazy);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -154,8 +166,9 @@ struct NoHook {
 };
 // after_stage runs once the block's own global loads have landed in LDS (the pipelined kernel issues the loads of its
 // strided chunk there, so that they are in flight during the block's stages and do not delay the block's first wait)
+// `src`: where the pass reads (`data` itself for the in-place kernels; see strided_pass_body)
 template <class A, int LOGB, bool INV, bool MUL, int LOGE = 4, class Hook = NoHook, bool NTIO = false>
-__device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const NttPrime *__restrict__ primes, u32 L,
+__device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const u64 *src, const NttPrime *__restrict__ primes, u32 L,
                                                 u32 log_n, u64 total_blocks, u32 lazy, const u64 *__restrict__ mul,
                                                 u64 mul_polys, u64 *__restrict__ lds_raw, u64 first_block,
                                                 Hook after_stage = Hook()) {
@@ -178,6 +191,7 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
     const u32 n = 1u << log_n;
     const u32 eblk = bi << LOGB;
     u64 *__restrict__ gptr = data + pid * n + eblk;
+    const u64 *sgptr = src + pid * n + eblk;
     u64 *__restrict__ lds = lds_raw + (size_t)sub * Cfg::LDS_WORDS;
 
     // Forward direction: the first register pass wants register k of thread lt = element (k << POS0) + lt, which 8-byte
@@ -195,7 +209,7 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
     if constexpr (kDirectLoad) {
 #pragma unroll
         for (int k = 0; k < Cfg::E; ++k)
-            x[k] = valid ? __builtin_nontemporal_load(gptr + ((u32)k << (LOGB - LOGE)) + lt) : 0ull;
+            x[k] = valid ? __builtin_nontemporal_load(sgptr + ((u32)k << (LOGB - LOGE)) + lt) : 0ull;
         // (forward: issuing them in front of the last register pass instead — the per-lane-twiddle one — costs 152 registers)
         after_stage();
         block_forward_core<A, LOGB, false, LOGE>(ar, x, lds, n, eblk, lt, lazy != 0);
@@ -208,7 +222,7 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const Nt
     // all global traffic as 16-byte vectors in natural order (1 KiB per wave instruction), staged
     // through LDS into / out of the register layouts of the first / last register pass
     if (valid) {
-        load_block_vectors<LOGB, LOGE, kNt>(io, gptr, lt);
+        load_block_vectors<LOGB, LOGE, kNt>(io, sgptr, lt);
     } else {
 #pragma unroll
         for (int j = 0; j < NV; ++j) io[j] = u64x2{0, 0};
@@ -280,7 +294,7 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_wave
     const u64 *__restrict__ mul, u64 mul_polys) {
     static_assert(LOGB >= 10 && LOGB <= 12, "the capped form is for blocks of 2^10 .. 2^12");
     extern __shared__ __attribute__((aligned(16))) u64 lds_raw[];
-    block_pass_body<A, LOGB, INV, MUL, 4, NoHook, NT>(data, primes, L, log_n, total_blocks, lazy, mul, mul_polys, lds_raw,
+    block_pass_body<A, LOGB, INV, MUL, 4, NoHook, NT>(data, data, primes, L, log_n, total_blocks, lazy, mul, mul_polys, lds_raw,
                                                       blockIdx.x);
 }
 template <class A, int LOGB, bool INV, bool MUL = false, bool NT = false>
@@ -289,7 +303,7 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_wave
     const u64 *__restrict__ mul, u64 mul_polys) {
     static_assert(LOGB >= 13, "blocks of 2^13 and 2^14");
     extern __shared__ __attribute__((aligned(16))) u64 lds_raw[];
-    block_pass_body<A, LOGB, INV, MUL, 4, NoHook, NT>(data, primes, L, log_n, total_blocks, lazy, mul, mul_polys, lds_raw,
+    block_pass_body<A, LOGB, INV, MUL, 4, NoHook, NT>(data, data, primes, L, log_n, total_blocks, lazy, mul, mul_polys, lds_raw,
                                                       blockIdx.x);
 }
 template <class A, int LOGB, bool INV, bool MUL = false, bool NT = false>
@@ -298,8 +312,18 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) void ntt_block_small_kerne
     const u64 *__restrict__ mul, u64 mul_polys) {
     static_assert(LOGB < 10, "blocks below 2^10");
     extern __shared__ __attribute__((aligned(16))) u64 lds_raw[];
-    block_pass_body<A, LOGB, INV, MUL, 4, NoHook, NT>(data, primes, L, log_n, total_blocks, lazy, mul, mul_polys, lds_raw,
+    block_pass_body<A, LOGB, INV, MUL, 4, NoHook, NT>(data, data, primes, L, log_n, total_blocks, lazy, mul, mul_polys, lds_raw,
                                                       blockIdx.x);
+}
+
+// out-of-place form of the 2^12 block pass (host-pointer path, ntt_transform_through_dev)
+template <class A, bool INV>
+__global__ __launch_bounds__(BlockCfg<12>::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_block_oop_kernel(
+    u64 *__restrict__ dst, const u64 *__restrict__ src, const NttPrime *__restrict__ primes, u32 L, u32 log_n, u64 total_blocks,
+    u32 lazy) {
+    extern __shared__ __attribute__((aligned(16))) u64 lds_raw[];
+    block_pass_body<A, 12, INV, false, 4, NoHook, false>(dst, src, primes, L, log_n, total_blocks, lazy, nullptr, 0, lds_raw,
+                                                         blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -439,7 +463,7 @@ __device__ __forceinline__ void ntt_pipe_body(
         }
     };
     if (chunk < blk_total) {
-        block_pass_body<A, LOGB, INV, MUL>(blk_data, primes, L, log_n, blk_total, INV ? 0u : lazy, mul, mul_polys, lds_raw,
+        block_pass_body<A, LOGB, INV, MUL>(blk_data, blk_data, primes, L, log_n, blk_total, INV ? 0u : lazy, mul, mul_polys, lds_raw,
                                            chunk, issue);
     } else {
         issue();
@@ -1103,6 +1127,60 @@ int ntt_forward_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *da
 int ntt_inverse_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, bool lazy,
                     hipStream_t s, const NttTuning &tune) {
     return transform(primes, L, log_n, arith, data, npolys, true, lazy, s, tune);
+}
+
+// Transform of a batch that lives in device-visible HOST memory (`io`: pinned / registered), every word crossing the link
+// once in each direction and no copy engine involved: single-pass rings run their in-place kernel on `io` itself; two-pass
+// rings (one strided pass + blocks of 2^12) read `io` in their first pass, keep the intermediate in `scratch` (device,
+// same size) and write `io` in their second.  PFHE_ERR_UNSUPPORTED: shape not covered (the caller copies instead).
+template <class A>
+static int through_dev_two_pass(const NttPlan &plan, const NttPrime *primes, u32 L, u32 log_n, u64 *io, u64 *scratch, u64 npolys,
+                                bool inverse, bool lazy, hipStream_t s) {
+    const int k = plan.strided[0];
+    const u32 log_s = log_n - k;
+    const u64 sthreads = (npolys << (log_n - k)) >> (k == 5 ? 0 : 1), sgrid = (sthreads + 255) / 256;  // K = 5: one column per thread
+    const u64 blocks = npolys << (log_n - 12);
+    if (sgrid > 0x7fffffffull || blocks > 0x7fffffffull) return PFHE_ERR_UNSUPPORTED;
+    constexpr size_t lds_bytes = (size_t)BlockCfg<12>::LDS_WORDS * sizeof(u64);
+    const auto strided = [&](auto kc, u64 *dst, const u64 *src) {
+        constexpr int K = decltype(kc)::value, VEC = K == 5 ? 1 : 2;
+        if (!inverse)
+            hipLaunchKernelGGL((ntt_strided_oop_kernel<A, K, VEC, false, false>), dim3((u32)sgrid), dim3(256), 0, s, dst, src, primes,
+                               L, log_n, log_s, sthreads, 0u);
+        else
+            hipLaunchKernelGGL((ntt_strided_oop_kernel<A, K, VEC, true, true>), dim3((u32)sgrid), dim3(256), 0, s, dst, src, primes,
+                               L, log_n, log_s, sthreads, lazy ? 1u : 0u);
+    };
+    const auto strided_k = [&](u64 *dst, const u64 *src) {
+        if (k == 3) strided(std::integral_constant<int, 3>{}, dst, src);
+        else if (k == 4) strided(std::integral_constant<int, 4>{}, dst, src);
+        else strided(std::integral_constant<int, 5>{}, dst, src);
+    };
+    if (!inverse) {
+        strided_k(scratch, io);
+        hipLaunchKernelGGL((ntt_block_oop_kernel<A, false>), dim3((u32)blocks), dim3(BlockCfg<12>::THREADS), lds_bytes, s, io,
+                           scratch, primes, L, log_n, blocks, lazy ? 1u : 0u);
+    } else {
+        hipLaunchKernelGGL((ntt_block_oop_kernel<A, true>), dim3((u32)blocks), dim3(BlockCfg<12>::THREADS), lds_bytes, s, scratch,
+                           io, primes, L, log_n, blocks, 0u);
+        strided_k(io, scratch);
+    }
+    PFHE_HIP(hipGetLastError());
+    return PFHE_OK;
+}
+
+int ntt_transform_through_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *io, u64 *scratch, u64 npolys,
+                              bool inverse, bool lazy, hipStream_t s, const NttTuning &tune) {
+    if (arith == kArithB32) return PFHE_ERR_UNSUPPORTED;
+    const NttPlan plan = make_ntt_plan(log_n, arith, tune);
+    if (plan.tiny || plan.n_strided == 0)
+        return inverse ? ntt_inverse_dev(primes, L, log_n, arith, io, npolys, lazy, s, tune)
+                       : ntt_forward_dev(primes, L, log_n, arith, io, npolys, lazy, s, tune);
+    if (plan.n_strided != 1 || plan.block_log != 12 || plan.strided[0] < 3 || plan.strided[0] > 5 || scratch == nullptr)
+        return PFHE_ERR_UNSUPPORTED;
+    if (arith == kArithMont) return through_dev_two_pass<MontArith>(plan, primes, L, log_n, io, scratch, npolys, inverse, lazy, s);
+    return arith == kArithPm ? through_dev_two_pass<PmArith>(plan, primes, L, log_n, io, scratch, npolys, inverse, lazy, s)
+                             : through_dev_two_pass<ShoupArith>(plan, primes, L, log_n, io, scratch, npolys, inverse, lazy, s);
 }
 
 int ntt_inverse_mul_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, const u64 *mul,

@@ -50,6 +50,11 @@ int ntt_forward_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *da
 int ntt_transform_form(u32 L, u32 log_n, int arith, u64 npolys, bool inverse, const NttTuning &tune, char *buf, size_t cap);
 int ntt_inverse_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, bool lazy,
                     hipStream_t s, const NttTuning &tune = NttTuning());
+// transform of a batch in device-visible HOST memory `io` (pinned / registered) without copy engines: the first pass reads
+// `io`, the last writes it, the intermediate of two-pass rings stays in `scratch` (device memory of the same size).
+// PFHE_ERR_UNSUPPORTED: shape not covered (u32 tables, more than one strided pass).  64-bit policies only.
+int ntt_transform_through_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *io, u64 *scratch, u64 npolys,
+                              bool inverse, bool lazy, hipStream_t s, const NttTuning &tune = NttTuning());
 // inverse transform of data (*) mul, the pointwise product fused into the loads of the first
 // (block) pass; `mul` holds mul_polys limb-polynomials (npolys, or one unit of L shared by the batch).
 // 64-bit policies only.
@@ -800,72 +805,13 @@ __device__ __forceinline__ void lds_put_layout(const u64 (&x)[1 << LOGE], u64 *_
 // slots it read in the previous exchange (layout FROM is that exchange's layout TO).
 // The threads that trade words in one exchange have ids inside one aligned block of 2^max(FROM, TO) threads; up to
 // 2^6 that is a single wave, whose LDS accesses execute in program order: no workgroup barrier between the
-// writes and the reads either (PFHE_NO_WAVE_LOCAL_EXCHANGE restores both barriers everywhere).
-#if defined(PFHE_EXCHANGE_DPP)
-// EXPERIMENT (round 4, VERDICT r3 "cross-lane register exchanges"): the exchange between layouts <4> and <0> is a
-// 16 x 16 transposition inside every aligned group of 16 lanes — one DPP row — so it can run in registers: four
-// recursive steps (lane distance 8, 4, 2, 1), each trading half of the 64-bit registers with the partner lane.  Distances
-// 8 and 4 are row shifts whose destination lanes a bank mask selects (two v_mov_b32_dpp per dword); distances 2 and 1 are
-// quad permutations, where no mask separates the two halves of a quad (two v_mov_b32_dpp + two v_cndmask_b32 per dword).
-// 224 vector instructions per exchange against 32 LDS instructions and none on the VALU: measured in
-// profiles/r04_exchange_dpp.txt, not adopted (this block compiles only under -DPFHE_EXCHANGE_DPP).
-template <int CTRL, int BANKS, bool BOUND>
-__device__ __forceinline__ u32 dpp_mov(u32 old, u32 src) {
-    return (u32)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xF, BANKS, BOUND);
-}
-__device__ __forceinline__ void dpp_transpose16(u64 (&x)[16]) {
-    const u32 lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    u32 lo[16], hi[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) lo[k] = (u32)x[k], hi[k] = (u32)(x[k] >> 32);
-    const auto step_shift = [&](auto dc, u32 (&v)[16]) {
-        constexpr int d = decltype(dc)::value;  // 8 or 4: lanes with bit d clear take banks (d == 8 ? 0b0011 : 0b0101)
-        constexpr int kLow = d == 8 ? 0x3 : 0x5, kHigh = d == 8 ? 0xC : 0xA;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            if (k & d) continue;
-            const u32 a = v[k], b = v[k | d];
-            v[k | d] = dpp_mov<0x100 + d, kLow, false>(b, a);   // row_shl:d — lanes without bit d: partner's A
-            v[k] = dpp_mov<0x110 + d, kHigh, false>(a, b);      // row_shr:d — lanes with bit d: partner's B
-        }
-    };
-    const auto step_quad = [&](auto dc, u32 (&v)[16]) {
-        constexpr int d = decltype(dc)::value;  // 2 or 1
-        constexpr int kPerm = d == 2 ? 0x4E : 0xB1;  // quad_perm [2,3,0,1] / [1,0,3,2]
-        const bool upper = (lane & d) != 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            if (k & d) continue;
-            const u32 a = v[k], b = v[k | d];
-            const u32 pa = dpp_mov<kPerm, 0xF, true>(0u, a), pb = dpp_mov<kPerm, 0xF, true>(0u, b);
-            v[k | d] = upper ? b : pa;
-            v[k] = upper ? pb : a;
-        }
-    };
-    step_shift(std::integral_constant<int, 8>{}, lo);
-    step_shift(std::integral_constant<int, 8>{}, hi);
-    step_shift(std::integral_constant<int, 4>{}, lo);
-    step_shift(std::integral_constant<int, 4>{}, hi);
-    step_quad(std::integral_constant<int, 2>{}, lo);
-    step_quad(std::integral_constant<int, 2>{}, hi);
-    step_quad(std::integral_constant<int, 1>{}, lo);
-    step_quad(std::integral_constant<int, 1>{}, hi);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) x[k] = ((u64)hi[k] << 32) | lo[k];
-}
-#endif
-
+// writes and the reads either.
+// (Round 4 measured the wave-local <4> <-> <0> exchange as an in-register DPP transposition instead: +222 vector
+// instructions per thread for 32 LDS instructions fewer, block pass +4.4 % — profiles/r04_exchange_dpp.txt; the code is in
+// the commit "Experiment: the <4> <-> <0> exchange of the block cores as a DPP transposition".)
 template <int FROM, int TO, bool FIRST, int LOGE = 4>
 __device__ __forceinline__ void lds_exchange(u64 (&x)[1 << LOGE], u64 *__restrict__ lds, u32 lt) {
     constexpr bool kLead = FIRST, kWaveLocal = (FROM > TO ? FROM : TO) <= 6;
-#if defined(PFHE_EXCHANGE_DPP)
-    if constexpr (LOGE == 4 && ((FROM == 4 && TO == 0) || (FROM == 0 && TO == 4))) {
-        // (a leading barrier still separates this chain's later LDS traffic from the caller's staging reads)
-        if constexpr (kLead) __syncthreads();
-        dpp_transpose16(x);
-        return;
-    }
-#endif
     if constexpr (kLead) __syncthreads();
     lds_put_layout<FROM, LOGE>(x, lds, lt);
     if constexpr (kWaveLocal) {

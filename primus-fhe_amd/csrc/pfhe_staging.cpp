@@ -172,18 +172,29 @@ HostStage::HostStage(int device) {
 // Pins [host, host + bytes) in place for this call.  Memory that already is pinned (hipHostMalloc, or registered by the
 // caller) needs nothing; a refusal (read-only mapping, pages held by another registration) sends the caller to the
 // bounce / pageable path.
-bool HostStage::pin(const void *host, size_t bytes) {
+bool HostStage::pin(const void *host, size_t bytes, bool any_size) {
     const Pool &P = pool();
     char *h = static_cast<char *>(const_cast<void *>(host));
     for (const StageCtx::Range &r : ctx_->registered)
         if (h >= r.p && h + bytes <= r.p + r.bytes) return true;  // pieces of a pinned slice; in-place downloads
-    if (!P.use_register || bytes < P.register_min) return false;
+    if (!P.use_register || (!any_size && bytes < P.register_min)) return false;
     if (hipHostRegister(h, bytes, hipHostRegisterDefault) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
     ctx_->registered.push_back(StageCtx::Range{h, bytes});
     return true;
+}
+
+void *HostStage::map(void *host, size_t bytes) {
+    // (no minimum size: against a bounce copy + two DMA operations, pinning — 1.1 us — pays from the smallest slice)
+    if (!pin(host, bytes, true)) return nullptr;
+    void *d = nullptr;
+    if (hipHostGetDevicePointer(&d, host, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return d;
 }
 
 void HostStage::unpin_all() {

@@ -60,7 +60,12 @@ class HostStage {
     // true asynchronous DMA.  False when the range is too small to be worth it or the runtime refuses (read-only
     // mapping, pages held by another registration): copies of it then go through the bounce buffer / the runtime's
     // pageable path.  copy_in / download call it themselves; a caller that copies a slice piece by piece pins it whole.
-    bool pin(const void *host, size_t bytes);
+    bool pin(const void *host, size_t bytes, bool any_size = false);
+    // pin() + the device-side address of the pinned range (kernels then read / write the caller's memory over the
+    // link themselves: no copy engine, no bounce); null when the range cannot be pinned
+    void *map(void *host, size_t bytes);
+    // marks the call as having queued work on the context's streams (kernels on mapped memory)
+    void touch() { dirty_ = true; }
 
   private:
     void unpin_all();

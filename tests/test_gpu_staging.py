@@ -140,3 +140,53 @@ def test_staging_release_returns_the_pool(pf):
     t.inverse_transform_slice(x)   # the pool grows again
     assert np.array_equal(x, np.arange(1 << 12, dtype=np.uint64))
     assert alloc_count(pf) > before
+
+
+@pytest.mark.parametrize("log_n", [10, 14, 15, 16, 17])
+@pytest.mark.parametrize("kind", ["pm", "mont", "shoup"])
+def test_zero_copy_slices_match_oracle(pf, orc, log_n, kind, monkeypatch):
+    """Slices of at most one piece are pinned in place and transformed by kernels that read and write the caller's
+    memory themselves (ntt_transform_through_dev: out-of-place first / last pass for two-pass rings, the in-place kernel
+    on the mapped memory for single-pass ones).  Every arithmetic policy, both directions, lazy forms, ragged batch."""
+    moduli = {"pm": Q61, "mont": Q61, "shoup": [Q62]}[kind]
+    if kind == "mont":
+        monkeypatch.setenv("PFHE_DISABLE_PM", "1")
+    d, o = pf.U64DcrtTable(log_n, moduli), orc.U64DcrtTable(log_n, moduli)
+    monkeypatch.delenv("PFHE_DISABLE_PM", raising=False)
+    n, L = 1 << log_n, len(moduli)
+    batch = max(1, min(3, (8 << 20) // (L * n * 8)))
+    rng = np.random.default_rng(log_n)
+    a = rand_rns(rng, moduli, n, batch)
+    assert a.nbytes <= (8 << 20)
+    ref = a.copy(); o.transform_slice(ref)
+    x = a.copy(); d.transform_slice(x)
+    assert np.array_equal(x, ref)
+    d.inverse_transform_slice(x)
+    assert np.array_equal(x, a)
+    qs = np.tile(np.repeat(np.array(moduli, dtype=np.uint64), n), batch)
+    lz = a.copy(); d.lazy_transform_slice(lz)
+    assert (lz < 4 * qs).all() and np.array_equal(lz % qs, ref)
+    lzi = ref.copy(); d.lazy_inverse_transform_slice(lzi)
+    assert (lzi < 2 * qs).all() and np.array_equal(lzi % qs, a)
+    # an unaligned view of a larger buffer (the slice does not start on a page, nor on 16 bytes of the pinned range)
+    big = np.zeros(a.size + 3, np.uint64)
+    view = big[1:1 + a.size]
+    view[:] = a
+    d.transform_slice(view)
+    assert np.array_equal(view, ref) and big[0] == 0 and big[-1] == 0 and big[-2] == 0
+
+
+def test_zero_copy_and_copy_paths_agree(pf, orc):
+    """PFHE_STAGE_ZERO_COPY=0 (read when the library is loaded... per process) cannot be flipped here; the copy path is
+    what slices above one piece take: compare a 3-polynomial slice (zero-copy) with the same polynomials inside a
+    24-polynomial slice (pinned + pipelined copies)."""
+    log_n = 16
+    n = 1 << log_n
+    d = pf.U64DcrtTable(log_n, Q61)
+    rng = np.random.default_rng(99)
+    small = rand_rns(rng, Q61, n, 1)
+    large = np.concatenate([small, rand_rns(rng, Q61, n, 23)])
+    assert small.nbytes <= (8 << 20) < large.nbytes
+    d.transform_slice(small)
+    d.transform_slice(large)
+    assert np.array_equal(large[:small.size], small)
