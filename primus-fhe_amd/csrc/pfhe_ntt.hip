@@ -92,7 +92,6 @@ __device__ __forceinline__ void strided_pass_body(u64 *__restrict__ data, const 
     const u32 n = 1u << log_n;
     const u32 ebase = hi << (log_s + K);  // element index of register 0, column 0
     const u64 word0 = (u64)pid_lo * n + ebase + (u64)col * VEC;
-    u64 *__restrict__ ptr = data + word0;
     const u64 *sptr = src + word0;
 
     u64 x[R][VEC];
@@ -114,12 +113,21 @@ __device__ __forceinline__ void strided_pass_body(u64 *__restrict__ data, const 
         strided_inverse_regs<A, K, VEC, FINAL>(ar, x, n, ebase, log_s, lazy != 0);
     }
 
+    // The store addresses are recomputed from an opaque copy of the column index: derived from `ptr` they are the load
+    // addresses, which the compiler keeps alive through all K stages (2^K 64-bit pairs: 32 of the two-column kernel's
+    // 134-136 registers, three waves per SIMD).  Recomputed: 100-106 registers, four waves, and the pass streams faster —
+    // forward K = 4: 2.10 -> 2.005 ms per 12.9 GB (6.13 -> 6.43 TB/s), inverse 2.18 -> 2.12 ms; inverse K = 5: 2.22 -> 2.04 ms.
+    // The forward one-column K = 5 kernel loses (2.10 -> 2.25 ms) and keeps its addresses.
+    constexpr bool kRecompute = VEC == 2 || INV;
+    u32 col2 = col;
+    if constexpr (kRecompute) asm volatile("" : "+v"(col2));
+    u64 *__restrict__ optr = data + (u64)pid_lo * n + ebase + (u64)col2 * VEC;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         if constexpr (VEC == 2) {
-            gstore<NT>(reinterpret_cast<u64x2 *>(ptr + ((u64)k << log_s)), u64x2{x[k][0], x[k][1]});
+            gstore<NT>(reinterpret_cast<u64x2 *>(optr + ((u64)k << log_s)), u64x2{x[k][0], x[k][1]});
         } else {
-            gstore<NT>(ptr + ((u64)k << log_s), x[k][0]);
+            gstore<NT>(optr + ((u64)k << log_s), x[k][0]);
         }
     }
 }
