@@ -115,7 +115,7 @@ __global__ __launch_bounds__(LOGE == 3 ? 512 : 256, LOGE == 3 ? kMulacc8MinWaves
 #pragma unroll
         for (int k = 0; k < (1 << LOGE); ++k)
             x[k] = __builtin_nontemporal_load(dg + (u64)ij * W + ((u32)k << (LOGB - LOGE)) + ltl);
-        block_forward_core<A, LOGB, true, LOGE>(ar, x, lds, n, eblk, ltl, /*lazy=*/true);  // digit_hat mod~ q
+        block_forward_core<A, LOGB, true, LOGE, NoLateHook, true>(ar, x, lds, n, eblk, ltl, /*lazy=*/true);  // digit_hat mod~ q, raw
         lds_put_layout<0, LOGE>(x, lds, ltl);
         __syncthreads();
         lds_get_vectors<LOGB, LOGE>(io, lds, ltl);  // natural order again: same positions as the key vectors
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_wave
             const int d = (sdigits + e * rows * ell * n + ltl)[(u64)ij * n + (u32)k * Cfg::TPB];
             x[k] = d < 0 ? ar.q + (u64)(long long)d : (u64)d;
         }
-        block_forward_core<A, LOGB>(ar, x, lds, n, 0u, ltl, /*lazy=*/true);
+        block_forward_core<A, LOGB, true, 4, NoLateHook, true>(ar, x, lds, n, 0u, ltl, /*lazy=*/true);
         const bool fold_now = (ij % kPmMacFoldEvery) == kPmMacFoldEvery - 1;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {

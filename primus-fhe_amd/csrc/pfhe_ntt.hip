@@ -529,7 +529,7 @@ __device__ __forceinline__ void block_mid_body(const A &ar, u64 *__restrict__ gp
 #pragma unroll
         for (int k = 0; k < Cfg::E; ++k) x[k] = valid ? __builtin_nontemporal_load(gptr + ((u32)k << POS0) + lt) : 0ull;
         after_load();
-        block_forward_core<A, LOGB, false>(ar, x, lds, n, eblk, lt, /*lazy=*/true);
+        block_forward_core<A, LOGB, false, 4, NoLateHook, true>(ar, x, lds, n, eblk, lt, /*lazy=*/true);  // raw: feeds the product
         lds_put_layout<0>(x, lds, lt);
     }
     {
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_wave
         {
             const u32 lt = opaque_tid();
             // (leading barrier of the first exchange: the previous polynomial's last exchange may still be read)
-            block_forward_core<A, LOGB, true>(ar, x, lds, n, 0u, lt, /*lazy=*/true);
+            block_forward_core<A, LOGB, true, 4, NoLateHook, true>(ar, x, lds, n, 0u, lt, /*lazy=*/true);  // raw: feeds the product
             lds_put_layout<0>(x, lds, lt);
         }
         {

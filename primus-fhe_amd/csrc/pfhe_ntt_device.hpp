@@ -683,7 +683,8 @@ __device__ __forceinline__ u32 last_table_off(u32 n, u32 e0, int j, int u) {
 
 // forward stages on register bits JHI..JLO (element bits POS+JHI .. POS+JLO); twiddle of the
 // butterfly at global element E, distance 2^p: fwd[(N + E) >> (p + 1)]
-template <class A, int POS, int JHI, int JLO, bool UNIFORM, int LOGE = 4>
+// EVEN: wide policies fold the x input at EVEN distances 2^p instead of odd ones (see block_forward_core)
+template <class A, int POS, int JHI, int JLO, bool UNIFORM, int LOGE = 4, bool EVEN = false>
 __device__ __forceinline__ void fwd_regpass(const A &ar, u64 (&x)[1 << LOGE], u32 n_plus_e, u32 n) {
     constexpr int E = 1 << LOGE;
 #pragma unroll
@@ -712,7 +713,7 @@ __device__ __forceinline__ void fwd_regpass(const A &ar, u64 (&x)[1 << LOGE], u3
                     const int ua = b >> j, va = b & ((1 << j) - 1), ub = (b + 1) >> j, vb = (b + 1) & ((1 << j) - 1);
                     const int a0 = (ua << (j + 1)) | va, a1 = a0 | (1 << j), b0 = (ub << (j + 1)) | vb, b1 = b0 | (1 << j);
                     if constexpr (A::kMont) mont_fwd_bfly2<kUni>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
-                    else if ((POS + j) & 1) pm_fwd_bfly2<true, kUni>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
+                    else if ((((POS + j) & 1) != 0) != EVEN) pm_fwd_bfly2<true, kUni>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
                     else pm_fwd_bfly2<false, kUni>(ar, x[a0], x[a1], w[ua], x[b0], x[b1], w[ub]);
                 }
             }
@@ -725,7 +726,7 @@ __device__ __forceinline__ void fwd_regpass(const A &ar, u64 (&x)[1 << LOGE], u3
 #pragma unroll
             for (int v = 0; v < (1 << j); ++v) {
                 const int k0 = (u << (j + 1)) | v, k1 = k0 | (1 << j);
-                if ((POS + j) & 1) fwd_bfly<true, kUni>(ar, x[k0], x[k1], w[u]);  // distance 2^(POS+j)
+                if ((((POS + j) & 1) != 0) != EVEN) fwd_bfly<true, kUni>(ar, x[k0], x[k1], w[u]);  // distance 2^(POS+j)
                 else fwd_bfly<false, kUni>(ar, x[k0], x[k1], w[u]);
             }
         }
@@ -828,7 +829,7 @@ struct NoLateHook {
     __device__ __forceinline__ void operator()() const {}
 };
 // before_last runs in front of the last register pass (the pipelined kernel may issue its strided chunk's loads there)
-template <class A, int LOGB, int POS, bool FIRST = false, int LOGE = 4, class Late = NoLateHook>
+template <class A, int LOGB, int POS, bool FIRST = false, int LOGE = 4, class Late = NoLateHook, bool EVEN = false>
 __device__ __forceinline__ void fwd_chain(const A &ar, u64 (&x)[1 << LOGE], u64 *__restrict__ lds, u32 n, u32 eblk, u32 lt,
                                           Late before_last = Late()) {
     constexpr bool UNI = BlockCfg<LOGB, LOGE>::TPB >= 64;  // a wave never straddles two blocks
@@ -838,21 +839,30 @@ __device__ __forceinline__ void fwd_chain(const A &ar, u64 (&x)[1 << LOGE], u64 
         asm volatile("" : "+v"(lt));  // this pass's LDS and twiddle addresses are computed here, not hoisted to the kernel's top
         lds_exchange<POS, NPOS, FIRST, LOGE>(x, lds, lt);
         if constexpr (NPOS == 0) before_last();
-        fwd_regpass<A, NPOS, JHI, 0, UNI, LOGE>(ar, x, n + eblk + layout<NPOS, LOGE>(lt, 0), n);
-        fwd_chain<A, LOGB, NPOS, false, LOGE, Late>(ar, x, lds, n, eblk, lt, before_last);
+        fwd_regpass<A, NPOS, JHI, 0, UNI, LOGE, EVEN>(ar, x, n + eblk + layout<NPOS, LOGE>(lt, 0), n);
+        fwd_chain<A, LOGB, NPOS, false, LOGE, Late, EVEN>(ar, x, lds, n, eblk, lt, before_last);
     }
 }
 
 // forward compute core: x holds layout<LOGB-LOGE> on entry and layout<0> (canonical unless lazy) on exit
 // LEAD = false: the caller filled x by lds_get_layout<LOGB-LOGE> from this LDS region (so the first exchange, too,
 // only overwrites slots its own thread read last) and needs no barrier in front of it.
-template <class A, int LOGB, bool LEAD = true, int LOGE = 4, class Late = NoLateHook>
+// RAW (only with lazy): the output feeds a product with a second data word on chip (PmArith::mul_full, Barrett) instead of
+// leaving the kernel, so the reference's [0,4q) contract of lazy outputs does not apply.  Wide policies then fold at EVEN
+// distances — the last stage, distance 1, folds its x input — and return x' = X + T, y' = X + 3q - T < 4U + 2^31 as they
+// are: below 2^63 + 2^32, which mul_full takes (its partial sums need y1 <= 2^31), and the finishing fold of every
+// coefficient (4 instructions each) is gone.  The stage in front of the core must have folded (inputs below 4U + 2^31):
+// true for canonical / [0,4q) inputs and behind a strided pass, whose last stage folds.  Montgomery tables skip their
+// closing conditional subtraction the same way (values below 7q; the Barrett product takes any 64-bit word).
+template <class A, int LOGB, bool LEAD = true, int LOGE = 4, class Late = NoLateHook, bool RAW = false>
 __device__ __forceinline__ void block_forward_core(const A &ar, u64 (&x)[1 << LOGE], u64 *__restrict__ lds, u32 n,
                                                    u32 eblk, u32 lt, bool lazy, Late before_last = Late()) {
     constexpr int POS0 = LOGB - LOGE, E = 1 << LOGE;
     constexpr bool UNI = BlockCfg<LOGB, LOGE>::TPB >= 64;  // a wave never straddles two blocks
-    fwd_regpass<A, POS0, LOGE - 1, 0, UNI, LOGE>(ar, x, n + eblk + layout<POS0, LOGE>(lt, 0), n);
-    fwd_chain<A, LOGB, POS0, LEAD, LOGE, Late>(ar, x, lds, n, eblk, lt, before_last);
+    constexpr bool EVEN = RAW && A::kWide;
+    fwd_regpass<A, POS0, LOGE - 1, 0, UNI, LOGE, EVEN>(ar, x, n + eblk + layout<POS0, LOGE>(lt, 0), n);
+    fwd_chain<A, LOGB, POS0, LEAD, LOGE, Late, EVEN>(ar, x, lds, n, eblk, lt, before_last);
+    if constexpr (RAW && (A::kWide || A::kMont)) return;
     if constexpr (A::kPacked) {  // distance-1 stage between the halves of each word
         if constexpr (LOGE == 4) {  // lane-ordered twiddles: slot 15 + k of group (eblk >> 4) + lt
             const u32 off0 = 15u * (n >> 4) + (eblk >> 4) + lt;
