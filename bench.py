@@ -234,17 +234,25 @@ def built_vgprs(kernel: str):
     return None if r is None else (r["vgpr"] or 0) + (r["agpr"] or 0)
 
 
+def vgpr_granules(allocated_registers: int) -> int:
+    """rocprofv3's VGPR_Count column for a gfx950 dispatch: the registers a wave is ALLOCATED — the code object's
+    .vgpr_count rounded up to the granule of 8 — counted in pairs (125 registers -> 128 allocated -> 64; checked on
+    every kernel of profiles/r04_a_rocprof.json against primus-fhe_amd/_codeobj.py)."""
+    return -(-allocated_registers // 8) * 4
+
+
 def provenance(path: str, profiled: dict):
     """A committed counter profile describes the kernels it was taken on.  Its figures are reported only when every
-    kernel it covers still has, in the library being timed, the register count the profiler recorded (rocprofv3's
-    VGPR_Count column, rounded to the allocation granule of 8 as the code object's .vgpr_count is not): a changed kernel
-    makes the profile stale and the traffic null.  Returns (fields for the JSON line, ok)."""
+    kernel it covers still has, in the library being timed, the register allocation the profiler recorded (rocprofv3's
+    VGPR_Count column, see vgpr_granules): a changed kernel makes the profile stale and the traffic null.  Returns
+    (fields for the JSON line, ok)."""
     rows = {}
     ok = bool(profiled)
     for k, v in (profiled or {}).items():
         now = built_vgprs(k)
-        rows[k] = {"profiled_vgpr_count": v, "built_vgpr_count": now}
-        if v is None or now is None or -(-now // 8) * 8 != -(-v // 8) * 8:
+        rows[k] = {"profiled_vgpr_count": v, "built_vgpr_count": now,
+                   "built_as_the_profiler_counts": None if now is None else vgpr_granules(now)}
+        if v is None or now is None or vgpr_granules(now) != v:
             ok = False
     return {"profile": os.path.basename(path), "profile_git_blob": git_blob_hash(path), "kernels_checked": rows,
             "profile_matches_build": ok}, ok

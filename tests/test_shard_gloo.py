@@ -181,16 +181,30 @@ def test_traffic_figures_carry_their_provenance():
     from primus_fhe_amd._codeobj import kernel_resources
     res = kernel_resources(p.library_path())
     assert res["ntt_pipe_fwd_kernel<PmArith, 12>"]["vgpr"] <= 128 and res["ntt_pipe_fwd_kernel<PmArith, 12>"]["scratch"] == 0
-    path = os.path.join(ROOT, "profiles", "r03_d_rocprof.json")
+    path = os.path.join(ROOT, "profiles", "r03_d_rocprof.json")   # (any committed file: only its blob id is read here)
     blob = subprocess.run(["git", "hash-object", path], capture_output=True, text=True, cwd=ROOT).stdout.strip()
     assert bench.git_blob_hash(path) == blob
     built = bench.built_vgprs("ntt_pipe_fwd_kernel<PmArith, 12>")
-    prov, ok = bench.provenance(path, {"ntt_pipe_fwd_kernel<PmArith, 12>": built})
+    assert bench.vgpr_granules(125) == 64 and bench.vgpr_granules(97) == 52   # as rocprofv3 reports them
+    prov, ok = bench.provenance(path, {"ntt_pipe_fwd_kernel<PmArith, 12>": bench.vgpr_granules(built)})
     assert ok and prov["profile_git_blob"] == blob
-    prov, ok = bench.provenance(path, {"ntt_pipe_fwd_kernel<PmArith, 12>": built + 16})
+    prov, ok = bench.provenance(path, {"ntt_pipe_fwd_kernel<PmArith, 12>": bench.vgpr_granules(built) + 8})
     assert not ok and not prov["profile_matches_build"]
     assert not bench.provenance(path, {"ntt_pipe_fwd_kernel<PmArith, 12>": None})[1]   # a profile without register counts
     assert not bench.provenance(path, {})[1]
+    # the newest committed profiles: their traffic is reported exactly when they describe the kernels of this tree
+    t = bench.pmc_traffic("ntt_pipe_fwd_kernel", 4096)
+    assert t is not None
+    if t["provenance"]["profile_matches_build"]:
+        assert 0.9e9 < t["bytes_per_launch"] < 1.2e9, t     # two passes over a 256 MiB tile
+    else:
+        assert t["bytes_per_launch"] is None
+    e = bench.extprod_traffic()
+    assert e is not None
+    if e["provenance"]["profile_matches_build"]:
+        assert 6 * 96 * 65536 < e["bytes_per_product"] < 12 * 96 * 65536, e
+    else:
+        assert e["bytes_per_product"] is None
 
 
 def test_bench_spawner_ends_the_other_ranks_when_one_dies(monkeypatch):
