@@ -15,6 +15,9 @@ unsafe extern "C" {
     pub fn pfhe_device_free(device: c_int, ptr: *mut c_void) -> c_int;
     pub fn pfhe_memcpy_h2d(device: c_int, dst: *mut c_void, src: *const c_void, bytes: usize, stream: *mut c_void) -> c_int;
     pub fn pfhe_memcpy_d2h(device: c_int, dst: *mut c_void, src: *const c_void, bytes: usize, stream: *mut c_void) -> c_int;
+    // host-pointer entry points stage through a per-device pool (no allocation per call): diagnostics
+    pub fn pfhe_debug_alloc_count() -> u64;
+    pub fn pfhe_staging_release(device: c_int) -> c_int;
 
     // U64NttTable
     pub fn pfhe_ntt_create(log_n: u32, modulus: u64, device: c_int, out: *mut *mut pfhe_ntt) -> c_int;
