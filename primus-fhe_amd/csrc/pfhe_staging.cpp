@@ -116,6 +116,7 @@ struct StageCtx {
     struct Range {
         char *p;
         size_t bytes;
+        bool owned;  // registered by this call (to be unregistered); false: memory the caller had pinned already
     };
     std::vector<Range> registered;  // ranges this call pinned in place (hipHostUnregister at the end of the call)
     std::vector<hipEvent_t> events;  // pooled, timing disabled
@@ -180,9 +181,21 @@ bool HostStage::pin(const void *host, size_t bytes, bool any_size) {
     if (!P.use_register || (!any_size && bytes < P.register_min)) return false;
     if (hipHostRegister(h, bytes, hipHostRegisterDefault) != hipSuccess) {
         (void)hipGetLastError();
-        return false;
+        // refused: memory that already is pinned (hipHostMalloc, or registered by the caller) is used as it is
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, h) != hipSuccess || at.type != hipMemoryTypeHost) {
+            (void)hipGetLastError();
+            return false;
+        }
+        hipPointerAttribute_t last{};
+        if (hipPointerGetAttributes(&last, h + bytes - 1) != hipSuccess || last.type != hipMemoryTypeHost) {
+            (void)hipGetLastError();
+            return false;
+        }
+        ctx_->registered.push_back(StageCtx::Range{h, bytes, false});
+        return true;
     }
-    ctx_->registered.push_back(StageCtx::Range{h, bytes});
+    ctx_->registered.push_back(StageCtx::Range{h, bytes, true});
     return true;
 }
 
@@ -199,7 +212,7 @@ void *HostStage::map(void *host, size_t bytes) {
 
 void HostStage::unpin_all() {
     for (const StageCtx::Range &r : ctx_->registered) {
-        if (hipHostUnregister(r.p) != hipSuccess) (void)hipGetLastError();
+        if (r.owned && hipHostUnregister(r.p) != hipSuccess) (void)hipGetLastError();
     }
     ctx_->registered.clear();
 }

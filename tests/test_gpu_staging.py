@@ -190,3 +190,37 @@ def test_zero_copy_and_copy_paths_agree(pf, orc):
     d.transform_slice(small)
     d.transform_slice(large)
     assert np.array_equal(large[:small.size], small)
+
+
+def test_memory_the_runtime_cannot_pin_takes_the_bounce_buffer(pf, orc, tmp_path):
+    """A read-only mapping cannot be registered for device writes (hipHostRegister refuses it); the input of an
+    out-of-place entry point may live there.  The call must still succeed (bounce buffer) and give the oracle's words;
+    and memory that already IS pinned (torch pinned tensor) is used as it is."""
+    import mmap
+
+    import torch
+    n = 1 << 14
+    base, obase = pf.RNSBase(Q61), orc.RNSBase(Q61)
+    rng = np.random.default_rng(11)
+    res = rand_rns(rng, Q61, n, 1)
+    ref = obase.compose_multiple_values_to(res, n)
+    path = tmp_path / "residues.bin"
+    path.write_bytes(res.tobytes())
+    with open(path, "rb") as fh:
+        mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+        ro = np.frombuffer(mm, dtype=np.uint64)
+        assert not ro.flags.writeable
+        big = np.empty(n * base.big_uint_value_len(), np.uint64)
+        base.compose_multiple_values_to(ro, big, n)
+        assert np.array_equal(big, ref)
+        del ro
+        mm.close()
+    # pinned memory of the caller: transform in place
+    log_n = 15
+    t, o = pf.U64NttTable(log_n, Q62), orc.U64NttTable(log_n, Q62)
+    a = rand_mod(rng, Q62, 1 << log_n)
+    exp = a.copy(); o.transform_slice(exp)
+    pinned = torch.from_numpy(a.view(np.int64).copy()).pin_memory()
+    view = pinned.numpy().view(np.uint64)
+    t.transform_slice(view)
+    assert np.array_equal(view, exp)
