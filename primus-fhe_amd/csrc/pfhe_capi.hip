@@ -248,6 +248,14 @@ size_t stage_chunk_bytes() {
     return v;
 }
 
+bool stage_zero_copy() {
+    static const bool v = [] {
+        const char *e = std::getenv("PFHE_STAGE_ZERO_COPY");
+        return !(e && *e == '0');
+    }();
+    return v;
+}
+
 int transform_host(const TableSet &t, u64 *host, size_t len, bool inverse, bool lazy) {
     if (!host && len) return PFHE_ERR_BAD_ARGUMENT;
     u64 units = 0;
@@ -265,11 +273,7 @@ int transform_host(const TableSet &t, u64 *host, size_t len, bool inverse, bool 
     // link themselves (first pass host -> device scratch, last pass device scratch -> host; single-pass rings in place on
     // the mapped memory).  Two kernel launches and one synchronisation instead of copy, two kernels, copy:
     // 2^16-point transform 60 -> 45 us (tools/perf_host_slice.py); PFHE_STAGE_ZERO_COPY=0 keeps the copies.
-    static const bool zero_copy = [] {
-        const char *e = std::getenv("PFHE_STAGE_ZERO_COPY");
-        return !(e && *e == '0');
-    }();
-    if (zero_copy && len * sizeof(u64) <= stage_chunk_bytes()) {
+    if (stage_zero_copy() && len * sizeof(u64) <= stage_chunk_bytes()) {
         if (u64 *mapped = static_cast<u64 *>(st.map(host, len * sizeof(u64)))) {
             const int rc = ntt_transform_through_dev(t.primes_dev, t.L, t.log_n, t.ntt_arith, mapped, d, units * t.L, inverse, lazy,
                                                      st.stream(), t.tune);

@@ -256,6 +256,15 @@ int transform32_host(const TableSet &t, u32 *host, size_t len, bool inverse, boo
     PFHE_TRY(st.alloc(len * sizeof(u32), &dv));
     u32 *d = static_cast<u32 *>(dv);
     const size_t unit = t.n * t.L;
+    // single-pass rings (N <= 2^15 coefficients): a slice of one piece is transformed in place on the pinned memory, the
+    // kernel reading and writing it over the link (see transform_host in pfhe_capi.hip); two-pass rings are copied
+    if (stage_zero_copy() && len * sizeof(u32) <= stage_chunk_bytes() && (t.log_n <= 4 || ntt_num_passes(t.log_n - 1, kArithB32, t.tune) == 1)) {
+        if (u32 *mapped = static_cast<u32 *>(st.map(host, len * sizeof(u32)))) {
+            st.touch();
+            PFHE_TRY(transform32_dev(t, mapped, len, inverse, lazy, st.stream()));
+            return st.finish();
+        }
+    }
     const bool pinned = st.pin(host, len * sizeof(u32));
     const size_t per = pinned ? std::max<size_t>(1, stage_chunk_bytes() / (unit * sizeof(u32))) : (size_t)units;
     const bool pipelined = per < units;
