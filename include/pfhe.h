@@ -72,8 +72,8 @@ int pfhe_memcpy_d2d(int device, void *dst_dev, const void *src_dev, size_t bytes
 int pfhe_memset_dev(int device, void *dst_dev, int byte, size_t bytes, void *stream);
 int pfhe_stream_synchronize(int device, void *stream);
 /* Host-pointer entry points (`*_slice`, `*_to` without `_dev`) behave like the reference's `&self, &mut [T]` methods
- * (table.rs:541-563: in place, no allocation per call): each call borrows a staging context — private stream, cached
- * device arena, pinned bounce buffer — from a per-device pool and returns it, so calls of a size seen before allocate
+ * (table.rs:541-563: in place, no allocation per call): each call borrows a staging context — private streams, cached
+ * device arena, pinned host buffer — from a per-device pool and returns it, so calls of a size seen before allocate
  * nothing and any number of threads may call through one handle concurrently (NttTable: Send + Sync).
  * pfhe_debug_alloc_count: device / pinned allocation and free calls the library has made since it was loaded (a
  * steady-state loop must not move it).  pfhe_staging_release: frees the idle contexts of `device` (-1: all devices),

@@ -235,15 +235,23 @@ int transform_dev(const TableSet &t, u64 *data, size_t len, bool inverse, bool l
 }
 
 // Host-pointer form of the transforms (table.rs:541-563 takes `&mut [T]` in place): the slice is staged through a
-// pooled context (pfhe_staging.hpp: no allocation in steady state) and pinned in place for the call.  Polynomials are
-// independent, so a long slice is cut into pieces of whole units and pipelined over the context's two streams: one
-// carries the copies in, the other waits for each piece, transforms it and copies it back — the copy back of piece i
-// overlaps the copy in of piece i + 1 (the link is full duplex).
+// pooled context (pfhe_staging.hpp: no allocation in steady state).  Polynomials are independent, so a long slice in
+// memory the CALLER pinned is cut into pieces of whole units and pipelined over the context's two streams: one carries the
+// copies in, the other waits for each piece, transforms it and copies it back — the copy back of piece i overlaps the
+// copy in of piece i + 1 (the link is full duplex); pageable copies block the calling thread and go as one piece.
 size_t stage_chunk_bytes() {
     static const size_t v = [] {
         const char *e = std::getenv("PFHE_STAGE_CHUNK");
         const unsigned long long x = e && *e ? std::strtoull(e, nullptr, 10) : 0ull;
         return x ? (size_t)x : (size_t)8 << 20;
+    }();
+    return v;
+}
+
+size_t stage_bounce_max() {
+    static const size_t v = [] {
+        const char *e = std::getenv("PFHE_STAGE_BOUNCE_MAX");
+        return e && *e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)1 << 20;
     }();
     return v;
 }
@@ -269,18 +277,31 @@ int transform_host(const TableSet &t, u64 *host, size_t len, bool inverse, bool 
     PFHE_TRY(st.alloc(len * sizeof(u64), &dv));
     u64 *d = static_cast<u64 *>(dv);
     const size_t unit = t.n * t.L;
-    // A slice of at most one piece is not copied at all: it is pinned in place and the kernels read and write it over the
-    // link themselves (first pass host -> device scratch, last pass device scratch -> host; single-pass rings in place on
-    // the mapped memory).  Two kernel launches and one synchronisation instead of copy, two kernels, copy:
-    // 2^16-point transform 60 -> 45 us (tools/perf_host_slice.py); PFHE_STAGE_ZERO_COPY=0 keeps the copies.
-    if (stage_zero_copy() && len * sizeof(u64) <= stage_chunk_bytes()) {
-        if (u64 *mapped = static_cast<u64 *>(st.map(host, len * sizeof(u64)))) {
+    // A slice of at most one bounce buffer takes no copy engine: the CPU copies it into the pool's pinned buffer (memory
+    // the caller pinned is used as it is), the kernels read and write that buffer over the link themselves (first pass
+    // host -> device scratch, last pass device scratch -> host; single-pass rings in place on the mapped memory), the CPU
+    // copies the result back.  Two kernel launches and one synchronisation instead of copy, two kernels, copy
+    // (tools/perf_host_slice.py); PFHE_STAGE_ZERO_COPY=0 keeps the copy engines.
+    if (stage_zero_copy() && len * sizeof(u64) <= stage_bounce_max() && aligned16(host)) {
+        u64 *mapped = static_cast<u64 *>(st.map(host, len * sizeof(u64)));
+        void *bounce = nullptr;
+        if (!mapped) {
+            void *bdev = nullptr;
+            bounce = st.bounce(len * sizeof(u64), &bdev);
+            if (bounce) {
+                std::memcpy(bounce, host, len * sizeof(u64));
+                mapped = static_cast<u64 *>(bdev);
+            }
+        }
+        if (mapped) {
             const int rc = ntt_transform_through_dev(t.primes_dev, t.L, t.log_n, t.ntt_arith, mapped, d, units * t.L, inverse, lazy,
                                                      st.stream(), t.tune);
             if (rc != PFHE_ERR_UNSUPPORTED) {
                 st.touch();
                 PFHE_TRY(rc);
-                return st.finish();
+                PFHE_TRY(st.finish());
+                if (bounce) std::memcpy(host, bounce, len * sizeof(u64));
+                return PFHE_OK;
             }
         }
     }

@@ -93,7 +93,7 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
         for (u64 done = 0; done < batch; done += p->chunk) {
             const u64 cur = std::min<u64>(p->chunk, batch - done);
             PFHE_TRY(gadget_signed_digits_dev(rns, p->basis, t.log_n, crt_polys + done * rows * in_words, (int *)p->sdigits, cur * rows, s));
-            PFHE_TRY(extprod_small_dev(t.primes_dev, t.L, t.log_n, t.pm, p->k, rows, ell, (const int *)p->sdigits,
+            PFHE_TRY(extprod_small_dev(t.primes_dev, t.L, t.log_n, t.ntt_arith, p->k, rows, ell, (const int *)p->sdigits,
                                        keys + (keys_shared ? 0 : done * key_words), keys_shared,
                                        result + done * (p->k + 1) * W, cur, accumulate, into_coeff, s));
         }
@@ -105,11 +105,9 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
     const bool fused = gadget_fused_supported(t.log_n, p->k) && p->use_fused &&
                        ((std::min<u64>(batch, p->chunk) * t.L) << (t.log_n - 12)) >= p->fused_min_wgs;
     const int passes = ntt_num_passes(t.log_n, t.ntt_arith, t.tune);
-    // Arithmetic of the plain transform passes in here.  The gadget kernels embed Shoup or pseudo-Mersenne butterflies
-    // (selector t.pm); generic primes below 2^61 have the cheaper Montgomery-form transforms (t.ntt_arith), whose
-    // passes may FOLLOW a Shoup pass (they accept values below 8q) but must not precede one (they leave values below
-    // 7q where the Shoup butterflies expect [0, 4q)): so the last digit pass and the result's inverse passes take
-    // t.ntt_arith, and the leading digit passes do unless the fused multiply-accumulate kernel consumes their output.
+    // One arithmetic for everything in here — the gadget kernels and the plain transform passes around them: the table's
+    // transform arithmetic t.ntt_arith (pseudo-Mersenne, Montgomery form for generic primes below 2^61 — round 4: the
+    // gadget kernels are instantiated for it too — or the reference's Shoup form).
     // coefficient-form output: the inverse transform's block pass runs inside the fused kernel, on the accumulators
     const bool inv_tail = fused && into_coeff && !accumulate && coeff_passes != nullptr && passes == 2 && p->use_fused_tail;
     if (inv_tail) *coeff_passes = 1;
@@ -151,20 +149,19 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
         // ---- stream a: steps (1)-(4) + strided passes into digit buffer `buf` ----
         if (fused && index >= 2 && !single) PFHE_HIP(hipStreamWaitEvent(sa, p->consumed[buf], 0));
         if (fused_decompose) {
-            PFHE_TRY(gadget_decompose_strided_dev(rns, p->basis, t.primes_dev, t.log_n, t.pm,
+            PFHE_TRY(gadget_decompose_strided_dev(rns, p->basis, t.primes_dev, t.log_n, t.ntt_arith,
                                                   crt_polys + done * rows * in_words, dg, cur * rows, sa, p->sdigits));
         } else {
             PFHE_TRY(gadget_decompose_dev(rns, p->basis, t.log_n, crt_polys + done * rows * in_words, dg, cur * rows, sa));
             for (int i = 0; i < passes - 1; ++i)
-                PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, fused ? (int)t.pm : t.ntt_arith, dg, npolys, false, i, false, sa,
-                                      nullptr, 0, t.tune));
+                PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.ntt_arith, dg, npolys, false, i, false, sa, nullptr, 0, t.tune));
         }
         if (!single) PFHE_HIP(hipEventRecord(p->produced[buf], sa));
         PFHE_TRY(stamp(sa));
         // ---- stream b: block pass (last pass of the transform) ----
         if (!single) PFHE_HIP(hipStreamWaitEvent(sb, p->produced[buf], 0));
         if (fused) {
-            PFHE_TRY(gadget_block_mulacc_dev(t.primes_dev, t.L, t.log_n, t.pm, p->k, rows * ell, dg,
+            PFHE_TRY(gadget_block_mulacc_dev(t.primes_dev, t.L, t.log_n, t.ntt_arith, p->k, rows * ell, dg,
                                              keys + (keys_shared ? 0 : done * key_words), keys_shared,
                                              result + done * (p->k + 1) * W, cur, accumulate, sb, inv_tail));
         } else {

@@ -444,7 +444,7 @@ int dispatch_extprod_small(u32 log_n, const int *sdigits, const u64 *ggsw, u64 s
 
 bool gadget_fused_supported(u32 log_n, u32 k) { return k == 1 && make_ntt_plan(log_n).block_log == 12; }
 
-int gadget_block_mulacc_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u32 k, u32 terms, const u64 *digits,
+int gadget_block_mulacc_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u32 k, u32 terms, const u64 *digits,
                             const u64 *ggsw, bool ggsw_shared, u64 *result, u64 batch, bool accumulate,
                             hipStream_t s, bool inv_tail) {
     if (!gadget_fused_supported(log_n, k) || terms == 0 || (inv_tail && accumulate)) return PFHE_ERR_UNSUPPORTED;
@@ -455,10 +455,15 @@ int gadget_block_mulacc_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u
     const u64 ggsw_words = ((u64)terms * (k + 1) * L) << log_n;
     constexpr size_t lds_bytes = (size_t)Cfg::LDS_WORDS * sizeof(u64);
     const u64 stride = ggsw_shared ? 0ull : ggsw_words;
-    if (pm) {
+    if (arith == kArithPm) {
         // 512 threads x 8 coefficients: 32 accumulator registers, four waves per SIMD (the 256 x 16 form holds 64 and
         // fits two: 48.0 -> 49.0 k products/s when it was replaced)
         hipLaunchKernelGGL((gadget_block_mulacc_kernel<PmArith, 2, 3>), dim3((u32)total_blocks), dim3(512), lds_bytes, s,
+                           digits, ggsw, stride, result, primes, L, log_n, terms, total_blocks, accumulate ? 1u : 0u,
+                           inv_tail ? 1u : 0u);
+    } else if (arith == kArithMont) {
+        // generic primes below 2^61: the Montgomery-form butterflies (7 multiplies) instead of the Shoup ones (10)
+        hipLaunchKernelGGL((gadget_block_mulacc_kernel<MontArith, 2>), dim3((u32)total_blocks), dim3(256), lds_bytes, s,
                            digits, ggsw, stride, result, primes, L, log_n, terms, total_blocks, accumulate ? 1u : 0u,
                            inv_tail ? 1u : 0u);
     } else {
@@ -508,13 +513,16 @@ int gadget_signed_digits_dev(const RnsDev &r, const BasisDev &b, u32 log_n, cons
     return PFHE_OK;
 }
 
-int extprod_small_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u32 k, u32 rows, u32 ell, const int *sdigits,
+int extprod_small_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u32 k, u32 rows, u32 ell, const int *sdigits,
                       const u64 *ggsw, bool ggsw_shared, u64 *result, u64 batch, bool accumulate, bool into_coeff,
                       hipStream_t s) {
     const u64 stride = ggsw_shared ? 0ull : (((u64)rows * ell * (k + 1) * L) << log_n);
     if (k == 1) {
-        return pm ? dispatch_extprod_small<PmArith, 2>(log_n, sdigits, ggsw, stride, result, primes, L, rows, ell, batch, accumulate, into_coeff, s)
-                  : dispatch_extprod_small<ShoupArith, 2>(log_n, sdigits, ggsw, stride, result, primes, L, rows, ell, batch, accumulate, into_coeff, s);
+        if (arith == kArithMont)
+            return dispatch_extprod_small<MontArith, 2>(log_n, sdigits, ggsw, stride, result, primes, L, rows, ell, batch, accumulate, into_coeff, s);
+        return arith == kArithPm
+                   ? dispatch_extprod_small<PmArith, 2>(log_n, sdigits, ggsw, stride, result, primes, L, rows, ell, batch, accumulate, into_coeff, s)
+                   : dispatch_extprod_small<ShoupArith, 2>(log_n, sdigits, ggsw, stride, result, primes, L, rows, ell, batch, accumulate, into_coeff, s);
     }
     return PFHE_ERR_UNSUPPORTED;
 }
@@ -530,14 +538,18 @@ static int digits_strided_by_width(const RnsDev &r, const BasisDev &b, const Ntt
                : launch_digits_strided<A, K, long long>(r, b, primes, log_n, crt_polys, (long long *)sdigits, digits, npolys, s);
 }
 
-int gadget_decompose_strided_dev(const RnsDev &r, const BasisDev &b, const NttPrime *primes, u32 log_n, bool pm,
+int gadget_decompose_strided_dev(const RnsDev &r, const BasisDev &b, const NttPrime *primes, u32 log_n, int arith,
                                  const u64 *crt_polys, u64 *digits, u64 npolys, hipStream_t s, void *sdigits) {
     if (!gadget_decompose_strided_supported(log_n, r.value_len) || sdigits == nullptr) return PFHE_ERR_UNSUPPORTED;
     if (npolys == 0) return PFHE_OK;
     const int k = make_ntt_plan(log_n).strided[0];
-    if (pm) {
+    if (arith == kArithPm) {
         return k == 4 ? digits_strided_by_width<PmArith, 4>(r, b, primes, log_n, crt_polys, sdigits, digits, npolys, s)
                       : digits_strided_by_width<PmArith, 3>(r, b, primes, log_n, crt_polys, sdigits, digits, npolys, s);
+    }
+    if (arith == kArithMont) {
+        return k == 4 ? digits_strided_by_width<MontArith, 4>(r, b, primes, log_n, crt_polys, sdigits, digits, npolys, s)
+                      : digits_strided_by_width<MontArith, 3>(r, b, primes, log_n, crt_polys, sdigits, digits, npolys, s);
     }
     return k == 4 ? digits_strided_by_width<ShoupArith, 4>(r, b, primes, log_n, crt_polys, sdigits, digits, npolys, s)
                   : digits_strided_by_width<ShoupArith, 3>(r, b, primes, log_n, crt_polys, sdigits, digits, npolys, s);

@@ -32,6 +32,7 @@ struct TableSet {
 int make_table_set(u32 log_n, const u64 *moduli, size_t count, int device, std::unique_ptr<TableSet> &out);
 int transform_dev(const TableSet &t, u64 *data, size_t len, bool inverse, bool lazy, hipStream_t s);
 int transform_host(const TableSet &t, u64 *host, size_t len, bool inverse, bool lazy);
+size_t stage_bounce_max();   // PFHE_STAGE_BOUNCE_MAX: largest slice that goes through the pinned bounce buffer
 bool stage_zero_copy();      // PFHE_STAGE_ZERO_COPY=0 clears it: one-piece host slices are copied instead of mapped
 size_t stage_chunk_bytes();  // PFHE_STAGE_CHUNK: bytes per piece of a pipelined host-pointer transform
 int pointwise(const TableSet &t, int mode, u64 *acc, const u64 *a, size_t len_a, const u64 *b, size_t len_b,

@@ -89,11 +89,12 @@ bool gadget_decompose_strided_supported(u32 log_n, u32 value_len);
 // `sdigits`: scratch of npolys * ell * N balanced digits of gadget_digit_bytes(log_basis) bytes each (int32 when
 // log_basis <= 31, else int64): a compact signed-digit kernel + a lifting strided pass.
 size_t gadget_digit_bytes(u32 log_basis);
-int gadget_decompose_strided_dev(const RnsDev &r, const BasisDev &b, const NttPrime *primes, u32 log_n, bool pm,
+// `arith`: the table's transform arithmetic (kArithPm, kArithMont or kArithShoup, pfhe_ntt_device.hpp)
+int gadget_decompose_strided_dev(const RnsDev &r, const BasisDev &b, const NttPrime *primes, u32 log_n, int arith,
                                  const u64 *crt_polys, u64 *digits, u64 npolys, hipStream_t s, void *sdigits);
 // inv_tail (not with accumulate): the kernel also runs the block pass of the INVERSE transform on its result blocks
 // before storing them; the caller finishes with the inverse transform's strided pass (ntt_pass_dev, inverse, index 1).
-int gadget_block_mulacc_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u32 k, u32 terms, const u64 *digits,
+int gadget_block_mulacc_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u32 k, u32 terms, const u64 *digits,
                             const u64 *ggsw, bool ggsw_shared, u64 *result, u64 batch, bool accumulate,
                             hipStream_t s, bool inv_tail = false);
 
@@ -102,7 +103,7 @@ int gadget_block_mulacc_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u
 bool extprod_small_supported(u32 log_n, u32 k, u32 value_len, u32 log_basis);
 int gadget_signed_digits_dev(const RnsDev &r, const BasisDev &b, u32 log_n, const u64 *crt_polys, int *sdigits,
                              u64 npolys, hipStream_t s);
-int extprod_small_dev(const NttPrime *primes, u32 L, u32 log_n, bool pm, u32 k, u32 rows, u32 ell, const int *sdigits,
+int extprod_small_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u32 k, u32 rows, u32 ell, const int *sdigits,
                       const u64 *ggsw, bool ggsw_shared, u64 *result, u64 batch, bool accumulate, bool into_coeff,
                       hipStream_t s);
 

@@ -34,7 +34,8 @@ hipError_t counted_free(void *p) {
 }
 hipError_t counted_host_malloc(void **p, size_t bytes) {
     g_alloc_events.fetch_add(1, std::memory_order_relaxed);
-    return hipHostMalloc(p, bytes, hipHostMallocDefault);
+    // coherent (fine-grained): kernels read what the CPU just copied in without any cache of theirs in between
+    return hipHostMalloc(p, bytes, hipHostMallocCoherent);
 }
 hipError_t counted_host_free(void *p) {
     g_alloc_events.fetch_add(1, std::memory_order_relaxed);
@@ -116,9 +117,9 @@ struct StageCtx {
     struct Range {
         char *p;
         size_t bytes;
-        bool owned;  // registered by this call (to be unregistered); false: memory the caller had pinned already
+        bool owned;  // (always false: nothing is registered here, see HostStage::pin)
     };
-    std::vector<Range> registered;  // ranges this call pinned in place (hipHostUnregister at the end of the call)
+    std::vector<Range> registered;  // ranges of this call that lie in memory the caller pinned
     std::vector<hipEvent_t> events;  // pooled, timing disabled
     size_t events_used = 0;
 };
@@ -130,12 +131,13 @@ struct Pool {
     size_t bounce_max, cache_max, register_min;
     bool use_register;
     Pool() {
-        // slices of at least register_min bytes are pinned in place for the call (PFHE_STAGE_REGISTER=0: never)
+        // slices of at least register_min bytes are looked up: memory the caller pinned is used as it is
+        // (PFHE_STAGE_REGISTER=0: never)
         use_register = env_bytes("PFHE_STAGE_REGISTER", 1) != 0;
         register_min = env_bytes("PFHE_STAGE_REGISTER_MIN", (size_t)128 << 10);
         // transfers up to bounce_max go through the pinned bounce buffer (a CPU copy + a true asynchronous DMA);
         // larger ones are handed to the runtime as they are (it pins the caller's pages in pieces)
-        bounce_max = env_bytes("PFHE_STAGE_BOUNCE_MAX", (size_t)4 << 20);
+        bounce_max = env_bytes("PFHE_STAGE_BOUNCE_MAX", (size_t)1 << 20);
         cache_max = env_bytes("PFHE_STAGE_CACHE_MAX", (size_t)2 << 30);
     }
 };
@@ -173,34 +175,28 @@ HostStage::HostStage(int device) {
 // Pins [host, host + bytes) in place for this call.  Memory that already is pinned (hipHostMalloc, or registered by the
 // caller) needs nothing; a refusal (read-only mapping, pages held by another registration) sends the caller to the
 // bounce / pageable path.
+// Memory the CALLER has pinned (hipHostMalloc, hipHostRegister, a torch pinned tensor) is copied from / to by true
+// asynchronous DMA and may be handed to kernels as it is.  Pageable memory is NOT registered here: round 4 tried
+// (hipHostRegister on the slice for the duration of the call, 1.1 us on this platform, kernels reading and writing the
+// mapped range) and got rare wrong words and host-heap corruption under a debugging allocator
+// (profiles/r04_experiments.txt, item 6) — pageable slices go through the pool's own pinned buffer instead.
 bool HostStage::pin(const void *host, size_t bytes, bool any_size) {
     const Pool &P = pool();
     char *h = static_cast<char *>(const_cast<void *>(host));
     for (const StageCtx::Range &r : ctx_->registered)
         if (h >= r.p && h + bytes <= r.p + r.bytes) return true;  // pieces of a pinned slice; in-place downloads
     if (!P.use_register || (!any_size && bytes < P.register_min)) return false;
-    if (hipHostRegister(h, bytes, hipHostRegisterDefault) != hipSuccess) {
+    hipPointerAttribute_t at{}, last{};
+    if (hipPointerGetAttributes(&at, h) != hipSuccess || at.type != hipMemoryTypeHost ||
+        hipPointerGetAttributes(&last, h + bytes - 1) != hipSuccess || last.type != hipMemoryTypeHost) {
         (void)hipGetLastError();
-        // refused: memory that already is pinned (hipHostMalloc, or registered by the caller) is used as it is
-        hipPointerAttribute_t at{};
-        if (hipPointerGetAttributes(&at, h) != hipSuccess || at.type != hipMemoryTypeHost) {
-            (void)hipGetLastError();
-            return false;
-        }
-        hipPointerAttribute_t last{};
-        if (hipPointerGetAttributes(&last, h + bytes - 1) != hipSuccess || last.type != hipMemoryTypeHost) {
-            (void)hipGetLastError();
-            return false;
-        }
-        ctx_->registered.push_back(StageCtx::Range{h, bytes, false});
-        return true;
+        return false;
     }
-    ctx_->registered.push_back(StageCtx::Range{h, bytes, true});
+    ctx_->registered.push_back(StageCtx::Range{h, bytes, false});
     return true;
 }
 
 void *HostStage::map(void *host, size_t bytes) {
-    // (no minimum size: against a bounce copy + two DMA operations, pinning — 1.1 us — pays from the smallest slice)
     if (!pin(host, bytes, true)) return nullptr;
     void *d = nullptr;
     if (hipHostGetDevicePointer(&d, host, 0) != hipSuccess) {
@@ -210,12 +206,22 @@ void *HostStage::map(void *host, size_t bytes) {
     return d;
 }
 
-void HostStage::unpin_all() {
-    for (const StageCtx::Range &r : ctx_->registered) {
-        if (r.owned && hipHostUnregister(r.p) != hipSuccess) (void)hipGetLastError();
+// a region of the pool's pinned, coherent host buffer and its device-side address
+void *HostStage::bounce(size_t bytes, void **dev) {
+    void *b = nullptr;
+    *dev = nullptr;
+    if (ctx_->pin.get(bytes, &b) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
     }
-    ctx_->registered.clear();
+    if (hipHostGetDevicePointer(dev, b, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return b;
 }
+
+void HostStage::unpin_all() { ctx_->registered.clear(); }
 
 int HostStage::order(hipStream_t signaller, hipStream_t waiter) {
     if (ctx_->events_used == ctx_->events.size()) {

@@ -8,11 +8,13 @@
 // does not move.  Contexts are handed out under a mutex, one per concurrent call, so any number of threads may call
 // through one table handle at the same time (NttTable: Send + Sync).
 //
-// How the bytes travel (tools/microbench10_host.hip, profiles/r04_microbench10_host_path.txt): slices of at least
-// 128 KiB are pinned IN PLACE for the duration of the call (hipHostRegister + hipHostUnregister cost 1.1 us together on
-// this platform, against 9 + 18 us of CPU copies into and out of a bounce buffer for 512 KiB) and copied by true
-// asynchronous DMA; smaller ones, and memory the runtime refuses to pin (read-only mappings, pages another call holds),
-// go through the pinned bounce buffer; PFHE_STAGE_REGISTER=0 switches the pinning off.
+// How the bytes travel (tools/microbench10_host.hip, profiles/r04_microbench10_host_path.txt): a slice of one piece is
+// copied by the CPU into the pool's pinned buffer (9 us per 512 KiB), transformed by kernels that read and write that
+// buffer over the link themselves (no copy engine: each copy-engine operation costs ~10 us of latency), and copied back
+// (10-18 us); longer slices are handed to the runtime's pageable copies (it pins the caller's pages in pieces).  Memory the
+// CALLER pinned is used as it is.  Registering the caller's pageable memory for the duration of a call — 1.1 us on this
+// platform, and 45 us per 2^16-point transform — was built and withdrawn: rare wrong words and heap corruption
+// (profiles/r04_experiments.txt, item 6).
 #pragma once
 #include <cstdint>
 
@@ -56,13 +58,14 @@ class HostStage {
     // stream `waiter` waits for everything queued so far on stream `signaller` (pooled events, no allocation)
     int order(hipStream_t signaller, hipStream_t waiter);
 
-    // Pins [host, host + bytes) in place until the end of the call (hipHostRegister) so that copies from / to it are
-    // true asynchronous DMA.  False when the range is too small to be worth it or the runtime refuses (read-only
-    // mapping, pages held by another registration): copies of it then go through the bounce buffer / the runtime's
-    // pageable path.  copy_in / download call it themselves; a caller that copies a slice piece by piece pins it whole.
+    // True when [host, host + bytes) lies in memory the CALLER has pinned: copies from / to it are then true asynchronous
+    // DMA.  Pageable memory is never registered here (see the note on top): it goes through the bounce buffer or the
+    // runtime's pageable path.  copy_in / download call it themselves.
     bool pin(const void *host, size_t bytes, bool any_size = false);
-    // pin() + the device-side address of the pinned range (kernels then read / write the caller's memory over the
-    // link themselves: no copy engine, no bounce); null when the range cannot be pinned
+    // a region of the pool's pinned, coherent host buffer (valid until the end of the call) and its device-side address
+    void *bounce(size_t bytes, void **dev);
+    // the device-side address of a range in caller-pinned memory (kernels then read / write it over the link
+    // themselves); null for pageable memory
     void *map(void *host, size_t bytes);
     // marks the call as having queued work on the context's streams (kernels on mapped memory)
     void touch() { dirty_ = true; }

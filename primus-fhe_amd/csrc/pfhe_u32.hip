@@ -241,8 +241,8 @@ int transform32_dev(const TableSet &t, u32 *data, size_t len, bool inverse, bool
     return ntt32_transform_dev(t.primes_dev, t.L, t.log_n, data, units * t.L, inverse, lazy, s, t.tune);
 }
 
-// host-pointer form: pooled staging context, slice pinned in place, pieces of whole units pipelined over its two
-// streams (see transform_host in pfhe_capi.hip)
+// host-pointer form: pooled staging context; a slice in memory the caller pinned is pipelined in pieces of whole units over
+// its two streams, pageable slices are copied as one piece (see transform_host in pfhe_capi.hip)
 int transform32_host(const TableSet &t, u32 *host, size_t len, bool inverse, bool lazy) {
     if (!host && len) return PFHE_ERR_BAD_ARGUMENT;
     u64 units = 0;
@@ -256,15 +256,6 @@ int transform32_host(const TableSet &t, u32 *host, size_t len, bool inverse, boo
     PFHE_TRY(st.alloc(len * sizeof(u32), &dv));
     u32 *d = static_cast<u32 *>(dv);
     const size_t unit = t.n * t.L;
-    // single-pass rings (N <= 2^15 coefficients): a slice of one piece is transformed in place on the pinned memory, the
-    // kernel reading and writing it over the link (see transform_host in pfhe_capi.hip); two-pass rings are copied
-    if (stage_zero_copy() && len * sizeof(u32) <= stage_chunk_bytes() && (t.log_n <= 4 || ntt_num_passes(t.log_n - 1, kArithB32, t.tune) == 1)) {
-        if (u32 *mapped = static_cast<u32 *>(st.map(host, len * sizeof(u32)))) {
-            st.touch();
-            PFHE_TRY(transform32_dev(t, mapped, len, inverse, lazy, st.stream()));
-            return st.finish();
-        }
-    }
     const bool pinned = st.pin(host, len * sizeof(u32));
     const size_t per = pinned ? std::max<size_t>(1, stage_chunk_bytes() / (unit * sizeof(u32))) : (size_t)units;
     const bool pipelined = per < units;

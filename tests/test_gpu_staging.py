@@ -145,9 +145,10 @@ def test_staging_release_returns_the_pool(pf):
 @pytest.mark.parametrize("log_n", [10, 14, 15, 16, 17])
 @pytest.mark.parametrize("kind", ["pm", "mont", "shoup"])
 def test_zero_copy_slices_match_oracle(pf, orc, log_n, kind, monkeypatch):
-    """Slices of at most one piece are pinned in place and transformed by kernels that read and write the caller's
-    memory themselves (ntt_transform_through_dev: out-of-place first / last pass for two-pass rings, the in-place kernel
-    on the mapped memory for single-pass ones).  Every arithmetic policy, both directions, lazy forms, ragged batch."""
+    """Slices up to the bounce limit are copied into the pool's pinned buffer and transformed by kernels that read and
+    write THAT buffer over the link themselves (ntt_transform_through_dev: out-of-place first / last pass for two-pass
+    rings, the in-place kernel on the mapped buffer for single-pass ones); larger ones take the copy engines.  Every
+    arithmetic policy, both directions, lazy forms, ragged batch, both sides of the limit."""
     moduli = {"pm": Q61, "mont": Q61, "shoup": [Q62]}[kind]
     if kind == "mont":
         monkeypatch.setenv("PFHE_DISABLE_PM", "1")
@@ -177,9 +178,9 @@ def test_zero_copy_slices_match_oracle(pf, orc, log_n, kind, monkeypatch):
 
 
 def test_zero_copy_and_copy_paths_agree(pf, orc):
-    """PFHE_STAGE_ZERO_COPY=0 (read when the library is loaded... per process) cannot be flipped here; the copy path is
-    what slices above one piece take: compare a 3-polynomial slice (zero-copy) with the same polynomials inside a
-    24-polynomial slice (pinned + pipelined copies)."""
+    """PFHE_STAGE_ZERO_COPY is read once per process and cannot be flipped here; the copy-engine path is what slices above
+    the bounce limit take: compare a one-limb polynomial (kernels on the pinned buffer), a 3-limb one (pageable copies)
+    and the same polynomials inside a 24-polynomial slice."""
     log_n = 16
     n = 1 << log_n
     d = pf.U64DcrtTable(log_n, Q61)
@@ -187,15 +188,18 @@ def test_zero_copy_and_copy_paths_agree(pf, orc):
     small = rand_rns(rng, Q61, n, 1)
     large = np.concatenate([small, rand_rns(rng, Q61, n, 23)])
     assert small.nbytes <= (8 << 20) < large.nbytes
+    one = small[:n].copy()                     # 512 KiB: below the bounce limit
+    t1 = pf.U64NttTable(log_n, Q61[0])
+    t1.transform_slice(one)
     d.transform_slice(small)
     d.transform_slice(large)
-    assert np.array_equal(large[:small.size], small)
+    assert np.array_equal(large[:small.size], small) and np.array_equal(small[:n], one)
 
 
 def test_memory_the_runtime_cannot_pin_takes_the_bounce_buffer(pf, orc, tmp_path):
-    """A read-only mapping cannot be registered for device writes (hipHostRegister refuses it); the input of an
-    out-of-place entry point may live there.  The call must still succeed (bounce buffer) and give the oracle's words;
-    and memory that already IS pinned (torch pinned tensor) is used as it is."""
+    """The input of an out-of-place entry point may live in a read-only mapping: the call must succeed (the library never
+    registers or writes caller memory it was not asked to write) and give the oracle's words; memory that already IS
+    pinned (torch pinned tensor) is used as it is, mapped for the kernels."""
     import mmap
 
     import torch
