@@ -223,13 +223,19 @@ void *HostStage::bounce(size_t bytes, void **dev) {
 
 void HostStage::unpin_all() { ctx_->registered.clear(); }
 
-int HostStage::order(hipStream_t signaller, hipStream_t waiter) {
+int HostStage::take_event(hipEvent_t *out) {
     if (ctx_->events_used == ctx_->events.size()) {
         hipEvent_t e = nullptr;
         PFHE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx_->events.push_back(e);
     }
-    hipEvent_t e = ctx_->events[ctx_->events_used++];
+    *out = ctx_->events[ctx_->events_used++];
+    return PFHE_OK;
+}
+
+int HostStage::order(hipStream_t signaller, hipStream_t waiter) {
+    hipEvent_t e = nullptr;
+    PFHE_TRY(take_event(&e));
     PFHE_HIP(hipEventRecord(e, signaller));
     PFHE_HIP(hipStreamWaitEvent(waiter, e, 0));
     return PFHE_OK;

@@ -57,6 +57,8 @@ class HostStage {
     int finish();
     // stream `waiter` waits for everything queued so far on stream `signaller` (pooled events, no allocation)
     int order(hipStream_t signaller, hipStream_t waiter);
+    // a pooled event (timing disabled), the context's until the end of the call
+    int take_event(hipEvent_t *out);
 
     // True when [host, host + bytes) lies in memory the CALLER has pinned: copies from / to it are then true asynchronous
     // DMA.  Pageable memory is never registered here (see the note on top): it goes through the bounce buffer or the

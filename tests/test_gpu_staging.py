@@ -228,3 +228,41 @@ def test_memory_the_runtime_cannot_pin_takes_the_bounce_buffer(pf, orc, tmp_path
     view = pinned.numpy().view(np.uint64)
     t.transform_slice(view)
     assert np.array_equal(view, exp)
+
+
+def test_long_pageable_slice_with_helper_thread_is_exact_and_reports_errors(pf, orc):
+    """Pageable slices of 8 MiB and more: the calling thread copies in and launches piece by piece, a helper thread
+    copies each finished piece back (transform_host in csrc/pfhe_capi.hip).  Ragged piece boundaries, both directions,
+    repeated calls (the pooled events are reused), and two callers at once."""
+    import threading
+    log_n = 15
+    n = 1 << log_n
+    d, o = pf.U64DcrtTable(log_n, Q61), orc.U64DcrtTable(log_n, Q61)
+    rng = np.random.default_rng(21)
+    a = rand_rns(rng, Q61, n, 29)          # 21.75 MiB: three pieces of 10 + 10 + 9 polynomials
+    assert a.nbytes >= (8 << 20)
+    ref = a.copy(); o.transform_slice(ref)
+    for _ in range(3):
+        x = a.copy()
+        d.transform_slice(x)
+        assert np.array_equal(x, ref)
+        d.inverse_transform_slice(x)
+        assert np.array_equal(x, a)
+    errors = []
+
+    def worker():
+        try:
+            y = a.copy()
+            d.transform_slice(y)
+            if not np.array_equal(y, ref):
+                raise AssertionError("mismatch under concurrency")
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    ths = [threading.Thread(target=worker) for _ in range(2)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errors, errors
+    before = alloc_count(pf)
+    x = a.copy(); d.transform_slice(x)
+    assert np.array_equal(x, ref) and alloc_count(pf) == before
