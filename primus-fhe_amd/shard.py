@@ -83,3 +83,33 @@ def strong_scaling_leg(total: int, world: int, rank: int, run_shard, steps: int,
     dt = timed_steps(lambda: run_shard(begin, end), steps, warmup, sync, dist, device)
     return {"scaling": "strong", "batch_total": total, "n_gpus": world, "range_of_rank0": [begin, end] if rank == 0 else None,
             "units_this_rank": end - begin, "steps": steps, "seconds": dt, "value": total * steps / dt}
+
+
+def run_on_devices(devices, total: int, make_worker):
+    """The other arrangement SURVEY.md §8e sketches: ONE process, one host thread + stream per device.  `devices` lists a
+    device index per shard (a device may appear more than once); shard r gets units shard_range(total, len(devices), r).
+    `make_worker(rank, device, begin, end)` is called INSIDE shard r's thread and returns that shard's result; every
+    handle a worker creates carries its device, and every C-ABI entry point switches to the handle's device for the
+    call, so the workers need no device bookkeeping of their own.  Returns the results in rank order; the first
+    exception of any worker is re-raised.  (The repository's measured path is one process per GPU — bench.py; this helper
+    and tests/test_gpu_multi_device.py exist so that the single-process form is exercised wherever two devices are.)"""
+    import threading
+
+    world = len(devices)
+    results, errors = [None] * world, []
+
+    def body(r):
+        try:
+            b, e = shard_range(total, world, r)
+            results[r] = make_worker(r, devices[r], b, e)
+        except BaseException as exc:  # noqa: BLE001 - re-raised below
+            errors.append(exc)
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return results
