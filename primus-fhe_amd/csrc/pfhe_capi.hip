@@ -187,6 +187,8 @@ int make_table_set(u32 log_n, const u64 *moduli, size_t count, int device, std::
             u32 inv = 1;  // Newton: q^-1 mod 2^32
             for (int it = 0; it < 5; ++it) inv *= 2u - (u32)q * inv;
             P.qinv32 = 0u - inv;
+            P.mont_qest = (u32)((1ull << (63 - __builtin_clzll(q))) / ((q >> 32) + 1));
+            P.mont_qf = ((1ull << 63) / q) * q;
         }
         if (!fl.empty()) {
             const void *flp = nullptr, *ilp = nullptr;

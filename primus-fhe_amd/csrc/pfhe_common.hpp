@@ -100,11 +100,15 @@ struct NttPrime {
     const ulonglong2 *fwd_last_m;
     const ulonglong2 *inv_last_m;
     u64 inv_n_m, inv_n_m2, inv_n_w_m, inv_n_w_m2;  // N^-1 and N^-1 * w in the same form
-    u32 qinv32, mont_pad;                          // -q^-1 mod 2^32
+    u32 qinv32;                                    // -q^-1 mod 2^32
+    u32 mont_qest;                                 // floor(2^(bits(q) - 1) / (floor(q / 2^32) + 1)) (MontArith::canon)
+    u64 mont_qf;                                   // the largest multiple of q that is <= 2^63 (MontArith::fold)
 };
 
-// MontArith covers primes below 2^61 (lazy values stay below 8q <= 2^64)
-inline bool mont_shape(u64 q) { return (q & 1) && q < (1ull << 61); }
+// MontArith covers odd primes in [2^48, 2^61): forward lazy values stay below 2^63 + 3q < 2^64, and the quotient estimate
+// of its closing reduction reads the high word of q only, which is exact enough from 2^48 (smaller primes keep the
+// Shoup transforms)
+inline bool mont_shape(u64 q) { return (q & 1) && q < (1ull << 61) && q >= (1ull << 48); }
 
 // q = 2^K - c qualifies for PmArith when 40 <= K <= 61 and c < 2^(K-33)
 inline bool pm_shape(u64 q, u32 &k, u64 &c) {

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256, 4) void digits_strided_kernel(const NttPrime *
         // centred lift (base.rs:279-312): d >= 0 -> d, d < 0 -> q_i - |d|
 #pragma unroll
         for (int k = 0; k < RK; ++k) x[k][0] = d[k] < 0 ? ar.q + (u64)(long long)d[k] : (u64)d[k];
-        strided_forward_regs<A, K, 1>(ar, x, n, 0u, log_s);
+        strided_forward_regs<A, K, 1, true>(ar, x, n, 0u, log_s);  // log_s + K = log_n: the transform's first stage is here
         u64 *__restrict__ dst = out + (pl * L + i) * n + col;
 #pragma unroll
         for (int k = 0; k < RK; ++k) gstore<true>(dst + ((u64)k << log_s), x[k][0]);

@@ -108,7 +108,7 @@ __device__ __forceinline__ void strided_pass_body(u64 *__restrict__ data, const 
     }
 
     if constexpr (!INV) {
-        strided_forward_regs<A, K, VEC>(ar, x, n, ebase, log_s);
+        strided_forward_regs<A, K, VEC, FINAL>(ar, x, n, ebase, log_s);  // (forward kernels: FINAL = first pass of the transform)
     } else {
         strided_inverse_regs<A, K, VEC, FINAL>(ar, x, n, ebase, log_s, lazy != 0);
     }
@@ -478,7 +478,7 @@ __device__ __forceinline__ void ntt_pipe_body(
     }
     if (has_str) {
         const A ar(primes + (chunk >> 4) % L);
-        if constexpr (!INV) strided_forward_regs<A, K, 1>(ar, sx, n, 0u, LOGB);
+        if constexpr (!INV) strided_forward_regs<A, K, 1, true>(ar, sx, n, 0u, LOGB);
         else strided_inverse_regs<A, K, 1, true>(ar, sx, n, 0u, LOGB, lazy != 0);  // the only strided pass: final stage
 #pragma unroll
         // forward: this is the intermediate (kPipeIntermediateNt); inverse: the final output (always non-temporal)
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_wave
     };
     const auto finish_f = [&]() {
         if (has_sf) {
-            strided_forward_regs<A, K, 1>(ars, sx, n, 0u, LOGB);
+            strided_forward_regs<A, K, 1, true>(ars, sx, n, 0u, LOGB);
             u64 *__restrict__ sp = sf_data + cbase + opaque_tid();
 #pragma unroll
             for (int k = 0; k < (1 << K); ++k) gstore<kPipeIntermediateNt>(sp + ((u64)k << LOGB), sx[k][0]);
@@ -898,7 +898,13 @@ int run_pass(const NttPlan &plan, const NttPrime *primes, u32 L, u32 log_n, u64 
     u32 log_s = log_n;
     for (int j = 0; j <= i; ++j) log_s -= plan.strided[j];
     const int k = plan.strided[i];
-    if (!inverse) return dispatch_strided<A, false, false>(k, data, primes, L, log_n, log_s, npolys, false, s, vec1);
+    if (!inverse) {
+        // Montgomery tables: the first pass of a forward transform skips the fold of its first stage (strided_forward_regs)
+        if constexpr (A::kMont) {
+            if (i == 0) return dispatch_strided<A, false, true>(k, data, primes, L, log_n, log_s, npolys, false, s, vec1);
+        }
+        return dispatch_strided<A, false, false>(k, data, primes, L, log_n, log_s, npolys, false, s, vec1);
+    }
     if (i == 0) return dispatch_strided<A, true, true>(k, data, primes, L, log_n, log_s, npolys, lazy, s, vec1);
     return dispatch_strided<A, true, false>(k, data, primes, L, log_n, log_s, npolys, false, s, vec1);
 }

@@ -312,25 +312,42 @@ struct PmArith {
 //   (shoup_factor/mod.rs:124-131) takes ten.  Lazy domain [0, 8q) inside 64 bits: see pfhe_mont_asm.hpp.  Exact
 //   integer arithmetic: canonical outputs are the Shoup path's, lazy outputs agree mod q and honour the reference's
 //   [0,4q) / [0,2q) contracts.  Products of two data words keep the Barrett form (mul_any).
+// low word of a*b + c in ONE instruction (v_mad_u64_u32): the compiler, asked for 32 bits of that sum, emits
+// v_mul_lo_u32 + v_add_u32
+static __device__ __forceinline__ u32 mad_lo32(u32 a, u32 b, u64 c) {
+    u64 d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
+    return (u32)d;
+}
+
 struct MontArith {
     struct Tw {
         u64 w, w2;
     };
-    u64 q, two_q, q3, q4;
+    u64 q, two_q, q3;
+    u64 qf;  // F: the largest multiple of q that is <= 2^63 (NttPrime::mont_qf; 4q <= F)
     CCVec2Ptr fwd, inv;
     GCVec2Ptr fwd_last, inv_last;
     Tw inv_n, inv_n_w;
     u64 bar_lo, bar_hi;
     u32 qinv;          // -q^-1 mod 2^32
-    u32 vq4_0, vq4_1;  // halves of 4q held in VGPRs (operands of the borrow chains in pfhe_mont_asm.hpp)
+    // Forward lazy domain [0, 2^63 + 3q): a forward butterfly folds x by adding 2^64 - F under the mask of its sign bit
+    // (halves in VGPRs: v_and_b32 with two VGPR operands issues at twice the rate of one that reads an SGPR; the
+    // inverse butterflies' carry chains use them too).  Inverse lazy domain [0, F).
+    u32 vnqf_0, vnqf_1;
+    // closing reduction (canon): quotient estimate k = floor(v_hi * qest / 2^(32 + qest_sh)) + 1 with
+    // qest = floor(2^(bits(q) - 1) / (floor(q / 2^32) + 1)) (NttPrime::mont_qest), qest_sh = bits(q) - 33
+    u32 qest, qest_sh;
+    u64 qest_one, nq;  // 2^(32 + qest_sh); 2^64 - q
 
     __device__ __forceinline__ explicit MontArith(const NttPrime *__restrict__ P)
-        : q(P->q), two_q(P->two_q), q3(P->q3), q4(P->q << 2), fwd((CCVec2Ptr)(const void *)P->fwd_m),
+        : q(P->q), two_q(P->two_q), q3(P->q3), qf(P->mont_qf), fwd((CCVec2Ptr)(const void *)P->fwd_m),
           inv((CCVec2Ptr)(const void *)P->inv_m), fwd_last((GCVec2Ptr)(const void *)P->fwd_last_m),
           inv_last((GCVec2Ptr)(const void *)P->inv_last_m), inv_n{P->inv_n_m, P->inv_n_m2},
           inv_n_w{P->inv_n_w_m, P->inv_n_w_m2}, bar_lo(P->bar_lo), bar_hi(P->bar_hi), qinv(P->qinv32),
-          vq4_0((u32)(P->q << 2)), vq4_1((u32)((P->q << 2) >> 32)) {
-        asm volatile("" : "+v"(vq4_0), "+v"(vq4_1));  // as uniform values they would live in SGPRs
+          vnqf_0((u32)(0 - P->mont_qf)), vnqf_1((u32)((0 - P->mont_qf) >> 32)), qest(P->mont_qest),
+          qest_sh(31u - (u32)__builtin_clzll(P->q)), qest_one(1ull << (63 - __builtin_clzll(P->q))), nq(0 - P->q) {
+        asm volatile("" : "+v"(vnqf_0), "+v"(vnqf_1));  // as uniform values they would live in SGPRs
     }
     static constexpr bool kLastTables = true;
     static constexpr bool kPacked = false;
@@ -358,10 +375,43 @@ struct MontArith {
     __device__ __forceinline__ u64 mul_lazy(u64 y, Tw t) const { return mont_mul1<false>(*this, y, t); }  // [0, 3q); twiddle operands in VGPRs: also right when the prime is a per-lane value
 #endif
     __device__ __forceinline__ u64 mul_any(u64 a, u64 b) const { return mul_mod_barrett(a, b, q, bar_lo, bar_hi); }
-    __device__ __forceinline__ u64 reduce_x(u64 x) const { return csub(x, q4); }                     // [0,8q) -> [0,4q)
+    __device__ __forceinline__ u64 reduce_x(u64 x) const { return csub(x, qf); }                     // [0,2F) -> [0,F)
     __device__ __forceinline__ u64 reduce_2q(u64 x) const { return csub(x, q); }
     __device__ __forceinline__ u64 canon3(u64 x) const { return csub(csub(x, two_q), q); }            // [0,4q) -> [0,q)
-    __device__ __forceinline__ u64 canon(u64 x) const { return canon3(csub(x, q4)); }                 // [0,8q) -> [0,q)
+    // [0, 2^63 + 3q) -> [0, q), the end of a forward transform: subtract (k + 1) q for an estimate k of the quotient that
+    // is exact or one short — k = floor(v_hi * qest / 2^(32 + qest_sh)) never exceeds floor(v / q) (v_hi * 2^32 <= v,
+    // (q_hi + 1) * 2^32 > q) and falls short of v / q by less than 1 + (v / q + 1) / q_hi + 2^-7 < 2 for q >= 2^48
+    // (v / q <= 2^63 / q + 3, q_hi >= q / 2^32 - 1: the middle term is below 2^95 / q^2 <= 1/2) — which leaves a value in
+    // [-q, q), then add q back under the sign mask.  Nine instructions, four of them of the cheap kind, where three
+    // conditional subtractions (4q, 2q, q) took twelve.
+    __device__ __forceinline__ u64 canon_with(u64 x, u32 q_lo, u32 q_hi, u64 one) const {
+        u64 est, t, carry;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=&v"(est), "=s"(carry) : "v"((u32)(x >> 32)), "s"(qest), "v"(one));
+        const u32 k = (u32)(est >> 32) >> qest_sh;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=&v"(t), "=s"(carry) : "v"(k), "s"((u32)nq), "v"(x));
+        const u32 th = mad_lo32(k, (u32)(nq >> 32), t >> 32);
+        const u32 m = (u32)((int)th >> 31);
+        return (((u64)th << 32) | (u32)t) + (((u64)(m & q_hi) << 32) | (m & q_lo));
+    }
+    __device__ __forceinline__ u64 canon(u64 x) const { return canon_with(x, (u32)q, (u32)(q >> 32), qest_one); }
+    // the same on every register of a thread (the constant of the estimate moved into VGPRs once)
+    template <int E>
+    __device__ __forceinline__ void canon_regs(u64 (&x)[E]) const {
+        u64 one = qest_one;
+        asm volatile("" : "+v"(one));
+#pragma unroll
+        for (int k = 0; k < E; ++k) x[k] = canon_with(x[k], (u32)q, (u32)(q >> 32), one);
+    }
+    // the fold of a forward butterfly: x - F when bit 63 of x is set (below 2^63 afterwards)
+    __device__ __forceinline__ u64 fold(u64 x) const {
+        const u32 m = (u32)((int)(u32)(x >> 32) >> 31);
+        const u64 a = ((u64)(m & vnqf_1) << 32) | (m & vnqf_0);
+        u64 r;
+        asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(r) : "v"(x), "v"(a));
+        return r;
+    }
+    // the reference's forward lazy contract is [0, 4q); 2^63 may be many multiples of q, so the canonical value it is
+    __device__ __forceinline__ u64 fwd_lazy(u64 x) const { return canon(x); }
     __device__ __forceinline__ u64 reduce_4q(u64 x) const { return canon(x); }
 };
 
@@ -405,11 +455,7 @@ struct B32Arith {
     // low word of a*b + c in ONE instruction (v_mad_u64_u32): the compiler, asked for 32 bits of that sum, emits
     // v_mul_lo_u32 + v_add_u32; passing the 64-bit product y*w as the addend makes the whole lazy product three
     // instructions (v_mul_hi_u32, v_mad_u64_u32, v_mad_u64_u32) instead of four
-    static __device__ __forceinline__ u32 mad_lo(u32 a, u32 b, u64 c) {
-        u64 d, carry;
-        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
-        return (u32)d;
-    }
+    static __device__ __forceinline__ u32 mad_lo(u32 a, u32 b, u64 c) { return mad_lo32(a, b, c); }
     // arithmetic.rs:16-20: w*y - q*floor(y*w'/2^32), wrapping, in [0,2q)
     __device__ __forceinline__ u32 mul1(u32 y, Tw t) const { return mad_lo(__umulhi(y, t.wp), 0u - q, (u64)y * t.w); }
     // the same product NEGATED, q*floor(y*w'/2^32) - w*y (wrapping), from a twiddle stored as 2^32 - w: a forward
@@ -491,14 +537,15 @@ struct B32Arith {
 // follow each other.  Inputs of a transform are below 4q < 4U by the reference's contract, so its first stage may
 // skip as well.  The callers' pattern: a block pass folds at odd distances (2^p, p odd), a strided pass at its
 // even register bits (so its last stage folds, whatever follows).
-template <bool FOLD = true, bool UNI = false, class A>
+// FIRST (Montgomery tables): the first stage of a transform, whose x needs no fold.
+template <bool FOLD = true, bool UNI = false, bool FIRST = false, class A>
 __device__ __forceinline__ void fwd_bfly(const A &ar, u64 &x, u64 &y, typename A::Tw w) {
     if constexpr (A::kPacked) {
         ar.fwd_bfly(x, y, w);
     } else if constexpr (A::kWide) {
         pm_fwd_bfly1<FOLD, UNI>(ar, x, y, w);
     } else if constexpr (A::kMont) {
-        mont_fwd_bfly1<UNI>(ar, x, y, w);  // (reduces x at every stage: below 8q in, below 7q out)
+        mont_fwd_bfly1<UNI, !FIRST>(ar, x, y, w);  // (folds x at every stage but the first of a transform: MontArith::fold)
     } else {
         const u64 tx = ar.reduce_x(x);
         const u64 t = ar.mul_lazy(y, w);
@@ -516,7 +563,7 @@ __device__ __forceinline__ void inv_bfly(const A &ar, u64 &x, u64 &y, typename A
     } else if constexpr (A::kWide) {
         pm_inv_bfly1<UNI>(ar, x, y, w);
     } else if constexpr (A::kMont) {
-        mont_inv_bfly1<UNI>(ar, x, y, w);  // inputs below 4q: x' < 4q, y' < 3q
+        mont_inv_bfly1<UNI>(ar, x, y, w);  // inputs below F: x' < F, y' < 3q
     } else {
         const u64 tx = x + y;
         const u64 ty = x + ar.two_q - y;
@@ -539,8 +586,8 @@ __device__ __forceinline__ void inv_final_bfly(const A &ar, u64 &x, u64 &y, bool
         x = lazy ? ar.reduce_x(rx) : ar.canon(rx);
         y = lazy ? ar.reduce_x(ry) : ar.canon(ry);
     } else if constexpr (A::kMont) {
-        const u64 tx = x + y;  // inputs below 4q; the product takes any 64-bit value
-        const u64 ty = sub_u64(x + ar.q4, y);
+        const u64 tx = x + y;  // inputs below F <= 2^63; the product takes any 64-bit value
+        const u64 ty = sub_u64(x + ar.qf, y);
         const u64 rx = ar.mul_lazy(tx, ar.tw_inv_n());    // [0, 3q)
         const u64 ry = ar.mul_lazy(ty, ar.tw_inv_n_w());
         // lazy: the reference's [0,2q) contract (one conditional subtraction of 2q); else canonical
@@ -564,7 +611,9 @@ __device__ __forceinline__ void inv_final_bfly(const A &ar, u64 &x, u64 &y, bool
 // (scalar/transform.rs:104-116)
 template <class A>
 __device__ __forceinline__ u64 fwd_finish(const A &ar, u64 x, bool lazy) {
-    if constexpr (A::kWide || A::kMont) {  // Mont: below 7q -> [0,4q) or [0,q)
+    if constexpr (A::kMont) {  // below 2^b + 3q -> [0,4q) or [0,q)
+        return lazy ? ar.fwd_lazy(x) : ar.canon(x);
+    } else if constexpr (A::kWide) {
         return lazy ? ar.reduce_x(x) : ar.canon(x);
     } else {
         return lazy ? x : ar.reduce_4q(x);
@@ -573,11 +622,20 @@ __device__ __forceinline__ u64 fwd_finish(const A &ar, u64 x, bool lazy) {
 
 // K forward stages on 2^K register-resident coefficients at stride 2^log_s (element index of
 // register 0 = ebase): the body of the forward strided pass, shared with the fused decomposition.
-template <class A, int K, int VEC>
+// FIRST: the pass holds the first stage of the transform (distance N/2), which reads the transform's inputs — below 4q by
+// the reference's contract (scalar/transform.rs:9), so Montgomery tables leave the fold of x out there.
+template <class A, int K, int VEC, bool FIRST = false>
 __device__ __forceinline__ void strided_forward_regs(const A &ar, u64 (&x)[1 << K][VEC], u32 n, u32 ebase, u32 log_s) {
     constexpr int R = 1 << K;
+    if constexpr (A::kMont && FIRST) {
+        const typename A::Tw w = ar.fwd_tw((n + ebase) >> (log_s + K));
 #pragma unroll
-    for (int j = K - 1; j >= 0; --j) {
+        for (int v = 0; v < (R >> 1); ++v)
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) fwd_bfly<true, true, true>(ar, x[v][c], x[v | (R >> 1)][c], w);
+    }
+#pragma unroll
+    for (int j = (A::kMont && FIRST) ? K - 2 : K - 1; j >= 0; --j) {
         const u32 base = (n + ebase) >> (log_s + j + 1);
 #pragma unroll
         for (int u = 0; u < (R >> (j + 1)); ++u) {
@@ -882,9 +940,13 @@ __device__ __forceinline__ void block_forward_core(const A &ar, u64 (&x)[1 << LO
 #pragma unroll
             for (int k = 0; k < E; ++k) x[k] = fwd_finish(ar, x[k], lazy);
         }
-    } else if constexpr (A::kMont) {  // below 7q -> [0,4q) (lazy contract) or [0,q)
+    } else if constexpr (A::kMont) {  // below 2^b + 3q -> [0,4q) (lazy contract) or [0,q)
+        if (!lazy) {
+            ar.canon_regs(x);
+        } else {
 #pragma unroll
-        for (int k = 0; k < E; ++k) x[k] = fwd_finish(ar, x[k], lazy);
+            for (int k = 0; k < E; ++k) x[k] = ar.fwd_lazy(x[k]);
+        }
     } else if (!lazy) {  // [0,4q) -> [0,q): scalar/transform.rs:104-116
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = ar.reduce_4q(x[k]);

@@ -14,11 +14,17 @@ seven 32 x 32 multiplies (six v_mad_u64_u32 + one v_mul_lo_u32) against the ten 
 Column 0 (y0*wm0 + y1*wm2_0 + m*q0, low word zero by construction) can carry twice; both carries join the high word of the
 column-1 addend.  Columns 1 (three products below 2^61 + the carry word) cannot overflow for q < 2^61.
 
-Lazy domain: values below 8q <= 2^64.  Forward: X = x - 4q if x >= 4q (so X < 4q), x' = X + T < 7q, y' = X + 3q - T < 7q.
-Inverse (inputs below 4q): x' = (x + y) - 4q if that is >= 4q (< 4q), y' = (x + 4q - y) * w < 3q.
+Forward lazy domain: values below 2^63 + 3q < 2^64.  The fold of x tests ONE bit instead of comparing: with F = c*q the
+largest multiple of q that is <= 2^63 (c >= 4), X = x - F when bit 63 of x is set (x - F < 3q + 2^63 - F < 4q),
+X = x otherwise, so X < 2^63 either way; x' = X + T < 2^63 + 3q, y' = X + 3q - T < 2^63 + 3q.  As instructions
+(MontArith::fold, in front of the asm block so that the compiler places it): v_ashrrev_i32 by 31 (the mask), two
+v_and_b32 with the halves of 2^64 - F, one v_lshl_add_u64 — 11.8 issue cycles where compare-and-select (v_sub_co,
+v_subb_co, 2 v_cndmask) took 17.4.  FOLD = false leaves the fold out: the first stage of a transform, whose inputs are
+below 4q by the reference's contract.  The closing reduction of a transform (MontArith::canon) takes any value of the domain.
+Inverse (inputs below F): x' = (x + y) - F if that is >= F (< F), y' = (x + F - y) * w < 3q <= F.
 
-    forward : 4 (conditional subtract) + 10 (product) + 4 = 18 instructions   (Shoup form, compiled: ~30)
-    inverse : 1 + 3 + 4 + 10                              = 18 instructions
+    forward : 4 (sign-bit fold) + 10 (product) + 4 = 18 instructions   (Shoup form, compiled: ~30)
+    inverse : 1 + 3 + 4 + 10                       = 18 instructions
 
 Run from the repository root:  python tools/gen_mont_asm.py
 """
@@ -56,16 +62,10 @@ def mul_seq(t, s, y0, y1, out=None):
 
 def fwd_seq(t, s):
     A, B, C, cy = t["A"], t["B"], t["C"], t["cy"]
-    seq = [
-        f"v_sub_co_u32_e64 v{C[0]}, {cy}, %[x0{s}], %[q40]",
-        f"v_subb_co_u32_e64 v{C[1]}, {cy}, %[x1{s}], %[q41], {cy}",
-        f"v_cndmask_b32_e64 v{C[0]}, v{C[0]}, %[x0{s}], {cy}",
-        f"v_cndmask_b32_e64 v{C[1]}, v{C[1]}, %[x1{s}], {cy}",             # X = x - 4q unless that borrows
-    ]
-    seq += mul_seq(t, s, f"%[y0{s}]", f"%[y1{s}]")
+    seq = mul_seq(t, s, f"%[y0{s}]", f"%[y1{s}]")                          # X = fold(x) arrives as an operand (A::fold)
     seq += [
-        f"v_lshl_add_u64 %[xo{s}], {pair(C)}, 0, {pair(A)}",                # x' = X + T
-        f"v_lshl_add_u64 {pair(B)}, {pair(C)}, 0, %[q3]",                   # X + 3q
+        f"v_lshl_add_u64 %[xo{s}], %[x{s}], 0, {pair(A)}",                  # x' = X + T
+        f"v_lshl_add_u64 {pair(B)}, %[x{s}], 0, %[q3]",                     # X + 3q
         f"v_sub_co_u32_e64 %[yo0{s}], {cy}, v{B[0]}, v{A[0]}",
         f"v_subb_co_u32_e64 %[yo1{s}], {cy}, v{B[1]}, v{A[1]}, {cy}",       # y' = X + 3q - T
     ]
@@ -75,16 +75,16 @@ def fwd_seq(t, s):
 def inv_seq(t, s):
     A, B, C, cy = t["A"], t["B"], t["C"], t["cy"]
     seq = [
-        f"v_lshl_add_u64 {pair(A)}, %[x{s}], 0, %[y{s}]",                   # A = x + y  (< 8q)
-        f"v_lshl_add_u64 {pair(C)}, %[x{s}], 0, %[q4]",                     # C = x + 4q
+        f"v_lshl_add_u64 {pair(A)}, %[x{s}], 0, %[y{s}]",                   # A = x + y  (< 2F)
+        f"v_lshl_add_u64 {pair(C)}, %[x{s}], 0, %[q4]",                     # C = x + F
         f"v_sub_co_u32_e64 v{C[0]}, {cy}, v{C[0]}, %[y0{s}]",
-        f"v_subb_co_u32_e64 v{C[1]}, {cy}, v{C[1]}, %[y1{s}], {cy}",        # C = x + 4q - y
-        f"v_sub_co_u32_e64 v{B[0]}, {cy}, v{A[0]}, %[q40]",
-        f"v_subb_co_u32_e64 v{B[1]}, {cy}, v{A[1]}, %[q41], {cy}",
-        f"v_cndmask_b32_e64 %[xo0{s}], v{B[0]}, v{A[0]}, {cy}",
-        f"v_cndmask_b32_e64 %[xo1{s}], v{B[1]}, v{A[1]}, {cy}",            # x' = (x + y) - 4q unless that borrows
+        f"v_subb_co_u32_e64 v{C[1]}, {cy}, v{C[1]}, %[y1{s}], {cy}",        # C = x + F - y
+        f"v_add_co_u32_e64 v{B[0]}, {cy}, v{A[0]}, %[nqf0]",
+        f"v_addc_co_u32_e64 v{B[1]}, {cy}, v{A[1]}, %[nqf1], {cy}",         # + (2^64 - F): carries iff x + y >= F
+        f"v_cndmask_b32_e64 %[xo0{s}], v{A[0]}, v{B[0]}, {cy}",
+        f"v_cndmask_b32_e64 %[xo1{s}], v{A[1]}, v{B[1]}, {cy}",            # x' = (x + y) - F when that is >= 0
     ]
-    seq += mul_seq(t, s, f"v{C[0]}", f"v{C[1]}", out=f"%[yo{s}]")          # y' = (x + 4q - y) * w
+    seq += mul_seq(t, s, f"v{C[0]}", f"v{C[1]}", out=f"%[yo{s}]")          # y' = (x + F - y) * w
     return seq
 
 
@@ -128,10 +128,10 @@ def gen_fwd(ways, uni):
     if ways == 2:
         outs += ['[cyb] "=&s"(cyb)']
     for s in sfx:
-        ins += [f'[x0{s}] "v"((u32)x{s})', f'[x1{s}] "v"((u32)(x{s} >> 32))', f'[y0{s}] "v"((u32)y{s})',
+        ins += [f'[x{s}] "v"(X{s})', f'[y0{s}] "v"((u32)y{s})',
                 f'[y1{s}] "v"((u32)(y{s} >> 32))'] + tw_ins(s, "s" if uni else "v")
-    ins += CONST_MUL + ['[q3] "s"(ar.q3)', '[q40] "v"(ar.vq4_0)', '[q41] "v"(ar.vq4_1)']
-    return emit_asm(lines, outs, ins, clobbers_of(sets, ["A", "B", "E", "C", "M"]), "        ")
+    ins += CONST_MUL + ['[q3] "s"(ar.q3)']
+    return emit_asm(lines, outs, ins, clobbers_of(sets, ["A", "B", "E", "M"]), "        ")
 
 
 def gen_inv(ways, uni):
@@ -145,7 +145,7 @@ def gen_inv(ways, uni):
     for s in sfx:
         ins += [f'[x{s}] "v"(x{s})', f'[y{s}] "v"(y{s})', f'[y0{s}] "v"((u32)y{s})', f'[y1{s}] "v"((u32)(y{s} >> 32))']
         ins += tw_ins(s, "s" if uni else "v")
-    ins += CONST_MUL + ['[q4] "s"(ar.q4)', '[q40] "v"(ar.vq4_0)', '[q41] "v"(ar.vq4_1)']
+    ins += CONST_MUL + ['[q4] "s"(ar.qf)', '[nqf0] "v"(ar.vnqf_0)', '[nqf1] "v"(ar.vnqf_1)']
     return emit_asm(lines, outs, ins, clobbers_of(sets, ["A", "B", "E", "C", "M"]), "        ")
 
 
@@ -162,9 +162,10 @@ HEADER = '''// pfhe_mont_asm.hpp — GENERATED by tools/gen_mont_asm.py; do not 
 //
 // NTT butterflies for any odd prime q < 2^61 (MontArith, pfhe_ntt_device.hpp): twiddles {w*2^32 mod q, w*2^64 mod q},
 // T = (y0*wm + y1*wm2 + m*q) / 2^32 < 3q with m = (low word) * (-q^-1) mod 2^32 — seven 32 x 32 multiplies; forward
-// X = x - 4q if x >= 4q, x' = X + T, y' = X + 3q - T (below 7q); inverse x' = x + y - 4q if that is >= 4q, y' = (x + 4q - y) * w.
-// Fixed temporaries v2..v19.  `A` provides q, q3 = 3q, q4 = 4q, qinv = -q^-1 mod 2^32 and, in VGPRs, the halves of 4q
-// (vq4_0, vq4_1).  UNI: the twiddle is wave-uniform and sits in SGPRs.
+// X = x - F if bit 63 of x is set (F = the largest multiple of q below 2^63), x' = X + T, y' = X + 3q - T (below 2^63 + 3q);
+// inverse x' = x + y - F if that is >= F, y' = (x + F - y) * w.
+// Fixed temporaries v2..v19.  `A` provides q, q3 = 3q, qf = F, qinv = -q^-1 mod 2^32, fold() and, in VGPRs, the halves of
+// 2^64 - F (vnqf_0, vnqf_1).  UNI: the twiddle is wave-uniform and sits in SGPRs.
 #pragma once
 
 namespace pfhe {
@@ -177,8 +178,9 @@ def main():
     for ways in (1, 2):
         sfx = ["a", "b"][:ways]
         args = ", ".join(f"u64 &x{s}, u64 &y{s}, TW w{s}" for s in sfx)
-        src += f"template <bool UNI, class A, class TW>\n__device__ __forceinline__ void mont_fwd_bfly{ways}(const A &ar, {args}) {{\n"
+        src += f"template <bool UNI, bool FOLD = true, class A, class TW>\n__device__ __forceinline__ void mont_fwd_bfly{ways}(const A &ar, {args}) {{\n"
         src += "    u64 " + ", ".join(f"xo{s}" for s in sfx) + ";\n    u32 " + ", ".join(f"yo0{s}, yo1{s}" for s in sfx) + ";\n"
+        src += "    const u64 " + ", ".join(f"X{s} = FOLD ? ar.fold(x{s}) : x{s}" for s in sfx) + ";\n"
         if ways == 2:
             src += "    u64 cyb;\n"
         src += "    if constexpr (UNI) {\n" + gen_fwd(ways, True) + "    } else {\n" + gen_fwd(ways, False) + "    }\n"
