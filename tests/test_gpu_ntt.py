@@ -800,15 +800,22 @@ def test_dcrt_small_rings_with_per_lane_primes(pf, orc, log_n, lazy):
         assert np.array_equal(to_host(fwd), a)
 
 
-# generic NTT-friendly primes (= 1 mod 2^18, NOT of pseudo-Mersenne shape), 61 / 61 / 59 / 45 / 33 bits: the domain of the
-# Montgomery-form transforms (MontArith, q < 2^61)
+# generic NTT-friendly primes (= 1 mod 2^18, NOT of pseudo-Mersenne shape), 61 / 61 / 59 / 45 / 33 bits.  The
+# Montgomery-form transforms (MontArith) take tables whose primes all lie in [2^48, 2^61); a table with a smaller prime
+# keeps the Shoup transforms, and the same assertions hold for it.
 GENERIC = [1635294906373636097, 1220953465133989889, 387168985270714369, 27672964759553, 7717519361]
+# the edges of that range: the largest such prime below 2^61 (forward lazy values reach 2^63 + 3q, 98 % of 2^64), 53 bits,
+# the first one above 2^48 (where the quotient estimate of the closing reduction is least exact) and the last one below
+GENERIC_EDGE = [2305843008942112769, 6804446355652609, 281474980380673, 281474975662081]
 
 
 @pytest.mark.parametrize("log_n,moduli,batch", [
     (4, GENERIC[:3], 5), (5, GENERIC[1:4], 8), (7, GENERIC[:1], 3), (9, GENERIC[2:5], 4), (10, GENERIC[:2], 3),
     (12, GENERIC[3:], 2), (13, GENERIC[:2], 2), (14, GENERIC[1:2], 2), (15, GENERIC[:2], 2), (16, GENERIC[:3], 2),
     (17, GENERIC[4:], 1),
+    (4, GENERIC_EDGE[:3], 4), (6, GENERIC_EDGE[:3], 3), (8, GENERIC_EDGE[1:3], 4), (9, GENERIC_EDGE[2:3], 5),
+    (11, GENERIC_EDGE[:3], 2), (12, GENERIC_EDGE[2:3], 3), (13, GENERIC_EDGE[1:3], 2), (14, GENERIC_EDGE[:1], 2),
+    (16, GENERIC_EDGE[:3], 2), (16, GENERIC_EDGE[2:], 1), (17, GENERIC_EDGE[:1], 1),
 ])
 def test_generic_primes_montgomery_transforms(pf, orc, log_n, moduli, batch, monkeypatch):
     """Tables whose primes are below 2^61 but not pseudo-Mersenne run their transforms in Montgomery form (MontArith: 7
