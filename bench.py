@@ -237,7 +237,7 @@ def built_vgprs(kernel: str):
 def vgpr_granules(allocated_registers: int) -> int:
     """rocprofv3's VGPR_Count column for a gfx950 dispatch: the registers a wave is ALLOCATED — the code object's
     .vgpr_count rounded up to the granule of 8 — counted in pairs (125 registers -> 128 allocated -> 64; checked on
-    every kernel of profiles/r04_a_rocprof.json against primus-fhe_amd/_codeobj.py)."""
+    every kernel of the newest profiles/*_rocprof.json against primus-fhe_amd/_codeobj.py)."""
     return -(-allocated_registers // 8) * 4
 
 
