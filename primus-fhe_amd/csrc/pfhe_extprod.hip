@@ -463,7 +463,8 @@ int gadget_block_mulacc_dev(const NttPrime *primes, u32 L, u32 log_n, int arith,
                            inv_tail ? 1u : 0u);
     } else if (arith == kArithMont) {
         // generic primes below 2^61: the Montgomery-form butterflies (7 multiplies) instead of the Shoup ones (10)
-        hipLaunchKernelGGL((gadget_block_mulacc_kernel<MontArith, 2>), dim3((u32)total_blocks), dim3(256), lds_bytes, s,
+        // (the 512-thread form here too: 38.7 -> 40.0 k products/s for three generic 61-bit primes, same box)
+        hipLaunchKernelGGL((gadget_block_mulacc_kernel<MontArith, 2, 3>), dim3((u32)total_blocks), dim3(512), lds_bytes, s,
                            digits, ggsw, stride, result, primes, L, log_n, terms, total_blocks, accumulate ? 1u : 0u,
                            inv_tail ? 1u : 0u);
     } else {

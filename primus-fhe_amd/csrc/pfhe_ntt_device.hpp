@@ -305,11 +305,12 @@ struct PmArith {
 };
 
 
-// MontArith — any odd prime q < 2^61 (the transforms of tables whose primes are not all pseudo-Mersenne): one-word
+// MontArith — odd primes in [2^48, 2^61) (the transforms of tables whose primes are not all pseudo-Mersenne): one-word
 //   Montgomery reduction with a split multiplicand.  Twiddles are stored as {wm = w*2^32 mod q, wm2 = w*2^64 mod q}
 //   (NttPrime::fwd_m / inv_m); T = (y0*wm + y1*wm2 + m*q) / 2^32 == y*w (mod q), T < 3q for ANY 64-bit y, with
 //   m = (low word of the sum) * (-q^-1 mod 2^32): seven 32 x 32 multiplies where the reference's Shoup product
-//   (shoup_factor/mod.rs:124-131) takes ten.  Lazy domain [0, 8q) inside 64 bits: see pfhe_mont_asm.hpp.  Exact
+//   (shoup_factor/mod.rs:124-131) takes ten.  Lazy domains: forward [0, 2^63 + 3q), inverse [0, F), F the largest
+//   multiple of q below 2^63 (the members below and pfhe_mont_asm.hpp).  Exact
 //   integer arithmetic: canonical outputs are the Shoup path's, lazy outputs agree mod q and honour the reference's
 //   [0,4q) / [0,2q) contracts.  Products of two data words keep the Barrett form (mul_any).
 // low word of a*b + c in ONE instruction (v_mad_u64_u32): the compiler, asked for 32 bits of that sum, emits
@@ -611,7 +612,7 @@ __device__ __forceinline__ void inv_final_bfly(const A &ar, u64 &x, u64 &y, bool
 // (scalar/transform.rs:104-116)
 template <class A>
 __device__ __forceinline__ u64 fwd_finish(const A &ar, u64 x, bool lazy) {
-    if constexpr (A::kMont) {  // below 2^b + 3q -> [0,4q) or [0,q)
+    if constexpr (A::kMont) {  // below 2^63 + 3q -> [0,q) (lazy too: inside the reference's [0,4q))
         return lazy ? ar.fwd_lazy(x) : ar.canon(x);
     } else if constexpr (A::kWide) {
         return lazy ? ar.reduce_x(x) : ar.canon(x);
@@ -911,7 +912,7 @@ __device__ __forceinline__ void fwd_chain(const A &ar, u64 (&x)[1 << LOGE], u64 
 // are: below 2^63 + 2^32, which mul_full takes (its partial sums need y1 <= 2^31), and the finishing fold of every
 // coefficient (4 instructions each) is gone.  The stage in front of the core must have folded (inputs below 4U + 2^31):
 // true for canonical / [0,4q) inputs and behind a strided pass, whose last stage folds.  Montgomery tables skip their
-// closing conditional subtraction the same way (values below 7q; the Barrett product takes any 64-bit word).
+// closing reduction the same way (values below 2^63 + 3q; the Barrett product takes any 64-bit word).
 template <class A, int LOGB, bool LEAD = true, int LOGE = 4, class Late = NoLateHook, bool RAW = false>
 __device__ __forceinline__ void block_forward_core(const A &ar, u64 (&x)[1 << LOGE], u64 *__restrict__ lds, u32 n,
                                                    u32 eblk, u32 lt, bool lazy, Late before_last = Late()) {
@@ -940,13 +941,8 @@ __device__ __forceinline__ void block_forward_core(const A &ar, u64 (&x)[1 << LO
 #pragma unroll
             for (int k = 0; k < E; ++k) x[k] = fwd_finish(ar, x[k], lazy);
         }
-    } else if constexpr (A::kMont) {  // below 2^b + 3q -> [0,4q) (lazy contract) or [0,q)
-        if (!lazy) {
-            ar.canon_regs(x);
-        } else {
-#pragma unroll
-            for (int k = 0; k < E; ++k) x[k] = ar.fwd_lazy(x[k]);
-        }
+    } else if constexpr (A::kMont) {  // below 2^63 + 3q -> [0,q), lazy or not (MontArith::fwd_lazy)
+        ar.canon_regs(x);
     } else if (!lazy) {  // [0,4q) -> [0,q): scalar/transform.rs:104-116
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = ar.reduce_4q(x[k]);
