@@ -218,6 +218,7 @@ def git_blob_hash(path: str) -> str:
 
 
 _BUILT_KERNELS = None
+_BUILT_CODE = None
 
 
 def built_vgprs(kernel: str):
@@ -234,27 +235,35 @@ def built_vgprs(kernel: str):
     return None if r is None else (r["vgpr"] or 0) + (r["agpr"] or 0)
 
 
-def vgpr_granules(allocated_registers: int) -> int:
-    """rocprofv3's VGPR_Count column for a gfx950 dispatch: the registers a wave is ALLOCATED — the code object's
-    .vgpr_count rounded up to the granule of 8 — counted in pairs (125 registers -> 128 allocated -> 64; checked on
-    every kernel of the newest profiles/*_rocprof.json against primus-fhe_amd/_codeobj.py)."""
-    return -(-allocated_registers // 8) * 4
+def built_code_hash(kernel: str):
+    """SHA-256 (16 hex digits) of `kernel`'s machine code in the libpfhe_hip.so this run loads, or None."""
+    global _BUILT_CODE
+    if _BUILT_CODE is None:
+        try:
+            import primus_fhe_amd as p
+            from primus_fhe_amd._codeobj import kernel_code_hashes
+            _BUILT_CODE = kernel_code_hashes(p.library_path())
+        except Exception:
+            _BUILT_CODE = {}
+    return _BUILT_CODE.get(kernel)
 
 
 def provenance(path: str, profiled: dict):
     """A committed counter profile describes the kernels it was taken on.  Its figures are reported only when every
-    kernel it covers still has, in the library being timed, the register allocation the profiler recorded (rocprofv3's
-    VGPR_Count column, see vgpr_granules): a changed kernel makes the profile stale and the traffic null.  Returns
-    (fields for the JSON line, ok)."""
+    kernel it covers has, in the library being timed, the MACHINE CODE the profiler ran: the profile names the SHA-256 of
+    each kernel's code (tools/pmc_summary.py, tools/collect_profiles2.py through primus-fhe_amd/_codeobj.py), and a
+    kernel whose code differs — or a profile that names no hash — makes the profile stale and the traffic null.  (Until
+    round 4 the check compared register allocations, which a kernel can keep while it changes what it moves.)
+    `profiled`: {kernel: code hash or None}.  Returns (fields for the JSON line, ok)."""
     rows = {}
     ok = bool(profiled)
-    for k, v in (profiled or {}).items():
-        now = built_vgprs(k)
-        rows[k] = {"profiled_vgpr_count": v, "built_vgpr_count": now,
-                   "built_as_the_profiler_counts": None if now is None else vgpr_granules(now)}
-        if v is None or now is None or vgpr_granules(now) != v:
+    for k, h in (profiled or {}).items():
+        now = built_code_hash(k)
+        rows[k] = {"profiled_code_sha256": h, "built_code_sha256": now, "built_vgpr_count": built_vgprs(k)}
+        if h is None or now is None or h != now:
             ok = False
     return {"profile": os.path.basename(path), "profile_git_blob": git_blob_hash(path), "kernels_checked": rows,
+            "check": "SHA-256 of each kernel's machine code, profile vs the library being timed",
             "profile_matches_build": ok}, ok
 
 
@@ -266,7 +275,8 @@ def extprod_traffic():
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_extprod_traffic.json")), reverse=True):
         try:
             d = json.load(open(path))
-            prov, ok = provenance(path, d.get("vgpr_count_by_kernel"))
+            prov, ok = provenance(path, {k: (d.get("code_sha256_by_kernel") or {}).get(k)
+                                         for k in d.get("vgpr_count_by_kernel") or {}})
             return {"bytes_per_product": float(d["bytes_per_product"]) if ok else None, "source": os.path.basename(path),
                     "method": d["method"], "provenance": prov}
         except Exception:
@@ -278,8 +288,8 @@ def pmc_traffic(kernel: str, batch: int):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 +
     WRITE_SIZE, separate --pmc runs of tools/profile_ntt.py at this shape; profiles/*_rocprof.json).
     bench.py cannot collect counters itself: the figure is READ FROM A COMMITTED PROFILE, named in `traffic_source` with its
-    git blob id, and is null when no profile of this launch shape is committed or when the profiled kernel's register
-    count differs from the one in the library being timed (provenance)."""
+    git blob id, and is null when no profile of this launch shape is committed or when the profiled kernel's machine code
+    differs from the one in the library being timed (provenance)."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof.json")), reverse=True):
         try:
@@ -301,7 +311,7 @@ def pmc_traffic(kernel: str, batch: int):
             tile_units = -(-batch // 24)
             if sel and max(r["grid_size"] for r in sel) == tile_units * 3 * 16 * 256:
                 launches = sum(r["launches"] for r in sel)
-                prov, ok = provenance(path, {r["kernel"]: r.get("vgpr_count") for r in sel})
+                prov, ok = provenance(path, {r["kernel"]: r.get("code_sha256") for r in sel})
                 return {"bytes_per_launch": sum(r["hbm_bytes_per_launch"] * r["launches"] for r in sel) / launches if ok else None,
                         "source": os.path.basename(path), "provenance": prov,
                         "method": "2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes (MI355X_MICROARCH.md, HBM), "
@@ -329,7 +339,7 @@ def pmc_traffic(kernel: str, batch: int):
         # strided pass = N/32 threads per polynomial
         want_grid = batch * 3 * ((1 << LOG_N) // 16 if "block" in want else (1 << LOG_N) // 32)
         if best and best["grid_size"] == want_grid:
-            prov, ok = provenance(path, {best["kernel"]: best.get("vgpr_count")})
+            prov, ok = provenance(path, {best["kernel"]: best.get("code_sha256")})
             return {"bytes_per_launch": best["hbm_bytes_per_launch"] if ok else None, "source": os.path.basename(path),
                     "provenance": prov,
                     "method": "2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes (MI355X_MICROARCH.md, HBM)"}
@@ -413,6 +423,10 @@ def main():
         else:
             dist.init_process_group(args.dist_backend)
 
+    from primus_fhe_amd.shard import device_identity, dist_evidence
+    # what the process group saw (not what the launcher's environment says): filled into the line below
+    dist_seen = dist_evidence(dist, device_identity(local_rank)) if dist is not None else None
+
     n, L, batch = 1 << LOG_N, 3, args.batch
     words = batch * L * n
     dump = {}
@@ -446,7 +460,13 @@ def main():
                                "forward DCRT NTT in place (config 3')" % batch,
                    "log_n": LOG_N, "moduli": Q61, "batch_per_gpu": batch, "sharding": "batch, no collectives"},
         "hbm_roofline_frac": value * 16 * n / world / (HBM_PEAK_GBS * 1e9),
+        # torch.distributed's own view: backend, world size, and every rank's device (PCI address, UUID) gathered over the
+        # group; without a process group (one rank) the one device this process used
+        "dist": dist_seen if dist_seen is not None else {"backend": None, "world_size": 1, "devices": [dict(device_identity(local_rank), rank=0)],
+                                                         "distinct_devices": 1},
     }
+    if dist_seen is not None and dist_seen["world_size"] != world:
+        raise SystemExit("bench.py: the process group has %d ranks, the launcher said %d" % (dist_seen["world_size"], world))
 
     # ---- config 4 / 5: RNS gadget external product, k=1, logB=30 (ell=6), batch 1024 per GPU, one shared
     #      GGSW replicated per device; every rank runs it, the rate is aggregated over ranks (weak scaling,
@@ -483,15 +503,22 @@ def main():
             dec_bytes = ep_batch * (2 * L + 2 * 6 * L) * n * 8  # CRT polynomials read + strided-pass digits written
             dom_bytes = mac_bytes if ms_mac >= ms_dec else dec_bytes
             traffic = extprod_traffic()
+            alg_bytes_ep = 96 * n * ep_batch  # CrtGlwe in (48 N) + DcrtGlwe out (48 N) per product
             result["external_product"]["roofline"] = {
                 "bound": "hbm", "kernel": "gadget_block_mulacc_kernel (block pass of the digits' transform + multiply-accumulate"
                                           " + inverse block pass of the result)"
                 if ms_mac >= ms_dec else "gadget_signed_digits_kernel + digits_strided_kernel",
                 "avg_launch_ms": dom_ms / max(1, launches), "launches_per_batch": launches,
                 "ms_per_batch": {"digits_and_strided_pass": ms_dec, "block_pass_and_multiply_accumulate": ms_mac},
-                "achieved": dom_bytes / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_batch": dom_bytes,
+                # the PRODUCT against the roofline, on SURVEY §8d's algorithmic bytes and the whole batch's time
+                "algorithmic_bytes_per_batch": alg_bytes_ep,
+                "achieved": alg_bytes_ep / dte / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": alg_bytes_ep / dte / 1e9 / HBM_PEAK_GBS,
+                # the dominant KERNEL on the bytes the two-pass plan makes it move (transformed digits in + result out): a
+                # statement about that kernel under this plan, not about the product
+                "kernel_compulsory_bytes": dom_bytes,
+                "kernel_achieved": dom_bytes / (dom_ms * 1e-3) / 1e9,
+                "kernel_frac": dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 # whole product, every kernel: HBM bytes per product from the committed counter passes x this batch
                 "traffic": traffic["bytes_per_product"] * ep_batch if traffic and traffic["bytes_per_product"] else None,
                 "traffic_unit": "bytes per batch of %d products, all kernels of the product (coefficient form)" % ep_batch,
@@ -499,9 +526,8 @@ def main():
                 "traffic_provenance": traffic["provenance"] if traffic else None,
                 "traffic_vs_algorithmic": traffic["bytes_per_product"] / (96 * n) if traffic and traffic["bytes_per_product"] else None,
                 "note": "the kernel runs 12 forward block transforms + 72 multiply-accumulates per word + 2 inverse block "
-                        "transforms per output block: VALUBusy 80+ % AND ~11x the product's algorithmic bytes in flight "
-                        "(the 36 half-transformed digit polynomials are written and read once): loaded on both units "
-                        "(profiles/r03_*_extprod_pmc.txt)"}
+                        "transforms per output block: VALU-bound (VALUBusy 90 %), and the plan moves ~9x the product's "
+                        "algorithmic bytes (the 36 half-transformed digit polynomials are written and read once)"}
         except Exception as e:  # measurement aid only
             result["external_product"]["roofline"] = {"error": str(e)[:200]}
     del out

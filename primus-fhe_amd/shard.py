@@ -74,6 +74,32 @@ def timed_steps(step, steps: int, warmup: int, sync, dist=None, device=None):
     return dt
 
 
+def device_identity(index=None) -> dict:
+    """What tells two GPUs apart: PCI domain:bus:device and the UUID of visible device `index` (None: a rank without a
+    GPU — the CPU tests — reports its host and process id instead)."""
+    import os
+    import socket
+    if index is None:
+        return {"device": None, "host": socket.gethostname(), "pid": os.getpid()}
+    import torch
+    pr = torch.cuda.get_device_properties(index)
+    pci = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+    return {"device": index, "pci": pci, "uuid": str(getattr(pr, "uuid", "")), "name": pr.name, "host": socket.gethostname(),
+            "pid": os.getpid()}
+
+
+def dist_evidence(dist, identity: dict) -> dict:
+    """What the process group ACTUALLY saw, for the bench line: backend and world size as torch.distributed reports them
+    (not the launcher's environment) and the identity of every rank's device, gathered over the group — "N ranks on N
+    distinct devices over RCCL" is then checkable from the line alone.  Collective: call on every rank."""
+    world = dist.get_world_size()
+    seen = [None] * world
+    dist.all_gather_object(seen, dict(identity, rank=dist.get_rank()))
+    keys = [(d.get("host"), d.get("pci") or d.get("pid")) for d in seen]
+    return {"backend": dist.get_backend(), "world_size": world, "devices": seen,
+            "distinct_devices": len(set(keys))}
+
+
 def strong_scaling_leg(total: int, world: int, rank: int, run_shard, steps: int, warmup: int, sync, dist=None,
                        device=None):
     """BASELINE config 5: a FIXED job of `total` independent units (ciphertexts) split over the ranks in contiguous

@@ -65,12 +65,15 @@ def _worker(rank, world, port, q):
     # gather the shards (test-only collective) and compare with the unsharded transform
     parts = [None] * world
     dist.all_gather_object(parts, (b, e, mine))
+    # the bench line's `dist` object: what the process group itself reports
+    from primus_fhe_amd.shard import device_identity, dist_evidence
+    ev = dist_evidence(dist, device_identity(None))
     dist.destroy_process_group()
     if rank == 0:
         full = data.copy()
         table.transform_slice(full)
         got = np.concatenate([p[2] for p in sorted(parts, key=lambda t: t[0])])
-        q.put((np.array_equal(got, full) and leg_ok, [(p[0], p[1]) for p in parts], dt, len(calls)))
+        q.put((np.array_equal(got, full) and leg_ok, [(p[0], p[1]) for p in parts], dt, len(calls), ev))
 
 
 def test_shard_range_properties():
@@ -94,13 +97,16 @@ def test_two_rank_gloo_sharding_matches_unsharded():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    ok, ranges, dt, ncalls = q.get(timeout=120)
+    ok, ranges, dt, ncalls, ev = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok
     assert sorted(ranges) == [(0, 4), (4, 7)]
     assert dt > 0 and ncalls == 3  # 1 warm-up + exactly 2 timed steps
+    # the `dist` object of the bench line: backend and world size from the process group, one identity per rank
+    assert ev["backend"] == "gloo" and ev["world_size"] == 2 and ev["distinct_devices"] == 2
+    assert sorted(d["rank"] for d in ev["devices"]) == [0, 1] and len({d["pid"] for d in ev["devices"]}) == 2
 
 
 def test_job_seed_makes_shard_input_position_only():
@@ -170,8 +176,9 @@ def test_bench_gpus_defaults_to_the_launchers_world_size(monkeypatch):
 
 
 def test_traffic_figures_carry_their_provenance():
-    """roofline.traffic is read from a committed profile: the line names the file, its git blob id and the register
-    counts it was taken at, and is null when the library being timed has different kernels."""
+    """roofline.traffic is read from a committed profile: the line names the file, its git blob id and the SHA-256 of the
+    machine code of every kernel it was taken on, and is null when the library being timed holds other code (VERDICT r3
+    item 7, r4 item 10)."""
     import subprocess
 
     import bench
@@ -184,14 +191,20 @@ def test_traffic_figures_carry_their_provenance():
     path = os.path.join(ROOT, "profiles", "r03_d_rocprof.json")   # (any committed file: only its blob id is read here)
     blob = subprocess.run(["git", "hash-object", path], capture_output=True, text=True, cwd=ROOT).stdout.strip()
     assert bench.git_blob_hash(path) == blob
-    built = bench.built_vgprs("ntt_pipe_fwd_kernel<PmArith, 12>")
-    assert bench.vgpr_granules(125) == 64 and bench.vgpr_granules(97) == 52   # as rocprofv3 reports them
-    prov, ok = bench.provenance(path, {"ntt_pipe_fwd_kernel<PmArith, 12>": bench.vgpr_granules(built)})
-    assert ok and prov["profile_git_blob"] == blob
-    prov, ok = bench.provenance(path, {"ntt_pipe_fwd_kernel<PmArith, 12>": bench.vgpr_granules(built) + 8})
+    k = "ntt_pipe_fwd_kernel<PmArith, 12>"
+    from primus_fhe_amd._codeobj import kernel_code_hashes
+    code = kernel_code_hashes(p.library_path())
+    assert set(code) == set(res) and all(len(h) == 16 for h in code.values())   # every kernel of the library has a hash
+    built = bench.built_code_hash(k)
+    assert built == code[k] and bench.built_vgprs(k) == res[k]["vgpr"]
+    prov, ok = bench.provenance(path, {k: built})
+    assert ok and prov["profile_git_blob"] == blob and prov["kernels_checked"][k]["built_code_sha256"] == built
+    # the same registers, other code: stale (VERDICT r4 item 10 — a kernel can change its traffic and keep its registers)
+    prov, ok = bench.provenance(path, {k: "0" * 16})
     assert not ok and not prov["profile_matches_build"]
-    assert not bench.provenance(path, {"ntt_pipe_fwd_kernel<PmArith, 12>": None})[1]   # a profile without register counts
+    assert not bench.provenance(path, {k: None})[1]   # a profile that names no code hash (rounds 1-4) is unverifiable
     assert not bench.provenance(path, {})[1]
+    assert not bench.provenance(path, {"no_such_kernel": built})[1]
     # the newest committed profiles: their traffic is reported exactly when they describe the kernels of this tree
     t = bench.pmc_traffic("ntt_pipe_fwd_kernel", 4096)
     assert t is not None

@@ -109,6 +109,14 @@ def counter_sum(name):
 
 
 fe, wr = counter_sum("FETCH_SIZE"), counter_sum("WRITE_SIZE")
+try:  # the code the counters were taken on (bench.py compares it with the library it times)
+    sys.path.insert(0, ROOT)
+    import primus_fhe_amd as _p
+    from primus_fhe_amd._codeobj import kernel_code_hashes
+    ep_code = kernel_code_hashes(_p.library_path())
+except Exception as _e:
+    print("collect_profiles2: no code hashes:", _e)
+    ep_code = {}
 if fe and wr:
     products = 4 * int(os.environ.get("BATCH", "1024"))
     per_kernel = {k: (2 * fe.get(k, 0.0) + wr.get(k, 0.0)) * 1024 / products for k in sorted(set(fe) | set(wr))}
@@ -116,6 +124,7 @@ if fe and wr:
                "method": "sum over every kernel launch of 2*FETCH_SIZE + WRITE_SIZE (separate --pmc passes, KiB), / products",
                "bytes_per_product": sum(per_kernel.values()), "bytes_per_product_by_kernel": per_kernel,
                "vgpr_count_by_kernel": ep_vgpr,
+               "code_sha256_by_kernel": {k: ep_code.get(k) for k in ep_vgpr},
                "algorithmic_bytes_per_product": 96 * 65536}
     json.dump(traffic, open(f"{dst}/{tag}_extprod_traffic.json", "w"), indent=1)
     ep.append("whole product: %.1f MB moved per product (algorithmic 6.29 MB): " % (traffic["bytes_per_product"] / 1e6) +

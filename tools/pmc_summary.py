@@ -10,7 +10,22 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def code_hashes():
+    """SHA-256 (16 hex digits) of the machine code of every kernel in the library the counters were taken on
+    (primus-fhe_amd/_codeobj.py): bench.py reports a profile's traffic only while the library it times holds the same code."""
+    try:
+        import primus_fhe_amd as p
+        from primus_fhe_amd._codeobj import kernel_code_hashes
+        return kernel_code_hashes(p.library_path())
+    except Exception as e:  # the summary is still written; bench.py then treats the profile as unverifiable
+        print("pmc_summary: no code hashes:", e)
+        return {}
 
 
 def one(pattern):
@@ -45,6 +60,7 @@ def main():
     for r in write:
         traffic[(short(r["Kernel_Name"]), int(r["Grid_Size"]))]["write_kib"].append(float(r["Counter_Value"]))
     rows = []
+    hashes = code_hashes()
     for key in sorted(set(dur) | set(traffic), key=lambda k: (k[0], -k[1])):
         d, t = dur.get(key, []), traffic.get(key, {"fetch_kib": [], "write_kib": []})
         if key[0].startswith("__amd"):
@@ -52,6 +68,7 @@ def main():
         f = sum(t["fetch_kib"]) / len(t["fetch_kib"]) if t["fetch_kib"] else None
         w = sum(t["write_kib"]) / len(t["write_kib"]) if t["write_kib"] else None
         row = {"kernel": key[0], "grid_size": key[1], "launches": len(d), "vgpr_count": vgpr.get(key[0]),
+               "code_sha256": hashes.get(key[0]),
                "avg_ms": sum(d) / len(d) / 1e6 if d else None,
                "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
                "read_bytes_corrected": None if f is None else 2 * f * 1024,
