@@ -33,6 +33,7 @@ struct NttTuning {
     bool pipelined = true;         // PFHE_DISABLE_PIPELINED clears it: N = 2^16 runs as tiles + 1 launches of ntt_pipe_kernel on the caller's stream
     int pipe_ramp = 0;             // PFHE_PIPE_RAMP: tile weights of the pipelined form ramp 1..ramp..1 (0 / 1: equal tiles)
     bool persist = true;           // PFHE_DISABLE_PERSIST clears it: N = 2^13 / 2^14 batches run ntt_persist_kernel (resident workgroups that prefetch their next polynomial)
+    int pipe_dma = 0;              // PFHE_PIPE_DMA: (block, chunk) pairs per workgroup of the LDS-DMA form of the forward pipelined kernel (0: the plain form)
     int pipelined_min_mb = 0;      // PFHE_PIPELINED_MIN_MB: smallest batch (MiB of data) that takes the pipelined form (0: built-in default)
     static NttTuning from_env();
 };
@@ -68,6 +69,11 @@ int ntt_polymul_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *da
 // U32NttTable / U32DcrtTable transforms (log_n = log2 of the polynomial length in coefficients)
 int ntt32_transform_dev(const NttPrime *primes, u32 L, u32 log_n, u32 *data, u64 npolys, bool inverse, bool lazy,
                         hipStream_t s, const NttTuning &tune = NttTuning());
+
+// LDS-DMA form of the forward pipelined kernel (pfhe_ntt_dma.hip): one launch over max(blk_total, str_total) (block, chunk)
+// pairs of N = 2^16, `per_wg` pairs per workgroup (bits 16.. of per_wg: experiment modes, see the kernel)
+int launch_pipe_fwd_dma(int arith, u64 *blk_data, u64 blk_total, u64 *str_data, u64 str_total, const NttPrime *primes, u32 L,
+                        bool lazy, int per_wg, hipStream_t s);
 
 int ntt_num_passes(u32 log_n, int arith = 0, const NttTuning &tune = NttTuning());
 void ntt_pass_name(u32 log_n, bool inverse, int index, char *buf, size_t cap, int arith = 0,
@@ -628,6 +634,16 @@ __device__ __forceinline__ u64 fwd_finish(const A &ar, u64 x, bool lazy) {
 template <class A, int K, int VEC, bool FIRST = false>
 __device__ __forceinline__ void strided_forward_regs(const A &ar, u64 (&x)[1 << K][VEC], u32 n, u32 ebase, u32 log_s) {
     constexpr int R = 1 << K;
+#ifdef PFHE_SKELETON  // timing-only build (tools/build_variant.sh skel -DPFHE_SKELETON): the data movement without the butterflies
+#pragma unroll
+    for (int v = 0; v < (R >> 1); ++v)
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            x[v][c] += x[v | (R >> 1)][c];
+            x[v | (R >> 1)][c] ^= x[v][c];
+        }
+    return;
+#endif
     if constexpr (A::kMont && FIRST) {
         const typename A::Tw w = ar.fwd_tw((n + ebase) >> (log_s + K));
 #pragma unroll
@@ -746,6 +762,14 @@ __device__ __forceinline__ u32 last_table_off(u32 n, u32 e0, int j, int u) {
 template <class A, int POS, int JHI, int JLO, bool UNIFORM, int LOGE = 4, bool EVEN = false>
 __device__ __forceinline__ void fwd_regpass(const A &ar, u64 (&x)[1 << LOGE], u32 n_plus_e, u32 n) {
     constexpr int E = 1 << LOGE;
+#ifdef PFHE_SKELETON  // timing-only build: see strided_forward_regs
+#pragma unroll
+    for (int v = 0; v < E / 2; ++v) {
+        x[v] += x[v | (E / 2)];
+        x[v | (E / 2)] ^= x[v];
+    }
+    return;
+#endif
 #pragma unroll
     for (int j = JHI; j >= JLO; --j) {
         const u32 base = maybe_uniform<POS, UNIFORM>(n_plus_e >> (POS + j + 1));
@@ -883,6 +907,10 @@ __device__ __forceinline__ void lds_exchange(u64 (&x)[1 << LOGE], u64 *__restric
     }
     lds_get_layout<TO, LOGE>(x, lds, lt);
 }
+
+// Stores of the pipelined kernels' INTERMEDIATE (strided pass -> block pass of the next launch; inverse: the other way
+// round): non-temporal, or plain so that tiles small enough stay in the 256 MiB Infinity Cache until they are read.
+constexpr bool kPipeIntermediateNt = false;
 
 struct NoLateHook {
     __device__ __forceinline__ void operator()() const {}
