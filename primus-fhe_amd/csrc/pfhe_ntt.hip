@@ -925,7 +925,6 @@ NttTuning NttTuning::from_env() {
     t.pipelined_min_mb = env_int("PFHE_PIPELINED_MIN_MB", 1, 1 << 20);
     t.pipe_ramp = env_int("PFHE_PIPE_RAMP", 1, 32);
     t.persist = std::getenv("PFHE_DISABLE_PERSIST") == nullptr;
-    t.pipe_dma = env_int("PFHE_PIPE_DMA", 1, 1 << 30);
     return t;
 }
 
@@ -1013,7 +1012,7 @@ constexpr int kPipelinedMaxTiles = 64;
 // the pipelined form of the two-pass transform (ntt_pipe_{fwd,inv}_kernel): tiles + 1 launches on the caller's stream
 template <class A, int LOGB>
 static int transform_pipelined(const NttPrime *primes, u32 L, u64 *data, u64 npolys, bool inverse, bool lazy,
-                               hipStream_t s, int tiles, int ramp, const u64 *mul, u64 mul_polys, int dma_per_wg = 0) {
+                               hipStream_t s, int tiles, int ramp, const u64 *mul, u64 mul_polys) {
     if (tiles > 64) tiles = 64;
     constexpr u32 log_n = LOGB + 4;
     constexpr size_t lds_bytes = (size_t)BlockCfg<LOGB>::LDS_WORDS * sizeof(u64);
@@ -1075,9 +1074,6 @@ static int transform_pipelined(const NttPrime *primes, u32 L, u64 *data, u64 npo
         if (inverse)
             hipLaunchKernelGGL((ntt_pipe_inv_kernel<A, LOGB, false>), dim3((u32)grid), dim3(threads), lds_bytes, s, bptr, bt,
                                sptr, st, primes, L, lazy ? 1u : 0u, mptr, mp);
-        else if (dma_per_wg > 0 && bt > 0 && LOGB == 12 && (A::kWide || A::kMont))  // LDS-DMA form (launches that have a block pass)
-            PFHE_TRY(launch_pipe_fwd_dma(A::kWide ? kArithPm : A::kMont ? kArithMont : kArithShoup, bptr, bt, sptr, st, primes, L,
-                                         lazy, dma_per_wg, s));
         else
             hipLaunchKernelGGL((ntt_pipe_fwd_kernel<A, LOGB>), dim3((u32)grid), dim3(threads), lds_bytes, s, bptr, bt, sptr, st,
                                primes, L, lazy ? 1u : 0u);
@@ -1121,14 +1117,12 @@ static int transform(const NttPrime *primes, u32 L, u32 log_n, int pm, u64 *data
     {
         const int pt = pipelined_tiles(L, log_n, pm, npolys, inverse, mul != nullptr, tune);
         if (pt >= 1 && pm == kArithMont)
-            return transform_pipelined<MontArith, 12>(primes, L, data, npolys, inverse, lazy, s, pt, tune.pipe_ramp, mul, mul_polys,
-                                                      tune.pipe_dma);
+            return transform_pipelined<MontArith, 12>(primes, L, data, npolys, inverse, lazy, s, pt, tune.pipe_ramp, mul, mul_polys);
         if (pt >= 1)
             return pm == kArithPm
-                       ? transform_pipelined<PmArith, 12>(primes, L, data, npolys, inverse, lazy, s, pt, tune.pipe_ramp, mul, mul_polys,
-                                                          tune.pipe_dma)
+                       ? transform_pipelined<PmArith, 12>(primes, L, data, npolys, inverse, lazy, s, pt, tune.pipe_ramp, mul, mul_polys)
                        : transform_pipelined<ShoupArith, 12>(primes, L, data, npolys, inverse, lazy, s, pt, tune.pipe_ramp, mul,
-                                                             mul_polys, tune.pipe_dma);
+                                                             mul_polys);
     }
     // one launch per pass on the caller's stream
     for (int i = 0; i < passes; ++i)

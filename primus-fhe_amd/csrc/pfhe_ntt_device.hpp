@@ -33,7 +33,6 @@ struct NttTuning {
     bool pipelined = true;         // PFHE_DISABLE_PIPELINED clears it: N = 2^16 runs as tiles + 1 launches of ntt_pipe_kernel on the caller's stream
     int pipe_ramp = 0;             // PFHE_PIPE_RAMP: tile weights of the pipelined form ramp 1..ramp..1 (0 / 1: equal tiles)
     bool persist = true;           // PFHE_DISABLE_PERSIST clears it: N = 2^13 / 2^14 batches run ntt_persist_kernel (resident workgroups that prefetch their next polynomial)
-    int pipe_dma = 0;              // PFHE_PIPE_DMA: (block, chunk) pairs per workgroup of the LDS-DMA form of the forward pipelined kernel (0: the plain form)
     int pipelined_min_mb = 0;      // PFHE_PIPELINED_MIN_MB: smallest batch (MiB of data) that takes the pipelined form (0: built-in default)
     static NttTuning from_env();
 };
@@ -69,11 +68,6 @@ int ntt_polymul_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *da
 // U32NttTable / U32DcrtTable transforms (log_n = log2 of the polynomial length in coefficients)
 int ntt32_transform_dev(const NttPrime *primes, u32 L, u32 log_n, u32 *data, u64 npolys, bool inverse, bool lazy,
                         hipStream_t s, const NttTuning &tune = NttTuning());
-
-// LDS-DMA form of the forward pipelined kernel (pfhe_ntt_dma.hip): one launch over max(blk_total, str_total) (block, chunk)
-// pairs of N = 2^16, `per_wg` pairs per workgroup (bits 16.. of per_wg: experiment modes, see the kernel)
-int launch_pipe_fwd_dma(int arith, u64 *blk_data, u64 blk_total, u64 *str_data, u64 str_total, const NttPrime *primes, u32 L,
-                        bool lazy, int per_wg, hipStream_t s);
 
 int ntt_num_passes(u32 log_n, int arith = 0, const NttTuning &tune = NttTuning());
 void ntt_pass_name(u32 log_n, bool inverse, int index, char *buf, size_t cap, int arith = 0,
