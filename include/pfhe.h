@@ -22,8 +22,9 @@
  *     otherwise; hipMalloc / pfhe_device_malloc memory always is).
  *   - handles are immutable after creation and may be shared between host threads
  *     (NttTable: Send + Sync, primus_ntt/src/ntt/mod.rs:16); an external-product plan owns
- *     scratch and is NOT concurrently usable (it mirrors `&mut DcrtGlevContext`,
- *     primus_lattice/src/context/glev.rs:4-10).
+ *     scratch and has one holder at a time (it mirrors `&mut DcrtGlevContext`,
+ *     primus_lattice/src/context/glev.rs:4-10): a call from a second thread while one is inside
+ *     is refused with PFHE_ERR_BAD_ARGUMENT, not raced.
  *   - there is NO CPU fallback: without a HIP device create() fails with PFHE_ERR_NO_DEVICE.
  */
 #ifndef PFHE_H
@@ -77,8 +78,15 @@ int pfhe_stream_synchronize(int device, void *stream);
  * nothing and any number of threads may call through one handle concurrently (NttTable: Send + Sync).
  * pfhe_debug_alloc_count: device / pinned allocation and free calls the library has made since it was loaded (a
  * steady-state loop must not move it).  pfhe_staging_release: frees the idle contexts of `device` (-1: all devices),
- * returns their number. */
+ * returns their number (at most PFHE_STAGE_IDLE_MAX, default 4, are kept per device anyway).
+ * pfhe_debug_stage_path_count(which): host-pointer calls that took path `which` since the library was loaded —
+ * 0 kernels on memory the CALLER pinned, 1 kernels on the pool's own pinned buffer, 2 copy engines on caller-pinned
+ * memory, 3 the runtime's pageable copies, 4 long pageable slices with the copy back on the context's helper thread.
+ * Streams: since round 4 the host-pointer entry points run on PRIVATE non-blocking streams of the borrowed context, not on
+ * the legacy null stream: they are ordered with respect to nothing the caller has queued elsewhere (they block until
+ * their own work is done, which is all `&mut [T]` semantics need). */
 uint64_t pfhe_debug_alloc_count(void);
+uint64_t pfhe_debug_stage_path_count(int which);
 int pfhe_staging_release(int device);
 /* Synthetic data: word i of the buffer = floor(splitmix64(seed, i) * q / 2^64), i.e. uniform in
  * [0,q) (per-modulus uniform sampling as primus_distr/src/common.rs:244-263).  Modulus-major RNS
@@ -381,12 +389,17 @@ typedef struct pfhe_extprod_plan pfhe_extprod_plan;
  * &mut DcrtGlevContext) — glwe/crt.rs:200-212, context/glev.rs:4-68.  The plan borrows `table`
  * (which must outlive it) and owns device scratch for `chunk` ciphertexts (0 = default: about 1 GiB of digit polynomials
  * per buffer, at least 64 and at most 65536 ciphertexts):
- * one buffer of chunk*(k+1)*ell*L*N words (+ chunk*(k+1)*ell*N int32).  Like `&mut DcrtGlevContext` it must not be used concurrently —
- * and it is bound to ONE stream at a time: calls on two different streams share the digit buffers with no cross-stream
- * dependency, so let the first stream finish (or record / wait an event) before using the plan on another. */
+ * one buffer of chunk*(k+1)*ell*L*N words (+ chunk*(k+1)*ell*N balanced digits: int32 for log_basis <= 31, else int64).
+ * Like `&mut DcrtGlevContext` (context/glev.rs:4-10) the plan has ONE holder at a time, and that is enforced: every
+ * pfhe_extprod_* call takes the plan for its duration, and a call from a second thread meanwhile returns
+ * PFHE_ERR_BAD_ARGUMENT ("plan in use") instead of racing on the digit buffers (pfhe_extprod_plan_in_use reports the
+ * flag; one plan per thread).  It is also bound to ONE stream at a time: device-pointer calls return when their kernels
+ * are queued, so calls on two different streams would share the digit buffers with no cross-stream dependency — let the
+ * first stream finish (or record / wait an event) before using the plan on another. */
 int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *base, const pfhe_basis *basis,
                              size_t glwe_dimension, size_t chunk, pfhe_extprod_plan **out);
 void pfhe_extprod_plan_destroy(pfhe_extprod_plan *plan);
+int pfhe_extprod_plan_in_use(const pfhe_extprod_plan *plan);  /* 1 while some thread is inside a pfhe_extprod_* call on it */
 size_t pfhe_extprod_plan_scratch_bytes(const pfhe_extprod_plan *plan);
 /* CrtGlwe::mul_dcrt_ggsw_to — glwe/crt.rs:200-227.  crt_glwe: batch x (k+1) CRT polynomials
  * |a1|..|ak|b|; dcrt_ggsw: ONE GGSW shared by the batch or batch GGSWs, each

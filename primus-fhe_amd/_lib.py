@@ -60,6 +60,7 @@ def _declare(lib: C.CDLL) -> None:
     sig("pfhe_memset_dev", ci, ci, vp, ci, sz, vp)
     sig("pfhe_stream_synchronize", ci, ci, vp)
     sig("pfhe_debug_alloc_count", u64)
+    sig("pfhe_debug_stage_path_count", u64, ci)
     sig("pfhe_staging_release", ci, ci)
     sig("pfhe_fill_uniform_dev", ci, ci, vp, sz, u64p, sz, sz, u64, vp)
 
@@ -144,6 +145,7 @@ def _declare(lib: C.CDLL) -> None:
     sig("pfhe_extprod_plan_create", ci, vp, vp, vp, sz, sz, C.POINTER(vp))
     sig("pfhe_extprod_plan_destroy", None, vp)
     sig("pfhe_extprod_plan_scratch_bytes", sz, vp)
+    sig("pfhe_extprod_plan_in_use", ci, vp)
     sig("pfhe_extprod_mul_dcrt_ggsw_to", ci, vp, vp, sz, vp, sz, vp, sz, ci)
     sig("pfhe_extprod_mul_dcrt_ggsw_to_dev", ci, vp, vp, sz, vp, sz, vp, sz, ci, vp)
     sig("pfhe_extprod_profile_dev", ci, vp, vp, sz, vp, sz, vp, sz, C.POINTER(C.c_double), C.POINTER(sz), vp)

@@ -6,7 +6,9 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
@@ -245,30 +247,9 @@ int transform_dev(const TableSet &t, u64 *data, size_t len, bool inverse, bool l
 // memory the CALLER pinned is cut into pieces of whole units and pipelined over the context's two streams: one carries the
 // copies in, the other waits for each piece, transforms it and copies it back — the copy back of piece i overlaps the
 // copy in of piece i + 1 (the link is full duplex); pageable copies block the calling thread and go as one piece.
-size_t stage_chunk_bytes() {
-    static const size_t v = [] {
-        const char *e = std::getenv("PFHE_STAGE_CHUNK");
-        const unsigned long long x = e && *e ? std::strtoull(e, nullptr, 10) : 0ull;
-        return x ? (size_t)x : (size_t)8 << 20;
-    }();
-    return v;
-}
-
-size_t stage_bounce_max() {
-    static const size_t v = [] {
-        const char *e = std::getenv("PFHE_STAGE_BOUNCE_MAX");
-        return e && *e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)1 << 20;
-    }();
-    return v;
-}
-
-bool stage_zero_copy() {
-    static const bool v = [] {
-        const char *e = std::getenv("PFHE_STAGE_ZERO_COPY");
-        return !(e && *e == '0');
-    }();
-    return v;
-}
+size_t stage_chunk_bytes() { return stage_knobs().chunk_bytes; }
+size_t stage_bounce_max() { return stage_knobs().bounce_max; }
+bool stage_zero_copy() { return stage_knobs().zero_copy; }
 
 int transform_host(const TableSet &t, u64 *host, size_t len, bool inverse, bool lazy) {
     if (!host && len) return PFHE_ERR_BAD_ARGUMENT;
@@ -290,6 +271,7 @@ int transform_host(const TableSet &t, u64 *host, size_t len, bool inverse, bool 
     // (tools/perf_host_slice.py); PFHE_STAGE_ZERO_COPY=0 keeps the copy engines.
     if (stage_zero_copy() && len * sizeof(u64) <= stage_bounce_max() && aligned16(host)) {
         u64 *mapped = static_cast<u64 *>(st.map(host, len * sizeof(u64)));
+        const bool caller_mapped = mapped != nullptr;
         void *bounce = nullptr;
         if (!mapped) {
             void *bdev = nullptr;
@@ -304,6 +286,7 @@ int transform_host(const TableSet &t, u64 *host, size_t len, bool inverse, bool 
                                                      st.stream(), t.tune);
             if (rc != PFHE_ERR_UNSUPPORTED) {
                 st.touch();
+                stage_path_note(caller_mapped ? kPathMappedCaller : kPathMappedBounce);
                 PFHE_TRY(rc);
                 PFHE_TRY(st.finish());
                 if (bounce) std::memcpy(host, bounce, len * sizeof(u64));
@@ -313,54 +296,62 @@ int transform_host(const TableSet &t, u64 *host, size_t len, bool inverse, bool 
     }
     const bool pinned = st.pin(host, len * sizeof(u64));
     // Long PAGEABLE slices: a pageable copy blocks the thread that issues it, so one thread alone cannot use both
-    // directions of the link.  A helper thread copies back while this one copies in: the slice is cut into up to eight
-    // pieces of at least 6 MiB; this thread, piece by piece, copies in and launches the transform on the context's first
-    // stream and records an event; the helper waits for each event and copies that piece back on the second stream.
-    // 16 RNS polynomials of 2^16: 0.95 -> 0.79 ms, 64: 3.67 -> 2.54 ms (tools/perf_host_slice.py).  PFHE_STAGE_THREADS=0:
-    // one thread.
-    static const bool helper_thread = [] {
-        const char *e = std::getenv("PFHE_STAGE_THREADS");
-        return !(e && *e == '0');
-    }();
-    if (!pinned && helper_thread && units >= 2 && len * sizeof(u64) >= ((size_t)8 << 20)) {
-        static const size_t max_pieces = [] {
-            const char *e = std::getenv("PFHE_STAGE_PIECES");
-            const unsigned long long x = e && *e ? std::strtoull(e, nullptr, 10) : 0ull;
-            return x >= 2 && x <= 64 ? (size_t)x : (size_t)8;
-        }();
+    // directions of the link.  The context's HELPER THREAD (parked between calls, pfhe_staging.hpp) copies back while this
+    // one copies in: the slice is cut into up to eight pieces of at least 6 MiB; this thread, piece by piece, copies in and
+    // launches the transform on the context's first stream and records an event; the helper waits for each event and copies
+    // that piece back on the second stream.  16 RNS polynomials of 2^16: 0.95 -> 0.79 ms, 64: 3.67 -> 2.54 ms
+    // (tools/perf_host_slice.py).  PFHE_STAGE_THREADS=0: one thread.
+    // Two rules keep the two threads apart.  (1) The helper sleeps on a condition variable until a piece is ready — no
+    // spinning beside the copying thread.  (2) Adjacent pieces share the page that holds their common boundary (slices are
+    // 8-byte aligned, not page aligned), and the runtime pins the caller's pages for the duration of a pageable copy: the
+    // helper copies piece k back only once this thread has FINISHED copying piece k + 1 in, so the two threads never have
+    // a page in common in flight (the withdrawn registration of round 4 — r04_experiments.txt item 6 — is the reason to be
+    // strict about who maps the caller's pages when).
+    const StageKnobs &K = stage_knobs();
+    if (!pinned && K.helper_thread && units >= 2 && len * sizeof(u64) >= ((size_t)8 << 20)) {
         // pieces of at least 6 MiB, at most eight (24 MiB: 2 / 3 / 4 / 6 / 8 pieces 861 / 829 / 808 / 855 / 844 us;
         // 96 MiB: 3.01 / 2.77 / 2.74 / 2.54 / 2.54 ms; one thread: 0.95 / 3.67 ms)
-        const size_t pieces = std::max<size_t>(2, std::min<size_t>({max_pieces, (size_t)units, len * sizeof(u64) / ((size_t)6 << 20)}));
+        const size_t pieces = std::max<size_t>(2, std::min<size_t>({K.pieces, (size_t)units, len * sizeof(u64) / ((size_t)6 << 20)}));
         std::vector<hipEvent_t> done(pieces);
         for (hipEvent_t &e : done) PFHE_TRY(st.take_event(&e));
         std::vector<size_t> off(pieces + 1);
         for (size_t i = 0; i <= pieces; ++i) off[i] = (size_t)(units * i / pieces) * unit;
-        std::atomic<int> issued{0}, helper_rc{PFHE_OK};
-        std::atomic<bool> abort_flag{false};
+        // shared with the helper's task; lives until helper_wait() or the HostStage destructor (which runs on_abandon and
+        // waits for the task) — `st` is declared after nothing the task uses, so every exit path is covered
+        struct Shared {
+            std::mutex mu;
+            std::condition_variable cv;
+            size_t copied_in = 0;  // pieces whose copy in has returned and whose transform is launched (event recorded)
+            bool all_in = false, abort = false;
+        } sh;
         const hipStream_t s_in = st.stream(), s_out = st.stream2();
-        const int device = t.device;
         st.touch();
-        std::thread helper([&]() {
-            if (hipSetDevice(device) != hipSuccess) {
-                helper_rc = PFHE_ERR_HIP;
-                return;
-            }
-            for (size_t i = 0; i < pieces; ++i) {
-                while (issued.load(std::memory_order_acquire) <= (int)i) {  // piece i not launched yet
-                    if (abort_flag.load(std::memory_order_acquire)) return;
-                    std::this_thread::yield();
+        stage_path_note(kPathHelper);
+        PFHE_TRY(st.helper_start(
+            [&]() -> int {
+                for (size_t i = 0; i < pieces; ++i) {
+                    {
+                        std::unique_lock<std::mutex> lk(sh.mu);
+                        // piece i is launched AND this thread's neighbour piece i + 1 is no longer being copied in
+                        sh.cv.wait(lk, [&] { return sh.abort || sh.all_in || sh.copied_in >= i + 2; });
+                        if (sh.abort) return PFHE_OK;
+                    }
+                    hipError_t e = hipEventSynchronize(done[i]);
+                    if (e == hipSuccess)
+                        e = hipMemcpyAsync(host + off[i], d + off[i], (off[i + 1] - off[i]) * sizeof(u64), hipMemcpyDeviceToHost, s_out);
+                    if (e == hipSuccess) e = hipStreamSynchronize(s_out);
+                    if (e != hipSuccess) {
+                        (void)hipGetLastError();
+                        return PFHE_ERR_HIP;
+                    }
                 }
-                hipError_t e = hipEventSynchronize(done[i]);
-                if (e == hipSuccess)
-                    e = hipMemcpyAsync(host + off[i], d + off[i], (off[i + 1] - off[i]) * sizeof(u64), hipMemcpyDeviceToHost, s_out);
-                if (e == hipSuccess) e = hipStreamSynchronize(s_out);
-                if (e != hipSuccess) {
-                    (void)hipGetLastError();
-                    helper_rc = PFHE_ERR_HIP;
-                    return;
-                }
-            }
-        });
+                return PFHE_OK;
+            },
+            [&]() {
+                std::lock_guard<std::mutex> lk(sh.mu);
+                sh.abort = true;
+                sh.cv.notify_all();
+            }));
         int rc = PFHE_OK;
         for (size_t i = 0; i < pieces && rc == PFHE_OK; ++i) {
             const size_t words = off[i + 1] - off[i];
@@ -370,12 +361,21 @@ int transform_host(const TableSet &t, u64 *host, size_t len, bool inverse, bool 
             }
             rc = transform_dev(t, d + off[i], words, inverse, lazy, s_in);
             if (rc == PFHE_OK && hipEventRecord(done[i], s_in) != hipSuccess) rc = hip_fail(hipGetLastError(), "hipEventRecord", __FILE__, __LINE__);
-            if (rc == PFHE_OK) issued.store((int)i + 1, std::memory_order_release);
+            if (rc == PFHE_OK) {
+                std::lock_guard<std::mutex> lk(sh.mu);
+                sh.copied_in = i + 1;
+                sh.all_in = i + 1 == pieces;
+                sh.cv.notify_all();
+            }
         }
-        if (rc != PFHE_OK) abort_flag.store(true, std::memory_order_release);
-        helper.join();
+        if (rc != PFHE_OK) {
+            std::lock_guard<std::mutex> lk(sh.mu);
+            sh.abort = true;
+            sh.cv.notify_all();
+        }
+        const int helper_rc = st.helper_wait();
         PFHE_TRY(rc);
-        PFHE_TRY(helper_rc.load());
+        PFHE_TRY(helper_rc);
         return st.finish();
     }
     // otherwise pageable copies go as one piece (they block the calling thread: nothing to pipeline)
@@ -530,6 +530,7 @@ int pfhe_device_count(int *count) {
 }
 
 uint64_t pfhe_debug_alloc_count(void) { return alloc_event_count(); }
+uint64_t pfhe_debug_stage_path_count(int which) { return stage_path_count(which); }
 int pfhe_staging_release(int device) { return staging_release(device); }
 
 int pfhe_device_malloc(int device, size_t bytes, void **out) {

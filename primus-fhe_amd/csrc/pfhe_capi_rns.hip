@@ -1,5 +1,7 @@
 // pfhe_capi_rns.hip — extern "C" boundary for RNSBase, BigUintApproxSignedBasis and the RNS gadget
 // external product (include/pfhe.h, second half).
+#include <atomic>
+#include <cstdint>
 #include <cstdlib>
 #include <memory>
 #include <new>
@@ -18,6 +20,14 @@ struct pfhe_basis {
 };
 struct pfhe_extprod_plan {
     const TableSet *table = nullptr;  // borrowed from the pfhe_dcrt (must outlive the plan)
+    // Exclusivity.  The plan owns the product's scratch (digit buffers), like the reference's `&mut DcrtGlevContext`
+    // (primus_lattice/src/context/glev.rs:4-10), which the borrow checker lets ONE caller hold at a time.  Here the holder
+    // is a thread: every entry point that touches the scratch takes the plan for the duration of the call (PlanLease), and
+    // a second thread that arrives meanwhile is refused with PFHE_ERR_BAD_ARGUMENT ("plan in use") instead of racing on the
+    // digit buffer.  owner = a per-thread token (0: free); depth counts nested entries of the owning thread (the host-pointer
+    // and profiling entry points call the device ones).
+    std::atomic<std::uintptr_t> owner{0};
+    int depth = 0;
     RnsDev rns{};
     BasisDev basis{};
     u32 k = 1;
@@ -63,6 +73,39 @@ int plan_check(const pfhe_extprod_plan *p) {
     if (!p || !p->table) return PFHE_ERR_BAD_ARGUMENT;
     return PFHE_OK;
 }
+
+// the calling thread's hold on a plan's scratch for one entry point (see pfhe_extprod_plan::owner)
+class PlanLease {
+  public:
+    explicit PlanLease(pfhe_extprod_plan *p) : p_(p) {
+        static thread_local char token;
+        const std::uintptr_t me = reinterpret_cast<std::uintptr_t>(&token);
+        std::uintptr_t free_ = 0;
+        if (p_->owner.load(std::memory_order_relaxed) == me) {
+            ++p_->depth;  // nested entry of the thread that holds the plan
+            held_ = true;
+        } else if (p_->owner.compare_exchange_strong(free_, me, std::memory_order_acquire)) {
+            p_->depth = 1;
+            held_ = true;
+        }
+    }
+    ~PlanLease() {
+        if (held_ && --p_->depth == 0) p_->owner.store(0, std::memory_order_release);
+    }
+    PlanLease(const PlanLease &) = delete;
+    PlanLease &operator=(const PlanLease &) = delete;
+    bool held() const { return held_; }
+
+  private:
+    pfhe_extprod_plan *p_;
+    bool held_ = false;
+};
+#define PFHE_PLAN_LEASE(plan)                                                                                       \
+    PlanLease lease_(plan);                                                                                          \
+    if (!lease_.held()) {                                                                                            \
+        set_last_error("external-product plan in use by another thread (one plan per thread, like &mut DcrtGlevContext)"); \
+        return PFHE_ERR_BAD_ARGUMENT;                                                                                \
+    }
 
 // one row of the product: acc[e] += glev[e or shared] (x) crt_poly[e]   (glwe/dcrt.rs:178-255)
 // rows == k+1 without `accumulate` gives CrtGlwe::mul_dcrt_ggsw_to (glwe/crt.rs:200-227).
@@ -613,6 +656,9 @@ int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *rns, const 
 }
 
 void pfhe_extprod_plan_destroy(pfhe_extprod_plan *p) { delete p; }
+int pfhe_extprod_plan_in_use(const pfhe_extprod_plan *p) {
+    return p && p->owner.load(std::memory_order_acquire) != 0 ? 1 : 0;
+}
 size_t pfhe_extprod_plan_scratch_bytes(const pfhe_extprod_plan *p) {
     if (!p) return 0;
     return (p->pipeline ? 2 : 1) * p->digits_words * 8 + (p->sdigits ? p->chunk * (p->k + 1) * p->basis.ell * p->table->n * p->sdigit_bytes : 0);
@@ -623,6 +669,7 @@ int pfhe_extprod_mul_dcrt_ggsw_to_dev(pfhe_extprod_plan *plan, const uint64_t *c
                                       size_t len_result, int into_coeff_form, void *stream) {
     PFHE_GUARD_BEGIN
     PFHE_TRY(plan_check(plan));
+    PFHE_PLAN_LEASE(plan);
     const TableSet &t = *plan->table;
     const size_t W = (size_t)t.L * t.n, glwe = (plan->k + 1) * W;
     const size_t ggsw = (size_t)(plan->k + 1) * plan->basis.ell * glwe;
@@ -659,6 +706,7 @@ int pfhe_extprod_profile_dev(pfhe_extprod_plan *plan, const uint64_t *crt_glwe_d
                              double *ms_out, size_t *launches_out, void *stream) {
     PFHE_GUARD_BEGIN
     PFHE_TRY(plan_check(plan));
+    PFHE_PLAN_LEASE(plan);
     if (!ms_out || !launches_out) return PFHE_ERR_BAD_ARGUMENT;
     if (plan->pipeline) {
         set_last_error("profiling needs a plan without the two-stream pipeline");
@@ -692,6 +740,7 @@ int pfhe_extprod_add_dcrt_glev_mul_crt_poly_assign_dev(pfhe_extprod_plan *plan, 
                                                        const uint64_t *crt_poly_dev, size_t len_poly, void *stream) {
     PFHE_GUARD_BEGIN
     PFHE_TRY(plan_check(plan));
+    PFHE_PLAN_LEASE(plan);
     const TableSet &t = *plan->table;
     const size_t W = (size_t)t.L * t.n, glwe = (plan->k + 1) * W, glev = plan->basis.ell * glwe;
     if (len_poly % W != 0) return PFHE_ERR_BAD_LENGTH;
@@ -717,6 +766,7 @@ int pfhe_extprod_glev_mul_crt_poly_to_dev(pfhe_extprod_plan *plan, const uint64_
                                           size_t len_result, void *stream) {
     PFHE_GUARD_BEGIN
     PFHE_TRY(plan_check(plan));
+    PFHE_PLAN_LEASE(plan);
     const TableSet &t = *plan->table;
     const size_t W = (size_t)t.L * t.n, glwe = (plan->k + 1) * W, glev = plan->basis.ell * glwe;
     if (len_poly % W != 0) return PFHE_ERR_BAD_LENGTH;
@@ -743,6 +793,7 @@ static int glev_big_uint_common(pfhe_extprod_plan *plan, uint64_t *out_dev, size
                                 size_t len_glev, const uint64_t *big_uint_poly_dev, size_t len_poly, bool accumulate,
                                 void *stream) {
     PFHE_TRY(plan_check(plan));
+    PFHE_PLAN_LEASE(plan);
     const TableSet &t = *plan->table;
     const size_t W = (size_t)t.L * t.n, glwe = (plan->k + 1) * W, glev = plan->basis.ell * glwe;
     const size_t in_words = (size_t)plan->rns.value_len * t.n;
@@ -786,6 +837,7 @@ int pfhe_extprod_mul_dcrt_ggsw_to(pfhe_extprod_plan *plan, const uint64_t *crt_g
                                   int into_coeff_form) {
     PFHE_GUARD_BEGIN
     PFHE_TRY(plan_check(plan));
+    PFHE_PLAN_LEASE(plan);
     if ((!crt_glwe || !dcrt_ggsw || !result) && len_glwe) return PFHE_ERR_BAD_ARGUMENT;
     DeviceGuard g(plan->table->device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;

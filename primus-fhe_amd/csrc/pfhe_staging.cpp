@@ -2,10 +2,14 @@
 #include "pfhe_staging.hpp"
 
 #include <atomic>
+#include <cerrno>
+#include <condition_variable>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 namespace pfhe {
@@ -13,16 +17,49 @@ namespace pfhe {
 namespace {
 std::atomic<std::uint64_t> g_alloc_events{0};
 
+// a non-negative decimal integer, the whole value; anything else (empty, signs, trailing text, overflow) -> dflt
 size_t env_bytes(const char *name, size_t dflt) {
     const char *v = std::getenv(name);
-    if (!v || !*v) return dflt;
+    if (!v || !*v || *v == '-' || *v == '+') return dflt;
     char *end = nullptr;
+    errno = 0;
     const unsigned long long x = std::strtoull(v, &end, 10);
-    return end == v ? dflt : (size_t)x;
+    return (end == v || *end != '\0' || errno == ERANGE) ? dflt : (size_t)x;
 }
 constexpr size_t kAlign = 256;
 size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+std::atomic<std::uint64_t> g_paths[kPathCount];
 }  // namespace
+
+const StageKnobs &stage_knobs() {
+    static const StageKnobs k = [] {
+        StageKnobs v;
+        // slices of at least register_min bytes are looked up: memory the caller pinned is used as it is
+        // (PFHE_STAGE_REGISTER=0: never)
+        v.use_register = env_bytes("PFHE_STAGE_REGISTER", 1) != 0;
+        v.register_min = env_bytes("PFHE_STAGE_REGISTER_MIN", (size_t)128 << 10);
+        // transfers up to bounce_max go through the pinned bounce buffer (a CPU copy + a true asynchronous DMA, or kernels
+        // on that buffer); larger ones are handed to the runtime as they are (it pins the caller's pages in pieces)
+        v.bounce_max = env_bytes("PFHE_STAGE_BOUNCE_MAX", (size_t)1 << 20);
+        v.cache_max = env_bytes("PFHE_STAGE_CACHE_MAX", (size_t)2 << 30);
+        const size_t chunk = env_bytes("PFHE_STAGE_CHUNK", 0);
+        v.chunk_bytes = chunk ? chunk : (size_t)8 << 20;
+        v.zero_copy = env_bytes("PFHE_STAGE_ZERO_COPY", 1) != 0;
+        v.helper_thread = env_bytes("PFHE_STAGE_THREADS", 1) != 0;
+        const size_t pieces = env_bytes("PFHE_STAGE_PIECES", 0);
+        v.pieces = pieces >= 2 && pieces <= 64 ? pieces : 8;
+        // idle contexts kept per device (each holds its arenas, up to cache_max): a burst of T concurrent callers leaves
+        // at most this many behind
+        v.idle_max = env_bytes("PFHE_STAGE_IDLE_MAX", 4);
+        return v;
+    }();
+    return k;
+}
+
+void stage_path_note(StagePath which) { g_paths[which].fetch_add(1, std::memory_order_relaxed); }
+std::uint64_t stage_path_count(int which) {
+    return which >= 0 && which < kPathCount ? g_paths[which].load(std::memory_order_relaxed) : 0;
+}
 
 hipError_t counted_malloc(void **p, size_t bytes) {
     g_alloc_events.fetch_add(1, std::memory_order_relaxed);
@@ -52,15 +89,17 @@ hipError_t counted_free_async(void *p, hipStream_t s) {
 std::uint64_t alloc_event_count() { return g_alloc_events.load(std::memory_order_relaxed); }
 
 // A bump arena over a few blocks.  A call that outgrows the cached block gets a further block (earlier regions stay
-// valid); when the context is returned the blocks are merged into ONE of the summed size, so the next call of the same
-// shape allocates nothing.  Arenas above `cache_max` are not kept.
+// valid); when the context is returned the blocks are merged into ONE block of the bytes the call actually asked for
+// (never the sum of the cached block and the overflow blocks), so the next call of the same shape allocates nothing.
+// Arenas above `cache_max` are not kept.
 struct Arena {
     struct Block {
         void *p;
         size_t cap;
     };
     std::vector<Block> blocks;
-    size_t used = 0;  // in blocks.back()
+    size_t used = 0;    // in blocks.back()
+    size_t asked = 0;   // bytes handed out during this call (rounded), over all blocks
     bool pinned = false;
 
     hipError_t raw_alloc(void **p, size_t bytes) const { return pinned ? counted_host_malloc(p, bytes) : counted_malloc(p, bytes); }
@@ -72,6 +111,7 @@ struct Arena {
     }
     hipError_t get(size_t bytes, void **out) {
         bytes = round_up(bytes ? bytes : 1, kAlign);
+        asked += bytes;
         if (!blocks.empty() && used + bytes <= blocks.back().cap) {
             *out = static_cast<char *>(blocks.back().p) + used;
             used += bytes;
@@ -85,11 +125,13 @@ struct Arena {
         *out = p;
         return hipSuccess;
     }
-    // end of a call: one block of the summed size (or nothing when that exceeds cache_max)
+    // end of a call: one block of max(cached block, bytes this call asked for) (or nothing when that exceeds cache_max)
     void recycle(size_t cache_max) {
         used = 0;
+        const size_t need = asked;
+        asked = 0;
         if (blocks.size() <= 1 && total() <= cache_max) return;
-        const size_t want = total();
+        const size_t want = std::max(blocks.empty() ? (size_t)0 : blocks.front().cap, need);
         for (const Block &b : blocks) raw_free(b.p);
         blocks.clear();
         if (want > cache_max) return;
@@ -100,7 +142,7 @@ struct Arena {
     void release() {
         for (const Block &b : blocks) raw_free(b.p);
         blocks.clear();
-        used = 0;
+        used = asked = 0;
     }
 };
 
@@ -122,24 +164,52 @@ struct StageCtx {
     std::vector<Range> registered;  // ranges of this call that lie in memory the caller pinned
     std::vector<hipEvent_t> events;  // pooled, timing disabled
     size_t events_used = 0;
+
+    // helper thread: parked on `cv` between tasks
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<int()> task;
+    bool has_task = false, task_done = false, quit = false;
+    int task_rc = PFHE_OK;
+
+    void worker_loop() {
+        (void)hipSetDevice(device);
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return has_task || quit; });
+            if (quit) return;
+            std::function<int()> fn = std::move(task);
+            has_task = false;
+            lk.unlock();
+            int rc;
+            try {
+                rc = fn();
+            } catch (...) {
+                rc = PFHE_ERR_HIP;
+            }
+            fn = nullptr;
+            lk.lock();
+            task_rc = rc;
+            task_done = true;
+            cv.notify_all();
+        }
+    }
+    void stop_worker() {
+        if (!worker.joinable()) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+        }
+        cv.notify_all();
+        worker.join();
+    }
 };
 
 namespace {
 struct Pool {
     std::mutex mu;
     std::vector<std::vector<StageCtx *>> idle;  // per device
-    size_t bounce_max, cache_max, register_min;
-    bool use_register;
-    Pool() {
-        // slices of at least register_min bytes are looked up: memory the caller pinned is used as it is
-        // (PFHE_STAGE_REGISTER=0: never)
-        use_register = env_bytes("PFHE_STAGE_REGISTER", 1) != 0;
-        register_min = env_bytes("PFHE_STAGE_REGISTER_MIN", (size_t)128 << 10);
-        // transfers up to bounce_max go through the pinned bounce buffer (a CPU copy + a true asynchronous DMA);
-        // larger ones are handed to the runtime as they are (it pins the caller's pages in pieces)
-        bounce_max = env_bytes("PFHE_STAGE_BOUNCE_MAX", (size_t)1 << 20);
-        cache_max = env_bytes("PFHE_STAGE_CACHE_MAX", (size_t)2 << 30);
-    }
 };
 // never destroyed: at process exit the HIP runtime may already be gone
 Pool &pool() {
@@ -181,14 +251,27 @@ HostStage::HostStage(int device) {
 // mapped range) and got rare wrong words and host-heap corruption under a debugging allocator
 // (profiles/r04_experiments.txt, item 6) — pageable slices go through the pool's own pinned buffer instead.
 bool HostStage::pin(const void *host, size_t bytes, bool any_size) {
-    const Pool &P = pool();
+    const StageKnobs &K = stage_knobs();
     char *h = static_cast<char *>(const_cast<void *>(host));
     for (const StageCtx::Range &r : ctx_->registered)
         if (h >= r.p && h + bytes <= r.p + r.bytes) return true;  // pieces of a pinned slice; in-place downloads
-    if (!P.use_register || (!any_size && bytes < P.register_min)) return false;
-    hipPointerAttribute_t at{}, last{};
-    if (hipPointerGetAttributes(&at, h) != hipSuccess || at.type != hipMemoryTypeHost ||
-        hipPointerGetAttributes(&last, h + bytes - 1) != hipSuccess || last.type != hipMemoryTypeHost) {
+    if (bytes == 0 || !K.use_register || (!any_size && bytes < K.register_min)) return false;
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, h) != hipSuccess || at.type != hipMemoryTypeHost) {
+        (void)hipGetLastError();
+        return false;
+    }
+    // The whole range must lie inside ONE pinned allocation / registration: pinned first and last bytes can belong to two
+    // different ones with pageable pages in between (a slice spanning two registered buffers, a partly registered array),
+    // and the mapped range is handed to kernels and copy engines as a whole.  The runtime reports start and size of the
+    // range that contains an address (HIP_POINTER_ATTRIBUTE_RANGE_START_ADDR / _RANGE_SIZE: the registration's own for
+    // hipHostRegister memory, where hipMemGetAddressRange returns a null base); when it cannot, or the slice sticks out of
+    // it, the slice is treated as pageable.
+    hipDeviceptr_t base = nullptr;
+    size_t extent = 0;
+    if (hipPointerGetAttribute(&base, HIP_POINTER_ATTRIBUTE_RANGE_START_ADDR, h) != hipSuccess ||
+        hipPointerGetAttribute(&extent, HIP_POINTER_ATTRIBUTE_RANGE_SIZE, h) != hipSuccess || base == nullptr ||
+        h < static_cast<char *>(base) || h + bytes > static_cast<char *>(base) + extent) {
         (void)hipGetLastError();
         return false;
     }
@@ -241,8 +324,55 @@ int HostStage::order(hipStream_t signaller, hipStream_t waiter) {
     return PFHE_OK;
 }
 
+static void destroy_ctx(StageCtx *c) {
+    c->stop_worker();
+    DeviceGuard g(c->device);
+    c->dev.release();
+    c->pin.release();
+    for (hipStream_t s : c->s)
+        if (s) (void)hipStreamDestroy(s);
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    delete c;
+}
+
+int HostStage::helper_start(std::function<int()> task, std::function<void()> on_abandon) {
+    if (helper_busy_) return PFHE_ERR_BAD_ARGUMENT;
+    StageCtx &c = *ctx_;
+    if (!c.worker.joinable()) {
+        try {
+            c.worker = std::thread([ctx = ctx_] { ctx->worker_loop(); });
+        } catch (...) {
+            return PFHE_ERR_HIP;
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        c.task = std::move(task);
+        c.has_task = true;
+        c.task_done = false;
+    }
+    on_abandon_ = std::move(on_abandon);
+    helper_busy_ = true;
+    c.cv.notify_all();
+    return PFHE_OK;
+}
+
+int HostStage::helper_wait() {
+    if (!helper_busy_) return PFHE_OK;
+    StageCtx &c = *ctx_;
+    std::unique_lock<std::mutex> lk(c.mu);
+    c.cv.wait(lk, [&] { return c.task_done; });
+    helper_busy_ = false;
+    on_abandon_ = nullptr;
+    return c.task_rc;
+}
+
 HostStage::~HostStage() {
     if (!ctx_) return;
+    if (helper_busy_) {  // an error path left while the helper's task may still reference the caller's frame
+        if (on_abandon_) on_abandon_();
+        (void)helper_wait();
+    }
     if (dirty_) {
         for (hipStream_t s : ctx_->s) (void)hipStreamSynchronize(s);
         (void)hipGetLastError();
@@ -250,12 +380,20 @@ HostStage::~HostStage() {
     unpin_all();
     ctx_->events_used = 0;
     ctx_->pending.clear();
+    const StageKnobs &K = stage_knobs();
+    ctx_->dev.recycle(K.cache_max);
+    ctx_->pin.recycle(K.cache_max);
     Pool &P = pool();
-    ctx_->dev.recycle(P.cache_max);
-    ctx_->pin.recycle(P.cache_max);
-    std::lock_guard<std::mutex> lk(P.mu);
-    if ((size_t)ctx_->device >= P.idle.size()) P.idle.resize(ctx_->device + 1);
-    P.idle[ctx_->device].push_back(ctx_);
+    StageCtx *surplus = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        if ((size_t)ctx_->device >= P.idle.size()) P.idle.resize(ctx_->device + 1);
+        // idle contexts are capped per device: a burst of concurrent callers does not pin its arenas for the life of the
+        // process (PFHE_STAGE_IDLE_MAX, default 4)
+        if (P.idle[ctx_->device].size() < K.idle_max) P.idle[ctx_->device].push_back(ctx_);
+        else surplus = ctx_;
+    }
+    if (surplus) destroy_ctx(surplus);
 }
 
 hipStream_t HostStage::stream() const { return ctx_->s[0]; }
@@ -263,6 +401,9 @@ hipStream_t HostStage::stream2() const { return ctx_->s[1]; }
 
 int HostStage::alloc(size_t bytes, void **dev) {
     *dev = nullptr;
+    // whoever takes arena memory is about to queue work on the context's streams: from here on every exit path — a failed
+    // launch or copy included — synchronises them before the arena is recycled and the context returns to the pool
+    dirty_ = true;
     PFHE_HIP(ctx_->dev.get(bytes, dev));
     return PFHE_OK;
 }
@@ -272,16 +413,18 @@ int HostStage::copy_in(void *dev, const void *host, size_t bytes, hipStream_t s)
     if (!s) s = ctx_->s[0];
     dirty_ = true;
     if (pin(host, bytes)) {
+        stage_path_note(kPathDmaCaller);
         PFHE_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s));
         return PFHE_OK;
     }
-    if (bytes <= pool().bounce_max) {
+    if (bytes <= stage_knobs().bounce_max) {
         void *b = nullptr;
         PFHE_HIP(ctx_->pin.get(bytes, &b));
         std::memcpy(b, host, bytes);
         PFHE_HIP(hipMemcpyAsync(dev, b, bytes, hipMemcpyHostToDevice, s));
         return PFHE_OK;
     }
+    stage_path_note(kPathPageable);
     PFHE_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s));
     return PFHE_OK;
 }
@@ -299,7 +442,7 @@ int HostStage::download(void *host, const void *dev, size_t bytes, hipStream_t s
         PFHE_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s));
         return PFHE_OK;
     }
-    if (bytes <= pool().bounce_max) {
+    if (bytes <= stage_knobs().bounce_max) {
         void *b = nullptr;
         PFHE_HIP(ctx_->pin.get(bytes, &b));
         PFHE_HIP(hipMemcpyAsync(b, dev, bytes, hipMemcpyDeviceToHost, s));
@@ -331,15 +474,7 @@ int staging_release(int device) {
             P.idle[d].clear();
         }
     }
-    for (StageCtx *c : victims) {
-        DeviceGuard g(c->device);
-        c->dev.release();
-        c->pin.release();
-        for (hipStream_t s : c->s)
-            if (s) (void)hipStreamDestroy(s);
-        for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
-        delete c;
-    }
+    for (StageCtx *c : victims) destroy_ctx(c);
     return (int)victims.size();
 }
 

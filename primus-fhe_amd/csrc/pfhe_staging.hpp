@@ -16,7 +16,9 @@
 // platform, and 45 us per 2^16-point transform — was built and withdrawn: rare wrong words and heap corruption
 // (profiles/r04_experiments.txt, item 6).
 #pragma once
+#include <cstddef>
 #include <cstdint>
+#include <functional>
 
 #include "pfhe_common.hpp"
 
@@ -30,6 +32,27 @@ hipError_t counted_host_free(void *p);
 hipError_t counted_malloc_async(void **p, size_t bytes, hipStream_t s);
 hipError_t counted_free_async(void *p, hipStream_t s);
 std::uint64_t alloc_event_count();
+
+// Environment knobs of the staging layer, parsed ONCE by one parser (a malformed value gives the built-in default
+// everywhere): PFHE_STAGE_BOUNCE_MAX, PFHE_STAGE_CACHE_MAX, PFHE_STAGE_REGISTER, PFHE_STAGE_REGISTER_MIN,
+// PFHE_STAGE_CHUNK, PFHE_STAGE_ZERO_COPY, PFHE_STAGE_THREADS, PFHE_STAGE_PIECES, PFHE_STAGE_IDLE_MAX.
+struct StageKnobs {
+    size_t bounce_max, cache_max, register_min, chunk_bytes, pieces, idle_max;
+    bool use_register, zero_copy, helper_thread;
+};
+const StageKnobs &stage_knobs();
+
+// Which way the bytes of host-pointer calls travelled (tests assert the path they mean to exercise):
+enum StagePath : int {
+    kPathMappedCaller = 0,  // kernels read / wrote memory the CALLER pinned (hipHostMalloc, hipHostRegister, torch pinned)
+    kPathMappedBounce = 1,  // kernels read / wrote the pool's own pinned buffer (CPU copies either side)
+    kPathDmaCaller = 2,     // copy engines on memory the caller pinned
+    kPathPageable = 3,      // the runtime's pageable copies
+    kPathHelper = 4,        // long pageable slice, copy back on the context's helper thread
+    kPathCount = 5
+};
+void stage_path_note(StagePath which);
+std::uint64_t stage_path_count(int which);
 
 struct StageCtx;
 
@@ -72,10 +95,21 @@ class HostStage {
     // marks the call as having queued work on the context's streams (kernels on mapped memory)
     void touch() { dirty_ = true; }
 
+    // The context's HELPER THREAD (started on first use, parked on a condition variable between calls, never spawned per
+    // call): helper_start hands it one task; helper_wait blocks until the task has returned and yields its status.  At
+    // most one task per call.  If a call leaves without helper_wait (an error path, an exception), the destructor runs
+    // `on_abandon` (which must make the task return promptly) and waits for the task before the context goes back to the
+    // pool — the task may reference the caller's stack.  A task that throws yields PFHE_ERR_HIP; nothing reaches
+    // std::terminate.
+    int helper_start(std::function<int()> task, std::function<void()> on_abandon);
+    int helper_wait();
+
   private:
     void unpin_all();
     StageCtx *ctx_ = nullptr;
     bool dirty_ = false;
+    bool helper_busy_ = false;
+    std::function<void()> on_abandon_;
 };
 
 // frees the idle contexts of `device` (-1: every device); returns how many were released

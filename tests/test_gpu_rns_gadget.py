@@ -520,3 +520,84 @@ def test_fused_kernel_threshold_switch(pf, orc, min_wgs, log_n, monkeypatch):
     pf.mul_dcrt_ggsw_to(full, ggsw, out, ctx, into_coeff_form=True)
     otable.inverse_transform_slice(exp)
     assert np.array_equal(out[:G], exp)
+
+
+def test_plan_has_one_holder_at_a_time(pf, orc):
+    """`&mut DcrtGlevContext` (primus_lattice/src/context/glev.rs:4-10): the reference's borrow checker lets one caller hold
+    the product's scratch.  Here a second THREAD that calls into a plan while another is inside gets PFHE_ERR_BAD_ARGUMENT
+    ("plan in use") instead of racing on the digit buffers: thread A runs a long host-pointer product, thread B waits until
+    pfhe_extprod_plan_in_use reports the holder and calls — exactly one error, A's result bit-exact, and the plan works
+    for B afterwards (same thread may nest: the host-pointer entry calls the device one)."""
+    import threading
+    log_n, k, batch = 14, 1, 12
+    rng = np.random.default_rng(77)
+    otable, glwe, ggsw, exp = make_case(orc, rng, log_n, k, Q61, 30, None, batch, True)
+    table, base = pf.U64DcrtTable(log_n, Q61), pf.RNSBase(Q61)
+    basis = pf.BigUintApproxSignedBasis(base, 30)
+    ctx = pf.DcrtGlevContext(table, base, basis, k, 2)       # 6 chunks: a long call
+    lib = pf.lib()
+    assert lib.pfhe_extprod_plan_in_use(ctx._h) == 0
+    out_a, out_b = np.empty_like(glwe), np.empty_like(glwe)
+    results = {}
+
+    def a():
+        try:
+            for _ in range(400):                              # back-to-back calls until B has been refused
+                pf.mul_dcrt_ggsw_to(glwe, ggsw, out_a, ctx)
+                if "b" in results:
+                    break
+            results["a"] = "ok"
+        except Exception as e:  # pragma: no cover
+            results["a"] = e
+
+    def b():
+        try:
+            slipped = 0
+            for _attempt in range(50):
+                for _ in range(5_000_000):
+                    if lib.pfhe_extprod_plan_in_use(ctx._h):
+                        break
+                else:  # pragma: no cover
+                    results["b"] = "never saw the holder"
+                    return
+                try:
+                    pf.mul_dcrt_ggsw_to(glwe, ggsw, out_b, ctx)
+                except pf.PfheError as e:
+                    results["b"] = e
+                    results["slipped"] = slipped
+                    return
+                # B arrived in the gap between two of A's calls: a legal, serial use — its result must be right; try again
+                if not np.array_equal(out_b, exp):
+                    results["b"] = "wrong result after a serial use"
+                    return
+                slipped += 1
+            results["b"] = "never refused"
+        except Exception as e:  # pragma: no cover
+            results["b"] = e
+
+    ta, tb = threading.Thread(target=a), threading.Thread(target=b)
+    ta.start(); tb.start(); ta.join(); tb.join()
+    assert results["a"] == "ok", results
+    assert np.array_equal(out_a, exp)                      # the holder's result: bit-exact
+    # exactly one refusal, of the right kind
+    assert isinstance(results["b"], pf.PfheError) and results["b"].kind == "BadArgument", results
+    assert "in use" in str(results["b"])
+    # deterministic half: while this thread is INSIDE a call the flag is up (seen from a watcher), and it is down after
+    seen = []
+    stop = threading.Event()
+
+    def watch():
+        while not stop.is_set():
+            if lib.pfhe_extprod_plan_in_use(ctx._h):
+                seen.append(1)
+                return
+
+    tw = threading.Thread(target=watch)
+    tw.start()
+    for _ in range(20):
+        pf.mul_dcrt_ggsw_to(glwe, ggsw, out_b, ctx)
+        if seen:
+            break
+    stop.set(); tw.join()
+    assert seen and lib.pfhe_extprod_plan_in_use(ctx._h) == 0
+    assert np.array_equal(out_b, exp)

@@ -266,3 +266,145 @@ def test_long_pageable_slice_with_helper_thread_is_exact_and_reports_errors(pf, 
     before = alloc_count(pf)
     x = a.copy(); d.transform_slice(x)
     assert np.array_equal(x, ref) and alloc_count(pf) == before
+
+
+def path_count(pf, which):
+    return int(pf.lib().pfhe_debug_stage_path_count(which))
+
+
+MAPPED_CALLER, MAPPED_BOUNCE, DMA_CALLER, PAGEABLE, HELPER = range(5)
+
+
+def _hip():
+    import torch
+    torch.cuda.init()
+    return torch.cuda.cudart()
+
+
+def _rc(v):
+    return int(getattr(v, "value", v))
+
+
+def test_every_staging_path_is_the_one_meant_and_exact(pf, orc):
+    """pfhe_debug_stage_path_count says which way a host-pointer call's bytes travelled: pageable slice up to the bounce
+    limit -> kernels on the pool's own pinned buffer; the same slice registered by the CALLER -> kernels on the caller's
+    memory; a long caller-pinned slice -> copy engines; a long pageable slice -> the helper-thread form."""
+    rt = _hip()
+    log_n = 16
+    n = 1 << log_n
+    t, o = pf.U64NttTable(log_n, Q61[0]), orc.U64NttTable(log_n, Q61[0])
+    rng = np.random.default_rng(31)
+    a = rand_mod(rng, Q61[0], n)
+    ref = a.copy(); o.transform_slice(ref)
+    c0 = [path_count(pf, w) for w in range(5)]
+    x = a.copy(); t.transform_slice(x)
+    assert np.array_equal(x, ref)
+    c1 = [path_count(pf, w) for w in range(5)]
+    assert c1[MAPPED_BOUNCE] == c0[MAPPED_BOUNCE] + 1 and c1[MAPPED_CALLER] == c0[MAPPED_CALLER]
+    y = a.copy()
+    assert _rc(rt.cudaHostRegister(y.ctypes.data, y.nbytes, 0)) == 0
+    try:
+        t.transform_slice(y)
+    finally:
+        rt.cudaHostUnregister(y.ctypes.data)
+    assert np.array_equal(y, ref)
+    c2 = [path_count(pf, w) for w in range(5)]
+    assert c2[MAPPED_CALLER] == c1[MAPPED_CALLER] + 1 and c2[MAPPED_BOUNCE] == c1[MAPPED_BOUNCE]
+    # 24 polynomials = 12 MiB: registered -> copy engines on the caller's memory; pageable -> helper thread
+    big = np.concatenate([a] * 24)
+    bref = np.concatenate([ref] * 24)
+    z = big.copy()
+    assert _rc(rt.cudaHostRegister(z.ctypes.data, z.nbytes, 0)) == 0
+    try:
+        t.transform_slice(z)
+    finally:
+        rt.cudaHostUnregister(z.ctypes.data)
+    assert np.array_equal(z, bref)
+    c3 = [path_count(pf, w) for w in range(5)]
+    assert c3[DMA_CALLER] > c2[DMA_CALLER] and c3[HELPER] == c2[HELPER]
+    w = big.copy(); t.transform_slice(w)
+    assert np.array_equal(w, bref)
+    c4 = [path_count(pf, w_) for w_ in range(5)]
+    assert c4[HELPER] == c3[HELPER] + 1
+
+
+def test_slice_spanning_two_registrations_is_not_treated_as_one_mapped_range(pf, orc):
+    """pinned first and last bytes do not make a pinned range.  One array whose two halves are registered
+    SEPARATELY (two registrations, adjacent): a slice over both must not be handed to the kernels as one mapped range —
+    it takes the library's own buffer — and a slice inside one registration still is used as it is."""
+    rt = _hip()
+    log_n = 15
+    n = 1 << log_n
+    t, o = pf.U64NttTable(log_n, Q62), orc.U64NttTable(log_n, Q62)
+    rng = np.random.default_rng(41)
+    page = 4096
+    raw = np.zeros(2 * n + page // 8, np.uint64)
+    skip = (-raw.ctypes.data % page) // 8          # page-aligned start: registrations cover whole pages
+    arr = raw[skip:skip + 2 * n]
+    arr[:] = rand_mod(rng, Q62, 2 * n)
+    orig = arr.copy()
+    ref = orig.copy(); o.transform_slice(ref)
+    half = n * 8
+    assert _rc(rt.cudaHostRegister(arr.ctypes.data, half, 0)) == 0
+    assert _rc(rt.cudaHostRegister(arr.ctypes.data + half, half, 0)) == 0
+    try:
+        c0 = [path_count(pf, w) for w in range(5)]
+        t.transform_slice(arr)                      # 512 KiB over both registrations
+        c1 = [path_count(pf, w) for w in range(5)]
+        assert np.array_equal(arr, ref)
+        assert c1[MAPPED_CALLER] == c0[MAPPED_CALLER] and c1[MAPPED_BOUNCE] == c0[MAPPED_BOUNCE] + 1
+        arr[:] = orig
+        t.transform_slice(arr[:n])                  # inside the first registration
+        c2 = [path_count(pf, w) for w in range(5)]
+        assert np.array_equal(arr[:n], ref[:n]) and np.array_equal(arr[n:], orig[n:])
+        assert c2[MAPPED_CALLER] == c1[MAPPED_CALLER] + 1
+    finally:
+        rt.cudaHostUnregister(arr.ctypes.data)
+        rt.cudaHostUnregister(arr.ctypes.data + half)
+
+
+def test_idle_contexts_are_capped_and_the_helper_thread_is_reused(pf, orc):
+    """A burst of concurrent callers leaves at most PFHE_STAGE_IDLE_MAX (4) contexts behind; the helper thread of a
+    context is started once and parked between calls (no thread per call)."""
+    import os
+    log_n = 14
+    n = 1 << log_n
+    t, o = pf.U64NttTable(log_n, Q61[0]), orc.U64NttTable(log_n, Q61[0])
+    rng = np.random.default_rng(51)
+    a = rand_mod(rng, Q61[0], n)
+    ref = a.copy(); o.transform_slice(ref)
+    pf.lib().pfhe_staging_release(-1)
+    errors = []
+    gate = threading.Barrier(8)
+
+    def worker():
+        try:
+            gate.wait()
+            for _ in range(20):
+                x = a.copy()
+                t.transform_slice(x)
+                if not np.array_equal(x, ref):
+                    raise AssertionError("mismatch")
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    th = [threading.Thread(target=worker) for _ in range(8)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errors, errors
+    assert 1 <= pf.lib().pfhe_staging_release(-1) <= 4
+    # helper thread: the long pageable form twice; the process's thread count grows by at most one in all
+    d, od = pf.U64DcrtTable(15, Q61), orc.U64DcrtTable(15, Q61)
+    big = rand_rns(rng, Q61, 1 << 15, 12)           # 9 MiB
+    bref = big.copy(); od.transform_slice(bref)
+
+    def nthreads():
+        return len(os.listdir("/proc/self/task"))
+
+    y = big.copy(); d.transform_slice(y)
+    assert np.array_equal(y, bref)
+    after_first = nthreads()
+    for _ in range(5):
+        y = big.copy(); d.transform_slice(y)
+        assert np.array_equal(y, bref)
+    assert nthreads() <= after_first, "a helper thread per call"
