@@ -243,7 +243,12 @@ int pfhe_dcrt_butterfly_mul_factor_to_dev(const pfhe_dcrt *table, uint64_t *a_de
                                           uint64_t *result_dev, void *stream);
 /* Fused "NTT -> pointwise mul by dcrt_poly -> INTT" of CRT polynomials in place:
  * CrtRlwe::mul_dcrt_polynomial_to (primus_lattice/src/rlwe/crt.rs:42-65) followed by
- * DcrtRlwe::into_coeff_form (primus_lattice/src/macros/mod.rs:901-911) per CRT polynomial. */
+ * DcrtRlwe::into_coeff_form (primus_lattice/src/macros/mod.rs:901-911) per CRT polynomial.
+ * Contract (the reference's: reduce_mul_slice_assign takes canonical operands, primus_reduce/src/slice_ops.rs:137-229):
+ * crt_poly_dev AND dcrt_poly_dev hold CANONICAL residues in [0, q_i).  A lazily transformed multiplicand ([0, 4q), the
+ * output of lazy_transform_slice) is outside the contract: the fused kernels multiply the forward half's unreduced words
+ * (up to 2^63 + 3q) by it with one 128 -> 64-bit reduction whose precondition is product < q * 2^64.  Reduce it first
+ * (pfhe_dcrt_transform_dev with lazy = 0 gives canonical values). */
 int pfhe_dcrt_mul_dcrt_polynomial_dev(const pfhe_dcrt *table, uint64_t *crt_poly_dev,
                                       size_t len, const uint64_t *dcrt_poly_dev, size_t len_b,
                                       void *stream);

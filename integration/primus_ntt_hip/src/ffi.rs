@@ -24,6 +24,10 @@ unsafe extern "C" {
     pub fn pfhe_ntt_destroy(t: *mut pfhe_ntt);
     pub fn pfhe_ntt_poly_length(t: *const pfhe_ntt) -> usize;
     pub fn pfhe_ntt_modulus(t: *const pfhe_ntt) -> u64;
+    pub fn pfhe_ntt_log_n(t: *const pfhe_ntt) -> u32;
+    pub fn pfhe_ntt_root(t: *const pfhe_ntt) -> u64;
+    pub fn pfhe_ntt_inv_root(t: *const pfhe_ntt) -> u64;
+    pub fn pfhe_ntt_inv_n(t: *const pfhe_ntt) -> u64;
     pub fn pfhe_ntt_transform_slice(t: *const pfhe_ntt, poly: *mut u64, len: usize) -> c_int;
     pub fn pfhe_ntt_inverse_transform_slice(t: *const pfhe_ntt, values: *mut u64, len: usize) -> c_int;
     pub fn pfhe_ntt_lazy_transform_slice(t: *const pfhe_ntt, poly: *mut u64, len: usize) -> c_int;
@@ -74,6 +78,8 @@ unsafe extern "C" {
     pub fn pfhe_extprod_plan_create(table: *const pfhe_dcrt, base: *const pfhe_rns, basis: *const pfhe_basis,
                                     glwe_dimension: usize, chunk: usize, out: *mut *mut pfhe_extprod_plan) -> c_int;
     pub fn pfhe_extprod_plan_destroy(p: *mut pfhe_extprod_plan);
+    /// 1 while some thread is inside a pfhe_extprod_* call on the plan (a second thread gets PFHE_ERR_BAD_ARGUMENT)
+    pub fn pfhe_extprod_plan_in_use(p: *const pfhe_extprod_plan) -> c_int;
     pub fn pfhe_extprod_mul_dcrt_ggsw_to_dev(plan: *mut pfhe_extprod_plan, crt_glwe_dev: *const u64, len_glwe: usize,
                                              dcrt_ggsw_dev: *const u64, len_ggsw: usize, result_dev: *mut u64,
                                              len_result: usize, into_coeff_form: c_int, stream: *mut c_void) -> c_int;

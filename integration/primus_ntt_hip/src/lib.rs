@@ -58,6 +58,28 @@ impl Drop for HipNttTable {
     }
 }
 
+/// The inherent getters of `U64NttTable` (crates/primus_ntt/src/ntt/prime64/table.rs:127-161).
+impl HipNttTable {
+    pub fn modulus(&self) -> u64 {
+        unsafe { ffi::pfhe_ntt_modulus(self.h) }
+    }
+    pub fn log_n(&self) -> u32 {
+        unsafe { ffi::pfhe_ntt_log_n(self.h) }
+    }
+    pub fn n(&self) -> usize {
+        unsafe { ffi::pfhe_ntt_poly_length(self.h) }
+    }
+    pub fn root(&self) -> u64 {
+        unsafe { ffi::pfhe_ntt_root(self.h) }
+    }
+    pub fn inv_root(&self) -> u64 {
+        unsafe { ffi::pfhe_ntt_inv_root(self.h) }
+    }
+    pub fn inv_n(&self) -> u64 {
+        unsafe { ffi::pfhe_ntt_inv_n(self.h) }
+    }
+}
+
 impl NttTable for HipNttTable {
     type ValueT = u64;
 

@@ -333,7 +333,7 @@ int transform_host(const TableSet &t, u64 *host, size_t len, bool inverse, bool 
                     {
                         std::unique_lock<std::mutex> lk(sh.mu);
                         // piece i is launched AND this thread's neighbour piece i + 1 is no longer being copied in
-                        sh.cv.wait(lk, [&] { return sh.abort || sh.all_in || sh.copied_in >= i + 2; });
+                        sh.cv.wait(lk, [&] { return sh.abort || sh.all_in || sh.copied_in >= i + 1 + K.helper_lag; });
                         if (sh.abort) return PFHE_OK;
                     }
                     hipError_t e = hipEventSynchronize(done[i]);

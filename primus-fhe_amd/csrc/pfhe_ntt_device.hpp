@@ -57,12 +57,15 @@ int ntt_transform_through_dev(const NttPrime *primes, u32 L, u32 log_n, int arit
                               bool inverse, bool lazy, hipStream_t s, const NttTuning &tune = NttTuning());
 // inverse transform of data (*) mul, the pointwise product fused into the loads of the first
 // (block) pass; `mul` holds mul_polys limb-polynomials (npolys, or one unit of L shared by the batch).
-// 64-bit policies only.
+// 64-bit policies only.  `mul` (and `data`) must be CANONICAL, [0, q): the product is A::mul_any, one reduction of a
+// 128-bit product whose precondition is a * b < q * 2^64.
 int ntt_inverse_mul_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, const u64 *mul,
                         u64 mul_polys, hipStream_t s, const NttTuning &tune = NttTuning());
 // data <- INTT(NTT(data) (*) mul) with the forward block pass, the product and the inverse block pass fused in one kernel
 // (one HBM round trip for N <= 2^14, three for two-pass rings).  PFHE_ERR_UNSUPPORTED: shape not covered, use
-// ntt_forward_dev + ntt_inverse_mul_dev.  64-bit policies only.
+// ntt_forward_dev + ntt_inverse_mul_dev.  64-bit policies only.  `mul` must be CANONICAL, [0, q): the forward half hands
+// RAW words (up to 2^63 + 3q for Montgomery tables, 2^63 + 2^32 for pseudo-Mersenne ones) to A::mul_any, whose
+// precondition a * b < q * 2^64 then holds only for b < q (a lazily transformed multiplicand in [0, 4q) breaks it).
 int ntt_polymul_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data, u64 npolys, const u64 *mul,
                     u64 mul_polys, hipStream_t s, const NttTuning &tune = NttTuning());
 // U32NttTable / U32DcrtTable transforms (log_n = log2 of the polynomial length in coefficients)

@@ -51,6 +51,8 @@ const StageKnobs &stage_knobs() {
         // idle contexts kept per device (each holds its arenas, up to cache_max): a burst of T concurrent callers leaves
         // at most this many behind
         v.idle_max = env_bytes("PFHE_STAGE_IDLE_MAX", 4);
+        // pieces the helper thread stays behind the copying thread (1: never a page in common in flight; 0: round 4's order)
+        v.helper_lag = env_bytes("PFHE_STAGE_LAG", 1) ? 1 : 0;
         return v;
     }();
     return k;

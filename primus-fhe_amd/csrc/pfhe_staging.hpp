@@ -35,9 +35,9 @@ std::uint64_t alloc_event_count();
 
 // Environment knobs of the staging layer, parsed ONCE by one parser (a malformed value gives the built-in default
 // everywhere): PFHE_STAGE_BOUNCE_MAX, PFHE_STAGE_CACHE_MAX, PFHE_STAGE_REGISTER, PFHE_STAGE_REGISTER_MIN,
-// PFHE_STAGE_CHUNK, PFHE_STAGE_ZERO_COPY, PFHE_STAGE_THREADS, PFHE_STAGE_PIECES, PFHE_STAGE_IDLE_MAX.
+// PFHE_STAGE_CHUNK, PFHE_STAGE_ZERO_COPY, PFHE_STAGE_THREADS, PFHE_STAGE_PIECES, PFHE_STAGE_IDLE_MAX, PFHE_STAGE_LAG.
 struct StageKnobs {
-    size_t bounce_max, cache_max, register_min, chunk_bytes, pieces, idle_max;
+    size_t bounce_max, cache_max, register_min, chunk_bytes, pieces, idle_max, helper_lag;
     bool use_register, zero_copy, helper_thread;
 };
 const StageKnobs &stage_knobs();

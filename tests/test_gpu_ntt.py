@@ -962,3 +962,39 @@ def test_plan_tuning_switches_change_the_plan_not_the_words(pf, orc, env, log_n,
     y = to_dev(a)
     d.mul_dcrt_polynomial_dev(y, to_dev(bh))
     assert np.array_equal(to_host(y), exp)
+
+
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("log_n", [12, 16])
+def test_fused_polymul_contract_canonical_multiplicand_at_its_extremes(pf, orc, generic, log_n, monkeypatch):
+    """pfhe_dcrt_mul_dcrt_polynomial_dev takes CANONICAL operands (include/pfhe.h; the reference's reduce_mul_slice_assign
+    does, primus_reduce/src/slice_ops.rs:137-229).  Inside, the forward half hands RAW words (up to 2^63 + 3q) to one
+    128 -> 64-bit reduction whose precondition is product < q * 2^64: the largest canonical multiplicand, q - 1 in every
+    word, against data that drives the forward butterflies to their bounds (q - 1 in every word, and a spike) must still be
+    exact, for pseudo-Mersenne and for Montgomery (generic-prime) tables.  A lazily transformed multiplicand ([0, 4q)) is
+    outside the contract and documented as such; the documented route — transform with lazy = 0 — is what is used here."""
+    if generic:
+        monkeypatch.setenv("PFHE_DISABLE_PM", "1")
+    d, o = pf.U64DcrtTable(log_n, Q61), orc.U64DcrtTable(log_n, Q61)
+    monkeypatch.delenv("PFHE_DISABLE_PM", raising=False)
+    n, L = 1 << log_n, 3
+    qs = np.repeat(np.array(Q61, np.uint64), n)
+    top = qs - np.uint64(1)
+    spike = np.zeros(L * n, np.uint64)
+    spike[::n] = top[::n]
+    rng = np.random.default_rng(3)
+    rnd = rand_rns(rng, Q61, n, 1)
+    for data in (top, spike, rnd):
+        for mul_coeff in (top, rnd):
+            mh = mul_coeff.copy()
+            o.transform_slice(mh)                      # canonical NTT-domain multiplicand
+            assert (mh < qs).all()
+            mh_top = top.copy()                        # and the extreme canonical multiplicand itself
+            for m in (mh, mh_top):
+                ref = data.copy()
+                o.transform_slice(ref)
+                o.mul_assign(ref, m)
+                o.inverse_transform_slice(ref)
+                x = to_dev(data.copy())
+                d.mul_dcrt_polynomial_dev(x, to_dev(m))
+                assert np.array_equal(to_host(x), ref)
