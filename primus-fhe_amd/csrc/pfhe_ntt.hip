@@ -925,6 +925,7 @@ NttTuning NttTuning::from_env() {
     t.pipelined_min_mb = env_int("PFHE_PIPELINED_MIN_MB", 1, 1 << 20);
     t.pipe_ramp = env_int("PFHE_PIPE_RAMP", 1, 32);
     t.persist = std::getenv("PFHE_DISABLE_PERSIST") == nullptr;
+    t.pipe_u32 = std::getenv("PFHE_PIPE_U32") != nullptr;
     return t;
 }
 
@@ -1087,13 +1088,21 @@ static int pipelined_tiles(u32 L, u32 log_n, int pm, u64 npolys, bool inverse, b
     const u64 bytes = (npolys << log_n) * sizeof(u64);
     // 64-bit tables, N = 2^16 = 2^4 x 2^12.  (The u32 tables' 2^15 words = 2^4 x 2^11 fit the same kernel template; measured
     // 2.858 ms against 2.866-2.874 ms for their two plain launches per 12 288 transforms: not instantiated.)
-    const bool shape = pm != kArithB32 && log_n == 16 && make_ntt_plan(log_n, pm, tune).block_log == 12;
+    // u32 tables: 2^15 words = 2^4 x 2^11, the same kernel template with 128-thread workgroups.  Round 5, 12 288 transforms,
+    // same box: INVERSE 2.594 -> 2.462-2.499 ms (6 / 12 tiles), taken by default; forward 2.468 -> 2.473 ms (its kernel
+    // needs 128 registers + 28 bytes of scratch), left on the two plain launches unless PFHE_PIPE_U32 is set.
+    const bool shape = (pm != kArithB32 && log_n == 16 && make_ntt_plan(log_n, pm, tune).block_log == 12) ||
+                       (pm == kArithB32 && (inverse || tune.pipe_u32) && log_n == 15 &&
+                        make_ntt_plan(log_n, pm, tune).block_log == 11);
     if (!(tune.pipelined && shape && ntt_num_passes(log_n, pm, tune) == 2 &&
           (!has_mul || inverse) && npolys % L == 0 &&
-          bytes >= (tune.pipelined_min_mb ? (u64)tune.pipelined_min_mb << 20 : kPipelinedMinBytes)))
+          bytes >= (tune.pipelined_min_mb ? (u64)tune.pipelined_min_mb << 20
+                                           : pm == kArithB32 ? 4 * kPipelinedMinBytes : kPipelinedMinBytes)))
         return 0;
+    // (u32 tables: tiles of 512 MiB — 6 tiles 2.462 ms, 12 tiles 2.494 ms, 24 tiles 2.586 ms per 3 GiB)
+    const u64 tile_bytes = pm == kArithB32 ? 2 * kPipelinedTileBytes : kPipelinedTileBytes;
     int pt = tune.pipe_tiles ? tune.pipe_tiles
-                                : (int)std::min<u64>((bytes + kPipelinedTileBytes / 2) / kPipelinedTileBytes, (u64)kPipelinedMaxTiles);
+                                : (int)std::min<u64>((bytes + tile_bytes / 2) / tile_bytes, (u64)kPipelinedMaxTiles);
     if (pt < 2) pt = 2;
     if (pt > kPipelinedMaxTiles) pt = kPipelinedMaxTiles;  // what transform_pipelined runs (its launch count is reported)
     if ((u64)pt > npolys / L) pt = (int)(npolys / L);
@@ -1116,6 +1125,8 @@ static int transform(const NttPrime *primes, u32 L, u32 log_n, int pm, u64 *data
     const int passes = ntt_num_passes(log_n, pm, tune);
     {
         const int pt = pipelined_tiles(L, log_n, pm, npolys, inverse, mul != nullptr, tune);
+        if (pt >= 1 && pm == kArithB32)
+            return transform_pipelined<B32Arith, 11>(primes, L, data, npolys, inverse, lazy, s, pt, tune.pipe_ramp, mul, mul_polys);
         if (pt >= 1 && pm == kArithMont)
             return transform_pipelined<MontArith, 12>(primes, L, data, npolys, inverse, lazy, s, pt, tune.pipe_ramp, mul, mul_polys);
         if (pt >= 1)

@@ -193,3 +193,46 @@ def test_u32_and_u64_tables_agree_on_the_gpu(pf, log_n):
     assert np.array_equal(x32.astype(np.uint64), x64)
     t32.inverse_transform_slice(x32); t64.inverse_transform_slice(x64)
     assert np.array_equal(x32, a) and np.array_equal(x64, a.astype(np.uint64))
+
+
+@pytest.mark.parametrize("batch,tiles", [(1400, 0), (1371, 5)])
+def test_u32_pipelined_inverse_equals_plain_passes(pf, orc, batch, tiles, monkeypatch):
+    """Round 5: from 1 GiB of u32 data the INVERSE N = 2^16 transform takes the pipelined form (ntt_pipe_inv_kernel<B32Arith,
+    11>, tiles of 512 MiB); the forward one only under PFHE_PIPE_U32.  Ragged batches and tile counts: bit-identical to the
+    two plain launches in both directions, oracle on the polynomials either side of the tile boundaries."""
+    import torch
+    log_n = 16
+    n, L = 1 << log_n, 3
+    if tiles:
+        monkeypatch.setenv("PFHE_PIPE_TILES", str(tiles))
+    t = pf.U32DcrtTable(log_n, Q30)
+    monkeypatch.setenv("PFHE_PIPE_U32", "1")
+    t_fwd = pf.U32DcrtTable(log_n, Q30)
+    monkeypatch.delenv("PFHE_PIPE_U32")
+    monkeypatch.setenv("PFHE_DISABLE_PIPELINED", "1")
+    t_plain = pf.U32DcrtTable(log_n, Q30)
+    monkeypatch.delenv("PFHE_DISABLE_PIPELINED")
+    o = orc.U32DcrtTable(log_n, Q30)
+    x = torch.empty(batch * L * n, dtype=torch.int32, device="cuda")
+    t.fill_uniform_dev(x, 0x5EED_0000_0000_0033)
+    orig = x.clone()
+    y = orig.clone()
+    t_plain.transform_dev(y)
+    z = orig.clone()
+    t_fwd.transform_dev(z)                       # forward pipelined (forced)
+    assert torch.equal(z, y)
+    t.transform_dev(x)                           # forward: plain passes by default
+    assert torch.equal(x, y)
+    for e in sorted({0, 1, batch // 5, batch // 2 - 1, batch // 2, batch - 1}):
+        s = slice(e * L * n, (e + 1) * L * n)
+        ref = to_host32(orig[s]).copy(); o.transform_slice(ref)
+        assert np.array_equal(to_host32(x[s]), ref), e
+    t.inverse_transform_dev(x)                   # inverse: pipelined by default
+    assert torch.equal(x, orig)
+    t_plain.inverse_transform_dev(z)
+    assert torch.equal(z, orig)
+    lz = y.clone()
+    t.inverse_transform_dev(lz, lazy=True)       # lazy inverse through the pipelined kernels: [0, 2q), same residues
+    h = to_host32(lz[:L * n]).astype(np.uint64)
+    qs = np.repeat(np.array(Q30, np.uint64), n)
+    assert (h < 2 * qs).all() and np.array_equal(h % qs, to_host32(orig[:L * n]).astype(np.uint64))
