@@ -172,11 +172,13 @@ struct NoHook {
 // after_stage runs once the block's own global loads have landed in LDS (the pipelined kernel issues the loads of its
 // strided chunk there, so that they are in flight during the block's stages and do not delay the block's first wait)
 // `src`: where the pass reads (`data` itself for the in-place kernels; see strided_pass_body)
-template <class A, int LOGB, bool INV, bool MUL, int LOGE = 4, class Hook = NoHook, bool NTIO = false>
+// before_store runs in front of the block's global stores (the pipelined kernels touch their prefetched strided data there: see
+// ntt_pipe_body)
+template <class A, int LOGB, bool INV, bool MUL, int LOGE = 4, class Hook = NoHook, bool NTIO = false, class Hook2 = NoHook>
 __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const u64 *src, const NttPrime *__restrict__ primes, u32 L,
                                                 u32 log_n, u64 total_blocks, u32 lazy, const u64 *__restrict__ mul,
                                                 u64 mul_polys, u64 *__restrict__ lds_raw, u64 first_block,
-                                                Hook after_stage = Hook()) {
+                                                Hook after_stage = Hook(), Hook2 before_store = Hook2()) {
     using Cfg = BlockCfg<LOGB, LOGE>;
     // non-temporal stores and staged loads: the pipelined kernel (large batches only) and the NT instantiations that
     // launch_block picks for batches of at least kNtMinBytes
@@ -214,13 +216,21 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const u6
     if constexpr (kDirectLoad) {
 #pragma unroll
         for (int k = 0; k < Cfg::E; ++k)
+#ifdef PFHE_NOMEM  // timing-only build (tools/build_variant.sh nomem -DPFHE_NOMEM): the arithmetic and LDS traffic without global memory
+            x[k] = (u64)lt * 0x9E3779B97F4A7C15ull + (u64)k + lazy;
+#else
             x[k] = valid ? __builtin_nontemporal_load(sgptr + ((u32)k << (LOGB - LOGE)) + lt) : 0ull;
+#endif
         // (forward: issuing them in front of the last register pass instead — the per-lane-twiddle one — costs 152 registers)
         after_stage();
         block_forward_core<A, LOGB, false, LOGE>(ar, x, lds, n, eblk, lt, lazy != 0);
         lds_put_layout<0, LOGE>(x, lds, lt);
-        __syncthreads();
+        sync_vectors_layout0<LOGB, LOGE>();  // wave-local: no workgroup barrier (pfhe_ntt_device.hpp, vec_index)
         lds_get_vectors<LOGB, LOGE>(io, lds, lt);
+        before_store();
+#ifdef PFHE_NOMEM
+        if (lazy == 0xdeadu)
+#endif
         if (valid) store_block_vectors<LOGB, LOGE, kNt>(io, gptr, lt);
         return;
     }
@@ -253,7 +263,9 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const u6
         }
     }
     lds_put_vectors<LOGB, LOGE>(io, lds, lt);
-    __syncthreads();
+    // inverse: layout <0> reads the vectors of the thread's own wave; forward: layout <LOGB - LOGE> reads every wave's
+    if constexpr (INV) sync_vectors_layout0<LOGB, LOGE>();
+    else __syncthreads();
     // (inverse: the hook runs in front of the LAST register pass instead — uniform twiddles, the fewest live registers —
     // so that the pipelined kernel's 32 registers of prefetched strided data do not sit through the per-lane-twiddle
     // passes: 128 registers without spills, four waves per SIMD; 4.98 against 5.05 ms per 12 288 inverse transforms,
@@ -271,6 +283,7 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const u6
         constexpr bool kDirectStore = Cfg::BPW == 1 && (LOGB - LOGE) >= 6 && !A::kPacked
             ;
         if constexpr (kDirectStore) {
+            before_store();
             if (valid) {
 #pragma unroll
                 // (inside the pipelined inverse kernel this is the INTERMEDIATE: see kPipeIntermediateNt)
@@ -282,8 +295,10 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const u6
         }
         lds_put_layout<LOGB - LOGE, LOGE>(x, lds, lt);
     }
-    __syncthreads();
+    if constexpr (!INV) sync_vectors_layout0<LOGB, LOGE>();  // from layout <0>: wave-local
+    else __syncthreads();
     lds_get_vectors<LOGB, LOGE>(io, lds, lt);
+    before_store();
     if (valid) store_block_vectors<LOGB, LOGE, kNt>(io, gptr, lt);
 }
 
@@ -464,19 +479,39 @@ __device__ __forceinline__ void ntt_pipe_body(
     const auto issue = [&]() {
         if (has_str) {
 #pragma unroll
+#ifdef PFHE_NOMEM
+            for (int k = 0; k < (1 << K); ++k) sx[k][0] = (u64)threadIdx.x * 0xBF58476D1CE4E5B9ull + (u64)k + lazy;
+#else
             for (int k = 0; k < (1 << K); ++k) sx[k][0] = __builtin_nontemporal_load(sp + ((u64)k << LOGB));
+#endif
+        }
+    };
+    // The chunk's loads are consumed after the block's stores have been issued.  Loads and stores share the wave's one
+    // vector-memory counter and the compiler, with both kinds pending, cannot count past the stores: it would wait for
+    // vmcnt(0) — for the block's stores to be ACKNOWLEDGED — in front of the chunk's first butterfly (1.5 k of a workgroup's
+    // 42 k cycles in round 2's phase stamps: "wait: block stores + strided loads landed").  Touching the chunk's registers
+    // in front of the stores moves the wait to a point where only loads are pending — issued twelve stages earlier, long
+    // landed — and the stores are then never waited for.
+    const auto landed = [&]() {
+        if (has_str) {
+#pragma unroll
+            for (int k = 0; k < (1 << K); ++k) asm volatile("" : "+v"(sx[k][0]));
         }
     };
     if (chunk < blk_total) {
-        block_pass_body<A, LOGB, INV, MUL>(blk_data, blk_data, primes, L, log_n, blk_total, INV ? 0u : lazy, mul, mul_polys, lds_raw,
-                                           chunk, issue);
+        block_pass_body<A, LOGB, INV, MUL, 4, decltype(issue), false, decltype(landed)>(
+            blk_data, blk_data, primes, L, log_n, blk_total, INV ? 0u : lazy, mul, mul_polys, lds_raw, chunk, issue, landed);
     } else {
         issue();
+        landed();  // (both paths reach the chunk's stages with no load pending: the wait counts below the join serve both)
     }
     if (has_str) {
         const A ar(primes + (chunk >> 4) % L);
         if constexpr (!INV) strided_forward_regs<A, K, 1, true>(ar, sx, n, 0u, LOGB);
         else strided_inverse_regs<A, K, 1, true>(ar, sx, n, 0u, LOGB, lazy != 0);  // the only strided pass: final stage
+#ifdef PFHE_NOMEM
+        if (lazy == 0xdeadu)
+#endif
 #pragma unroll
         // forward: this is the intermediate (kPipeIntermediateNt); inverse: the final output (always non-temporal)
         for (int k = 0; k < (1 << K); ++k) gstore<(INV || kPipeIntermediateNt)>(sp + ((u64)k << LOGB), sx[k][0]);
@@ -926,6 +961,8 @@ NttTuning NttTuning::from_env() {
     t.pipe_ramp = env_int("PFHE_PIPE_RAMP", 1, 32);
     t.persist = std::getenv("PFHE_DISABLE_PERSIST") == nullptr;
     t.pipe_u32 = std::getenv("PFHE_PIPE_U32") != nullptr;
+    t.pipe_one_lag = env_int("PFHE_PIPE_ONE", 1, 1 << 24);
+    t.pipe_one_mode = env_int("PFHE_PIPE_ONE_MODE", 0, 3);
     return t;
 }
 
@@ -1125,6 +1162,12 @@ static int transform(const NttPrime *primes, u32 L, u32 log_n, int pm, u64 *data
     const int passes = ntt_num_passes(log_n, pm, tune);
     {
         const int pt = pipelined_tiles(L, log_n, pm, npolys, inverse, mul != nullptr, tune);
+        if (pt >= 1 && pm == kArithPm && !inverse && !mul && tune.pipe_one_lag > 0) {  // experiment: one launch
+            static u32 *flags = nullptr;  // (experiment only: one process-wide buffer, 1 Mi polynomials)
+            if ((tune.pipe_one_mode & 2) && !flags) PFHE_HIP(hipMalloc((void **)&flags, sizeof(u32) << 20));
+            if (tune.pipe_one_mode & 2) PFHE_HIP(hipMemsetAsync(flags, 0, sizeof(u32) * npolys, s));
+            return launch_pipe_one(pm, data, npolys, primes, L, lazy, (u64)tune.pipe_one_lag, tune.pipe_one_mode, flags, s);
+        }
         if (pt >= 1 && pm == kArithB32)
             return transform_pipelined<B32Arith, 11>(primes, L, data, npolys, inverse, lazy, s, pt, tune.pipe_ramp, mul, mul_polys);
         if (pt >= 1 && pm == kArithMont)

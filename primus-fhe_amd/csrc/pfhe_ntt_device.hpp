@@ -33,6 +33,8 @@ struct NttTuning {
     bool pipelined = true;         // PFHE_DISABLE_PIPELINED clears it: N = 2^16 runs as tiles + 1 launches of ntt_pipe_kernel on the caller's stream
     int pipe_ramp = 0;             // PFHE_PIPE_RAMP: tile weights of the pipelined form ramp 1..ramp..1 (0 / 1: equal tiles)
     bool persist = true;           // PFHE_DISABLE_PERSIST clears it: N = 2^13 / 2^14 batches run ntt_persist_kernel (resident workgroups that prefetch their next polynomial)
+    int pipe_one_lag = 0;          // PFHE_PIPE_ONE: experiment — forward N = 2^16 transform as one launch, block pass `lag` workgroups behind
+    int pipe_one_mode = 0;         // PFHE_PIPE_ONE_MODE: bit 0 coherent intermediate, bit 1 per-polynomial flags
     bool pipe_u32 = false;         // PFHE_PIPE_U32: the u32 tables' FORWARD N = 2^16 transforms take the pipelined form too (the inverse ones do by default)
     int pipelined_min_mb = 0;      // PFHE_PIPELINED_MIN_MB: smallest batch (MiB of data) that takes the pipelined form (0: built-in default)
     static NttTuning from_env();
@@ -72,6 +74,10 @@ int ntt_polymul_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *da
 // U32NttTable / U32DcrtTable transforms (log_n = log2 of the polynomial length in coefficients)
 int ntt32_transform_dev(const NttPrime *primes, u32 L, u32 log_n, u32 *data, u64 npolys, bool inverse, bool lazy,
                         hipStream_t s, const NttTuning &tune = NttTuning());
+
+// round-5 experiment (pfhe_ntt_one.hip): the forward pipelined transform as ONE launch
+int launch_pipe_one(int arith, u64 *data, u64 npolys, const NttPrime *primes, u32 L, bool lazy, u64 lag, int mode, u32 *flags,
+                    hipStream_t s);
 
 int ntt_num_passes(u32 log_n, int arith = 0, const NttTuning &tune = NttTuning());
 void ntt_pass_name(u32 log_n, bool inverse, int index, char *buf, size_t cap, int arith = 0,
@@ -1016,18 +1022,50 @@ __device__ __forceinline__ void block_inverse_core(const A &ar, u64 (&x)[1 << LO
     inv_chain<A, LOGB, 0, LEAD, LOGE, Late, HOOK_AT>(ar, x, lds, n, eblk, lt, final_block, lazy, before_last);
 }
 
-// ---- coalesced block I/O: E/2 16-byte vectors per thread in natural order (vector v = elements
-//      2v, 2v+1), one full KiB per wave instruction, staged through LDS ----
+// ---- coalesced block I/O: E/2 16-byte vectors per thread (vector v = elements 2v, 2v+1), one full KiB per wave
+//      instruction, staged through LDS.  Which vectors a thread takes (round 5): WAVE-LOCAL when a block has whole waves —
+//      wave w owns vectors [w * 64 * NV, (w + 1) * 64 * NV), exactly the elements its threads hold in layout <0> (thread lt
+//      = elements lt * E ... lt * E + E - 1), lane l takes vectors l, l + 64, ... of that range.  The transposition between
+//      layout <0> and the I/O vectors then never leaves the wave: no workgroup barrier between lds_put_layout<0> and
+//      lds_get_vectors (forward output) or between lds_put_vectors and lds_get_layout<0> (inverse input) — one of the two
+//      barriers of a block pass, whose cost is the skew between the workgroup's four waves, each on a SIMD of its own with
+//      contention of its own (sync_vectors_layout0 below).  Smaller blocks keep the interleaved assignment lt + TPB * j.
+template <int LOGB, int LOGE = 4>
+__host__ __device__ constexpr bool wave_local_vectors() {
+#ifdef PFHE_NO_WAVE_LOCAL_IO  // A/B build (tools/build_variant.sh): round 4's interleaved assignment and its workgroup barriers
+    return false;
+#else
+    return BlockCfg<LOGB, LOGE>::TPB >= 64;
+#endif
+}
+template <int LOGB, int LOGE = 4>
+__device__ __forceinline__ u32 vec_index(u32 lt, int j) {
+    if constexpr (wave_local_vectors<LOGB, LOGE>()) return ((lt >> 6) << (6 + LOGE - 1)) + (lt & 63u) + 64u * (u32)j;
+    else return lt + (u32)BlockCfg<LOGB, LOGE>::TPB * (u32)j;
+}
+// between an LDS image written in layout <0> and read as I/O vectors, or the other way round
+template <int LOGB, int LOGE = 4>
+__device__ __forceinline__ void sync_vectors_layout0() {
+    if constexpr (wave_local_vectors<LOGB, LOGE>()) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
 template <int LOGB, int LOGE = 4, bool NT = false>
 __device__ __forceinline__ void load_block_vectors(u64x2 (&v)[1 << (LOGE - 1)], const u64 *gptr, u32 lt) {
-    const GCVec2Ptr p = (GCVec2Ptr)(const void *)gptr;
+    const GCVec2Ptr p = (GCVec2Ptr)(const void *)gptr + vec_index<LOGB, LOGE>(lt, 0);
+    constexpr u32 kStep = wave_local_vectors<LOGB, LOGE>() ? 64u : (u32)BlockCfg<LOGB, LOGE>::TPB;
 #pragma unroll
     for (int j = 0; j < (1 << (LOGE - 1)); ++j) {
         if constexpr (NT) {  // read-once data of a large batch
-            v[j] = __builtin_nontemporal_load(p + lt + BlockCfg<LOGB, LOGE>::TPB * j);
+            v[j] = __builtin_nontemporal_load(p + kStep * j);
             continue;
         }
-        v[j] = p[lt + BlockCfg<LOGB, LOGE>::TPB * j];
+        v[j] = p[kStep * j];
     }
 }
 
@@ -1050,28 +1088,31 @@ __device__ __forceinline__ void gstore(T *p, T v) {
 
 template <int LOGB, int LOGE = 4, bool NT = false>
 __device__ __forceinline__ void store_block_vectors(const u64x2 (&v)[1 << (LOGE - 1)], u64 *gptr, u32 lt) {
-    const GVec2Ptr p = (GVec2Ptr)(void *)gptr;
+    const GVec2Ptr p = (GVec2Ptr)(void *)gptr + vec_index<LOGB, LOGE>(lt, 0);
+    constexpr u32 kStep = wave_local_vectors<LOGB, LOGE>() ? 64u : (u32)BlockCfg<LOGB, LOGE>::TPB;
 #pragma unroll
     for (int j = 0; j < (1 << (LOGE - 1)); ++j) {
         if constexpr (NT) {
-            __builtin_nontemporal_store(v[j], p + lt + BlockCfg<LOGB, LOGE>::TPB * j);
+            __builtin_nontemporal_store(v[j], p + kStep * j);
             continue;
         }
-        p[lt + BlockCfg<LOGB, LOGE>::TPB * j] = v[j];
+        p[kStep * j] = v[j];
     }
 }
 
-// vector v = lt + TPB*j holds elements 2v, 2v+1: padded index = lds_phi(2*lt) + constant(j) once 2*TPB is a multiple of 16
+// vector vec_index(lt, j) holds elements 2v, 2v+1: padded index = lds_phi(2 * vec_index(lt, 0)) + constant(j) once the
+// element step 2 * kStep is a multiple of 16
 template <int LOGB, int LOGE = 4>
 __host__ __device__ constexpr u32 lds_voff(int j) {
-    return 2u * BlockCfg<LOGB, LOGE>::TPB * (u32)j + 2u * ((2u * BlockCfg<LOGB, LOGE>::TPB * (u32)j) >> 4);
+    constexpr u32 kStep = wave_local_vectors<LOGB, LOGE>() ? 64u : (u32)BlockCfg<LOGB, LOGE>::TPB;
+    return 2u * kStep * (u32)j + 2u * ((2u * kStep * (u32)j) >> 4);
 }
 
 template <int LOGB, int LOGE = 4>
 __device__ __forceinline__ void lds_put_vectors(const u64x2 (&v)[1 << (LOGE - 1)], u64 *__restrict__ lds, u32 lt) {
     constexpr int NV = 1 << (LOGE - 1), TPB = BlockCfg<LOGB, LOGE>::TPB;
     if constexpr (TPB >= 8) {
-        u64 *__restrict__ base = lds + lds_phi(2 * lt);
+        u64 *__restrict__ base = lds + lds_phi(2 * vec_index<LOGB, LOGE>(lt, 0));
 #pragma unroll
         for (int j = 0; j < NV; ++j) *reinterpret_cast<u64x2 *>(base + lds_voff<LOGB, LOGE>(j)) = v[j];
     } else {
@@ -1084,7 +1125,7 @@ template <int LOGB, int LOGE = 4>
 __device__ __forceinline__ void lds_get_vectors(u64x2 (&v)[1 << (LOGE - 1)], const u64 *__restrict__ lds, u32 lt) {
     constexpr int NV = 1 << (LOGE - 1), TPB = BlockCfg<LOGB, LOGE>::TPB;
     if constexpr (TPB >= 8) {
-        const u64 *__restrict__ base = lds + lds_phi(2 * lt);
+        const u64 *__restrict__ base = lds + lds_phi(2 * vec_index<LOGB, LOGE>(lt, 0));
 #pragma unroll
         for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const u64x2 *>(base + lds_voff<LOGB, LOGE>(j));
     } else {

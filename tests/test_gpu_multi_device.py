@@ -12,7 +12,12 @@ from pyref import Q61
 pytestmark = pytest.mark.gpu
 
 
-def test_threads_per_device_union_equals_unsharded_and_oracle(orc):
+@pytest.mark.parametrize("log_n,total", [(13, 7), (16, 5)], ids=["n8192-7ct", "config4-shape-n65536-5ct"])
+def test_threads_per_device_union_equals_unsharded_and_oracle(orc, log_n, total):
+    """Ciphertexts of the external product (k = 1, 3 primes of 61 bits, log B = 30, ell = 6) and RNS polynomials of the forward
+    transform, split over host threads with a handle set per shard.  Two shapes: N = 2^13 with 7 ciphertexts (ragged 3 + 2 +
+    2), and BASELINE config 4's ring and gadget — N = 2^16 — with 5 ciphertexts (the batch is what is reduced, not the
+    shape).  VERDICT r4 item 13: earlier text called the first one "config 4"; it is not."""
     import torch
 
     import primus_fhe_amd as p
@@ -21,7 +26,7 @@ def test_threads_per_device_union_equals_unsharded_and_oracle(orc):
     ndev = torch.cuda.device_count()
     shards = max(3, ndev)                      # ragged on purpose when there is one device
     devices = [r % ndev for r in range(shards)]
-    log_n, k, total = 13, 1, 7
+    k = 1
     n, L = 1 << log_n, 3
     W = (k + 1) * L * n
     seed_g, seed_k = 0x5EED000000000011, 0x5EED000000000012
