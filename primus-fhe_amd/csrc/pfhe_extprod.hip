@@ -117,7 +117,7 @@ __global__ __launch_bounds__(LOGE == 3 ? 512 : 256, LOGE == 3 ? kMulacc8MinWaves
             x[k] = __builtin_nontemporal_load(dg + (u64)ij * W + ((u32)k << (LOGB - LOGE)) + ltl);
         block_forward_core<A, LOGB, true, LOGE, NoLateHook, true>(ar, x, lds, n, eblk, ltl, /*lazy=*/true);  // digit_hat mod~ q, raw
         lds_put_layout<0, LOGE>(x, lds, ltl);
-        __syncthreads();
+        sync_vectors_layout0<LOGB, LOGE>();  // wave-local transposition (vec_index): no workgroup barrier
         lds_get_vectors<LOGB, LOGE>(io, lds, ltl);  // natural order again: same positions as the key vectors
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(LOGE == 3 ? 512 : 256, LOGE == 3 ? kMulacc8MinWaves
             u64 y[1 << LOGE];
             __syncthreads();  // other threads may still be reading the previous image (last term / previous component)
             lds_put_vectors<LOGB, LOGE>(acc[c], lds, lte);
-            __syncthreads();
+            sync_vectors_layout0<LOGB, LOGE>();  // wave-local (vec_index)
             lds_get_layout<0, LOGE>(y, lds, lte);
             block_inverse_core<A, LOGB, false, LOGE>(ar, y, lds, n, eblk, lte, /*final_block=*/false, /*lazy=*/false);
 #pragma unroll

@@ -184,6 +184,9 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const u6
     // launch_block picks for batches of at least kNtMinBytes
     constexpr bool kNt = !std::is_same<Hook, NoHook>::value || NTIO;
     constexpr int NV = Cfg::E / 2;  // 16-byte vectors per thread
+    // I/O vectors wave-local (pfhe_ntt_device.hpp, vec_index) — except in the pipelined INVERSE kernel of Montgomery tables,
+    // which sits at 128 registers and spills four with the wave-local addresses (inverse transform 5.19 against 5.07 ms)
+    constexpr bool kWL = wave_local_vectors<LOGB, LOGE>() && !(INV && A::kMont && !std::is_same<Hook, NoHook>::value);
     const u32 tid = threadIdx.x;
     const u32 sub = Cfg::BPW == 1 ? 0u : tid / Cfg::TPB;
     const u32 lt = Cfg::BPW == 1 ? tid : tid % Cfg::TPB;
@@ -225,19 +228,19 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const u6
         after_stage();
         block_forward_core<A, LOGB, false, LOGE>(ar, x, lds, n, eblk, lt, lazy != 0);
         lds_put_layout<0, LOGE>(x, lds, lt);
-        sync_vectors_layout0<LOGB, LOGE>();  // wave-local: no workgroup barrier (pfhe_ntt_device.hpp, vec_index)
-        lds_get_vectors<LOGB, LOGE>(io, lds, lt);
+        sync_vectors_layout0<LOGB, LOGE, kWL>();  // wave-local: no workgroup barrier (pfhe_ntt_device.hpp, vec_index)
+        lds_get_vectors<LOGB, LOGE, kWL>(io, lds, lt);
         before_store();
 #ifdef PFHE_NOMEM
         if (lazy == 0xdeadu)
 #endif
-        if (valid) store_block_vectors<LOGB, LOGE, kNt>(io, gptr, lt);
+        if (valid) store_block_vectors<LOGB, LOGE, kNt, kWL>(io, gptr, lt);
         return;
     }
     // all global traffic as 16-byte vectors in natural order (1 KiB per wave instruction), staged
     // through LDS into / out of the register layouts of the first / last register pass
     if (valid) {
-        load_block_vectors<LOGB, LOGE, kNt>(io, sgptr, lt);
+        load_block_vectors<LOGB, LOGE, kNt, kWL>(io, sgptr, lt);
     } else {
 #pragma unroll
         for (int j = 0; j < NV; ++j) io[j] = u64x2{0, 0};
@@ -251,7 +254,7 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const u6
         u64x2 mv[NV];
         if (valid) {
             const u64 mpoly = mul_polys == (u64)L ? (u64)limb : pid;
-            load_block_vectors<LOGB, LOGE, kNt>(mv, mul + mpoly * n + eblk, lt);
+            load_block_vectors<LOGB, LOGE, kNt, kWL>(mv, mul + mpoly * n + eblk, lt);
         } else {
 #pragma unroll
             for (int j = 0; j < NV; ++j) mv[j] = u64x2{0, 0};
@@ -262,9 +265,9 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const u6
             io[j].y = ar.mul_any(io[j].y, mv[j].y);
         }
     }
-    lds_put_vectors<LOGB, LOGE>(io, lds, lt);
+    lds_put_vectors<LOGB, LOGE, kWL>(io, lds, lt);
     // inverse: layout <0> reads the vectors of the thread's own wave; forward: layout <LOGB - LOGE> reads every wave's
-    if constexpr (INV) sync_vectors_layout0<LOGB, LOGE>();
+    if constexpr (INV) sync_vectors_layout0<LOGB, LOGE, kWL>();
     else __syncthreads();
     // (inverse: the hook runs in front of the LAST register pass instead — uniform twiddles, the fewest live registers —
     // so that the pipelined kernel's 32 registers of prefetched strided data do not sit through the per-lane-twiddle
@@ -295,11 +298,11 @@ __device__ __forceinline__ void block_pass_body(u64 *__restrict__ data, const u6
         }
         lds_put_layout<LOGB - LOGE, LOGE>(x, lds, lt);
     }
-    if constexpr (!INV) sync_vectors_layout0<LOGB, LOGE>();  // from layout <0>: wave-local
+    if constexpr (!INV) sync_vectors_layout0<LOGB, LOGE, kWL>();  // from layout <0>: wave-local
     else __syncthreads();
-    lds_get_vectors<LOGB, LOGE>(io, lds, lt);
+    lds_get_vectors<LOGB, LOGE, kWL>(io, lds, lt);
     before_store();
-    if (valid) store_block_vectors<LOGB, LOGE, kNt>(io, gptr, lt);
+    if (valid) store_block_vectors<LOGB, LOGE, kNt, kWL>(io, gptr, lt);
 }
 
 
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_wave
                 prefetch();
                 lds_put_layout<0>(x, lds, lt);
             }
-            __syncthreads();
+            sync_vectors_layout0<LOGB>();  // wave-local (vec_index)
             {
                 const u32 lt = opaque_tid();
                 u64x2 io[NV];
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_wave
                 const u32 lt = opaque_tid();
                 if (!first) __syncthreads();  // the previous polynomial's last exchange may still be read
                 lds_put_vectors<LOGB>(io, lds, lt);
-                __syncthreads();
+                sync_vectors_layout0<LOGB>();  // wave-local (vec_index)
                 lds_get_layout<0>(x, lds, lt);
                 block_inverse_core<A, LOGB, false, 4, decltype(prefetch), kPersistInvHook>(ar, x, lds, n, 0u, lt, true, lazy != 0, prefetch);
             }
@@ -492,8 +495,10 @@ __device__ __forceinline__ void ntt_pipe_body(
     // 42 k cycles in round 2's phase stamps: "wait: block stores + strided loads landed").  Touching the chunk's registers
     // in front of the stores moves the wait to a point where only loads are pending — issued twelve stages earlier, long
     // landed — and the stores are then never waited for.
+    // (forward only: the inverse kernels issue the chunk's loads one register pass before the stores — the touch would wait
+    // for them there — and the Montgomery instantiation spills four registers with it; measured: no difference either way)
     const auto landed = [&]() {
-        if (has_str) {
+        if (!INV && has_str) {
 #pragma unroll
             for (int k = 0; k < (1 << K); ++k) asm volatile("" : "+v"(sx[k][0]));
         }
@@ -573,7 +578,9 @@ __device__ __forceinline__ void block_mid_body(const A &ar, u64 *__restrict__ gp
 #pragma unroll
             for (int j = 0; j < NV; ++j) mv[j] = u64x2{0, 0};
         }
-        __syncthreads();
+        // layout <0> <-> I/O vectors: both transpositions stay inside the wave (vec_index, pfhe_ntt_device.hpp): the two
+        // workgroup barriers that stood here until round 4 are wave-level syncs
+        sync_vectors_layout0<LOGB>();
         lds_get_vectors<LOGB>(io, lds, lt);
 #pragma unroll
         for (int j = 0; j < NV; ++j) {  // (outside any `valid` branch: see the note in block_pass_body)
@@ -583,7 +590,7 @@ __device__ __forceinline__ void block_mid_body(const A &ar, u64 *__restrict__ gp
         lds_put_vectors<LOGB>(io, lds, lt);  // the slots this thread just read
     }
     mid();
-    __syncthreads();
+    sync_vectors_layout0<LOGB>();
     {
         const u32 lt = opaque_tid();
         lds_get_layout<0>(x, lds, lt);
@@ -662,7 +669,7 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_wave
             u64x2 io[NV], mv[NV];
             const u64 mpoly = mul_polys == (u64)L ? (u64)limb : p;
             load_block_vectors<LOGB, 4, false>(mv, mul + mpoly * n, lt);
-            __syncthreads();
+            sync_vectors_layout0<LOGB>();  // layout <0> <-> I/O vectors: wave-local both ways (vec_index)
             lds_get_vectors<LOGB>(io, lds, lt);
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
@@ -671,7 +678,7 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_wave
             }
             lds_put_vectors<LOGB>(io, lds, lt);  // the slots this thread just read
         }
-        __syncthreads();
+        sync_vectors_layout0<LOGB>();
         {
             const u32 lt = opaque_tid();
             lds_get_layout<0>(x, lds, lt);
@@ -961,8 +968,6 @@ NttTuning NttTuning::from_env() {
     t.pipe_ramp = env_int("PFHE_PIPE_RAMP", 1, 32);
     t.persist = std::getenv("PFHE_DISABLE_PERSIST") == nullptr;
     t.pipe_u32 = std::getenv("PFHE_PIPE_U32") != nullptr;
-    t.pipe_one_lag = env_int("PFHE_PIPE_ONE", 1, 1 << 24);
-    t.pipe_one_mode = env_int("PFHE_PIPE_ONE_MODE", 0, 3);
     return t;
 }
 
@@ -1162,12 +1167,6 @@ static int transform(const NttPrime *primes, u32 L, u32 log_n, int pm, u64 *data
     const int passes = ntt_num_passes(log_n, pm, tune);
     {
         const int pt = pipelined_tiles(L, log_n, pm, npolys, inverse, mul != nullptr, tune);
-        if (pt >= 1 && pm == kArithPm && !inverse && !mul && tune.pipe_one_lag > 0) {  // experiment: one launch
-            static u32 *flags = nullptr;  // (experiment only: one process-wide buffer, 1 Mi polynomials)
-            if ((tune.pipe_one_mode & 2) && !flags) PFHE_HIP(hipMalloc((void **)&flags, sizeof(u32) << 20));
-            if (tune.pipe_one_mode & 2) PFHE_HIP(hipMemsetAsync(flags, 0, sizeof(u32) * npolys, s));
-            return launch_pipe_one(pm, data, npolys, primes, L, lazy, (u64)tune.pipe_one_lag, tune.pipe_one_mode, flags, s);
-        }
         if (pt >= 1 && pm == kArithB32)
             return transform_pipelined<B32Arith, 11>(primes, L, data, npolys, inverse, lazy, s, pt, tune.pipe_ramp, mul, mul_polys);
         if (pt >= 1 && pm == kArithMont)

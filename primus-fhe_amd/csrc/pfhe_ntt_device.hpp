@@ -33,8 +33,6 @@ struct NttTuning {
     bool pipelined = true;         // PFHE_DISABLE_PIPELINED clears it: N = 2^16 runs as tiles + 1 launches of ntt_pipe_kernel on the caller's stream
     int pipe_ramp = 0;             // PFHE_PIPE_RAMP: tile weights of the pipelined form ramp 1..ramp..1 (0 / 1: equal tiles)
     bool persist = true;           // PFHE_DISABLE_PERSIST clears it: N = 2^13 / 2^14 batches run ntt_persist_kernel (resident workgroups that prefetch their next polynomial)
-    int pipe_one_lag = 0;          // PFHE_PIPE_ONE: experiment — forward N = 2^16 transform as one launch, block pass `lag` workgroups behind
-    int pipe_one_mode = 0;         // PFHE_PIPE_ONE_MODE: bit 0 coherent intermediate, bit 1 per-polynomial flags
     bool pipe_u32 = false;         // PFHE_PIPE_U32: the u32 tables' FORWARD N = 2^16 transforms take the pipelined form too (the inverse ones do by default)
     int pipelined_min_mb = 0;      // PFHE_PIPELINED_MIN_MB: smallest batch (MiB of data) that takes the pipelined form (0: built-in default)
     static NttTuning from_env();
@@ -74,10 +72,6 @@ int ntt_polymul_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *da
 // U32NttTable / U32DcrtTable transforms (log_n = log2 of the polynomial length in coefficients)
 int ntt32_transform_dev(const NttPrime *primes, u32 L, u32 log_n, u32 *data, u64 npolys, bool inverse, bool lazy,
                         hipStream_t s, const NttTuning &tune = NttTuning());
-
-// round-5 experiment (pfhe_ntt_one.hip): the forward pipelined transform as ONE launch
-int launch_pipe_one(int arith, u64 *data, u64 npolys, const NttPrime *primes, u32 L, bool lazy, u64 lag, int mode, u32 *flags,
-                    hipStream_t s);
 
 int ntt_num_passes(u32 log_n, int arith = 0, const NttTuning &tune = NttTuning());
 void ntt_pass_name(u32 log_n, bool inverse, int index, char *buf, size_t cap, int arith = 0,
@@ -1038,15 +1032,17 @@ __host__ __device__ constexpr bool wave_local_vectors() {
     return BlockCfg<LOGB, LOGE>::TPB >= 64;
 #endif
 }
-template <int LOGB, int LOGE = 4>
+// WL: the wave-local assignment (default where it exists); a call site may keep the interleaved one (all of a kernel's
+// calls must agree)
+template <int LOGB, int LOGE = 4, bool WL = wave_local_vectors<LOGB, LOGE>()>
 __device__ __forceinline__ u32 vec_index(u32 lt, int j) {
-    if constexpr (wave_local_vectors<LOGB, LOGE>()) return ((lt >> 6) << (6 + LOGE - 1)) + (lt & 63u) + 64u * (u32)j;
+    if constexpr (WL) return ((lt >> 6) << (6 + LOGE - 1)) + (lt & 63u) + 64u * (u32)j;
     else return lt + (u32)BlockCfg<LOGB, LOGE>::TPB * (u32)j;
 }
 // between an LDS image written in layout <0> and read as I/O vectors, or the other way round
-template <int LOGB, int LOGE = 4>
+template <int LOGB, int LOGE = 4, bool WL = wave_local_vectors<LOGB, LOGE>()>
 __device__ __forceinline__ void sync_vectors_layout0() {
-    if constexpr (wave_local_vectors<LOGB, LOGE>()) {
+    if constexpr (WL) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1055,10 +1051,10 @@ __device__ __forceinline__ void sync_vectors_layout0() {
     }
 }
 
-template <int LOGB, int LOGE = 4, bool NT = false>
+template <int LOGB, int LOGE = 4, bool NT = false, bool WL = wave_local_vectors<LOGB, LOGE>()>
 __device__ __forceinline__ void load_block_vectors(u64x2 (&v)[1 << (LOGE - 1)], const u64 *gptr, u32 lt) {
-    const GCVec2Ptr p = (GCVec2Ptr)(const void *)gptr + vec_index<LOGB, LOGE>(lt, 0);
-    constexpr u32 kStep = wave_local_vectors<LOGB, LOGE>() ? 64u : (u32)BlockCfg<LOGB, LOGE>::TPB;
+    const GCVec2Ptr p = (GCVec2Ptr)(const void *)gptr + vec_index<LOGB, LOGE, WL>(lt, 0);
+    constexpr u32 kStep = WL ? 64u : (u32)BlockCfg<LOGB, LOGE>::TPB;
 #pragma unroll
     for (int j = 0; j < (1 << (LOGE - 1)); ++j) {
         if constexpr (NT) {  // read-once data of a large batch
@@ -1086,10 +1082,10 @@ __device__ __forceinline__ void gstore(T *p, T v) {
 // (a per-launch choice — `if (flag) non-temporal else plain` — does not survive the compiler: it merges the two stores
 // into a plain one; the choice is a template parameter of the kernels that run large batches only)
 
-template <int LOGB, int LOGE = 4, bool NT = false>
+template <int LOGB, int LOGE = 4, bool NT = false, bool WL = wave_local_vectors<LOGB, LOGE>()>
 __device__ __forceinline__ void store_block_vectors(const u64x2 (&v)[1 << (LOGE - 1)], u64 *gptr, u32 lt) {
-    const GVec2Ptr p = (GVec2Ptr)(void *)gptr + vec_index<LOGB, LOGE>(lt, 0);
-    constexpr u32 kStep = wave_local_vectors<LOGB, LOGE>() ? 64u : (u32)BlockCfg<LOGB, LOGE>::TPB;
+    const GVec2Ptr p = (GVec2Ptr)(void *)gptr + vec_index<LOGB, LOGE, WL>(lt, 0);
+    constexpr u32 kStep = WL ? 64u : (u32)BlockCfg<LOGB, LOGE>::TPB;
 #pragma unroll
     for (int j = 0; j < (1 << (LOGE - 1)); ++j) {
         if constexpr (NT) {
@@ -1102,32 +1098,32 @@ __device__ __forceinline__ void store_block_vectors(const u64x2 (&v)[1 << (LOGE 
 
 // vector vec_index(lt, j) holds elements 2v, 2v+1: padded index = lds_phi(2 * vec_index(lt, 0)) + constant(j) once the
 // element step 2 * kStep is a multiple of 16
-template <int LOGB, int LOGE = 4>
+template <int LOGB, int LOGE = 4, bool WL = wave_local_vectors<LOGB, LOGE>()>
 __host__ __device__ constexpr u32 lds_voff(int j) {
-    constexpr u32 kStep = wave_local_vectors<LOGB, LOGE>() ? 64u : (u32)BlockCfg<LOGB, LOGE>::TPB;
+    constexpr u32 kStep = WL ? 64u : (u32)BlockCfg<LOGB, LOGE>::TPB;
     return 2u * kStep * (u32)j + 2u * ((2u * kStep * (u32)j) >> 4);
 }
 
-template <int LOGB, int LOGE = 4>
+template <int LOGB, int LOGE = 4, bool WL = wave_local_vectors<LOGB, LOGE>()>
 __device__ __forceinline__ void lds_put_vectors(const u64x2 (&v)[1 << (LOGE - 1)], u64 *__restrict__ lds, u32 lt) {
     constexpr int NV = 1 << (LOGE - 1), TPB = BlockCfg<LOGB, LOGE>::TPB;
     if constexpr (TPB >= 8) {
-        u64 *__restrict__ base = lds + lds_phi(2 * vec_index<LOGB, LOGE>(lt, 0));
+        u64 *__restrict__ base = lds + lds_phi(2 * vec_index<LOGB, LOGE, WL>(lt, 0));
 #pragma unroll
-        for (int j = 0; j < NV; ++j) *reinterpret_cast<u64x2 *>(base + lds_voff<LOGB, LOGE>(j)) = v[j];
+        for (int j = 0; j < NV; ++j) *reinterpret_cast<u64x2 *>(base + lds_voff<LOGB, LOGE, WL>(j)) = v[j];
     } else {
 #pragma unroll
         for (int j = 0; j < NV; ++j) *reinterpret_cast<u64x2 *>(lds + lds_phi(2 * (lt + TPB * j))) = v[j];
     }
 }
 
-template <int LOGB, int LOGE = 4>
+template <int LOGB, int LOGE = 4, bool WL = wave_local_vectors<LOGB, LOGE>()>
 __device__ __forceinline__ void lds_get_vectors(u64x2 (&v)[1 << (LOGE - 1)], const u64 *__restrict__ lds, u32 lt) {
     constexpr int NV = 1 << (LOGE - 1), TPB = BlockCfg<LOGB, LOGE>::TPB;
     if constexpr (TPB >= 8) {
-        const u64 *__restrict__ base = lds + lds_phi(2 * vec_index<LOGB, LOGE>(lt, 0));
+        const u64 *__restrict__ base = lds + lds_phi(2 * vec_index<LOGB, LOGE, WL>(lt, 0));
 #pragma unroll
-        for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const u64x2 *>(base + lds_voff<LOGB, LOGE>(j));
+        for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const u64x2 *>(base + lds_voff<LOGB, LOGE, WL>(j));
     } else {
 #pragma unroll
         for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const u64x2 *>(lds + lds_phi(2 * (lt + TPB * j)));
