@@ -732,9 +732,12 @@ def main():
             t32.transform_dev(x32)
         torch.cuda.synchronize()
         dt32 = (time.perf_counter() - t0) / reps
+        ms32i = time_ms(lambda: t32.inverse_transform_dev(x32), reps)   # (pipelined form from 1 GiB of data, round 5)
         result["ntt_u32"] = {"value": batch * L / dt32, "unit": "NTT/s (forward limb-NTTs, u32 data, 30-bit primes)",
                              "ms_per_batch": dt32 * 1e3, "moduli": q30,
-                             "hbm_roofline_frac": batch * L / dt32 * 8 * n / (HBM_PEAK_GBS * 1e9)}
+                             "hbm_roofline_frac": batch * L / dt32 * 8 * n / (HBM_PEAK_GBS * 1e9),
+                             "inverse": {"value": batch * L / ms32i * 1e3, "unit": "NTT/s", "ms_per_batch": ms32i,
+                                         "hbm_roofline_frac": batch * L / ms32i * 1e3 * 8 * n / (HBM_PEAK_GBS * 1e9)}}
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
 
