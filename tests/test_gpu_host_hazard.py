@@ -48,3 +48,5 @@ def test_pageable_slices_under_heap_churn_including_the_helper_thread_form():
     under the same churn, four caller threads through the same handles."""
     run(["6000", "--churn-threads", "3", "--seed", "9"])
     run(["600", "--churn-threads", "2", "--seed", "11", "--max-bytes", str(24 << 20), "--callers", "4"])
+    # ADVICE r4: the multi-threaded setting under the debugging allocator, the one that triggered round 4's item 6
+    run(["300", "--churn-threads", "2", "--seed", "13", "--max-bytes", str(24 << 20), "--callers", "4"], {"MALLOC_CHECK_": "3"})

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates primus-fhe_amd/csrc/pfhe_mont_asm.hpp: NTT butterflies for ANY odd prime q < 2^61 as hand-scheduled gfx950
+"""Generates primus-fhe_amd/csrc/pfhe_mont_asm.hpp: NTT butterflies for odd primes 2^48 <= q < 2^61 (any odd q < 2^61 for the butterflies themselves) as hand-scheduled gfx950
 instruction sequences (inline asm with fixed temporaries, same conventions as tools/gen_pm_asm.py).
 
 Arithmetic (MontArith, pfhe_ntt_device.hpp): one-word Montgomery reduction with a split multiplicand.  The table holds
@@ -160,7 +160,7 @@ def gen_mul(uni):
 
 HEADER = '''// pfhe_mont_asm.hpp — GENERATED by tools/gen_mont_asm.py; do not edit by hand.
 //
-// NTT butterflies for any odd prime q < 2^61 (MontArith, pfhe_ntt_device.hpp): twiddles {w*2^32 mod q, w*2^64 mod q},
+// NTT butterflies for odd primes 2^48 <= q < 2^61 (MontArith, pfhe_ntt_device.hpp; the butterflies hold for any odd q < 2^61, the closing quotient-estimate reduction needs q >= 2^48): twiddles {w*2^32 mod q, w*2^64 mod q},
 // T = (y0*wm + y1*wm2 + m*q) / 2^32 < 3q with m = (low word) * (-q^-1) mod 2^32 — seven 32 x 32 multiplies; forward
 // X = x - F if bit 63 of x is set (F = the largest multiple of q below 2^63), x' = X + T, y' = X + 3q - T (below 2^63 + 3q);
 // inverse x' = x + y - F if that is >= F, y' = (x + F - y) * w.
