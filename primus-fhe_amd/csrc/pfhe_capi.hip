@@ -316,8 +316,9 @@ int transform_host(const TableSet &t, u64 *host, size_t len, bool inverse, bool 
         for (hipEvent_t &e : done) PFHE_TRY(st.take_event(&e));
         std::vector<size_t> off(pieces + 1);
         for (size_t i = 0; i <= pieces; ++i) off[i] = (size_t)(units * i / pieces) * unit;
-        // shared with the helper's task; lives until helper_wait() or the HostStage destructor (which runs on_abandon and
-        // waits for the task) — `st` is declared after nothing the task uses, so every exit path is covered
+        // shared with the helper's task: must outlive it on EVERY exit path.  `st` was declared before these locals and is
+        // therefore destroyed after them, so its destructor's own wait would come too late for an exception thrown between
+        // helper_start and helper_wait: the Joiner below, declared after everything the task references, aborts and waits first.
         struct Shared {
             std::mutex mu;
             std::condition_variable cv;
@@ -352,6 +353,19 @@ int transform_host(const TableSet &t, u64 *host, size_t len, bool inverse, bool 
                 sh.abort = true;
                 sh.cv.notify_all();
             }));
+        struct Joiner {
+            HostStage &st;
+            Shared &sh;
+            ~Joiner() {
+                if (!st.helper_busy()) return;
+                {
+                    std::lock_guard<std::mutex> lk(sh.mu);
+                    sh.abort = true;
+                }
+                sh.cv.notify_all();
+                (void)st.helper_wait();
+            }
+        } joiner{st, sh};
         int rc = PFHE_OK;
         for (size_t i = 0; i < pieces && rc == PFHE_OK; ++i) {
             const size_t words = off[i + 1] - off[i];

@@ -103,6 +103,7 @@ class HostStage {
     // std::terminate.
     int helper_start(std::function<int()> task, std::function<void()> on_abandon);
     int helper_wait();
+    bool helper_busy() const { return helper_busy_; }
 
   private:
     void unpin_all();
