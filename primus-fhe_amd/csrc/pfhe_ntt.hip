@@ -968,6 +968,7 @@ NttTuning NttTuning::from_env() {
     t.pipe_ramp = env_int("PFHE_PIPE_RAMP", 1, 32);
     t.persist = std::getenv("PFHE_DISABLE_PERSIST") == nullptr;
     t.pipe_u32 = std::getenv("PFHE_PIPE_U32") != nullptr;
+    t.pipe_lds_extra = env_int("PFHE_PIPE_LDS_EXTRA", 1, 120 << 10);
     return t;
 }
 
@@ -1055,10 +1056,12 @@ constexpr int kPipelinedMaxTiles = 64;
 // the pipelined form of the two-pass transform (ntt_pipe_{fwd,inv}_kernel): tiles + 1 launches on the caller's stream
 template <class A, int LOGB>
 static int transform_pipelined(const NttPrime *primes, u32 L, u64 *data, u64 npolys, bool inverse, bool lazy,
-                               hipStream_t s, int tiles, int ramp, const u64 *mul, u64 mul_polys) {
+                               hipStream_t s, int tiles, int ramp, const u64 *mul, u64 mul_polys, int lds_extra = 0) {
     if (tiles > 64) tiles = 64;
     constexpr u32 log_n = LOGB + 4;
-    constexpr size_t lds_bytes = (size_t)BlockCfg<LOGB>::LDS_WORDS * sizeof(u64);
+    // (PFHE_PIPE_LDS_EXTRA, measurement aid: unused LDS bytes per workgroup, i.e. fewer resident workgroups per CU — the N of
+    // DESIGN.md §5's queueing model made smaller on purpose)
+    const size_t lds_bytes = (size_t)BlockCfg<LOGB>::LDS_WORDS * sizeof(u64) + (size_t)lds_extra;
     constexpr u32 threads = BlockCfg<LOGB>::THREADS;
     const u64 units = npolys / L;
     // tile boundaries: weights ramp up 1, 2, ... ramp and down again (ramp 1 = equal tiles).  The first and the last
@@ -1168,14 +1171,17 @@ static int transform(const NttPrime *primes, u32 L, u32 log_n, int pm, u64 *data
     {
         const int pt = pipelined_tiles(L, log_n, pm, npolys, inverse, mul != nullptr, tune);
         if (pt >= 1 && pm == kArithB32)
-            return transform_pipelined<B32Arith, 11>(primes, L, data, npolys, inverse, lazy, s, pt, tune.pipe_ramp, mul, mul_polys);
+            return transform_pipelined<B32Arith, 11>(primes, L, data, npolys, inverse, lazy, s, pt, tune.pipe_ramp, mul, mul_polys,
+                                                     tune.pipe_lds_extra);
         if (pt >= 1 && pm == kArithMont)
-            return transform_pipelined<MontArith, 12>(primes, L, data, npolys, inverse, lazy, s, pt, tune.pipe_ramp, mul, mul_polys);
+            return transform_pipelined<MontArith, 12>(primes, L, data, npolys, inverse, lazy, s, pt, tune.pipe_ramp, mul, mul_polys,
+                                                      tune.pipe_lds_extra);
         if (pt >= 1)
             return pm == kArithPm
-                       ? transform_pipelined<PmArith, 12>(primes, L, data, npolys, inverse, lazy, s, pt, tune.pipe_ramp, mul, mul_polys)
+                       ? transform_pipelined<PmArith, 12>(primes, L, data, npolys, inverse, lazy, s, pt, tune.pipe_ramp, mul, mul_polys,
+                                                          tune.pipe_lds_extra)
                        : transform_pipelined<ShoupArith, 12>(primes, L, data, npolys, inverse, lazy, s, pt, tune.pipe_ramp, mul,
-                                                             mul_polys);
+                                                             mul_polys, tune.pipe_lds_extra);
     }
     // one launch per pass on the caller's stream
     for (int i = 0; i < passes; ++i)

@@ -33,6 +33,7 @@ struct NttTuning {
     bool pipelined = true;         // PFHE_DISABLE_PIPELINED clears it: N = 2^16 runs as tiles + 1 launches of ntt_pipe_kernel on the caller's stream
     int pipe_ramp = 0;             // PFHE_PIPE_RAMP: tile weights of the pipelined form ramp 1..ramp..1 (0 / 1: equal tiles)
     bool persist = true;           // PFHE_DISABLE_PERSIST clears it: N = 2^13 / 2^14 batches run ntt_persist_kernel (resident workgroups that prefetch their next polynomial)
+    int pipe_lds_extra = 0;        // PFHE_PIPE_LDS_EXTRA: measurement aid — unused LDS bytes per workgroup of the pipelined kernels (fewer resident workgroups per CU)
     bool pipe_u32 = false;         // PFHE_PIPE_U32: the u32 tables' FORWARD N = 2^16 transforms take the pipelined form too (the inverse ones do by default)
     int pipelined_min_mb = 0;      // PFHE_PIPELINED_MIN_MB: smallest batch (MiB of data) that takes the pipelined form (0: built-in default)
     static NttTuning from_env();
