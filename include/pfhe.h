@@ -398,9 +398,10 @@ typedef struct pfhe_extprod_plan pfhe_extprod_plan;
  * Like `&mut DcrtGlevContext` (context/glev.rs:4-10) the plan has ONE holder at a time, and that is enforced: every
  * pfhe_extprod_* call takes the plan for its duration, and a call from a second thread meanwhile returns
  * PFHE_ERR_BAD_ARGUMENT ("plan in use") instead of racing on the digit buffers (pfhe_extprod_plan_in_use reports the
- * flag; one plan per thread).  It is also bound to ONE stream at a time: device-pointer calls return when their kernels
- * are queued, so calls on two different streams would share the digit buffers with no cross-stream dependency — let the
- * first stream finish (or record / wait an event) before using the plan on another. */
+ * flag; one plan per thread).  Streams: device-pointer calls return when their kernels are queued; the plan remembers an event
+ * behind its last call and a call on a DIFFERENT stream first makes that stream wait for it, so using one plan from one
+ * stream after another needs no event handling by the caller (round 5; until then this was the caller's job).  Work
+ * captured into a HIP graph is outside that bookkeeping: do not replay a graph that uses a plan beside other users of it. */
 int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *base, const pfhe_basis *basis,
                              size_t glwe_dimension, size_t chunk, pfhe_extprod_plan **out);
 void pfhe_extprod_plan_destroy(pfhe_extprod_plan *plan);

@@ -28,6 +28,10 @@ struct pfhe_extprod_plan {
     // and profiling entry points call the device ones).
     std::atomic<std::uintptr_t> owner{0};
     int depth = 0;
+    // cross-stream ordering of successive calls (run_product): the event recorded behind the last call's kernels
+    hipEvent_t last_done = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool last_valid = false;
     RnsDev rns{};
     BasisDev basis{};
     u32 k = 1;
@@ -60,7 +64,7 @@ struct pfhe_extprod_plan {
         for (u64 *d : digits)
             if (d) (void)counted_free(d);
         if (sdigits) (void)counted_free(sdigits);
-        for (hipEvent_t e : {fork, join_a, join_b, produced[0], produced[1], consumed[0], consumed[1]})
+        for (hipEvent_t e : {fork, join_a, join_b, produced[0], produced[1], consumed[0], consumed[1], last_done})
             if (e) (void)hipEventDestroy(e);
         if (sa) (void)hipStreamDestroy(sa);
         if (sb) (void)hipStreamDestroy(sb);
@@ -115,9 +119,8 @@ class PlanLease {
 // transform this function already ran on the result: -1 = all of them (small-ring kernel), 1 = the block pass
 // (fused into the multiply-accumulate kernel; the caller runs the remaining strided pass), 0 = none.
 // `big_input`: the input polynomials are BigUintPolynomials (value_len limbs per coefficient) instead of CRT ones.
-int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 *keys, bool keys_shared, u64 *result,
-                u64 batch, bool accumulate, hipStream_t s, bool into_coeff = false, int *coeff_passes = nullptr,
-                bool big_input = false) {
+int run_product_impl(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 *keys, bool keys_shared, u64 *result,
+                     u64 batch, bool accumulate, hipStream_t s, bool into_coeff, int *coeff_passes, bool big_input) {
     if (coeff_passes) *coeff_passes = 0;
     const TableSet &t = *p->table;
     const u64 W = (u64)t.L * t.n;
@@ -233,6 +236,32 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
         PFHE_HIP(hipStreamWaitEvent(s, p->join_b, 0));
     }
     return PFHE_OK;
+}
+
+
+// The plan's digit buffers are touched by run_product_impl only.  Successive calls on DIFFERENT streams are ordered here:
+// every call records the plan's `last_done` event behind its last kernel, and a call on another stream first makes that
+// stream wait for it — so "one plan, used from one stream after another" needs no event handling by the caller (calls by
+// two THREADS at once are refused by the lease above; work captured into a HIP graph is outside this bookkeeping: a
+// capturing stream neither waits nor records, and a graph that uses a plan must not be replayed beside other users of it).
+int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 *keys, bool keys_shared, u64 *result,
+                u64 batch, bool accumulate, hipStream_t s, bool into_coeff = false, int *coeff_passes = nullptr,
+                bool big_input = false) {
+    const bool tracked = p->last_done != nullptr && !stream_is_capturing(s);
+    if (tracked && p->last_valid && p->last_stream != s) PFHE_HIP(hipStreamWaitEvent(s, p->last_done, 0));
+    const int rc = run_product_impl(p, crt_polys, rows, keys, keys_shared, result, batch, accumulate, s, into_coeff, coeff_passes,
+                                    big_input);
+    if (tracked) {  // also after a failed call: whatever it queued still uses the buffers
+        if (hipEventRecord(p->last_done, s) == hipSuccess) {
+            p->last_stream = s;
+            p->last_valid = true;
+        } else {
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(s);  // no event: fall back to draining the stream
+            p->last_valid = false;
+        }
+    }
+    return rc;
 }
 
 }  // namespace
@@ -650,6 +679,7 @@ int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *rns, const 
     PFHE_HIP(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
     PFHE_HIP(hipEventCreateWithFlags(&p->join_a, hipEventDisableTiming));
     PFHE_HIP(hipEventCreateWithFlags(&p->join_b, hipEventDisableTiming));
+    PFHE_HIP(hipEventCreateWithFlags(&p->last_done, hipEventDisableTiming));
     *out = p.release();
     return PFHE_OK;
     PFHE_GUARD_END

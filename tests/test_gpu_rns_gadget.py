@@ -601,3 +601,28 @@ def test_plan_has_one_holder_at_a_time(pf, orc):
     stop.set(); tw.join()
     assert seen and lib.pfhe_extprod_plan_in_use(ctx._h) == 0
     assert np.array_equal(out_b, exp)
+
+
+def test_plan_used_from_one_stream_after_another_is_ordered_by_the_library(pf, orc):
+    """A plan's digit buffers are shared by all its calls.  Two products queued back to back on two DIFFERENT streams (no
+    event handling by the caller, no synchronisation in between): the library makes the second stream wait for the first
+    call's kernels (run_product, csrc/pfhe_capi_rns.hip).  Both results must be the oracle's — a long first call (chunks of
+    2 ciphertexts, 24 of them) that is still running when the second is queued."""
+    import torch
+    log_n, k = 14, 1
+    rng = np.random.default_rng(78)
+    otable, g1, ggsw, e1 = make_case(orc, rng, log_n, k, Q61, 30, None, 24, True)
+    _, g2, ggsw2, e2 = make_case(orc, rng, log_n, k, Q61, 30, None, 3, True)
+    table, base = pf.U64DcrtTable(log_n, Q61), pf.RNSBase(Q61)
+    ctx = pf.DcrtGlevContext(table, base, pf.BigUintApproxSignedBasis(base, 30), k, 2)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    d1, dk1, d2, dk2 = to_dev(g1), to_dev(ggsw), to_dev(g2), to_dev(ggsw2)
+    o1, o2 = torch.empty_like(d1), torch.empty_like(d2)
+    torch.cuda.synchronize()
+    for _ in range(5):
+        pf.mul_dcrt_ggsw_to_dev(d1, dk1, o1, ctx, stream=s1.cuda_stream)
+        pf.mul_dcrt_ggsw_to_dev(d2, dk2, o2, ctx, stream=s2.cuda_stream)   # other stream, same plan, nothing in between
+        pf.mul_dcrt_ggsw_to_dev(d1, dk1, o1, ctx, stream=s1.cuda_stream)   # and back
+        s1.synchronize(); s2.synchronize()
+        assert np.array_equal(to_host(o1), e1)
+        assert np.array_equal(to_host(o2), e2)
