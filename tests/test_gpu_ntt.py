@@ -998,3 +998,24 @@ def test_fused_polymul_contract_canonical_multiplicand_at_its_extremes(pf, orc, 
                 x = to_dev(data.copy())
                 d.mul_dcrt_polynomial_dev(x, to_dev(m))
                 assert np.array_equal(to_host(x), ref)
+
+
+def test_pipelined_form_with_fewer_resident_workgroups_is_the_same_transform(pf, monkeypatch):
+    """PFHE_PIPE_LDS_EXTRA (measurement aid of DESIGN.md §5: unused LDS per workgroup of the pipelined kernels, i.e. three or
+    two resident workgroups per CU instead of four) changes residency, never results."""
+    import torch
+    log_n, L, batch = 16, 3, 171
+    n = 1 << log_n
+    t = pf.U64DcrtTable(log_n, Q61)
+    x = _fill(pf, batch * L * n, Q61, n, 4242)
+    ref = x.clone()
+    t.transform_dev(ref)
+    for extra in (12288, 28672):
+        monkeypatch.setenv("PFHE_PIPE_LDS_EXTRA", str(extra))
+        t2 = pf.U64DcrtTable(log_n, Q61)
+        assert t2.transform_form(batch * L * n)[0] == "ntt_pipe_fwd_kernel"
+        y = x.clone()
+        t2.transform_dev(y)
+        assert torch.equal(y, ref)
+        t2.inverse_transform_dev(y)
+        assert torch.equal(y, x)
