@@ -371,7 +371,8 @@ class BigUintApproxSignedBasis {
 };
 
 // DcrtGlevContext (crates/primus_lattice/src/context/glev.rs:4-68) + the handles the reference
-// passes next to it; one per stream, not concurrently usable.
+// passes next to it.  One holder at a time, like the `&mut` it mirrors: a call from a second thread while one is inside throws
+// (PFHE_ERR_BAD_ARGUMENT, "plan in use"); successive calls on different streams are ordered by the library.
 class DcrtGlevContext {
   public:
     DcrtGlevContext(const U64DcrtTable &table, const RNSBase &base, const BigUintApproxSignedBasis &basis,
@@ -382,6 +383,7 @@ class DcrtGlevContext {
     DcrtGlevContext(const DcrtGlevContext &) = delete;
     DcrtGlevContext &operator=(const DcrtGlevContext &) = delete;
     pfhe_extprod_plan *handle() const { return h_; }
+    bool in_use() const { return pfhe_extprod_plan_in_use(h_) != 0; }  // some thread is inside a call on this context
 
   private:
     pfhe_extprod_plan *h_ = nullptr;

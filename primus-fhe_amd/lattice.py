@@ -20,7 +20,9 @@ from .rns import BigUintApproxSignedBasis, RNSBase
 
 class DcrtGlevContext:
     """Working context of the external product (context/glev.rs:4-68): bundles basis, table and
-    RNS base and owns the device scratch; use one per stream/thread (it is `&mut` in the reference)."""
+    RNS base and owns the device scratch.  It is `&mut` in the reference; here it has one holder at a time: a call from a
+    second thread while one is inside raises PfheError (BadArgument, "plan in use"); successive calls on different streams
+    are ordered by the library."""
 
     def __init__(self, table: U64DcrtTable, rns_base: RNSBase, basis: BigUintApproxSignedBasis,
                  glwe_dimension: int = 1, chunk: int = 0):
@@ -37,6 +39,10 @@ class DcrtGlevContext:
 
     def scratch_bytes(self) -> int:
         return int(lib().pfhe_extprod_plan_scratch_bytes(self._h))
+
+    def in_use(self) -> bool:
+        """True while some thread is inside a call on this context."""
+        return bool(lib().pfhe_extprod_plan_in_use(self._h))
 
     def glwe_len(self) -> int:
         return (self.glwe_dimension + 1) * self.table.crt_poly_length()
