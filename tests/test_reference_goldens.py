@@ -280,3 +280,47 @@ def test_consumer_runs_the_hip_backend_on_a_handmade_file(orc, tmp_path):
     f.write_text(json.dumps(doc))
     problems, _ = check_reference_file(str(f), HipBackend(pf))
     assert problems == []
+
+
+def test_rust_generator_and_python_consumer_list_the_same_cases():
+    """integration/emit_golden/src/main.rs cannot be compiled here; what CAN be checked is that its case tables are the ones
+    the consumer regenerates (shapes, moduli, batches, seeds) — a drifted table would produce a reference file whose entries
+    the tests then recompute from other inputs."""
+    import re
+    src = open(os.path.join(os.path.dirname(HERE), "integration", "emit_golden", "src", "main.rs")).read()
+    consts = {"Q62": pyref.Q62, "Q61[0]": Q61[0], "Q61[1]": Q61[1], "Q61[2]": Q61[2]}
+    assert f"const Q62: u64 = {pyref.Q62};" in src
+    assert "const Q61: [u64; 3] = [%s];" % ", ".join(str(q) for q in Q61) in src
+    assert "0x5EED_0000_0000_0000" in src and "0x9E37_79B9_7F4A_7C15" in src      # the SplitMix64 stream of golden_inputs.py
+
+    def tuples(pattern):
+        m = re.search(pattern + r"\s*\[(.*?)\]\s*(?:;|\.iter\(\))", src, re.S)
+        assert m, pattern
+        body = m.group(1)
+        for k, v in consts.items():
+            body = body.replace(k, str(v))
+        body = re.sub(r"(\d)(u32|u64|usize)", r"\1", body)
+        return [tuple(int(x) for x in t.split(",")) for t in re.findall(r"\(([^()]*)\)", body)]
+
+    committed = json.load(open(os.path.join(HERE, "golden", "digests.json")))
+    ntt = tuples(r"let ntt_cases: \[\(u32, u64, usize\); 6\] =\s*")
+    assert ntt == [(d["log_n"], int(d["q"]), d["batch"]) for d in committed if d["kind"] == "ntt_forward"]
+    assert all(d["seed"] == 0x500 + d["case"] for d in committed if d["kind"] == "ntt_forward") and "0x500 + cid as u64" in src
+    poly = tuples(r"for \(cid, &\(log_n, batch\)\) in ")
+    assert poly == [(d["log_n"], d["batch"]) for d in committed if d["kind"] == "dcrt_polymul"]
+    assert "(0x600 + cid as u64, 0x610 + cid as u64)" in src
+    assert all((d["seed_a"], d["seed_b"]) == (0x600 + d["case"], 0x610 + d["case"]) for d in committed if d["kind"] == "dcrt_polymul")
+    ext = tuples(r"for \(cid, &\(log_n, k, log_basis, batch\)\) in ")
+    assert ext == [(d["log_n"], d["k"], d["log_basis"], d["batch"]) for d in committed if d["kind"] == "external_product"]
+    assert "(0x700 + cid as u64, 0x710 + cid as u64)" in src
+    assert all((d["seed_glwe"], d["seed_ggsw"]) == (0x700 + d["case"], 0x710 + d["case"])
+               for d in committed if d["kind"] == "external_product")
+    u32 = tuples(r"for \(cid, &\(log_n, q, batch\)\) in ")
+    assert u32 == [(c["log_n"], int(c["q"]), c["batch"]) for c in EXTRA_CASES if c["kind"] == "ntt32_forward"]
+    assert "0x810 + cid as u64" in src and all(c["seed"] == 0x810 + c["case"] for c in EXTRA_CASES if c["kind"] == "ntt32_forward")
+    gad = tuples(r"for \(cid, &\(log_basis, count\)\) in ")
+    assert gad == [(c["log_basis"], c["count"]) for c in EXTRA_CASES if c["kind"] == "gadget_digits"]
+    assert "0x300 + 0x40 + cid as u64" in src and all(c["seed"] == 0x340 + c["case"] for c in EXTRA_CASES if c["kind"] != "ntt32_forward")
+    # every kind the generator writes is one the consumer knows
+    kinds = set(re.findall(r'\\"kind\\": \\"([a-z0-9_]+)\\"', src))
+    assert kinds == {"ntt_forward", "dcrt_polymul", "external_product", "ntt32_forward", "rns_compose", "gadget_digits"}
