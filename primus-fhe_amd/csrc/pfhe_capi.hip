@@ -35,6 +35,10 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
 }
 
 DeviceGuard::DeviceGuard(int device) {
+    // hipGetLastError() is per host thread and sticky: an error the CALLER's own earlier HIP call left behind (a refused
+    // hipHostRegister, say) would otherwise be reported by the first launch check of this entry point as if a kernel of
+    // this library had failed (found by tools/hazard_suite_probe.sh, round 5).  Every entry point starts from a clean slate.
+    (void)hipGetLastError();
     if (hipGetDevice(&prev) != hipSuccess) {
         prev = -1;
         (void)hipGetLastError();

@@ -967,7 +967,7 @@ NttTuning NttTuning::from_env() {
     t.pipelined_min_mb = env_int("PFHE_PIPELINED_MIN_MB", 1, 1 << 20);
     t.pipe_ramp = env_int("PFHE_PIPE_RAMP", 1, 32);
     t.persist = std::getenv("PFHE_DISABLE_PERSIST") == nullptr;
-    t.pipe_u32 = std::getenv("PFHE_PIPE_U32") != nullptr;
+    t.pipe_u32 = std::getenv("PFHE_NO_PIPE_U32") == nullptr;
     t.pipe_lds_extra = env_int("PFHE_PIPE_LDS_EXTRA", 1, 120 << 10);
     return t;
 }
@@ -1134,8 +1134,9 @@ static int pipelined_tiles(u32 L, u32 log_n, int pm, u64 npolys, bool inverse, b
     // 64-bit tables, N = 2^16 = 2^4 x 2^12.  (The u32 tables' 2^15 words = 2^4 x 2^11 fit the same kernel template; measured
     // 2.858 ms against 2.866-2.874 ms for their two plain launches per 12 288 transforms: not instantiated.)
     // u32 tables: 2^15 words = 2^4 x 2^11, the same kernel template with 128-thread workgroups.  Round 5, 12 288 transforms,
-    // same box: INVERSE 2.594 -> 2.462-2.499 ms (6 / 12 tiles), taken by default; forward 2.468 -> 2.473 ms (its kernel
-    // needs 128 registers + 28 bytes of scratch), left on the two plain launches unless PFHE_PIPE_U32 is set.
+    // same box: INVERSE 2.594 -> 2.462-2.499 ms (6 / 12 tiles); forward 2.512-2.527 -> 2.472-2.480 ms once the wave-local
+    // I/O vectors had brought its kernel from 128 registers + 28 bytes of scratch to 120 and none (before that: 2.468 ->
+    // 2.473, not taken).  Both directions take it by default; PFHE_NO_PIPE_U32 keeps the forward one on two plain launches.
     const bool shape = (pm != kArithB32 && log_n == 16 && make_ntt_plan(log_n, pm, tune).block_log == 12) ||
                        (pm == kArithB32 && (inverse || tune.pipe_u32) && log_n == 15 &&
                         make_ntt_plan(log_n, pm, tune).block_log == 11);

@@ -34,7 +34,7 @@ struct NttTuning {
     int pipe_ramp = 0;             // PFHE_PIPE_RAMP: tile weights of the pipelined form ramp 1..ramp..1 (0 / 1: equal tiles)
     bool persist = true;           // PFHE_DISABLE_PERSIST clears it: N = 2^13 / 2^14 batches run ntt_persist_kernel (resident workgroups that prefetch their next polynomial)
     int pipe_lds_extra = 0;        // PFHE_PIPE_LDS_EXTRA: measurement aid — unused LDS bytes per workgroup of the pipelined kernels (fewer resident workgroups per CU)
-    bool pipe_u32 = false;         // PFHE_PIPE_U32: the u32 tables' FORWARD N = 2^16 transforms take the pipelined form too (the inverse ones do by default)
+    bool pipe_u32 = true;          // the u32 tables' FORWARD N = 2^16 transforms take the pipelined form like the inverse ones (PFHE_NO_PIPE_U32: two plain launches)
     int pipelined_min_mb = 0;      // PFHE_PIPELINED_MIN_MB: smallest batch (MiB of data) that takes the pipelined form (0: built-in default)
     static NttTuning from_env();
 };

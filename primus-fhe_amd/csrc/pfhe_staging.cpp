@@ -53,6 +53,10 @@ const StageKnobs &stage_knobs() {
         v.idle_max = env_bytes("PFHE_STAGE_IDLE_MAX", 4);
         // pieces the helper thread stays behind the copying thread (1: never a page in common in flight; 0: round 4's order)
         v.helper_lag = env_bytes("PFHE_STAGE_LAG", 1) ? 1 : 0;
+        // OPT-IN: register the caller's pageable slice for the duration of a call (round 4's withdrawn default, 45 us per
+        // 2^16-point transform instead of 62; round 5 could not make it fail — r05_experiments.txt item 7 — but the cause of
+        // round 4's rare wrong words was never established, so it stays off unless asked for)
+        v.register_pageable = env_bytes("PFHE_STAGE_REGISTER_PAGEABLE", 0) != 0;
         return v;
     }();
     return k;
@@ -161,7 +165,7 @@ struct StageCtx {
     struct Range {
         char *p;
         size_t bytes;
-        bool owned;  // (always false: nothing is registered here, see HostStage::pin)
+        bool owned;  // registered by the library for this call (opt-in PFHE_STAGE_REGISTER_PAGEABLE; see HostStage::pin)
     };
     std::vector<Range> registered;  // ranges of this call that lie in memory the caller pinned
     std::vector<hipEvent_t> events;  // pooled, timing disabled
@@ -261,6 +265,16 @@ bool HostStage::pin(const void *host, size_t bytes, bool any_size) {
     hipPointerAttribute_t at{};
     if (hipPointerGetAttributes(&at, h) != hipSuccess || at.type != hipMemoryTypeHost) {
         (void)hipGetLastError();
+        // pageable memory.  Opt-in only: pin it in place for this call (unpin_all releases it once the streams are idle).
+        // A refusal — pages already held by another registration, a read-only mapping — sends the caller to the bounce /
+        // pageable path like any unpinned slice.
+        if (K.register_pageable && bytes >= ((size_t)4 << 10) &&
+            hipHostRegister(h, bytes, hipHostRegisterDefault) == hipSuccess) {
+            ctx_->registered.push_back(StageCtx::Range{h, bytes, true});
+            stage_path_note(kPathLibRegistered);
+            return true;
+        }
+        (void)hipGetLastError();
         return false;
     }
     // The whole range must lie inside ONE pinned allocation / registration: pinned first and last bytes can belong to two
@@ -306,7 +320,11 @@ void *HostStage::bounce(size_t bytes, void **dev) {
     return b;
 }
 
-void HostStage::unpin_all() { ctx_->registered.clear(); }
+void HostStage::unpin_all() {
+    for (const StageCtx::Range &r : ctx_->registered)
+        if (r.owned && hipHostUnregister(r.p) != hipSuccess) (void)hipGetLastError();
+    ctx_->registered.clear();
+}
 
 int HostStage::take_event(hipEvent_t *out) {
     if (ctx_->events_used == ctx_->events.size()) {

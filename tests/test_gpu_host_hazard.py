@@ -50,3 +50,12 @@ def test_pageable_slices_under_heap_churn_including_the_helper_thread_form():
     run(["600", "--churn-threads", "2", "--seed", "11", "--max-bytes", str(24 << 20), "--callers", "4"])
     # the multi-threaded setting under the debugging allocator, the one that triggered round 4's item 6
     run(["300", "--churn-threads", "2", "--seed", "13", "--max-bytes", str(24 << 20), "--callers", "4"], {"MALLOC_CHECK_": "3"})
+
+
+def test_library_side_registration_is_opt_in_and_exact_when_asked_for():
+    """PFHE_STAGE_REGISTER_PAGEABLE=1 (off by default — DESIGN.md §5 says why) makes the library register a pageable slice
+    for its call, as round 4's did: path counter 5 moves, every word still matches; without the variable it never moves."""
+    on = run(["1500", "--churn-threads", "2", "--seed", "17"], {"PFHE_STAGE_REGISTER_PAGEABLE": "1"})
+    assert eval(on.split("staging paths ")[1])[5] > 1000, on
+    off = run(["300", "--churn-threads", "2", "--seed", "17"], {"PFHE_STAGE_REGISTER_PAGEABLE": "0"})
+    assert eval(off.split("staging paths ")[1])[5] == 0, off

@@ -151,5 +151,6 @@ for th in churners:
     th.join()
 print(f"{args.iters * max(1, args.callers)} calls in {dt:.1f} s, {bad} mismatches, {registered_calls} caller-registered ({zero_copy_calls} of them on the "
       f"zero-copy kernels), churn threads {args.churn_threads} (damaged blocks {sum(damaged)}), alloc events "
-      f"{p.lib().pfhe_debug_alloc_count()}")
+      f"{p.lib().pfhe_debug_alloc_count()}, staging paths "
+      f"{[int(p.lib().pfhe_debug_stage_path_count(w)) for w in range(6)]}")
 sys.exit(1 if bad or sum(damaged) else 0)
