@@ -80,10 +80,13 @@ int pfhe_stream_synchronize(int device, void *stream);
  * steady-state loop must not move it).  pfhe_staging_release: frees the idle contexts of `device` (-1: all devices),
  * returns their number (at most PFHE_STAGE_IDLE_MAX, default 4, are kept per device anyway).
  * pfhe_debug_stage_path_count(which): host-pointer calls that took path `which` since the library was loaded —
- * 0 kernels on memory the CALLER pinned, 1 kernels on the pool's own pinned buffer, 2 copy engines on caller-pinned
- * memory, 3 the runtime's pageable copies, 4 long pageable slices with the copy back on the context's helper thread, 5 pageable
- * slices the library registered for the call (opt-in: PFHE_STAGE_REGISTER_PAGEABLE=1 in the environment when the library is
- * loaded; off by default — round 4 withdrew it as a default for rare wrong words of unestablished cause).
+ * 0 kernels on pinned memory the caller ALLOCATED (hipHostMalloc, a torch pinned tensor), 1 kernels on the pool's own pinned
+ * buffer (pageable slices, and since round 5 slices the caller merely REGISTERED with hipHostRegister: kernels running on a
+ * per-call registration return rare wrong words on this platform with plain HIP alone — tools/microbench12_register_hazard.hip),
+ * 2 copy engines on caller-pinned memory (allocated or registered), 3 the runtime's pageable copies, 4 long pageable slices
+ * with the copy back on the context's helper thread.
+ * Every entry point clears the calling thread's pending HIP error (hipGetLastError is sticky per thread) on the way in, so
+ * that an earlier failed HIP call of the caller's own is not reported as a failure of this library's launches.
  * Streams: since round 4 the host-pointer entry points run on PRIVATE non-blocking streams of the borrowed context, not on
  * the legacy null stream: they are ordered with respect to nothing the caller has queued elsewhere (they block until
  * their own work is done, which is all `&mut [T]` semantics need). */

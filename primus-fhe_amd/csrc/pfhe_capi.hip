@@ -312,7 +312,8 @@ int transform_host(const TableSet &t, u64 *host, size_t len, bool inverse, bool 
     // a page in common in flight (the withdrawn registration of round 4 — r04_experiments.txt item 6 — is the reason to be
     // strict about who maps the caller's pages when).
     const StageKnobs &K = stage_knobs();
-    if (!pinned && K.helper_thread && units >= 2 && len * sizeof(u64) >= ((size_t)8 << 20)) {
+    if (!pinned && K.helper_thread && units >= 2 && len * sizeof(u64) >= ((size_t)8 << 20) &&
+        !st.touches_pinned(host, len * sizeof(u64))) {  // (a partly registered slice: copy_in / download stage it)
         // pieces of at least 6 MiB, at most eight (24 MiB: 2 / 3 / 4 / 6 / 8 pieces 861 / 829 / 808 / 855 / 844 us;
         // 96 MiB: 3.01 / 2.77 / 2.74 / 2.54 / 2.54 ms; one thread: 0.95 / 3.67 ms)
         const size_t pieces = std::max<size_t>(2, std::min<size_t>({K.pieces, (size_t)units, len * sizeof(u64) / ((size_t)6 << 20)}));

@@ -53,10 +53,6 @@ const StageKnobs &stage_knobs() {
         v.idle_max = env_bytes("PFHE_STAGE_IDLE_MAX", 4);
         // pieces the helper thread stays behind the copying thread (1: never a page in common in flight; 0: round 4's order)
         v.helper_lag = env_bytes("PFHE_STAGE_LAG", 1) ? 1 : 0;
-        // OPT-IN: register the caller's pageable slice for the duration of a call (round 4's withdrawn default, 45 us per
-        // 2^16-point transform instead of 62; round 5 could not make it fail — r05_experiments.txt item 7 — but the cause of
-        // round 4's rare wrong words was never established, so it stays off unless asked for)
-        v.register_pageable = env_bytes("PFHE_STAGE_REGISTER_PAGEABLE", 0) != 0;
         return v;
     }();
     return k;
@@ -165,7 +161,7 @@ struct StageCtx {
     struct Range {
         char *p;
         size_t bytes;
-        bool owned;  // registered by the library for this call (opt-in PFHE_STAGE_REGISTER_PAGEABLE; see HostStage::pin)
+        bool owned;  // (always false: nothing is registered here, see HostStage::pin)
     };
     std::vector<Range> registered;  // ranges of this call that lie in memory the caller pinned
     std::vector<hipEvent_t> events;  // pooled, timing disabled
@@ -252,7 +248,8 @@ HostStage::HostStage(int device) {
 // caller) needs nothing; a refusal (read-only mapping, pages held by another registration) sends the caller to the
 // bounce / pageable path.
 // Memory the CALLER has pinned (hipHostMalloc, hipHostRegister, a torch pinned tensor) is copied from / to by true
-// asynchronous DMA and may be handed to kernels as it is.  Pageable memory is NOT registered here: round 4 tried
+// asynchronous DMA; only driver-allocated pinned memory is also handed to kernels as it is (map() below).  Pageable memory
+// is NOT registered here: round 4 tried
 // (hipHostRegister on the slice for the duration of the call, 1.1 us on this platform, kernels reading and writing the
 // mapped range) and got rare wrong words and host-heap corruption under a debugging allocator
 // (profiles/r04_experiments.txt, item 6) — pageable slices go through the pool's own pinned buffer instead.
@@ -264,16 +261,6 @@ bool HostStage::pin(const void *host, size_t bytes, bool any_size) {
     if (bytes == 0 || !K.use_register || (!any_size && bytes < K.register_min)) return false;
     hipPointerAttribute_t at{};
     if (hipPointerGetAttributes(&at, h) != hipSuccess || at.type != hipMemoryTypeHost) {
-        (void)hipGetLastError();
-        // pageable memory.  Opt-in only: pin it in place for this call (unpin_all releases it once the streams are idle).
-        // A refusal — pages already held by another registration, a read-only mapping — sends the caller to the bounce /
-        // pageable path like any unpinned slice.
-        if (K.register_pageable && bytes >= ((size_t)4 << 10) &&
-            hipHostRegister(h, bytes, hipHostRegisterDefault) == hipSuccess) {
-            ctx_->registered.push_back(StageCtx::Range{h, bytes, true});
-            stage_path_note(kPathLibRegistered);
-            return true;
-        }
         (void)hipGetLastError();
         return false;
     }
@@ -295,8 +282,24 @@ bool HostStage::pin(const void *host, size_t bytes, bool any_size) {
     return true;
 }
 
+// Device-side address of caller memory that KERNELS may read and write in place — only memory the DRIVER allocated pinned
+// (hipHostMalloc; a torch pinned tensor).  Memory that is merely REGISTERED (hipHostRegister: a userptr mapping of pages the
+// host kernel still owns) is not handed to kernels: tools/microbench12_register_hazard.hip — plain HIP, no code of this
+// library — registers a heap block, runs a kernel on the mapped range and unregisters it, between pageable hipMemcpy's of the
+// same block, and on two MI355X hosts out of three finds 7-10 blocks in 10 000 with wrong words (part of them the values
+// from before the kernel, at reused heap addresses under MALLOC_CHECK_=3); never on hipHostMalloc memory, never through the
+// copy engines (profiles/r05_microbench12_register_hazard.txt).  That is round 4's "rare wrong words" (r04_experiments.txt
+// item 6), reproduced this round from the caller's side inside the full test suite (tools/hazard_suite_probe.sh).
+// hipHostGetFlags tells the two apart on this runtime: it succeeds for hipHostMalloc memory and fails for a registration
+// (tools/probe_host_kinds.hip; every other attribute — type, device pointer, range — reads the same for both).  A registered
+// slice takes the pool's own pinned buffer (short) or the copy engines (long) instead.
 void *HostStage::map(void *host, size_t bytes) {
     if (!pin(host, bytes, true)) return nullptr;
+    unsigned flags = 0;
+    if (hipHostGetFlags(&flags, host) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
     void *d = nullptr;
     if (hipHostGetDevicePointer(&d, host, 0) != hipSuccess) {
         (void)hipGetLastError();
@@ -320,11 +323,20 @@ void *HostStage::bounce(size_t bytes, void **dev) {
     return b;
 }
 
-void HostStage::unpin_all() {
-    for (const StageCtx::Range &r : ctx_->registered)
-        if (r.owned && hipHostUnregister(r.p) != hipSuccess) (void)hipGetLastError();
-    ctx_->registered.clear();
+// true when the first or the last byte of the range is pinned memory (for a range pin() has refused: it lies PARTLY inside
+// registrations; the runtime copies such a range neither as pinned nor as pageable memory — see staged_copy)
+bool HostStage::touches_pinned(const void *host, size_t bytes) {
+    if (bytes == 0) return false;
+    const char *h = static_cast<const char *>(host);
+    for (const char *p : {h, h + bytes - 1}) {
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost) return true;
+        (void)hipGetLastError();
+    }
+    return false;
 }
+
+void HostStage::unpin_all() { ctx_->registered.clear(); }
 
 int HostStage::take_event(hipEvent_t *out) {
     if (ctx_->events_used == ctx_->events.size()) {
@@ -445,7 +457,30 @@ int HostStage::copy_in(void *dev, const void *host, size_t bytes, hipStream_t s)
         return PFHE_OK;
     }
     stage_path_note(kPathPageable);
-    PFHE_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s));
+    if (hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s) == hipSuccess) return PFHE_OK;
+    (void)hipGetLastError();
+    return staged_copy(dev, const_cast<void *>(host), bytes, true, s);
+}
+
+// Last resort for a range the runtime refuses to copy as one piece — a slice that lies partly inside registrations of the
+// caller's (two adjacent registrations, a partly registered array) is neither pinned nor pageable to hipMemcpyAsync and comes
+// back as "invalid argument": the CPU moves it through one chunk of the pool's pinned buffer at a time, synchronously.
+int HostStage::staged_copy(void *dev, void *host, size_t bytes, bool to_device, hipStream_t s) {
+    const size_t chunk = std::min(bytes, std::max<size_t>(stage_knobs().bounce_max, (size_t)64 << 10));
+    void *b = nullptr;
+    PFHE_HIP(ctx_->pin.get(chunk, &b));
+    for (size_t off = 0; off < bytes; off += chunk) {
+        const size_t n = std::min(chunk, bytes - off);
+        if (to_device) {
+            std::memcpy(b, static_cast<char *>(host) + off, n);
+            PFHE_HIP(hipMemcpyAsync(static_cast<char *>(dev) + off, b, n, hipMemcpyHostToDevice, s));
+            PFHE_HIP(hipStreamSynchronize(s));
+        } else {
+            PFHE_HIP(hipMemcpyAsync(b, static_cast<char *>(dev) + off, n, hipMemcpyDeviceToHost, s));
+            PFHE_HIP(hipStreamSynchronize(s));
+            std::memcpy(static_cast<char *>(host) + off, b, n);
+        }
+    }
     return PFHE_OK;
 }
 
@@ -469,8 +504,9 @@ int HostStage::download(void *host, const void *dev, size_t bytes, hipStream_t s
         ctx_->pending.push_back(StageCtx::Pending{host, b, bytes});
         return PFHE_OK;
     }
-    PFHE_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s));
-    return PFHE_OK;
+    if (hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s) == hipSuccess) return PFHE_OK;
+    (void)hipGetLastError();
+    return staged_copy(const_cast<void *>(dev), host, bytes, false, s);
 }
 
 int HostStage::finish() {

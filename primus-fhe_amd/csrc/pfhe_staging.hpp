@@ -35,12 +35,10 @@ std::uint64_t alloc_event_count();
 
 // Environment knobs of the staging layer, parsed ONCE by one parser (a malformed value gives the built-in default
 // everywhere): PFHE_STAGE_BOUNCE_MAX, PFHE_STAGE_CACHE_MAX, PFHE_STAGE_REGISTER, PFHE_STAGE_REGISTER_MIN,
-// PFHE_STAGE_CHUNK, PFHE_STAGE_ZERO_COPY, PFHE_STAGE_THREADS, PFHE_STAGE_PIECES, PFHE_STAGE_IDLE_MAX, PFHE_STAGE_LAG,
-// PFHE_STAGE_REGISTER_PAGEABLE.
+// PFHE_STAGE_CHUNK, PFHE_STAGE_ZERO_COPY, PFHE_STAGE_THREADS, PFHE_STAGE_PIECES, PFHE_STAGE_IDLE_MAX, PFHE_STAGE_LAG.
 struct StageKnobs {
     size_t bounce_max, cache_max, register_min, chunk_bytes, pieces, idle_max, helper_lag;
     bool use_register, zero_copy, helper_thread;
-    bool register_pageable;  // PFHE_STAGE_REGISTER_PAGEABLE=1 (opt-in): pageable slices are registered for the call
 };
 const StageKnobs &stage_knobs();
 
@@ -51,8 +49,7 @@ enum StagePath : int {
     kPathDmaCaller = 2,     // copy engines on memory the caller pinned
     kPathPageable = 3,      // the runtime's pageable copies
     kPathHelper = 4,        // long pageable slice, copy back on the context's helper thread
-    kPathLibRegistered = 5, // a pageable slice the LIBRARY registered for the call (opt-in, PFHE_STAGE_REGISTER_PAGEABLE=1)
-    kPathCount = 6
+    kPathCount = 5
 };
 void stage_path_note(StagePath which);
 std::uint64_t stage_path_count(int which);
@@ -79,6 +76,9 @@ class HostStage {
     int copy_in(void *dev, const void *host, size_t bytes, hipStream_t s = nullptr);
     // asynchronous copy back to host memory, complete after finish()
     int download(void *host, const void *dev, size_t bytes, hipStream_t s = nullptr);
+    // a range the runtime refuses as one piece (partly registered): chunk by chunk through the pool's pinned buffer
+    int staged_copy(void *dev, void *host, size_t bytes, bool to_device, hipStream_t s);
+    bool touches_pinned(const void *host, size_t bytes);
     // waits for everything queued on the context's streams and completes the downloads
     int finish();
     // stream `waiter` waits for everything queued so far on stream `signaller` (pooled events, no allocation)

@@ -26,8 +26,8 @@ def orc():
 # ---------------------------------------------------------------------------------------------
 # Hazard probe (profiles/r05_experiments.txt item 7): with PFHE_TEST_CALLER_REGISTER=1 every host-slice
 # transform of the suite runs the way a caller that pins per call would run it — hipHostRegister on the slice, the call,
-# hipHostUnregister — so that "per-call registration by the CALLER" can be tried in the same process history as the
-# library-side form (PFHE_STAGE_REGISTER_PAGEABLE=1).  Off by default; nothing in the product reads this variable.
+# hipHostUnregister — inside the process history of the full suite (torch's pageable copies of the same arrays included),
+# which is where round 4's failure lived (tools/hazard_suite_probe.sh).  Off by default; nothing in the product reads it.
 # ---------------------------------------------------------------------------------------------
 if os.environ.get("PFHE_TEST_CALLER_REGISTER") == "1":
 

@@ -249,10 +249,10 @@ def test_a_pending_hip_error_of_the_caller_is_not_reported_as_ours(pf, orc):
     assert int(getattr(rc, "value", rc)) != 0
     t.transform_slice(view)
     assert np.array_equal(view, exp)
-    x = a.copy()
+    dev = torch.from_numpy(a.view(np.int64).copy()).cuda()               # (torch checks the sticky error after its own
+    torch.cuda.synchronize()                                            #  calls too: nothing of torch's in between)
     rc = rt.cudaHostRegister(view.ctypes.data, view.nbytes, 0)
     assert int(getattr(rc, "value", rc)) != 0
-    dev = torch.from_numpy(x.view(np.int64)).cuda()
     t.transform_dev(dev)
     assert np.array_equal(dev.cpu().numpy().view(np.uint64), exp)
 
@@ -313,16 +313,18 @@ def _rc(v):
 
 
 def _default_paths_only():
-    """The path a call takes is asserted for the DEFAULT knobs; the two hazard probes change it on purpose."""
-    if os.environ.get("PFHE_STAGE_REGISTER_PAGEABLE") == "1" or os.environ.get("PFHE_TEST_CALLER_REGISTER") == "1":
+    """The path a call takes is asserted for unwrapped calls; tests/conftest.py's hazard probe registers every slice."""
+    if os.environ.get("PFHE_TEST_CALLER_REGISTER") == "1":
         pytest.skip("staging path changed by a hazard-probe switch")
 
 
 def test_every_staging_path_is_the_one_meant_and_exact(pf, orc):
     """pfhe_debug_stage_path_count says which way a host-pointer call's bytes travelled: pageable slice up to the bounce
-    limit -> kernels on the pool's own pinned buffer; the same slice registered by the CALLER -> kernels on the caller's
+    limit -> kernels on the pool's own pinned buffer; the same slice REGISTERED by the caller -> the pool's buffer too
+    (round 5: kernels never run on a registration); a slice in memory the caller ALLOCATED pinned -> kernels on the caller's
     memory; a long caller-pinned slice -> copy engines; a long pageable slice -> the helper-thread form."""
     _default_paths_only()
+    import torch
     rt = _hip()
     log_n = 16
     n = 1 << log_n
@@ -343,7 +345,14 @@ def test_every_staging_path_is_the_one_meant_and_exact(pf, orc):
         rt.cudaHostUnregister(y.ctypes.data)
     assert np.array_equal(y, ref)
     c2 = [path_count(pf, w) for w in range(5)]
-    assert c2[MAPPED_CALLER] == c1[MAPPED_CALLER] + 1 and c2[MAPPED_BOUNCE] == c1[MAPPED_BOUNCE]
+    assert c2[MAPPED_CALLER] == c1[MAPPED_CALLER] and c2[MAPPED_BOUNCE] == c1[MAPPED_BOUNCE] + 1
+    pinned = torch.from_numpy(a.view(np.int64).copy()).pin_memory()      # hipHostMalloc memory
+    v = pinned.numpy().view(np.uint64)
+    t.transform_slice(v)
+    assert np.array_equal(v, ref)
+    c2b = [path_count(pf, w) for w in range(5)]
+    assert c2b[MAPPED_CALLER] == c2[MAPPED_CALLER] + 1 and c2b[MAPPED_BOUNCE] == c2[MAPPED_BOUNCE]
+    c2 = c2b
     # 24 polynomials = 12 MiB: registered -> copy engines on the caller's memory; pageable -> helper thread
     big = np.concatenate([a] * 24)
     bref = np.concatenate([ref] * 24)
@@ -362,37 +371,41 @@ def test_every_staging_path_is_the_one_meant_and_exact(pf, orc):
     assert c4[HELPER] == c3[HELPER] + 1
 
 
-def test_slice_spanning_two_registrations_is_not_treated_as_one_mapped_range(pf, orc):
+def test_slice_spanning_two_registrations_is_not_treated_as_one_pinned_range(pf, orc):
     """pinned first and last bytes do not make a pinned range.  One array whose two halves are registered
-    SEPARATELY (two registrations, adjacent): a slice over both must not be handed to the kernels as one mapped range —
-    it takes the library's own buffer — and a slice inside one registration still is used as it is."""
+    SEPARATELY (two registrations, adjacent): a long slice over both must not be given to the copy engines as one pinned
+    range — it travels as pageable memory — while a slice inside one registration is (copy engines on the caller's memory)."""
     _default_paths_only()
     rt = _hip()
     log_n = 15
     n = 1 << log_n
+    per_half = 20                                   # 20 polynomials = 5 MiB per registration; both: 10 MiB, helper-thread size
     t, o = pf.U64NttTable(log_n, Q62), orc.U64NttTable(log_n, Q62)
     rng = np.random.default_rng(41)
     page = 4096
-    raw = np.zeros(2 * n + page // 8, np.uint64)
+    words = 2 * per_half * n
+    raw = np.zeros(words + page // 8, np.uint64)
     skip = (-raw.ctypes.data % page) // 8          # page-aligned start: registrations cover whole pages
-    arr = raw[skip:skip + 2 * n]
-    arr[:] = rand_mod(rng, Q62, 2 * n)
+    arr = raw[skip:skip + words]
+    arr[:] = rand_mod(rng, Q62, words)
     orig = arr.copy()
     ref = orig.copy(); o.transform_slice(ref)
-    half = n * 8
+    half = per_half * n * 8
     assert _rc(rt.cudaHostRegister(arr.ctypes.data, half, 0)) == 0
     assert _rc(rt.cudaHostRegister(arr.ctypes.data + half, half, 0)) == 0
     try:
         c0 = [path_count(pf, w) for w in range(5)]
-        t.transform_slice(arr)                      # 512 KiB over both registrations
+        t.transform_slice(arr)                      # 10 MiB over both registrations: the runtime refuses it as one
+        #                                             range ('invalid argument'); staged chunk by chunk, no helper thread
         c1 = [path_count(pf, w) for w in range(5)]
         assert np.array_equal(arr, ref)
-        assert c1[MAPPED_CALLER] == c0[MAPPED_CALLER] and c1[MAPPED_BOUNCE] == c0[MAPPED_BOUNCE] + 1
+        assert c1[DMA_CALLER] == c0[DMA_CALLER] and c1[MAPPED_CALLER] == c0[MAPPED_CALLER] and c1[PAGEABLE] > c0[PAGEABLE]
+        assert c1[HELPER] == c0[HELPER]
         arr[:] = orig
-        t.transform_slice(arr[:n])                  # inside the first registration
+        t.transform_slice(arr[:per_half * n])       # inside the first registration
         c2 = [path_count(pf, w) for w in range(5)]
-        assert np.array_equal(arr[:n], ref[:n]) and np.array_equal(arr[n:], orig[n:])
-        assert c2[MAPPED_CALLER] == c1[MAPPED_CALLER] + 1
+        assert np.array_equal(arr[:per_half * n], ref[:per_half * n]) and np.array_equal(arr[per_half * n:], orig[per_half * n:])
+        assert c2[DMA_CALLER] > c1[DMA_CALLER] and c2[MAPPED_CALLER] == c1[MAPPED_CALLER]
     finally:
         rt.cudaHostUnregister(arr.ctypes.data)
         rt.cudaHostUnregister(arr.ctypes.data + half)

@@ -149,8 +149,8 @@ dt = time.perf_counter() - t0
 stop.value = 1
 for th in churners:
     th.join()
-print(f"{args.iters * max(1, args.callers)} calls in {dt:.1f} s, {bad} mismatches, {registered_calls} caller-registered ({zero_copy_calls} of them on the "
-      f"zero-copy kernels), churn threads {args.churn_threads} (damaged blocks {sum(damaged)}), alloc events "
+print(f"{args.iters * max(1, args.callers)} calls in {dt:.1f} s, {bad} mismatches, {registered_calls} caller-registered ({zero_copy_calls} of them "
+      f"short enough for the zero-copy kernels), churn threads {args.churn_threads} (damaged blocks {sum(damaged)}), alloc events "
       f"{p.lib().pfhe_debug_alloc_count()}, staging paths "
-      f"{[int(p.lib().pfhe_debug_stage_path_count(w)) for w in range(6)]}")
+      f"{[int(p.lib().pfhe_debug_stage_path_count(w)) for w in range(5)]}")
 sys.exit(1 if bad or sum(damaged) else 0)
