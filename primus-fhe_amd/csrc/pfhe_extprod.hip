@@ -321,7 +321,7 @@ int launch_digits_strided(const RnsDev &r, const BasisDev &b, const NttPrime *pr
 // 8*N per output polynomial, and the key out of L2.
 // ------------------------------------------------------------------------------------------
 template <class A, int LOGB, int NC>
-__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_waves_per_eu(2, 3))) void extprod_small_kernel(
+__device__ __forceinline__ void extprod_small_body(
     const int *__restrict__ sdigits, const u64 *__restrict__ ggsw, u64 ggsw_stride, u64 *__restrict__ result,
     const NttPrime *__restrict__ primes, u32 L, u32 rows, u32 ell, u64 total, u32 accumulate, u32 into_coeff) {
     using Cfg = BlockCfg<LOGB>;
@@ -413,6 +413,16 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_wave
     if constexpr (NC > 1) epilogue(std::integral_constant<int, 1>{});
     if constexpr (NC > 2) epilogue(std::integral_constant<int, 2>{});
     static_assert(NC <= 3, "add an epilogue call per component");
+}
+
+// (the body runs with the arithmetic's fold-inside form: at 256 registers this kernel has no room for the values the
+// 16-instruction butterfly keeps alive in front of its asm block — pfhe_ntt_device.hpp, PmArith::kFoldOutside)
+template <class A, int LOGB, int NC>
+__global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_waves_per_eu(2, 3))) void extprod_small_kernel(
+    const int *__restrict__ sdigits, const u64 *__restrict__ ggsw, u64 ggsw_stride, u64 *__restrict__ result,
+    const NttPrime *__restrict__ primes, u32 L, u32 rows, u32 ell, u64 total, u32 accumulate, u32 into_coeff) {
+    extprod_small_body<typename FoldInsideOf<A>::type, LOGB, NC>(sdigits, ggsw, ggsw_stride, result, primes, L, rows, ell, total,
+                                                                  accumulate, into_coeff);
 }
 
 template <class A, int LOGB, int NC>

@@ -307,6 +307,28 @@ struct PmArith {
     // fwd_bfly / inv_bfly below, not the reference's [0,4q) / [0,2q)
     static constexpr bool kWide = true;
     static constexpr bool kMont = false;
+    // forward butterflies with a fold: the shift and the mask of x are C++ in front of the asm block (pfhe_pm_asm.hpp; 16
+    // instructions instead of 17 — x is dead after the butterfly, the compiler masks its high half in place and the copy of its
+    // low half into the addend pair disappears)
+#ifdef PFHE_PM_FOLD_INSIDE  // A/B build (tools/build_variant.sh foldin -DPFHE_PM_FOLD_INSIDE): round 4's 17-instruction form everywhere
+    static constexpr bool kFoldOutside = false;
+#else
+    static constexpr bool kFoldOutside = true;
+#endif
+};
+// the same arithmetic with the fold inside the asm block: for a kernel at its register limit (extprod_small_kernel: 256
+// registers; the outside form costs it 28 bytes of scratch per lane)
+struct PmArithFoldInside : PmArith {
+    using PmArith::PmArith;
+    static constexpr bool kFoldOutside = false;
+};
+template <class A>
+struct FoldInsideOf {
+    using type = A;
+};
+template <>
+struct FoldInsideOf<PmArith> {
+    using type = PmArithFoldInside;
 };
 
 

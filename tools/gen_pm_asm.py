@@ -15,6 +15,7 @@ shifts left, min/max, any 32-bit op with an SGPR operand), v_add_co / v_addc_co 
 
     forward, no fold : 5 mad + mov + addc + alignbit + and + 2 lshl_add_u64 + sub_co + subb  = 13 instr, 51 cycles
     forward, fold    : + lshrrev + and + mov + mad                                           = 17 instr, 62 cycles
+                       (round 5: lshrrev + and placed by the compiler in front of the block, no mov  = 16 instr, 60 cycles)
     (until late in round 2 the tail was not, not, 2 x lshl_add_u64: 14 / 18 instructions for the same cycles — but the
     kernels run at the package power cap, where an instruction less is worth more than its issue slot)
     inverse          : lshl_add_u64 + (lshrrev, and, mad) + lshl_add_u64 + sub_co + subb + multiply (10) = 18 instr
@@ -41,6 +42,9 @@ if os.environ.get("PM_ASM_HIGH_TEMPS"):  # experiment: the first placement tried
 # forward y' = X + 3q - T as a 64-bit borrow chain into two 32-bit outputs (3 instructions) instead of not, not, two 64-bit
 # adds (4): one instruction fewer per butterfly (1846 -> 1742 in the block pass); PM_ASM_NOT_ADD=1 restores the old tail
 SUBC = not os.environ.get("PM_ASM_NOT_ADD")
+# forward fold: shift and mask of x as C++ in front of the asm block (round 5; PM_ASM_FOLD_INSIDE=1 restores the 17-instruction
+# form with the three instructions and the copy inside the block)
+FOLD_OUTSIDE = not os.environ.get("PM_ASM_FOLD_INSIDE")
 
 
 def pair(p):
@@ -65,10 +69,15 @@ def mul_seq(t, s, y0, y1, out=None):
     ]
 
 
-def fwd_seq(t, s, fold):
+def fwd_seq(t, s, fold, outside=False):
     A, B, E, C, cy = t["A"], t["B"], t["E"], t["C"], t["cy"]
     seq = []
-    if fold:
+    if fold and outside:
+        # the shift and the mask are C++ in front of the block (x is dead afterwards: the compiler masks its high half in
+        # place), so the copy of the low half into the addend pair is gone: 16 instructions
+        seq += [f"v_mad_u64_u32 {pair(C)}, {cy}, %[e{s}], %[c], %[xm{s}]"]  # X = (x >> K)*c + (x mod 2^K)
+        X = pair(C)
+    elif fold:
         seq += [
             f"v_lshrrev_b32 v{E[0]}, %[sh], %[x1{s}]",
             f"v_and_b32 v{C[1]}, %[m], %[x1{s}]",
@@ -165,11 +174,11 @@ def clobbers_of(sets, keys):
     return ["vcc"] + regs
 
 
-def gen_fwd(ways, fold, uni):
+def gen_fwd(ways, fold, uni, outside=False):
     tc = "s" if uni else "v"
     sfx = ["a", "b"][:ways]
     sets = SETS[:ways]
-    lines = interleave([fwd_seq(t, s, fold) for t, s in zip(sets, sfx)])
+    lines = interleave([fwd_seq(t, s, fold, outside) for t, s in zip(sets, sfx)])
     outs, ins = [], []
     for s in sfx:
         if SUBC:
@@ -179,7 +188,9 @@ def gen_fwd(ways, fold, uni):
     if ways == 2:
         outs += ['[cyb] "=&s"(cyb)']
     for s in sfx:
-        if fold:
+        if fold and outside:
+            ins += [f'[e{s}] "v"(e{s})', f'[xm{s}] "v"(xm{s})']
+        elif fold:
             ins += [f'[x0{s}] "v"((u32)x{s})', f'[x1{s}] "v"((u32)(x{s} >> 32))']
         else:
             ins += [f'[x{s}] "v"(x{s})']
@@ -188,10 +199,17 @@ def gen_fwd(ways, fold, uni):
                 f'[v0{s}] "{tc}"((u32)w{s}.w2)', f'[v1{s}] "{tc}"((u32)(w{s}.w2 >> 32))']
     ins += ['[sh1] "s"(ar.sh + 1)', '[m1] "v"(ar.vmask1)', '[c2] "s"(ar.c2)',
             '[q3] "s"(ar.q3)' if SUBC else '[q3p1] "s"(ar.q3 + 1)']
-    if fold:
+    if fold and outside:
+        ins += ['[c] "s"(ar.c)']
+    elif fold:
         ins += ['[sh] "v"(ar.vsh)', '[m] "v"(ar.vmask)', '[c] "s"(ar.c)']
     keys = ["A", "B", "E"] + (["C"] if fold else [])
-    return emit_asm(lines, outs, ins, clobbers_of(sets, keys), indent="        ")
+    pre = ""
+    if fold and outside:
+        for s in sfx:
+            pre += (f"        const u32 e{s} = (u32)(x{s} >> 32) >> ar.vsh;\n"
+                    f"        const u64 xm{s} = ((u64)((u32)(x{s} >> 32) & ar.vmask) << 32) | (u32)x{s};\n")
+    return pre + emit_asm(lines, outs, ins, clobbers_of(sets, keys), indent="        ")
 
 
 def gen_inv(ways, uni):
@@ -221,7 +239,8 @@ HEADER = '''// pfhe_pm_asm.hpp — GENERATED by tools/gen_pm_asm.py; do not edit
 // T = fold(y0*w + y1*w2) <= 3q with w2 = w*2^32 mod q; forward x' = X + T, y' = X + 3q - T with X = x or fold(x);
 // inverse x' = fold(x + y), y' = (x + 3q - y)*w.  `A` must provide q3, c, c2, sh = K - 32 and, held in VGPRs (an SGPR operand doubles the cost of a
 // v_and_b32 or v_lshrrev_b32), vsh = K - 32, vmask = 2^(K-32)-1 and vmask1 = 2^(K-31)-1.
-// UNI: the twiddle is wave-uniform and sits in SGPRs.
+// UNI: the twiddle is wave-uniform and sits in SGPRs.  A::kFoldOutside: the shift and the mask of a forward fold are C++ in
+// front of the block (16 instructions per butterfly instead of 17; a kernel at its register limit may prefer the other form).
 #pragma once
 
 namespace pfhe {
@@ -245,7 +264,13 @@ def main():
         for fold in (False, True):
             for uni in (False, True):
                 cond = f"{'FOLD' if fold else '!FOLD'} && {'UNI' if uni else '!UNI'}"
-                src += f"    {'if' if first else 'else if'} constexpr ({cond}) {{\n" + gen_fwd(ways, fold, uni) + "    }"
+                src += f"    {'if' if first else 'else if'} constexpr ({cond}) {{\n"
+                if fold and FOLD_OUTSIDE:
+                    src += ("        if constexpr (A::kFoldOutside) {\n" + gen_fwd(ways, fold, uni, True).replace("\n        ", "\n            ").replace("        ", "            ", 1)
+                            + "        } else {\n" + gen_fwd(ways, fold, uni, False).replace("\n        ", "\n            ").replace("        ", "            ", 1) + "        }\n")
+                else:
+                    src += gen_fwd(ways, fold, uni)
+                src += "    }"
                 src += "\n" if False else " "
                 first = False
         src = src.rstrip() + "\n"
