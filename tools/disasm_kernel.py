@@ -45,7 +45,7 @@ def main():
                 lds = sum(v for k, v in c.items() if k.startswith("ds_"))
                 vmem = sum(v for k, v in c.items() if k.startswith(("global_", "buffer_", "flat_", "scratch_")))
                 print(f"{pretty[n]}: {len(ins)} instructions, VALU {valu} (v_mad_u64_u32 {c['v_mad_u64_u32']}, v_lshl_add_u64 "
-                      f"{c['v_lshl_add_u64']}, v_mov_b32 {c['v_mov_b32']}), DS {lds}, VMEM {vmem} (global_load_lds "
+                      f"{c['v_lshl_add_u64']}, v_mov_b32 {c['v_mov_b32'] + c['v_mov_b32_e32'] + c['v_mov_b32_e64']}), DS {lds}, VMEM {vmem} (global_load_lds "
                       f"{sum(v for k, v in c.items() if k.startswith('global_load_lds'))}), s_barrier {c['s_barrier']}, "
                       f"s_waitcnt {c['s_waitcnt']}")
                 if args.out:
