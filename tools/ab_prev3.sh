@@ -1,0 +1,9 @@
+# three alternations of the tree against variants/libpfhe_hip_$1.so on the headline shape (and the pipelined-kernel parity tests first)
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; V=$R/primus-fhe_amd/variants/libpfhe_hip_$1.so
+for rep in 1 2 3; do
+  for which in tree variant; do
+    if [ $which = variant ]; then export PFHE_LIB_PATH=$V; else unset PFHE_LIB_PATH; fi
+    echo -n "$which n16: "; REPS=30 python3 $R/tools/perf_passes.py 2>&1 | tail -1 | grep -o "fwd_total=[^ ]*\|inv_total=[^ ]*" | paste - -
+  done
+done
