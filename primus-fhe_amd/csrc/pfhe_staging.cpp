@@ -286,7 +286,7 @@ bool HostStage::pin(const void *host, size_t bytes, bool any_size) {
 // (hipHostMalloc; a torch pinned tensor).  Memory that is merely REGISTERED (hipHostRegister: a userptr mapping of pages the
 // host kernel still owns) is not handed to kernels: tools/microbench12_register_hazard.hip — plain HIP, no code of this
 // library — registers a heap block, runs a kernel on the mapped range and unregisters it, between pageable hipMemcpy's of the
-// same block, and on two MI355X hosts out of three finds 7-10 blocks in 10 000 with wrong words (part of them the values
+// same block, and on four MI355X hosts out of five finds 2-16 blocks in 10 000 with wrong words (part of them the values
 // from before the kernel, at reused heap addresses under MALLOC_CHECK_=3); never on hipHostMalloc memory, never through the
 // copy engines (profiles/r05_microbench12_register_hazard.txt).  That is round 4's "rare wrong words" (r04_experiments.txt
 // item 6), reproduced this round from the caller's side inside the full test suite (tools/hazard_suite_probe.sh).

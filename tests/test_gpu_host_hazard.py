@@ -4,8 +4,8 @@ Round 4's library registered the caller's pageable slice for the duration of a c
 mapped range -> hipHostUnregister) and, about once in twenty full test runs, produced wrong words and — under a debugging
 allocator — a corrupted heap; the registration was withdrawn, cause not established.  Round 5 established it (DESIGN.md §5,
 profiles/r05_experiments.txt item 7): plain HIP alone — tools/microbench12_register_hazard.hip — gets wrong words from
-KERNELS running on a per-call registration when the process also makes pageable copies of the same heap blocks, on two hosts
-out of three; the copy engines on registered memory, pageable copies and kernels on hipHostMalloc memory never.  So the
+KERNELS running on a per-call registration when the process also makes pageable copies of the same heap blocks, on four hosts
+out of five; the copy engines on registered memory, pageable copies and kernels on hipHostMalloc memory never.  So the
 library hands kernels only pinned memory the caller ALLOCATED; a slice the caller merely registered is staged like a
 pageable one (short) or moved by the copy engines (long).  tools/stress_host_slice.py drives the public ABI with a caller
 who registers every slice for its call: >= 20 000 calls, fresh arrays that reappear at reused addresses, host threads
