@@ -45,6 +45,7 @@ SUBC = not os.environ.get("PM_ASM_NOT_ADD")
 # forward fold: shift and mask of x as C++ in front of the asm block (round 5; PM_ASM_FOLD_INSIDE=1 restores the 17-instruction
 # form with the three instructions and the copy inside the block)
 FOLD_OUTSIDE = not os.environ.get("PM_ASM_FOLD_INSIDE")
+CANON_OUTSIDE = bool(os.environ.get("PM_ASM_CANON_OUTSIDE"))  # experiment only
 
 
 def pair(p):
@@ -124,6 +125,14 @@ def inv_seq(t, s):
 def canon_seq(t, s):
     """any 64-bit x -> [0, q): fold (x mod~ q < 2^K + 2^31 < 2q), then subtract q unless that borrows"""
     A, E, C, cy = t["A"], t["E"], t["C"], t["cy"]
+    if CANON_OUTSIDE:  # experiment (r05_experiments.txt item 12): shift and mask as C++ in front of the block, as in the butterflies
+        return [
+            f"v_mad_u64_u32 {pair(C)}, {cy}, %[e{s}], %[c], %[xm{s}]",
+            f"v_lshl_add_u64 {pair(A)}, {pair(C)}, 0, %[negq]",
+            f"v_cmp_gt_i32_e64 {cy}, 0, v{A[1]}",
+            f"v_cndmask_b32_e64 %[o0{s}], v{A[0]}, v{C[0]}, {cy}",
+            f"v_cndmask_b32_e64 %[o1{s}], v{A[1]}, v{C[1]}, {cy}",
+        ]
     return [
         f"v_lshrrev_b32 v{E[0]}, %[sh], %[x1{s}]",
         f"v_and_b32 v{C[1]}, %[m], %[x1{s}]",
@@ -145,10 +154,19 @@ def gen_canon(ways):
         outs += [f'[o0{s}] "=&v"(o0{s})', f'[o1{s}] "=&v"(o1{s})']
     if ways == 2:
         outs += ['[cyb] "=&s"(cyb)']
+    pre = ""
     for s in sfx:
-        ins += [f'[x0{s}] "v"((u32)x{s})', f'[x1{s}] "v"((u32)(x{s} >> 32))']
-    ins += ['[sh] "v"(ar.vsh)', '[m] "v"(ar.vmask)', '[c] "s"(ar.c)', '[negq] "s"(0ull - ar.q)']
-    return emit_asm(lines, outs, ins, clobbers_of(sets, ["A", "E", "C"]), indent="    ")
+        if CANON_OUTSIDE:
+            pre += (f"    const u32 e{s} = (u32)(x{s} >> 32) >> ar.vsh;\n"
+                    f"    const u64 xm{s} = ((u64)((u32)(x{s} >> 32) & ar.vmask) << 32) | (u32)x{s};\n")
+            ins += [f'[e{s}] "v"(e{s})', f'[xm{s}] "v"(xm{s})']
+        else:
+            ins += [f'[x0{s}] "v"((u32)x{s})', f'[x1{s}] "v"((u32)(x{s} >> 32))']
+    if CANON_OUTSIDE:
+        ins += ['[c] "s"(ar.c)', '[negq] "s"(0ull - ar.q)']
+    else:
+        ins += ['[sh] "v"(ar.vsh)', '[m] "v"(ar.vmask)', '[c] "s"(ar.c)', '[negq] "s"(0ull - ar.q)']
+    return pre + emit_asm(lines, outs, ins, clobbers_of(sets, ["A", "E", "C"]), indent="    ")
 
 
 def interleave(seqs):
