@@ -481,25 +481,11 @@ __device__ __forceinline__ void ntt_pipe_body(
     u64 sx[1 << K][1];
     const auto issue = [&]() {
         if (has_str) {
-#ifdef PFHE_NOMEM
 #pragma unroll
+#ifdef PFHE_NOMEM
             for (int k = 0; k < (1 << K); ++k) sx[k][0] = (u64)threadIdx.x * 0xBF58476D1CE4E5B9ull + (u64)k + lazy;
 #else
-#ifdef PFHE_ROW_CHAIN  // experiment (r05_experiments.txt item 13): row k's address = row k-1's + an opaque scalar stride
-            {
-                u64 stride = (u64)sizeof(u64) << LOGB;
-                asm("" : "+s"(stride));
-                const char *addr = reinterpret_cast<const char *>(sp);
-#pragma unroll
-                for (int k = 0; k < (1 << K); ++k) {
-                    sx[k][0] = __builtin_nontemporal_load(reinterpret_cast<const u64 *>(addr));
-                    addr += stride;
-                }
-            }
-#else
-#pragma unroll
             for (int k = 0; k < (1 << K); ++k) sx[k][0] = __builtin_nontemporal_load(sp + ((u64)k << LOGB));
-#endif
 #endif
         }
     };
@@ -531,22 +517,9 @@ __device__ __forceinline__ void ntt_pipe_body(
 #ifdef PFHE_NOMEM
         if (lazy == 0xdeadu)
 #endif
+#pragma unroll
         // forward: this is the intermediate (kPipeIntermediateNt); inverse: the final output (always non-temporal)
-#ifdef PFHE_ROW_CHAIN
-        {
-            u64 stride = (u64)sizeof(u64) << LOGB;
-            asm("" : "+s"(stride));
-            char *addr = reinterpret_cast<char *>(sp);
-#pragma unroll
-            for (int k = 0; k < (1 << K); ++k) {
-                gstore<(INV || kPipeIntermediateNt)>(reinterpret_cast<u64 *>(addr), sx[k][0]);
-                addr += stride;
-            }
-        }
-#else
-#pragma unroll
         for (int k = 0; k < (1 << K); ++k) gstore<(INV || kPipeIntermediateNt)>(sp + ((u64)k << LOGB), sx[k][0]);
-#endif
     }
 }
 
