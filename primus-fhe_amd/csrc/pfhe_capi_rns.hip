@@ -32,8 +32,9 @@ struct pfhe_extprod_plan {
     hipEvent_t last_done = nullptr;
     hipStream_t last_stream = nullptr;
     bool last_valid = false;
-    RnsDev rns{};
-    BasisDev basis{};
+    RnsParams rns;
+    BasisParams basis_par;
+    BasisCore basis{};  // the scalar constants of basis_par
     u32 k = 1;
     size_t chunk = 1;
     // digit buffer(s) of chunk * (k+1) * ell * L * N words.  Chunks run one after the other on the caller's stream
@@ -124,9 +125,9 @@ int run_product_impl(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const
     if (coeff_passes) *coeff_passes = 0;
     const TableSet &t = *p->table;
     const u64 W = (u64)t.L * t.n;
-    RnsDev rns = p->rns;
-    rns.big_input = big_input ? 1u : 0u;
-    const u64 in_words = big_input ? (u64)rns.value_len * t.n : W;  // words per input polynomial
+    RnsParams rns = p->rns;
+    rns.dev.big_input = rns.wide_tab.big_input = big_input ? 1u : 0u;
+    const u64 in_words = big_input ? (u64)rns.dev.value_len * t.n : W;  // words per input polynomial
     const u32 ell = p->basis.ell;
     const u64 key_words = (u64)rows * ell * (p->k + 1) * W;
     // a single chunk has nothing to pipeline: run it on the caller's stream without the fork/join events
@@ -134,11 +135,11 @@ int run_product_impl(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const
     // (ciphertext, limb, block), so it only pays once that fills the chip
     // small rings: digit extraction + ONE kernel for everything else, chunk by chunk on the caller's stream
     // (one workgroup per (ciphertext, limb) runs 12+ transforms back to back: it needs a batch that fills the chip)
-    if (p->sdigits != nullptr && extprod_small_supported(t.log_n, p->k, p->rns.value_len, p->basis.log_basis) &&
+    if (p->sdigits != nullptr && extprod_small_supported(t.log_n, p->k, p->rns.dev.value_len, p->basis.log_basis) &&
         batch * t.L >= 1024 && p->use_small) {
         for (u64 done = 0; done < batch; done += p->chunk) {
             const u64 cur = std::min<u64>(p->chunk, batch - done);
-            PFHE_TRY(gadget_signed_digits_dev(rns, p->basis, t.log_n, crt_polys + done * rows * in_words, (int *)p->sdigits, cur * rows, s));
+            PFHE_TRY(gadget_signed_digits_dev(rns, p->basis_par, t.log_n, crt_polys + done * rows * in_words, (int *)p->sdigits, cur * rows, s));
             PFHE_TRY(extprod_small_dev(t.primes_dev, t.L, t.log_n, t.ntt_arith, p->k, rows, ell, (const int *)p->sdigits,
                                        keys + (keys_shared ? 0 : done * key_words), keys_shared,
                                        result + done * (p->k + 1) * W, cur, accumulate, into_coeff, s));
@@ -157,7 +158,7 @@ int run_product_impl(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const
     // coefficient-form output: the inverse transform's block pass runs inside the fused kernel, on the accumulators
     const bool inv_tail = fused && into_coeff && !accumulate && coeff_passes != nullptr && passes == 2 && p->use_fused_tail;
     if (inv_tail) *coeff_passes = 1;
-    const bool fused_decompose = gadget_decompose_strided_supported(t.log_n, p->rns.value_len) &&
+    const bool fused_decompose = gadget_decompose_strided_supported(t.log_n, p->rns.dev.value_len) &&
                                  p->use_fused_decompose && p->sdigits != nullptr;
     if (!single) {
         PFHE_HIP(hipEventRecord(p->fork, s));
@@ -195,10 +196,10 @@ int run_product_impl(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const
         // ---- stream a: steps (1)-(4) + strided passes into digit buffer `buf` ----
         if (fused && index >= 2 && !single) PFHE_HIP(hipStreamWaitEvent(sa, p->consumed[buf], 0));
         if (fused_decompose) {
-            PFHE_TRY(gadget_decompose_strided_dev(rns, p->basis, t.primes_dev, t.log_n, t.ntt_arith,
+            PFHE_TRY(gadget_decompose_strided_dev(rns, p->basis_par, t.primes_dev, t.log_n, t.ntt_arith,
                                                   crt_polys + done * rows * in_words, dg, cur * rows, sa, p->sdigits));
         } else {
-            PFHE_TRY(gadget_decompose_dev(rns, p->basis, t.log_n, crt_polys + done * rows * in_words, dg, cur * rows, sa));
+            PFHE_TRY(gadget_decompose_dev(rns, p->basis_par, t.log_n, crt_polys + done * rows * in_words, dg, cur * rows, sa));
             for (int i = 0; i < passes - 1; ++i)
                 PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.ntt_arith, dg, npolys, false, i, false, sa, nullptr, 0, t.tune));
         }
@@ -278,19 +279,24 @@ int pfhe_rns_create(const uint64_t *moduli, size_t count, int device, pfhe_rns *
     PFHE_TRY(build_rns((const u64 *)moduli, count, r->h));
     PFHE_TRY(capi_check_device(device));
     r->h.device = device;
+    if (r->h.par.wide()) {  // more than kMaxLimbs moduli: the constants live in a device table
+        DeviceGuard g(device);
+        if (!g.ok) return PFHE_ERR_NO_DEVICE;
+        PFHE_TRY(upload_rns_wide(r->h));
+    }
     *out = r.release();
     return PFHE_OK;
     PFHE_GUARD_END
 }
 
 void pfhe_rns_destroy(pfhe_rns *r) { delete r; }
-size_t pfhe_rns_moduli_count(const pfhe_rns *r) { return r ? r->h.dev.L : 0; }
-size_t pfhe_rns_big_uint_value_len(const pfhe_rns *r) { return r ? r->h.dev.value_len : 0; }
+size_t pfhe_rns_moduli_count(const pfhe_rns *r) { return r ? r->h.par.dev.L : 0; }
+size_t pfhe_rns_big_uint_value_len(const pfhe_rns *r) { return r ? r->h.par.dev.value_len : 0; }
 
 int pfhe_rns_moduli_product(const pfhe_rns *r, uint64_t *out, size_t len) {
     if (!r || !out) return PFHE_ERR_BAD_ARGUMENT;
-    if (len != r->h.dev.value_len) return PFHE_ERR_BAD_LENGTH;
-    for (size_t j = 0; j < len; ++j) out[j] = r->h.dev.Q[j];
+    if (len != r->h.par.dev.value_len) return PFHE_ERR_BAD_LENGTH;
+    for (size_t j = 0; j < len; ++j) out[j] = r->h.Q[j];
     return PFHE_OK;
 }
 
@@ -299,14 +305,14 @@ int pfhe_rns_compose_multiple_values_to_dev(const pfhe_rns *r, const uint64_t *m
                                             void *stream) {
     PFHE_GUARD_BEGIN
     if (!r || ((!multi_residues_dev || !big_uint_values_dev) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (len_in != value_count * r->h.dev.L || len_out != value_count * r->h.dev.value_len) {
+    if (len_in != value_count * r->h.par.dev.L || len_out != value_count * r->h.par.dev.value_len) {
         set_last_error("compose: multi_residues must hold moduli_count*value_count words and the output "
                        "value_count*big_uint_value_len words");
         return PFHE_ERR_BAD_LENGTH;
     }
     DeviceGuard g(r->h.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    return rns_compose_dev(r->h.dev, (const u64 *)multi_residues_dev, (u64 *)big_uint_values_dev, value_count,
+    return rns_compose_dev(r->h.par, (const u64 *)multi_residues_dev, (u64 *)big_uint_values_dev, value_count,
                            (hipStream_t)stream);
     PFHE_GUARD_END
 }
@@ -315,7 +321,7 @@ int pfhe_rns_compose_multiple_values_to(const pfhe_rns *r, const uint64_t *multi
                                         uint64_t *big_uint_values, size_t len_out, size_t value_count) {
     PFHE_GUARD_BEGIN
     if (!r || ((!multi_residues || !big_uint_values) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (len_in != value_count * r->h.dev.L || len_out != value_count * r->h.dev.value_len) return PFHE_ERR_BAD_LENGTH;
+    if (len_in != value_count * r->h.par.dev.L || len_out != value_count * r->h.par.dev.value_len) return PFHE_ERR_BAD_LENGTH;
     if (value_count == 0) return PFHE_OK;
     DeviceGuard g(r->h.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
@@ -324,7 +330,7 @@ int pfhe_rns_compose_multiple_values_to(const pfhe_rns *r, const uint64_t *multi
     void *in = nullptr, *o = nullptr;
     PFHE_TRY(st.upload(multi_residues, len_in * 8, &in));
     PFHE_TRY(st.alloc(len_out * 8, &o));
-    PFHE_TRY(rns_compose_dev(r->h.dev, (const u64 *)in, (u64 *)o, value_count, st.stream()));
+    PFHE_TRY(rns_compose_dev(r->h.par, (const u64 *)in, (u64 *)o, value_count, st.stream()));
     PFHE_TRY(st.download(big_uint_values, o, len_out * 8));
     return st.finish();
     PFHE_GUARD_END
@@ -335,16 +341,16 @@ int pfhe_rns_wrapping_decompose_small_values_to_dev(const pfhe_rns *r, const uin
                                                     uint64_t small_value_modulus, void *stream) {
     PFHE_GUARD_BEGIN
     if (!r || ((!small_values_dev || !multi_residues_dev) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (len_out != value_count * r->h.dev.L) return PFHE_ERR_BAD_LENGTH;
-    for (u32 i = 0; i < r->h.dev.L; ++i) {
-        if (small_value_modulus >= r->h.dev.q[i] || small_value_modulus < 2) {  // base.rs:288-292
+    if (len_out != value_count * r->h.par.dev.L) return PFHE_ERR_BAD_LENGTH;
+    for (u32 i = 0; i < r->h.par.dev.L; ++i) {
+        if (small_value_modulus >= r->h.moduli[i] || small_value_modulus < 2) {  // base.rs:288-292
             set_last_error("small_value_modulus must be >= 2 and smaller than every RNS modulus");
             return PFHE_ERR_BAD_ARGUMENT;
         }
     }
     DeviceGuard g(r->h.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    return rns_wrapping_decompose_dev(r->h.dev, (const u64 *)small_values_dev, (u64 *)multi_residues_dev, value_count,
+    return rns_wrapping_decompose_dev(r->h.par, (const u64 *)small_values_dev, (u64 *)multi_residues_dev, value_count,
                                       small_value_modulus, (hipStream_t)stream);
     PFHE_GUARD_END
 }
@@ -354,7 +360,7 @@ int pfhe_rns_wrapping_decompose_small_values_to(const pfhe_rns *r, const uint64_
                                                 uint64_t small_value_modulus) {
     PFHE_GUARD_BEGIN
     if (!r || ((!small_values || !multi_residues) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (len_out != value_count * r->h.dev.L) return PFHE_ERR_BAD_LENGTH;
+    if (len_out != value_count * r->h.par.dev.L) return PFHE_ERR_BAD_LENGTH;
     if (value_count == 0) return PFHE_OK;
     DeviceGuard g(r->h.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
@@ -374,13 +380,13 @@ static int add_scaled_common(const pfhe_rns *r, const uint64_t *small_dev, size_
                              size_t len_acc, uint64_t small_value_modulus, bool centred, const uint64_t *factors,
                              void *stream) {
     if (!r || !factors || ((!small_dev || !acc_dev) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (len_acc != value_count * r->h.dev.L) return PFHE_ERR_BAD_LENGTH;
-    for (u32 i = 0; i < r->h.dev.L; ++i) {
-        if (centred && (small_value_modulus >= r->h.dev.q[i] || small_value_modulus < 2)) {  // base.rs:337-341
+    if (len_acc != value_count * r->h.par.dev.L) return PFHE_ERR_BAD_LENGTH;
+    for (u32 i = 0; i < r->h.par.dev.L; ++i) {
+        if (centred && (small_value_modulus >= r->h.moduli[i] || small_value_modulus < 2)) {  // base.rs:337-341
             set_last_error("small_value_modulus must be >= 2 and smaller than every RNS modulus");
             return PFHE_ERR_BAD_ARGUMENT;
         }
-        if (factors[2 * i] >= r->h.dev.q[i]) {
+        if (factors[2 * i] >= r->h.moduli[i]) {
             set_last_error("factor values must be reduced modulo their modulus");
             return PFHE_ERR_BAD_ARGUMENT;
         }
@@ -389,7 +395,7 @@ static int add_scaled_common(const pfhe_rns *r, const uint64_t *small_dev, size_
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
     // base.rs:343,371-378: a small modulus of two takes the unsigned branch (a 1 stays +1)
     const bool lift = centred && small_value_modulus != 2;
-    return rns_add_decompose_scaled_dev(r->h.dev, (const u64 *)small_dev, (u64 *)acc_dev, value_count, small_value_modulus,
+    return rns_add_decompose_scaled_dev(r->h.par, (const u64 *)small_dev, (u64 *)acc_dev, value_count, small_value_modulus,
                                         lift, (const u64 *)factors, (hipStream_t)stream);
 }
 
@@ -413,7 +419,7 @@ int pfhe_rns_add_decompose_small_values_scaled_dev(const pfhe_rns *r, const uint
 static int add_scaled_host(const pfhe_rns *r, const uint64_t *small_values, size_t value_count, uint64_t *acc,
                            size_t len_acc, uint64_t small_value_modulus, bool centred, const uint64_t *factors) {
     if (!r || !factors || ((!small_values || !acc) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (len_acc != value_count * r->h.dev.L) return PFHE_ERR_BAD_LENGTH;
+    if (len_acc != value_count * r->h.par.dev.L) return PFHE_ERR_BAD_LENGTH;
     if (value_count == 0) return PFHE_OK;
     DeviceGuard g(r->h.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
@@ -451,16 +457,21 @@ int pfhe_basis_create(const pfhe_rns *rns, uint32_t log_basis, size_t reverse_le
     *out = nullptr;
     auto b = std::make_unique<pfhe_basis>();
     PFHE_TRY(build_basis(rns->h, log_basis, reverse_length, b->h));
+    if (b->h.par.wide()) {
+        DeviceGuard g(b->h.device);
+        if (!g.ok) return PFHE_ERR_NO_DEVICE;
+        PFHE_TRY(upload_basis_wide(b->h));
+    }
     *out = b.release();
     return PFHE_OK;
     PFHE_GUARD_END
 }
 
 void pfhe_basis_destroy(pfhe_basis *b) { delete b; }
-size_t pfhe_basis_decompose_length(const pfhe_basis *b) { return b ? b->h.dev.ell : 0; }
-uint32_t pfhe_basis_log_basis(const pfhe_basis *b) { return b ? b->h.dev.log_basis : 0; }
-uint32_t pfhe_basis_drop_bits(const pfhe_basis *b) { return b ? b->h.dev.drop_bits : 0; }
-uint64_t pfhe_basis_basis_value(const pfhe_basis *b) { return b ? b->h.dev.basis : 0; }
+size_t pfhe_basis_decompose_length(const pfhe_basis *b) { return b ? b->h.par.dev.ell : 0; }
+uint32_t pfhe_basis_log_basis(const pfhe_basis *b) { return b ? b->h.par.dev.log_basis : 0; }
+uint32_t pfhe_basis_drop_bits(const pfhe_basis *b) { return b ? b->h.par.dev.drop_bits : 0; }
+uint64_t pfhe_basis_basis_value(const pfhe_basis *b) { return b ? b->h.par.dev.basis : 0; }
 
 int pfhe_basis_scalars(const pfhe_basis *b, uint64_t *out, size_t len) {
     if (!b || !out) return PFHE_ERR_BAD_ARGUMENT;
@@ -480,10 +491,10 @@ int pfhe_basis_init_value_carry_slice_inplace_dev(const pfhe_basis *b, uint64_t 
                                                   uint8_t *carries_dev, size_t count, void *stream) {
     PFHE_GUARD_BEGIN
     if (!b || ((!values_dev || !carries_dev) && count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (len != count * b->h.dev.value_len) return PFHE_ERR_BAD_LENGTH;  // basis.rs:332
+    if (len != count * b->h.par.dev.value_len) return PFHE_ERR_BAD_LENGTH;  // basis.rs:332
     DeviceGuard g(b->h.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    return basis_init_value_carry_dev(b->h.dev, (u64 *)values_dev, carries_dev, count, (hipStream_t)stream);
+    return basis_init_value_carry_dev(b->h.par, (u64 *)values_dev, carries_dev, count, (hipStream_t)stream);
     PFHE_GUARD_END
 }
 
@@ -491,7 +502,7 @@ int pfhe_basis_init_value_carry_slice_inplace(const pfhe_basis *b, uint64_t *val
                                               size_t count) {
     PFHE_GUARD_BEGIN
     if (!b || ((!values || !carries) && count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (len != count * b->h.dev.value_len) return PFHE_ERR_BAD_LENGTH;
+    if (len != count * b->h.par.dev.value_len) return PFHE_ERR_BAD_LENGTH;
     if (count == 0) return PFHE_OK;
     DeviceGuard g(b->h.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
@@ -500,7 +511,7 @@ int pfhe_basis_init_value_carry_slice_inplace(const pfhe_basis *b, uint64_t *val
     void *v = nullptr, *c = nullptr;
     PFHE_TRY(st.upload(values, len * 8, &v));
     PFHE_TRY(st.alloc(count, &c));
-    PFHE_TRY(basis_init_value_carry_dev(b->h.dev, (u64 *)v, (unsigned char *)c, count, st.stream()));
+    PFHE_TRY(basis_init_value_carry_dev(b->h.par, (u64 *)v, (unsigned char *)c, count, st.stream()));
     PFHE_TRY(st.download(values, v, len * 8));
     PFHE_TRY(st.download(carries, c, count));
     return st.finish();
@@ -512,11 +523,11 @@ int pfhe_basis_unsigned_decompose_slice_to_dev(const pfhe_basis *b, size_t level
                                                void *stream) {
     PFHE_GUARD_BEGIN
     if (!b || ((!values_dev || !digits_dev || !carries_dev) && count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (level >= b->h.dev.ell) return PFHE_ERR_BAD_ARGUMENT;
-    if (len != count * b->h.dev.value_len) return PFHE_ERR_BAD_LENGTH;  // common.rs:316-317
+    if (level >= b->h.par.dev.ell) return PFHE_ERR_BAD_ARGUMENT;
+    if (len != count * b->h.par.dev.value_len) return PFHE_ERR_BAD_LENGTH;  // common.rs:316-317
     DeviceGuard g(b->h.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    return basis_unsigned_decompose_dev(b->h.dev, (u32)level, (const u64 *)values_dev, (u64 *)digits_dev, carries_dev,
+    return basis_unsigned_decompose_dev(b->h.par, (u32)level, (const u64 *)values_dev, (u64 *)digits_dev, carries_dev,
                                         count, (hipStream_t)stream);
     PFHE_GUARD_END
 }
@@ -525,8 +536,8 @@ int pfhe_basis_unsigned_decompose_slice_to(const pfhe_basis *b, size_t level, co
                                            uint64_t *digits, uint8_t *carries, size_t count) {
     PFHE_GUARD_BEGIN
     if (!b || ((!values || !digits || !carries) && count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (level >= b->h.dev.ell) return PFHE_ERR_BAD_ARGUMENT;
-    if (len != count * b->h.dev.value_len) return PFHE_ERR_BAD_LENGTH;
+    if (level >= b->h.par.dev.ell) return PFHE_ERR_BAD_ARGUMENT;
+    if (len != count * b->h.par.dev.value_len) return PFHE_ERR_BAD_LENGTH;
     if (count == 0) return PFHE_OK;
     DeviceGuard g(b->h.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
@@ -536,7 +547,7 @@ int pfhe_basis_unsigned_decompose_slice_to(const pfhe_basis *b, size_t level, co
     PFHE_TRY(st.upload(values, len * 8, &v));
     PFHE_TRY(st.alloc(count * 8, &d));
     PFHE_TRY(st.upload(carries, count, &c));
-    PFHE_TRY(basis_unsigned_decompose_dev(b->h.dev, (u32)level, (const u64 *)v, (u64 *)d, (unsigned char *)c, count,
+    PFHE_TRY(basis_unsigned_decompose_dev(b->h.par, (u32)level, (const u64 *)v, (u64 *)d, (unsigned char *)c, count,
                                           st.stream()));
     PFHE_TRY(st.download(digits, d, count * 8));
     PFHE_TRY(st.download(carries, c, count));
@@ -548,13 +559,13 @@ int pfhe_basis_init_value_carry_slice_to_dev(const pfhe_basis *b, const uint64_t
                                              uint64_t *adjusted_dev, uint8_t *carries_dev, size_t count, void *stream) {
     PFHE_GUARD_BEGIN
     if (!b || ((!values_dev || !adjusted_dev || !carries_dev) && count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (len != count * b->h.dev.value_len) return PFHE_ERR_BAD_LENGTH;  // basis.rs:378-379
+    if (len != count * b->h.par.dev.value_len) return PFHE_ERR_BAD_LENGTH;  // basis.rs:378-379
     if (count == 0) return PFHE_OK;
     DeviceGuard g(b->h.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
     if (adjusted_dev != values_dev)
         PFHE_HIP(hipMemcpyAsync(adjusted_dev, values_dev, len * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    return basis_init_value_carry_dev(b->h.dev, (u64 *)adjusted_dev, carries_dev, count, (hipStream_t)stream);
+    return basis_init_value_carry_dev(b->h.par, (u64 *)adjusted_dev, carries_dev, count, (hipStream_t)stream);
     PFHE_GUARD_END
 }
 
@@ -562,7 +573,7 @@ int pfhe_basis_init_value_carry_slice_to(const pfhe_basis *b, const uint64_t *va
                                          uint8_t *carries, size_t count) {
     PFHE_GUARD_BEGIN
     if (!b || ((!values || !adjusted || !carries) && count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (len != count * b->h.dev.value_len) return PFHE_ERR_BAD_LENGTH;
+    if (len != count * b->h.par.dev.value_len) return PFHE_ERR_BAD_LENGTH;
     if (count == 0) return PFHE_OK;
     if (adjusted != values) std::memcpy(adjusted, values, len * 8);
     return pfhe_basis_init_value_carry_slice_inplace(b, adjusted, len, carries, count);
@@ -574,15 +585,15 @@ int pfhe_basis_decompose_slice_to_dev(const pfhe_basis *b, size_t level, const u
                                       void *stream) {
     PFHE_GUARD_BEGIN
     if (!b || ((!values_dev || !decomposed_dev || !carries_dev) && count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (level >= b->h.dev.ell) return PFHE_ERR_BAD_ARGUMENT;
-    if (len != count * b->h.dev.value_len || len_out != len) return PFHE_ERR_BAD_LENGTH;  // common.rs:296-297
+    if (level >= b->h.par.dev.ell) return PFHE_ERR_BAD_ARGUMENT;
+    if (len != count * b->h.par.dev.value_len || len_out != len) return PFHE_ERR_BAD_LENGTH;  // common.rs:296-297
     if (count && values_dev == decomposed_dev) {
         set_last_error("decompose_slice_to needs distinct input and output buffers");
         return PFHE_ERR_BAD_ARGUMENT;
     }
     DeviceGuard g(b->h.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    return basis_signed_decompose_dev(b->h.rns, b->h.dev, (u32)level, (const u64 *)values_dev, (u64 *)decomposed_dev,
+    return basis_signed_decompose_dev(b->h.rns, b->h.par, (u32)level, (const u64 *)values_dev, (u64 *)decomposed_dev,
                                       carries_dev, count, (hipStream_t)stream);
     PFHE_GUARD_END
 }
@@ -591,8 +602,8 @@ int pfhe_basis_decompose_slice_to(const pfhe_basis *b, size_t level, const uint6
                                   uint64_t *decomposed, size_t len_out, uint8_t *carries, size_t count) {
     PFHE_GUARD_BEGIN
     if (!b || ((!values || !decomposed || !carries) && count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (level >= b->h.dev.ell) return PFHE_ERR_BAD_ARGUMENT;
-    if (len != count * b->h.dev.value_len || len_out != len) return PFHE_ERR_BAD_LENGTH;
+    if (level >= b->h.par.dev.ell) return PFHE_ERR_BAD_ARGUMENT;
+    if (len != count * b->h.par.dev.value_len || len_out != len) return PFHE_ERR_BAD_LENGTH;
     if (count == 0) return PFHE_OK;
     DeviceGuard g(b->h.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
@@ -602,7 +613,7 @@ int pfhe_basis_decompose_slice_to(const pfhe_basis *b, size_t level, const uint6
     PFHE_TRY(st.upload(values, len * 8, &v));
     PFHE_TRY(st.alloc(len * 8, &d));
     PFHE_TRY(st.upload(carries, count, &c));
-    PFHE_TRY(basis_signed_decompose_dev(b->h.rns, b->h.dev, (u32)level, (const u64 *)v, (u64 *)d, (unsigned char *)c, count,
+    PFHE_TRY(basis_signed_decompose_dev(b->h.rns, b->h.par, (u32)level, (const u64 *)v, (u64 *)d, (unsigned char *)c, count,
                                         st.stream()));
     PFHE_TRY(st.download(decomposed, d, len * 8));
     PFHE_TRY(st.download(carries, c, count));
@@ -618,29 +629,28 @@ int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *rns, const 
     if (!out || !table || !rns || !basis || glwe_dimension == 0 || glwe_dimension > 64) return PFHE_ERR_BAD_ARGUMENT;
     *out = nullptr;
     const TableSet *t = capi_table_of(table);
-    if (t->L != rns->h.dev.L) {
+    if (t->L != rns->h.par.dev.L) {
         set_last_error("DCRT table and RNS base have different moduli counts");
         return PFHE_ERR_BAD_ARGUMENT;
     }
     for (u32 i = 0; i < t->L; ++i) {
-        if (t->primes[i].q != rns->h.dev.q[i]) {
+        if (t->primes[i].q != rns->h.moduli[i]) {
             set_last_error("DCRT table and RNS base must use the same moduli in the same order");
             return PFHE_ERR_BAD_ARGUMENT;
         }
     }
-    if (basis->h.rns.value_len != rns->h.dev.value_len || basis->h.rns.L != rns->h.dev.L) return PFHE_ERR_BAD_ARGUMENT;
-    for (u32 j = 0; j < rns->h.dev.value_len; ++j)
-        if (basis->h.rns.Q[j] != rns->h.dev.Q[j]) return PFHE_ERR_BAD_ARGUMENT;  // basis.rs:52
+    if (basis->h.rns.dev.L != rns->h.par.dev.L || basis->h.Q != rns->h.Q) return PFHE_ERR_BAD_ARGUMENT;  // basis.rs:52
     for (u32 i = 0; i < t->L; ++i) {
-        if (basis->h.dev.basis >= t->primes[i].q) {  // wrapping_decompose needs B < q_i (base.rs:288-292)
+        if (basis->h.par.dev.basis >= t->primes[i].q) {  // wrapping_decompose needs B < q_i (base.rs:288-292)
             set_last_error("gadget basis must be smaller than every RNS modulus");
             return PFHE_ERR_BAD_ARGUMENT;
         }
     }
     auto p = std::make_unique<pfhe_extprod_plan>();
     p->table = t;
-    p->rns = rns->h.dev;
-    p->basis = basis->h.dev;
+    p->rns = rns->h.par;
+    p->basis_par = basis->h.par;
+    p->basis = basis->h.par.dev;
     p->k = (u32)glwe_dimension;
     // default: about 2 GiB of digit polynomials per buffer, at least 128 ciphertexts — measured at N = 2^16, 3 limbs
     // with today's kernels (ms per 1024 products): 32: 21.7, 64: 21.2, 128: 20.8, 256: 20.9, 1024: 20.8 (round 1, slower
@@ -667,8 +677,8 @@ int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *rns, const 
         PFHE_HIP(hipEventCreateWithFlags(&p->produced[i], hipEventDisableTiming));
         PFHE_HIP(hipEventCreateWithFlags(&p->consumed[i], hipEventDisableTiming));
     }
-    if ((gadget_decompose_strided_supported(t->log_n, p->rns.value_len) && p->use_fused_decompose) ||
-        extprod_small_supported(t->log_n, p->k, p->rns.value_len, p->basis.log_basis)) {
+    if ((gadget_decompose_strided_supported(t->log_n, p->rns.dev.value_len) && p->use_fused_decompose) ||
+        extprod_small_supported(t->log_n, p->k, p->rns.dev.value_len, p->basis.log_basis)) {
         void *d = nullptr;
         p->sdigit_bytes = gadget_digit_bytes(p->basis.log_basis);
         PFHE_HIP(counted_malloc(&d, p->chunk * (p->k + 1) * p->basis.ell * t->n * p->sdigit_bytes));
@@ -826,7 +836,7 @@ static int glev_big_uint_common(pfhe_extprod_plan *plan, uint64_t *out_dev, size
     PFHE_PLAN_LEASE(plan);
     const TableSet &t = *plan->table;
     const size_t W = (size_t)t.L * t.n, glwe = (plan->k + 1) * W, glev = plan->basis.ell * glwe;
-    const size_t in_words = (size_t)plan->rns.value_len * t.n;
+    const size_t in_words = (size_t)plan->rns.dev.value_len * t.n;
     if (len_poly % in_words != 0) return PFHE_ERR_BAD_LENGTH;  // glwe/dcrt.rs:277
     const u64 batch = len_poly / in_words;
     if (len_out != batch * glwe || (len_glev != glev && len_glev != batch * glev)) {

@@ -22,13 +22,41 @@
 
 namespace pfhe {
 
+// Constants by value (both bases of at most kMaxLimbs moduli) ...
 struct ConvDev {
     u32 lin, lout;
     u64 q[kMaxLimbs], inv[kMaxLimbs], inv_p[kMaxLimbs];       // input base
     u64 p[kMaxLimbs], mu_lo[kMaxLimbs], mu_hi[kMaxLimbs];     // output base + floor(2^128/p)
     u64 m[kMaxLimbs][kMaxLimbs];                              // m[j][i] = (Q/q_i) mod p_j
     u64 q_mod_p0;                                             // Q mod p_0
+    static constexpr int kScaled = kMaxLimbs;                 // per-thread scaled residues
+    __device__ u64 q_in(u32 i) const { return q[i]; }
+    __device__ u64 inv_in(u32 i) const { return inv[i]; }
+    __device__ u64 inv_in_p(u32 i) const { return inv_p[i]; }
+    __device__ u64 p_out(u32 j) const { return p[j]; }
+    __device__ u64 ratio_lo(u32 j) const { return mu_lo[j]; }
+    __device__ u64 ratio_hi(u32 j) const { return mu_hi[j]; }
+    __device__ u64 matrix(u32 j, u32 i) const { return m[j][i]; }
 };
+// ... or, when either base is wider (BaseConverter::new takes any two bases, converter.rs:43-69), in a device table:
+// q[W] | inv[W] | inv_p[W] | p[W] | mu_lo[W] | mu_hi[W] | m[W][W], W = kMaxWideLimbs.  SCALED: the per-thread array of
+// scaled residues, lin rounded up to a multiple of 8 (its loops are unrolled over SCALED so that it stays in registers).
+template <int SCALED>
+struct ConvWide {
+    u32 lin, lout;
+    const u64 *tab;
+    u64 q_mod_p0;
+    static constexpr int kScaled = SCALED;
+    static constexpr u32 W = kMaxWideLimbs;
+    __device__ u64 q_in(u32 i) const { return tab[i]; }
+    __device__ u64 inv_in(u32 i) const { return tab[W + i]; }
+    __device__ u64 inv_in_p(u32 i) const { return tab[2 * W + i]; }
+    __device__ u64 p_out(u32 j) const { return tab[3 * W + j]; }
+    __device__ u64 ratio_lo(u32 j) const { return tab[4 * W + j]; }
+    __device__ u64 ratio_hi(u32 j) const { return tab[5 * W + j]; }
+    __device__ u64 matrix(u32 j, u32 i) const { return tab[(6 + j) * W + i]; }
+};
+constexpr size_t kConvTableWords = (size_t)(6 + kMaxWideLimbs) * kMaxWideLimbs;
 
 namespace {
 
@@ -41,60 +69,74 @@ u32 grid_for(u64 items) {
     return (u32)g;
 }
 
-// reduce_dot_product for fewer than DOT_PRODUCT_INNER_CHUNK = 16 terms (compact/slice.rs:380-405):
-// one 128-bit accumulator (overflow discarded like the reference's carrying_add), reduce, reduce_add(., 0)
-__device__ __forceinline__ u64 dot_mod(const ConvDev &C, u32 j, const u64 *t) {
+// reduce_dot_product (compact/slice.rs:380-405): one 128-bit accumulator (overflow discarded like the reference's
+// carrying_add), reduce, reduce_add(., 0).  The reference folds the accumulator every DOT_PRODUCT_INNER_CHUNK = 16 terms;
+// a sum of up to 32 products below 2^124 cannot overflow 128 bits, and the value reduced is the same integer.
+template <class CT>
+__device__ __forceinline__ u64 dot_mod(const CT &C, u32 j, const u64 (&t)[CT::kScaled]) {
     u64 lo = 0, hi = 0;
-    for (u32 i = 0; i < C.lin; ++i) {
-        const u64 pl = t[i] * C.m[j][i], ph = mulhi64(t[i], C.m[j][i]);
-        lo += pl;
-        hi += ph + (lo < pl);
+#pragma unroll
+    for (int i = 0; i < CT::kScaled; ++i) {
+        if ((u32)i < C.lin) {
+            const u64 m = C.matrix(j, i);
+            const u64 pl = t[i] * m, ph = mulhi64(t[i], m);
+            lo += pl;
+            hi += ph + (lo < pl);
+        }
     }
-    return add_mod(barrett_reduce128(lo, hi, C.p[j], C.mu_lo[j], C.mu_hi[j]), 0, C.p[j]);
+    return add_mod(barrett_reduce128(lo, hi, C.p_out(j), C.ratio_lo(j), C.ratio_hi(j)), 0, C.p_out(j));
 }
 
-__device__ __forceinline__ void load_scaled(const ConvDev &C, const u64 *__restrict__ in, u64 n, u64 c, u64 *t) {
+template <class CT>
+__device__ __forceinline__ void load_scaled(const CT &C, const u64 *__restrict__ in, u64 n, u64 c, u64 (&t)[CT::kScaled]) {
     // converter.rs:160-176: x mod q_i when the factor is one, else the Shoup product — both are
     // (factor * x) mod q_i, canonical
-    for (u32 i = 0; i < C.lin; ++i) t[i] = mul_shoup(in[(u64)i * n + c], C.inv[i], C.inv_p[i], C.q[i]);
+#pragma unroll
+    for (int i = 0; i < CT::kScaled; ++i)
+        t[i] = (u32)i < C.lin ? mul_shoup(in[(u64)i * n + c], C.inv_in(i), C.inv_in_p(i), C.q_in(i)) : 0;
 }
 
-__global__ __launch_bounds__(kThreads) void fast_convert_kernel(ConvDev C, const u64 *__restrict__ in,
+template <class CT>
+__global__ __launch_bounds__(kThreads) void fast_convert_kernel(CT C, const u64 *__restrict__ in,
                                                                 u64 *__restrict__ out, u64 n) {
     const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
-    u64 t[kMaxLimbs];
+    u64 t[CT::kScaled];
     load_scaled(C, in, n, c, t);
     for (u32 j = 0; j < C.lout; ++j) out[(u64)j * n + c] = dot_mod(C, j, t);
 }
 
 // fast_convert_array_to_pair_iter (converter.rs:233-272): two output moduli, one (mod p_0, mod p_1) pair per
 // coefficient, written interleaved — one 16-byte store per thread
-__global__ __launch_bounds__(kThreads) void fast_convert_pair_kernel(ConvDev C, const u64 *__restrict__ in,
+template <class CT>
+__global__ __launch_bounds__(kThreads) void fast_convert_pair_kernel(CT C, const u64 *__restrict__ in,
                                                                      u64 *__restrict__ out, u64 n) {
     const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
-    u64 t[kMaxLimbs];
+    u64 t[CT::kScaled];
     load_scaled(C, in, n, c, t);
     *reinterpret_cast<ulonglong2 *>(out + 2 * c) = ulonglong2{dot_mod(C, 0, t), dot_mod(C, 1, t)};
 }
 
-__global__ __launch_bounds__(kThreads) void exact_convert_kernel(ConvDev C, const u64 *__restrict__ in,
+template <class CT>
+__global__ __launch_bounds__(kThreads) void exact_convert_kernel(CT C, const u64 *__restrict__ in,
                                                                  u64 *__restrict__ out, u64 n) {
     const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
-    u64 t[kMaxLimbs];
+    u64 t[CT::kScaled];
     load_scaled(C, in, n, c, t);
-    double sum = 0.0;
-    for (u32 i = 0; i < C.lin; ++i) sum = __dadd_rn(sum, __ddiv_rn((double)t[i], (double)C.q[i]));
+    double sum = 0.0;  // left to right, as converter.rs:291-345 sums
+#pragma unroll
+    for (int i = 0; i < CT::kScaled; ++i)
+        if ((u32)i < C.lin) sum = __dadd_rn(sum, __ddiv_rn((double)t[i], (double)C.q_in(i)));
     const double r = __dadd_rn(sum, 0.5);
     u64 v;  // Rust `as u64`: truncation toward zero, saturating, NaN -> 0
     if (!(r > 0.0)) v = 0;
     else if (r >= 18446744073709551616.0) v = ~0ull;
     else v = (u64)r;
     const u64 dot = dot_mod(C, 0, t);
-    const u64 vq = mul_mod_barrett(v, C.q_mod_p0, C.p[0], C.mu_lo[0], C.mu_hi[0]);
-    out[c] = sub_mod(dot, vq, C.p[0]);
+    const u64 vq = mul_mod_barrett(v, C.q_mod_p0, C.p_out(0), C.ratio_lo(0), C.ratio_hi(0));
+    out[c] = sub_mod(dot, vq, C.p_out(0));
 }
 
 // value mod q_i by Horner over the limbs, most significant first; every step reduces hi:lo < q*2^64
@@ -108,6 +150,20 @@ __global__ __launch_bounds__(kThreads) void decompose_big_kernel(ConvDev C, u32 
     for (u32 j = 0; j < C.lout; ++j) {
         u64 r = 0;
         for (u32 k = value_len; k-- > 0;) r = barrett_reduce128(v[k], r, C.p[j], C.mu_lo[j], C.mu_hi[j]);
+        multi[(u64)j * count + c] = r;
+    }
+}
+// the same for a wide base: the limbs are re-read per modulus (a thread's value_len words stay in its cache lines)
+__global__ __launch_bounds__(kThreads) void decompose_big_wide_kernel(RnsWide R, const u64 *__restrict__ values,
+                                                                      u64 *__restrict__ multi, u64 count) {
+    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= count) return;
+    const u32 value_len = R.value_len;
+    const u64 *__restrict__ v = values + c * value_len;
+    for (u32 j = 0; j < R.L; ++j) {
+        const u64 p = R.modulus(j), lo = R.ratio_lo(j), hi = R.ratio_hi(j);
+        u64 r = 0;
+        for (u32 k = value_len; k-- > 0;) r = barrett_reduce128(v[k], r, p, lo, hi);
         multi[(u64)j * count + c] = r;
     }
 }
@@ -126,14 +182,6 @@ u64 big_mod(const u64 *limbs, u32 len, u64 q) {
     return (u64)r;
 }
 
-void fill_output_side(ConvDev &c, const RnsDev &out) {
-    c.lout = out.L;
-    for (u32 j = 0; j < out.L; ++j) {
-        c.p[j] = out.q[j];
-        barrett_ratio(out.q[j], c.mu_lo[j], c.mu_hi[j]);
-    }
-}
-
 }  // namespace
 }  // namespace pfhe
 
@@ -141,8 +189,73 @@ using namespace pfhe;
 
 struct pfhe_conv {
     int device = 0;
-    ConvDev dev{};
+    u32 lin = 0, lout = 0;
+    ConvDev dev{};                     // valid when both bases have at most kMaxLimbs moduli
+    std::shared_ptr<DeviceBlob> blob;  // else: the device table of ConvWide
+    u64 q_mod_p0 = 0;
+    std::vector<u64> matrix;           // host copy, [lout][lin]
+    bool wide() const { return blob != nullptr; }
 };
+
+namespace {
+
+// table of the device-table form
+int conv_upload(int device, const RnsHost *in, const RnsHost &out, const std::vector<u64> &matrix,
+                std::shared_ptr<DeviceBlob> &blob) {
+    constexpr size_t W = kMaxWideLimbs;
+    std::vector<u64> t(kConvTableWords, 0);
+    const size_t lin = in ? in->moduli.size() : 0, lout = out.moduli.size();
+    for (size_t i = 0; i < lin; ++i) {
+        t[i] = in->moduli[i];
+        t[W + i] = in->inv_punct[i];
+        t[2 * W + i] = in->inv_punct_p[i];
+    }
+    for (size_t j = 0; j < lout; ++j) {
+        t[3 * W + j] = out.moduli[j];
+        barrett_ratio(out.moduli[j], t[4 * W + j], t[5 * W + j]);
+        for (size_t i = 0; i < lin; ++i) t[(6 + j) * W + i] = matrix[j * lin + i];
+    }
+    auto b = std::make_shared<DeviceBlob>();
+    b->device = device;
+    PFHE_HIP(counted_malloc(&b->ptr, t.size() * sizeof(u64)));
+    PFHE_HIP(hipMemcpy(b->ptr, t.data(), t.size() * sizeof(u64), hipMemcpyHostToDevice));
+    blob = std::move(b);
+    return PFHE_OK;
+}
+
+// runs F<CT>::launch with the constants in the form the converter holds
+template <template <class> class F, class... A>
+int conv_dispatch(const pfhe_conv *c, A &&...a) {
+    if (!c->wide()) return F<ConvDev>::launch(c->dev, a...);
+    const u64 *tab = (const u64 *)c->blob->ptr;
+    if (c->lin <= 8) return F<ConvWide<8>>::launch(ConvWide<8>{c->lin, c->lout, tab, c->q_mod_p0}, a...);
+    if (c->lin <= 16) return F<ConvWide<16>>::launch(ConvWide<16>{c->lin, c->lout, tab, c->q_mod_p0}, a...);
+    if (c->lin <= 24) return F<ConvWide<24>>::launch(ConvWide<24>{c->lin, c->lout, tab, c->q_mod_p0}, a...);
+    return F<ConvWide<32>>::launch(ConvWide<32>{c->lin, c->lout, tab, c->q_mod_p0}, a...);
+}
+template <class CT>
+struct FastLaunch {
+    static int launch(const CT &C, const u64 *in, u64 *out, u64 n, hipStream_t s) {
+        hipLaunchKernelGGL(fast_convert_kernel<CT>, dim3(grid_for(n)), dim3(kThreads), 0, s, C, in, out, n);
+        return PFHE_OK;
+    }
+};
+template <class CT>
+struct PairLaunch {
+    static int launch(const CT &C, const u64 *in, u64 *out, u64 n, hipStream_t s) {
+        hipLaunchKernelGGL(fast_convert_pair_kernel<CT>, dim3(grid_for(n)), dim3(kThreads), 0, s, C, in, out, n);
+        return PFHE_OK;
+    }
+};
+template <class CT>
+struct ExactLaunch {
+    static int launch(const CT &C, const u64 *in, u64 *out, u64 n, hipStream_t s) {
+        hipLaunchKernelGGL(exact_convert_kernel<CT>, dim3(grid_for(n)), dim3(kThreads), 0, s, C, in, out, n);
+        return PFHE_OK;
+    }
+};
+
+}  // namespace
 
 extern "C" {
 
@@ -155,43 +268,59 @@ int pfhe_conv_create(const pfhe_rns *input_base, const pfhe_rns *output_base, pf
         return PFHE_ERR_BAD_ARGUMENT;
     }
     auto c = std::make_unique<pfhe_conv>();
-    const RnsDev &in = input_base->h.dev;
-    c->device = input_base->h.device;
-    c->dev.lin = in.L;
-    for (u32 i = 0; i < in.L; ++i) {
-        c->dev.q[i] = in.q[i];
-        c->dev.inv[i] = in.inv_punct[i];
-        c->dev.inv_p[i] = in.inv_punct_p[i];
+    const RnsHost &in = input_base->h, &ob = output_base->h;
+    const u32 lin = (u32)in.moduli.size(), lout = (u32)ob.moduli.size(), len = in.par.dev.value_len;
+    c->device = in.device;
+    c->lin = lin;
+    c->lout = lout;
+    c->matrix.assign((size_t)lin * lout, 0);
+    for (u32 j = 0; j < lout; ++j)
+        for (u32 i = 0; i < lin; ++i) c->matrix[(size_t)j * lin + i] = big_mod(&in.punct[(size_t)i * len], len, ob.moduli[j]);
+    c->q_mod_p0 = big_mod(in.Q.data(), len, ob.moduli[0]);
+    if (lin <= (u32)kMaxLimbs && lout <= (u32)kMaxLimbs) {
+        ConvDev &d = c->dev;
+        d.lin = lin;
+        d.lout = lout;
+        for (u32 i = 0; i < lin; ++i) {
+            d.q[i] = in.moduli[i];
+            d.inv[i] = in.inv_punct[i];
+            d.inv_p[i] = in.inv_punct_p[i];
+        }
+        for (u32 j = 0; j < lout; ++j) {
+            d.p[j] = ob.moduli[j];
+            barrett_ratio(ob.moduli[j], d.mu_lo[j], d.mu_hi[j]);
+            for (u32 i = 0; i < lin; ++i) d.m[j][i] = c->matrix[(size_t)j * lin + i];
+        }
+        d.q_mod_p0 = c->q_mod_p0;
+    } else {
+        DeviceGuard g(c->device);
+        if (!g.ok) return PFHE_ERR_NO_DEVICE;
+        PFHE_TRY(conv_upload(c->device, &in, ob, c->matrix, c->blob));
     }
-    fill_output_side(c->dev, output_base->h.dev);
-    for (u32 j = 0; j < c->dev.lout; ++j)
-        for (u32 i = 0; i < in.L; ++i) c->dev.m[j][i] = big_mod(in.punct[i], in.value_len, c->dev.p[j]);
-    c->dev.q_mod_p0 = big_mod(in.Q, in.value_len, c->dev.p[0]);
     *out = c.release();
     return PFHE_OK;
     PFHE_GUARD_END
 }
 
 void pfhe_conv_destroy(pfhe_conv *c) { delete c; }
-size_t pfhe_conv_input_moduli_count(const pfhe_conv *c) { return c ? c->dev.lin : 0; }
-size_t pfhe_conv_output_moduli_count(const pfhe_conv *c) { return c ? c->dev.lout : 0; }
+size_t pfhe_conv_input_moduli_count(const pfhe_conv *c) { return c ? c->lin : 0; }
+size_t pfhe_conv_output_moduli_count(const pfhe_conv *c) { return c ? c->lout : 0; }
 
 int pfhe_conv_base_change_matrix(const pfhe_conv *c, uint64_t *out, size_t len) {
     if (!c || !out) return PFHE_ERR_BAD_ARGUMENT;
-    if (len != (size_t)c->dev.lin * c->dev.lout) return PFHE_ERR_BAD_LENGTH;
-    for (u32 j = 0; j < c->dev.lout; ++j)
-        for (u32 i = 0; i < c->dev.lin; ++i) out[j * c->dev.lin + i] = c->dev.m[j][i];
+    if (len != c->matrix.size()) return PFHE_ERR_BAD_LENGTH;
+    std::copy(c->matrix.begin(), c->matrix.end(), out);
     return PFHE_OK;
 }
 
 static int conv_check(const pfhe_conv *c, const void *in, size_t len_in, const void *out, size_t len_out,
                       size_t poly_length, bool exact) {
     if (!c || ((!in || !out) && poly_length)) return PFHE_ERR_BAD_ARGUMENT;
-    if (exact && c->dev.lout != 1) {  // converter.rs:284-288 asserts
+    if (exact && c->lout != 1) {  // converter.rs:284-288 asserts
         set_last_error("output base in exact_convert_array must hold exactly one modulus");
         return PFHE_ERR_BAD_ARGUMENT;
     }
-    if (len_in != poly_length * c->dev.lin || len_out != poly_length * c->dev.lout) return PFHE_ERR_BAD_LENGTH;
+    if (len_in != poly_length * c->lin || len_out != poly_length * c->lout) return PFHE_ERR_BAD_LENGTH;
     return PFHE_OK;
 }
 
@@ -202,8 +331,7 @@ int pfhe_conv_fast_convert_array_dev(const pfhe_conv *c, const uint64_t *crt_pol
     if (poly_length == 0) return PFHE_OK;
     DeviceGuard g(c->device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    hipLaunchKernelGGL(fast_convert_kernel, dim3(grid_for(poly_length)), dim3(kThreads), 0, (hipStream_t)stream, c->dev,
-                       (const u64 *)crt_poly_in_dev, (u64 *)crt_poly_out_dev, (u64)poly_length);
+    PFHE_TRY((conv_dispatch<FastLaunch>(c, (const u64 *)crt_poly_in_dev, (u64 *)crt_poly_out_dev, (u64)poly_length, (hipStream_t)stream)));
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
     PFHE_GUARD_END
@@ -213,17 +341,16 @@ int pfhe_conv_fast_convert_array_to_pairs_dev(const pfhe_conv *c, const uint64_t
                                               uint64_t *pairs_out_dev, size_t len_out, size_t poly_length, void *stream) {
     PFHE_GUARD_BEGIN
     if (!c || ((!crt_poly_in_dev || !pairs_out_dev) && poly_length)) return PFHE_ERR_BAD_ARGUMENT;
-    if (c->dev.lout != 2) {  // converter.rs:239-243 asserts
+    if (c->lout != 2) {  // converter.rs:239-243 asserts
         set_last_error("output base in fast_convert_array_to_pair must contain exactly two moduli");
         return PFHE_ERR_BAD_ARGUMENT;
     }
-    if (len_in != poly_length * c->dev.lin || len_out != 2 * poly_length) return PFHE_ERR_BAD_LENGTH;
+    if (len_in != poly_length * c->lin || len_out != 2 * poly_length) return PFHE_ERR_BAD_LENGTH;
     PFHE_REQUIRE_ALIGNED(pairs_out_dev);
     if (poly_length == 0) return PFHE_OK;
     DeviceGuard g(c->device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    hipLaunchKernelGGL(fast_convert_pair_kernel, dim3(grid_for(poly_length)), dim3(kThreads), 0, (hipStream_t)stream,
-                       c->dev, (const u64 *)crt_poly_in_dev, (u64 *)pairs_out_dev, (u64)poly_length);
+    PFHE_TRY((conv_dispatch<PairLaunch>(c, (const u64 *)crt_poly_in_dev, (u64 *)pairs_out_dev, (u64)poly_length, (hipStream_t)stream)));
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
     PFHE_GUARD_END
@@ -236,8 +363,7 @@ int pfhe_conv_exact_convert_array_dev(const pfhe_conv *c, const uint64_t *crt_po
     if (poly_length == 0) return PFHE_OK;
     DeviceGuard g(c->device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    hipLaunchKernelGGL(exact_convert_kernel, dim3(grid_for(poly_length)), dim3(kThreads), 0, (hipStream_t)stream, c->dev,
-                       (const u64 *)crt_poly_in_dev, (u64 *)crt_poly_out_dev, (u64)poly_length);
+    PFHE_TRY((conv_dispatch<ExactLaunch>(c, (const u64 *)crt_poly_in_dev, (u64 *)crt_poly_out_dev, (u64)poly_length, (hipStream_t)stream)));
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
     PFHE_GUARD_END
@@ -282,15 +408,24 @@ int pfhe_rns_decompose_big_uint_values_to_dev(const pfhe_rns *r, const uint64_t 
                                               void *stream) {
     PFHE_GUARD_BEGIN
     if (!r || ((!big_uint_values_dev || !multi_residues_dev) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
-    const RnsDev &R = r->h.dev;
+    const RnsDev &R = r->h.par.dev;
     if (len_in != value_count * R.value_len || len_out != value_count * R.L) return PFHE_ERR_BAD_LENGTH;
     if (value_count == 0) return PFHE_OK;
     DeviceGuard g(r->h.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    ConvDev c{};
-    fill_output_side(c, R);
-    hipLaunchKernelGGL(decompose_big_kernel, dim3(grid_for(value_count)), dim3(kThreads), 0, (hipStream_t)stream, c,
-                       R.value_len, (const u64 *)big_uint_values_dev, (u64 *)multi_residues_dev, (u64)value_count);
+    if (r->h.par.wide()) {
+        hipLaunchKernelGGL(decompose_big_wide_kernel, dim3(grid_for(value_count)), dim3(kThreads), 0, (hipStream_t)stream,
+                           r->h.par.wide_tab, (const u64 *)big_uint_values_dev, (u64 *)multi_residues_dev, (u64)value_count);
+    } else {
+        ConvDev c{};
+        c.lout = R.L;
+        for (u32 j = 0; j < R.L; ++j) {
+            c.p[j] = R.q[j];
+            barrett_ratio(R.q[j], c.mu_lo[j], c.mu_hi[j]);
+        }
+        hipLaunchKernelGGL(decompose_big_kernel, dim3(grid_for(value_count)), dim3(kThreads), 0, (hipStream_t)stream, c,
+                           R.value_len, (const u64 *)big_uint_values_dev, (u64 *)multi_residues_dev, (u64)value_count);
+    }
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
     PFHE_GUARD_END
@@ -300,7 +435,7 @@ int pfhe_rns_decompose_big_uint_values_to(const pfhe_rns *r, const uint64_t *big
                                           uint64_t *multi_residues, size_t len_out, size_t value_count) {
     PFHE_GUARD_BEGIN
     if (!r || ((!big_uint_values || !multi_residues) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (len_in != value_count * r->h.dev.value_len || len_out != value_count * r->h.dev.L) return PFHE_ERR_BAD_LENGTH;
+    if (len_in != value_count * r->h.par.dev.value_len || len_out != value_count * r->h.par.dev.L) return PFHE_ERR_BAD_LENGTH;
     if (value_count == 0) return PFHE_OK;
     DeviceGuard g(r->h.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;

@@ -27,7 +27,7 @@ namespace pfhe {
 namespace {
 
 constexpr int kEwThreads = 256;
-constexpr int kMaxEwLimbs = 8;
+constexpr int kMaxEwLimbs = 32;  // per-limb scalars travel as kernel arguments (512 bytes)
 // Launch shape, measured on 3 GiB operands (tools/perf_elementwise.py): one 16-byte vector per thread and as many
 // workgroups as there are vectors (the dispatcher then walks memory in address order) with non-temporal loads and
 // stores streams at 6.3 TB/s; the usual "8 workgroups per CU + grid-stride loop, 4 vectors in flight per thread"
@@ -245,7 +245,6 @@ int check_common(const pfhe_dcrt *table, const void *p0, const void *p1, const v
         set_last_error("length must be a whole number of RNS polynomials (L * N words)");
         return PFHE_ERR_BAD_LENGTH;
     }
-    if (t.L > (u32)kMaxEwLimbs) return PFHE_ERR_UNSUPPORTED;
     return PFHE_OK;
 }
 
@@ -260,6 +259,10 @@ int binary_op(const pfhe_dcrt *table, const uint64_t *a, const uint64_t *b, uint
 // scalars: L plain residues (factor == false) or L (value, quotient) pairs
 int load_scalars(const TableSet &t, const uint64_t *scalars, bool factor, EwScalars &sc) {
     if (!scalars) return PFHE_ERR_BAD_ARGUMENT;
+    if (t.L > (u32)kMaxEwLimbs) {  // add / sub / neg / monomial / inv take any number of limbs; the scalar forms 32
+        set_last_error("per-limb scalars are supported for at most 32 limbs");
+        return PFHE_ERR_UNSUPPORTED;
+    }
     for (u32 r = 0; r < t.L; ++r) {
         sc.value[r] = factor ? scalars[2 * r] : scalars[r];
         if (sc.value[r] >= t.primes[r].q) {

@@ -215,48 +215,88 @@ __global__ __launch_bounds__(LOGE == 3 ? 512 : 256, LOGE == 3 ? kMulacc8MinWaves
 // across all levels: 234 VGPRs at 3 limbs and 528 bytes of scratch per lane at 4.  The digit width is now a template
 // parameter of the two kernels and that kernel is gone.)
 // ------------------------------------------------------------------------------------------
-// Two adjacent coefficients per thread: 16-byte loads of the residues, one store of the digit pair.
-template <int LEN, class DT = int>
-__global__ __launch_bounds__(256) void gadget_signed_digits_kernel(RnsDev R, BasisDev B, u32 log_n,
+// CPT coefficients per thread.  Two adjacent ones for big integers of at most 4 limbs held by value (16-byte loads of
+// the residues, one store of the digit pair: every BASELINE config); one for longer integers and for the device-table
+// form of a wide base (RT = RnsWide, BT = BasisDev or BasisWide), whose residues are fetched as the lift consumes them.
+template <int LEN, class DT, class RT, class BT, int CPT>
+__global__ __launch_bounds__(256) void gadget_signed_digits_kernel(RT R, BT B, u32 log_n,
                                                                   const u64 *__restrict__ crt, DT *__restrict__ out,
-                                                                  u64 total_pairs) {
+                                                                  u64 total_threads) {
     const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total_pairs) return;
+    if (gid >= total_threads) return;
     const u32 n = 1u << log_n;
-    const u64 poly = (gid * 2) >> log_n;
-    const u32 t = (u32)((gid * 2) & (n - 1));
-    u64 v[2][LEN];
+    const u64 poly = (gid * CPT) >> log_n;
+    const u32 t = (u32)((gid * CPT) & (n - 1));
+    const u32 vl = kByValue<RT> ? (u32)LEN : R.value_len;
+    u64 v[CPT][LEN];
     if (R.big_input) {  // BigUintPolynomial input (glwe/dcrt.rs:258-338): already composed
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
+        for (int e = 0; e < CPT; ++e)
 #pragma unroll
-            for (int j = 0; j < LEN; ++j) v[e][j] = crt[(poly * n + t + e) * LEN + j];
-    } else {
-        u64 r[2][kMaxLimbs];
+            for (int j = 0; j < LEN; ++j) v[e][j] = (u32)j < vl ? crt[(poly * n + t + e) * vl + j] : 0;
+    } else if constexpr (kByValue<RT>) {
+        u64 r[CPT][kMaxLimbs];
         for (u32 i = 0; i < R.L; ++i) {
-            const u64x2 w = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(crt + (poly * R.L + i) * n + t));  // read once
-            r[0][i] = w.x;
-            r[1][i] = w.y;
+            if constexpr (CPT == 2) {
+                const u64x2 w = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(crt + (poly * R.L + i) * n + t));  // read once
+                r[0][i] = w.x;
+                r[1][i] = w.y;
+            } else {
+                r[0][i] = __builtin_nontemporal_load(crt + (poly * R.L + i) * n + t);
+            }
         }
-        compose<LEN>(R, r[0], v[0]);
-        compose<LEN>(R, r[1], v[1]);
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) compose<LEN>(R, r[e], v[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < CPT; ++e)
+            compose_general<LEN>(R, [&](u32 i) { return __builtin_nontemporal_load(crt + (poly * R.L + i) * n + t + e); }, v[e]);
     }
-    u32 carry[2] = {init_value_carry<LEN>(B, v[0]), init_value_carry<LEN>(B, v[1])};
+    u32 carry[CPT];
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) carry[e] = init_value_carry<LEN>(B, v[e]);
     const u64 half = (B.basis + 1) / 2;
     DT *__restrict__ o = out + poly * B.ell * n + t;
     typedef DT DT2 __attribute__((ext_vector_type(2)));
     for (u32 j = 0; j < B.ell; ++j) {
-        DT d[2];
+        DT d[CPT];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < CPT; ++e) {
             const u64 temp = window<LEN>(v[e], B.drop_bits + j * B.log_basis, B.basis_minus_one, B.log_basis) + carry[e];
             carry[e] = (temp & B.carry_mask) != 0;
             const u64 u = temp & B.basis_minus_one;
             d[e] = (B.basis != 2 && u >= half) ? (DT)((long long)u - (long long)B.basis) : (DT)u;
         }
-        *reinterpret_cast<DT2 *>(o + (u64)j * n) = DT2{d[0], d[1]};
+        if constexpr (CPT == 2) *reinterpret_cast<DT2 *>(o + (u64)j * n) = DT2{d[0], d[1]};
+        else o[(u64)j * n] = d[0];
     }
 }
+
+// steps (1)-(3) for `npolys` polynomials of 2^log_n coefficients (log_n >= 1), any base the handles accept
+template <class DT>
+struct SignedDigitsLaunch {
+    template <int LEN>
+    struct At {
+        static int run(const RnsParams &r, const BasisParams &b, u32 log_n, const u64 *crt, DT *sdigits, u64 npolys, hipStream_t s) {
+            const u64 coeffs = npolys << log_n;
+            constexpr int CPT = LEN <= 4 ? 2 : 1;
+            if (b.wide()) {
+                hipLaunchKernelGGL((gadget_signed_digits_kernel<LEN, DT, RnsWide, BasisWide, 1>), dim3((u32)((coeffs + 255) / 256)), dim3(256), 0, s,
+                                   r.wide_tab, b.wide_tab, log_n, crt, sdigits, coeffs);
+            } else if constexpr (LEN <= kMaxLimbs) {
+                if (r.wide()) {
+                    hipLaunchKernelGGL((gadget_signed_digits_kernel<LEN, DT, RnsWide, BasisDev, 1>), dim3((u32)((coeffs + 255) / 256)), dim3(256), 0, s,
+                                       r.wide_tab, b.dev, log_n, crt, sdigits, coeffs);
+                } else {
+                    const u64 threads = coeffs / CPT;
+                    hipLaunchKernelGGL((gadget_signed_digits_kernel<LEN, DT, RnsDev, BasisDev, CPT>), dim3((u32)((threads + 255) / 256)), dim3(256), 0, s,
+                                       r.dev, b.dev, log_n, crt, sdigits, threads);
+                }
+            }
+            return PFHE_OK;
+        }
+    };
+};
 
 template <class A, int K, class DT = int>
 __global__ __launch_bounds__(256, 4) void digits_strided_kernel(const NttPrime *__restrict__ primes, u32 L, u32 log_n,
@@ -288,23 +328,12 @@ __global__ __launch_bounds__(256, 4) void digits_strided_kernel(const NttPrime *
 }
 
 template <class A, int K, class DT>
-int launch_digits_strided(const RnsDev &r, const BasisDev &b, const NttPrime *primes, u32 log_n, const u64 *crt,
+int launch_digits_strided(const RnsParams &r, const BasisParams &b, const NttPrime *primes, u32 log_n, const u64 *crt,
                           DT *sdigits, u64 *digits, u64 npolys, hipStream_t s) {
-    const u64 coeffs = (npolys << log_n) / 2;  // two coefficients per thread (N >= 2^9 on this path)
-    const u32 g1 = (u32)((coeffs + 255) / 256);
-    switch (r.value_len) {
-#define PFHE_CASE(LEN)                                                                                        \
-    case LEN:                                                                                                 \
-        hipLaunchKernelGGL((gadget_signed_digits_kernel<LEN, DT>), dim3(g1), dim3(256), 0, s, r, b, log_n, crt, sdigits, \
-                           coeffs);                                                                           \
-        break;
-        PFHE_CASE(1) PFHE_CASE(2) PFHE_CASE(3) PFHE_CASE(4)
-#undef PFHE_CASE
-        default: return PFHE_ERR_UNSUPPORTED;
-    }
+    PFHE_TRY((dispatch_len<SignedDigitsLaunch<DT>::template At>(r.dev.value_len, r, b, log_n, crt, sdigits, npolys, s)));
     PFHE_HIP(hipGetLastError());
-    const u64 total = (npolys * b.ell) << (log_n - K);
-    hipLaunchKernelGGL((digits_strided_kernel<A, K, DT>), dim3((u32)((total + 255) / 256)), dim3(256), 0, s, primes, r.L,
+    const u64 total = (npolys * b.dev.ell) << (log_n - K);
+    hipLaunchKernelGGL((digits_strided_kernel<A, K, DT>), dim3((u32)((total + 255) / 256)), dim3(256), 0, s, primes, r.dev.L,
                        log_n, (const DT *)sdigits, digits, total);
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
@@ -494,7 +523,7 @@ namespace pfhe {
 // most 4 stages (N = 2^13 * 2^K... i.e. block 2^12 and K <= 4) and big integers of at most 4 limbs
 bool gadget_decompose_strided_supported(u32 log_n, u32 value_len) {
     const NttPlan plan = make_ntt_plan(log_n);
-    return !plan.tiny && plan.n_strided == 1 && plan.strided[0] >= 3 && plan.strided[0] <= 4 && value_len <= 4;
+    return !plan.tiny && plan.n_strided == 1 && plan.strided[0] >= 3 && plan.strided[0] <= 4 && value_len <= (u32)kMaxWideLimbs;
 }
 
 // Small-ring path (extprod_small_kernel): digits that fit int32; enabled where it measured faster than the
@@ -505,21 +534,10 @@ bool extprod_small_supported(u32 log_n, u32 k, u32 value_len, u32 log_basis) {
 }
 
 // steps (1)-(3) alone: balanced int32 digits of `npolys` CRT polynomials ([poly][level][N])
-int gadget_signed_digits_dev(const RnsDev &r, const BasisDev &b, u32 log_n, const u64 *crt_polys, int *sdigits,
+int gadget_signed_digits_dev(const RnsParams &r, const BasisParams &b, u32 log_n, const u64 *crt_polys, int *sdigits,
                              u64 npolys, hipStream_t s) {
-    const u64 coeffs = (npolys << log_n) / 2;  // two coefficients per thread
-    if (coeffs == 0) return PFHE_OK;
-    const u32 g1 = (u32)((coeffs + 255) / 256);
-    switch (r.value_len) {
-#define PFHE_CASE(LEN)                                                                                              \
-    case LEN:                                                                                                       \
-        hipLaunchKernelGGL((gadget_signed_digits_kernel<LEN>), dim3(g1), dim3(256), 0, s, r, b, log_n, crt_polys, sdigits, \
-                           coeffs);                                                                                 \
-        break;
-        PFHE_CASE(1) PFHE_CASE(2) PFHE_CASE(3) PFHE_CASE(4)
-#undef PFHE_CASE
-        default: return PFHE_ERR_UNSUPPORTED;
-    }
+    if ((npolys << log_n) == 0) return PFHE_OK;
+    PFHE_TRY((dispatch_len<SignedDigitsLaunch<int>::At>(r.dev.value_len, r, b, log_n, crt_polys, sdigits, npolys, s)));
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
 }
@@ -542,16 +560,16 @@ int extprod_small_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u32 k
 size_t gadget_digit_bytes(u32 log_basis) { return log_basis <= 31 ? sizeof(int) : sizeof(long long); }
 
 template <class A, int K>
-static int digits_strided_by_width(const RnsDev &r, const BasisDev &b, const NttPrime *primes, u32 log_n, const u64 *crt_polys,
+static int digits_strided_by_width(const RnsParams &r, const BasisParams &b, const NttPrime *primes, u32 log_n, const u64 *crt_polys,
                                    void *sdigits, u64 *digits, u64 npolys, hipStream_t s) {
-    return b.log_basis <= 31
+    return b.dev.log_basis <= 31
                ? launch_digits_strided<A, K, int>(r, b, primes, log_n, crt_polys, (int *)sdigits, digits, npolys, s)
                : launch_digits_strided<A, K, long long>(r, b, primes, log_n, crt_polys, (long long *)sdigits, digits, npolys, s);
 }
 
-int gadget_decompose_strided_dev(const RnsDev &r, const BasisDev &b, const NttPrime *primes, u32 log_n, int arith,
+int gadget_decompose_strided_dev(const RnsParams &r, const BasisParams &b, const NttPrime *primes, u32 log_n, int arith,
                                  const u64 *crt_polys, u64 *digits, u64 npolys, hipStream_t s, void *sdigits) {
-    if (!gadget_decompose_strided_supported(log_n, r.value_len) || sdigits == nullptr) return PFHE_ERR_UNSUPPORTED;
+    if (!gadget_decompose_strided_supported(log_n, r.dev.value_len) || sdigits == nullptr) return PFHE_ERR_UNSUPPORTED;
     if (npolys == 0) return PFHE_OK;
     const int k = make_ntt_plan(log_n).strided[0];
     if (arith == kArithPm) {

@@ -12,9 +12,12 @@
 // (1)-(4) additionally as ONE fused kernel that keeps the composed big integer in registers and
 // never writes it (the reference writes N*value_len words of scratch and re-reads them ell times).
 // All values are exact integers; every output is canonical.
+#include <type_traits>
+
 #include "pfhe_modmath.hpp"
 #include "pfhe_rns.hpp"
 #include "pfhe_rns_device.hpp"
+#include "pfhe_staging.hpp"
 
 namespace pfhe {
 
@@ -37,21 +40,31 @@ __device__ __forceinline__ u64 window_dyn(const u64 *v, u32 start, u64 mask, u32
 }
 
 // ---- unfused kernels: one reference slice function each ----
+// RT: RnsDev (constants by value) or RnsWide (device table); BT: BasisDev or BasisWide.  A by-value instantiation is
+// compiled for the exact limb count LEN = value_len; a wide one for value_len rounded up (zero top limbs) and addresses
+// memory with the run-time value_len.
 
-template <int LEN>
-__global__ __launch_bounds__(kThreads) void compose_kernel(RnsDev R, const u64 *__restrict__ multi,
+template <int LEN, class RT>
+__global__ __launch_bounds__(kThreads) void compose_kernel(RT R, const u64 *__restrict__ multi,
                                                            u64 *__restrict__ out, u64 count) {
     const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= count) return;
-    u64 r[kMaxLimbs];
-    for (u32 i = 0; i < R.L; ++i) r[i] = multi[(u64)i * count + c];
     u64 v[LEN];
-    compose<LEN>(R, r, v);
+    if constexpr (kByValue<RT>) {
+        u64 r[kMaxLimbs];
+        for (u32 i = 0; i < R.L; ++i) r[i] = multi[(u64)i * count + c];
+        compose<LEN>(R, r, v);
+    } else {
+        compose_general<LEN>(R, [&](u32 i) { return multi[(u64)i * count + c]; }, v);
+    }
+    const u32 vl = kByValue<RT> ? (u32)LEN : R.value_len;
 #pragma unroll
-    for (int j = 0; j < LEN; ++j) out[c * LEN + j] = v[j];
+    for (int j = 0; j < LEN; ++j)
+        if ((u32)j < vl) out[c * vl + j] = v[j];
 }
 
-__global__ __launch_bounds__(kThreads) void wrapping_decompose_kernel(RnsDev R, const u64 *__restrict__ small,
+template <class RT>
+__global__ __launch_bounds__(kThreads) void wrapping_decompose_kernel(RT R, const u64 *__restrict__ small,
                                                                      u64 *__restrict__ multi, u64 count,
                                                                      u64 small_modulus) {
     const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -60,7 +73,7 @@ __global__ __launch_bounds__(kThreads) void wrapping_decompose_kernel(RnsDev R, 
     const u64 half = (small_modulus + 1) / 2;
     for (u32 i = 0; i < R.L; ++i) {
         u64 o = v;
-        if (small_modulus != 2 && v >= half) o = R.q[i] - small_modulus + v;
+        if (small_modulus != 2 && v >= half) o = R.modulus(i) - small_modulus + v;
         multi[(u64)i * count + c] = o;
     }
 }
@@ -69,40 +82,44 @@ __global__ __launch_bounds__(kThreads) void wrapping_decompose_kernel(RnsDev R, 
 // (base.rs:326-384, slice::wrapping_decompose_chunk_scaled_to :739-757) when `centred`, else
 // add_decompose_small_values_scaled (base.rs:398-416; also the reference's small_value_modulus == 2 branch).
 // `fv` / `fq`: the ShoupFactor (value, quotient) of each modulus.
+template <int MAXL>
 struct ScaledFactors {
-    u64 value[kMaxLimbs], quotient[kMaxLimbs];
+    u64 value[MAXL], quotient[MAXL];
 };
-__global__ __launch_bounds__(kThreads) void add_decompose_scaled_kernel(RnsDev R, const u64 *__restrict__ small,
+template <class RT, int MAXL>
+__global__ __launch_bounds__(kThreads) void add_decompose_scaled_kernel(RT R, const u64 *__restrict__ small,
                                                                        u64 *__restrict__ acc, u64 count,
                                                                        u64 small_modulus, bool centred,
-                                                                       ScaledFactors F) {
+                                                                       ScaledFactors<MAXL> F) {
     const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= count) return;
     const u64 v = small[c];
     const u64 half = (small_modulus + 1) / 2;
     for (u32 i = 0; i < R.L; ++i) {
-        const u64 q = R.q[i];
+        const u64 q = R.modulus(i);
         const u64 lifted = (centred && v >= half) ? q - small_modulus + v : v;
         const u64 idx = (u64)i * count + c;
         acc[idx] = add_mod(acc[idx], mul_shoup(lifted, F.value[i], F.quotient[i], q), q);
     }
 }
 
-template <int LEN>
-__global__ __launch_bounds__(kThreads) void init_value_carry_kernel(BasisDev B, u64 *__restrict__ values,
+template <int LEN, class BT>
+__global__ __launch_bounds__(kThreads) void init_value_carry_kernel(BT B, u64 *__restrict__ values,
                                                                     unsigned char *__restrict__ carries, u64 count) {
     const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= count) return;
+    const u32 vl = kByValue<BT> ? (u32)LEN : B.value_len;
     u64 v[LEN];
 #pragma unroll
-    for (int j = 0; j < LEN; ++j) v[j] = values[c * LEN + j];
+    for (int j = 0; j < LEN; ++j) v[j] = (u32)j < vl ? values[c * vl + j] : 0;
     const u32 carry = init_value_carry<LEN>(B, v);
 #pragma unroll
-    for (int j = 0; j < LEN; ++j) values[c * LEN + j] = v[j];
+    for (int j = 0; j < LEN; ++j)
+        if ((u32)j < vl) values[c * vl + j] = v[j];
     carries[c] = (unsigned char)carry;
 }
 
-__global__ __launch_bounds__(kThreads) void unsigned_decompose_kernel(BasisDev B, u32 level,
+__global__ __launch_bounds__(kThreads) void unsigned_decompose_kernel(BasisCore B, u32 level,
                                                                      const u64 *__restrict__ values,
                                                                      u64 *__restrict__ digits,
                                                                      unsigned char *__restrict__ carries, u64 count) {
@@ -116,7 +133,8 @@ __global__ __launch_bounds__(kThreads) void unsigned_decompose_kernel(BasisDev B
 
 // common.rs:255-272 over a slice (:289-306): the signed digit as a residue modulo Q.  With the carry set the digit
 // temp stands for temp - B and is stored as (Q - B) + temp; temp == B is the digit 0.
-__global__ __launch_bounds__(kThreads) void signed_decompose_kernel(RnsDev R, BasisDev B, u32 level,
+template <class RT>
+__global__ __launch_bounds__(kThreads) void signed_decompose_kernel(RT R, BasisCore B, u32 level,
                                                                    const u64 *__restrict__ values,
                                                                    u64 *__restrict__ out,
                                                                    unsigned char *__restrict__ carries, u64 count) {
@@ -132,7 +150,7 @@ __global__ __launch_bounds__(kThreads) void signed_decompose_kernel(RnsDev R, Ba
         // Q - (B - temp), limb by limb with borrow (B - temp >= 1)
         u64 sub = B.basis - temp;
         for (u32 j = 0; j < len; ++j) {
-            const u64 q = R.Q[j];
+            const u64 q = R.product(j);
             d[j] = q - sub;
             sub = q < sub ? 1 : 0;
         }
@@ -143,23 +161,28 @@ __global__ __launch_bounds__(kThreads) void signed_decompose_kernel(RnsDev R, Ba
 }
 
 // ---- fused steps (1)-(4): one thread per coefficient, big integer kept in registers ----
-template <int LEN>
-__global__ __launch_bounds__(kThreads) void gadget_decompose_kernel(RnsDev R, BasisDev B, u32 log_n,
+template <int LEN, class RT, class BT>
+__global__ __launch_bounds__(kThreads) void gadget_decompose_kernel(RT R, BT B, u32 log_n,
                                                                    const u64 *__restrict__ crt, u64 *__restrict__ out,
                                                                    u64 total) {
     const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total) return;
     const u64 n = 1ull << log_n;
     const u64 poly = gid >> log_n, t = gid & (n - 1);
+    const u32 vl = kByValue<RT> ? (u32)LEN : R.value_len;
     u64 v[LEN];
     if (R.big_input) {  // glwe/dcrt.rs:258-338: the polynomial arrives composed
 #pragma unroll
-        for (int j = 0; j < LEN; ++j) v[j] = crt[(poly * n + t) * LEN + j];
+        for (int j = 0; j < LEN; ++j) v[j] = (u32)j < vl ? crt[(poly * n + t) * vl + j] : 0;
     } else {
         const u64 *__restrict__ in = crt + poly * R.L * n + t;
-        u64 r[kMaxLimbs];
-        for (u32 i = 0; i < R.L; ++i) r[i] = in[(u64)i * n];
-        compose<LEN>(R, r, v);
+        if constexpr (kByValue<RT>) {
+            u64 r[kMaxLimbs];
+            for (u32 i = 0; i < R.L; ++i) r[i] = in[(u64)i * n];
+            compose<LEN>(R, r, v);
+        } else {
+            compose_general<LEN>(R, [&](u32 i) { return in[(u64)i * n]; }, v);
+        }
     }
     u32 carry = init_value_carry<LEN>(B, v);
     const u64 half = (B.basis + 1) / 2;
@@ -170,7 +193,7 @@ __global__ __launch_bounds__(kThreads) void gadget_decompose_kernel(RnsDev R, Ba
         const u64 u = temp & B.basis_minus_one;
         for (u32 i = 0; i < R.L; ++i) {
             u64 res = u;
-            if (B.basis != 2 && u >= half) res = R.q[i] - B.basis + u;  // centred lift, base.rs:721-730
+            if (B.basis != 2 && u >= half) res = R.modulus(i) - B.basis + u;  // centred lift, base.rs:721-730
             o[((u64)j * R.L + i) * n] = res;
         }
     }
@@ -219,108 +242,160 @@ __global__ __launch_bounds__(kThreads) void gadget_mulacc_kernel(const NttPrime 
     *out = barrett_reduce128(lo, hi, P->q, P->bar_lo, P->bar_hi);
 }
 
-template <template <int> class F, class... A>
-int dispatch_len(u32 len, A &&...a) {
-    switch (len) {
-        case 1: return F<1>::run(a...);
-        case 2: return F<2>::run(a...);
-        case 3: return F<3>::run(a...);
-        case 4: return F<4>::run(a...);
-        case 5: return F<5>::run(a...);
-        case 6: return F<6>::run(a...);
-        case 7: return F<7>::run(a...);
-        case 8: return F<8>::run(a...);
-    }
-    set_last_error("unsupported big-integer length");
-    return PFHE_ERR_UNSUPPORTED;
-}
-
 template <int LEN>
 struct ComposeLaunch {
-    static int run(const RnsDev &r, const u64 *multi, u64 *out, u64 count, hipStream_t s) {
-        hipLaunchKernelGGL(compose_kernel<LEN>, dim3(grid_for(count)), dim3(kThreads), 0, s, r, multi, out, count);
+    static int run(const RnsParams &r, const u64 *multi, u64 *out, u64 count, hipStream_t s) {
+        const dim3 g(grid_for(count)), th(kThreads);
+        if (r.wide()) hipLaunchKernelGGL((compose_kernel<LEN, RnsWide>), g, th, 0, s, r.wide_tab, multi, out, count);
+        else if constexpr (LEN <= kMaxLimbs) hipLaunchKernelGGL((compose_kernel<LEN, RnsDev>), g, th, 0, s, r.dev, multi, out, count);
         return PFHE_OK;
     }
 };
 template <int LEN>
 struct InitLaunch {
-    static int run(const BasisDev &b, u64 *values, unsigned char *carries, u64 count, hipStream_t s) {
-        hipLaunchKernelGGL(init_value_carry_kernel<LEN>, dim3(grid_for(count)), dim3(kThreads), 0, s, b, values,
-                           carries, count);
+    static int run(const BasisParams &b, u64 *values, unsigned char *carries, u64 count, hipStream_t s) {
+        const dim3 g(grid_for(count)), th(kThreads);
+        if (b.wide()) hipLaunchKernelGGL((init_value_carry_kernel<LEN, BasisWide>), g, th, 0, s, b.wide_tab, values, carries, count);
+        else if constexpr (LEN <= kMaxLimbs) hipLaunchKernelGGL((init_value_carry_kernel<LEN, BasisDev>), g, th, 0, s, b.dev, values, carries, count);
         return PFHE_OK;
     }
 };
 template <int LEN>
 struct FusedLaunch {
-    static int run(const RnsDev &r, const BasisDev &b, u32 log_n, const u64 *crt, u64 *out, u64 total, hipStream_t s) {
-        hipLaunchKernelGGL(gadget_decompose_kernel<LEN>, dim3(grid_for(total)), dim3(kThreads), 0, s, r, b, log_n, crt,
-                           out, total);
+    static int run(const RnsParams &r, const BasisParams &b, u32 log_n, const u64 *crt, u64 *out, u64 total, hipStream_t s) {
+        const dim3 g(grid_for(total)), th(kThreads);
+        if (b.wide()) {  // value_len <= L: a wide basis implies a wide base
+            hipLaunchKernelGGL((gadget_decompose_kernel<LEN, RnsWide, BasisWide>), g, th, 0, s, r.wide_tab, b.wide_tab, log_n, crt, out, total);
+        } else if constexpr (LEN <= kMaxLimbs) {
+            if (r.wide()) hipLaunchKernelGGL((gadget_decompose_kernel<LEN, RnsWide, BasisDev>), g, th, 0, s, r.wide_tab, b.dev, log_n, crt, out, total);
+            else hipLaunchKernelGGL((gadget_decompose_kernel<LEN, RnsDev, BasisDev>), g, th, 0, s, r.dev, b.dev, log_n, crt, out, total);
+        }
         return PFHE_OK;
     }
 };
 
 }  // namespace
 
-int rns_compose_dev(const RnsDev &r, const u64 *multi, u64 *out, u64 count, hipStream_t s) {
+DeviceBlob::~DeviceBlob() {
+    if (!ptr) return;
+    DeviceGuard g(device);
+    (void)counted_free(ptr);
+}
+
+static int upload_table(int device, const std::vector<u64> &host, std::shared_ptr<DeviceBlob> &blob) {
+    auto b = std::make_shared<DeviceBlob>();
+    b->device = device;
+    PFHE_HIP(counted_malloc(&b->ptr, host.size() * sizeof(u64)));
+    PFHE_HIP(hipMemcpy(b->ptr, host.data(), host.size() * sizeof(u64), hipMemcpyHostToDevice));
+    blob = std::move(b);
+    return PFHE_OK;
+}
+
+int upload_rns_wide(RnsHost &r) {
+    RnsParams &p = r.par;
+    if (!p.wide()) return PFHE_OK;
+    constexpr size_t W = kMaxWideLimbs;
+    const size_t L = p.dev.L, len = p.dev.value_len;
+    std::vector<u64> t(RnsWide::table_words(), 0);
+    for (size_t i = 0; i < L; ++i) {
+        t[i] = r.moduli[i];
+        t[W + i] = r.inv_punct[i];
+        t[2 * W + i] = r.inv_punct_p[i];
+        t[4 * W + i] = r.ratio_lo[i];
+        t[5 * W + i] = r.ratio_hi[i];
+        for (size_t j = 0; j < len; ++j) t[(6 + i) * W + j] = r.punct[i * len + j];
+    }
+    for (size_t j = 0; j < len; ++j) t[3 * W + j] = r.Q[j];
+    PFHE_TRY(upload_table(r.device, t, p.blob));
+    p.wide_tab = RnsWide{p.dev.L, p.dev.value_len, 0u, 0u, (const u64 *)p.blob->ptr};
+    return PFHE_OK;
+}
+
+int upload_basis_wide(BasisHost &b) {
+    BasisParams &p = b.par;
+    if (!p.wide()) return PFHE_OK;
+    constexpr size_t W = kMaxWideLimbs;
+    std::vector<u64> t(2 * W, 0);
+    for (size_t j = 0; j < p.dev.value_len; ++j) {
+        t[j] = b.threshold[j];
+        t[W + j] = b.add[j];
+    }
+    PFHE_TRY(upload_table(b.device, t, p.blob));
+    static_cast<BasisCore &>(p.wide_tab) = static_cast<const BasisCore &>(p.dev);
+    p.wide_tab.tab = (const u64 *)p.blob->ptr;
+    return PFHE_OK;
+}
+
+int rns_compose_dev(const RnsParams &r, const u64 *multi, u64 *out, u64 count, hipStream_t s) {
     if (count == 0) return PFHE_OK;
-    PFHE_TRY((dispatch_len<ComposeLaunch>(r.value_len, r, multi, out, count, s)));
+    PFHE_TRY((dispatch_len<ComposeLaunch>(r.dev.value_len, r, multi, out, count, s)));
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
 }
 
-int rns_wrapping_decompose_dev(const RnsDev &r, const u64 *small, u64 *multi, u64 count, u64 small_modulus,
+int rns_wrapping_decompose_dev(const RnsParams &r, const u64 *small, u64 *multi, u64 count, u64 small_modulus,
                                hipStream_t s) {
     if (count == 0) return PFHE_OK;
-    hipLaunchKernelGGL(wrapping_decompose_kernel, dim3(grid_for(count)), dim3(kThreads), 0, s, r, small, multi, count,
-                       small_modulus);
+    const dim3 g(grid_for(count)), th(kThreads);
+    if (r.wide()) hipLaunchKernelGGL(wrapping_decompose_kernel<RnsWide>, g, th, 0, s, r.wide_tab, small, multi, count, small_modulus);
+    else hipLaunchKernelGGL(wrapping_decompose_kernel<RnsDev>, g, th, 0, s, r.dev, small, multi, count, small_modulus);
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
 }
 
-int rns_add_decompose_scaled_dev(const RnsDev &r, const u64 *small_values, u64 *acc, u64 value_count,
-                                 u64 small_value_modulus, bool centred, const u64 *factor_pairs, hipStream_t s) {
-    if (value_count == 0) return PFHE_OK;
-    ScaledFactors f{};
-    for (u32 i = 0; i < r.L; ++i) {
+template <class RT, int MAXL>
+static void launch_add_scaled(const RT &R, const u64 *small_values, u64 *acc, u64 value_count, u64 small_value_modulus,
+                              bool centred, const u64 *factor_pairs, hipStream_t s) {
+    ScaledFactors<MAXL> f{};
+    for (u32 i = 0; i < R.L; ++i) {
         f.value[i] = factor_pairs[2 * i];
         f.quotient[i] = factor_pairs[2 * i + 1];
     }
-    hipLaunchKernelGGL(add_decompose_scaled_kernel, dim3(grid_for(value_count)), dim3(kThreads), 0, s, r, small_values, acc,
-                       value_count, small_value_modulus, centred, f);
+    hipLaunchKernelGGL((add_decompose_scaled_kernel<RT, MAXL>), dim3(grid_for(value_count)), dim3(kThreads), 0, s, R,
+                       small_values, acc, value_count, small_value_modulus, centred, f);
+}
+
+int rns_add_decompose_scaled_dev(const RnsParams &r, const u64 *small_values, u64 *acc, u64 value_count,
+                                 u64 small_value_modulus, bool centred, const u64 *factor_pairs, hipStream_t s) {
+    if (value_count == 0) return PFHE_OK;
+    if (r.wide()) launch_add_scaled<RnsWide, kMaxWideLimbs>(r.wide_tab, small_values, acc, value_count, small_value_modulus, centred, factor_pairs, s);
+    else launch_add_scaled<RnsDev, kMaxLimbs>(r.dev, small_values, acc, value_count, small_value_modulus, centred, factor_pairs, s);
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
 }
 
-int basis_init_value_carry_dev(const BasisDev &b, u64 *values, unsigned char *carries, u64 count, hipStream_t s) {
+int basis_init_value_carry_dev(const BasisParams &b, u64 *values, unsigned char *carries, u64 count, hipStream_t s) {
     if (count == 0) return PFHE_OK;
-    PFHE_TRY((dispatch_len<InitLaunch>(b.value_len, b, values, carries, count, s)));
+    PFHE_TRY((dispatch_len<InitLaunch>(b.dev.value_len, b, values, carries, count, s)));
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
 }
 
-int basis_unsigned_decompose_dev(const BasisDev &b, u32 level, const u64 *values, u64 *digits,
+int basis_unsigned_decompose_dev(const BasisParams &b, u32 level, const u64 *values, u64 *digits,
                                  unsigned char *carries, u64 count, hipStream_t s) {
     if (count == 0) return PFHE_OK;
-    hipLaunchKernelGGL(unsigned_decompose_kernel, dim3(grid_for(count)), dim3(kThreads), 0, s, b, level, values, digits,
-                       carries, count);
+    hipLaunchKernelGGL(unsigned_decompose_kernel, dim3(grid_for(count)), dim3(kThreads), 0, s,
+                       static_cast<const BasisCore &>(b.dev), level, values, digits, carries, count);
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
 }
 
-int basis_signed_decompose_dev(const RnsDev &r, const BasisDev &b, u32 level, const u64 *values, u64 *decomposed,
+int basis_signed_decompose_dev(const RnsParams &r, const BasisParams &b, u32 level, const u64 *values, u64 *decomposed,
                                unsigned char *carries, u64 count, hipStream_t s) {
     if (count == 0) return PFHE_OK;
-    hipLaunchKernelGGL(signed_decompose_kernel, dim3(grid_for(count)), dim3(kThreads), 0, s, r, b, level, values,
-                       decomposed, carries, count);
+    const dim3 g(grid_for(count)), th(kThreads);
+    const BasisCore &core = b.dev;
+    if (r.wide()) hipLaunchKernelGGL(signed_decompose_kernel<RnsWide>, g, th, 0, s, r.wide_tab, core, level, values, decomposed, carries, count);
+    else hipLaunchKernelGGL(signed_decompose_kernel<RnsDev>, g, th, 0, s, r.dev, core, level, values, decomposed, carries, count);
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
 }
 
-int gadget_decompose_dev(const RnsDev &r, const BasisDev &b, u32 log_n, const u64 *crt, u64 *digits, u64 npolys,
+int gadget_decompose_dev(const RnsParams &r, const BasisParams &b, u32 log_n, const u64 *crt, u64 *digits, u64 npolys,
                          hipStream_t s) {
     const u64 total = npolys << log_n;
     if (total == 0) return PFHE_OK;
-    PFHE_TRY((dispatch_len<FusedLaunch>(r.value_len, r, b, log_n, crt, digits, total, s)));
+    PFHE_TRY((dispatch_len<FusedLaunch>(r.dev.value_len, r, b, log_n, crt, digits, total, s)));
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
 }

@@ -8,9 +8,16 @@
 
 namespace pfhe {
 
-constexpr int kMaxLimbs = 8;  // RNS moduli / big-integer limbs supported by the device kernels
+// Two forms of the same constants.  Bases of at most kMaxLimbs moduli travel BY VALUE as kernel arguments (RnsDev /
+// BasisDev: SGPR-resident, the form every BASELINE config takes).  Wider bases — RNSBase::new (base.rs:79-117) takes any
+// number of moduli — keep their constants in a device table built once per handle (RnsWide / BasisWide, up to
+// kMaxWideLimbs moduli: a by-value RnsDev of that width would be 9 KiB of kernel arguments).  Both forms offer the same
+// accessors, and the device functions (pfhe_rns_device.hpp) and kernels (pfhe_rns.hip) are templates over them.
+constexpr int kMaxLimbs = 8;
+constexpr int kMaxWideLimbs = 32;
 
 // RNSBase<u64, BarrettModulus<u64>> constants (primus_rns/src/base.rs:26-117), passed by value.
+// L and value_len are valid for every base; the arrays only when L <= kMaxLimbs.
 struct RnsDev {
     u32 L, value_len;
     // 1: the decomposition kernels read their input as big integers (value_len limbs per coefficient,
@@ -27,53 +34,115 @@ struct RnsDev {
     u32 garner, pad2_;
     u64 g_inv[3][2], g_inv_p[3][2];  // g_inv[i][j] = q_j^-1 mod q_i (j < i) and its Shoup quotient
     u64 g_prod[2];                   // q0*q1, little-endian
+    __host__ __device__ u64 modulus(u32 i) const { return q[i]; }
+    __host__ __device__ u64 inv(u32 i) const { return inv_punct[i]; }
+    __host__ __device__ u64 inv_p(u32 i) const { return inv_punct_p[i]; }
+    __host__ __device__ u64 punctured(u32 i, u32 j) const { return punct[i][j]; }
+    __host__ __device__ u64 product(u32 j) const { return Q[j]; }
+};
+
+// The device-table form: `tab` holds q[W] | inv_punct[W] | inv_punct_p[W] | Q[W] | floor(2^128/q) low[W] | high[W] |
+// punct[W][W] with W = kMaxWideLimbs, every row zero-padded to W words (a kernel instantiated for a limb count above
+// value_len computes with zero top limbs).
+struct RnsWide {
+    u32 L, value_len;
+    u32 big_input, pad_;
+    const u64 *tab;
+    static constexpr u32 W = kMaxWideLimbs;
+    static constexpr u32 garner = 0;
+    __device__ u64 modulus(u32 i) const { return tab[i]; }
+    __device__ u64 inv(u32 i) const { return tab[W + i]; }
+    __device__ u64 inv_p(u32 i) const { return tab[2 * W + i]; }
+    __device__ u64 product(u32 j) const { return tab[3 * W + j]; }
+    __device__ u64 ratio_lo(u32 i) const { return tab[4 * W + i]; }  // BarrettModulus ratio (barrett/mod.rs:52-59)
+    __device__ u64 ratio_hi(u32 i) const { return tab[5 * W + i]; }
+    __device__ u64 punctured(u32 i, u32 j) const { return tab[(6 + i) * W + j]; }
+    static constexpr size_t table_words() { return (size_t)(6 + W) * W; }
 };
 
 // BigUintApproxSignedBasis<u64> constants (primus_decompose/src/big_integer/basis.rs:17-211).
-struct BasisDev {
+struct BasisCore {
     u32 value_len, ell, log_basis, drop_bits;
     u32 mode;  // bit0: extract initial carry, bit1: adjust values >= threshold
     u32 carry_index;
     u64 carry_bit_mask;
     u64 basis, basis_minus_one, carry_mask;
+};
+struct BasisDev : BasisCore {  // by value; arrays valid when value_len <= kMaxLimbs
     u64 threshold[kMaxLimbs], add[kMaxLimbs];
+    __host__ __device__ u64 split(u32 j) const { return threshold[j]; }
+    __host__ __device__ u64 addend(u32 j) const { return add[j]; }
+};
+struct BasisWide : BasisCore {  // tab: threshold[W] | add[W], zero-padded
+    const u64 *tab;
+    __device__ u64 split(u32 j) const { return tab[j]; }
+    __device__ u64 addend(u32 j) const { return tab[kMaxWideLimbs + j]; }
+};
+
+// a device allocation shared by the handles that copy a base's constants (an RNSBase, the bases derived from it, the
+// external-product plans): freed with its last holder
+struct DeviceBlob {
+    int device = 0;
+    void *ptr = nullptr;
+    ~DeviceBlob();
+};
+
+// what the launchers take: the by-value form, or (wide()) the device-table form and its owner
+struct RnsParams {
+    RnsDev dev{};
+    RnsWide wide_tab{};
+    std::shared_ptr<DeviceBlob> blob;
+    bool wide() const { return dev.L > (u32)kMaxLimbs; }
+};
+struct BasisParams {
+    BasisDev dev{};
+    BasisWide wide_tab{};
+    std::shared_ptr<DeviceBlob> blob;
+    bool wide() const { return dev.value_len > (u32)kMaxLimbs; }
 };
 
 struct RnsHost {
     int device = 0;
-    RnsDev dev{};
-    std::vector<u64> moduli;
+    RnsParams par;
+    // host copies, any width: moduli; Q and every Q/q_i as value_len little-endian limbs; (Q/q_i)^-1 mod q_i + quotient
+    std::vector<u64> moduli, Q, punct, inv_punct, inv_punct_p;
+    std::vector<u64> ratio_lo, ratio_hi;  // floor(2^128 / q_i)
 };
 
 struct BasisHost {
     int device = 0;
-    BasisDev dev{};
-    RnsDev rns{};
+    BasisParams par;
+    RnsParams rns;
+    std::vector<u64> Q;                // of the base it was built from (basis.rs:52)
+    std::vector<u64> threshold, add;   // value_len limbs each (zero when the mode bit is clear)
     std::vector<u64> scalars;          // ell * value_len : 2^(drop + j*log_basis)
     std::vector<u64> scalars_residue;  // ell * L
 };
 
 int build_rns(const u64 *moduli, size_t count, RnsHost &out);
 int build_basis(const RnsHost &rns, u32 log_basis, size_t reverse_length, BasisHost &out);
+// device tables of the wide forms (no-ops for bases that fit the by-value form); `device` must be current
+int upload_rns_wide(RnsHost &r);
+int upload_basis_wide(BasisHost &b);
 
 // --- device launchers (pfhe_rns.hip); all pointers are device pointers ---
-int rns_compose_dev(const RnsDev &r, const u64 *multi_residues, u64 *big_uint_values, u64 value_count,
+int rns_compose_dev(const RnsParams &r, const u64 *multi_residues, u64 *big_uint_values, u64 value_count,
                     hipStream_t s);
-int rns_wrapping_decompose_dev(const RnsDev &r, const u64 *small_values, u64 *multi_residues, u64 value_count,
+int rns_wrapping_decompose_dev(const RnsParams &r, const u64 *small_values, u64 *multi_residues, u64 value_count,
                                u64 small_value_modulus, hipStream_t s);
 // acc += factor * lift(small) per modulus (centred lift unless !centred); factor_pairs: L host (value, quotient) pairs
-int rns_add_decompose_scaled_dev(const RnsDev &r, const u64 *small_values, u64 *acc, u64 value_count,
+int rns_add_decompose_scaled_dev(const RnsParams &r, const u64 *small_values, u64 *acc, u64 value_count,
                                  u64 small_value_modulus, bool centred, const u64 *factor_pairs, hipStream_t s);
-int basis_init_value_carry_dev(const BasisDev &b, u64 *values, unsigned char *carries, u64 count, hipStream_t s);
-int basis_unsigned_decompose_dev(const BasisDev &b, u32 level, const u64 *values, u64 *digits,
+int basis_init_value_carry_dev(const BasisParams &b, u64 *values, unsigned char *carries, u64 count, hipStream_t s);
+int basis_unsigned_decompose_dev(const BasisParams &b, u32 level, const u64 *values, u64 *digits,
                                  unsigned char *carries, u64 count, hipStream_t s);
 // signed digits as residues modulo Q, value_len limbs each (common.rs:255-272, 289-306)
-int basis_signed_decompose_dev(const RnsDev &r, const BasisDev &b, u32 level, const u64 *values, u64 *decomposed,
+int basis_signed_decompose_dev(const RnsParams &r, const BasisParams &b, u32 level, const u64 *values, u64 *decomposed,
                                unsigned char *carries, u64 count, hipStream_t s);
 // Fused steps (1)-(4) of add_dcrt_glev_mul_crt_poly_assign (glwe/dcrt.rs:219-244) for `npolys` CRT
 // polynomials of L*N words: writes, per input polynomial, ell digit polynomials in CRT form
 // (centred lift), laid out [poly][level][limb][N].
-int gadget_decompose_dev(const RnsDev &r, const BasisDev &b, u32 log_n, const u64 *crt_polys, u64 *digits,
+int gadget_decompose_dev(const RnsParams &r, const BasisParams &b, u32 log_n, const u64 *crt_polys, u64 *digits,
                          u64 npolys, hipStream_t s);
 // result[e][c][r][t] = sum_{i,j} ggsw[(e)][i][j][c][r][t] * digits[e][i][j][r][t]  (mod q_r)
 // (steps (6) of glwe/dcrt.rs:248 summed over rows and levels, glwe/crt.rs:219-226).
@@ -90,7 +159,7 @@ bool gadget_decompose_strided_supported(u32 log_n, u32 value_len);
 // log_basis <= 31, else int64): a compact signed-digit kernel + a lifting strided pass.
 size_t gadget_digit_bytes(u32 log_basis);
 // `arith`: the table's transform arithmetic (kArithPm, kArithMont or kArithShoup, pfhe_ntt_device.hpp)
-int gadget_decompose_strided_dev(const RnsDev &r, const BasisDev &b, const NttPrime *primes, u32 log_n, int arith,
+int gadget_decompose_strided_dev(const RnsParams &r, const BasisParams &b, const NttPrime *primes, u32 log_n, int arith,
                                  const u64 *crt_polys, u64 *digits, u64 npolys, hipStream_t s, void *sdigits);
 // inv_tail (not with accumulate): the kernel also runs the block pass of the INVERSE transform on its result blocks
 // before storing them; the caller finishes with the inverse transform's strided pass (ntt_pass_dev, inverse, index 1).
@@ -101,7 +170,7 @@ int gadget_block_mulacc_dev(const NttPrime *primes, u32 L, u32 log_n, int arith,
 // Small rings (N = 2^10..2^12): digit extraction to int32 + ONE kernel for transforms, multiply-accumulate and
 // (optionally) the inverse transforms (pfhe_extprod.hip, extprod_small_kernel).
 bool extprod_small_supported(u32 log_n, u32 k, u32 value_len, u32 log_basis);
-int gadget_signed_digits_dev(const RnsDev &r, const BasisDev &b, u32 log_n, const u64 *crt_polys, int *sdigits,
+int gadget_signed_digits_dev(const RnsParams &r, const BasisParams &b, u32 log_n, const u64 *crt_polys, int *sdigits,
                              u64 npolys, hipStream_t s);
 int extprod_small_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u32 k, u32 rows, u32 ell, const int *sdigits,
                       const u64 *ggsw, bool ggsw_shared, u64 *result, u64 batch, bool accumulate, bool into_coeff,

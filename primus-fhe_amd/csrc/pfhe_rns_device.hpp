@@ -2,10 +2,40 @@
 // kernel per reference slice function) and pfhe_extprod.hip (fused kernels).
 #pragma once
 
+#include <type_traits>
+
 #include "pfhe_modmath.hpp"
 #include "pfhe_rns.hpp"
 
 namespace pfhe {
+
+// constants held by value (RnsDev / BasisDev): the kernel is compiled for the exact limb count; device-table forms
+// (RnsWide / BasisWide) are compiled for a rounded-up count and address memory with the run-time value_len
+template <class T>
+constexpr bool kByValue = std::is_same<T, RnsDev>::value || std::is_same<T, BasisDev>::value;
+
+// limb count a kernel is instantiated for: the exact one up to kMaxLimbs, then the next multiple of four
+template <template <int> class F, class... A>
+int dispatch_len(u32 len, A &&...a) {
+    switch (len <= (u32)kMaxLimbs ? len : (len + 3u) & ~3u) {
+        case 1: return F<1>::run(a...);
+        case 2: return F<2>::run(a...);
+        case 3: return F<3>::run(a...);
+        case 4: return F<4>::run(a...);
+        case 5: return F<5>::run(a...);
+        case 6: return F<6>::run(a...);
+        case 7: return F<7>::run(a...);
+        case 8: return F<8>::run(a...);
+        case 12: return F<12>::run(a...);
+        case 16: return F<16>::run(a...);
+        case 20: return F<20>::run(a...);
+        case 24: return F<24>::run(a...);
+        case 28: return F<28>::run(a...);
+        case 32: return F<32>::run(a...);
+    }
+    set_last_error("unsupported big-integer length");
+    return PFHE_ERR_UNSUPPORTED;
+}
 
 // Mixed-radix form of the CRT lift (RnsDev::garner): digits v0 = r0, v1 = (r1 - v0) / q0 mod q1,
 // v2 = ((r2 - v0) / q0 - v1) / q1 mod q2, then x = v0 + q0*v1 + q0*q1*v2 < Q — no comparison with Q, no subtraction.
@@ -36,23 +66,21 @@ __device__ __forceinline__ void compose_garner(const RnsDev &R, const u64 *r, u6
     for (int j = 3; j < LEN; ++j) v[j] = 0;
 }
 
-// v (LEN limbs, canonical in [0,Q)) = CRT lift of residues r[0..L)  — base.rs:609-633.
-template <int LEN>
-__device__ __forceinline__ void compose(const RnsDev &R, const u64 *r, u64 (&v)[LEN]) {
-    if (R.garner) {
-        compose_garner<LEN>(R, r, v);
-        return;
-    }
+// v (LEN limbs, canonical in [0,Q)) = CRT lift of the residues fetch(0..L)  — base.rs:609-633, the general form:
+// v += P_i * (inv_i * r_i mod q_i), minus Q whenever the sum overflows or reaches Q.  RT: RnsDev or RnsWide.
+template <int LEN, class RT, class Fetch>
+__device__ __forceinline__ void compose_general(const RT &R, Fetch fetch, u64 (&v)[LEN]) {
 #pragma unroll
     for (int j = 0; j < LEN; ++j) v[j] = 0;
     for (u32 i = 0; i < R.L; ++i) {
-        const u64 t = mul_shoup(r[i], R.inv_punct[i], R.inv_punct_p[i], R.q[i]);
+        const u64 t = mul_shoup(fetch(i), R.inv(i), R.inv_p(i), R.modulus(i));
         // v += P_i * t  (LEN limbs + carry word)
         u64 carry = 0;
 #pragma unroll
         for (int j = 0; j < LEN; ++j) {
-            const u64 lo = R.punct[i][j] * t;
-            const u64 hi = mulhi64(R.punct[i][j], t);
+            const u64 p = R.punctured(i, j);
+            const u64 lo = p * t;
+            const u64 hi = mulhi64(p, t);
             u64 s = v[j] + lo;
             u64 c1 = s < lo;
             u64 s2 = s + carry;
@@ -66,8 +94,8 @@ __device__ __forceinline__ void compose(const RnsDev &R, const u64 *r, u64 (&v)[
             ge = true;  // equal counts as >=
 #pragma unroll
             for (int j = LEN - 1; j >= 0; --j) {
-                if (v[j] != R.Q[j]) {
-                    ge = v[j] > R.Q[j];
+                if (v[j] != R.product(j)) {
+                    ge = v[j] > R.product(j);
                     break;
                 }
             }
@@ -76,8 +104,9 @@ __device__ __forceinline__ void compose(const RnsDev &R, const u64 *r, u64 (&v)[
             u64 borrow = 0;
 #pragma unroll
             for (int j = 0; j < LEN; ++j) {
-                const u64 d = v[j] - R.Q[j];
-                const u64 b1 = v[j] < R.Q[j];
+                const u64 qj = R.product(j);
+                const u64 d = v[j] - qj;
+                const u64 b1 = v[j] < qj;
                 const u64 d2 = d - borrow;
                 const u64 b2 = d < borrow;
                 v[j] = d2;
@@ -87,15 +116,25 @@ __device__ __forceinline__ void compose(const RnsDev &R, const u64 *r, u64 (&v)[
     }
 }
 
-// basis.rs:334-349: if v >= threshold: v += add ; returns the initial carry bit
+// the by-value form with its residues already in registers
 template <int LEN>
-__device__ __forceinline__ u32 init_value_carry(const BasisDev &B, u64 (&v)[LEN]) {
+__device__ __forceinline__ void compose(const RnsDev &R, const u64 *r, u64 (&v)[LEN]) {
+    if (R.garner) {
+        compose_garner<LEN>(R, r, v);
+        return;
+    }
+    compose_general<LEN>(R, [&](u32 i) { return r[i]; }, v);
+}
+
+// basis.rs:334-349: if v >= threshold: v += add ; returns the initial carry bit.  BT: BasisDev or BasisWide.
+template <int LEN, class BT>
+__device__ __forceinline__ u32 init_value_carry(const BT &B, u64 (&v)[LEN]) {
     if (B.mode & 2u) {
         bool ge = true;
 #pragma unroll
         for (int j = LEN - 1; j >= 0; --j) {
-            if (v[j] != B.threshold[j]) {
-                ge = v[j] > B.threshold[j];
+            if (v[j] != B.split(j)) {
+                ge = v[j] > B.split(j);
                 break;
             }
         }
@@ -103,7 +142,7 @@ __device__ __forceinline__ u32 init_value_carry(const BasisDev &B, u64 (&v)[LEN]
             u64 carry = 0;
 #pragma unroll
             for (int j = 0; j < LEN; ++j) {
-                const u64 s = v[j] + B.add[j];
+                const u64 s = v[j] + B.addend(j);
                 const u64 c1 = s < v[j];
                 const u64 s2 = s + carry;
                 const u64 c2 = s2 < s;

@@ -106,25 +106,43 @@ int build_rns(const u64 *moduli, size_t count, RnsHost &out) {
     for (size_t i = 0; i < count; ++i)
         for (size_t j = i + 1; j < count; ++j)
             if (gcd64(moduli[i], moduli[j]) != 1) return PFHE_ERR_COPRIME;  // base.rs:83-89
-    if (count > (size_t)kMaxLimbs) {
-        set_last_error("more than 8 RNS moduli are not supported by the device kernels");
+    if (count > (size_t)kMaxWideLimbs) {
+        set_last_error("more than 32 RNS moduli are not supported by the device kernels");
         return PFHE_ERR_UNSUPPORTED;
     }
     Big Q{moduli[0]};
     for (size_t i = 1; i < count; ++i) Q = big_mul_u64(Q, moduli[i]);
-    RnsDev d{};
-    d.L = (u32)count;
-    d.value_len = (u32)Q.size();
-    for (size_t j = 0; j < Q.size(); ++j) d.Q[j] = Q[j];
+    const size_t len = Q.size();
+    out.moduli.assign(moduli, moduli + count);
+    out.Q = Q;
+    out.punct.assign(count * len, 0);
+    out.inv_punct.assign(count, 0);
+    out.inv_punct_p.assign(count, 0);
+    out.ratio_lo.assign(count, 0);
+    out.ratio_hi.assign(count, 0);
     for (size_t i = 0; i < count; ++i) {
-        d.q[i] = moduli[i];
+        const u128 top = ((u128)1 << 64);  // floor(2^128 / q): high word, then the remainder carried down
+        out.ratio_hi[i] = (u64)(top / moduli[i]);
+        out.ratio_lo[i] = (u64)(((top % moduli[i]) << 64) / moduli[i]);
         Big P{1};
         for (size_t j = 0; j < count; ++j)
             if (j != i) P = big_mul_u64(P, moduli[j]);
-        for (size_t j = 0; j < P.size(); ++j) d.punct[i][j] = P[j];
+        std::copy(P.begin(), P.end(), out.punct.begin() + i * len);
         const u64 inv = inv_mod(big_mod_u64(P, moduli[i]), moduli[i]);
-        d.inv_punct[i] = inv;
-        d.inv_punct_p[i] = (u64)(((u128)inv << 64) / moduli[i]);
+        out.inv_punct[i] = inv;
+        out.inv_punct_p[i] = (u64)(((u128)inv << 64) / moduli[i]);
+    }
+    RnsDev d{};
+    d.L = (u32)count;
+    d.value_len = (u32)len;
+    if (count <= (size_t)kMaxLimbs) {  // the by-value form; wider bases get their device table from upload_rns_wide
+        for (size_t j = 0; j < len; ++j) d.Q[j] = Q[j];
+        for (size_t i = 0; i < count; ++i) {
+            d.q[i] = moduli[i];
+            for (size_t j = 0; j < len; ++j) d.punct[i][j] = out.punct[i * len + j];
+            d.inv_punct[i] = out.inv_punct[i];
+            d.inv_punct_p[i] = out.inv_punct_p[i];
+        }
     }
     u64 qmin = moduli[0], qmax = moduli[0];
     for (size_t i = 1; i < count; ++i) {
@@ -143,19 +161,18 @@ int build_rns(const u64 *moduli, size_t count, RnsHost &out) {
         d.g_prod[0] = (u64)p01;
         d.g_prod[1] = (u64)(p01 >> 64);
     }
-    out.dev = d;
-    out.moduli.assign(moduli, moduli + count);
+    out.par = RnsParams{};
+    out.par.dev = d;
     return PFHE_OK;
 }
 
 int build_basis(const RnsHost &rns, u32 log_basis, size_t reverse_length, BasisHost &out) {
-    const RnsDev &r = rns.dev;
-    const u32 len = r.value_len;
+    const u32 len = rns.par.dev.value_len, L = rns.par.dev.L;
     if (log_basis == 0 || log_basis >= 64) {  // basis.rs:51
         set_last_error("log_basis must be in 1..63");
         return PFHE_ERR_BAD_ARGUMENT;
     }
-    Big Q(r.Q, r.Q + len);
+    const Big &Q = rns.Q;
     const u32 unused = (u32)__builtin_clzll(Q[len - 1]);
     const u32 bits = 64 * len - unused;
     size_t ell = bits / log_basis;
@@ -212,9 +229,11 @@ int build_basis(const RnsHost &rns, u32 log_basis, size_t reverse_length, BasisH
         }
         have = true;
     }
+    out.threshold.assign(len, 0);
+    out.add.assign(len, 0);
     if (have && big_cmp(t, Q) < 0) {
         d.mode |= 2u;
-        for (u32 j = 0; j < len; ++j) d.threshold[j] = t[j];
+        out.threshold = t;
         // add = (2^bits - 1) - (Q - 1)  (basis.rs:137-147)
         Big a(len, ~0ull);
         a[len - 1] >>= unused;
@@ -222,19 +241,27 @@ int build_basis(const RnsHost &rns, u32 log_basis, size_t reverse_length, BasisH
         Big one{1};
         big_sub(qm1, one);
         big_sub(a, qm1);
-        for (u32 j = 0; j < len; ++j) d.add[j] = a[j];
+        out.add = a;
     }
-    out.dev = d;
-    out.rns = r;
+    if (len <= (u32)kMaxLimbs) {  // the by-value form; wider values get their device table from upload_basis_wide
+        for (u32 j = 0; j < len; ++j) {
+            d.threshold[j] = out.threshold[j];
+            d.add[j] = out.add[j];
+        }
+    }
+    out.par = BasisParams{};
+    out.par.dev = d;
+    out.rns = rns.par;
+    out.Q = Q;
     out.device = rns.device;
     out.scalars.assign(ell * len, 0);
-    out.scalars_residue.assign(ell * r.L, 0);
+    out.scalars_residue.assign(ell * L, 0);
     Big s(len, 0);
     s[0] = 1;
     big_shl(s, drop);
     for (size_t j = 0; j < ell; ++j) {  // basis.rs:149-173
         std::copy(s.begin(), s.end(), out.scalars.begin() + j * len);
-        for (u32 i = 0; i < r.L; ++i) out.scalars_residue[j * r.L + i] = big_mod_u64(s, r.q[i]);
+        for (u32 i = 0; i < L; ++i) out.scalars_residue[j * L + i] = big_mod_u64(s, rns.moduli[i]);
         big_shl(s, log_basis);
     }
     return PFHE_OK;

@@ -57,17 +57,22 @@ def test_no_cpu_fallback_without_device(pfhe):
 
 
 def test_rns_base_moduli_cap_is_reported_before_the_device_is_touched(pfhe):
-    """RNSBase::new (primus_rns/src/base.rs:79-117) takes any number of moduli; the device kernels keep a base's
-    constants in kernel arguments sized for 8 (include/pfhe.h, pfhe_rns_create): a ninth modulus is refused with
-    PFHE_ERR_UNSUPPORTED — not truncated, not a crash — and the reference's own errors keep their precedence."""
-    primes = [1152921504606584833, 1152921504598720513, 1152921504597016577, 1152921504595968001, 1152921504595640321,
-              1152921504593412097, 1152921504592429057, 1152921504589938689, 1152921504586530817]
+    """RNSBase::new (primus_rns/src/base.rs:79-117) takes any number of moduli; here up to 8 travel as kernel arguments
+    and up to 32 in a device table (csrc/pfhe_rns.hpp).  A 33rd modulus is refused with PFHE_ERR_UNSUPPORTED — not
+    truncated, not a crash — and the reference's own errors keep their precedence.  (Nine moduli are accepted: on a box
+    without a GPU the constructor gets as far as the device check.)"""
+    from primes import ntt_primes_below
+    primes = ntt_primes_below(33, 60, 16)
     with pytest.raises(pfhe.PfheError) as e:
         pfhe.RNSBase(primes)
-    assert e.value.kind == "Unsupported" and "8" in str(e.value)
+    assert e.value.kind == "Unsupported" and "32" in str(e.value)
     with pytest.raises(pfhe.PfheError) as e:
-        pfhe.RNSBase(primes[:8] + [primes[0]])      # CoPrimeError first (base.rs:83-89)
+        pfhe.RNSBase(primes[:32] + [primes[0]])      # CoPrimeError first (base.rs:83-89)
     assert e.value.kind == "CoPrimeError"
+    try:
+        assert pfhe.RNSBase(primes[:9]).moduli_count() == 9
+    except pfhe.PfheError as err:
+        assert err.kind == "NoDevice"
     with pytest.raises(pfhe.PfheError) as e:
         pfhe.RNSBase([])
     assert e.value.kind == "EmptyBase"
