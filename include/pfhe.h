@@ -24,7 +24,7 @@
  *     (NttTable: Send + Sync, primus_ntt/src/ntt/mod.rs:16); an external-product plan owns
  *     scratch and has one holder at a time (it mirrors `&mut DcrtGlevContext`,
  *     primus_lattice/src/context/glev.rs:4-10): a call from a second thread while one is inside
- *     is refused with PFHE_ERR_BAD_ARGUMENT, not raced.
+ *     is refused with PFHE_ERR_BUSY, not raced.
  *   - there is NO CPU fallback: without a HIP device create() fails with PFHE_ERR_NO_DEVICE.
  */
 #ifndef PFHE_H
@@ -54,7 +54,8 @@ typedef enum pfhe_status {
     PFHE_ERR_NO_DEVICE = 34,
     PFHE_ERR_HIP = 35,
     PFHE_ERR_UNSUPPORTED = 36,
-    PFHE_ERR_NO_INVERSE = 37 /* ReduceError::NoInverse: an element of an inversion is not a unit */
+    PFHE_ERR_NO_INVERSE = 37, /* ReduceError::NoInverse: an element of an inversion is not a unit */
+    PFHE_ERR_BUSY = 38        /* an external-product plan is held by another thread (one holder at a time) */
 } pfhe_status;
 
 const char *pfhe_status_string(int status);
@@ -268,7 +269,8 @@ int pfhe_dcrt_mul_dcrt_polynomial_dev(const pfhe_dcrt *table, uint64_t *crt_poly
  * forms) and, for sub, `b` (sub_rev_assign, crt/sub.rs:69).  Inputs must be canonical ([0, q_r)), as in the
  * reference.  `scalars`: L residues on the host; `factors`: L ShoupFactor (value, quotient) pairs on the host.
  * The single-modulus NttPolynomial / Polynomial forms (primus_poly/src/ntt/{add,sub,neg,inv}.rs) are the L = 1 case:
- * bind them to a pfhe_dcrt created with one modulus. */
+ * bind them to a pfhe_dcrt created with one modulus.  add / sub / neg / mul_monomial / inv take tables of any number
+ * of limbs; the forms with per-limb scalars or factors up to 32 (UNSUPPORTED beyond). */
 int pfhe_dcrt_add_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, const uint64_t *b_dev, uint64_t *out_dev,
                          size_t len, void *stream);
 int pfhe_dcrt_sub_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, const uint64_t *b_dev, uint64_t *out_dev,
@@ -299,7 +301,9 @@ typedef struct pfhe_rns pfhe_rns;
 
 /* RNSBase::new(moduli) — base.rs:79-117.  Errors: EMPTY_BASE (:47-49), COPRIME (:83-89),
  * UNREPRESENTABLE_MODULUS when a modulus is not in (1, 2^62) (BarrettModulus::new,
- * primus_modulus/src/barrett/mod.rs:39-44), UNSUPPORTED for more than 8 moduli. */
+ * primus_modulus/src/barrett/mod.rs:39-44), UNSUPPORTED for more than 32 moduli (bases of up to 8 moduli carry their
+ * constants as kernel arguments, wider ones — up to 32 — in a device table owned by the handle and shared with the
+ * bases, converters and plans derived from it; the same limit holds for both bases of a pfhe_conv). */
 int pfhe_rns_create(const uint64_t *moduli, size_t count, int device, pfhe_rns **out);
 void pfhe_rns_destroy(pfhe_rns *base);
 size_t pfhe_rns_moduli_count(const pfhe_rns *base);        /* base.rs:124 */
@@ -402,7 +406,7 @@ typedef struct pfhe_extprod_plan pfhe_extprod_plan;
  * one buffer of chunk*(k+1)*ell*L*N words (+ chunk*(k+1)*ell*N balanced digits: int32 for log_basis <= 31, else int64).
  * Like `&mut DcrtGlevContext` (context/glev.rs:4-10) the plan has ONE holder at a time, and that is enforced: every
  * pfhe_extprod_* call takes the plan for its duration, and a call from a second thread meanwhile returns
- * PFHE_ERR_BAD_ARGUMENT ("plan in use") instead of racing on the digit buffers (pfhe_extprod_plan_in_use reports the
+ * PFHE_ERR_BUSY ("plan in use") instead of racing on the digit buffers (pfhe_extprod_plan_in_use reports the
  * flag; one plan per thread).  Streams: device-pointer calls return when their kernels are queued; the plan remembers an event
  * behind its last call and a call on a DIFFERENT stream first makes that stream wait for it, so using one plan from one
  * stream after another needs no event handling by the caller (round 5; until then this was the caller's job).  Work
@@ -411,6 +415,9 @@ int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *base, const
                              size_t glwe_dimension, size_t chunk, pfhe_extprod_plan **out);
 void pfhe_extprod_plan_destroy(pfhe_extprod_plan *plan);
 int pfhe_extprod_plan_in_use(const pfhe_extprod_plan *plan);  /* 1 while some thread is inside a pfhe_extprod_* call on it */
+/* Test aid, not a reference interface: hold != 0 takes the plan for the calling thread exactly as an entry point does
+ * (PFHE_ERR_BUSY when another thread holds it) and keeps it until the same thread calls with hold == 0. */
+int pfhe_extprod_plan_debug_hold(pfhe_extprod_plan *plan, int hold);
 size_t pfhe_extprod_plan_scratch_bytes(const pfhe_extprod_plan *plan);
 /* CrtGlwe::mul_dcrt_ggsw_to — glwe/crt.rs:200-227.  crt_glwe: batch x (k+1) CRT polynomials
  * |a1|..|ak|b|; dcrt_ggsw: ONE GGSW shared by the batch or batch GGSWs, each
@@ -598,6 +605,148 @@ int pfhe_dcrt32_transform_num_passes(const pfhe_dcrt32 *table);
 const char *pfhe_dcrt32_transform_pass_name(const pfhe_dcrt32 *table, int inverse, int index);
 int pfhe_dcrt32_transform_pass_dev(const pfhe_dcrt32 *table, uint32_t *poly_dev, size_t len,
                                    int inverse, int index, int lazy, void *stream);
+
+/* =====================================================================================
+ * The <u32> instantiations of the same generics: RNSBase<u32, BarrettModulus<u32>> (primus_rns/src/base.rs:26-37),
+ * BigUintApproxSignedBasis<u32> (primus_decompose/src/big_integer/basis.rs:33 — the type the reference's own
+ * tests/big_uint.rs:13 runs) and CrtGlwe<u32>::mul_dcrt_ggsw_to over a U32DcrtTable (primus_lattice/src/glwe/crt.rs:200-227,
+ * primus_ntt/src/dcrt/prime32.rs:11).  Same contracts as the 64-bit entry points above with uint32_t words: residues,
+ * digits and the limbs of big integers are u32 in memory (big_uint_value_len counts u32 limbs: as many as Q needs,
+ * big_integer.rs:675-686); moduli below 2^30; log_basis below 32.  Every output is the canonical integer the reference's
+ * u32 arithmetic produces.
+ * ===================================================================================== */
+typedef struct pfhe_rns32 pfhe_rns32;
+typedef struct pfhe_basis32 pfhe_basis32;
+typedef struct pfhe_extprod32_plan pfhe_extprod32_plan;
+
+/* RNSBase::new(moduli) — base.rs:79-117.  Errors: EMPTY_BASE (:47-49), COPRIME (:83-89),
+ * UNREPRESENTABLE_MODULUS when a modulus is not in (1, 2^30) (BarrettModulus::<u32>::new,
+ * primus_modulus/src/barrett/mod.rs:39-44), UNSUPPORTED for more than 32 moduli (bases of up to 8 moduli carry their
+ * constants as kernel arguments, wider ones — up to 32 — in a device table owned by the handle and shared with the
+ * bases, converters and plans derived from it; the same limit holds for both bases of a pfhe_conv). */
+int pfhe_rns32_create(const uint32_t *moduli, size_t count, int device, pfhe_rns32 **out);
+void pfhe_rns32_destroy(pfhe_rns32 *base);
+size_t pfhe_rns32_moduli_count(const pfhe_rns32 *base);        /* base.rs:124 */
+size_t pfhe_rns32_big_uint_value_len(const pfhe_rns32 *base);  /* base.rs:139 */
+int pfhe_rns32_moduli_product(const pfhe_rns32 *base, uint32_t *out, size_t len); /* base.rs:133 */
+/* compose_multiple_values_to — base.rs:648-675 (-> compose_to :609-633): residue i of value c is
+ * multi_residues[i*value_count + c] (modulus-major); value c is written as big_uint_value_len
+ * little-endian limbs at big_uint_values[c*big_uint_value_len], canonical in [0, Q). */
+int pfhe_rns32_compose_multiple_values_to(const pfhe_rns32 *base, const uint32_t *multi_residues,
+                                        size_t len_in, uint32_t *big_uint_values, size_t len_out,
+                                        size_t value_count);
+int pfhe_rns32_compose_multiple_values_to_dev(const pfhe_rns32 *base, const uint32_t *multi_residues_dev,
+                                            size_t len_in, uint32_t *big_uint_values_dev,
+                                            size_t len_out, size_t value_count, void *stream);
+/* wrapping_decompose_small_values_to — base.rs:279-312 (+ :721-730): centred lift of u in
+ * [0, small_value_modulus): u < ceil(m/2) ? u : q_i - m + u ; m == 2 copies. */
+int pfhe_rns32_wrapping_decompose_small_values_to(const pfhe_rns32 *base, const uint32_t *small_values,
+                                                size_t value_count, uint32_t *multi_residues,
+                                                size_t len_out, uint32_t small_value_modulus);
+int pfhe_rns32_wrapping_decompose_small_values_to_dev(const pfhe_rns32 *base,
+                                                    const uint32_t *small_values_dev,
+                                                    size_t value_count, uint32_t *multi_residues_dev,
+                                                    size_t len_out, uint32_t small_value_modulus,
+                                                    void *stream);
+/* add_wrapping_decompose_small_values_scaled — base.rs:326-384 (+ slice::wrapping_decompose_chunk_scaled_to
+ * :739-757): acc[i][c] = reduce_add(acc[i][c], factor_i * lift_i(small[c])) with the centred lift above (m == 2
+ * takes the unsigned branch, base.rs:371-378); add_decompose_small_values_scaled — base.rs:398-416: the same
+ * without the lift (= add_decompose_small_polynomial_scaled, :429-443).  `acc`: L*value_count words,
+ * modulus-major, accumulated in place; `factors`: L ShoupFactor<u32> (value, quotient) pairs on the host (quotient = floor(value * 2^32 / q_i)). */
+int pfhe_rns32_add_wrapping_decompose_small_values_scaled(const pfhe_rns32 *base, const uint32_t *small_values,
+                                                        size_t value_count, uint32_t *acc, size_t len_acc,
+                                                        uint32_t small_value_modulus, const uint32_t *factors);
+int pfhe_rns32_add_wrapping_decompose_small_values_scaled_dev(const pfhe_rns32 *base, const uint32_t *small_values_dev,
+                                                            size_t value_count, uint32_t *acc_dev, size_t len_acc,
+                                                            uint32_t small_value_modulus, const uint32_t *factors,
+                                                            void *stream);
+int pfhe_rns32_add_decompose_small_values_scaled(const pfhe_rns32 *base, const uint32_t *small_values, size_t value_count,
+                                               uint32_t *acc, size_t len_acc, const uint32_t *factors);
+int pfhe_rns32_add_decompose_small_values_scaled_dev(const pfhe_rns32 *base, const uint32_t *small_values_dev,
+                                                   size_t value_count, uint32_t *acc_dev, size_t len_acc,
+                                                   const uint32_t *factors, void *stream);
+
+/* BigUintApproxSignedBasis::new(Q, log_basis, reverse_length, rns_base) — basis.rs:40-211.
+ * reverse_length == 0 means None (full chain); 0 < log_basis < 32 (:51).  The reference asserts; we return BAD_ARGUMENT. */
+int pfhe_basis32_create(const pfhe_rns32 *base, uint32_t log_basis, size_t reverse_length,
+                      pfhe_basis32 **out);
+void pfhe_basis32_destroy(pfhe_basis32 *basis);
+size_t pfhe_basis32_decompose_length(const pfhe_basis32 *basis); /* basis.rs:236 */
+uint32_t pfhe_basis32_log_basis(const pfhe_basis32 *basis);      /* :242 */
+uint32_t pfhe_basis32_drop_bits(const pfhe_basis32 *basis);      /* :248 */
+uint32_t pfhe_basis32_basis_value(const pfhe_basis32 *basis);    /* :224 */
+/* scalar_iter (:283) = 2^(drop + j*log_basis) as big_uint_value_len limbs per level;
+ * iter_scalar_residues (:266) = the same reduced modulo every RNS modulus. */
+int pfhe_basis32_scalars(const pfhe_basis32 *basis, uint32_t *out, size_t len);
+int pfhe_basis32_scalars_residue(const pfhe_basis32 *basis, uint32_t *out, size_t len);
+/* init_value_carry_slice_inplace — basis.rs:326-367.  carries are one byte (0/1) per value. */
+int pfhe_basis32_init_value_carry_slice_inplace(const pfhe_basis32 *basis, uint32_t *values, size_t len,
+                                              uint8_t *carries, size_t count);
+int pfhe_basis32_init_value_carry_slice_inplace_dev(const pfhe_basis32 *basis, uint32_t *values_dev,
+                                                  size_t len, uint8_t *carries_dev, size_t count,
+                                                  void *stream);
+/* decomposer_iter().nth(level).unsigned_decompose_slice_to — big_integer/common.rs:309-325
+ * (-> unsigned_decompose_to :275-285); level 0 is the least significant digit. */
+int pfhe_basis32_unsigned_decompose_slice_to(const pfhe_basis32 *basis, size_t level,
+                                           const uint32_t *values, size_t len, uint32_t *digits,
+                                           uint8_t *carries, size_t count);
+int pfhe_basis32_unsigned_decompose_slice_to_dev(const pfhe_basis32 *basis, size_t level,
+                                               const uint32_t *values_dev, size_t len,
+                                               uint32_t *digits_dev, uint8_t *carries_dev,
+                                               size_t count, void *stream);
+/* init_value_carry_slice_to — basis.rs:371-420: the out-of-place form (input untouched). */
+int pfhe_basis32_init_value_carry_slice_to(const pfhe_basis32 *basis, const uint32_t *values, size_t len,
+                                         uint32_t *adjusted_values, uint8_t *carries, size_t count);
+int pfhe_basis32_init_value_carry_slice_to_dev(const pfhe_basis32 *basis, const uint32_t *values_dev, size_t len,
+                                             uint32_t *adjusted_values_dev, uint8_t *carries_dev, size_t count,
+                                             void *stream);
+/* decomposer_iter().nth(level).decompose_slice_to — big_integer/common.rs:289-306 (-> decompose_to :255-272): the
+ * SIGNED digit as a residue modulo Q, big_uint_value_len limbs per value (a negative digit d is stored as Q + d);
+ * len_out must equal len; input and output must be distinct buffers. */
+int pfhe_basis32_decompose_slice_to(const pfhe_basis32 *basis, size_t level, const uint32_t *values, size_t len,
+                                  uint32_t *decomposed_values, size_t len_out, uint8_t *carries, size_t count);
+int pfhe_basis32_decompose_slice_to_dev(const pfhe_basis32 *basis, size_t level, const uint32_t *values_dev, size_t len,
+                                      uint32_t *decomposed_values_dev, size_t len_out, uint8_t *carries_dev,
+                                      size_t count, void *stream);
+/* RNSBase::decompose_big_uint_values_to — base.rs:457-481 */
+int pfhe_rns32_decompose_big_uint_values_to(const pfhe_rns32 *base, const uint32_t *big_uint_values,
+                                          size_t len_in, uint32_t *multi_residues, size_t len_out,
+                                          size_t value_count);
+int pfhe_rns32_decompose_big_uint_values_to_dev(const pfhe_rns32 *base,
+                                              const uint32_t *big_uint_values_dev, size_t len_in,
+                                              uint32_t *multi_residues_dev, size_t len_out,
+                                              size_t value_count, void *stream);
+
+/* The plan of the u32 product: as pfhe_extprod_plan_create (one holder at a time, `table` borrowed, device scratch for
+ * `chunk` ciphertexts: chunk*(k+1)*ell*L*N u32 words; 0 = about 1 GiB, at least 128 ciphertexts). */
+int pfhe_extprod32_plan_create(const pfhe_dcrt32 *table, const pfhe_rns32 *base, const pfhe_basis32 *basis,
+                               size_t glwe_dimension, size_t chunk, pfhe_extprod32_plan **out);
+void pfhe_extprod32_plan_destroy(pfhe_extprod32_plan *plan);
+int pfhe_extprod32_plan_in_use(const pfhe_extprod32_plan *plan);
+size_t pfhe_extprod32_plan_scratch_bytes(const pfhe_extprod32_plan *plan);
+/* CrtGlwe::mul_dcrt_ggsw_to — glwe/crt.rs:200-227 (layouts as pfhe_extprod_mul_dcrt_ggsw_to) */
+int pfhe_extprod32_mul_dcrt_ggsw_to(pfhe_extprod32_plan *plan, const uint32_t *crt_glwe, size_t len_glwe,
+                                    const uint32_t *dcrt_ggsw, size_t len_ggsw, uint32_t *result, size_t len_result,
+                                    int into_coeff_form);
+int pfhe_extprod32_mul_dcrt_ggsw_to_dev(pfhe_extprod32_plan *plan, const uint32_t *crt_glwe_dev, size_t len_glwe,
+                                        const uint32_t *dcrt_ggsw_dev, size_t len_ggsw, uint32_t *result_dev,
+                                        size_t len_result, int into_coeff_form, void *stream);
+/* DcrtGlwe::add_dcrt_glev_mul_crt_poly_assign — glwe/dcrt.rs:178-255; DcrtGlev::mul_crt_poly_to — glev/dcrt.rs:45-110 */
+int pfhe_extprod32_add_dcrt_glev_mul_crt_poly_assign_dev(pfhe_extprod32_plan *plan, uint32_t *acc_dev, size_t len_acc,
+                                                         const uint32_t *dcrt_glev_dev, size_t len_glev,
+                                                         const uint32_t *crt_poly_dev, size_t len_poly, void *stream);
+int pfhe_extprod32_glev_mul_crt_poly_to_dev(pfhe_extprod32_plan *plan, const uint32_t *dcrt_glev_dev, size_t len_glev,
+                                            const uint32_t *crt_poly_dev, size_t len_poly, uint32_t *result_dev,
+                                            size_t len_result, void *stream);
+/* DcrtGlwe::add_dcrt_glev_mul_big_uint_poly_assign — glwe/dcrt.rs:258-338; DcrtGlev::mul_big_uint_poly_to —
+ * glev/dcrt.rs:113-175 (the polynomial as big_uint_value_len u32 limbs per coefficient) */
+int pfhe_extprod32_add_dcrt_glev_mul_big_uint_poly_assign_dev(pfhe_extprod32_plan *plan, uint32_t *acc_dev, size_t len_acc,
+                                                              const uint32_t *dcrt_glev_dev, size_t len_glev,
+                                                              const uint32_t *big_uint_poly_dev, size_t len_poly,
+                                                              void *stream);
+int pfhe_extprod32_glev_mul_big_uint_poly_to_dev(pfhe_extprod32_plan *plan, const uint32_t *dcrt_glev_dev, size_t len_glev,
+                                                 const uint32_t *big_uint_poly_dev, size_t len_poly, uint32_t *result_dev,
+                                                 size_t len_result, void *stream);
 
 #ifdef __cplusplus
 }

@@ -372,7 +372,7 @@ class BigUintApproxSignedBasis {
 
 // DcrtGlevContext (crates/primus_lattice/src/context/glev.rs:4-68) + the handles the reference
 // passes next to it.  One holder at a time, like the `&mut` it mirrors: a call from a second thread while one is inside throws
-// (PFHE_ERR_BAD_ARGUMENT, "plan in use"); successive calls on different streams are ordered by the library.
+// (PFHE_ERR_BUSY, "plan in use"); successive calls on different streams are ordered by the library.
 class DcrtGlevContext {
   public:
     DcrtGlevContext(const U64DcrtTable &table, const RNSBase &base, const BigUintApproxSignedBasis &basis,

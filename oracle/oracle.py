@@ -26,7 +26,8 @@ def build(native: bool = False, out_dir: str | None = None) -> str:
     out = os.path.join(out_dir, "liboracle_native.so")
     subprocess.run(
         ["gcc", "-O3", "-march=native", "-fPIC", "-std=c11", "-shared", "-o", out,
-         os.path.join(_HERE, "pfhe_oracle.c"), os.path.join(_HERE, "pfhe_oracle_avx512.c")],
+         os.path.join(_HERE, "pfhe_oracle.c"), os.path.join(_HERE, "pfhe_oracle_avx512.c"),
+         os.path.join(_HERE, "pfhe_oracle_rns32.c")],
         check=True,
     )
     return out
@@ -172,6 +173,36 @@ def _load(path: str | None = None) -> C.CDLL:
     sig("orc_add_dcrt_glev_mul_crt_poly_assign", None, vp, vp, vp, sz, _u64p, _u64p, _u64p)
     sig("orc_add_dcrt_glev_mul_big_uint_poly_assign", None, vp, vp, vp, sz, _u64p, _u64p, _u64p)
     sig("orc_mul_dcrt_ggsw_to", None, vp, vp, vp, sz, _u64p, _u64p, _u64p)
+    # the <u32> instantiations (pfhe_oracle_rns32.c)
+    u32p = C.POINTER(C.c_uint32)
+    sig("orc_rns32_new", ci, u32p, sz, C.POINTER(vp))
+    sig("orc_rns32_free", None, vp)
+    sig("orc_rns32_moduli_count", sz, vp)
+    sig("orc_rns32_value_len", sz, vp)
+    sig("orc_rns32_moduli_product", u32p, vp)
+    sig("orc_rns32_punctured_product", u32p, vp)
+    sig("orc_rns32_compose_to", None, vp, u32p, u32p)
+    sig("orc_rns32_compose_multiple_values_to", None, vp, u32p, u32p, sz)
+    sig("orc_rns32_decompose_to", None, vp, u32p, u32p)
+    sig("orc_rns32_decompose_big_uint_values_to", None, vp, u32p, u32p, sz)
+    sig("orc_rns32_wrapping_decompose_small_values_to", None, vp, u32p, u32p, sz, u32)
+    sig("orc_rns32_add_wrapping_decompose_small_values_scaled", None, vp, u32p, u32p, sz, u32, u32p)
+    sig("orc_rns32_add_decompose_small_values_scaled", None, vp, u32p, u32p, sz, u32p)
+    sig("orc_basis32_new", ci, vp, u32, sz, C.POINTER(vp))
+    sig("orc_basis32_free", None, vp)
+    sig("orc_basis32_decompose_length", sz, vp)
+    for g in ("log_basis", "drop_bits", "basis_value"):
+        sig("orc_basis32_" + g, u32, vp)
+    sig("orc_basis32_init_mode", ci, vp)
+    sig("orc_basis32_scalars", u32p, vp)
+    sig("orc_basis32_scalars_residue", u32p, vp)
+    sig("orc_basis32_init_value_carry_slice_inplace", None, vp, u32p, _u8p, sz)
+    sig("orc_basis32_init_value_carry_slice_to", None, vp, u32p, u32p, _u8p, sz)
+    sig("orc_basis32_unsigned_decompose_slice_to", None, vp, sz, u32p, u32p, _u8p, sz)
+    sig("orc_basis32_decompose_slice_to", None, vp, sz, u32p, u32p, _u8p, sz)
+    sig("orc_add_dcrt32_glev_mul_crt_poly_assign", None, vp, vp, vp, sz, u32p, u32p, u32p)
+    sig("orc_add_dcrt32_glev_mul_big_uint_poly_assign", None, vp, vp, vp, sz, u32p, u32p, u32p)
+    sig("orc_mul_dcrt32_ggsw_to", None, vp, vp, vp, sz, u32p, u32p, u32p)
     return lib
 
 
@@ -759,3 +790,127 @@ def mul_dcrt_ggsw_to(table: U64DcrtTable, rns: RNSBase, basis, k, crt_glwe, dcrt
     out = np.empty((k + 1) * table.crt_poly_length, np.uint64)
     lib().orc_mul_dcrt_ggsw_to(table._h, rns._h, basis._h, k, _p(crt_glwe), _p(dcrt_ggsw), _p(out))
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# The <u32> instantiations (pfhe_oracle_rns32.c): RNSBase<u32>, BigUintApproxSignedBasis<u32>, external product over
+# U32DcrtTable.  numpy uint32 arrays throughout.
+# ---------------------------------------------------------------------------------------------
+def _arr32(ptr, n) -> np.ndarray:
+    return np.ctypeslib.as_array(ptr, shape=(n,)).copy() if n else np.empty(0, np.uint32)
+
+
+class RNSBase32:
+    """primus_rns::RNSBase<u32, BarrettModulus<u32>> (base.rs:26-117 with T = u32)."""
+
+    def __init__(self, moduli):
+        self.moduli = [int(m) for m in moduli]
+        arr = np.array(self.moduli, np.uint32)
+        h = C.c_void_p()
+        rc = lib().orc_rns32_new(_p32(arr) if len(arr) else None, len(self.moduli), C.byref(h))
+        if rc:
+            raise OracleError(rc)
+        self._h = h
+        self.count = len(self.moduli)
+        self.value_len = int(lib().orc_rns32_value_len(h))
+        self.moduli_product = _arr32(lib().orc_rns32_moduli_product(h), self.value_len)
+        self.punctured_product = _arr32(lib().orc_rns32_punctured_product(h), self.value_len * self.count)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_rns32_free(self._h)
+            self._h = None
+
+    def compose_multiple_values_to(self, multi_residues, value_count):
+        out = np.empty(value_count * self.value_len, np.uint32)
+        lib().orc_rns32_compose_multiple_values_to(self._h, _p32(multi_residues), _p32(out), value_count)
+        return out
+
+    def decompose_big_uint_values_to(self, values, value_count):
+        out = np.empty(self.count * value_count, np.uint32)
+        lib().orc_rns32_decompose_big_uint_values_to(self._h, _p32(values), _p32(out), value_count)
+        return out
+
+    def wrapping_decompose_small_values_to(self, small_values, small_value_modulus):
+        sv = np.ascontiguousarray(small_values, np.uint32)
+        out = np.empty(self.count * sv.size, np.uint32)
+        lib().orc_rns32_wrapping_decompose_small_values_to(self._h, _p32(sv), _p32(out), sv.size, small_value_modulus)
+        return out
+
+    def add_wrapping_decompose_small_values_scaled(self, small_values, acc, small_value_modulus, factors):
+        sv = np.ascontiguousarray(small_values, np.uint32)
+        f = np.ascontiguousarray(np.array(factors, np.uint32).reshape(-1))
+        assert acc.size == self.count * sv.size and f.size == 2 * self.count
+        lib().orc_rns32_add_wrapping_decompose_small_values_scaled(self._h, _p32(sv), _p32(acc), sv.size, small_value_modulus,
+                                                                   _p32(f))
+
+    def add_decompose_small_values_scaled(self, small_values, acc, factors):
+        sv = np.ascontiguousarray(small_values, np.uint32)
+        f = np.ascontiguousarray(np.array(factors, np.uint32).reshape(-1))
+        assert acc.size == self.count * sv.size and f.size == 2 * self.count
+        lib().orc_rns32_add_decompose_small_values_scaled(self._h, _p32(sv), _p32(acc), sv.size, _p32(f))
+
+
+class BigUintApproxSignedBasis32:
+    """primus_decompose::big_integer::BigUintApproxSignedBasis<u32> (basis.rs:33; tests/big_uint.rs:13)."""
+
+    def __init__(self, rns: RNSBase32, log_basis: int, reverse_length: int | None = None):
+        h = C.c_void_p()
+        rc = lib().orc_basis32_new(rns._h, log_basis, reverse_length or 0, C.byref(h))
+        if rc:
+            raise OracleError(rc)
+        self._h = h
+        self.rns = rns
+        self.decompose_length = int(lib().orc_basis32_decompose_length(h))
+        self.log_basis = int(lib().orc_basis32_log_basis(h))
+        self.drop_bits = int(lib().orc_basis32_drop_bits(h))
+        self.basis_value = int(lib().orc_basis32_basis_value(h))
+        self.init_mode = int(lib().orc_basis32_init_mode(h))
+        self.scalars = _arr32(lib().orc_basis32_scalars(h), rns.value_len * self.decompose_length)
+        self.scalars_residue = _arr32(lib().orc_basis32_scalars_residue(h), rns.count * self.decompose_length)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_basis32_free(self._h)
+            self._h = None
+
+    def init_value_carry_slice_inplace(self, values, count):
+        carries = np.zeros(count, np.uint8)
+        lib().orc_basis32_init_value_carry_slice_inplace(self._h, _p32(values), carries.ctypes.data_as(_u8p), count)
+        return carries
+
+    def init_value_carry_slice_to(self, values, count):
+        adjusted, carries = np.empty_like(values), np.zeros(count, np.uint8)
+        lib().orc_basis32_init_value_carry_slice_to(self._h, _p32(values), _p32(adjusted), carries.ctypes.data_as(_u8p), count)
+        return adjusted, carries
+
+    def unsigned_decompose_slice_to(self, level, values, carries, count):
+        digits = np.empty(count, np.uint32)
+        lib().orc_basis32_unsigned_decompose_slice_to(self._h, level, _p32(values), _p32(digits),
+                                                      carries.ctypes.data_as(_u8p), count)
+        return digits
+
+    def decompose_slice_to(self, level, values, carries, count):
+        out = np.empty(values.size, np.uint32)
+        lib().orc_basis32_decompose_slice_to(self._h, level, _p32(values), _p32(out), carries.ctypes.data_as(_u8p), count)
+        return out
+
+
+def _tables32(table: U32DcrtTable):
+    return (C.c_void_p * table.count)(*[t._h for t in table.tables])
+
+
+def mul_dcrt32_ggsw_to(table: U32DcrtTable, rns: RNSBase32, basis: BigUintApproxSignedBasis32, k, crt_glwe, dcrt_ggsw):
+    """CrtGlwe<u32>::mul_dcrt_ggsw_to; returns the DcrtGlwe result ((k+1)*L*N u32 words, NTT form)."""
+    out = np.empty((k + 1) * table.crt_poly_length, np.uint32)
+    lib().orc_mul_dcrt32_ggsw_to(_tables32(table), rns._h, basis._h, k, _p32(crt_glwe), _p32(dcrt_ggsw), _p32(out))
+    return out
+
+
+def add_dcrt32_glev_mul_crt_poly_assign(table: U32DcrtTable, rns: RNSBase32, basis, k, acc, glev, crt_poly):
+    lib().orc_add_dcrt32_glev_mul_crt_poly_assign(_tables32(table), rns._h, basis._h, k, _p32(acc), _p32(glev), _p32(crt_poly))
+
+
+def add_dcrt32_glev_mul_big_uint_poly_assign(table: U32DcrtTable, rns: RNSBase32, basis, k, acc, glev, big_uint_poly):
+    lib().orc_add_dcrt32_glev_mul_big_uint_poly_assign(_tables32(table), rns._h, basis._h, k, _p32(acc), _p32(glev),
+                                                       _p32(big_uint_poly))

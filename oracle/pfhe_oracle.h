@@ -293,6 +293,54 @@ void orc_mul_dcrt_ggsw_to(const orc_dcrt *table, const orc_rns *rns, const orc_b
                           size_t glwe_dimension, const uint64_t *crt_glwe,
                           const uint64_t *dcrt_ggsw, uint64_t *result);
 
+/* ---------------- the <u32> instantiations: RNSBase<u32>, BigUintApproxSignedBasis<u32>, the external product over
+ * U32DcrtTable (pfhe_oracle_rns32.c: 32-bit limb arithmetic throughout, written against the reference's generic source) */
+typedef struct orc_rns32 orc_rns32;
+typedef struct orc_basis32 orc_basis32;
+int orc_rns32_new(const uint32_t *moduli, size_t count, orc_rns32 **out);
+void orc_rns32_free(orc_rns32 *b);
+size_t orc_rns32_moduli_count(const orc_rns32 *b);
+size_t orc_rns32_value_len(const orc_rns32 *b);
+const uint32_t *orc_rns32_moduli_product(const orc_rns32 *b);
+const uint32_t *orc_rns32_punctured_product(const orc_rns32 *b);
+void orc_rns32_compose_to(const orc_rns32 *b, const uint32_t *residues, uint32_t *value);
+void orc_rns32_compose_multiple_values_to(const orc_rns32 *b, const uint32_t *multi_residues, uint32_t *big_uint_values,
+                                          size_t value_count);
+void orc_rns32_decompose_to(const orc_rns32 *b, const uint32_t *value, uint32_t *residues);
+void orc_rns32_decompose_big_uint_values_to(const orc_rns32 *b, const uint32_t *big_uint_values, uint32_t *multi_residues,
+                                            size_t value_count);
+void orc_rns32_wrapping_decompose_small_values_to(const orc_rns32 *b, const uint32_t *small_values, uint32_t *multi_residues,
+                                                  size_t value_count, uint32_t small_value_modulus);
+void orc_rns32_add_wrapping_decompose_small_values_scaled(const orc_rns32 *b, const uint32_t *small_values, uint32_t *acc,
+                                                          size_t value_count, uint32_t small_value_modulus,
+                                                          const uint32_t *factors);
+void orc_rns32_add_decompose_small_values_scaled(const orc_rns32 *b, const uint32_t *small_values, uint32_t *acc,
+                                                 size_t value_count, const uint32_t *factors);
+int orc_basis32_new(const orc_rns32 *rns, uint32_t log_basis, size_t reverse_length, orc_basis32 **out);
+void orc_basis32_free(orc_basis32 *b);
+size_t orc_basis32_decompose_length(const orc_basis32 *b);
+uint32_t orc_basis32_log_basis(const orc_basis32 *b);
+uint32_t orc_basis32_drop_bits(const orc_basis32 *b);
+uint32_t orc_basis32_basis_value(const orc_basis32 *b);
+int orc_basis32_init_mode(const orc_basis32 *b);
+const uint32_t *orc_basis32_scalars(const orc_basis32 *b);
+const uint32_t *orc_basis32_scalars_residue(const orc_basis32 *b);
+void orc_basis32_init_value_carry_slice_inplace(const orc_basis32 *b, uint32_t *values, uint8_t *carries, size_t count);
+void orc_basis32_init_value_carry_slice_to(const orc_basis32 *b, const uint32_t *values, uint32_t *adjusted, uint8_t *carries,
+                                           size_t count);
+void orc_basis32_unsigned_decompose_slice_to(const orc_basis32 *b, size_t level, const uint32_t *values, uint32_t *digits,
+                                             uint8_t *carries, size_t count);
+void orc_basis32_decompose_slice_to(const orc_basis32 *b, size_t level, const uint32_t *values, uint32_t *decomposed,
+                                    uint8_t *carries, size_t count);
+/* `tables`: one orc_u32_ntt per modulus of the base, in base order (U32DcrtTable, dcrt/prime32.rs:11) */
+void orc_add_dcrt32_glev_mul_crt_poly_assign(const orc_u32_ntt *const *tables, const orc_rns32 *rns, const orc_basis32 *basis,
+                                             size_t k, uint32_t *acc, const uint32_t *dcrt_glev, const uint32_t *crt_poly);
+void orc_add_dcrt32_glev_mul_big_uint_poly_assign(const orc_u32_ntt *const *tables, const orc_rns32 *rns,
+                                                  const orc_basis32 *basis, size_t k, uint32_t *acc, const uint32_t *dcrt_glev,
+                                                  const uint32_t *big_uint_poly);
+void orc_mul_dcrt32_ggsw_to(const orc_u32_ntt *const *tables, const orc_rns32 *rns, const orc_basis32 *basis, size_t k,
+                            const uint32_t *crt_glwe, const uint32_t *dcrt_ggsw, uint32_t *result);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,7 +14,7 @@ u64p = C.POINTER(C.c_uint64)
 STATUS = {
     0: "OK", 1: "NoPrimitiveRoot", 2: "DegreeConversionErr", 3: "DegreeTooLarge", 4: "NttTableErr",
     5: "ModulusTooLarge", 16: "EmptyBase", 17: "CoPrimeError", 18: "UnrepresentableModulus",
-    32: "BadLength", 33: "BadArgument", 34: "NoDevice", 35: "HipError", 36: "Unsupported", 37: "NoInverse",
+    32: "BadLength", 33: "BadArgument", 34: "NoDevice", 35: "HipError", 36: "Unsupported", 37: "NoInverse", 38: "Busy",
 }
 
 
@@ -113,46 +113,54 @@ def _declare(lib: C.CDLL) -> None:
     sig("pfhe_dcrt_inv_to_dev", ci, vp, vp, vp, sz, vp)
     sig("pfhe_dcrt_butterfly_mul_factor_to_dev", ci, vp, vp, vp, sz, vp, sz, vp, vp)
     u8p = C.POINTER(C.c_uint8)
-    sig("pfhe_rns_create", ci, u64p, sz, ci, C.POINTER(vp))
-    sig("pfhe_rns_destroy", None, vp)
-    sig("pfhe_rns_moduli_count", sz, vp)
-    sig("pfhe_rns_big_uint_value_len", sz, vp)
-    sig("pfhe_rns_moduli_product", ci, vp, vp, sz)
-    sig("pfhe_rns_compose_multiple_values_to", ci, vp, vp, sz, vp, sz, sz)
-    sig("pfhe_rns_compose_multiple_values_to_dev", ci, vp, vp, sz, vp, sz, sz, vp)
-    sig("pfhe_rns_wrapping_decompose_small_values_to", ci, vp, vp, sz, vp, sz, u64)
-    sig("pfhe_rns_wrapping_decompose_small_values_to_dev", ci, vp, vp, sz, vp, sz, u64, vp)
-    sig("pfhe_rns_add_wrapping_decompose_small_values_scaled", ci, vp, vp, sz, vp, sz, u64, u64p)
-    sig("pfhe_rns_add_wrapping_decompose_small_values_scaled_dev", ci, vp, vp, sz, vp, sz, u64, u64p, vp)
-    sig("pfhe_rns_add_decompose_small_values_scaled", ci, vp, vp, sz, vp, sz, u64p)
-    sig("pfhe_rns_add_decompose_small_values_scaled_dev", ci, vp, vp, sz, vp, sz, u64p, vp)
-    sig("pfhe_basis_create", ci, vp, u32, sz, C.POINTER(vp))
-    sig("pfhe_basis_destroy", None, vp)
-    sig("pfhe_basis_decompose_length", sz, vp)
-    sig("pfhe_basis_log_basis", u32, vp)
-    sig("pfhe_basis_drop_bits", u32, vp)
-    sig("pfhe_basis_basis_value", u64, vp)
-    sig("pfhe_basis_scalars", ci, vp, vp, sz)
-    sig("pfhe_basis_scalars_residue", ci, vp, vp, sz)
-    sig("pfhe_basis_init_value_carry_slice_inplace", ci, vp, vp, sz, vp, sz)
-    sig("pfhe_basis_init_value_carry_slice_inplace_dev", ci, vp, vp, sz, vp, sz, vp)
-    sig("pfhe_basis_unsigned_decompose_slice_to", ci, vp, sz, vp, sz, vp, vp, sz)
-    sig("pfhe_basis_unsigned_decompose_slice_to_dev", ci, vp, sz, vp, sz, vp, vp, sz, vp)
-    sig("pfhe_basis_init_value_carry_slice_to", ci, vp, vp, sz, vp, vp, sz)
-    sig("pfhe_basis_init_value_carry_slice_to_dev", ci, vp, vp, sz, vp, vp, sz, vp)
-    sig("pfhe_basis_decompose_slice_to", ci, vp, sz, vp, sz, vp, sz, vp, sz)
-    sig("pfhe_basis_decompose_slice_to_dev", ci, vp, sz, vp, sz, vp, sz, vp, sz, vp)
-    sig("pfhe_extprod_plan_create", ci, vp, vp, vp, sz, sz, C.POINTER(vp))
-    sig("pfhe_extprod_plan_destroy", None, vp)
-    sig("pfhe_extprod_plan_scratch_bytes", sz, vp)
-    sig("pfhe_extprod_plan_in_use", ci, vp)
-    sig("pfhe_extprod_mul_dcrt_ggsw_to", ci, vp, vp, sz, vp, sz, vp, sz, ci)
-    sig("pfhe_extprod_mul_dcrt_ggsw_to_dev", ci, vp, vp, sz, vp, sz, vp, sz, ci, vp)
+    # RNSBase<W> / BigUintApproxSignedBasis<W>: the same entry points for W = u64 (pfhe_rns, pfhe_basis) and
+    # W = u32 (pfhe_rns32, pfhe_basis32)
+    u32p = C.POINTER(u32)
+    for rns, basis, w, wp in (("pfhe_rns_", "pfhe_basis_", u64, u64p), ("pfhe_rns32_", "pfhe_basis32_", u32, u32p)):
+        sig(rns + "create", ci, wp, sz, ci, C.POINTER(vp))
+        sig(rns + "destroy", None, vp)
+        sig(rns + "moduli_count", sz, vp)
+        sig(rns + "big_uint_value_len", sz, vp)
+        sig(rns + "moduli_product", ci, vp, vp, sz)
+        sig(rns + "compose_multiple_values_to", ci, vp, vp, sz, vp, sz, sz)
+        sig(rns + "compose_multiple_values_to_dev", ci, vp, vp, sz, vp, sz, sz, vp)
+        sig(rns + "wrapping_decompose_small_values_to", ci, vp, vp, sz, vp, sz, w)
+        sig(rns + "wrapping_decompose_small_values_to_dev", ci, vp, vp, sz, vp, sz, w, vp)
+        sig(rns + "add_wrapping_decompose_small_values_scaled", ci, vp, vp, sz, vp, sz, w, wp)
+        sig(rns + "add_wrapping_decompose_small_values_scaled_dev", ci, vp, vp, sz, vp, sz, w, wp, vp)
+        sig(rns + "add_decompose_small_values_scaled", ci, vp, vp, sz, vp, sz, wp)
+        sig(rns + "add_decompose_small_values_scaled_dev", ci, vp, vp, sz, vp, sz, wp, vp)
+        sig(rns + "decompose_big_uint_values_to", ci, vp, vp, sz, vp, sz, sz)
+        sig(rns + "decompose_big_uint_values_to_dev", ci, vp, vp, sz, vp, sz, sz, vp)
+        sig(basis + "create", ci, vp, u32, sz, C.POINTER(vp))
+        sig(basis + "destroy", None, vp)
+        sig(basis + "decompose_length", sz, vp)
+        sig(basis + "log_basis", u32, vp)
+        sig(basis + "drop_bits", u32, vp)
+        sig(basis + "basis_value", w, vp)
+        sig(basis + "scalars", ci, vp, vp, sz)
+        sig(basis + "scalars_residue", ci, vp, vp, sz)
+        sig(basis + "init_value_carry_slice_inplace", ci, vp, vp, sz, vp, sz)
+        sig(basis + "init_value_carry_slice_inplace_dev", ci, vp, vp, sz, vp, sz, vp)
+        sig(basis + "unsigned_decompose_slice_to", ci, vp, sz, vp, sz, vp, vp, sz)
+        sig(basis + "unsigned_decompose_slice_to_dev", ci, vp, sz, vp, sz, vp, vp, sz, vp)
+        sig(basis + "init_value_carry_slice_to", ci, vp, vp, sz, vp, vp, sz)
+        sig(basis + "init_value_carry_slice_to_dev", ci, vp, vp, sz, vp, vp, sz, vp)
+        sig(basis + "decompose_slice_to", ci, vp, sz, vp, sz, vp, sz, vp, sz)
+        sig(basis + "decompose_slice_to_dev", ci, vp, sz, vp, sz, vp, sz, vp, sz, vp)
+    for ep in ("pfhe_extprod_", "pfhe_extprod32_"):
+        sig(ep + "plan_create", ci, vp, vp, vp, sz, sz, C.POINTER(vp))
+        sig(ep + "plan_destroy", None, vp)
+        sig(ep + "plan_scratch_bytes", sz, vp)
+        sig(ep + "plan_in_use", ci, vp)
+        sig(ep + "mul_dcrt_ggsw_to", ci, vp, vp, sz, vp, sz, vp, sz, ci)
+        sig(ep + "mul_dcrt_ggsw_to_dev", ci, vp, vp, sz, vp, sz, vp, sz, ci, vp)
+        sig(ep + "add_dcrt_glev_mul_crt_poly_assign_dev", ci, vp, vp, sz, vp, sz, vp, sz, vp)
+        sig(ep + "glev_mul_crt_poly_to_dev", ci, vp, vp, sz, vp, sz, vp, sz, vp)
+        sig(ep + "add_dcrt_glev_mul_big_uint_poly_assign_dev", ci, vp, vp, sz, vp, sz, vp, sz, vp)
+        sig(ep + "glev_mul_big_uint_poly_to_dev", ci, vp, vp, sz, vp, sz, vp, sz, vp)
+    sig("pfhe_extprod_plan_debug_hold", ci, vp, ci)
     sig("pfhe_extprod_profile_dev", ci, vp, vp, sz, vp, sz, vp, sz, C.POINTER(C.c_double), C.POINTER(sz), vp)
-    sig("pfhe_extprod_add_dcrt_glev_mul_crt_poly_assign_dev", ci, vp, vp, sz, vp, sz, vp, sz, vp)
-    sig("pfhe_extprod_glev_mul_crt_poly_to_dev", ci, vp, vp, sz, vp, sz, vp, sz, vp)
-    sig("pfhe_extprod_add_dcrt_glev_mul_big_uint_poly_assign_dev", ci, vp, vp, sz, vp, sz, vp, sz, vp)
-    sig("pfhe_extprod_glev_mul_big_uint_poly_to_dev", ci, vp, vp, sz, vp, sz, vp, sz, vp)
     sig("pfhe_dcrt_transform_num_passes", ci, vp)
     sig("pfhe_dcrt_transform_pass_name", C.c_char_p, vp, ci, ci)
     sig("pfhe_dcrt_transform_pass_dev", ci, vp, vp, sz, ci, ci, ci, vp)
@@ -172,11 +180,8 @@ def _declare(lib: C.CDLL) -> None:
         sig("pfhe_conv_" + g, ci, vp, vp, sz, vp, sz, sz)
         sig("pfhe_conv_" + g + "_dev", ci, vp, vp, sz, vp, sz, sz, vp)
     sig("pfhe_conv_fast_convert_array_to_pairs_dev", ci, vp, vp, sz, vp, sz, sz, vp)
-    sig("pfhe_rns_decompose_big_uint_values_to", ci, vp, vp, sz, vp, sz, sz)
-    sig("pfhe_rns_decompose_big_uint_values_to_dev", ci, vp, vp, sz, vp, sz, sz, vp)
 
     # u32 tables
-    u32p = C.POINTER(u32)
     sig("pfhe_ntt32_create", ci, u32, u32, ci, C.POINTER(vp))
     sig("pfhe_ntt32_destroy", None, vp)
     sig("pfhe_ntt32_poly_length", sz, vp)

@@ -530,6 +530,7 @@ const char *pfhe_status_string(int status) {
         case PFHE_ERR_HIP: return "HIP runtime error";
         case PFHE_ERR_UNSUPPORTED: return "unsupported parameter";
         case PFHE_ERR_NO_INVERSE: return "element has no inverse";
+        case PFHE_ERR_BUSY: return "external-product plan is held by another thread";
     }
     return "unknown status";
 }

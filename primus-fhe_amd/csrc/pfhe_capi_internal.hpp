@@ -18,7 +18,9 @@
     }
 
 struct pfhe_dcrt;
+struct pfhe_dcrt32;
 namespace pfhe {
 int capi_check_device(int device);
 const TableSet *capi_table_of(const pfhe_dcrt *t);
+const TableSet *capi_table32_of(const pfhe_dcrt32 *t);
 }  // namespace pfhe

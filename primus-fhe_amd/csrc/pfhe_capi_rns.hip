@@ -7,6 +7,7 @@
 #include <new>
 
 #include <cstring>
+#include <type_traits>
 
 #include "pfhe_capi_internal.hpp"
 #include "pfhe_ntt_device.hpp"
@@ -15,22 +16,18 @@
 
 using namespace pfhe;
 
-struct pfhe_basis {
-    BasisHost h;
-};
 struct pfhe_extprod_plan {
     const TableSet *table = nullptr;  // borrowed from the pfhe_dcrt (must outlive the plan)
     // Exclusivity.  The plan owns the product's scratch (digit buffers), like the reference's `&mut DcrtGlevContext`
     // (primus_lattice/src/context/glev.rs:4-10), which the borrow checker lets ONE caller hold at a time.  Here the holder
     // is a thread: every entry point that touches the scratch takes the plan for the duration of the call (PlanLease), and
-    // a second thread that arrives meanwhile is refused with PFHE_ERR_BAD_ARGUMENT ("plan in use") instead of racing on the
+    // a second thread that arrives meanwhile is refused with PFHE_ERR_BUSY ("plan in use") instead of racing on the
     // digit buffer.  owner = a per-thread token (0: free); depth counts nested entries of the owning thread (the host-pointer
     // and profiling entry points call the device ones).
     std::atomic<std::uintptr_t> owner{0};
     int depth = 0;
     // cross-stream ordering of successive calls (run_product): the event recorded behind the last call's kernels
     hipEvent_t last_done = nullptr;
-    hipStream_t last_stream = nullptr;
     bool last_valid = false;
     RnsParams rns;
     BasisParams basis_par;
@@ -72,6 +69,30 @@ struct pfhe_extprod_plan {
     }
 };
 
+// The <u32> instantiation of the same product: CrtGlwe<u32>::mul_dcrt_ggsw_to over a U32DcrtTable (glwe/crt.rs:200-227,
+// dcrt/prime32.rs:11).  Steps (1)-(4) fused (gadget_decompose_kernel on u32 words: the lifted digit polynomials, u32),
+// the table's forward transform over all of them, one multiply-accumulate kernel, chunk after chunk on the caller's stream.
+struct pfhe_extprod32_plan {
+    const TableSet *table = nullptr;  // borrowed from the pfhe_dcrt32 (must outlive the plan)
+    std::atomic<std::uintptr_t> owner{0};  // one holder at a time, as pfhe_extprod_plan
+    int depth = 0;
+    hipEvent_t last_done = nullptr;
+    bool last_valid = false;
+    RnsParams rns;
+    BasisParams basis_par;
+    BasisCore basis{};
+    u32 k = 1;
+    size_t chunk = 1;
+    u32 *digits = nullptr;  // chunk * (k+1) * ell * L * N words
+    size_t digits_words = 0;
+    ~pfhe_extprod32_plan() {
+        if (!table) return;
+        DeviceGuard g(table->device);
+        if (digits) (void)counted_free(digits);
+        if (last_done) (void)hipEventDestroy(last_done);
+    }
+};
+
 namespace {
 
 int plan_check(const pfhe_extprod_plan *p) {
@@ -80,36 +101,49 @@ int plan_check(const pfhe_extprod_plan *p) {
 }
 
 // the calling thread's hold on a plan's scratch for one entry point (see pfhe_extprod_plan::owner)
+inline std::uintptr_t plan_thread_token() {
+    static thread_local char token;
+    return reinterpret_cast<std::uintptr_t>(&token);
+}
+// take (or re-enter) the plan for the calling thread; false: another thread holds it
+template <class Plan>
+bool plan_acquire(Plan *p) {
+    const std::uintptr_t me = plan_thread_token();
+    std::uintptr_t free_ = 0;
+    if (p->owner.load(std::memory_order_relaxed) == me) {
+        ++p->depth;  // nested entry of the thread that holds the plan
+        return true;
+    }
+    if (p->owner.compare_exchange_strong(free_, me, std::memory_order_acquire)) {
+        p->depth = 1;
+        return true;
+    }
+    return false;
+}
+template <class Plan>
+void plan_release(Plan *p) {
+    if (--p->depth == 0) p->owner.store(0, std::memory_order_release);
+}
+template <class Plan>
 class PlanLease {
   public:
-    explicit PlanLease(pfhe_extprod_plan *p) : p_(p) {
-        static thread_local char token;
-        const std::uintptr_t me = reinterpret_cast<std::uintptr_t>(&token);
-        std::uintptr_t free_ = 0;
-        if (p_->owner.load(std::memory_order_relaxed) == me) {
-            ++p_->depth;  // nested entry of the thread that holds the plan
-            held_ = true;
-        } else if (p_->owner.compare_exchange_strong(free_, me, std::memory_order_acquire)) {
-            p_->depth = 1;
-            held_ = true;
-        }
-    }
+    explicit PlanLease(Plan *p) : p_(p), held_(plan_acquire(p)) {}
     ~PlanLease() {
-        if (held_ && --p_->depth == 0) p_->owner.store(0, std::memory_order_release);
+        if (held_) plan_release(p_);
     }
     PlanLease(const PlanLease &) = delete;
     PlanLease &operator=(const PlanLease &) = delete;
     bool held() const { return held_; }
 
   private:
-    pfhe_extprod_plan *p_;
+    Plan *p_;
     bool held_ = false;
 };
 #define PFHE_PLAN_LEASE(plan)                                                                                       \
-    PlanLease lease_(plan);                                                                                          \
+    PlanLease<typename std::remove_pointer<decltype(plan)>::type> lease_(plan);                                                                                          \
     if (!lease_.held()) {                                                                                            \
         set_last_error("external-product plan in use by another thread (one plan per thread, like &mut DcrtGlevContext)"); \
-        return PFHE_ERR_BAD_ARGUMENT;                                                                                \
+        return PFHE_ERR_BUSY;                                                                                        \
     }
 
 // one row of the product: acc[e] += glev[e or shared] (x) crt_poly[e]   (glwe/dcrt.rs:178-255)
@@ -249,12 +283,13 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
                 u64 batch, bool accumulate, hipStream_t s, bool into_coeff = false, int *coeff_passes = nullptr,
                 bool big_input = false) {
     const bool tracked = p->last_done != nullptr && !stream_is_capturing(s);
-    if (tracked && p->last_valid && p->last_stream != s) PFHE_HIP(hipStreamWaitEvent(s, p->last_done, 0));
+    // (always, also on the stream that recorded it: a handle comparison would miss a stream destroyed and re-created at
+    // the same address; waiting on one's own stream's event costs nothing)
+    if (tracked && p->last_valid) PFHE_HIP(hipStreamWaitEvent(s, p->last_done, 0));
     const int rc = run_product_impl(p, crt_polys, rows, keys, keys_shared, result, batch, accumulate, s, into_coeff, coeff_passes,
                                     big_input);
     if (tracked) {  // also after a failed call: whatever it queued still uses the buffers
         if (hipEventRecord(p->last_done, s) == hipSuccess) {
-            p->last_stream = s;
             p->last_valid = true;
         } else {
             (void)hipGetLastError();
@@ -267,359 +302,499 @@ int run_product(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const u64 
 
 }  // namespace
 
-extern "C" {
+// ---- RNSBase<W> / BigUintApproxSignedBasis<W> behind both word widths of the C ABI (W = uint64_t: pfhe_rns / pfhe_basis;
+//      W = uint32_t: pfhe_rns32 / pfhe_basis32).  One implementation, instantiated twice. ----
+namespace {
 
-/* ------------------------------ RNSBase ------------------------------ */
+template <class W>
+using DevWord = typename std::conditional<sizeof(W) == 8, u64, u32>::type;
+template <class W>
+size_t words_per_value(const RnsHost &h) { return sizeof(W) == 8 ? h.par.dev.value_len : h.par.dev.value_words; }
+template <class W>
+size_t words_per_value(const BasisHost &h) { return sizeof(W) == 8 ? h.par.dev.value_len : h.par.dev.value_words; }
 
-int pfhe_rns_create(const uint64_t *moduli, size_t count, int device, pfhe_rns **out) {
-    PFHE_GUARD_BEGIN
-    if (!out || (!moduli && count)) return PFHE_ERR_BAD_ARGUMENT;
-    *out = nullptr;
-    auto r = std::make_unique<pfhe_rns>();
-    PFHE_TRY(build_rns((const u64 *)moduli, count, r->h));
+// word j (of the caller's width) of a big integer held as 64-bit limbs
+template <class W>
+W word_of(const std::vector<u64> &limbs, size_t base, size_t j) {
+    if (sizeof(W) == 8) return (W)limbs[base + j];
+    return (W)(limbs[base + j / 2] >> (32 * (j & 1)));
+}
+
+template <class W>
+int rns_create_impl(const W *moduli, size_t count, int device, RnsHost &h) {
+    if (!moduli && count) return PFHE_ERR_BAD_ARGUMENT;
+    std::vector<u64> m(moduli, moduli + count);
+    PFHE_TRY(build_rns(m.data(), count, h, 8 * sizeof(W)));
     PFHE_TRY(capi_check_device(device));
-    r->h.device = device;
-    if (r->h.par.wide()) {  // more than kMaxLimbs moduli: the constants live in a device table
+    h.device = device;
+    if (h.par.wide()) {  // more than kMaxLimbs moduli: the constants live in a device table
         DeviceGuard g(device);
         if (!g.ok) return PFHE_ERR_NO_DEVICE;
-        PFHE_TRY(upload_rns_wide(r->h));
+        PFHE_TRY(upload_rns_wide(h));
     }
-    *out = r.release();
-    return PFHE_OK;
-    PFHE_GUARD_END
-}
-
-void pfhe_rns_destroy(pfhe_rns *r) { delete r; }
-size_t pfhe_rns_moduli_count(const pfhe_rns *r) { return r ? r->h.par.dev.L : 0; }
-size_t pfhe_rns_big_uint_value_len(const pfhe_rns *r) { return r ? r->h.par.dev.value_len : 0; }
-
-int pfhe_rns_moduli_product(const pfhe_rns *r, uint64_t *out, size_t len) {
-    if (!r || !out) return PFHE_ERR_BAD_ARGUMENT;
-    if (len != r->h.par.dev.value_len) return PFHE_ERR_BAD_LENGTH;
-    for (size_t j = 0; j < len; ++j) out[j] = r->h.Q[j];
     return PFHE_OK;
 }
 
-int pfhe_rns_compose_multiple_values_to_dev(const pfhe_rns *r, const uint64_t *multi_residues_dev, size_t len_in,
-                                            uint64_t *big_uint_values_dev, size_t len_out, size_t value_count,
-                                            void *stream) {
-    PFHE_GUARD_BEGIN
-    if (!r || ((!multi_residues_dev || !big_uint_values_dev) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (len_in != value_count * r->h.par.dev.L || len_out != value_count * r->h.par.dev.value_len) {
+template <class W>
+int rns_moduli_product_impl(const RnsHost *h, W *out, size_t len) {
+    if (!h || !out) return PFHE_ERR_BAD_ARGUMENT;
+    if (len != words_per_value<W>(*h)) return PFHE_ERR_BAD_LENGTH;
+    for (size_t j = 0; j < len; ++j) out[j] = word_of<W>(h->Q, 0, j);
+    return PFHE_OK;
+}
+
+template <class W>
+int rns_compose_dev_impl(const RnsHost *h, const W *in_dev, size_t len_in, W *out_dev, size_t len_out, size_t value_count,
+                         void *stream) {
+    if (!h || ((!in_dev || !out_dev) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
+    if (len_in != value_count * h->par.dev.L || len_out != value_count * words_per_value<W>(*h)) {
         set_last_error("compose: multi_residues must hold moduli_count*value_count words and the output "
                        "value_count*big_uint_value_len words");
         return PFHE_ERR_BAD_LENGTH;
     }
-    DeviceGuard g(r->h.device);
+    DeviceGuard g(h->device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    return rns_compose_dev(r->h.par, (const u64 *)multi_residues_dev, (u64 *)big_uint_values_dev, value_count,
-                           (hipStream_t)stream);
-    PFHE_GUARD_END
+    return rns_compose_dev(h->par, (const DevWord<W> *)in_dev, (DevWord<W> *)out_dev, value_count, (hipStream_t)stream);
 }
 
-int pfhe_rns_compose_multiple_values_to(const pfhe_rns *r, const uint64_t *multi_residues, size_t len_in,
-                                        uint64_t *big_uint_values, size_t len_out, size_t value_count) {
-    PFHE_GUARD_BEGIN
-    if (!r || ((!multi_residues || !big_uint_values) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (len_in != value_count * r->h.par.dev.L || len_out != value_count * r->h.par.dev.value_len) return PFHE_ERR_BAD_LENGTH;
+template <class W>
+int rns_compose_host_impl(const RnsHost *h, const W *in, size_t len_in, W *out, size_t len_out, size_t value_count) {
+    if (!h || ((!in || !out) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
+    if (len_in != value_count * h->par.dev.L || len_out != value_count * words_per_value<W>(*h)) return PFHE_ERR_BAD_LENGTH;
     if (value_count == 0) return PFHE_OK;
-    DeviceGuard g(r->h.device);
+    DeviceGuard g(h->device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    HostStage st(r->h.device);  // pooled staging context: no allocation in steady state
+    HostStage st(h->device);  // pooled staging context: no allocation in steady state
     if (!st.ok()) return PFHE_ERR_HIP;
-    void *in = nullptr, *o = nullptr;
-    PFHE_TRY(st.upload(multi_residues, len_in * 8, &in));
-    PFHE_TRY(st.alloc(len_out * 8, &o));
-    PFHE_TRY(rns_compose_dev(r->h.par, (const u64 *)in, (u64 *)o, value_count, st.stream()));
-    PFHE_TRY(st.download(big_uint_values, o, len_out * 8));
+    void *i = nullptr, *o = nullptr;
+    PFHE_TRY(st.upload(in, len_in * sizeof(W), &i));
+    PFHE_TRY(st.alloc(len_out * sizeof(W), &o));
+    PFHE_TRY(rns_compose_dev(h->par, (const DevWord<W> *)i, (DevWord<W> *)o, value_count, st.stream()));
+    PFHE_TRY(st.download(out, o, len_out * sizeof(W)));
     return st.finish();
-    PFHE_GUARD_END
 }
 
-int pfhe_rns_wrapping_decompose_small_values_to_dev(const pfhe_rns *r, const uint64_t *small_values_dev,
-                                                    size_t value_count, uint64_t *multi_residues_dev, size_t len_out,
-                                                    uint64_t small_value_modulus, void *stream) {
-    PFHE_GUARD_BEGIN
-    if (!r || ((!small_values_dev || !multi_residues_dev) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (len_out != value_count * r->h.par.dev.L) return PFHE_ERR_BAD_LENGTH;
-    for (u32 i = 0; i < r->h.par.dev.L; ++i) {
-        if (small_value_modulus >= r->h.moduli[i] || small_value_modulus < 2) {  // base.rs:288-292
+inline int small_modulus_check(const RnsHost &h, u64 small_value_modulus) {
+    for (u64 q : h.moduli) {
+        if (small_value_modulus >= q || small_value_modulus < 2) {  // base.rs:288-292, :337-341
             set_last_error("small_value_modulus must be >= 2 and smaller than every RNS modulus");
             return PFHE_ERR_BAD_ARGUMENT;
         }
     }
-    DeviceGuard g(r->h.device);
+    return PFHE_OK;
+}
+
+template <class W>
+int rns_wrapping_dev_impl(const RnsHost *h, const W *small_dev, size_t value_count, W *multi_dev, size_t len_out,
+                          u64 small_value_modulus, void *stream) {
+    if (!h || ((!small_dev || !multi_dev) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
+    if (len_out != value_count * h->par.dev.L) return PFHE_ERR_BAD_LENGTH;
+    PFHE_TRY(small_modulus_check(*h, small_value_modulus));
+    DeviceGuard g(h->device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    return rns_wrapping_decompose_dev(r->h.par, (const u64 *)small_values_dev, (u64 *)multi_residues_dev, value_count,
+    return rns_wrapping_decompose_dev(h->par, (const DevWord<W> *)small_dev, (DevWord<W> *)multi_dev, value_count,
                                       small_value_modulus, (hipStream_t)stream);
-    PFHE_GUARD_END
 }
 
-int pfhe_rns_wrapping_decompose_small_values_to(const pfhe_rns *r, const uint64_t *small_values, size_t value_count,
-                                                uint64_t *multi_residues, size_t len_out,
-                                                uint64_t small_value_modulus) {
-    PFHE_GUARD_BEGIN
-    if (!r || ((!small_values || !multi_residues) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (len_out != value_count * r->h.par.dev.L) return PFHE_ERR_BAD_LENGTH;
+template <class W>
+int rns_wrapping_host_impl(const RnsHost *h, const W *small, size_t value_count, W *multi, size_t len_out,
+                           u64 small_value_modulus) {
+    if (!h || ((!small || !multi) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
+    if (len_out != value_count * h->par.dev.L) return PFHE_ERR_BAD_LENGTH;
     if (value_count == 0) return PFHE_OK;
-    DeviceGuard g(r->h.device);
+    DeviceGuard g(h->device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    HostStage st(r->h.device);  // pooled staging context: no allocation in steady state
+    HostStage st(h->device);
     if (!st.ok()) return PFHE_ERR_HIP;
-    void *in = nullptr, *o = nullptr;
-    PFHE_TRY(st.upload(small_values, value_count * 8, &in));
-    PFHE_TRY(st.alloc(len_out * 8, &o));
-    PFHE_TRY(pfhe_rns_wrapping_decompose_small_values_to_dev(r, (const uint64_t *)in, value_count, (uint64_t *)o,
-                                                             len_out, small_value_modulus, st.stream()));
-    PFHE_TRY(st.download(multi_residues, o, len_out * 8));
+    void *i = nullptr, *o = nullptr;
+    PFHE_TRY(st.upload(small, value_count * sizeof(W), &i));
+    PFHE_TRY(st.alloc(len_out * sizeof(W), &o));
+    PFHE_TRY(rns_wrapping_dev_impl<W>(h, (const W *)i, value_count, (W *)o, len_out, small_value_modulus, st.stream()));
+    PFHE_TRY(st.download(multi, o, len_out * sizeof(W)));
     return st.finish();
-    PFHE_GUARD_END
 }
 
-static int add_scaled_common(const pfhe_rns *r, const uint64_t *small_dev, size_t value_count, uint64_t *acc_dev,
-                             size_t len_acc, uint64_t small_value_modulus, bool centred, const uint64_t *factors,
-                             void *stream) {
-    if (!r || !factors || ((!small_dev || !acc_dev) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (len_acc != value_count * r->h.par.dev.L) return PFHE_ERR_BAD_LENGTH;
-    for (u32 i = 0; i < r->h.par.dev.L; ++i) {
-        if (centred && (small_value_modulus >= r->h.moduli[i] || small_value_modulus < 2)) {  // base.rs:337-341
-            set_last_error("small_value_modulus must be >= 2 and smaller than every RNS modulus");
-            return PFHE_ERR_BAD_ARGUMENT;
-        }
-        if (factors[2 * i] >= r->h.moduli[i]) {
+// `factors`: L ShoupFactor<W> (value, quotient) pairs.  64-bit pairs are used as given; for 32-bit ones the 64-bit
+// quotient the kernels multiply by is derived from the value (the product is the same canonical residue)
+template <class W>
+int rns_add_scaled_dev_impl(const RnsHost *h, const W *small_dev, size_t value_count, W *acc_dev, size_t len_acc,
+                            u64 small_value_modulus, bool centred, const W *factors, void *stream) {
+    if (!h || !factors || ((!small_dev || !acc_dev) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
+    const u32 L = h->par.dev.L;
+    if (len_acc != value_count * L) return PFHE_ERR_BAD_LENGTH;
+    if (centred) PFHE_TRY(small_modulus_check(*h, small_value_modulus));
+    std::vector<u64> pairs(2 * (size_t)L);
+    for (u32 i = 0; i < L; ++i) {
+        if (factors[2 * i] >= h->moduli[i]) {
             set_last_error("factor values must be reduced modulo their modulus");
             return PFHE_ERR_BAD_ARGUMENT;
         }
+        pairs[2 * i] = factors[2 * i];
+        pairs[2 * i + 1] = sizeof(W) == 8 ? (u64)factors[2 * i + 1]
+                                          : (u64)((((unsigned __int128)factors[2 * i]) << 64) / h->moduli[i]);
     }
-    DeviceGuard g(r->h.device);
+    DeviceGuard g(h->device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
     // base.rs:343,371-378: a small modulus of two takes the unsigned branch (a 1 stays +1)
     const bool lift = centred && small_value_modulus != 2;
-    return rns_add_decompose_scaled_dev(r->h.par, (const u64 *)small_dev, (u64 *)acc_dev, value_count, small_value_modulus,
-                                        lift, (const u64 *)factors, (hipStream_t)stream);
+    return rns_add_decompose_scaled_dev(h->par, (const DevWord<W> *)small_dev, (DevWord<W> *)acc_dev, value_count,
+                                        small_value_modulus, lift, pairs.data(), (hipStream_t)stream);
 }
 
-int pfhe_rns_add_wrapping_decompose_small_values_scaled_dev(const pfhe_rns *r, const uint64_t *small_values_dev,
-                                                            size_t value_count, uint64_t *acc_dev, size_t len_acc,
-                                                            uint64_t small_value_modulus, const uint64_t *factors,
-                                                            void *stream) {
-    PFHE_GUARD_BEGIN
-    return add_scaled_common(r, small_values_dev, value_count, acc_dev, len_acc, small_value_modulus, true, factors, stream);
-    PFHE_GUARD_END
-}
-
-int pfhe_rns_add_decompose_small_values_scaled_dev(const pfhe_rns *r, const uint64_t *small_values_dev, size_t value_count,
-                                                   uint64_t *acc_dev, size_t len_acc, const uint64_t *factors,
-                                                   void *stream) {
-    PFHE_GUARD_BEGIN
-    return add_scaled_common(r, small_values_dev, value_count, acc_dev, len_acc, 0, false, factors, stream);
-    PFHE_GUARD_END
-}
-
-static int add_scaled_host(const pfhe_rns *r, const uint64_t *small_values, size_t value_count, uint64_t *acc,
-                           size_t len_acc, uint64_t small_value_modulus, bool centred, const uint64_t *factors) {
-    if (!r || !factors || ((!small_values || !acc) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (len_acc != value_count * r->h.par.dev.L) return PFHE_ERR_BAD_LENGTH;
+template <class W>
+int rns_add_scaled_host_impl(const RnsHost *h, const W *small, size_t value_count, W *acc, size_t len_acc,
+                             u64 small_value_modulus, bool centred, const W *factors) {
+    if (!h || !factors || ((!small || !acc) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
+    if (len_acc != value_count * h->par.dev.L) return PFHE_ERR_BAD_LENGTH;
     if (value_count == 0) return PFHE_OK;
-    DeviceGuard g(r->h.device);
+    DeviceGuard g(h->device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    HostStage st(r->h.device);  // pooled staging context: no allocation in steady state
+    HostStage st(h->device);
     if (!st.ok()) return PFHE_ERR_HIP;
-    void *in = nullptr, *a = nullptr;
-    PFHE_TRY(st.upload(small_values, value_count * 8, &in));
-    PFHE_TRY(st.upload(acc, len_acc * 8, &a));
-    PFHE_TRY(add_scaled_common(r, (const uint64_t *)in, value_count, (uint64_t *)a, len_acc, small_value_modulus, centred,
-                               factors, st.stream()));
-    PFHE_TRY(st.download(acc, a, len_acc * 8));
+    void *i = nullptr, *a = nullptr;
+    PFHE_TRY(st.upload(small, value_count * sizeof(W), &i));
+    PFHE_TRY(st.upload(acc, len_acc * sizeof(W), &a));
+    PFHE_TRY(rns_add_scaled_dev_impl<W>(h, (const W *)i, value_count, (W *)a, len_acc, small_value_modulus, centred, factors,
+                                        st.stream()));
+    PFHE_TRY(st.download(acc, a, len_acc * sizeof(W)));
     return st.finish();
 }
 
-int pfhe_rns_add_wrapping_decompose_small_values_scaled(const pfhe_rns *r, const uint64_t *small_values,
-                                                        size_t value_count, uint64_t *acc, size_t len_acc,
-                                                        uint64_t small_value_modulus, const uint64_t *factors) {
-    PFHE_GUARD_BEGIN
-    return add_scaled_host(r, small_values, value_count, acc, len_acc, small_value_modulus, true, factors);
-    PFHE_GUARD_END
+template <class W>
+int rns_decompose_big_dev_impl(const RnsHost *h, const W *values_dev, size_t len_in, W *multi_dev, size_t len_out,
+                               size_t value_count, void *stream) {
+    if (!h || ((!values_dev || !multi_dev) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
+    if (len_in != value_count * words_per_value<W>(*h) || len_out != value_count * h->par.dev.L) return PFHE_ERR_BAD_LENGTH;
+    if (value_count == 0) return PFHE_OK;
+    DeviceGuard g(h->device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    return rns_decompose_big_dev(h->par, (const DevWord<W> *)values_dev, (DevWord<W> *)multi_dev, value_count,
+                                 (hipStream_t)stream);
 }
 
-int pfhe_rns_add_decompose_small_values_scaled(const pfhe_rns *r, const uint64_t *small_values, size_t value_count,
-                                               uint64_t *acc, size_t len_acc, const uint64_t *factors) {
-    PFHE_GUARD_BEGIN
-    return add_scaled_host(r, small_values, value_count, acc, len_acc, 0, false, factors);
-    PFHE_GUARD_END
+template <class W>
+int rns_decompose_big_host_impl(const RnsHost *h, const W *values, size_t len_in, W *multi, size_t len_out,
+                                size_t value_count) {
+    if (!h || ((!values || !multi) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
+    if (len_in != value_count * words_per_value<W>(*h) || len_out != value_count * h->par.dev.L) return PFHE_ERR_BAD_LENGTH;
+    if (value_count == 0) return PFHE_OK;
+    DeviceGuard g(h->device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    HostStage st(h->device);
+    if (!st.ok()) return PFHE_ERR_HIP;
+    void *i = nullptr, *o = nullptr;
+    PFHE_TRY(st.upload(values, len_in * sizeof(W), &i));
+    PFHE_TRY(st.alloc(len_out * sizeof(W), &o));
+    PFHE_TRY(rns_decompose_big_dev_impl<W>(h, (const W *)i, len_in, (W *)o, len_out, value_count, st.stream()));
+    PFHE_TRY(st.download(multi, o, len_out * sizeof(W)));
+    return st.finish();
 }
 
-/* ------------------------------ BigUintApproxSignedBasis ------------------------------ */
+/* ---- BigUintApproxSignedBasis<W> ---- */
 
-int pfhe_basis_create(const pfhe_rns *rns, uint32_t log_basis, size_t reverse_length, pfhe_basis **out) {
-    PFHE_GUARD_BEGIN
-    if (!out || !rns) return PFHE_ERR_BAD_ARGUMENT;
-    *out = nullptr;
-    auto b = std::make_unique<pfhe_basis>();
-    PFHE_TRY(build_basis(rns->h, log_basis, reverse_length, b->h));
-    if (b->h.par.wide()) {
-        DeviceGuard g(b->h.device);
+inline int basis_create_impl(const RnsHost *rns, uint32_t log_basis, size_t reverse_length, BasisHost &b) {
+    if (!rns) return PFHE_ERR_BAD_ARGUMENT;
+    PFHE_TRY(build_basis(*rns, log_basis, reverse_length, b));
+    if (b.par.wide()) {
+        DeviceGuard g(b.device);
         if (!g.ok) return PFHE_ERR_NO_DEVICE;
-        PFHE_TRY(upload_basis_wide(b->h));
+        PFHE_TRY(upload_basis_wide(b));
     }
-    *out = b.release();
     return PFHE_OK;
-    PFHE_GUARD_END
 }
 
-void pfhe_basis_destroy(pfhe_basis *b) { delete b; }
-size_t pfhe_basis_decompose_length(const pfhe_basis *b) { return b ? b->h.par.dev.ell : 0; }
-uint32_t pfhe_basis_log_basis(const pfhe_basis *b) { return b ? b->h.par.dev.log_basis : 0; }
-uint32_t pfhe_basis_drop_bits(const pfhe_basis *b) { return b ? b->h.par.dev.drop_bits : 0; }
-uint64_t pfhe_basis_basis_value(const pfhe_basis *b) { return b ? b->h.par.dev.basis : 0; }
-
-int pfhe_basis_scalars(const pfhe_basis *b, uint64_t *out, size_t len) {
+template <class W>
+int basis_scalars_impl(const BasisHost *b, W *out, size_t len) {
     if (!b || !out) return PFHE_ERR_BAD_ARGUMENT;
-    if (len != b->h.scalars.size()) return PFHE_ERR_BAD_LENGTH;
-    std::copy(b->h.scalars.begin(), b->h.scalars.end(), out);
+    const size_t vw = words_per_value<W>(*b), vl = b->par.dev.value_len, ell = b->par.dev.ell;
+    if (len != ell * vw) return PFHE_ERR_BAD_LENGTH;
+    for (size_t j = 0; j < ell; ++j)
+        for (size_t w = 0; w < vw; ++w) out[j * vw + w] = word_of<W>(b->scalars, j * vl, w);
     return PFHE_OK;
 }
 
-int pfhe_basis_scalars_residue(const pfhe_basis *b, uint64_t *out, size_t len) {
+template <class W>
+int basis_scalars_residue_impl(const BasisHost *b, W *out, size_t len) {
     if (!b || !out) return PFHE_ERR_BAD_ARGUMENT;
-    if (len != b->h.scalars_residue.size()) return PFHE_ERR_BAD_LENGTH;
-    std::copy(b->h.scalars_residue.begin(), b->h.scalars_residue.end(), out);
+    if (len != b->scalars_residue.size()) return PFHE_ERR_BAD_LENGTH;
+    for (size_t i = 0; i < len; ++i) out[i] = (W)b->scalars_residue[i];
     return PFHE_OK;
 }
 
-int pfhe_basis_init_value_carry_slice_inplace_dev(const pfhe_basis *b, uint64_t *values_dev, size_t len,
-                                                  uint8_t *carries_dev, size_t count, void *stream) {
-    PFHE_GUARD_BEGIN
+template <class W>
+int basis_init_dev_impl(const BasisHost *b, W *values_dev, size_t len, uint8_t *carries_dev, size_t count, void *stream) {
     if (!b || ((!values_dev || !carries_dev) && count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (len != count * b->h.par.dev.value_len) return PFHE_ERR_BAD_LENGTH;  // basis.rs:332
-    DeviceGuard g(b->h.device);
+    if (len != count * words_per_value<W>(*b)) return PFHE_ERR_BAD_LENGTH;  // basis.rs:332
+    DeviceGuard g(b->device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    return basis_init_value_carry_dev(b->h.par, (u64 *)values_dev, carries_dev, count, (hipStream_t)stream);
-    PFHE_GUARD_END
+    return basis_init_value_carry_dev(b->par, (DevWord<W> *)values_dev, carries_dev, count, (hipStream_t)stream);
 }
 
-int pfhe_basis_init_value_carry_slice_inplace(const pfhe_basis *b, uint64_t *values, size_t len, uint8_t *carries,
-                                              size_t count) {
-    PFHE_GUARD_BEGIN
+template <class W>
+int basis_init_host_impl(const BasisHost *b, W *values, size_t len, uint8_t *carries, size_t count) {
     if (!b || ((!values || !carries) && count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (len != count * b->h.par.dev.value_len) return PFHE_ERR_BAD_LENGTH;
+    if (len != count * words_per_value<W>(*b)) return PFHE_ERR_BAD_LENGTH;
     if (count == 0) return PFHE_OK;
-    DeviceGuard g(b->h.device);
+    DeviceGuard g(b->device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    HostStage st(b->h.device);  // pooled staging context: no allocation in steady state
+    HostStage st(b->device);
     if (!st.ok()) return PFHE_ERR_HIP;
     void *v = nullptr, *c = nullptr;
-    PFHE_TRY(st.upload(values, len * 8, &v));
+    PFHE_TRY(st.upload(values, len * sizeof(W), &v));
     PFHE_TRY(st.alloc(count, &c));
-    PFHE_TRY(basis_init_value_carry_dev(b->h.par, (u64 *)v, (unsigned char *)c, count, st.stream()));
-    PFHE_TRY(st.download(values, v, len * 8));
+    PFHE_TRY(basis_init_value_carry_dev(b->par, (DevWord<W> *)v, (unsigned char *)c, count, st.stream()));
+    PFHE_TRY(st.download(values, v, len * sizeof(W)));
     PFHE_TRY(st.download(carries, c, count));
     return st.finish();
-    PFHE_GUARD_END
 }
 
-int pfhe_basis_unsigned_decompose_slice_to_dev(const pfhe_basis *b, size_t level, const uint64_t *values_dev,
-                                               size_t len, uint64_t *digits_dev, uint8_t *carries_dev, size_t count,
-                                               void *stream) {
-    PFHE_GUARD_BEGIN
-    if (!b || ((!values_dev || !digits_dev || !carries_dev) && count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (level >= b->h.par.dev.ell) return PFHE_ERR_BAD_ARGUMENT;
-    if (len != count * b->h.par.dev.value_len) return PFHE_ERR_BAD_LENGTH;  // common.rs:316-317
-    DeviceGuard g(b->h.device);
-    if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    return basis_unsigned_decompose_dev(b->h.par, (u32)level, (const u64 *)values_dev, (u64 *)digits_dev, carries_dev,
-                                        count, (hipStream_t)stream);
-    PFHE_GUARD_END
-}
-
-int pfhe_basis_unsigned_decompose_slice_to(const pfhe_basis *b, size_t level, const uint64_t *values, size_t len,
-                                           uint64_t *digits, uint8_t *carries, size_t count) {
-    PFHE_GUARD_BEGIN
-    if (!b || ((!values || !digits || !carries) && count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (level >= b->h.par.dev.ell) return PFHE_ERR_BAD_ARGUMENT;
-    if (len != count * b->h.par.dev.value_len) return PFHE_ERR_BAD_LENGTH;
-    if (count == 0) return PFHE_OK;
-    DeviceGuard g(b->h.device);
-    if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    HostStage st(b->h.device);  // pooled staging context: no allocation in steady state
-    if (!st.ok()) return PFHE_ERR_HIP;
-    void *v = nullptr, *d = nullptr, *c = nullptr;
-    PFHE_TRY(st.upload(values, len * 8, &v));
-    PFHE_TRY(st.alloc(count * 8, &d));
-    PFHE_TRY(st.upload(carries, count, &c));
-    PFHE_TRY(basis_unsigned_decompose_dev(b->h.par, (u32)level, (const u64 *)v, (u64 *)d, (unsigned char *)c, count,
-                                          st.stream()));
-    PFHE_TRY(st.download(digits, d, count * 8));
-    PFHE_TRY(st.download(carries, c, count));
-    return st.finish();
-    PFHE_GUARD_END
-}
-
-int pfhe_basis_init_value_carry_slice_to_dev(const pfhe_basis *b, const uint64_t *values_dev, size_t len,
-                                             uint64_t *adjusted_dev, uint8_t *carries_dev, size_t count, void *stream) {
-    PFHE_GUARD_BEGIN
+template <class W>
+int basis_init_to_dev_impl(const BasisHost *b, const W *values_dev, size_t len, W *adjusted_dev, uint8_t *carries_dev,
+                           size_t count, void *stream) {
     if (!b || ((!values_dev || !adjusted_dev || !carries_dev) && count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (len != count * b->h.par.dev.value_len) return PFHE_ERR_BAD_LENGTH;  // basis.rs:378-379
+    if (len != count * words_per_value<W>(*b)) return PFHE_ERR_BAD_LENGTH;  // basis.rs:378-379
     if (count == 0) return PFHE_OK;
-    DeviceGuard g(b->h.device);
+    DeviceGuard g(b->device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
     if (adjusted_dev != values_dev)
-        PFHE_HIP(hipMemcpyAsync(adjusted_dev, values_dev, len * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    return basis_init_value_carry_dev(b->h.par, (u64 *)adjusted_dev, carries_dev, count, (hipStream_t)stream);
-    PFHE_GUARD_END
+        PFHE_HIP(hipMemcpyAsync(adjusted_dev, values_dev, len * sizeof(W), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return basis_init_value_carry_dev(b->par, (DevWord<W> *)adjusted_dev, carries_dev, count, (hipStream_t)stream);
 }
 
-int pfhe_basis_init_value_carry_slice_to(const pfhe_basis *b, const uint64_t *values, size_t len, uint64_t *adjusted,
-                                         uint8_t *carries, size_t count) {
-    PFHE_GUARD_BEGIN
+template <class W>
+int basis_init_to_host_impl(const BasisHost *b, const W *values, size_t len, W *adjusted, uint8_t *carries, size_t count) {
     if (!b || ((!values || !adjusted || !carries) && count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (len != count * b->h.par.dev.value_len) return PFHE_ERR_BAD_LENGTH;
+    if (len != count * words_per_value<W>(*b)) return PFHE_ERR_BAD_LENGTH;
     if (count == 0) return PFHE_OK;
-    if (adjusted != values) std::memcpy(adjusted, values, len * 8);
-    return pfhe_basis_init_value_carry_slice_inplace(b, adjusted, len, carries, count);
-    PFHE_GUARD_END
+    if (adjusted != values) std::memcpy(adjusted, values, len * sizeof(W));
+    return basis_init_host_impl<W>(b, adjusted, len, carries, count);
 }
 
-int pfhe_basis_decompose_slice_to_dev(const pfhe_basis *b, size_t level, const uint64_t *values_dev, size_t len,
-                                      uint64_t *decomposed_dev, size_t len_out, uint8_t *carries_dev, size_t count,
-                                      void *stream) {
-    PFHE_GUARD_BEGIN
+template <class W>
+int basis_unsigned_dev_impl(const BasisHost *b, size_t level, const W *values_dev, size_t len, W *digits_dev,
+                            uint8_t *carries_dev, size_t count, void *stream) {
+    if (!b || ((!values_dev || !digits_dev || !carries_dev) && count)) return PFHE_ERR_BAD_ARGUMENT;
+    if (level >= b->par.dev.ell) return PFHE_ERR_BAD_ARGUMENT;
+    if (len != count * words_per_value<W>(*b)) return PFHE_ERR_BAD_LENGTH;  // common.rs:316-317
+    DeviceGuard g(b->device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    return basis_unsigned_decompose_dev(b->par, (u32)level, (const DevWord<W> *)values_dev, (DevWord<W> *)digits_dev,
+                                        carries_dev, count, (hipStream_t)stream);
+}
+
+template <class W>
+int basis_unsigned_host_impl(const BasisHost *b, size_t level, const W *values, size_t len, W *digits, uint8_t *carries,
+                             size_t count) {
+    if (!b || ((!values || !digits || !carries) && count)) return PFHE_ERR_BAD_ARGUMENT;
+    if (level >= b->par.dev.ell) return PFHE_ERR_BAD_ARGUMENT;
+    if (len != count * words_per_value<W>(*b)) return PFHE_ERR_BAD_LENGTH;
+    if (count == 0) return PFHE_OK;
+    DeviceGuard g(b->device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    HostStage st(b->device);
+    if (!st.ok()) return PFHE_ERR_HIP;
+    void *v = nullptr, *d = nullptr, *c = nullptr;
+    PFHE_TRY(st.upload(values, len * sizeof(W), &v));
+    PFHE_TRY(st.alloc(count * sizeof(W), &d));
+    PFHE_TRY(st.upload(carries, count, &c));
+    PFHE_TRY(basis_unsigned_decompose_dev(b->par, (u32)level, (const DevWord<W> *)v, (DevWord<W> *)d, (unsigned char *)c, count,
+                                          st.stream()));
+    PFHE_TRY(st.download(digits, d, count * sizeof(W)));
+    PFHE_TRY(st.download(carries, c, count));
+    return st.finish();
+}
+
+template <class W>
+int basis_signed_dev_impl(const BasisHost *b, size_t level, const W *values_dev, size_t len, W *decomposed_dev,
+                          size_t len_out, uint8_t *carries_dev, size_t count, void *stream) {
     if (!b || ((!values_dev || !decomposed_dev || !carries_dev) && count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (level >= b->h.par.dev.ell) return PFHE_ERR_BAD_ARGUMENT;
-    if (len != count * b->h.par.dev.value_len || len_out != len) return PFHE_ERR_BAD_LENGTH;  // common.rs:296-297
+    if (level >= b->par.dev.ell) return PFHE_ERR_BAD_ARGUMENT;
+    if (len != count * words_per_value<W>(*b) || len_out != len) return PFHE_ERR_BAD_LENGTH;  // common.rs:296-297
     if (count && values_dev == decomposed_dev) {
         set_last_error("decompose_slice_to needs distinct input and output buffers");
         return PFHE_ERR_BAD_ARGUMENT;
     }
-    DeviceGuard g(b->h.device);
+    DeviceGuard g(b->device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    return basis_signed_decompose_dev(b->h.rns, b->h.par, (u32)level, (const u64 *)values_dev, (u64 *)decomposed_dev,
-                                      carries_dev, count, (hipStream_t)stream);
-    PFHE_GUARD_END
+    return basis_signed_decompose_dev(b->rns, b->par, (u32)level, (const DevWord<W> *)values_dev,
+                                      (DevWord<W> *)decomposed_dev, carries_dev, count, (hipStream_t)stream);
 }
 
-int pfhe_basis_decompose_slice_to(const pfhe_basis *b, size_t level, const uint64_t *values, size_t len,
-                                  uint64_t *decomposed, size_t len_out, uint8_t *carries, size_t count) {
-    PFHE_GUARD_BEGIN
+template <class W>
+int basis_signed_host_impl(const BasisHost *b, size_t level, const W *values, size_t len, W *decomposed, size_t len_out,
+                           uint8_t *carries, size_t count) {
     if (!b || ((!values || !decomposed || !carries) && count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (level >= b->h.par.dev.ell) return PFHE_ERR_BAD_ARGUMENT;
-    if (len != count * b->h.par.dev.value_len || len_out != len) return PFHE_ERR_BAD_LENGTH;
+    if (level >= b->par.dev.ell) return PFHE_ERR_BAD_ARGUMENT;
+    if (len != count * words_per_value<W>(*b) || len_out != len) return PFHE_ERR_BAD_LENGTH;
     if (count == 0) return PFHE_OK;
-    DeviceGuard g(b->h.device);
+    DeviceGuard g(b->device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    HostStage st(b->h.device);  // pooled staging context: no allocation in steady state
+    HostStage st(b->device);
     if (!st.ok()) return PFHE_ERR_HIP;
     void *v = nullptr, *d = nullptr, *c = nullptr;
-    PFHE_TRY(st.upload(values, len * 8, &v));
-    PFHE_TRY(st.alloc(len * 8, &d));
+    PFHE_TRY(st.upload(values, len * sizeof(W), &v));
+    PFHE_TRY(st.alloc(len * sizeof(W), &d));
     PFHE_TRY(st.upload(carries, count, &c));
-    PFHE_TRY(basis_signed_decompose_dev(b->h.rns, b->h.par, (u32)level, (const u64 *)v, (u64 *)d, (unsigned char *)c, count,
-                                        st.stream()));
-    PFHE_TRY(st.download(decomposed, d, len * 8));
+    PFHE_TRY(basis_signed_decompose_dev(b->rns, b->par, (u32)level, (const DevWord<W> *)v, (DevWord<W> *)d,
+                                        (unsigned char *)c, count, st.stream()));
+    PFHE_TRY(st.download(decomposed, d, len * sizeof(W)));
     PFHE_TRY(st.download(carries, c, count));
     return st.finish();
-    PFHE_GUARD_END
 }
+
+}  // namespace
+
+// the entry points of one word width: NS = pfhe_rns / pfhe_rns32, BS = pfhe_basis / pfhe_basis32, W = the C word type
+#define H(p) ((p) ? &(p)->h : nullptr)
+#define PFHE_RNS_FAMILY(NS, BS, W)                                                                                         \
+    int NS##_create(const W *moduli, size_t count, int device, NS **out) {                                                \
+        PFHE_GUARD_BEGIN                                                                                                   \
+        if (!out) return PFHE_ERR_BAD_ARGUMENT;                                                                            \
+        *out = nullptr;                                                                                                    \
+        auto r = std::make_unique<NS>();                                                                                   \
+        PFHE_TRY(rns_create_impl<W>(moduli, count, device, r->h));                                                         \
+        *out = r.release();                                                                                                \
+        return PFHE_OK;                                                                                                    \
+        PFHE_GUARD_END                                                                                                     \
+    }                                                                                                                      \
+    void NS##_destroy(NS *r) { delete r; }                                                                                 \
+    size_t NS##_moduli_count(const NS *r) { return r ? r->h.par.dev.L : 0; }                                               \
+    size_t NS##_big_uint_value_len(const NS *r) { return r ? words_per_value<W>(r->h) : 0; }                               \
+    int NS##_moduli_product(const NS *r, W *out, size_t len) { return rns_moduli_product_impl<W>(H(r), out, len); }        \
+    int NS##_compose_multiple_values_to_dev(const NS *r, const W *multi_residues_dev, size_t len_in,                      \
+                                            W *big_uint_values_dev, size_t len_out, size_t value_count, void *stream) {   \
+        PFHE_GUARD_BEGIN                                                                                                   \
+        return rns_compose_dev_impl<W>(H(r), multi_residues_dev, len_in, big_uint_values_dev, len_out, value_count, stream); \
+        PFHE_GUARD_END                                                                                                     \
+    }                                                                                                                      \
+    int NS##_compose_multiple_values_to(const NS *r, const W *multi_residues, size_t len_in, W *big_uint_values,          \
+                                        size_t len_out, size_t value_count) {                                              \
+        PFHE_GUARD_BEGIN                                                                                                   \
+        return rns_compose_host_impl<W>(H(r), multi_residues, len_in, big_uint_values, len_out, value_count);              \
+        PFHE_GUARD_END                                                                                                     \
+    }                                                                                                                      \
+    int NS##_wrapping_decompose_small_values_to_dev(const NS *r, const W *small_values_dev, size_t value_count,           \
+                                                    W *multi_residues_dev, size_t len_out, W small_value_modulus,         \
+                                                    void *stream) {                                                        \
+        PFHE_GUARD_BEGIN                                                                                                   \
+        return rns_wrapping_dev_impl<W>(H(r), small_values_dev, value_count, multi_residues_dev, len_out,                  \
+                                        small_value_modulus, stream);                                                      \
+        PFHE_GUARD_END                                                                                                     \
+    }                                                                                                                      \
+    int NS##_wrapping_decompose_small_values_to(const NS *r, const W *small_values, size_t value_count,                   \
+                                                W *multi_residues, size_t len_out, W small_value_modulus) {               \
+        PFHE_GUARD_BEGIN                                                                                                   \
+        return rns_wrapping_host_impl<W>(H(r), small_values, value_count, multi_residues, len_out, small_value_modulus);   \
+        PFHE_GUARD_END                                                                                                     \
+    }                                                                                                                      \
+    int NS##_add_wrapping_decompose_small_values_scaled_dev(const NS *r, const W *small_values_dev, size_t value_count,   \
+                                                            W *acc_dev, size_t len_acc, W small_value_modulus,            \
+                                                            const W *factors, void *stream) {                              \
+        PFHE_GUARD_BEGIN                                                                                                   \
+        return rns_add_scaled_dev_impl<W>(H(r), small_values_dev, value_count, acc_dev, len_acc, small_value_modulus,      \
+                                          true, factors, stream);                                                          \
+        PFHE_GUARD_END                                                                                                     \
+    }                                                                                                                      \
+    int NS##_add_decompose_small_values_scaled_dev(const NS *r, const W *small_values_dev, size_t value_count,            \
+                                                   W *acc_dev, size_t len_acc, const W *factors, void *stream) {           \
+        PFHE_GUARD_BEGIN                                                                                                   \
+        return rns_add_scaled_dev_impl<W>(H(r), small_values_dev, value_count, acc_dev, len_acc, 0, false, factors, stream); \
+        PFHE_GUARD_END                                                                                                     \
+    }                                                                                                                      \
+    int NS##_add_wrapping_decompose_small_values_scaled(const NS *r, const W *small_values, size_t value_count, W *acc,   \
+                                                        size_t len_acc, W small_value_modulus, const W *factors) {         \
+        PFHE_GUARD_BEGIN                                                                                                   \
+        return rns_add_scaled_host_impl<W>(H(r), small_values, value_count, acc, len_acc, small_value_modulus, true, factors); \
+        PFHE_GUARD_END                                                                                                     \
+    }                                                                                                                      \
+    int NS##_add_decompose_small_values_scaled(const NS *r, const W *small_values, size_t value_count, W *acc,            \
+                                               size_t len_acc, const W *factors) {                                         \
+        PFHE_GUARD_BEGIN                                                                                                   \
+        return rns_add_scaled_host_impl<W>(H(r), small_values, value_count, acc, len_acc, 0, false, factors);              \
+        PFHE_GUARD_END                                                                                                     \
+    }                                                                                                                      \
+    int NS##_decompose_big_uint_values_to_dev(const NS *r, const W *big_uint_values_dev, size_t len_in,                   \
+                                              W *multi_residues_dev, size_t len_out, size_t value_count, void *stream) {  \
+        PFHE_GUARD_BEGIN                                                                                                   \
+        return rns_decompose_big_dev_impl<W>(H(r), big_uint_values_dev, len_in, multi_residues_dev, len_out, value_count,  \
+                                             stream);                                                                      \
+        PFHE_GUARD_END                                                                                                     \
+    }                                                                                                                      \
+    int NS##_decompose_big_uint_values_to(const NS *r, const W *big_uint_values, size_t len_in, W *multi_residues,        \
+                                          size_t len_out, size_t value_count) {                                            \
+        PFHE_GUARD_BEGIN                                                                                                   \
+        return rns_decompose_big_host_impl<W>(H(r), big_uint_values, len_in, multi_residues, len_out, value_count);        \
+        PFHE_GUARD_END                                                                                                     \
+    }                                                                                                                      \
+    int BS##_create(const NS *rns, uint32_t log_basis, size_t reverse_length, BS **out) {                                 \
+        PFHE_GUARD_BEGIN                                                                                                   \
+        if (!out || !rns) return PFHE_ERR_BAD_ARGUMENT;                                                                    \
+        *out = nullptr;                                                                                                    \
+        auto b = std::make_unique<BS>();                                                                                   \
+        PFHE_TRY(basis_create_impl(H(rns), log_basis, reverse_length, b->h));                                              \
+        *out = b.release();                                                                                                \
+        return PFHE_OK;                                                                                                    \
+        PFHE_GUARD_END                                                                                                     \
+    }                                                                                                                      \
+    void BS##_destroy(BS *b) { delete b; }                                                                                 \
+    size_t BS##_decompose_length(const BS *b) { return b ? b->h.par.dev.ell : 0; }                                         \
+    uint32_t BS##_log_basis(const BS *b) { return b ? b->h.par.dev.log_basis : 0; }                                        \
+    uint32_t BS##_drop_bits(const BS *b) { return b ? b->h.par.dev.drop_bits : 0; }                                        \
+    W BS##_basis_value(const BS *b) { return b ? (W)b->h.par.dev.basis : 0; }                                              \
+    int BS##_scalars(const BS *b, W *out, size_t len) { return basis_scalars_impl<W>(H(b), out, len); }                    \
+    int BS##_scalars_residue(const BS *b, W *out, size_t len) { return basis_scalars_residue_impl<W>(H(b), out, len); }    \
+    int BS##_init_value_carry_slice_inplace_dev(const BS *b, W *values_dev, size_t len, uint8_t *carries_dev,             \
+                                                size_t count, void *stream) {                                              \
+        PFHE_GUARD_BEGIN                                                                                                   \
+        return basis_init_dev_impl<W>(H(b), values_dev, len, carries_dev, count, stream);                                  \
+        PFHE_GUARD_END                                                                                                     \
+    }                                                                                                                      \
+    int BS##_init_value_carry_slice_inplace(const BS *b, W *values, size_t len, uint8_t *carries, size_t count) {         \
+        PFHE_GUARD_BEGIN                                                                                                   \
+        return basis_init_host_impl<W>(H(b), values, len, carries, count);                                                 \
+        PFHE_GUARD_END                                                                                                     \
+    }                                                                                                                      \
+    int BS##_unsigned_decompose_slice_to_dev(const BS *b, size_t level, const W *values_dev, size_t len, W *digits_dev,   \
+                                             uint8_t *carries_dev, size_t count, void *stream) {                           \
+        PFHE_GUARD_BEGIN                                                                                                   \
+        return basis_unsigned_dev_impl<W>(H(b), level, values_dev, len, digits_dev, carries_dev, count, stream);           \
+        PFHE_GUARD_END                                                                                                     \
+    }                                                                                                                      \
+    int BS##_unsigned_decompose_slice_to(const BS *b, size_t level, const W *values, size_t len, W *digits,               \
+                                         uint8_t *carries, size_t count) {                                                 \
+        PFHE_GUARD_BEGIN                                                                                                   \
+        return basis_unsigned_host_impl<W>(H(b), level, values, len, digits, carries, count);                              \
+        PFHE_GUARD_END                                                                                                     \
+    }                                                                                                                      \
+    int BS##_init_value_carry_slice_to_dev(const BS *b, const W *values_dev, size_t len, W *adjusted_dev,                 \
+                                           uint8_t *carries_dev, size_t count, void *stream) {                             \
+        PFHE_GUARD_BEGIN                                                                                                   \
+        return basis_init_to_dev_impl<W>(H(b), values_dev, len, adjusted_dev, carries_dev, count, stream);                 \
+        PFHE_GUARD_END                                                                                                     \
+    }                                                                                                                      \
+    int BS##_init_value_carry_slice_to(const BS *b, const W *values, size_t len, W *adjusted, uint8_t *carries,           \
+                                       size_t count) {                                                                     \
+        PFHE_GUARD_BEGIN                                                                                                   \
+        return basis_init_to_host_impl<W>(H(b), values, len, adjusted, carries, count);                                    \
+        PFHE_GUARD_END                                                                                                     \
+    }                                                                                                                      \
+    int BS##_decompose_slice_to_dev(const BS *b, size_t level, const W *values_dev, size_t len, W *decomposed_dev,        \
+                                    size_t len_out, uint8_t *carries_dev, size_t count, void *stream) {                    \
+        PFHE_GUARD_BEGIN                                                                                                   \
+        return basis_signed_dev_impl<W>(H(b), level, values_dev, len, decomposed_dev, len_out, carries_dev, count, stream); \
+        PFHE_GUARD_END                                                                                                     \
+    }                                                                                                                      \
+    int BS##_decompose_slice_to(const BS *b, size_t level, const W *values, size_t len, W *decomposed, size_t len_out,    \
+                                uint8_t *carries, size_t count) {                                                          \
+        PFHE_GUARD_BEGIN                                                                                                   \
+        return basis_signed_host_impl<W>(H(b), level, values, len, decomposed, len_out, carries, count);                   \
+        PFHE_GUARD_END                                                                                                     \
+    }
+
+extern "C" {
+
+PFHE_RNS_FAMILY(pfhe_rns, pfhe_basis, uint64_t)
+PFHE_RNS_FAMILY(pfhe_rns32, pfhe_basis32, uint32_t)
 
 /* ------------------------------ external product ------------------------------ */
 
@@ -698,6 +873,15 @@ int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *rns, const 
 void pfhe_extprod_plan_destroy(pfhe_extprod_plan *p) { delete p; }
 int pfhe_extprod_plan_in_use(const pfhe_extprod_plan *p) {
     return p && p->owner.load(std::memory_order_acquire) != 0 ? 1 : 0;
+}
+// test aid: hold != 0 takes the plan for the calling thread as an entry point would (PFHE_ERR_BUSY if another thread has
+// it) and keeps it until the same thread calls with hold == 0
+int pfhe_extprod_plan_debug_hold(pfhe_extprod_plan *p, int hold) {
+    if (plan_check(p) != PFHE_OK) return PFHE_ERR_BAD_ARGUMENT;
+    if (hold) return plan_acquire(p) ? PFHE_OK : PFHE_ERR_BUSY;
+    if (p->owner.load(std::memory_order_relaxed) != plan_thread_token()) return PFHE_ERR_BAD_ARGUMENT;
+    plan_release(p);
+    return PFHE_OK;
 }
 size_t pfhe_extprod_plan_scratch_bytes(const pfhe_extprod_plan *p) {
     if (!p) return 0;
@@ -891,6 +1075,215 @@ int pfhe_extprod_mul_dcrt_ggsw_to(pfhe_extprod_plan *plan, const uint64_t *crt_g
                                                (uint64_t *)r, len_result, into_coeff_form, st.stream()));
     PFHE_TRY(st.download(result, r, len_result * 8));
     return st.finish();
+    PFHE_GUARD_END
+}
+
+/* ------------------------------ external product over U32DcrtTable ------------------------------ */
+
+}  // extern "C"
+
+namespace {
+
+int run_product32(pfhe_extprod32_plan *p, const u32 *polys, u32 rows, const u32 *keys, bool keys_shared, u32 *result,
+                  u64 batch, bool accumulate, hipStream_t s, bool big_input) {
+    const TableSet &t = *p->table;
+    const bool tracked = p->last_done != nullptr && !stream_is_capturing(s);
+    if (tracked && p->last_valid) PFHE_HIP(hipStreamWaitEvent(s, p->last_done, 0));
+    const u64 W = (u64)t.L * t.n;
+    RnsParams rns = p->rns;
+    rns.dev.big_input = rns.wide_tab.big_input = big_input ? 1u : 0u;
+    const u64 in_words = big_input ? (u64)rns.dev.value_words * t.n : W;
+    const u32 ell = p->basis.ell;
+    const u64 key_words = (u64)rows * ell * (p->k + 1) * W;
+    int rc = PFHE_OK;
+    for (u64 done = 0; done < batch && rc == PFHE_OK; done += p->chunk) {
+        const u64 cur = std::min<u64>(p->chunk, batch - done);
+        rc = gadget_decompose_dev<u32>(rns, p->basis_par, t.log_n, polys + done * rows * in_words, p->digits, cur * rows, s);
+        if (rc == PFHE_OK)
+            rc = ntt32_transform_dev(t.primes_dev, t.L, t.log_n, p->digits, cur * rows * ell * t.L, false, false, s, t.tune);
+        if (rc == PFHE_OK)
+            rc = gadget_mulacc32_dev(t.primes_dev, t.L, t.log_n, p->k, rows, ell, p->digits,
+                                     keys + (keys_shared ? 0 : done * key_words), keys_shared,
+                                     result + done * (p->k + 1) * W, cur, accumulate, s);
+    }
+    if (tracked) {  // also after a failed call: whatever it queued still uses the buffer
+        if (hipEventRecord(p->last_done, s) == hipSuccess) {
+            p->last_valid = true;
+        } else {
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(s);
+            p->last_valid = false;
+        }
+    }
+    return rc;
+}
+
+int plan32_check(const pfhe_extprod32_plan *p) { return (!p || !p->table) ? PFHE_ERR_BAD_ARGUMENT : PFHE_OK; }
+
+// one GLev row against `batch` polynomials (CRT residues or big integers), accumulating or overwriting
+int glev32_common(pfhe_extprod32_plan *plan, uint32_t *out_dev, size_t len_out, const uint32_t *dcrt_glev_dev, size_t len_glev,
+                  const uint32_t *poly_dev, size_t len_poly, bool accumulate, bool big_input, void *stream) {
+    PFHE_TRY(plan32_check(plan));
+    PFHE_PLAN_LEASE(plan);
+    const TableSet &t = *plan->table;
+    const size_t W = (size_t)t.L * t.n, glwe = (plan->k + 1) * W, glev = plan->basis.ell * glwe;
+    const size_t in_words = big_input ? (size_t)plan->rns.dev.value_words * t.n : W;
+    if (len_poly % in_words != 0) return PFHE_ERR_BAD_LENGTH;
+    const u64 batch = len_poly / in_words;
+    if (len_out != batch * glwe || (len_glev != glev && len_glev != batch * glev)) {
+        set_last_error("glev product: acc/result must be batch*(k+1)*L*N words and the GLev one or batch of ell*(k+1)*L*N");
+        return PFHE_ERR_BAD_LENGTH;
+    }
+    if (batch == 0) return PFHE_OK;
+    if (!out_dev || !dcrt_glev_dev || !poly_dev) return PFHE_ERR_BAD_ARGUMENT;
+    PFHE_REQUIRE_ALIGNED(out_dev);
+    PFHE_REQUIRE_ALIGNED(dcrt_glev_dev);
+    PFHE_REQUIRE_ALIGNED(poly_dev);
+    DeviceGuard g(t.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    return run_product32(plan, poly_dev, 1, dcrt_glev_dev, len_glev == glev, out_dev, batch, accumulate, (hipStream_t)stream,
+                         big_input);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pfhe_extprod32_plan_create(const pfhe_dcrt32 *table, const pfhe_rns32 *rns, const pfhe_basis32 *basis,
+                               size_t glwe_dimension, size_t chunk, pfhe_extprod32_plan **out) {
+    PFHE_GUARD_BEGIN
+    if (!out || !table || !rns || !basis || glwe_dimension == 0 || glwe_dimension > 64) return PFHE_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    const TableSet *t = capi_table32_of(table);
+    if (t->L != rns->h.par.dev.L) {
+        set_last_error("DCRT table and RNS base have different moduli counts");
+        return PFHE_ERR_BAD_ARGUMENT;
+    }
+    for (u32 i = 0; i < t->L; ++i) {
+        if (t->primes[i].q != rns->h.moduli[i]) {
+            set_last_error("DCRT table and RNS base must use the same moduli in the same order");
+            return PFHE_ERR_BAD_ARGUMENT;
+        }
+        if (basis->h.par.dev.basis >= t->primes[i].q) {  // wrapping_decompose needs B < q_i (base.rs:288-292)
+            set_last_error("gadget basis must be smaller than every RNS modulus");
+            return PFHE_ERR_BAD_ARGUMENT;
+        }
+    }
+    if (basis->h.rns.dev.L != rns->h.par.dev.L || basis->h.Q != rns->h.Q) return PFHE_ERR_BAD_ARGUMENT;  // basis.rs:52
+    auto p = std::make_unique<pfhe_extprod32_plan>();
+    p->table = t;
+    p->rns = rns->h.par;
+    p->basis_par = basis->h.par;
+    p->basis = basis->h.par.dev;
+    p->k = (u32)glwe_dimension;
+    if (chunk == 0) {  // about 1 GiB of digit polynomials, at least 128 ciphertexts
+        const size_t per_ct = (size_t)(glwe_dimension + 1) * p->basis.ell * t->L * t->n * sizeof(u32);
+        chunk = std::max<size_t>(128, std::min<size_t>(65536, ((size_t)1 << 30) / per_ct));
+    }
+    p->chunk = chunk;
+    p->digits_words = p->chunk * (p->k + 1) * p->basis.ell * t->L * t->n;
+    DeviceGuard g(t->device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    void *d = nullptr;
+    PFHE_HIP(counted_malloc(&d, p->digits_words * sizeof(u32)));
+    p->digits = (u32 *)d;
+    PFHE_HIP(hipEventCreateWithFlags(&p->last_done, hipEventDisableTiming));
+    *out = p.release();
+    return PFHE_OK;
+    PFHE_GUARD_END
+}
+
+void pfhe_extprod32_plan_destroy(pfhe_extprod32_plan *p) { delete p; }
+int pfhe_extprod32_plan_in_use(const pfhe_extprod32_plan *p) {
+    return p && p->owner.load(std::memory_order_acquire) != 0 ? 1 : 0;
+}
+size_t pfhe_extprod32_plan_scratch_bytes(const pfhe_extprod32_plan *p) { return p ? p->digits_words * sizeof(u32) : 0; }
+
+int pfhe_extprod32_mul_dcrt_ggsw_to_dev(pfhe_extprod32_plan *plan, const uint32_t *crt_glwe_dev, size_t len_glwe,
+                                        const uint32_t *dcrt_ggsw_dev, size_t len_ggsw, uint32_t *result_dev,
+                                        size_t len_result, int into_coeff_form, void *stream) {
+    PFHE_GUARD_BEGIN
+    PFHE_TRY(plan32_check(plan));
+    PFHE_PLAN_LEASE(plan);
+    const TableSet &t = *plan->table;
+    const size_t W = (size_t)t.L * t.n, glwe = (plan->k + 1) * W;
+    const size_t ggsw = (size_t)(plan->k + 1) * plan->basis.ell * glwe;
+    if (len_glwe % glwe != 0 || len_result != len_glwe || (len_ggsw != ggsw && len_ggsw != len_glwe / glwe * ggsw)) {
+        set_last_error("external product: glwe/result must be batch*(k+1)*L*N words and the GGSW one or batch "
+                       "ciphertexts of (k+1)*ell*(k+1)*L*N words");
+        return PFHE_ERR_BAD_LENGTH;
+    }
+    const u64 batch = len_glwe / glwe;
+    if (batch == 0) return PFHE_OK;
+    if (!crt_glwe_dev || !dcrt_ggsw_dev || !result_dev) return PFHE_ERR_BAD_ARGUMENT;
+    PFHE_REQUIRE_ALIGNED(crt_glwe_dev);
+    PFHE_REQUIRE_ALIGNED(dcrt_ggsw_dev);
+    PFHE_REQUIRE_ALIGNED(result_dev);
+    DeviceGuard g(t.device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    // result.set_zero() (glwe/crt.rs:217) is implied: the multiply-accumulate overwrites
+    PFHE_TRY(run_product32(plan, crt_glwe_dev, plan->k + 1, dcrt_ggsw_dev, len_ggsw == ggsw, result_dev, batch, false,
+                           (hipStream_t)stream, false));
+    if (into_coeff_form)  // DcrtGlwe::into_coeff_form, macros/mod.rs:901-911
+        PFHE_TRY(ntt32_transform_dev(t.primes_dev, t.L, t.log_n, result_dev, batch * (plan->k + 1) * t.L, true, false,
+                                     (hipStream_t)stream, t.tune));
+    return PFHE_OK;
+    PFHE_GUARD_END
+}
+
+int pfhe_extprod32_mul_dcrt_ggsw_to(pfhe_extprod32_plan *plan, const uint32_t *crt_glwe, size_t len_glwe,
+                                    const uint32_t *dcrt_ggsw, size_t len_ggsw, uint32_t *result, size_t len_result,
+                                    int into_coeff_form) {
+    PFHE_GUARD_BEGIN
+    PFHE_TRY(plan32_check(plan));
+    PFHE_PLAN_LEASE(plan);
+    if ((!crt_glwe || !dcrt_ggsw || !result) && len_glwe) return PFHE_ERR_BAD_ARGUMENT;
+    DeviceGuard g(plan->table->device);
+    if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    HostStage st(plan->table->device);
+    if (!st.ok()) return PFHE_ERR_HIP;
+    void *a = nullptr, *k = nullptr, *r = nullptr;
+    PFHE_TRY(st.upload(crt_glwe, len_glwe * sizeof(u32), &a));
+    PFHE_TRY(st.upload(dcrt_ggsw, len_ggsw * sizeof(u32), &k));
+    PFHE_TRY(st.alloc(len_result * sizeof(u32), &r));
+    PFHE_TRY(pfhe_extprod32_mul_dcrt_ggsw_to_dev(plan, (const uint32_t *)a, len_glwe, (const uint32_t *)k, len_ggsw,
+                                                 (uint32_t *)r, len_result, into_coeff_form, st.stream()));
+    PFHE_TRY(st.download(result, r, len_result * sizeof(u32)));
+    return st.finish();
+    PFHE_GUARD_END
+}
+
+int pfhe_extprod32_add_dcrt_glev_mul_crt_poly_assign_dev(pfhe_extprod32_plan *plan, uint32_t *acc_dev, size_t len_acc,
+                                                         const uint32_t *dcrt_glev_dev, size_t len_glev,
+                                                         const uint32_t *crt_poly_dev, size_t len_poly, void *stream) {
+    PFHE_GUARD_BEGIN
+    return glev32_common(plan, acc_dev, len_acc, dcrt_glev_dev, len_glev, crt_poly_dev, len_poly, true, false, stream);
+    PFHE_GUARD_END
+}
+
+int pfhe_extprod32_glev_mul_crt_poly_to_dev(pfhe_extprod32_plan *plan, const uint32_t *dcrt_glev_dev, size_t len_glev,
+                                            const uint32_t *crt_poly_dev, size_t len_poly, uint32_t *result_dev,
+                                            size_t len_result, void *stream) {
+    PFHE_GUARD_BEGIN
+    return glev32_common(plan, result_dev, len_result, dcrt_glev_dev, len_glev, crt_poly_dev, len_poly, false, false, stream);
+    PFHE_GUARD_END
+}
+
+int pfhe_extprod32_add_dcrt_glev_mul_big_uint_poly_assign_dev(pfhe_extprod32_plan *plan, uint32_t *acc_dev, size_t len_acc,
+                                                              const uint32_t *dcrt_glev_dev, size_t len_glev,
+                                                              const uint32_t *big_uint_poly_dev, size_t len_poly,
+                                                              void *stream) {
+    PFHE_GUARD_BEGIN
+    return glev32_common(plan, acc_dev, len_acc, dcrt_glev_dev, len_glev, big_uint_poly_dev, len_poly, true, true, stream);
+    PFHE_GUARD_END
+}
+
+int pfhe_extprod32_glev_mul_big_uint_poly_to_dev(pfhe_extprod32_plan *plan, const uint32_t *dcrt_glev_dev, size_t len_glev,
+                                                 const uint32_t *big_uint_poly_dev, size_t len_poly, uint32_t *result_dev,
+                                                 size_t len_result, void *stream) {
+    PFHE_GUARD_BEGIN
+    return glev32_common(plan, result_dev, len_result, dcrt_glev_dev, len_glev, big_uint_poly_dev, len_poly, false, true,
+                         stream);
     PFHE_GUARD_END
 }
 

@@ -139,35 +139,6 @@ __global__ __launch_bounds__(kThreads) void exact_convert_kernel(CT C, const u64
     out[c] = sub_mod(dot, vq, C.p_out(0));
 }
 
-// value mod q_i by Horner over the limbs, most significant first; every step reduces hi:lo < q*2^64
-__global__ __launch_bounds__(kThreads) void decompose_big_kernel(ConvDev C, u32 value_len,
-                                                                 const u64 *__restrict__ values,
-                                                                 u64 *__restrict__ multi, u64 count) {
-    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= count) return;
-    u64 v[kMaxLimbs];
-    for (u32 k = 0; k < value_len; ++k) v[k] = values[c * value_len + k];
-    for (u32 j = 0; j < C.lout; ++j) {
-        u64 r = 0;
-        for (u32 k = value_len; k-- > 0;) r = barrett_reduce128(v[k], r, C.p[j], C.mu_lo[j], C.mu_hi[j]);
-        multi[(u64)j * count + c] = r;
-    }
-}
-// the same for a wide base: the limbs are re-read per modulus (a thread's value_len words stay in its cache lines)
-__global__ __launch_bounds__(kThreads) void decompose_big_wide_kernel(RnsWide R, const u64 *__restrict__ values,
-                                                                      u64 *__restrict__ multi, u64 count) {
-    const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= count) return;
-    const u32 value_len = R.value_len;
-    const u64 *__restrict__ v = values + c * value_len;
-    for (u32 j = 0; j < R.L; ++j) {
-        const u64 p = R.modulus(j), lo = R.ratio_lo(j), hi = R.ratio_hi(j);
-        u64 r = 0;
-        for (u32 k = value_len; k-- > 0;) r = barrett_reduce128(v[k], r, p, lo, hi);
-        multi[(u64)j * count + c] = r;
-    }
-}
-
 void barrett_ratio(u64 q, u64 &lo, u64 &hi) {
     unsigned __int128 rem = 1;
     unsigned __int128 c1 = rem << 64;
@@ -400,54 +371,6 @@ int pfhe_conv_exact_convert_array(const pfhe_conv *c, const uint64_t *crt_poly_i
                                   uint64_t *crt_poly_out, size_t len_out, size_t poly_length) {
     PFHE_GUARD_BEGIN
     return conv_host(c, crt_poly_in, len_in, crt_poly_out, len_out, poly_length, true);
-    PFHE_GUARD_END
-}
-
-int pfhe_rns_decompose_big_uint_values_to_dev(const pfhe_rns *r, const uint64_t *big_uint_values_dev, size_t len_in,
-                                              uint64_t *multi_residues_dev, size_t len_out, size_t value_count,
-                                              void *stream) {
-    PFHE_GUARD_BEGIN
-    if (!r || ((!big_uint_values_dev || !multi_residues_dev) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
-    const RnsDev &R = r->h.par.dev;
-    if (len_in != value_count * R.value_len || len_out != value_count * R.L) return PFHE_ERR_BAD_LENGTH;
-    if (value_count == 0) return PFHE_OK;
-    DeviceGuard g(r->h.device);
-    if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    if (r->h.par.wide()) {
-        hipLaunchKernelGGL(decompose_big_wide_kernel, dim3(grid_for(value_count)), dim3(kThreads), 0, (hipStream_t)stream,
-                           r->h.par.wide_tab, (const u64 *)big_uint_values_dev, (u64 *)multi_residues_dev, (u64)value_count);
-    } else {
-        ConvDev c{};
-        c.lout = R.L;
-        for (u32 j = 0; j < R.L; ++j) {
-            c.p[j] = R.q[j];
-            barrett_ratio(R.q[j], c.mu_lo[j], c.mu_hi[j]);
-        }
-        hipLaunchKernelGGL(decompose_big_kernel, dim3(grid_for(value_count)), dim3(kThreads), 0, (hipStream_t)stream, c,
-                           R.value_len, (const u64 *)big_uint_values_dev, (u64 *)multi_residues_dev, (u64)value_count);
-    }
-    PFHE_HIP(hipGetLastError());
-    return PFHE_OK;
-    PFHE_GUARD_END
-}
-
-int pfhe_rns_decompose_big_uint_values_to(const pfhe_rns *r, const uint64_t *big_uint_values, size_t len_in,
-                                          uint64_t *multi_residues, size_t len_out, size_t value_count) {
-    PFHE_GUARD_BEGIN
-    if (!r || ((!big_uint_values || !multi_residues) && value_count)) return PFHE_ERR_BAD_ARGUMENT;
-    if (len_in != value_count * r->h.par.dev.value_len || len_out != value_count * r->h.par.dev.L) return PFHE_ERR_BAD_LENGTH;
-    if (value_count == 0) return PFHE_OK;
-    DeviceGuard g(r->h.device);
-    if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    HostStage st(r->h.device);
-    if (!st.ok()) return PFHE_ERR_HIP;
-    void *din = nullptr, *dout = nullptr;
-    PFHE_TRY(st.upload(big_uint_values, len_in * 8, &din));
-    PFHE_TRY(st.alloc(len_out * 8, &dout));
-    PFHE_TRY(pfhe_rns_decompose_big_uint_values_to_dev(r, (const uint64_t *)din, len_in, (uint64_t *)dout, len_out,
-                                                       value_count, st.stream()));
-    PFHE_TRY(st.download(multi_residues, dout, len_out * 8));
-    return st.finish();
     PFHE_GUARD_END
 }
 

@@ -22,7 +22,10 @@ struct RnsDev {
     u32 L, value_len;
     // 1: the decomposition kernels read their input as big integers (value_len limbs per coefficient,
     // coefficient-major: BigUintPolynomial) instead of composing it from L residues (CrtPolynomial)
-    u32 big_input, pad_;
+    u32 big_input;
+    // words of a big integer in the CALLER's word type: value_len for RNSBase<u64>; for RNSBase<u32> (pfhe_rns32: the same
+    // constants, 32-bit residues and limbs in memory) the number of u32 limbs of Q, 2 * value_len or one less
+    u32 value_words;
     u64 q[kMaxLimbs];
     u64 inv_punct[kMaxLimbs], inv_punct_p[kMaxLimbs];  // (Q/q_i)^-1 mod q_i and its Shoup quotient
     u64 punct[kMaxLimbs][kMaxLimbs];                    // Q/q_i, little-endian limbs
@@ -46,7 +49,7 @@ struct RnsDev {
 // value_len computes with zero top limbs).
 struct RnsWide {
     u32 L, value_len;
-    u32 big_input, pad_;
+    u32 big_input, value_words;
     const u64 *tab;
     static constexpr u32 W = kMaxWideLimbs;
     static constexpr u32 garner = 0;
@@ -65,6 +68,7 @@ struct BasisCore {
     u32 value_len, ell, log_basis, drop_bits;
     u32 mode;  // bit0: extract initial carry, bit1: adjust values >= threshold
     u32 carry_index;
+    u32 value_words, pad_;  // as RnsDev::value_words
     u64 carry_bit_mask;
     u64 basis, basis_minus_one, carry_mask;
 };
@@ -103,6 +107,7 @@ struct BasisParams {
 
 struct RnsHost {
     int device = 0;
+    u32 word_bits = 64;  // width of the caller's words (see RnsDev::value_words)
     RnsParams par;
     // host copies, any width: moduli; Q and every Q/q_i as value_len little-endian limbs; (Q/q_i)^-1 mod q_i + quotient
     std::vector<u64> moduli, Q, punct, inv_punct, inv_punct_p;
@@ -111,6 +116,7 @@ struct RnsHost {
 
 struct BasisHost {
     int device = 0;
+    u32 word_bits = 64;
     BasisParams par;
     RnsParams rns;
     std::vector<u64> Q;                // of the base it was built from (basis.rs:52)
@@ -119,36 +125,52 @@ struct BasisHost {
     std::vector<u64> scalars_residue;  // ell * L
 };
 
-int build_rns(const u64 *moduli, size_t count, RnsHost &out);
+// word_bits: 64 (RNSBase<u64>: moduli below 2^62) or 32 (RNSBase<u32>: below 2^30, BarrettModulus<u32>)
+int build_rns(const u64 *moduli, size_t count, RnsHost &out, u32 word_bits = 64);
 int build_basis(const RnsHost &rns, u32 log_basis, size_t reverse_length, BasisHost &out);
 // device tables of the wide forms (no-ops for bases that fit the by-value form); `device` must be current
 int upload_rns_wide(RnsHost &r);
 int upload_basis_wide(BasisHost &b);
 
 // --- device launchers (pfhe_rns.hip); all pointers are device pointers ---
-int rns_compose_dev(const RnsParams &r, const u64 *multi_residues, u64 *big_uint_values, u64 value_count,
-                    hipStream_t s);
-int rns_wrapping_decompose_dev(const RnsParams &r, const u64 *small_values, u64 *multi_residues, u64 value_count,
+// WT = u64 (RNSBase<u64>, BigUintApproxSignedBasis<u64>) or u32 (the <u32> instantiations of the same generics,
+// base.rs:26-37, big_integer/basis.rs:33): residues, digits and big-integer limbs are WT words in memory; the arithmetic
+// inside is the same (every result is a canonical integer, so the word width of the reference's arithmetic is not visible).
+template <class WT>
+int rns_compose_dev(const RnsParams &r, const WT *multi_residues, WT *big_uint_values, u64 value_count, hipStream_t s);
+template <class WT>
+int rns_wrapping_decompose_dev(const RnsParams &r, const WT *small_values, WT *multi_residues, u64 value_count,
                                u64 small_value_modulus, hipStream_t s);
-// acc += factor * lift(small) per modulus (centred lift unless !centred); factor_pairs: L host (value, quotient) pairs
-int rns_add_decompose_scaled_dev(const RnsParams &r, const u64 *small_values, u64 *acc, u64 value_count,
+// acc += factor * lift(small) per modulus (centred lift unless !centred); factor_pairs: L host (value, quotient) pairs of
+// 64-bit Shoup factors (quotient = floor(value * 2^64 / q))
+template <class WT>
+int rns_add_decompose_scaled_dev(const RnsParams &r, const WT *small_values, WT *acc, u64 value_count,
                                  u64 small_value_modulus, bool centred, const u64 *factor_pairs, hipStream_t s);
-int basis_init_value_carry_dev(const BasisParams &b, u64 *values, unsigned char *carries, u64 count, hipStream_t s);
-int basis_unsigned_decompose_dev(const BasisParams &b, u32 level, const u64 *values, u64 *digits,
+template <class WT>
+int rns_decompose_big_dev(const RnsParams &r, const WT *big_uint_values, WT *multi_residues, u64 value_count, hipStream_t s);
+template <class WT>
+int basis_init_value_carry_dev(const BasisParams &b, WT *values, unsigned char *carries, u64 count, hipStream_t s);
+template <class WT>
+int basis_unsigned_decompose_dev(const BasisParams &b, u32 level, const WT *values, WT *digits,
                                  unsigned char *carries, u64 count, hipStream_t s);
-// signed digits as residues modulo Q, value_len limbs each (common.rs:255-272, 289-306)
-int basis_signed_decompose_dev(const RnsParams &r, const BasisParams &b, u32 level, const u64 *values, u64 *decomposed,
+// signed digits as residues modulo Q, value_words limbs each (common.rs:255-272, 289-306)
+template <class WT>
+int basis_signed_decompose_dev(const RnsParams &r, const BasisParams &b, u32 level, const WT *values, WT *decomposed,
                                unsigned char *carries, u64 count, hipStream_t s);
 // Fused steps (1)-(4) of add_dcrt_glev_mul_crt_poly_assign (glwe/dcrt.rs:219-244) for `npolys` CRT
 // polynomials of L*N words: writes, per input polynomial, ell digit polynomials in CRT form
 // (centred lift), laid out [poly][level][limb][N].
-int gadget_decompose_dev(const RnsParams &r, const BasisParams &b, u32 log_n, const u64 *crt_polys, u64 *digits,
+template <class WT>
+int gadget_decompose_dev(const RnsParams &r, const BasisParams &b, u32 log_n, const WT *crt_polys, WT *digits,
                          u64 npolys, hipStream_t s);
 // result[e][c][r][t] = sum_{i,j} ggsw[(e)][i][j][c][r][t] * digits[e][i][j][r][t]  (mod q_r)
 // (steps (6) of glwe/dcrt.rs:248 summed over rows and levels, glwe/crt.rs:219-226).
 // accumulate != 0 adds into the existing result instead of overwriting it.
 int gadget_mulacc_dev(const NttPrime *primes, u32 L, u32 log_n, u32 k, u32 rows, u32 ell, const u64 *digits,
                       const u64 *ggsw, bool ggsw_shared, u64 *result, u64 batch, bool accumulate, hipStream_t s);
+// the same on u32 residues (primes: a U32DcrtTable's, q < 2^30, bar_lo = floor(2^64 / q))
+int gadget_mulacc32_dev(const NttPrime *primes, u32 L, u32 log_n, u32 k, u32 rows, u32 ell, const u32 *digits,
+                        const u32 *ggsw, bool ggsw_shared, u32 *result, u64 batch, bool accumulate, hipStream_t s);
 
 // Fused "last forward pass + multiply-accumulate" (pfhe_extprod.hip): `digits` must already have gone
 // through the strided passes of the forward transform.  Available for k = 1 and a 2^12 block pass.
@@ -178,7 +200,17 @@ int extprod_small_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u32 k
 
 }  // namespace pfhe
 
-// handle behind the C ABI's `pfhe_rns` (shared by pfhe_capi_rns.hip and pfhe_convert.hip)
+// handles behind the C ABI (shared by pfhe_capi_rns.hip and pfhe_convert.hip); the *32 ones are the <u32> instantiations
+// of the same reference generics: the same host structs with word_bits = 32
 struct pfhe_rns {
     pfhe::RnsHost h;
+};
+struct pfhe_rns32 {
+    pfhe::RnsHost h;
+};
+struct pfhe_basis {
+    pfhe::BasisHost h;
+};
+struct pfhe_basis32 {
+    pfhe::BasisHost h;
 };

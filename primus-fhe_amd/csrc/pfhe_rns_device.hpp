@@ -162,6 +162,56 @@ __device__ __forceinline__ u32 init_value_carry(const BT &B, u64 (&v)[LEN]) {
     return carry;
 }
 
+// ---- big integers in the caller's word type WT (u64, or u32 for the <u32> instantiations of the reference generics) ----
+// words per big integer as a kernel addresses memory: compile-time for by-value constants with 64-bit words
+template <int LEN, class WT, class CT>
+__device__ __forceinline__ u32 words_of(const CT &C) {
+    if constexpr (sizeof(WT) == 8 && kByValue<CT>) return (u32)LEN;
+    else if constexpr (sizeof(WT) == 8) return C.value_len;
+    else return C.value_words;
+}
+// v (LEN 64-bit limbs) <- the `words` WT words at p; limbs beyond them are zero
+template <int LEN, class WT>
+__device__ __forceinline__ void load_limbs(const WT *p, u32 words, u64 (&v)[LEN]) {
+#pragma unroll
+    for (int j = 0; j < LEN; ++j) {
+        if constexpr (sizeof(WT) == 8) {
+            v[j] = (u32)j < words ? p[j] : 0;
+        } else {
+            const u64 lo = (u32)(2 * j) < words ? p[2 * j] : 0u, hi = (u32)(2 * j + 1) < words ? p[2 * j + 1] : 0u;
+            v[j] = lo | (hi << 32);
+        }
+    }
+}
+template <int LEN, class WT>
+__device__ __forceinline__ void store_limbs(WT *p, u32 words, const u64 (&v)[LEN]) {
+#pragma unroll
+    for (int j = 0; j < LEN; ++j) {
+        if constexpr (sizeof(WT) == 8) {
+            if ((u32)j < words) p[j] = v[j];
+        } else {
+            if ((u32)(2 * j) < words) p[2 * j] = (WT)v[j];
+            if ((u32)(2 * j + 1) < words) p[2 * j + 1] = (WT)(v[j] >> 32);
+        }
+    }
+}
+// word j of the moduli product in the caller's word type
+template <class WT, class RT>
+__device__ __forceinline__ u64 product_word(const RT &R, u32 j) {
+    if constexpr (sizeof(WT) == 8) return R.product(j);
+    else return (R.product(j >> 1) >> (32u * (j & 1u))) & 0xffffffffull;
+}
+// window of log_basis bits starting at bit `start` of a big integer stored as WT words — common.rs:132-140
+// (log_basis < bits of WT, so the window spans at most two words)
+template <class WT>
+__device__ __forceinline__ u64 window_words(const WT *v, u32 start, u64 mask, u32 log_basis) {
+    constexpr u32 WB = 8 * sizeof(WT);
+    const u32 idx = start / WB, shr = start % WB;
+    u64 w = (u64)v[idx] >> shr;
+    if (shr + log_basis > WB) w |= (u64)v[idx + 1] << (WB - shr);
+    return w & mask;
+}
+
 // window of log_basis bits starting at bit `start` of the LEN-limb value — common.rs:132-140
 template <int LEN>
 __device__ __forceinline__ u64 window(const u64 (&v)[LEN], u32 start, u64 mask, u32 log_basis) {

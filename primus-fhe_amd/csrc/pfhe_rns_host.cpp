@@ -94,12 +94,12 @@ static u64 inv_mod(u64 a, u64 q) {
     return (u64)t;
 }
 
-int build_rns(const u64 *moduli, size_t count, RnsHost &out) {
+int build_rns(const u64 *moduli, size_t count, RnsHost &out, u32 word_bits) {
     if (count == 0) return PFHE_ERR_EMPTY_BASE;  // base.rs:47-49
     for (size_t i = 0; i < count; ++i) {
-        // BarrettModulus::new requires 1 < q < 2^62 (primus_modulus/src/barrett/mod.rs:39-44)
-        if (moduli[i] <= 1 || moduli[i] >= (1ull << 62)) {
-            set_last_error("RNS modulus must satisfy 1 < q < 2^62");
+        // BarrettModulus::<T>::new requires 1 < q < 2^(T::BITS - 2) (primus_modulus/src/barrett/mod.rs:39-44)
+        if (moduli[i] <= 1 || moduli[i] >= (1ull << (word_bits - 2))) {
+            set_last_error(word_bits == 64 ? "RNS modulus must satisfy 1 < q < 2^62" : "RNS modulus must satisfy 1 < q < 2^30");
             return PFHE_ERR_UNREPRESENTABLE_MODULUS;
         }
     }
@@ -135,6 +135,9 @@ int build_rns(const u64 *moduli, size_t count, RnsHost &out) {
     RnsDev d{};
     d.L = (u32)count;
     d.value_len = (u32)len;
+    // limbs of Q in the caller's word type (multiply_many_values, big_integer.rs:675-686: as many as Q needs)
+    d.value_words = word_bits == 64 ? (u32)len : (u32)(2 * len - ((Q[len - 1] >> 32) == 0 ? 1 : 0));
+    out.word_bits = word_bits;
     if (count <= (size_t)kMaxLimbs) {  // the by-value form; wider bases get their device table from upload_rns_wide
         for (size_t j = 0; j < len; ++j) d.Q[j] = Q[j];
         for (size_t i = 0; i < count; ++i) {
@@ -168,8 +171,8 @@ int build_rns(const u64 *moduli, size_t count, RnsHost &out) {
 
 int build_basis(const RnsHost &rns, u32 log_basis, size_t reverse_length, BasisHost &out) {
     const u32 len = rns.par.dev.value_len, L = rns.par.dev.L;
-    if (log_basis == 0 || log_basis >= 64) {  // basis.rs:51
-        set_last_error("log_basis must be in 1..63");
+    if (log_basis == 0 || log_basis >= rns.word_bits) {  // basis.rs:51: 0 < log_basis < T::BITS
+        set_last_error(rns.word_bits == 64 ? "log_basis must be in 1..63" : "log_basis must be in 1..31");
         return PFHE_ERR_BAD_ARGUMENT;
     }
     const Big &Q = rns.Q;
@@ -192,6 +195,7 @@ int build_basis(const RnsHost &rns, u32 log_basis, size_t reverse_length, BasisH
     const u64 B = 1ull << log_basis, bm1 = B - 1;
     BasisDev d{};
     d.value_len = len;
+    d.value_words = rns.par.dev.value_words;
     d.ell = (u32)ell;
     d.log_basis = log_basis;
     d.drop_bits = drop;
@@ -254,6 +258,7 @@ int build_basis(const RnsHost &rns, u32 log_basis, size_t reverse_length, BasisH
     out.rns = rns.par;
     out.Q = Q;
     out.device = rns.device;
+    out.word_bits = rns.word_bits;
     out.scalars.assign(ell * len, 0);
     out.scalars_residue.assign(ell * L, 0);
     Big s(len, 0);

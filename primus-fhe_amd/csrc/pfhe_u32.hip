@@ -355,6 +355,9 @@ struct pfhe_ntt32 {
 struct pfhe_dcrt32 {
     std::unique_ptr<TableSet> t;
 };
+namespace pfhe {
+const TableSet *capi_table32_of(const pfhe_dcrt32 *t) { return t->t.get(); }
+}  // namespace pfhe
 
 extern "C" {
 

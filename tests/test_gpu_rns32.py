@@ -1,0 +1,247 @@
+"""GPU parity of the <u32> instantiations — RNSBase<u32>, BigUintApproxSignedBasis<u32>, CrtGlwe<u32>::mul_dcrt_ggsw_to over
+U32DcrtTable (primus_rns/src/base.rs:26-37, primus_decompose/src/big_integer/basis.rs:33, primus_lattice/src/glwe/crt.rs:200-227,
+primus_ntt/src/dcrt/prime32.rs:11) — through the C ABI (pfhe_rns32_*, pfhe_basis32_*, pfhe_extprod32_*) against the
+oracle's 32-bit-limb restatement (oracle/pfhe_oracle_rns32.c), Python integers and the schoolbook product.
+
+The device code runs the 64-bit kernels with 32-bit words in memory; the oracle does 32-bit limb arithmetic throughout, so
+a disagreement in limb packing, limb count or word-straddling windows shows here.
+"""
+import numpy as np
+import pytest
+
+import pyref
+from primes import ntt_primes_below
+from pyref import crt_compose
+from test_gpu_u32 import to_dev32, to_host32
+from test_oracle_rns32 import Q30, REF_U32, int_to_limbs32, limbs32_to_int, rand32, shoup32
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pf():
+    import primus_fhe_amd as p
+    return p
+
+
+# L (narrow / wide), odd and even numbers of u32 limbs (value_len 2, 3, 1, 1, 5, 8, 15, 28)
+BASES = [REF_U32, Q30, Q30[:1], [97, 101, 103], ntt_primes_below(5, 30, 4), ntt_primes_below(9, 28, 4),
+         ntt_primes_below(16, 30, 4), ntt_primes_below(30, 30, 4)]
+
+
+def test_errors(pf):
+    with pytest.raises(pf.PfheError) as e:
+        pf.RNSBase32([])
+    assert e.value.kind == "EmptyBase"
+    with pytest.raises(pf.PfheError) as e:
+        pf.RNSBase32([21, 35])
+    assert e.value.kind == "CoPrimeError"
+    with pytest.raises(pf.PfheError) as e:
+        pf.RNSBase32([1 << 30, 97])          # BarrettModulus::<u32>::new (barrett/mod.rs:39-44)
+    assert e.value.kind == "UnrepresentableModulus"
+    base = pf.RNSBase32(Q30)
+    for lb in (0, 32):                       # basis.rs:51: 0 < log_basis < T::BITS
+        with pytest.raises(pf.PfheError) as e:
+            pf.BigUintApproxSignedBasis32(base, lb)
+        assert e.value.kind == "BadArgument"
+    with pytest.raises(TypeError):
+        base.compose_multiple_values_to(np.zeros(3, np.uint64), np.zeros(3, np.uint32), 1)
+    # B = 2^30 exceeds the moduli: fine for the basis, refused where the centred lift needs B < q_i (base.rs:288-292)
+    with pytest.raises(pf.PfheError) as e:
+        pf.DcrtGlevContext32(pf.U32DcrtTable(4, Q30), base, pf.BigUintApproxSignedBasis32(base, 30), 1)
+    assert e.value.kind == "BadArgument"
+
+
+@pytest.mark.parametrize("moduli", BASES, ids=lambda m: f"L{len(m)}_{m[0]}")
+@pytest.mark.parametrize("count", [1, 1000])
+def test_rns32_matches_oracle(pf, orc, moduli, count):
+    rng = np.random.default_rng(len(moduli) + count)
+    base, obase = pf.RNSBase32(moduli), orc.RNSBase32(moduli)
+    vl, L = base.big_uint_value_len(), len(moduli)
+    assert vl == obase.value_len and base.moduli_count() == L
+    assert np.array_equal(base.moduli_product(), obase.moduli_product)
+    res = rand32(rng, moduli, count)
+    res[0] = 0
+    for i, q in enumerate(moduli):
+        res[i * count + count - 1] = q - 1
+    out = np.empty(count * vl, np.uint32)
+    base.compose_multiple_values_to(res, out, count)
+    assert np.array_equal(out, obase.compose_multiple_values_to(res, count))
+    c = count // 2
+    assert limbs32_to_int(out[c * vl:(c + 1) * vl]) == crt_compose([int(res[i * count + c]) for i in range(L)], moduli)
+    back = np.empty_like(res)
+    base.decompose_big_uint_values_to(out, back, count)
+    assert np.array_equal(back, res)
+    dout, dback = to_dev32(np.zeros_like(out)), to_dev32(np.zeros_like(res))
+    base.compose_multiple_values_to_dev(to_dev32(res), dout, count)
+    base.decompose_big_uint_values_to_dev(dout, dback, count)
+    assert np.array_equal(to_host32(dout), out) and np.array_equal(to_host32(dback), res)
+    with pytest.raises(pf.PfheError) as e:
+        base.compose_multiple_values_to(res[:-1].copy(), out, count)
+    assert e.value.kind == "BadLength"
+    for sm in (2, 3, 16):
+        if sm >= min(moduli):
+            continue
+        small = rng.integers(0, sm, count, dtype=np.uint64).astype(np.uint32)
+        lifted = np.empty(L * count, np.uint32)
+        base.wrapping_decompose_small_values_to(small, lifted, count, sm)
+        assert np.array_equal(lifted, obase.wrapping_decompose_small_values_to(small, sm))
+        f = [shoup32(int(rng.integers(0, q)), q) for q in moduli]
+        acc = rand32(rng, moduli, count)
+        oacc = acc.copy()
+        base.add_wrapping_decompose_small_values_scaled(small, acc, count, sm, f)
+        obase.add_wrapping_decompose_small_values_scaled(small, oacc, sm, f)
+        assert np.array_equal(acc, oacc)
+        base.add_decompose_small_values_scaled(small, acc, count, f)
+        obase.add_decompose_small_values_scaled(small, oacc, f)
+        assert np.array_equal(acc, oacc)
+
+
+@pytest.mark.parametrize("moduli,log_basis,rev", [(REF_U32, 7, None), (REF_U32, 6, None), (Q30, 15, None), (Q30, 15, 4),
+                                                  (Q30, 29, None), (Q30, 1, None), (Q30, 31, 2), (Q30[:1], 10, None),
+                                                  (ntt_primes_below(9, 28, 4), 13, None), (ntt_primes_below(16, 30, 4), 20, 9),
+                                                  (ntt_primes_below(30, 30, 4), 31, None)])
+def test_basis32_steps_match_oracle(pf, orc, moduli, log_basis, rev):
+    rng = np.random.default_rng(log_basis + len(moduli))
+    base, obase = pf.RNSBase32(moduli), orc.RNSBase32(moduli)
+    basis, obasis = pf.BigUintApproxSignedBasis32(base, log_basis, rev), orc.BigUintApproxSignedBasis32(obase, log_basis, rev)
+    assert (basis.decompose_length(), basis.log_basis(), basis.drop_bits(), basis.basis_value()) == \
+        (obasis.decompose_length, obasis.log_basis, obasis.drop_bits, obasis.basis_value)
+    assert np.array_equal(basis.scalars(), obasis.scalars)
+    assert np.array_equal(basis.scalars_residue(), obasis.scalars_residue)
+    g = pyref.Gadget(moduli, log_basis, rev)
+    vl, n = base.big_uint_value_len(), 333
+    vals = [int.from_bytes(rng.bytes(4 * vl + 8), "little") % g.Q for _ in range(n)]
+    vals[:6] = [0, 1, g.Q - 1, g.Q // 2, (g.threshold or 1) - 1, g.threshold or 1]
+    values = np.concatenate([int_to_limbs32(v, vl) for v in vals])
+    ov = values.copy()
+    oc = obasis.init_value_carry_slice_inplace(ov, n)
+    gv, gc = values.copy(), np.zeros(n, np.uint8)
+    basis.init_value_carry_slice_inplace(gv, gc)
+    assert np.array_equal(gv, ov) and np.array_equal(gc, oc)
+    adj, c2 = np.empty_like(values), np.zeros(n, np.uint8)
+    basis.init_value_carry_slice_to(values, adj, c2)
+    assert np.array_equal(adj, ov) and np.array_equal(c2, oc)
+    for j in range(basis.decompose_length()):
+        sc = gc.copy()
+        sd = np.empty_like(gv)
+        basis.decompose_slice_to(j, gv, sd, sc)
+        assert np.array_equal(sd, obasis.decompose_slice_to(j, ov, oc.copy(), n)), j
+        od = obasis.unsigned_decompose_slice_to(j, ov, oc, n)
+        gd = np.empty(n, np.uint32)
+        basis.unsigned_decompose_slice_to(j, gv, gd, gc)
+        assert np.array_equal(gd, od) and np.array_equal(gc, oc) and np.array_equal(sc, gc), j
+        assert [int(x) for x in gd[:6]] == [g.unsigned_digits(v)[j] for v in vals[:6]]
+
+
+def make_case32(orc, rng, log_n, k, moduli, log_basis, rev, batch, shared):
+    n, L = 1 << log_n, len(moduli)
+    otable, obase = orc.U32DcrtTable(log_n, moduli), orc.RNSBase32(moduli)
+    obasis = orc.BigUintApproxSignedBasis32(obase, log_basis, rev)
+    ell = obasis.decompose_length
+    glwe = rand32(rng, moduli, n, batch * (k + 1))
+    ggsw = rand32(rng, moduli, n, (1 if shared else batch) * (k + 1) * ell * (k + 1))
+    G, K = (k + 1) * L * n, (k + 1) * ell * (k + 1) * L * n
+    exp = np.concatenate([orc.mul_dcrt32_ggsw_to(otable, obase, obasis, k, glwe[e * G:(e + 1) * G].copy(),
+                                                 ggsw[(0 if shared else e) * K:((0 if shared else e) + 1) * K].copy())
+                          for e in range(batch)])
+    return otable, obase, obasis, glwe, ggsw, exp
+
+
+@pytest.mark.parametrize("log_n,k,moduli,log_basis,rev,batch,shared,chunk", [
+    (3, 1, Q30, 15, None, 1, True, 0), (4, 1, Q30, 15, None, 5, True, 2), (4, 1, Q30, 15, None, 5, False, 3),
+    (6, 2, Q30[:2], 10, 3, 3, True, 1), (10, 1, REF_U32, 7, None, 2, False, 0), (12, 1, Q30, 15, None, 3, True, 2),
+    (13, 1, Q30, 13, None, 1, True, 0), (16, 1, Q30, 15, None, 2, False, 1), (15, 1, Q30, 29, None, 2, True, 0),
+    (11, 1, ntt_primes_below(9, 28, 11), 13, 6, 2, True, 0), (16, 1, ntt_primes_below(12, 30, 16), 20, 4, 1, True, 0),
+])
+def test_external_product32_matches_oracle(pf, orc, log_n, k, moduli, log_basis, rev, batch, shared, chunk):
+    rng = np.random.default_rng(log_n * 7 + batch)
+    otable, obase, obasis, glwe, ggsw, exp = make_case32(orc, rng, log_n, k, moduli, log_basis, rev, batch, shared)
+    table, base = pf.U32DcrtTable(log_n, moduli), pf.RNSBase32(moduli)
+    basis = pf.BigUintApproxSignedBasis32(base, log_basis, rev)
+    ctx = pf.DcrtGlevContext32(table, base, basis, k, chunk)
+    assert ctx.scratch_bytes() > 0 and not ctx.in_use()
+    out = np.empty_like(glwe)
+    pf.mul_dcrt_ggsw_to(glwe, ggsw, out, ctx)
+    assert np.array_equal(out, exp)
+    pf.mul_dcrt_ggsw_to(glwe, ggsw, out, ctx, into_coeff_form=True)
+    otable.inverse_transform_slice(exp)
+    assert np.array_equal(out, exp)
+    with pytest.raises(pf.PfheError) as e:
+        pf.mul_dcrt_ggsw_to(glwe, ggsw[:-1].copy(), out, ctx)
+    assert e.value.kind == "BadLength"
+    # GLev row forms: accumulate / overwrite, residues / big integers
+    n, L, ell = 1 << log_n, len(moduli), basis.decompose_length()
+    W = L * n
+    poly, glev = glwe[:W].copy(), ggsw[:ell * (k + 1) * W].copy()
+    acc0 = rand32(rng, moduli, n, k + 1)
+    oacc = acc0.copy()
+    orc.add_dcrt32_glev_mul_crt_poly_assign(otable, obase, obasis, k, oacc, glev, poly)
+    dacc = to_dev32(acc0)
+    pf.add_dcrt_glev_mul_crt_poly_assign_dev(dacc, to_dev32(glev), to_dev32(poly), ctx)
+    assert np.array_equal(to_host32(dacc), oacc)
+    big = np.empty(n * base.big_uint_value_len(), np.uint32)
+    base.compose_multiple_values_to(poly, big, n)
+    dacc2 = to_dev32(acc0)
+    pf.add_dcrt_glev_mul_big_uint_poly_assign_dev(dacc2, to_dev32(glev), to_dev32(big), ctx)
+    assert np.array_equal(to_host32(dacc2), oacc)
+    r1, r2 = to_dev32(np.zeros((k + 1) * W, np.uint32)), to_dev32(np.zeros((k + 1) * W, np.uint32))
+    pf.glev_mul_crt_poly_to_dev(to_dev32(glev), to_dev32(poly), r1, ctx)
+    pf.glev_mul_big_uint_poly_to_dev(to_dev32(glev), to_dev32(big), r2, ctx)
+    zero = np.zeros((k + 1) * W, np.uint32)
+    orc.add_dcrt32_glev_mul_crt_poly_assign(otable, obase, obasis, k, zero, glev, poly)
+    assert np.array_equal(to_host32(r1), zero) and np.array_equal(to_host32(r2), zero)
+
+
+def test_external_product32_equals_schoolbook(pf):
+    log_n, k, moduli, log_basis = 3, 1, Q30, 15
+    rng = np.random.default_rng(42)
+    n, L = 1 << log_n, 3
+    table, base = pf.U32DcrtTable(log_n, moduli), pf.RNSBase32(moduli)
+    basis = pf.BigUintApproxSignedBasis32(base, log_basis)
+    g = pyref.Gadget(moduli, log_basis)
+    ell = g.ell
+    assert ell == basis.decompose_length() == 6
+    glwe = rand32(rng, moduli, n, k + 1)
+    key_coeff = rand32(rng, moduli, n, (k + 1) * ell * (k + 1))
+    ggsw = key_coeff.copy()
+    table.transform_slice(ggsw)
+    ctx = pf.DcrtGlevContext32(table, base, basis, k)
+    out = np.empty_like(glwe)
+    pf.mul_dcrt_ggsw_to(glwe, ggsw, out, ctx, into_coeff_form=True)
+    exp = pyref.external_product_coeff(moduli, n, k, g, glwe.reshape(k + 1, L, n).tolist(),
+                                       key_coeff.reshape(k + 1, ell, k + 1, L, n).tolist())
+    assert out.reshape(k + 1, L, n).tolist() == exp
+
+
+def test_bench_shape_full_batch_every_ciphertext(pf, orc):
+    """The bench leg's shape (N = 2^16, three 30-bit primes, log B = 15 -> ell = 6, k = 1, batch 1024, one shared GGSW):
+    every one of the 1024 products against the oracle, one ciphertext per task on all host cores."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import torch
+    from gpu_util import usable_cores
+    log_n, k, batch = 16, 1, 1024
+    n, L = 1 << log_n, 3
+    table, base = pf.U32DcrtTable(log_n, Q30), pf.RNSBase32(Q30)
+    basis = pf.BigUintApproxSignedBasis32(base, 15)
+    ctx = pf.DcrtGlevContext32(table, base, basis, k)
+    G = ctx.glwe_len()
+    glwe = torch.empty(batch * G, dtype=torch.int32, device="cuda")
+    ggsw = torch.empty(ctx.ggsw_len(), dtype=torch.int32, device="cuda")
+    table.fill_uniform_dev(glwe, 0x5EED000000000432)
+    table.fill_uniform_dev(ggsw, 99)
+    out = torch.empty_like(glwe)
+    pf.mul_dcrt_ggsw_to_dev(glwe, ggsw, out, ctx)
+    torch.cuda.synchronize()
+    otable, obase = orc.U32DcrtTable(log_n, Q30), orc.RNSBase32(Q30)
+    obasis = orc.BigUintApproxSignedBasis32(obase, 15)
+    hk, hg, ho = to_host32(ggsw), to_host32(glwe), to_host32(out)
+
+    def one(e):
+        exp = orc.mul_dcrt32_ggsw_to(otable, obase, obasis, k, hg[e * G:(e + 1) * G], hk)
+        return bool(np.array_equal(ho[e * G:(e + 1) * G], exp))
+
+    with ThreadPoolExecutor(usable_cores()) as ex:
+        ok = list(ex.map(one, range(batch)))
+    assert all(ok), [e for e, v in enumerate(ok) if not v][:10]

@@ -524,10 +524,11 @@ def test_fused_kernel_threshold_switch(pf, orc, min_wgs, log_n, monkeypatch):
 
 def test_plan_has_one_holder_at_a_time(pf, orc):
     """`&mut DcrtGlevContext` (primus_lattice/src/context/glev.rs:4-10): the reference's borrow checker lets one caller hold
-    the product's scratch.  Here a second THREAD that calls into a plan while another is inside gets PFHE_ERR_BAD_ARGUMENT
-    ("plan in use") instead of racing on the digit buffers: thread A runs a long host-pointer product, thread B waits until
-    pfhe_extprod_plan_in_use reports the holder and calls — exactly one error, A's result bit-exact, and the plan works
-    for B afterwards (same thread may nest: the host-pointer entry calls the device one)."""
+    the product's scratch.  Here a second THREAD that calls into a plan while another holds it gets PFHE_ERR_BUSY ("plan in
+    use") instead of racing on the digit buffers.  Deterministic: thread A takes the plan exactly as an entry point does
+    (pfhe_extprod_plan_debug_hold) and keeps it while thread B calls — one refusal of the right kind, nothing written —
+    then releases it, and B's next call succeeds bit-exactly.  The same thread may nest (the host-pointer entry calls the
+    device one), and while a thread is INSIDE a real call a watcher sees the flag."""
     import threading
     log_n, k, batch = 14, 1, 12
     rng = np.random.default_rng(77)
@@ -537,52 +538,35 @@ def test_plan_has_one_holder_at_a_time(pf, orc):
     ctx = pf.DcrtGlevContext(table, base, basis, k, 2)       # 6 chunks: a long call
     lib = pf.lib()
     assert lib.pfhe_extprod_plan_in_use(ctx._h) == 0
-    out_a, out_b = np.empty_like(glwe), np.empty_like(glwe)
-    results = {}
+    held, release, results = threading.Event(), threading.Event(), {}
 
     def a():
-        try:
-            for _ in range(400):                              # back-to-back calls until B has been refused
-                pf.mul_dcrt_ggsw_to(glwe, ggsw, out_a, ctx)
-                if "b" in results:
-                    break
-            results["a"] = "ok"
-        except Exception as e:  # pragma: no cover
-            results["a"] = e
+        results["hold"] = lib.pfhe_extprod_plan_debug_hold(ctx._h, 1)
+        out_a = np.empty_like(glwe)
+        pf.mul_dcrt_ggsw_to(glwe, ggsw, out_a, ctx)          # the holder itself may call (nested entry)
+        results["a_ok"] = bool(np.array_equal(out_a, exp))
+        held.set()
+        release.wait(60)
+        results["release"] = lib.pfhe_extprod_plan_debug_hold(ctx._h, 0)
 
-    def b():
-        try:
-            slipped = 0
-            for _attempt in range(50):
-                for _ in range(5_000_000):
-                    if lib.pfhe_extprod_plan_in_use(ctx._h):
-                        break
-                else:  # pragma: no cover
-                    results["b"] = "never saw the holder"
-                    return
-                try:
-                    pf.mul_dcrt_ggsw_to(glwe, ggsw, out_b, ctx)
-                except pf.PfheError as e:
-                    results["b"] = e
-                    results["slipped"] = slipped
-                    return
-                # B arrived in the gap between two of A's calls: a legal, serial use — its result must be right; try again
-                if not np.array_equal(out_b, exp):
-                    results["b"] = "wrong result after a serial use"
-                    return
-                slipped += 1
-            results["b"] = "never refused"
-        except Exception as e:  # pragma: no cover
-            results["b"] = e
-
-    ta, tb = threading.Thread(target=a), threading.Thread(target=b)
-    ta.start(); tb.start(); ta.join(); tb.join()
-    assert results["a"] == "ok", results
-    assert np.array_equal(out_a, exp)                      # the holder's result: bit-exact
-    # exactly one refusal, of the right kind
-    assert isinstance(results["b"], pf.PfheError) and results["b"].kind == "BadArgument", results
-    assert "in use" in str(results["b"])
-    # deterministic half: while this thread is INSIDE a call the flag is up (seen from a watcher), and it is down after
+    ta = threading.Thread(target=a)
+    ta.start()
+    assert held.wait(60)
+    assert lib.pfhe_extprod_plan_in_use(ctx._h) == 1
+    out_b = np.full_like(glwe, 7)
+    with pytest.raises(pf.PfheError) as e:                   # this (main) thread is the second caller
+        pf.mul_dcrt_ggsw_to(glwe, ggsw, out_b, ctx)
+    assert e.value.kind == "Busy" and "in use" in str(e.value)
+    assert (out_b == 7).all()                                # refused before anything ran
+    assert lib.pfhe_extprod_plan_debug_hold(ctx._h, 1) == 38  # PFHE_ERR_BUSY for the hook too
+    assert lib.pfhe_extprod_plan_debug_hold(ctx._h, 0) == 33  # releasing what one does not hold: BAD_ARGUMENT
+    release.set()
+    ta.join()
+    assert results == {"hold": 0, "a_ok": True, "release": 0}
+    assert lib.pfhe_extprod_plan_in_use(ctx._h) == 0
+    pf.mul_dcrt_ggsw_to(glwe, ggsw, out_b, ctx)
+    assert np.array_equal(out_b, exp)
+    # while this thread is INSIDE a call the flag is up (seen from a watcher), and it is down after
     seen = []
     stop = threading.Event()
 
@@ -598,9 +582,10 @@ def test_plan_has_one_holder_at_a_time(pf, orc):
         pf.mul_dcrt_ggsw_to(glwe, ggsw, out_b, ctx)
         if seen:
             break
-    stop.set(); tw.join()
-    assert seen and lib.pfhe_extprod_plan_in_use(ctx._h) == 0
-    assert np.array_equal(out_b, exp)
+    stop.set()
+    tw.join()
+    assert seen, "the watcher never saw the holder flag during 20 host-pointer products"
+    assert lib.pfhe_extprod_plan_in_use(ctx._h) == 0
 
 
 def test_plan_used_from_one_stream_after_another_is_ordered_by_the_library(pf, orc):
