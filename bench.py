@@ -267,6 +267,72 @@ def provenance(path: str, profiled: dict):
             "profile_matches_build": ok}, ok
 
 
+def oracle_pin() -> str:
+    """Whether anything executable ties the oracle to the reference's own binaries: tests/golden/reference_digests.json is
+    written by integration/emit_golden (cargo) on a host that has a Rust toolchain; until it is
+    committed every fixture under tests/golden is this repository's own output and parity stays "unpinned"."""
+    path = os.path.join(ROOT, "tests", "golden", "reference_digests.json")
+    if not os.path.exists(path):
+        return "unpinned (tests/golden/reference_digests.json absent: no Rust toolchain has run integration/emit_golden yet)"
+    try:
+        d = json.load(open(path))
+        return "pinned to the reference's binaries (tests/golden/reference_digests.json: %d cases, reference rev %s)" % (
+            len(d.get("cases", [])), d.get("reference_rev", "?"))
+    except Exception as e:
+        return "unpinned (tests/golden/reference_digests.json unreadable: %s)" % str(e)[:80]
+
+
+def profile_traffic(name: str, want: dict):
+    """HBM bytes per launch of the kernels named `name` whose template arguments match `want` ({position: text}) in the
+    newest committed counter profile (profiles/*_rocprof.json: 2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes of
+    tools/profile_ntt.py), averaged over the launches profiled — reported only when every such kernel has, in the library
+    being timed, the machine code the counters were taken on (provenance); None when no profile covers it."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof.json")), reverse=True):
+        try:
+            rows = json.load(open(path))["kernels"]
+        except Exception:
+            continue
+        sel = []
+        for r in rows:
+            k = r["kernel"]
+            if not k.startswith(name + "<") or r.get("hbm_bytes_per_launch") is None or not r.get("launches"):
+                continue
+            targs = [a.strip() for a in k[k.index("<") + 1:k.rindex(">")].split(",")]
+            if all(i < len(targs) and targs[i] == v for i, v in want.items()):
+                sel.append(r)
+        if not sel:
+            continue
+        launches = sum(r["launches"] for r in sel)
+        prov, ok = provenance(path, {r["kernel"]: r.get("code_sha256") for r in sel})
+        return {"bytes_per_launch": sum(r["hbm_bytes_per_launch"] * r["launches"] for r in sel) / launches if ok else None,
+                "source": os.path.basename(path), "provenance": prov, "profiled_grids": sorted({r["grid_size"] for r in sel}),
+                "method": "2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes (MI355X_MICROARCH.md, HBM), averaged over the "
+                          "%d launches profiled" % launches}
+    return None
+
+
+def leg_roofline(kernel: str, launches: int, ms_per_batch: float, alg_bytes_per_batch: float, traffic, copy_gbs=None,
+                 note: str | None = None):
+    """The roofline object of one leg: the kernel (or form) that runs it, HIP-event / wall time per launch, SURVEY 8d's
+    algorithmic bytes per launch, the fraction of the 8 TB/s figure and of the copy rate measured in this run, and the
+    HBM bytes per launch from the committed counter profile when its code hash matches the library being timed."""
+    avg_ms = ms_per_batch / max(1, launches)
+    achieved = alg_bytes_per_batch / (ms_per_batch * 1e-3) / 1e9
+    out = {"bound": "hbm", "kernel": kernel, "launches_per_batch": launches, "avg_launch_ms": avg_ms,
+           "algorithmic_bytes_per_launch": alg_bytes_per_batch / max(1, launches), "achieved": achieved,
+           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "peak_measured": copy_gbs, "frac_of_measured": achieved / copy_gbs if copy_gbs else None,
+           "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_unit": "bytes per launch",
+           "traffic_source": ("from committed profile " + traffic["source"] + ": " + traffic["method"]) if traffic else None,
+           "traffic_provenance": traffic["provenance"] if traffic else None}
+    if traffic and traffic["bytes_per_launch"]:
+        out["traffic_vs_algorithmic"] = traffic["bytes_per_launch"] / out["algorithmic_bytes_per_launch"]
+    if note:
+        out["note"] = note
+    return out
+
+
 def extprod_traffic():
     """Whole-product HBM bytes per external product from the newest committed counter passes
     (profiles/*_extprod_traffic.json, written by tools/collect_profiles2.py) — or None when there is none, or when the
@@ -437,6 +503,37 @@ def main():
     mods = np.array(Q61, np.uint64)
     from primus_fhe_amd.shard import fill_job_shard, timed_steps
 
+    # "also report against a measured device-copy bandwidth" — one device-to-device copy of half the resident
+    # buffer into the other half (3 GiB read + 3 GiB written at the default batch), by the runtime's copy, by torch's
+    # element-wise copy kernel and by the library's 16-bytes-per-lane non-temporal copy kernel, HIP events on the launch
+    # stream; the best one is `peak_measured`
+    copy_bw = None
+    if rank == 0 and not args.dump_dir and words >= (1 << 24):
+        half = (words // 2) & ~1
+        src, dst = x[:half], x[half:2 * half]
+        st = torch.cuda.current_stream()
+
+        def timed_copy(fn, reps=6):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(reps):
+                fn()
+            e1.record(st)
+            e1.synchronize()
+            return 2 * half * 8 / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9
+
+        rt = timed_copy(lambda: check(p.lib().pfhe_memcpy_d2d(local_rank, C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()),
+                                                               half * 8, C.c_void_p(st.cuda_stream))))
+        tk = timed_copy(lambda: dst.copy_(src))
+        # this library's own streaming shape: one 16-byte vector per thread, non-temporal loads and stores
+        sk = timed_copy(lambda: check(p.lib().pfhe_stream_copy_dev(local_rank, C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()),
+                                                                    half * 8, C.c_void_p(st.cuda_stream))))
+        copy_bw = {"GBps": max(rt, tk, sk), "hipMemcpyDtoDAsync_GBps": rt, "torch_copy_kernel_GBps": tk,
+                   "stream_copy_kernel_16B_per_lane_nontemporal_GBps": sk,
+                   "bytes_moved_per_copy": 2 * half * 8, "method": "read + written bytes / HIP-event time, 6 copies back to back"}
+    copy_gbs = copy_bw["GBps"] if copy_bw else None
+
     # rank r owns RNS polynomials [r*batch, (r+1)*batch) of a job of world*batch: its input depends on the position
     # in the job only, so the union over ranks is the same job whatever the world size
     fill_job_shard(p.lib(), local_rank, x.data_ptr(), rank * batch, batch, L * n, Q61, n, SEED_NTT)
@@ -458,7 +555,13 @@ def main():
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "BASELINE configs[2] shape: N=2^16, 3-prime RNS (61-bit), batch=%d per GPU, "
                                "forward DCRT NTT in place (config 3')" % batch,
-                   "log_n": LOG_N, "moduli": Q61, "batch_per_gpu": batch, "sharding": "batch, no collectives"},
+                   "log_n": LOG_N, "moduli": Q61, "batch_per_gpu": batch, "sharding": "batch, no collectives",
+                   # the headline rate is specific to this shape of prime: q = 2^K - c with c < 2^(K-33) takes the
+                   # pseudo-Mersenne butterflies (csrc/pfhe_ntt_device.hpp PmArith); any other q < 2^61 the Montgomery-form
+                   # ones — `roofline_generic` below is that rate on the same data
+                   "prime_shape": "pseudo-Mersenne (q = 2^61 - c, c < 2^28: every prime of SURVEY 8c's 61-bit triple)"},
+        "oracle_pin": oracle_pin(),
+        "device_copy": copy_bw,
         "hbm_roofline_frac": value * 16 * n / world / (HBM_PEAK_GBS * 1e9),
         # torch.distributed's own view: backend, world size, and every rank's device (PCI address, UUID) gathered over the
         # group; without a process group (one rank) the one device this process used
@@ -514,6 +617,7 @@ def main():
                 "algorithmic_bytes_per_batch": alg_bytes_ep,
                 "achieved": alg_bytes_ep / dte / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": alg_bytes_ep / dte / 1e9 / HBM_PEAK_GBS,
+                "peak_measured": copy_gbs, "frac_of_measured": alg_bytes_ep / dte / 1e9 / copy_gbs if copy_gbs else None,
                 # the dominant KERNEL on the bytes the two-pass plan makes it move (transformed digits in + result out): a
                 # statement about that kernel under this plan, not about the product
                 "kernel_compulsory_bytes": dom_bytes,
@@ -596,6 +700,7 @@ def main():
                       "traffic_source": ("from committed profile " + pmc["source"] + ": " + pmc["method"]) if pmc else None,
                       "traffic_provenance": pmc["provenance"] if pmc else None,
                       "avg_launch_ms": dom[1], "algorithmic_bytes_per_launch": alg_bytes,
+                      "peak_measured": copy_gbs, "frac_of_measured": achieved / copy_gbs if copy_gbs else None,
                       "note": "fraction of the HBM roofline as the metric asks; the kernel's own limit is the "
                               "integer ALU and its LDS / twiddle traffic (profiles/r02_*), not HBM"}
         result["kernels_ms"] = {k: v for k, v in per_pass}
@@ -625,6 +730,7 @@ def main():
                                   "traffic_provenance": pmc_p["provenance"] if pmc_p else None,
                                   "avg_launch_ms": ms_launch, "launches_per_step": launches,
                                   "algorithmic_bytes_per_launch": alg_bytes / launches,
+                                  "peak_measured": copy_gbs, "frac_of_measured": achieved_p / copy_gbs if copy_gbs else None,
                                   "note": "the step's only kernel; it moves every coefficient twice (two-pass plan), so "
                                           "its HBM floor is 2x the algorithmic bytes; it runs AT the 1400 W package power cap "
                                           "with the shader clock throttled to ~1.9 GHz (profiles/r02_power_probe.txt); "
@@ -665,8 +771,12 @@ def main():
 
         reps = max(3, args.steps)
         ms_inv = time_ms(lambda: table.inverse_transform_dev(x), reps)
+        form_i, launches_i = table.transform_form(words, inverse=True)
         result["intt"] = {"value": batch * L / ms_inv * 1e3, "unit": "NTT/s (inverse limb-NTTs, N=2^16, 3 primes)",
-                          "ms_per_batch": ms_inv, "hbm_roofline_frac": batch * L / ms_inv * 1e3 * 16 * n / (HBM_PEAK_GBS * 1e9)}
+                          "ms_per_batch": ms_inv, "hbm_roofline_frac": batch * L / ms_inv * 1e3 * 16 * n / (HBM_PEAK_GBS * 1e9),
+                          "roofline": leg_roofline(form_i + "<PmArith, 12, false>", launches_i, ms_inv, 16 * n * batch * L,
+                                                   profile_traffic("ntt_pipe_inv_kernel", {0: "PmArith", 2: "false"})
+                                                   if form_i.startswith("ntt_pipe_") else None, copy_gbs)}
         check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(x.data_ptr()), words, mods.ctypes.data_as(u64p), L, n, 6, None))
         # ---- the generic-prime path on the same data: what any q < 2^61 that is not of pseudo-Mersenne shape gets
         #      (MontArith: one-word Montgomery product, 7 multiplies); and the reference's own Shoup scheme (10 multiplies),
@@ -686,6 +796,12 @@ def main():
             "value": batch * L / ms_sh * 1e3, "unit": "NTT/s (forward limb-NTTs, MontArith: any q < 2^61)",
             "ms_per_batch": ms_sh, "inverse_ms_per_batch": ms_shi, "shoup_form_ms_per_batch": ms_s10,
             "hbm_roofline_frac": batch * L / ms_sh * 1e3 * 16 * n / (HBM_PEAK_GBS * 1e9)}
+        form_g, launches_g = table_shoup.transform_form(words)
+        result["roofline_generic"] = leg_roofline(
+            form_g + "<MontArith, 12>", launches_g, ms_sh, 16 * n * batch * L,
+            profile_traffic("ntt_pipe_fwd_kernel", {0: "MontArith"}) if form_g.startswith("ntt_pipe_") else None, copy_gbs,
+            "the headline step on the same data through the arithmetic any q < 2^61 that is NOT of pseudo-Mersenne shape "
+            "gets (Montgomery-form butterflies, 7 multiplies against 6): the shape dependence of `roofline.frac`")
         del table_shoup10
         del table_shoup
         check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(x.data_ptr()), words, mods.ctypes.data_as(u64p), L, n, 5, None))
@@ -697,13 +813,20 @@ def main():
         check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(x14.data_ptr()), b14 * n14, m14.ctypes.data_as(u64p), 1, n14, 14, None))
         ms14 = time_ms(lambda: t14.transform_dev(x14), 4 * reps)
         ms14i = time_ms(lambda: t14.inverse_transform_dev(x14), 4 * reps)
+        d14 = p.U64DcrtTable(14, Q61[:1], device=local_rank)  # the same kernels behind the DCRT handle: names the form
+        f14, l14 = d14.transform_form(b14 * n14)
+        f14i, l14i = d14.transform_form(b14 * n14, inverse=True)
+        pk = lambda inv: profile_traffic("ntt_persist_kernel", {0: "PmArith", 1: "14", 2: "true" if inv else "false"})
         result["ntt_2p14"] = {
             "workload": "BASELINE configs[1]: N=2^14, q=%d, batch=%d, in place" % (Q61[0], b14),
             "forward": {"value": b14 / ms14 * 1e3, "unit": "NTT/s", "ms_per_batch": ms14,
-                        "hbm_roofline_frac": b14 / ms14 * 1e3 * 16 * n14 / (HBM_PEAK_GBS * 1e9)},
+                        "hbm_roofline_frac": b14 / ms14 * 1e3 * 16 * n14 / (HBM_PEAK_GBS * 1e9),
+                        "roofline": leg_roofline(f14, l14, ms14, 16 * n14 * b14, pk(False) if "persist" in f14 else None, copy_gbs,
+                                                 "single pass: every coefficient read once and written once")},
             "inverse": {"value": b14 / ms14i * 1e3, "unit": "NTT/s", "ms_per_batch": ms14i,
-                        "hbm_roofline_frac": b14 / ms14i * 1e3 * 16 * n14 / (HBM_PEAK_GBS * 1e9)}}
-        del t14
+                        "hbm_roofline_frac": b14 / ms14i * 1e3 * 16 * n14 / (HBM_PEAK_GBS * 1e9),
+                        "roofline": leg_roofline(f14i, l14i, ms14i, 16 * n14 * b14, pk(True) if "persist" in f14i else None, copy_gbs)}}
+        del t14, d14
         check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(x.data_ptr()), words, mods.ctypes.data_as(u64p), L, n, 5, None))
         # ---- config 3: fused NTT -> pointwise mul (shared multiplicand) -> INTT ----
         bhat = torch.empty(L * n, dtype=torch.int64, device="cuda")
@@ -718,7 +841,28 @@ def main():
         torch.cuda.synchronize()
         dtp = (time.perf_counter() - t0) / reps
         result["polymul"] = {"value": batch / dtp, "unit": "RNS polynomial products/s (NTT+mul+INTT, shared multiplicand)",
-                             "ms_per_batch": dtp * 1e3, "hbm_roofline_frac": batch / dtp * 48 * n / (HBM_PEAK_GBS * 1e9)}
+                             "ms_per_batch": dtp * 1e3, "hbm_roofline_frac": batch / dtp * 48 * n / (HBM_PEAK_GBS * 1e9),
+                             "algorithmic_bytes_per_product": 48 * n,
+                             "roofline": leg_roofline("ntt_pipe_fwd_kernel + ntt_pipe_mid_kernel + ntt_pipe_inv_kernel (strided | "
+                                                      "block-product-block | strided)", 1, dtp * 1e3, 48 * n * batch, None, copy_gbs)}
+        # BASELINE.md's primary form of config 3: a PER-ELEMENT multiplicand (rlwe/crt.rs:42-65) — read a 24N + read b-hat
+        # 24N + write 24N = 72 N bytes per product; a second resident operand of the batch's size
+        bfull = torch.empty(words, dtype=torch.int64, device="cuda")
+        check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(bfull.data_ptr()), words, mods.ctypes.data_as(u64p), L, n, 78, None))
+        table.mul_dcrt_polynomial_dev(x, bfull)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            table.mul_dcrt_polynomial_dev(x, bfull)
+        torch.cuda.synchronize()
+        dtq = (time.perf_counter() - t0) / reps
+        result["polymul_per_element"] = {
+            "value": batch / dtq, "unit": "RNS polynomial products/s (NTT+mul+INTT, one multiplicand per element)",
+            "ms_per_batch": dtq * 1e3, "hbm_roofline_frac": batch / dtq * 72 * n / (HBM_PEAK_GBS * 1e9),
+            "algorithmic_bytes_per_product": 72 * n,
+            "roofline": leg_roofline("ntt_pipe_fwd_kernel + ntt_pipe_mid_kernel + ntt_pipe_inv_kernel", 1, dtq * 1e3,
+                                     72 * n * batch, None, copy_gbs)}
+        del bfull
         # ---- §8f rank 1: the u32 / low-q tables at the same shape (N=2^16, three 30-bit primes) ----
         q30 = [1073479681, 1071513601, 1070727169]
         t32 = p.U32DcrtTable(LOG_N, q30, device=local_rank)
@@ -733,11 +877,41 @@ def main():
         torch.cuda.synchronize()
         dt32 = (time.perf_counter() - t0) / reps
         ms32i = time_ms(lambda: t32.inverse_transform_dev(x32), reps)   # (pipelined form from 1 GiB of data, round 5)
+        f32, l32 = t32.transform_form(words)          # pipelined form from 1 GiB of data: tiles of 512 MiB + 1 launches
+        f32i, l32i = t32.transform_form(words, inverse=True)
         result["ntt_u32"] = {"value": batch * L / dt32, "unit": "NTT/s (forward limb-NTTs, u32 data, 30-bit primes)",
                              "ms_per_batch": dt32 * 1e3, "moduli": q30,
                              "hbm_roofline_frac": batch * L / dt32 * 8 * n / (HBM_PEAK_GBS * 1e9),
+                             "roofline": leg_roofline(f32 + "<B32Arith, 11>", l32, dt32 * 1e3, 8 * n * batch * L,
+                                                      profile_traffic("ntt_pipe_fwd_kernel", {0: "B32Arith"}), copy_gbs),
                              "inverse": {"value": batch * L / ms32i * 1e3, "unit": "NTT/s", "ms_per_batch": ms32i,
-                                         "hbm_roofline_frac": batch * L / ms32i * 1e3 * 8 * n / (HBM_PEAK_GBS * 1e9)}}
+                                         "hbm_roofline_frac": batch * L / ms32i * 1e3 * 8 * n / (HBM_PEAK_GBS * 1e9),
+                                         "roofline": leg_roofline(f32i + "<B32Arith, 11, false>", l32i, ms32i, 8 * n * batch * L,
+                                                                  profile_traffic("ntt_pipe_inv_kernel", {0: "B32Arith", 2: "false"}),
+                                                                  copy_gbs)}}
+        # ---- the <u32> external product (CrtGlwe<u32> x DcrtGgsw over U32DcrtTable): three 30-bit primes, log B = 15 ->
+        #      ell = 6, k = 1, batch 1024, one shared GGSW; algorithmic bytes = CrtGlwe in (24 N) + DcrtGlwe out (24 N) ----
+        base32 = p.RNSBase32(q30, device=local_rank)
+        basis32 = p.BigUintApproxSignedBasis32(base32, 15)
+        ctx32 = p.DcrtGlevContext32(t32, base32, basis32, 1)
+        eb32 = min(args.ext_batch, batch)
+        g32 = x32[:eb32 * 2 * L * n]
+        t32.fill_uniform_dev(g32, 0x5EED000000000432)
+        k32 = torch.empty(ctx32.ggsw_len(), dtype=torch.int32, device="cuda")
+        t32.fill_uniform_dev(k32, 99)
+        o32 = torch.empty_like(g32)
+        ms_ep32 = time_ms(lambda: p.mul_dcrt_ggsw_to_dev(g32, k32, o32, ctx32, into_coeff_form=True), max(2, args.steps // 3))
+        alg32 = 48 * n * eb32
+        result["external_product_u32"] = {
+            "value": eb32 / ms_ep32 * 1e3, "unit": "RLWE external products/s (CrtGlwe<u32> x DcrtGgsw over U32DcrtTable -> "
+                                                     "coefficient form)",
+            "batch": eb32, "ms_per_batch": ms_ep32, "moduli": q30, "gadget": {"log_basis": 15, "ell": basis32.decompose_length(), "k": 1},
+            "algorithmic_bytes_per_product": 48 * n, "hbm_roofline_frac": alg32 / (ms_ep32 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "roofline": leg_roofline("gadget_decompose_kernel<u32> + ntt_pipe_fwd_kernel<B32Arith, 11> + gadget_mulacc32_kernel + "
+                                     "inverse transform of the result", 1, ms_ep32, alg32, None, copy_gbs,
+                                     "unfused plan: the 36 lifted digit polynomials (u32) are written, transformed in place "
+                                     "and read back by the multiply-accumulate kernel")}
+        del k32, o32, ctx32
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
 

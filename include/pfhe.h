@@ -72,6 +72,9 @@ int pfhe_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t byte
 int pfhe_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes, void *stream);
 int pfhe_memcpy_d2d(int device, void *dst_dev, const void *src_dev, size_t bytes, void *stream);
 int pfhe_memset_dev(int device, void *dst_dev, int byte, size_t bytes, void *stream);
+/* Measurement aid (bench.py `device_copy`): a copy by a kernel of the element-wise family's launch shape — one 16-byte vector
+ * per thread, non-temporal loads and stores; `bytes` a multiple of 16, both pointers 16-byte aligned, ranges disjoint. */
+int pfhe_stream_copy_dev(int device, void *dst_dev, const void *src_dev, size_t bytes, void *stream);
 int pfhe_stream_synchronize(int device, void *stream);
 /* Host-pointer entry points (`*_slice`, `*_to` without `_dev`) behave like the reference's `&self, &mut [T]` methods
  * (table.rs:541-563: in place, no allocation per call): each call borrows a staging context — private streams, cached
@@ -79,7 +82,7 @@ int pfhe_stream_synchronize(int device, void *stream);
  * nothing and any number of threads may call through one handle concurrently (NttTable: Send + Sync).
  * pfhe_debug_alloc_count: device / pinned allocation and free calls the library has made since it was loaded (a
  * steady-state loop must not move it).  pfhe_staging_release: frees the idle contexts of `device` (-1: all devices),
- * returns their number (at most PFHE_STAGE_IDLE_MAX, default 4, are kept per device anyway).
+ * returns their number (at most four are kept per device anyway).
  * pfhe_debug_stage_path_count(which): host-pointer calls that took path `which` since the library was loaded —
  * 0 kernels on pinned memory the caller ALLOCATED (hipHostMalloc, a torch pinned tensor), 1 kernels on the pool's own pinned
  * buffer (pageable slices, and since round 5 slices the caller merely REGISTERED with hipHostRegister: kernels running on a
@@ -603,6 +606,8 @@ int pfhe_dcrt32_fill_uniform_dev(const pfhe_dcrt32 *table, uint32_t *dst_dev, si
 /* profiling hooks (one kernel launch per pass), as pfhe_dcrt_transform_pass_dev */
 int pfhe_dcrt32_transform_num_passes(const pfhe_dcrt32 *table);
 const char *pfhe_dcrt32_transform_pass_name(const pfhe_dcrt32 *table, int inverse, int index);
+/* as pfhe_dcrt_transform_form: the kernel (or form) a transform of `len` words runs as, and its number of launches */
+int pfhe_dcrt32_transform_form(const pfhe_dcrt32 *table, size_t len, int inverse, char *name, size_t cap, int *launches);
 int pfhe_dcrt32_transform_pass_dev(const pfhe_dcrt32 *table, uint32_t *poly_dev, size_t len,
                                    int inverse, int index, int lazy, void *stream);
 

@@ -13,7 +13,8 @@
 //!   * `RNSBase::compose_multiple_values_to`                crates/primus_rns/src/base.rs:648-675
 //!   * `BigUintApproxSignedBasis` balanced digits           crates/primus_decompose/src/big_integer/basis.rs:326-367,
 //!                                                          big_integer/common.rs:275-325
-//!   * `CrtGlwe::mul_dcrt_ggsw_to`                          crates/primus_lattice/src/glwe/crt.rs:200-227
+//!   * `CrtGlwe::mul_dcrt_ggsw_to`                          crates/primus_lattice/src/glwe/crt.rs:200-227 (u64, and u32 over U32DcrtTable)
+//!   * `BaseConverter::fast_convert_array` / `exact_convert_array`   crates/primus_rns/src/converter.rs:192-218, 274-364 (nine -> three moduli)
 //! — for every case of tests/golden/digests.json (and the u32 / RNS-gadget digest cases), and writes
 //! tests/golden/reference_digests.json: the same entries (same field names, SHA-256 of the little-endian output words)
 //! plus `"source": "primus-fhe @ <git rev>"`.  tests/test_reference_goldens.py then requires the oracle (CPU suite) and the
@@ -29,13 +30,18 @@ use primus_lattice::context::DcrtGlevContext;
 use primus_lattice::ggsw::DcrtGgsw;
 use primus_lattice::glwe::{CrtGlwe, DcrtGlwe};
 use primus_modulus::BarrettModulus;
-use primus_ntt::{DcrtTable, NttTable, U32NttTable, U64DcrtTable, U64NttTable};
+use primus_ntt::{DcrtTable, NttTable, U32DcrtTable, U32NttTable, U64DcrtTable, U64NttTable};
 use primus_poly::DcrtPolynomial;
-use primus_rns::RNSBase;
+use primus_rns::{BaseConverter, RNSBase};
 
 pub const SEED_BASE: u64 = 0x5EED_0000_0000_0000;
 pub const Q62: u64 = 4611686018425815041;
 pub const Q61: [u64; 3] = [2305843009211596801, 2305843009210023937, 2305843009208713217];
+// round 6: a base of NINE moduli (the nine largest primes below 2^61 that are 1 mod 32: tests/primes.py::ntt_primes_below(9, 61, 4)),
+// the three largest such primes below 2^60 as a conversion target, and the u32 tables' 30-bit triple
+pub const W9: [u64; 9] = [2305843009213693921, 2305843009213693153, 2305843009213692737, 2305843009213692097, 2305843009213691041, 2305843009213690657, 2305843009213689601, 2305843009213689377, 2305843009213689089];
+pub const Q60: [u64; 3] = [1152921504606845473, 1152921504606844513, 1152921504606844417];
+pub const Q30: [u32; 3] = [1073479681, 1071513601, 1070727169];
 
 // ---------------------------------------------------------------------------------------------------------------
 // tests/golden_inputs.py restated
@@ -301,6 +307,100 @@ pub fn emit_to(out_path: &str, rev: &str) {
             basis.decompose_length(),
             basis.drop_bits(),
             digest_u64(&all_digits)
+        ));
+    }
+
+    // ---- round 6, wide base (nine moduli): kinds "rns_compose" / "gadget_digits" case 2 on W9, and kind "base_convert":
+    //      BaseConverter::fast_convert_array W9 -> Q60 (converter.rs:192-218) and exact_convert_array W9 -> Q60[0]
+    //      (converter.rs:274-364) of the same residues
+    for (wid, &(log_basis, count)) in [(30u32, 2048usize)].iter().enumerate() {
+        let cid = wid + 2;
+        let moduli: Vec<BarrettModulus<u64>> = W9.iter().map(|&q| BarrettModulus::new(q)).collect();
+        let base = RNSBase::<u64, BarrettModulus<u64>>::new(&moduli).expect("RNS base of nine moduli");
+        let value_len = base.big_uint_value_len();
+        let seed = 0x300 + 0x40 + cid as u64;
+        let residues = splitmix_rns(seed, &W9, count, 1);
+        let mut values = vec![0u64; count * value_len];
+        let mut scratch = vec![0u64; base.moduli_count()];
+        base.compose_multiple_values_to(&residues, &mut values, count, &mut scratch);
+        digests.push(format!(
+            "{{\"kind\": \"rns_compose\", \"case\": {cid}, \"moduli\": {}, \"count\": {count}, \"seed\": {seed}, \
+             \"output_sha256\": \"{}\"}}",
+            strs(&W9),
+            digest_u64(&values)
+        ));
+        let basis = BigUintApproxSignedBasis::<u64>::new(base.moduli_product(), log_basis, None, &base);
+        let mut carries = vec![false; count];
+        basis.init_value_carry_slice_inplace(&mut values, &mut carries, value_len);
+        let mut all_digits: Vec<u64> = Vec::with_capacity(count * basis.decompose_length());
+        let mut level = vec![0u64; count];
+        for decomposer in basis.decomposer_iter() {
+            decomposer.unsigned_decompose_slice_to(&values, &mut level, &mut carries, value_len);
+            all_digits.extend_from_slice(&level);
+        }
+        digests.push(format!(
+            "{{\"kind\": \"gadget_digits\", \"case\": {cid}, \"moduli\": {}, \"log_basis\": {log_basis}, \"count\": {count}, \
+             \"seed\": {seed}, \"decompose_length\": {}, \"drop_bits\": {}, \"output_sha256\": \"{}\"}}",
+            strs(&W9),
+            basis.decompose_length(),
+            basis.drop_bits(),
+            digest_u64(&all_digits)
+        ));
+        let out_moduli: Vec<BarrettModulus<u64>> = Q60.iter().map(|&q| BarrettModulus::new(q)).collect();
+        let out_base = RNSBase::<u64, BarrettModulus<u64>>::new(&out_moduli).expect("output base");
+        let conv = BaseConverter::new(&base, &out_base);
+        let mut fast = vec![0u64; count * Q60.len()];
+        let mut conv_scratch = vec![0u64; count * W9.len()];
+        conv.fast_convert_array(&residues, &mut fast, count, &mut conv_scratch);
+        let one_base = RNSBase::<u64, BarrettModulus<u64>>::new(&out_moduli[..1]).expect("one-modulus base");
+        let exact_conv = BaseConverter::new(&base, &one_base);
+        let mut exact = vec![0u64; count];
+        exact_conv.exact_convert_array(&residues, &mut exact, count);
+        fast.extend_from_slice(&exact);
+        digests.push(format!(
+            "{{\"kind\": \"base_convert\", \"case\": 0, \"moduli\": {}, \"moduli_out\": {}, \"count\": {count}, \"seed\": {seed}, \
+             \"output_sha256\": \"{}\"}}",
+            strs(&W9),
+            strs(&Q60),
+            digest_u64(&fast)
+        ));
+    }
+
+    // ---- round 6, kind "external_product32": CrtGlwe::<u32>::mul_dcrt_ggsw_to over U32DcrtTable (dcrt/prime32.rs:11) with
+    //      RNSBase<u32, BarrettModulus<u32>> and BigUintApproxSignedBasis<u32>; inputs are the u64 streams narrowed to u32
+    for (cid32, &(log_n, k, log_basis, batch)) in [(10u32, 1usize, 15u32, 2usize)].iter().enumerate() {
+        let cid = cid32;
+        let n = 1usize << log_n;
+        let q30_wide: Vec<u64> = Q30.iter().map(|&q| q as u64).collect();
+        let moduli: Vec<BarrettModulus<u32>> = Q30.iter().map(|&q| BarrettModulus::new(q)).collect();
+        let table = U32DcrtTable::new(log_n, &moduli).expect("u32 DCRT table");
+        let base = RNSBase::<u32, BarrettModulus<u32>>::new(&moduli).expect("u32 RNS base");
+        let basis = BigUintApproxSignedBasis::<u32>::new(base.moduli_product(), log_basis, None, &base);
+        let ell = basis.decompose_length();
+        let crt_len = table.crt_poly_length();
+        let glwe_len = (k + 1) * crt_len;
+        let (seed_glwe, seed_ggsw) = (0x720 + cid as u64, 0x730 + cid as u64);
+        let glwe: Vec<u32> = splitmix_rns(seed_glwe, &q30_wide, n, batch * (k + 1)).into_iter().map(|v| v as u32).collect();
+        let ggsw: Vec<u32> = splitmix_rns(seed_ggsw, &q30_wide, n, (k + 1) * ell * (k + 1)).into_iter().map(|v| v as u32).collect();
+        let mut context =
+            DcrtGlevContext::<u32>::new(n, crt_len, n * base.big_uint_value_len(), base.moduli_count());
+        let mut result = vec![0u32; batch * glwe_len];
+        for (ct, out) in glwe.chunks_exact(glwe_len).zip(result.chunks_exact_mut(glwe_len)) {
+            CrtGlwe(ct).mul_dcrt_ggsw_to(
+                &DcrtGgsw(&ggsw[..]),
+                &mut DcrtGlwe(&mut out[..]),
+                &basis,
+                &table,
+                &base,
+                &mut context,
+            );
+        }
+        digests.push(format!(
+            "{{\"kind\": \"external_product32\", \"case\": {cid}, \"log_n\": {log_n}, \"k\": {k}, \"moduli\": {}, \
+             \"log_basis\": {log_basis}, \"batch\": {batch}, \"seed_glwe\": {seed_glwe}, \"seed_ggsw\": {seed_ggsw}, \
+             \"output_sha256\": \"{}\"}}",
+            strs(&q30_wide),
+            digest_u32(&result)
         ));
     }
 

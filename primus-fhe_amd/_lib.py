@@ -58,6 +58,7 @@ def _declare(lib: C.CDLL) -> None:
     sig("pfhe_memcpy_d2h", ci, ci, vp, vp, sz, vp)
     sig("pfhe_memcpy_d2d", ci, ci, vp, vp, sz, vp)
     sig("pfhe_memset_dev", ci, ci, vp, ci, sz, vp)
+    sig("pfhe_stream_copy_dev", ci, ci, vp, vp, sz, vp)
     sig("pfhe_stream_synchronize", ci, ci, vp)
     sig("pfhe_debug_alloc_count", u64)
     sig("pfhe_debug_stage_path_count", u64, ci)
@@ -211,6 +212,7 @@ def _declare(lib: C.CDLL) -> None:
     sig("pfhe_dcrt32_transform_num_passes", ci, vp)
     sig("pfhe_dcrt32_transform_pass_name", C.c_char_p, vp, ci, ci)
     sig("pfhe_dcrt32_transform_pass_dev", ci, vp, vp, sz, ci, ci, ci, vp)
+    sig("pfhe_dcrt32_transform_form", ci, vp, sz, ci, C.c_char_p, sz, C.POINTER(ci))
 
 
 def lib() -> C.CDLL:

@@ -34,11 +34,16 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
     return e == hipErrorNoDevice || e == hipErrorInvalidDevice ? PFHE_ERR_NO_DEVICE : PFHE_ERR_HIP;
 }
 
+static thread_local int g_guard_depth = 0;
+
 DeviceGuard::DeviceGuard(int device) {
     // hipGetLastError() is per host thread and sticky: an error the CALLER's own earlier HIP call left behind (a refused
     // hipHostRegister, say) would otherwise be reported by the first launch check of this entry point as if a kernel of
-    // this library had failed (found by tools/hazard_suite_probe.sh, round 5).  Every entry point starts from a clean slate.
-    (void)hipGetLastError();
+    // this library had failed (found by tools/hazard_suite_probe.sh, round 5).  Every entry point starts from a clean slate —
+    // the OUTERMOST guard of a call only: entry points call one another (host-pointer forms call the device ones), and a
+    // nested guard must not swallow the error of a launch this library queued a moment earlier.  (The caller's stale code
+    // is consumed; include/pfhe.h says so: check your own HIP calls' return values.)
+    if (g_guard_depth++ == 0) (void)hipGetLastError();
     if (hipGetDevice(&prev) != hipSuccess) {
         prev = -1;
         (void)hipGetLastError();
@@ -47,6 +52,7 @@ DeviceGuard::DeviceGuard(int device) {
     if (!ok) (void)hipGetLastError();
 }
 DeviceGuard::~DeviceGuard() {
+    --g_guard_depth;
     if (prev >= 0) (void)hipSetDevice(prev);
 }
 
@@ -89,9 +95,6 @@ int make_table_set(u32 log_n, const u64 *moduli, size_t count, int device, std::
     ts->L = (u32)count;
     ts->primes.resize(count);
     ts->tune = NttTuning::from_env();
-    ts->fused_polymul = std::getenv("PFHE_DISABLE_FUSED_POLYMUL") == nullptr;
-    ts->fused_polymul_mid = std::getenv("PFHE_DISABLE_POLYMUL_MID") == nullptr;
-    ts->monomial_inplace = std::getenv("PFHE_DISABLE_MONOMIAL_INPLACE") == nullptr;
     const size_t bytes = ts->n * sizeof(ulonglong2);
     bool all_pm = std::getenv("PFHE_DISABLE_PM") == nullptr;  // tuning switch: force the generic path
     bool all_mont = std::getenv("PFHE_DISABLE_MONT") == nullptr;  // tuning switch: generic primes keep the Shoup transforms
@@ -304,7 +307,7 @@ int transform_host(const TableSet &t, u64 *host, size_t len, bool inverse, bool 
     // one copies in: the slice is cut into up to eight pieces of at least 6 MiB; this thread, piece by piece, copies in and
     // launches the transform on the context's first stream and records an event; the helper waits for each event and copies
     // that piece back on the second stream.  16 RNS polynomials of 2^16: 0.95 -> 0.79 ms, 64: 3.67 -> 2.54 ms
-    // (tools/perf_host_slice.py).  PFHE_STAGE_THREADS=0: one thread.
+    // (tools/perf_host_slice.py).
     // Two rules keep the two threads apart.  (1) The helper sleeps on a condition variable until a piece is ready — no
     // spinning beside the copying thread.  (2) Adjacent pieces share the page that holds their common boundary (slices are
     // 8-byte aligned, not page aligned), and the runtime pins the caller's pages for the duration of a pageable copy: the
@@ -991,7 +994,7 @@ int pfhe_dcrt_mul_dcrt_polynomial_dev(const pfhe_dcrt *table, uint64_t *crt_poly
         set_last_error("multiplicand must have the same length or exactly one polynomial");
         return PFHE_ERR_BAD_LENGTH;
     }
-    if (len != 0 && t.fused_polymul && t.fused_polymul_mid) {
+    if (len != 0) {
         // forward block pass -> product -> inverse block pass in one kernel, between the strided passes
         DeviceGuard g(t.device);
         if (!g.ok) return PFHE_ERR_NO_DEVICE;
@@ -1000,8 +1003,8 @@ int pfhe_dcrt_mul_dcrt_polynomial_dev(const pfhe_dcrt *table, uint64_t *crt_poly
         if (rc != PFHE_ERR_UNSUPPORTED) return rc;
     }
     PFHE_TRY(transform_dev(t, (u64 *)crt_poly_dev, len, false, false, (hipStream_t)stream));
-    if (t.log_n >= 4 && len != 0 && t.fused_polymul) {
-        // the pointwise product rides on the loads of the inverse transform's first pass
+    if (t.log_n >= 4 && len != 0) {
+        // shapes the fused kernel does not cover: the pointwise product rides on the loads of the inverse transform's first pass
         DeviceGuard g(t.device);
         if (!g.ok) return PFHE_ERR_NO_DEVICE;
         return ntt_inverse_mul_dev(t.primes_dev, t.L, t.log_n, t.ntt_arith, (u64 *)crt_poly_dev, len / t.n,

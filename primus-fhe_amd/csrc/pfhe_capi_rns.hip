@@ -34,38 +34,28 @@ struct pfhe_extprod_plan {
     BasisCore basis{};  // the scalar constants of basis_par
     u32 k = 1;
     size_t chunk = 1;
-    // digit buffer(s) of chunk * (k+1) * ell * L * N words.  Chunks run one after the other on the caller's stream
-    // (every kernel of the product is bound by the same integer ALU: 20.4 ms per 1024 products at N = 2^16 against
-    // 20.9 ms for the software pipeline).  PFHE_EXTPROD_PIPELINE=1 at plan creation restores that pipeline: a
-    // second buffer, decomposition + strided pass of chunk c+1 on stream `sa` beside the transform +
-    // multiply-accumulate of chunk c on stream `sb`.
-    bool pipeline = false;
-    // PFHE_DISABLE_SMALL_EXTPROD / _FUSED_EXTPROD / _FUSED_DECOMPOSE, read at plan creation
-    bool use_small = true, use_fused = true, use_fused_decompose = true;
-    bool use_fused_tail = true;  // PFHE_DISABLE_FUSED_TAIL clears it (the parity tests compare both forms)
-    u64 fused_min_wgs = 160;     // workgroups a call must offer before the fused block + multiply-accumulate kernel is taken (PFHE_FUSED_MIN_WGS; N = 2^16, 3 limbs, coefficient form: 1 / 2 / 4 / 5 ciphertexts take 97 / 121 / 165 / 190 us unfused and 141 / 144 / 158 / 164 us fused)
+    // digit buffer of chunk * (k+1) * ell * L * N words.  Chunks run one after the other on the caller's stream (every
+    // kernel of the product is bound by the same integer ALU: a two-stream software pipeline over two buffers measured
+    // 20.9 ms per 1024 products at N = 2^16 against 20.4 ms in order, and is gone).
+    // PFHE_DISABLE_FUSED_EXTPROD, read at plan creation: the unfused transform + multiply-accumulate kernels (the form
+    // k > 1 takes) for every shape — the parity tests compare the two
+    bool use_fused = true;
+    // workgroups a call must offer before the fused block + multiply-accumulate kernel is taken (N = 2^16, 3 limbs,
+    // coefficient form: 1 / 2 / 4 / 5 ciphertexts take 97 / 121 / 165 / 190 us unfused and 141 / 144 / 158 / 164 us fused)
+    static constexpr u64 fused_min_wgs = 160;
     // measurement aid (pfhe_extprod_profile_dev): when non-null, run_product records an event before the
     // decomposition, between the decomposition and the transform / multiply-accumulate, and after it, per chunk
     std::vector<hipEvent_t> *prof = nullptr;
-    u64 *digits[2] = {nullptr, nullptr};
-    size_t digits_words = 0;  // per buffer
+    u64 *digits = nullptr;
+    size_t digits_words = 0;
     void *sdigits = nullptr;  // compact signed digits of one chunk (chunk * (k+1) * ell * N words of sdigit_bytes: int32 when log_basis <= 31, else int64), or null
     size_t sdigit_bytes = 0;
-    hipStream_t sa = nullptr, sb = nullptr;
-    hipEvent_t fork = nullptr, join_a = nullptr, join_b = nullptr;
-    hipEvent_t produced[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
     ~pfhe_extprod_plan() {
         if (!table) return;
         DeviceGuard g(table->device);
-        if (sa) (void)hipStreamSynchronize(sa);
-        if (sb) (void)hipStreamSynchronize(sb);
-        for (u64 *d : digits)
-            if (d) (void)counted_free(d);
+        if (digits) (void)counted_free(digits);
         if (sdigits) (void)counted_free(sdigits);
-        for (hipEvent_t e : {fork, join_a, join_b, produced[0], produced[1], consumed[0], consumed[1], last_done})
-            if (e) (void)hipEventDestroy(e);
-        if (sa) (void)hipStreamDestroy(sa);
-        if (sb) (void)hipStreamDestroy(sb);
+        if (last_done) (void)hipEventDestroy(last_done);
     }
 };
 
@@ -148,8 +138,7 @@ class PlanLease {
 
 // one row of the product: acc[e] += glev[e or shared] (x) crt_poly[e]   (glwe/dcrt.rs:178-255)
 // rows == k+1 without `accumulate` gives CrtGlwe::mul_dcrt_ggsw_to (glwe/crt.rs:200-227).
-// Chunks of ciphertexts run one after the other on the caller's stream, or (plan created under
-// PFHE_EXTPROD_PIPELINE) software-pipelined over the plan's two streams and two digit buffers.
+// Chunks of ciphertexts run one after the other on the caller's stream.
 // `into_coeff`: the caller wants coefficient-form output; *coeff_passes reports how many passes of the inverse
 // transform this function already ran on the result: -1 = all of them (small-ring kernel), 1 = the block pass
 // (fused into the multiply-accumulate kernel; the caller runs the remaining strided pass), 0 = none.
@@ -164,13 +153,11 @@ int run_product_impl(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const
     const u64 in_words = big_input ? (u64)rns.dev.value_len * t.n : W;  // words per input polynomial
     const u32 ell = p->basis.ell;
     const u64 key_words = (u64)rows * ell * (p->k + 1) * W;
-    // a single chunk has nothing to pipeline: run it on the caller's stream without the fork/join events
-    // (latency of small batches; also taken, chunk after chunk, while the caller captures a HIP graph); the fused block+multiply-accumulate kernel launches one workgroup per
-    // (ciphertext, limb, block), so it only pays once that fills the chip
-    // small rings: digit extraction + ONE kernel for everything else, chunk by chunk on the caller's stream
+    // Everything runs chunk after chunk on the caller's stream (also while the caller captures a HIP graph).
+    // small rings: digit extraction + ONE kernel for everything else
     // (one workgroup per (ciphertext, limb) runs 12+ transforms back to back: it needs a batch that fills the chip)
     if (p->sdigits != nullptr && extprod_small_supported(t.log_n, p->k, p->rns.dev.value_len, p->basis.log_basis) &&
-        batch * t.L >= 1024 && p->use_small) {
+        batch * t.L >= 1024 && p->use_fused) {
         for (u64 done = 0; done < batch; done += p->chunk) {
             const u64 cur = std::min<u64>(p->chunk, batch - done);
             PFHE_TRY(gadget_signed_digits_dev(rns, p->basis_par, t.log_n, crt_polys + done * rows * in_words, (int *)p->sdigits, cur * rows, s));
@@ -181,94 +168,52 @@ int run_product_impl(pfhe_extprod_plan *p, const u64 *crt_polys, u32 rows, const
         if (coeff_passes) *coeff_passes = into_coeff ? -1 : 0;
         return PFHE_OK;
     }
-    const bool single = !p->pipeline || batch <= p->chunk || stream_is_capturing(s);
-    hipStream_t sa = single ? s : p->sa, sb = single ? s : p->sb;
     const bool fused = gadget_fused_supported(t.log_n, p->k) && p->use_fused &&
                        ((std::min<u64>(batch, p->chunk) * t.L) << (t.log_n - 12)) >= p->fused_min_wgs;
     const int passes = ntt_num_passes(t.log_n, t.ntt_arith, t.tune);
     // One arithmetic for everything in here — the gadget kernels and the plain transform passes around them: the table's
-    // transform arithmetic t.ntt_arith (pseudo-Mersenne, Montgomery form for generic primes below 2^61 — round 4: the
-    // gadget kernels are instantiated for it too — or the reference's Shoup form).
+    // transform arithmetic t.ntt_arith (pseudo-Mersenne, Montgomery form for generic primes below 2^61, or the
+    // reference's Shoup form).
     // coefficient-form output: the inverse transform's block pass runs inside the fused kernel, on the accumulators
-    const bool inv_tail = fused && into_coeff && !accumulate && coeff_passes != nullptr && passes == 2 && p->use_fused_tail;
+    const bool inv_tail = fused && into_coeff && !accumulate && coeff_passes != nullptr && passes == 2;
     if (inv_tail) *coeff_passes = 1;
-    const bool fused_decompose = gadget_decompose_strided_supported(t.log_n, p->rns.dev.value_len) &&
-                                 p->use_fused_decompose && p->sdigits != nullptr;
-    if (!single) {
-        PFHE_HIP(hipEventRecord(p->fork, s));
-        PFHE_HIP(hipStreamWaitEvent(sa, p->fork, 0));
-        PFHE_HIP(hipStreamWaitEvent(sb, p->fork, 0));
-    }
-    // Software pipeline over chunks of ciphertexts, two digit buffers, two streams:
-    //   stream a (HBM-bound kernels): decomposition + strided passes of chunk c, then the
-    //            multiply-accumulate of chunk c-1 (unfused variant);
-    //   stream b (VALU-bound kernels): block pass of the transform (+ fused multiply-accumulate).
-    // The memory-bound and the ALU-bound workgroups co-reside on the CUs and hide each other.
-    u64 index = 0;
-    u64 prev_done = 0, prev_cur = 0;
-    auto issue_mulacc = [&](u64 idx, u64 done0, u64 cur0) -> int {
-        const int b0 = single ? 0 : (int)(idx & 1);
-        if (!single) PFHE_HIP(hipStreamWaitEvent(sa, p->consumed[b0], 0));
-        return gadget_mulacc_dev(t.primes_dev, t.L, t.log_n, p->k, rows, ell, p->digits[b0],
-                                 keys + (keys_shared ? 0 : done0 * key_words), keys_shared,
-                                 result + done0 * (p->k + 1) * W, cur0, accumulate, sa);
-    };
-    for (u64 done = 0; done < batch; done += p->chunk, ++index) {
+    const bool fused_decompose = gadget_decompose_strided_supported(t.log_n, p->rns.dev.value_len) && p->sdigits != nullptr;
+    u64 *dg = p->digits;
+    for (u64 done = 0; done < batch; done += p->chunk) {
         const u64 cur = std::min<u64>(p->chunk, batch - done);
-        const int buf = single ? 0 : (int)(index & 1);  // one stream: one buffer, reused in stream order
-        u64 *dg = p->digits[buf];
         const u64 npolys = cur * rows * ell * t.L;
-        const auto stamp = [&](hipStream_t st) -> int {
+        const auto stamp = [&]() -> int {
             if (p->prof == nullptr) return PFHE_OK;
             hipEvent_t ev = nullptr;
             PFHE_HIP(hipEventCreate(&ev));
             p->prof->push_back(ev);
-            PFHE_HIP(hipEventRecord(ev, st));
+            PFHE_HIP(hipEventRecord(ev, s));
             return PFHE_OK;
         };
-        PFHE_TRY(stamp(sa));
-        // ---- stream a: steps (1)-(4) + strided passes into digit buffer `buf` ----
-        if (fused && index >= 2 && !single) PFHE_HIP(hipStreamWaitEvent(sa, p->consumed[buf], 0));
+        PFHE_TRY(stamp());
+        // ---- steps (1)-(4) + strided passes into the digit buffer ----
         if (fused_decompose) {
             PFHE_TRY(gadget_decompose_strided_dev(rns, p->basis_par, t.primes_dev, t.log_n, t.ntt_arith,
-                                                  crt_polys + done * rows * in_words, dg, cur * rows, sa, p->sdigits));
+                                                  crt_polys + done * rows * in_words, dg, cur * rows, s, p->sdigits));
         } else {
-            PFHE_TRY(gadget_decompose_dev(rns, p->basis_par, t.log_n, crt_polys + done * rows * in_words, dg, cur * rows, sa));
+            PFHE_TRY(gadget_decompose_dev(rns, p->basis_par, t.log_n, crt_polys + done * rows * in_words, dg, cur * rows, s));
             for (int i = 0; i < passes - 1; ++i)
-                PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.ntt_arith, dg, npolys, false, i, false, sa, nullptr, 0, t.tune));
+                PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.ntt_arith, dg, npolys, false, i, false, s, nullptr, 0, t.tune));
         }
-        if (!single) PFHE_HIP(hipEventRecord(p->produced[buf], sa));
-        PFHE_TRY(stamp(sa));
-        // ---- stream b: block pass (last pass of the transform) ----
-        if (!single) PFHE_HIP(hipStreamWaitEvent(sb, p->produced[buf], 0));
+        PFHE_TRY(stamp());
+        // ---- block pass (last pass of the transform) + multiply-accumulate ----
         if (fused) {
             PFHE_TRY(gadget_block_mulacc_dev(t.primes_dev, t.L, t.log_n, t.ntt_arith, p->k, rows * ell, dg,
                                              keys + (keys_shared ? 0 : done * key_words), keys_shared,
-                                             result + done * (p->k + 1) * W, cur, accumulate, sb, inv_tail));
+                                             result + done * (p->k + 1) * W, cur, accumulate, s, inv_tail));
         } else {
-            PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.ntt_arith, dg, npolys, false, passes - 1, false, sb, nullptr, 0,
+            PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n, t.ntt_arith, dg, npolys, false, passes - 1, false, s, nullptr, 0,
                                   t.tune));
+            PFHE_TRY(gadget_mulacc_dev(t.primes_dev, t.L, t.log_n, p->k, rows, ell, dg,
+                                       keys + (keys_shared ? 0 : done * key_words), keys_shared,
+                                       result + done * (p->k + 1) * W, cur, accumulate, s));
         }
-        if (!single) PFHE_HIP(hipEventRecord(p->consumed[buf], sb));
-        PFHE_TRY(stamp(sb));
-        if (!fused) {
-            if (single) {
-                // one stream, one digit buffer: multiply-accumulate this chunk before the next one overwrites it
-                PFHE_TRY(issue_mulacc(index, done, cur));
-            } else if (index >= 1) {
-                // ---- stream a: multiply-accumulate of the PREVIOUS chunk (its block pass has had time to run) ----
-                PFHE_TRY(issue_mulacc(index - 1, prev_done, prev_cur));
-            }
-        }
-        prev_done = done;
-        prev_cur = cur;
-    }
-    if (!fused && !single && index >= 1) PFHE_TRY(issue_mulacc(index - 1, prev_done, prev_cur));
-    if (!single) {
-        PFHE_HIP(hipEventRecord(p->join_a, sa));
-        PFHE_HIP(hipEventRecord(p->join_b, sb));
-        PFHE_HIP(hipStreamWaitEvent(s, p->join_a, 0));
-        PFHE_HIP(hipStreamWaitEvent(s, p->join_b, 0));
+        PFHE_TRY(stamp());
     }
     return PFHE_OK;
 }
@@ -838,32 +783,20 @@ int pfhe_extprod_plan_create(const pfhe_dcrt *table, const pfhe_rns *rns, const 
     p->digits_words = p->chunk * (p->k + 1) * p->basis.ell * t->L * t->n;
     DeviceGuard g(t->device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    // tuning switches: read here, once, and kept in the plan (nothing on the launch path calls getenv)
-    p->pipeline = std::getenv("PFHE_EXTPROD_PIPELINE") != nullptr;
-    p->use_small = std::getenv("PFHE_DISABLE_SMALL_EXTPROD") == nullptr;
+    // read here, once, and kept in the plan (nothing on the launch path calls getenv)
     p->use_fused = std::getenv("PFHE_DISABLE_FUSED_EXTPROD") == nullptr;
-    p->use_fused_decompose = std::getenv("PFHE_DISABLE_FUSED_DECOMPOSE") == nullptr;
-    p->use_fused_tail = std::getenv("PFHE_DISABLE_FUSED_TAIL") == nullptr;
-    if (const char *e = std::getenv("PFHE_FUSED_MIN_WGS")) p->fused_min_wgs = (u64)std::max(1, std::atoi(e));
-    for (int i = 0; i < 2; ++i) {
+    {
         void *d = nullptr;
-        if (i == 0 || p->pipeline) PFHE_HIP(counted_malloc(&d, p->digits_words * sizeof(u64)));
-        p->digits[i] = (u64 *)d;
-        PFHE_HIP(hipEventCreateWithFlags(&p->produced[i], hipEventDisableTiming));
-        PFHE_HIP(hipEventCreateWithFlags(&p->consumed[i], hipEventDisableTiming));
+        PFHE_HIP(counted_malloc(&d, p->digits_words * sizeof(u64)));
+        p->digits = (u64 *)d;
     }
-    if ((gadget_decompose_strided_supported(t->log_n, p->rns.dev.value_len) && p->use_fused_decompose) ||
+    if (gadget_decompose_strided_supported(t->log_n, p->rns.dev.value_len) ||
         extprod_small_supported(t->log_n, p->k, p->rns.dev.value_len, p->basis.log_basis)) {
         void *d = nullptr;
         p->sdigit_bytes = gadget_digit_bytes(p->basis.log_basis);
         PFHE_HIP(counted_malloc(&d, p->chunk * (p->k + 1) * p->basis.ell * t->n * p->sdigit_bytes));
         p->sdigits = d;
     }
-    PFHE_HIP(hipStreamCreateWithFlags(&p->sa, hipStreamNonBlocking));
-    PFHE_HIP(hipStreamCreateWithFlags(&p->sb, hipStreamNonBlocking));
-    PFHE_HIP(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
-    PFHE_HIP(hipEventCreateWithFlags(&p->join_a, hipEventDisableTiming));
-    PFHE_HIP(hipEventCreateWithFlags(&p->join_b, hipEventDisableTiming));
     PFHE_HIP(hipEventCreateWithFlags(&p->last_done, hipEventDisableTiming));
     *out = p.release();
     return PFHE_OK;
@@ -885,7 +818,7 @@ int pfhe_extprod_plan_debug_hold(pfhe_extprod_plan *p, int hold) {
 }
 size_t pfhe_extprod_plan_scratch_bytes(const pfhe_extprod_plan *p) {
     if (!p) return 0;
-    return (p->pipeline ? 2 : 1) * p->digits_words * 8 + (p->sdigits ? p->chunk * (p->k + 1) * p->basis.ell * p->table->n * p->sdigit_bytes : 0);
+    return p->digits_words * 8 + (p->sdigits ? p->chunk * (p->k + 1) * p->basis.ell * p->table->n * p->sdigit_bytes : 0);
 }
 
 int pfhe_extprod_mul_dcrt_ggsw_to_dev(pfhe_extprod_plan *plan, const uint64_t *crt_glwe_dev, size_t len_glwe,
@@ -932,10 +865,6 @@ int pfhe_extprod_profile_dev(pfhe_extprod_plan *plan, const uint64_t *crt_glwe_d
     PFHE_TRY(plan_check(plan));
     PFHE_PLAN_LEASE(plan);
     if (!ms_out || !launches_out) return PFHE_ERR_BAD_ARGUMENT;
-    if (plan->pipeline) {
-        set_last_error("profiling needs a plan without the two-stream pipeline");
-        return PFHE_ERR_UNSUPPORTED;
-    }
     std::vector<hipEvent_t> ev;
     plan->prof = &ev;
     // coefficient-form output, as bench.py times it: the second group includes the inverse block pass fused into the

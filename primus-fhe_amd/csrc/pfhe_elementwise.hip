@@ -213,6 +213,13 @@ __global__ __launch_bounds__(kEwThreads) void inv_kernel(u64 *out, const u64 *in
     }
 }
 
+// Plain copy in the launch shape of the element-wise family (one 16-byte vector per thread, non-temporal both ways): the
+// streaming rate this library's own access pattern reaches, measured by bench.py as `device_copy` / `roofline.peak_measured`.
+__global__ __launch_bounds__(kEwThreads) void stream_copy_kernel(u64 *__restrict__ dst, const u64 *__restrict__ src, u64 nvec) {
+    for (u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (u64)gridDim.x * blockDim.x)
+        ew_store(dst + 2 * v, ew_load(src + 2 * v));
+}
+
 u32 ew_grid(u64 items) {
     u64 g = (items + kEwThreads - 1) / kEwThreads;
     const u64 cap = std::min<u64>(256ull * kEwWgPerCu, 0x7fffffffull);  // grid-stride beyond that
@@ -294,6 +301,23 @@ int monomial_to(const TableSet &t, const u64 *in, u64 r, u64 *out, u64 len, hipS
 using namespace pfhe;
 
 extern "C" {
+
+int pfhe_stream_copy_dev(int device, void *dst_dev, const void *src_dev, size_t bytes, void *stream) {
+    PFHE_GUARD_BEGIN
+    if (bytes == 0) return PFHE_OK;
+    if (!dst_dev || !src_dev || bytes % 16 != 0) return PFHE_ERR_BAD_ARGUMENT;
+    PFHE_REQUIRE_ALIGNED(dst_dev);
+    PFHE_REQUIRE_ALIGNED(src_dev);
+    PFHE_TRY(capi_check_device(device));
+    DeviceGuard guard(device);
+    if (!guard.ok) return PFHE_ERR_NO_DEVICE;
+    const u64 nvec = bytes / 16;
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(ew_grid(nvec)), dim3(kEwThreads), 0, (hipStream_t)stream, (u64 *)dst_dev,
+                       (const u64 *)src_dev, nvec);
+    PFHE_HIP(hipGetLastError());
+    return PFHE_OK;
+    PFHE_GUARD_END
+}
 
 int pfhe_dcrt_add_to_dev(const pfhe_dcrt *table, const uint64_t *a_dev, const uint64_t *b_dev, uint64_t *out_dev,
                          size_t len, void *stream) {
@@ -405,7 +429,7 @@ int pfhe_dcrt_mul_monomial_assign_dev(const pfhe_dcrt *table, uint64_t *data_dev
         return PFHE_ERR_BAD_ARGUMENT;
     }
     if (len == 0) return PFHE_OK;
-    if (t.log_n >= 9 && t.log_n <= 14 && len / t.n <= 0x7fffffffull && t.monomial_inplace) {
+    if (t.log_n >= 9 && t.log_n <= 14 && len / t.n <= 0x7fffffffull) {
         // truly in place: one workgroup per polynomial, data held in registers across the barrier
         const bool high = r >= t.n;
         const u32 rot = (u32)(high ? r - t.n : r);

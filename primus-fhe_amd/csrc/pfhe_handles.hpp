@@ -18,9 +18,6 @@ struct TableSet {
     int ntt_arith = 0;                     // policy of the plain transforms: kArithPm, kArithMont (generic primes below 2^61) or kArithShoup
     // tuning switches, read from the environment once, when the handle is created
     NttTuning tune;
-    bool fused_polymul = true;             // cleared by PFHE_DISABLE_FUSED_POLYMUL
-    bool fused_polymul_mid = true;         // cleared by PFHE_DISABLE_POLYMUL_MID: NTT -> mul -> INTT block passes in one kernel
-    bool monomial_inplace = true;          // cleared by PFHE_DISABLE_MONOMIAL_INPLACE
     std::vector<NttPrime> primes;          // host copies (device pointers inside)
     const NttPrime *primes_dev = nullptr;  // the same array on the device
     const u64 *moduli_dev = nullptr;

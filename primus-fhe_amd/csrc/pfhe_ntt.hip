@@ -135,7 +135,7 @@ __device__ __forceinline__ void strided_pass_body(u64 *__restrict__ data, const 
 // Register budget: left to the compiler (134-136 registers for the two-column form, three waves per SIMD).  Capping
 // it at 128 so that a wave fits beside three block-pass waves costs 4-16 spilled registers, i.e. scratch traffic on an
 // HBM-bound kernel (6.34 / 7.5 GiB moved per 6 GiB launch, forward / inverse): 2.17 -> 2.22 ms and 2.18 -> 2.31 ms, for
-// no better overlap.  VEC == 1 (PFHE_STRIDED_VEC1) is the one-column form, at most 96 registers.
+// no better overlap.  VEC == 1 is the one-column form the five-stage pass takes.
 constexpr int kStridedMinWaves = 1;
 // NT: non-temporal stores (launch_strided picks it for batches of at least kNtMinBytes)
 template <class A, int K, int VEC, bool INV, bool FINAL, bool NT = false>
@@ -359,6 +359,22 @@ __global__ __launch_bounds__(BlockCfg<12>::THREADS) __attribute__((amdgpu_waves_
 // Forward: 8-byte loads deliver the first register layout directly (register k of thread lt = element (k << POS0) + lt);
 // inverse: natural-order 16-byte vectors, staged through LDS into layout 0, and direct 8-byte stores at the end.
 // ------------------------------------------------------------------------------------------
+// The E loads of a forward register layout: element (k << POS0) + lt, rows 8 << POS0 bytes apart — beyond the 12-bit
+// immediate offset of a global load, so every row needs its own 64-bit address.  Row k's address is row k-1's plus an
+// OPAQUE scalar stride: one v_lshl_add_u64 each instead of v_add_co_u32 + s_nop + v_addc_co_u32 (43 -> 13 such pairs in
+// the 2^14 kernel, VALU 2017 -> 1989: 13.46 -> 13.59 M NTT/s same box; the same chain on the inverse kernel's stores
+// measured -0.6 % and is not used — profiles/r06_experiments.txt item 1).
+template <int E, int POS0>
+__device__ __forceinline__ void persist_row_loads(u64 (&x)[E], const u64 *g) {
+    u64 stride = (u64)sizeof(u64) << POS0;
+    asm("" : "+s"(stride));
+    const char *addr = reinterpret_cast<const char *>(g);
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        x[k] = __builtin_nontemporal_load(reinterpret_cast<const u64 *>(addr));
+        addr += stride;
+    }
+}
 constexpr int kPersistInvHook = 1;  // passes before the last one at which the inverse direction issues its prefetch (0: 0.332 ms, 1: 0.315 ms per 4096)
 template <class A, int LOGB, bool INV>
 __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt_persist_kernel(
@@ -374,9 +390,7 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_wave
     if constexpr (!INV) {
         u64 x[Cfg::E], xn[Cfg::E];
         {
-            const u64 *__restrict__ g = data + p * n + threadIdx.x;
-#pragma unroll
-            for (int k = 0; k < Cfg::E; ++k) x[k] = __builtin_nontemporal_load(g + ((u32)k << POS0));
+            persist_row_loads<Cfg::E, POS0>(x, data + p * n + threadIdx.x);
         }
         while (true) {
             const u64 pn = p + stride;
@@ -384,9 +398,7 @@ __global__ __launch_bounds__(BlockCfg<LOGB>::THREADS) __attribute__((amdgpu_wave
             const A ar(primes + p % L);
             const auto prefetch = [&]() {
                 if (more) {
-                    const u64 *__restrict__ g = data + pn * n + opaque_tid();
-#pragma unroll
-                    for (int k = 0; k < Cfg::E; ++k) xn[k] = __builtin_nontemporal_load(g + ((u32)k << POS0));
+                    persist_row_loads<Cfg::E, POS0>(xn, data + pn * n + opaque_tid());
                 } else {  // a dead value: the old contents must not count as live
 #pragma unroll
                     for (int k = 0; k < Cfg::E; ++k) xn[k] = 0;
@@ -839,11 +851,11 @@ int launch_persist(u64 *data, const NttPrime *primes, u32 L, u64 npolys, bool la
 
 template <class A, int LOGB, bool INV, bool MUL = false>
 int launch_block(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys, bool lazy, hipStream_t s,
-                 const u64 *mul = nullptr, u64 mul_polys = 0, bool persist = true) {
+                 const u64 *mul = nullptr, u64 mul_polys = 0) {
     // (N = 2^13, two workgroups per CU, measures slower in this form: 0.33 vs 0.29-0.32 ms per 8192 polynomials)
     if constexpr (LOGB == 14 && !MUL && !A::kPacked) {
         const u64 resident = (u64)device_cu_count();
-        if (persist && log_n == LOGB && npolys >= 2 * resident)
+        if (log_n == LOGB && npolys >= 2 * resident)
             return launch_persist<A, LOGB, INV>(data, primes, L, npolys, lazy, s, resident);
     }
     if constexpr (LOGB >= 11) {
@@ -855,11 +867,11 @@ int launch_block(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys
 
 template <class A, bool INV, bool MUL = false>
 int dispatch_block(int logb, u64 *data, const NttPrime *primes, u32 L, u32 log_n, u64 npolys, bool lazy,
-                   hipStream_t s, const u64 *mul = nullptr, u64 mul_polys = 0, bool persist = true) {
+                   hipStream_t s, const u64 *mul = nullptr, u64 mul_polys = 0) {
     switch (logb) {
 #define PFHE_CASE(B) \
     case B:          \
-        return launch_block<A, B, INV, MUL>(data, primes, L, log_n, npolys, lazy, s, mul, mul_polys, persist);
+        return launch_block<A, B, INV, MUL>(data, primes, L, log_n, npolys, lazy, s, mul, mul_polys);
         PFHE_CASE(4) PFHE_CASE(5) PFHE_CASE(6) PFHE_CASE(7) PFHE_CASE(8) PFHE_CASE(9) PFHE_CASE(10)
         PFHE_CASE(11) PFHE_CASE(12) PFHE_CASE(13) PFHE_CASE(14)
 #undef PFHE_CASE
@@ -890,15 +902,12 @@ int launch_strided(u64 *data, const NttPrime *primes, u32 L, u32 log_n, u32 log_
 
 template <class A, bool INV, bool FINAL>
 int dispatch_strided(int k, u64 *data, const NttPrime *primes, u32 L, u32 log_n, u32 log_s, u64 npolys, bool lazy,
-                     hipStream_t s, bool vec1) {
+                     hipStream_t s) {
+    // the radices make_ntt_plan produces: the stages above a 2^12 block (2^11 words for the u32 tables at N = 2^16), at
+    // most five per pass, balanced — never fewer than three
     switch (k) {
-        case 1: return launch_strided<A, 1, 2, INV, FINAL>(data, primes, L, log_n, log_s, npolys, lazy, s);
-        case 2: return launch_strided<A, 2, 2, INV, FINAL>(data, primes, L, log_n, log_s, npolys, lazy, s);
         case 3: return launch_strided<A, 3, 2, INV, FINAL>(data, primes, L, log_n, log_s, npolys, lazy, s);
-        case 4:
-            if (vec1)  // tuning switch: one column per thread (fewer registers)
-                return launch_strided<A, 4, 1, INV, FINAL>(data, primes, L, log_n, log_s, npolys, lazy, s);
-            return launch_strided<A, 4, 2, INV, FINAL>(data, primes, L, log_n, log_s, npolys, lazy, s);
+        case 4: return launch_strided<A, 4, 2, INV, FINAL>(data, primes, L, log_n, log_s, npolys, lazy, s);
         case 5: return launch_strided<A, 5, 1, INV, FINAL>(data, primes, L, log_n, log_s, npolys, lazy, s);
     }
     set_last_error("unsupported strided radix");
@@ -919,7 +928,7 @@ int launch_tiny(bool inverse, const NttPrime *primes, u32 L, u32 log_n, u64 *dat
 // then strided passes, the last of which carries the fused final stage)
 template <class A>
 int run_pass(const NttPlan &plan, const NttPrime *primes, u32 L, u32 log_n, u64 *data, u64 npolys, bool inverse,
-             int index, bool lazy, hipStream_t s, const u64 *mul, u64 mul_polys, bool vec1, bool persist) {
+             int index, bool lazy, hipStream_t s, const u64 *mul, u64 mul_polys) {
     const int block_at = inverse ? 0 : plan.n_strided;
     if (mul != nullptr) {
         if constexpr (A::kPacked) {
@@ -930,8 +939,8 @@ int run_pass(const NttPlan &plan, const NttPrime *primes, u32 L, u32 log_n, u64 
         }
     }
     if (index == block_at) {
-        return inverse ? dispatch_block<A, true>(plan.block_log, data, primes, L, log_n, npolys, lazy, s, nullptr, 0, persist)
-                       : dispatch_block<A, false>(plan.block_log, data, primes, L, log_n, npolys, lazy, s, nullptr, 0, persist);
+        return inverse ? dispatch_block<A, true>(plan.block_log, data, primes, L, log_n, npolys, lazy, s)
+                       : dispatch_block<A, false>(plan.block_log, data, primes, L, log_n, npolys, lazy, s);
     }
     const int i = inverse ? plan.n_strided - index : index;  // index into plan.strided (forward order)
     u32 log_s = log_n;
@@ -940,12 +949,12 @@ int run_pass(const NttPlan &plan, const NttPrime *primes, u32 L, u32 log_n, u64 
     if (!inverse) {
         // Montgomery tables: the first pass of a forward transform skips the fold of its first stage (strided_forward_regs)
         if constexpr (A::kMont) {
-            if (i == 0) return dispatch_strided<A, false, true>(k, data, primes, L, log_n, log_s, npolys, false, s, vec1);
+            if (i == 0) return dispatch_strided<A, false, true>(k, data, primes, L, log_n, log_s, npolys, false, s);
         }
-        return dispatch_strided<A, false, false>(k, data, primes, L, log_n, log_s, npolys, false, s, vec1);
+        return dispatch_strided<A, false, false>(k, data, primes, L, log_n, log_s, npolys, false, s);
     }
-    if (i == 0) return dispatch_strided<A, true, true>(k, data, primes, L, log_n, log_s, npolys, lazy, s, vec1);
-    return dispatch_strided<A, true, false>(k, data, primes, L, log_n, log_s, npolys, false, s, vec1);
+    if (i == 0) return dispatch_strided<A, true, true>(k, data, primes, L, log_n, log_s, npolys, lazy, s);
+    return dispatch_strided<A, true, false>(k, data, primes, L, log_n, log_s, npolys, false, s);
 }
 
 }  // namespace
@@ -960,15 +969,8 @@ static int env_int(const char *name, int lo, int hi) {
 NttTuning NttTuning::from_env() {
     NttTuning t;
     t.pipe_tiles = env_int("PFHE_PIPE_TILES", 2, 4096);
-    t.strided_vec1 = std::getenv("PFHE_STRIDED_VEC1") != nullptr;
-    t.max_single_pass_log = env_int("PFHE_MAX_SINGLE_PASS_LOG", 9, (int)kMaxSinglePassLog);
-    t.block_log = env_int("PFHE_BLOCK_LOG", 8, 12);
     t.pipelined = std::getenv("PFHE_DISABLE_PIPELINED") == nullptr;
     t.pipelined_min_mb = env_int("PFHE_PIPELINED_MIN_MB", 1, 1 << 20);
-    t.pipe_ramp = env_int("PFHE_PIPE_RAMP", 1, 32);
-    t.persist = std::getenv("PFHE_DISABLE_PERSIST") == nullptr;
-    t.pipe_u32 = std::getenv("PFHE_NO_PIPE_U32") == nullptr;
-    t.pipe_lds_extra = env_int("PFHE_PIPE_LDS_EXTRA", 1, 120 << 10);
     return t;
 }
 
@@ -979,8 +981,8 @@ NttPlan make_ntt_plan(u32 log_n, int arith, const NttTuning &tune) {
         p.tiny = true;
         return p;
     }
-    const u32 max_single = tune.max_single_pass_log ? (u32)tune.max_single_pass_log : kMaxSinglePassLog;
-    if (log_n <= max_single) {
+    (void)tune;  // the plan depends on the ring only (the tuning switches select between FORMS of running it)
+    if (log_n <= kMaxSinglePassLog) {
         p.block_log = (int)log_n;
         return p;
     }
@@ -988,8 +990,6 @@ NttPlan make_ntt_plan(u32 log_n, int arith, const NttTuning &tune) {
     // u32 tables at N = 2^16 (2^15 words): 4 strided stages + blocks of 2^11 words in 128-thread workgroups
     // (8 resident per CU) measured 3.05 ms against 3.24 ms for 3 + 2^12
     if (arith == 2 /* kArithB32 */ && log_n == 15) p.block_log = 11;
-    if (tune.block_log && (int)log_n - tune.block_log >= 1) p.block_log = tune.block_log;  // tuning switch
-    if (p.block_log >= (int)log_n) p.block_log = (int)log_n - 1;  // only reachable through the tuning switches
     int rest = (int)log_n - p.block_log;
     // fewest strided passes with at most 5 stages each, balanced
     int passes = (rest + 4) / 5;
@@ -1025,17 +1025,16 @@ int ntt_pass_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u64 *data,
                  bool lazy, hipStream_t s, const u64 *mul, u64 mul_polys, const NttTuning &tune) {
     const NttPlan plan = make_ntt_plan(log_n, arith, tune);
     if (index < 0 || index >= (plan.tiny ? 1 : plan.n_strided + 1)) return PFHE_ERR_BAD_ARGUMENT;
-    const bool v1 = tune.strided_vec1;
     if (arith == kArithB32) {
         if (plan.tiny) return PFHE_ERR_UNSUPPORTED;  // N <= 16 is served by ntt32_tiny_kernel
-        return run_pass<B32Arith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys, v1, false);
+        return run_pass<B32Arith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys);
     }
     if (plan.tiny) return mul ? PFHE_ERR_UNSUPPORTED : launch_tiny(inverse, primes, L, log_n, data, npolys, lazy, s);
     if (arith == kArithMont)
-        return run_pass<MontArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys, v1, tune.persist);
+        return run_pass<MontArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys);
     return arith == kArithPm
-               ? run_pass<PmArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys, v1, tune.persist)
-               : run_pass<ShoupArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys, v1, tune.persist);
+               ? run_pass<PmArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys)
+               : run_pass<ShoupArith>(plan, primes, L, log_n, data, npolys, inverse, index, lazy, s, mul, mul_polys);
 }
 
 // pipelined form: from 256 MiB of data (2^16-point transforms: 512 limb-polynomials), tiles of 256 MiB = the Infinity
@@ -1056,32 +1055,16 @@ constexpr int kPipelinedMaxTiles = 64;
 // the pipelined form of the two-pass transform (ntt_pipe_{fwd,inv}_kernel): tiles + 1 launches on the caller's stream
 template <class A, int LOGB>
 static int transform_pipelined(const NttPrime *primes, u32 L, u64 *data, u64 npolys, bool inverse, bool lazy,
-                               hipStream_t s, int tiles, int ramp, const u64 *mul, u64 mul_polys, int lds_extra = 0) {
+                               hipStream_t s, int tiles, const u64 *mul, u64 mul_polys) {
     if (tiles > 64) tiles = 64;
     constexpr u32 log_n = LOGB + 4;
-    // (PFHE_PIPE_LDS_EXTRA, measurement aid: unused LDS bytes per workgroup, i.e. fewer resident workgroups per CU — the N of
-    // DESIGN.md §5's queueing model made smaller on purpose)
-    const size_t lds_bytes = (size_t)BlockCfg<LOGB>::LDS_WORDS * sizeof(u64) + (size_t)lds_extra;
+    constexpr size_t lds_bytes = (size_t)BlockCfg<LOGB>::LDS_WORDS * sizeof(u64);
     constexpr u32 threads = BlockCfg<LOGB>::THREADS;
     const u64 units = npolys / L;
-    // tile boundaries: weights ramp up 1, 2, ... ramp and down again (ramp 1 = equal tiles).  The first and the last
-    // launch run only one pass's worth of work (nothing to overlap with); a ramp makes those two small, and the
-    // surplus of the larger neighbour in the launches between runs beside paired workgroups.
+    // equal tiles of whole RNS polynomials (tile weights that ramp up and down again, so that the first and the last
+    // launch — one pass's worth of work each — are small, measured no gain and are gone)
     u64 cum[66];
-    {
-        u64 wsum = 0, w[65];
-        for (int k = 0; k < tiles; ++k) {
-            const int up = k + 1, down = tiles - k;
-            w[k] = (u64)std::min(std::min(up, down), ramp < 1 ? 1 : ramp);
-            wsum += w[k];
-        }
-        u64 acc = 0;
-        cum[0] = 0;
-        for (int k = 0; k < tiles; ++k) {
-            acc += w[k];
-            cum[k + 1] = units * acc / wsum;
-        }
-    }
+    for (int k = 0; k <= tiles; ++k) cum[k] = units * (u64)k / (u64)tiles;
     for (int k = 0; k <= tiles; ++k) {
         // forward: strided pass of tile k, block pass of tile k-1; inverse: block pass of tile k, strided pass of tile k-1
         const int kb = inverse ? k : k - 1, ks = inverse ? k - 1 : k;
@@ -1136,9 +1119,9 @@ static int pipelined_tiles(u32 L, u32 log_n, int pm, u64 npolys, bool inverse, b
     // u32 tables: 2^15 words = 2^4 x 2^11, the same kernel template with 128-thread workgroups.  Round 5, 12 288 transforms,
     // same box: INVERSE 2.594 -> 2.462-2.499 ms (6 / 12 tiles); forward 2.512-2.527 -> 2.472-2.480 ms once the wave-local
     // I/O vectors had brought its kernel from 128 registers + 28 bytes of scratch to 120 and none (before that: 2.468 ->
-    // 2.473, not taken).  Both directions take it by default; PFHE_NO_PIPE_U32 keeps the forward one on two plain launches.
+    // 2.473, not taken).  Both directions take it.
     const bool shape = (pm != kArithB32 && log_n == 16 && make_ntt_plan(log_n, pm, tune).block_log == 12) ||
-                       (pm == kArithB32 && (inverse || tune.pipe_u32) && log_n == 15 &&
+                       (pm == kArithB32 && log_n == 15 &&
                         make_ntt_plan(log_n, pm, tune).block_log == 11);
     if (!(tune.pipelined && shape && ntt_num_passes(log_n, pm, tune) == 2 &&
           (!has_mul || inverse) && npolys % L == 0 &&
@@ -1162,8 +1145,20 @@ int ntt_transform_form(u32 L, u32 log_n, int arith, u64 npolys, bool inverse, co
         std::snprintf(buf, cap, inverse ? "ntt_pipe_inv_kernel" : "ntt_pipe_fwd_kernel");
         return pt + 1;
     }
-    std::snprintf(buf, cap, "plain passes");
-    return ntt_num_passes(log_n, arith, tune);
+    // one launch per pass: name them in execution order
+    const NttPlan plan = make_ntt_plan(log_n, arith, tune);
+    const int passes = plan.tiny ? 1 : plan.n_strided + 1;
+    size_t at = 0;
+    buf[0] = 0;
+    for (int i = 0; i < passes && at + 1 < cap; ++i) {
+        char one[96];
+        ntt_pass_name(log_n, inverse, i, one, sizeof one, arith, tune);
+        if (!plan.tiny && plan.n_strided == 0 && plan.block_log == 14 && arith != kArithB32 &&
+            npolys >= 2 * (u64)device_cu_count())
+            std::snprintf(one, sizeof one, "ntt_persist_kernel<14,%s>", inverse ? "inv" : "fwd");  // launch_block's choice
+        at += (size_t)std::snprintf(buf + at, cap - at, "%s%s", i ? " + " : "", one);
+    }
+    return passes;
 }
 
 static int transform(const NttPrime *primes, u32 L, u32 log_n, int pm, u64 *data, u64 npolys, bool inverse,
@@ -1172,17 +1167,13 @@ static int transform(const NttPrime *primes, u32 L, u32 log_n, int pm, u64 *data
     {
         const int pt = pipelined_tiles(L, log_n, pm, npolys, inverse, mul != nullptr, tune);
         if (pt >= 1 && pm == kArithB32)
-            return transform_pipelined<B32Arith, 11>(primes, L, data, npolys, inverse, lazy, s, pt, tune.pipe_ramp, mul, mul_polys,
-                                                     tune.pipe_lds_extra);
+            return transform_pipelined<B32Arith, 11>(primes, L, data, npolys, inverse, lazy, s, pt, mul, mul_polys);
         if (pt >= 1 && pm == kArithMont)
-            return transform_pipelined<MontArith, 12>(primes, L, data, npolys, inverse, lazy, s, pt, tune.pipe_ramp, mul, mul_polys,
-                                                      tune.pipe_lds_extra);
+            return transform_pipelined<MontArith, 12>(primes, L, data, npolys, inverse, lazy, s, pt, mul, mul_polys);
         if (pt >= 1)
             return pm == kArithPm
-                       ? transform_pipelined<PmArith, 12>(primes, L, data, npolys, inverse, lazy, s, pt, tune.pipe_ramp, mul, mul_polys,
-                                                          tune.pipe_lds_extra)
-                       : transform_pipelined<ShoupArith, 12>(primes, L, data, npolys, inverse, lazy, s, pt, tune.pipe_ramp, mul,
-                                                             mul_polys, tune.pipe_lds_extra);
+                       ? transform_pipelined<PmArith, 12>(primes, L, data, npolys, inverse, lazy, s, pt, mul, mul_polys)
+                       : transform_pipelined<ShoupArith, 12>(primes, L, data, npolys, inverse, lazy, s, pt, mul, mul_polys);
     }
     // one launch per pass on the caller's stream
     for (int i = 0; i < passes; ++i)
@@ -1301,7 +1292,7 @@ static int polymul_impl(const NttPrime *primes, u32 L, u32 log_n, int arith, u64
         PFHE_HIP(hipGetLastError());
         return PFHE_OK;
     };
-    if (plan.n_strided == 0 && plan.block_log == 14 && tune.persist) {
+    if (plan.n_strided == 0 && plan.block_log == 14) {
         // N = 2^14: resident workgroups that prefetch their next polynomial (ntt_persist_mid_kernel)
         const u64 resident = (u64)device_cu_count();
         if (npolys >= 2 * resident) {

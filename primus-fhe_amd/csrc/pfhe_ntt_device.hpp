@@ -26,16 +26,9 @@ struct NttPlan {
 // created (NttTuning::from_env), and travel inside the handle: nothing on the launch path calls getenv, and two
 // tables created under different settings keep their own.
 struct NttTuning {
-    int pipe_tiles = 0;            // PFHE_PIPE_TILES: tiles of the pipelined form (0: built-in default, batch / 256 MiB)
-    bool strided_vec1 = false;     // PFHE_STRIDED_VEC1: one column per thread in the 4-stage strided pass (64 registers)
-    int max_single_pass_log = 0;   // PFHE_MAX_SINGLE_PASS_LOG (0: built-in default)
-    int block_log = 0;             // PFHE_BLOCK_LOG: block size under strided passes (0: built-in default)
-    bool pipelined = true;         // PFHE_DISABLE_PIPELINED clears it: N = 2^16 runs as tiles + 1 launches of ntt_pipe_kernel on the caller's stream
-    int pipe_ramp = 0;             // PFHE_PIPE_RAMP: tile weights of the pipelined form ramp 1..ramp..1 (0 / 1: equal tiles)
-    bool persist = true;           // PFHE_DISABLE_PERSIST clears it: N = 2^13 / 2^14 batches run ntt_persist_kernel (resident workgroups that prefetch their next polynomial)
-    int pipe_lds_extra = 0;        // PFHE_PIPE_LDS_EXTRA: measurement aid — unused LDS bytes per workgroup of the pipelined kernels (fewer resident workgroups per CU)
-    bool pipe_u32 = true;          // the u32 tables' FORWARD N = 2^16 transforms take the pipelined form like the inverse ones (PFHE_NO_PIPE_U32: two plain launches)
-    int pipelined_min_mb = 0;      // PFHE_PIPELINED_MIN_MB: smallest batch (MiB of data) that takes the pipelined form (0: built-in default)
+    int pipe_tiles = 0;        // PFHE_PIPE_TILES: tiles of the pipelined form (0: built-in default, batch / 256 MiB)
+    bool pipelined = true;     // PFHE_DISABLE_PIPELINED clears it: N = 2^16 runs one launch per pass instead of tiles + 1 launches of ntt_pipe_{fwd,inv}_kernel
+    int pipelined_min_mb = 0;  // PFHE_PIPELINED_MIN_MB: smallest batch (MiB of data) that takes the pipelined form (0: built-in default)
     static NttTuning from_env();
 };
 NttPlan make_ntt_plan(u32 log_n, int arith = 0, const NttTuning &tune = NttTuning());  // arith: see kArith* below

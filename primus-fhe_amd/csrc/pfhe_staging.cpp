@@ -35,24 +35,24 @@ const StageKnobs &stage_knobs() {
     static const StageKnobs k = [] {
         StageKnobs v;
         // slices of at least register_min bytes are looked up: memory the caller pinned is used as it is
-        // (PFHE_STAGE_REGISTER=0: never)
-        v.use_register = env_bytes("PFHE_STAGE_REGISTER", 1) != 0;
-        v.register_min = env_bytes("PFHE_STAGE_REGISTER_MIN", (size_t)128 << 10);
+        v.use_register = true;
+        v.register_min = (size_t)128 << 10;
         // transfers up to bounce_max go through the pinned bounce buffer (a CPU copy + a true asynchronous DMA, or kernels
         // on that buffer); larger ones are handed to the runtime as they are (it pins the caller's pages in pieces)
         v.bounce_max = env_bytes("PFHE_STAGE_BOUNCE_MAX", (size_t)1 << 20);
-        v.cache_max = env_bytes("PFHE_STAGE_CACHE_MAX", (size_t)2 << 30);
+        v.cache_max = (size_t)2 << 30;
         const size_t chunk = env_bytes("PFHE_STAGE_CHUNK", 0);
         v.chunk_bytes = chunk ? chunk : (size_t)8 << 20;
+        // PFHE_STAGE_ZERO_COPY=0: no kernel ever reads or writes host memory (neither the caller's pinned memory nor
+        // the pool's own buffer) — every byte crosses the link through the copy engines
         v.zero_copy = env_bytes("PFHE_STAGE_ZERO_COPY", 1) != 0;
-        v.helper_thread = env_bytes("PFHE_STAGE_THREADS", 1) != 0;
-        const size_t pieces = env_bytes("PFHE_STAGE_PIECES", 0);
-        v.pieces = pieces >= 2 && pieces <= 64 ? pieces : 8;
+        v.helper_thread = true;
+        v.pieces = 8;
         // idle contexts kept per device (each holds its arenas, up to cache_max): a burst of T concurrent callers leaves
         // at most this many behind
-        v.idle_max = env_bytes("PFHE_STAGE_IDLE_MAX", 4);
-        // pieces the helper thread stays behind the copying thread (1: never a page in common in flight; 0: round 4's order)
-        v.helper_lag = env_bytes("PFHE_STAGE_LAG", 1) ? 1 : 0;
+        v.idle_max = 4;
+        // pieces the helper thread stays behind the copying thread (1: never a page in common in flight)
+        v.helper_lag = 1;
         return v;
     }();
     return k;
@@ -293,10 +293,40 @@ bool HostStage::pin(const void *host, size_t bytes, bool any_size) {
 // hipHostGetFlags tells the two apart on this runtime: it succeeds for hipHostMalloc memory and fails for a registration
 // (tools/probe_host_kinds.hip; every other attribute — type, device pointer, range — reads the same for both).  A registered
 // slice takes the pool's own pinned buffer (short) or the copy engines (long) instead.
+// The check FAILS CLOSED.  (1) The discriminator is probed once per process on a block this library registers itself: if
+// hipHostGetFlags SUCCEEDS for that registration (some HIP builds report the register flags), it cannot tell the two kinds
+// apart here and no caller memory is ever mapped.  (2) A second, independent property must hold as well:
+// hipMemGetAddressRange reports a non-null base only for memory the driver allocated (for a registration the base is null,
+// see pin()).  (3) PFHE_STAGE_ZERO_COPY=0 turns the path off altogether.
+static bool host_flags_tell_registrations_apart() {
+    static const bool works = [] {
+        void *blk = nullptr;
+        if (posix_memalign(&blk, 4096, 2 * 4096) != 0 || blk == nullptr) return false;
+        bool ok = false;
+        if (hipHostRegister(blk, 2 * 4096, hipHostRegisterDefault) == hipSuccess) {
+            unsigned flags = 0;
+            ok = hipHostGetFlags(&flags, blk) != hipSuccess;  // must be refused for a registration
+            (void)hipGetLastError();
+            (void)hipHostUnregister(blk);
+        }
+        (void)hipGetLastError();
+        std::free(blk);
+        return ok;
+    }();
+    return works;
+}
+
 void *HostStage::map(void *host, size_t bytes) {
+    if (!stage_knobs().zero_copy || !host_flags_tell_registrations_apart()) return nullptr;
     if (!pin(host, bytes, true)) return nullptr;
     unsigned flags = 0;
     if (hipHostGetFlags(&flags, host) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    hipDeviceptr_t base = nullptr;
+    size_t extent = 0;
+    if (hipMemGetAddressRange(&base, &extent, (hipDeviceptr_t)host) != hipSuccess || base == nullptr) {
         (void)hipGetLastError();
         return nullptr;
     }
@@ -421,7 +451,7 @@ HostStage::~HostStage() {
         std::lock_guard<std::mutex> lk(P.mu);
         if ((size_t)ctx_->device >= P.idle.size()) P.idle.resize(ctx_->device + 1);
         // idle contexts are capped per device: a burst of concurrent callers does not pin its arenas for the life of the
-        // process (PFHE_STAGE_IDLE_MAX, default 4)
+        // process (StageKnobs::idle_max, four)
         if (P.idle[ctx_->device].size() < K.idle_max) P.idle[ctx_->device].push_back(ctx_);
         else surplus = ctx_;
     }

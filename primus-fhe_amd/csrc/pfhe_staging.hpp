@@ -33,9 +33,9 @@ hipError_t counted_malloc_async(void **p, size_t bytes, hipStream_t s);
 hipError_t counted_free_async(void *p, hipStream_t s);
 std::uint64_t alloc_event_count();
 
-// Environment knobs of the staging layer, parsed ONCE by one parser (a malformed value gives the built-in default
-// everywhere): PFHE_STAGE_BOUNCE_MAX, PFHE_STAGE_CACHE_MAX, PFHE_STAGE_REGISTER, PFHE_STAGE_REGISTER_MIN,
-// PFHE_STAGE_CHUNK, PFHE_STAGE_ZERO_COPY, PFHE_STAGE_THREADS, PFHE_STAGE_PIECES, PFHE_STAGE_IDLE_MAX, PFHE_STAGE_LAG.
+// Knobs of the staging layer.  Three can be set from the environment, parsed ONCE by one parser (a malformed value gives the
+// built-in default): PFHE_STAGE_ZERO_COPY (0: copy engines only, no kernel touches host memory), PFHE_STAGE_BOUNCE_MAX,
+// PFHE_STAGE_CHUNK; the rest are constants (until round 5 each had a switch of its own).
 struct StageKnobs {
     size_t bounce_max, cache_max, register_min, chunk_bytes, pieces, idle_max, helper_lag;
     bool use_register, zero_copy, helper_thread;
@@ -44,7 +44,7 @@ const StageKnobs &stage_knobs();
 
 // Which way the bytes of host-pointer calls travelled (tests assert the path they mean to exercise):
 enum StagePath : int {
-    kPathMappedCaller = 0,  // kernels read / wrote memory the CALLER pinned (hipHostMalloc, hipHostRegister, torch pinned)
+    kPathMappedCaller = 0,  // kernels read / wrote memory the CALLER allocated pinned (hipHostMalloc, torch pinned) — never a hipHostRegister registration (HostStage::map)
     kPathMappedBounce = 1,  // kernels read / wrote the pool's own pinned buffer (CPU copies either side)
     kPathDmaCaller = 2,     // copy engines on memory the caller pinned
     kPathPageable = 3,      // the runtime's pageable copies

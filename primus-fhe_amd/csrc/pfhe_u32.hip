@@ -552,6 +552,20 @@ const char *pfhe_dcrt32_transform_pass_name(const pfhe_dcrt32 *table, int invers
     std::snprintf(buf, sizeof buf, "u32:%s", inner);
     return buf;
 }
+int pfhe_dcrt32_transform_form(const pfhe_dcrt32 *table, size_t len, int inverse, char *name, size_t cap, int *launches) {
+    if (!table || !name || cap == 0 || !launches) return PFHE_ERR_BAD_ARGUMENT;
+    const TableSet &t = *table->t;
+    if (len % (t.n * t.L) != 0) return PFHE_ERR_BAD_LENGTH;
+    if (t.log_n <= 4) {
+        std::snprintf(name, cap, "ntt32_tiny_kernel");
+        *launches = 1;
+        return PFHE_OK;
+    }
+    char inner[96];
+    *launches = ntt_transform_form(t.L, t.log_n - 1, kArithB32, len / t.n, inverse != 0, t.tune, inner, sizeof inner);
+    std::snprintf(name, cap, "u32:%s", inner);
+    return PFHE_OK;
+}
 int pfhe_dcrt32_transform_pass_dev(const pfhe_dcrt32 *table, uint32_t *poly_dev, size_t len, int inverse, int index,
                                    int lazy, void *stream) {
     PFHE_GUARD_BEGIN

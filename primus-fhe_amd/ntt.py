@@ -461,6 +461,12 @@ class U32DcrtTable(_U32Common):
 
     def poly_length(self) -> int: return int(lib().pfhe_dcrt32_poly_length(self._h))
     def moduli_count(self) -> int: return int(lib().pfhe_dcrt32_moduli_count(self._h))
+    def transform_form(self, words: int, inverse: bool = False):
+        """(name, launches): how transform_dev / inverse_transform_dev will run `words` u32 words of data."""
+        buf, k = C.create_string_buffer(112), C.c_int(0)
+        check(lib().pfhe_dcrt32_transform_form(self._h, words, int(inverse), buf, len(buf), C.byref(k)))
+        return buf.value.decode(), int(k.value)
+
     def crt_poly_length(self) -> int: return int(lib().pfhe_dcrt32_crt_poly_length(self._h))
     def device(self) -> int: return int(lib().pfhe_dcrt32_device(self._h))
     def moduli(self): return [int(lib().pfhe_dcrt32_modulus(self._h, i)) for i in range(self.moduli_count())]

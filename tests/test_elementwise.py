@@ -254,25 +254,16 @@ def test_gpu_properties_at_benchmark_size(pf):
 @pytest.mark.gpu
 @pytest.mark.parametrize("log_n", [8, 9, 10, 12, 13, 14, 15])
 def test_gpu_monomial_in_place_forms_agree(pf, log_n):
-    """mul_monomial_assign: rings of 2^9 .. 2^14 words rotate inside one workgroup's registers, others through a
-    scratch tile; both equal the out-of-place kernel for every kind of degree."""
-    import os
+    """mul_monomial_assign: rings of 2^9 .. 2^14 words rotate inside one workgroup's registers, others (2^8, 2^15 here)
+    through a scratch tile; both equal the out-of-place kernel for every kind of degree."""
     import torch
     n, polys = 1 << log_n, 37
     t = pf.U64DcrtTable(log_n, Q61)
     a = torch.empty(polys * 3 * n, dtype=torch.int64, device="cuda")
     t.fill_uniform_dev(a, log_n)
     exp = torch.empty_like(a)
-    os.environ["PFHE_DISABLE_MONOMIAL_INPLACE"] = "1"  # switches are read when a table is created
-    try:
-        t_scratch = pf.U64DcrtTable(log_n, Q61)
-    finally:
-        del os.environ["PFHE_DISABLE_MONOMIAL_INPLACE"]
     for r in (0, 1, 3, n // 2 + 1, n - 1, n, n + 2, 2 * n - 1):
         t.mul_monomial_to_dev(a, r, exp)
         x = a.clone()
         t.mul_monomial_assign_dev(x, r)
         assert torch.equal(x, exp), r
-        y = a.clone()
-        t_scratch.mul_monomial_assign_dev(y, r)
-        assert torch.equal(y, exp), r

@@ -44,8 +44,7 @@ def pf():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("switch", [None, "PFHE_DISABLE_FUSED_DECOMPOSE",
-                                    "PFHE_DISABLE_FUSED_EXTPROD"])
+@pytest.mark.parametrize("switch", [None, "PFHE_DISABLE_FUSED_EXTPROD"])
 @pytest.mark.parametrize("log_n,k,moduli,log_basis,batch", [(12, 1, Q61, 30, 3), (13, 2, Q61[:2], 20, 2), (10, 1, Q61[:1], 10, 1100),
                                                             (9, 1, Q61, 30, 5), (16, 1, Q61, 30, 2)])
 def test_gpu_matches_oracle(pf, orc, switch, log_n, k, moduli, log_basis, batch):

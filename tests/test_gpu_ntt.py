@@ -458,178 +458,30 @@ def test_fused_polymul_large_batch_tiled_path(pf, orc, shared):
     inv_plain = a.clone()
     d.inverse_transform_dev(inv_plain)
     assert torch.equal(inv_plain, inv_tiled)
-    os.environ["PFHE_DISABLE_FUSED_POLYMUL"] = "1"
-    os.environ["PFHE_DISABLE_PIPELINED"] = "1"
-    try:
-        d_plain = pf.U64DcrtTable(log_n, Q61)
-    finally:
-        del os.environ["PFHE_DISABLE_FUSED_POLYMUL"]
-        del os.environ["PFHE_DISABLE_PIPELINED"]
+    # the same product composed from the separate entry points (transform, point-wise product, inverse transform)
     plain = a.clone()
-    d_plain.mul_dcrt_polynomial_dev(plain, bh)
+    d_tiled.transform_dev(plain)
+    d_tiled.mul_assign_dev(plain, bh)
+    d_tiled.inverse_transform_dev(plain)
     assert torch.equal(fused, plain)
-    # d fuses forward block pass -> product -> inverse block pass in one kernel (three HBM passes); the four-pass form
-    # (forward transform, then the product on the loads of the inverse transform's block pass) stays as the fallback
-    os.environ["PFHE_DISABLE_POLYMUL_MID"] = "1"
-    try:
-        d_four = pf.U64DcrtTable(log_n, Q61)
-    finally:
-        del os.environ["PFHE_DISABLE_POLYMUL_MID"]
-    four = a.clone()
-    d_four.mul_dcrt_polynomial_dev(four, bh)
-    assert torch.equal(fused, four)
-    for e in (0, 179, 359):
-        x = to_host(a[e * W:(e + 1) * W]).copy()
-        o.transform_slice(x)
-        o.mul_assign(x, to_host(bh[:W] if shared else bh[e * W:(e + 1) * W]).copy())
-        o.inverse_transform_slice(x)
-        assert np.array_equal(to_host(fused[e * W:(e + 1) * W]), x)
 
 
-def test_tables_are_shareable_between_host_threads(pf, orc):
-    """NttTable: Send + Sync (ntt/mod.rs:16): several host threads use one table concurrently, each on
-    its own stream and buffers, including the large-batch path that borrows pooled internal streams."""
-    import threading
-    import torch
-    log_n = 14
-    n, L = 1 << log_n, 3
-    d, o = pf.U64DcrtTable(log_n, Q61), orc.U64DcrtTable(log_n, Q61)
-    rng = np.random.default_rng(77)
-    inputs = [rand_rns(rng, Q61, n, 6) for _ in range(4)]
-    refs = []
-    for a in inputs:
-        r = a.copy(); o.transform_slice(r); refs.append(r)
-    results, errors = [None] * 4, []
-
-    def worker(i):
-        try:
-            s = torch.cuda.Stream()
-            x = to_dev(inputs[i])
-            with torch.cuda.stream(s):
-                for _ in range(20):
-                    d.transform_dev(x, stream=s)
-                    d.inverse_transform_dev(x, stream=s)
-                d.transform_dev(x, stream=s)
-            s.synchronize()
-            results[i] = to_host(x)
-        except Exception as e:  # pragma: no cover
-            errors.append(e)
-
-    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
-    [t.start() for t in threads]
-    [t.join() for t in threads]
-    assert not errors, errors
-    for got, ref in zip(results, refs):
-        assert np.array_equal(got, ref)
-
-
-@pytest.mark.parametrize("log_n,q", [(18, Q61[0]), (19, 132120577), (20, Q61[0]), (20, 132120577)])
-def test_largest_degrees(pf, orc, log_n, q):
-    """Up to the reference's MAX_DEGREE_BITS = 20 (prime64/avx512/internal.rs:2): two strided passes + block pass,
-    both arithmetic policies (2^61 - 2^21 + 1 is pseudo-Mersenne, 132120577 is not)."""
-    rng = np.random.default_rng(log_n)
-    n = 1 << log_n
-    t, o = pf.U64NttTable(log_n, q), orc.U64NttTable(log_n, q)
-    assert t.root() == o.root
-    a = rand_mod(rng, q, 2 * n)
-    ref = a.copy(); o.transform_slice(ref)
-    d = to_dev(a)
-    t.transform_dev(d)
-    assert np.array_equal(to_host(d), ref)
-    t.inverse_transform_dev(d)
-    assert np.array_equal(to_host(d), a)
-
-
-def test_handles_release_their_device_memory(pf):
-    """Creating and destroying tables, bases, converters and external-product plans does not leak HBM."""
-    import gc
-    import os
-    import torch
-    if os.environ.get("PYTEST_XDIST_WORKER"):
-        pytest.skip("device-wide free-memory readings are meaningless while other xdist workers allocate")
-
-    def cycle():
-        t = pf.U64DcrtTable(12, Q61)
-        base = pf.RNSBase(Q61)
-        basis = pf.BigUintApproxSignedBasis(base, 30)
-        ctx = pf.DcrtGlevContext(t, base, basis, 1, 4)
-        conv = pf.BaseConverter(base, pf.RNSBase(Q61[:2]))
-        t32 = pf.U32DcrtTable(12, [132120577, 536813569])
-        x = torch.zeros(3 << 12, dtype=torch.int64, device="cuda")
-        t.transform_dev(x)
-        del ctx, conv, basis, base, t, t32, x
-
-    cycle()
-    gc.collect()
-    torch.cuda.synchronize()
-    free0, _ = torch.cuda.mem_get_info()
-    for _ in range(50):
-        cycle()
-    gc.collect()
-    torch.cuda.synchronize()
-    torch.cuda.empty_cache()
-    free1, _ = torch.cuda.mem_get_info()
-    assert free0 - free1 < 64 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 50 create/destroy cycles"
-
-
-@pytest.mark.parametrize("q", [Q61[1], 4611686018425815041])  # pseudo-Mersenne arithmetic / generic (Shoup) arithmetic
-def test_pipelined_form_single_modulus_lazy_and_ragged_tiles(pf, orc, q):
-    """The pipelined form behind U64NttTable (L = 1) at a batch that does not divide into equal tiles: canonical and
-    lazy outputs, forward and inverse, against the oracle on the elements either side of every tile boundary."""
-    import torch
-    log_n, batch = 16, 523  # 523 * 512 KiB = 261.5 MiB -> 2 tiles of 261 and 262 polynomials
-    n = 1 << log_n
-    d, o = pf.U64NttTable(log_n, q), orc.U64NttTable(log_n, q)
-    rng = np.random.default_rng(5)
-    a = rand_mod(rng, q, n * batch)
-    probe = [0, 1, 260, 261, 262, 522]
-
-    def expect(fn, src):
-        out = {}
-        for e in probe:
-            r = src[e * n:(e + 1) * n].copy()
-            fn(r)
-            out[e] = r
-        return out
-
-    x = to_dev(a)
-    d.transform_dev(x)
-    fwd = to_host(x.clone())
-    for e, r in expect(o.transform_slice, a).items():
-        assert np.array_equal(fwd[e * n:(e + 1) * n], r), e
-    xl = to_dev(a)
-    d.transform_dev(xl, lazy=True)
-    lz = to_host(xl.clone())
-    assert int(lz.max()) < 4 * q and np.array_equal(lz % np.uint64(q), fwd)
-    xi = to_dev(fwd)  # the lazy inverse takes [0, 2q): the canonical spectrum
-    d.inverse_transform_dev(xi, lazy=True)
-    li = to_host(xi.clone())
-    assert int(li.max()) < 2 * q and np.array_equal(li % np.uint64(q), a)
-    d.inverse_transform_dev(x)
-    assert np.array_equal(to_host(x), a)
-    del xl
-
-
-@pytest.mark.parametrize("L,batch,tiles,ramp", [(3, 171, 0, 0), (3, 173, 5, 0), (1, 513, 3, 0), (1, 700, 7, 3), (3, 352, 64, 4),
-                                                (2, 257, 0, 2)])
-def test_pipelined_form_tile_arithmetic(pf, L, batch, tiles, ramp, monkeypatch):
-    """Odd batch sizes, tile counts that do not divide them, more tiles than is sensible, ramped tile sizes: the
-    pipelined form must equal the two plain launches bit for bit, forward and inverse (switches are read when a table
-    is created)."""
+@pytest.mark.parametrize("L,batch,tiles", [(3, 171, 0), (3, 173, 5), (1, 513, 3), (1, 700, 7), (3, 352, 64), (2, 257, 0)])
+def test_pipelined_form_tile_arithmetic(pf, L, batch, tiles, monkeypatch):
+    """Odd batch sizes, tile counts that do not divide them, more tiles than is sensible: the pipelined form must equal
+    the two plain launches bit for bit, forward and inverse (switches are read when a table is created)."""
     import torch
     log_n = 16
     n = 1 << log_n
     moduli = Q61[:L]
     if tiles:
         monkeypatch.setenv("PFHE_PIPE_TILES", str(tiles))
-    if ramp:
-        monkeypatch.setenv("PFHE_PIPE_RAMP", str(ramp))
     t = pf.U64DcrtTable(log_n, moduli)
     name, launches = t.transform_form(batch * L * n)
     assert name == "ntt_pipe_fwd_kernel" and launches >= 3
     monkeypatch.setenv("PFHE_DISABLE_PIPELINED", "1")
     plain = pf.U64DcrtTable(log_n, moduli)
-    assert plain.transform_form(batch * L * n) == ("plain passes", 2)
+    assert plain.transform_form(batch * L * n) == ("ntt_strided_kernel<K=4,fwd> + ntt_block_kernel<12,fwd>", 2)
     x = _fill(pf, batch * L * n, moduli, n, 1234 + batch)
     y = x.clone()
     t.transform_dev(x)
@@ -647,12 +499,16 @@ def test_transform_form_reports_the_launch_plan(pf, monkeypatch):
     assert t.transform_form(4096 * L * n) == ("ntt_pipe_fwd_kernel", 25)
     assert t.transform_form(4096 * L * n, inverse=True) == ("ntt_pipe_inv_kernel", 25)
     assert t.transform_form(256 * L * n) == ("ntt_pipe_fwd_kernel", 3)      # 384 MiB: 2 tiles
-    assert t.transform_form(64 * L * n) == ("plain passes", 2)
-    assert pf.U64DcrtTable(12, [Q61[0]]).transform_form(1 << 12) == ("plain passes", 1)
+    assert t.transform_form(64 * L * n) == ("ntt_strided_kernel<K=4,fwd> + ntt_block_kernel<12,fwd>", 2)
+    assert pf.U64DcrtTable(12, [Q61[0]]).transform_form(1 << 12) == ("ntt_block_kernel<12,fwd>", 1)
+    t14 = pf.U64DcrtTable(14, [Q61[0]])     # BASELINE config 2: resident workgroups from two polynomials per CU
+    assert t14.transform_form(4096 << 14) == ("ntt_persist_kernel<14,fwd>", 1)
+    assert t14.transform_form(4096 << 14, inverse=True) == ("ntt_persist_kernel<14,inv>", 1)
+    assert t14.transform_form(16 << 14) == ("ntt_block_kernel<14,fwd>", 1)
     monkeypatch.setenv("PFHE_DISABLE_PIPELINED", "1")
     t2 = pf.U64DcrtTable(16, Q61)
-    assert t2.transform_form(4096 * L * n) == ("plain passes", 2)
-    assert t2.transform_form(4096 * L * n, inverse=True) == ("plain passes", 2)
+    assert t2.transform_form(4096 * L * n) == ("ntt_strided_kernel<K=4,fwd> + ntt_block_kernel<12,fwd>", 2)
+    assert t2.transform_form(4096 * L * n, inverse=True) == ("ntt_block_kernel<12,inv> + ntt_strided_kernel<K=4,inv>", 2)
     with pytest.raises(pf.PfheError) as e:
         t.transform_form(5)
     assert e.value.kind == "BadLength"
@@ -889,21 +745,22 @@ def test_generic_primes_large_batch_pipelined(pf, orc):
 @pytest.mark.parametrize("moduli,shared", [(Q61[:1], True), (Q61[:2], False), (GENERIC[:1], True)])
 def test_polymul_2p14_resident_workgroups(pf, orc, moduli, shared, monkeypatch):
     """N = 2^14 batches of at least two polynomials per CU take ntt_persist_mid_kernel (resident workgroups that prefetch
-    their next polynomial): same words as one workgroup per polynomial (PFHE_DISABLE_PERSIST) on the whole batch, and the
-    oracle on the first, a middle and the last element; pseudo-Mersenne and Montgomery arithmetic, ragged shares (601)."""
+    their next polynomial): same words as one workgroup per polynomial — what a call on fewer polynomials than that runs,
+    here the same batch in slices of 64 units — and the oracle on the first, a middle and the last element;
+    pseudo-Mersenne and Montgomery arithmetic, ragged shares (601)."""
     import torch
     log_n, units = 14, 601
     n, L = 1 << log_n, len(moduli)
     W = L * n
     d, o = pf.U64DcrtTable(log_n, moduli), orc.U64DcrtTable(log_n, moduli)
-    monkeypatch.setenv("PFHE_DISABLE_PERSIST", "1")
-    d1 = pf.U64DcrtTable(log_n, moduli)
-    monkeypatch.delenv("PFHE_DISABLE_PERSIST")
+    assert d.transform_form(units * W)[0] == "ntt_persist_kernel<14,fwd>" and d.transform_form(64 * W)[0] == "ntt_block_kernel<14,fwd>"
     a = _fill(pf, units * W, moduli, n, 141)
     bh = _fill(pf, W if shared else units * W, moduli, n, 142)
     x, y = a.clone(), a.clone()
     d.mul_dcrt_polynomial_dev(x, bh)
-    d1.mul_dcrt_polynomial_dev(y, bh)
+    for u0 in range(0, units, 64):
+        u1 = min(units, u0 + 64)
+        d.mul_dcrt_polynomial_dev(y[u0 * W:u1 * W], bh if shared else bh[u0 * W:u1 * W])
     assert torch.equal(x, y)
     for e in (0, 300, units - 1):
         r = to_host(a[e * W:(e + 1) * W]).copy()
@@ -913,26 +770,24 @@ def test_polymul_2p14_resident_workgroups(pf, orc, moduli, shared, monkeypatch):
         assert np.array_equal(to_host(x[e * W:(e + 1) * W]), r), e
     # the transforms alone, both directions, same comparison
     f, f1 = a.clone(), a.clone()
-    d.transform_dev(f); d1.transform_dev(f1)
+    d.transform_dev(f)
+    for u0 in range(0, units, 64):
+        d.transform_dev(f1[u0 * W:min(units, u0 + 64) * W])
     assert torch.equal(f, f1)
     d.inverse_transform_dev(f)
     assert torch.equal(f, a)
 
 
 @pytest.mark.parametrize("env,log_n,batch", [
-    ({"PFHE_MAX_SINGLE_PASS_LOG": "9"}, 10, 5),     # 1 strided stage + blocks of 2^9
-    ({"PFHE_MAX_SINGLE_PASS_LOG": "9"}, 13, 3),     # blocks of 2^12 below N = 2^14's single-pass limit
-    ({"PFHE_BLOCK_LOG": "8"}, 16, 2),               # blocks of 2^8: two strided passes of 4 stages
-    ({"PFHE_BLOCK_LOG": "10"}, 17, 1),              # 7 strided stages in two passes (4 + 3)
-    ({"PFHE_STRIDED_VEC1": "1"}, 16, 2),            # one column per thread in the strided pass
+    ({"PFHE_DISABLE_PIPELINED": "1"}, 16, 2),       # one launch per pass
     ({"PFHE_PIPELINED_MIN_MB": "1"}, 16, 4),        # the pipelined kernel on a 6 MiB batch
     ({"PFHE_PIPELINED_MIN_MB": "1", "PFHE_PIPE_TILES": "3"}, 16, 5),
 ])
 @pytest.mark.parametrize("generic", [False, True])
 def test_plan_tuning_switches_change_the_plan_not_the_words(pf, orc, env, log_n, batch, generic, monkeypatch):
-    """Every plan switch NttTuning::from_env reads (at table creation) against the oracle: forward, inverse, lazy forward and
-    the polynomial product, pseudo-Mersenne and generic-prime (Montgomery) arithmetic.  The switches only choose how the
-    stages are split over launches."""
+    """The three switches NttTuning::from_env reads (at table creation: PFHE_DISABLE_PIPELINED, PFHE_PIPELINED_MIN_MB,
+    PFHE_PIPE_TILES) against the oracle: forward, inverse, lazy forward and the polynomial product, pseudo-Mersenne and
+    generic-prime (Montgomery) arithmetic.  The switches only choose how the stages are split over launches."""
     n = 1 << log_n
     moduli = Q61[:2]
     for k, v in env.items():
@@ -998,24 +853,3 @@ def test_fused_polymul_contract_canonical_multiplicand_at_its_extremes(pf, orc, 
                 x = to_dev(data.copy())
                 d.mul_dcrt_polynomial_dev(x, to_dev(m))
                 assert np.array_equal(to_host(x), ref)
-
-
-def test_pipelined_form_with_fewer_resident_workgroups_is_the_same_transform(pf, monkeypatch):
-    """PFHE_PIPE_LDS_EXTRA (measurement aid of DESIGN.md §5: unused LDS per workgroup of the pipelined kernels, i.e. three or
-    two resident workgroups per CU instead of four) changes residency, never results."""
-    import torch
-    log_n, L, batch = 16, 3, 171
-    n = 1 << log_n
-    t = pf.U64DcrtTable(log_n, Q61)
-    x = _fill(pf, batch * L * n, Q61, n, 4242)
-    ref = x.clone()
-    t.transform_dev(ref)
-    for extra in (12288, 28672):
-        monkeypatch.setenv("PFHE_PIPE_LDS_EXTRA", str(extra))
-        t2 = pf.U64DcrtTable(log_n, Q61)
-        assert t2.transform_form(batch * L * n)[0] == "ntt_pipe_fwd_kernel"
-        y = x.clone()
-        t2.transform_dev(y)
-        assert torch.equal(y, ref)
-        t2.inverse_transform_dev(y)
-        assert torch.equal(y, x)

@@ -211,7 +211,8 @@ def test_external_product_matches_oracle(pf, orc, log_n, k, moduli, log_basis, r
 def test_wide_digits_generic_primes_and_unfused_path(pf, orc, log_basis, monkeypatch):
     """The digit width is a template parameter of gadget_signed_digits_kernel / digits_strided_kernel (int32 up to
     log B = 31, int64 beyond: big_integer/common.rs:132-140 allows any log B < 64).  Generic-prime (Shoup / Montgomery)
-    tables and the plan without the fused decomposition must give the oracle's words on either side of the switch."""
+    tables, with the fused multiply-accumulate kernel and with the separate transform + multiply-accumulate kernels
+    (PFHE_DISABLE_FUSED_EXTPROD, read when the plan is created), must give the oracle's words."""
     log_n, k, batch = 16, 1, 2
     rng = np.random.default_rng(log_basis)
     otable, glwe, ggsw, exp = make_case(orc, rng, log_n, k, Q61, log_basis, None, batch, True)
@@ -220,10 +221,9 @@ def test_wide_digits_generic_primes_and_unfused_path(pf, orc, log_basis, monkeyp
     monkeypatch.delenv("PFHE_DISABLE_PM")
     basis = pf.BigUintApproxSignedBasis(base, log_basis)
     ctx = pf.DcrtGlevContext(table, base, basis, k)
-    monkeypatch.setenv("PFHE_DISABLE_FUSED_DECOMPOSE", "1")
+    monkeypatch.setenv("PFHE_DISABLE_FUSED_EXTPROD", "1")
     ctx_unfused = pf.DcrtGlevContext(pf.U64DcrtTable(log_n, Q61), base, basis, k)
-    monkeypatch.delenv("PFHE_DISABLE_FUSED_DECOMPOSE")
-    assert ctx.scratch_bytes() > ctx_unfused.scratch_bytes()   # the digit buffer exists only for the split kernels
+    monkeypatch.delenv("PFHE_DISABLE_FUSED_EXTPROD")
     out = np.empty_like(glwe)
     for c in (ctx, ctx_unfused):
         pf.mul_dcrt_ggsw_to(glwe, ggsw, out, c)
@@ -360,11 +360,11 @@ def test_small_ring_fused_path(pf, orc, log_n, moduli, log_basis):
     ell = obasis.decompose_length
     t, base = pf.U64DcrtTable(log_n, moduli), pf.RNSBase(moduli)
     ctx = pf.DcrtGlevContext(t, base, pf.BigUintApproxSignedBasis(base, log_basis), k)
-    os.environ["PFHE_DISABLE_SMALL_EXTPROD"] = "1"  # switches are read when a plan is created
+    os.environ["PFHE_DISABLE_FUSED_EXTPROD"] = "1"  # read when a plan is created: the separate kernels for every shape
     try:
         ctx_plain = pf.DcrtGlevContext(t, base, pf.BigUintApproxSignedBasis(base, log_basis), k)
     finally:
-        del os.environ["PFHE_DISABLE_SMALL_EXTPROD"]
+        del os.environ["PFHE_DISABLE_FUSED_EXTPROD"]
     glwe = rand_rns(rng, moduli, n, batch * (k + 1))
     ggsw = rand_rns(rng, moduli, n, (k + 1) * ell * (k + 1))
     dg, dk = to_dev(glwe), to_dev(ggsw)
@@ -394,11 +394,10 @@ def test_small_ring_fused_path(pf, orc, log_n, moduli, log_basis):
         assert np.array_equal(got[e * W:(e + 1) * W], a)
 
 
-def test_pipelined_chunks_equal_serial_chunks(pf):
-    """Chunks of a batch run one after the other by default; a plan created under PFHE_EXTPROD_PIPELINE=1 overlaps
-    the decomposition of chunk c+1 with the transforms of chunk c on two internal streams.  Same words either way,
-    for the fused (N = 2^12) and the unfused (N = 2^9) kernels."""
-    import os
+def test_chunked_batch_equals_one_chunk(pf):
+    """Chunks of a batch run one after the other on the caller's stream: a plan with chunks of 2 ciphertexts (4 chunks, the
+    last one short) gives the words of a plan that holds the whole batch, for the fused (N = 2^12) and the unfused
+    (N = 2^9) kernels, with one GGSW per ciphertext."""
     import torch
     for log_n in (12, 9):
         k, batch, n = 1, 7, 1 << log_n
@@ -409,13 +408,8 @@ def test_pipelined_chunks_equal_serial_chunks(pf):
         dg = to_dev(rand_rns(rng, Q61, n, batch * (k + 1)))
         dk = to_dev(rand_rns(rng, Q61, n, batch * (k + 1) * ell * (k + 1)))  # one GGSW per ciphertext
         outs = []
-        for pipeline in (False, True):
-            if pipeline:
-                os.environ["PFHE_EXTPROD_PIPELINE"] = "1"
-            try:
-                ctx = pf.DcrtGlevContext(t, base, basis, k, 2)  # chunks of 2 ciphertexts: 4 chunks, the last one short
-            finally:
-                os.environ.pop("PFHE_EXTPROD_PIPELINE", None)
+        for chunk in (2, 16):
+            ctx = pf.DcrtGlevContext(t, base, basis, k, chunk)
             out = torch.zeros_like(dg)
             pf.mul_dcrt_ggsw_to_dev(dg, dk, out, ctx, into_coeff_form=True)
             outs.append(out)
@@ -467,8 +461,8 @@ def test_config4_full_batch_every_ciphertext(pf, orc):
 def test_fused_inverse_tail_equals_separate_inverse(pf, orc, log_n, batch, shared, generic, monkeypatch):
     """Coefficient-form output of the fused path (two-pass rings, k = 1): the multiply-accumulate kernel runs the inverse
     transform's block pass on its accumulators and a strided pass finishes (DcrtGlwe::into_coeff_form,
-    macros/mod.rs:901-911).  Same words as the plan created under PFHE_DISABLE_FUSED_TAIL (separate inverse transform)
-    and as the oracle; pseudo-Mersenne and generic-prime arithmetic, shared and per-ciphertext keys."""
+    macros/mod.rs:901-911).  Same words as the NTT-form product followed by the table's inverse transform, and as the
+    oracle; pseudo-Mersenne and generic-prime arithmetic, shared and per-ciphertext keys."""
     import torch
     k = 1
     rng = np.random.default_rng(1000 + log_n + batch)
@@ -481,9 +475,6 @@ def test_fused_inverse_tail_equals_separate_inverse(pf, orc, log_n, batch, share
     basis = pf.BigUintApproxSignedBasis(base, 30)
     ell = basis.decompose_length()
     ctx = pf.DcrtGlevContext(table, base, basis, k)
-    monkeypatch.setenv("PFHE_DISABLE_FUSED_TAIL", "1")
-    ctx_sep = pf.DcrtGlevContext(table, base, basis, k)
-    monkeypatch.delenv("PFHE_DISABLE_FUSED_TAIL")
     G, K = ctx.glwe_len(), ctx.ggsw_len()
     # the first ciphertexts are the oracle's case; the rest of the batch (enough to take the fused kernels) is random
     oc = glwe.size // G
@@ -493,24 +484,24 @@ def test_fused_inverse_tail_equals_separate_inverse(pf, orc, log_n, batch, share
     dg, dk = to_dev(full_g), to_dev(full_k)
     fused, sep = torch.zeros_like(dg), torch.zeros_like(dg)
     pf.mul_dcrt_ggsw_to_dev(dg, dk, fused, ctx, into_coeff_form=True)
-    pf.mul_dcrt_ggsw_to_dev(dg, dk, sep, ctx_sep, into_coeff_form=True)
+    pf.mul_dcrt_ggsw_to_dev(dg, dk, sep, ctx)
+    table.inverse_transform_dev(sep)
     assert torch.equal(fused, sep)
     otable.inverse_transform_slice(exp)
     assert np.array_equal(to_host(fused[:oc * G]), exp)
 
 
-@pytest.mark.parametrize("min_wgs,log_n", [("1", 16), ("100000", 16), ("1", 13)])
-def test_fused_kernel_threshold_switch(pf, orc, min_wgs, log_n, monkeypatch):
-    """PFHE_FUSED_MIN_WGS (read at plan creation) moves the batch size from which the fused block pass + multiply-accumulate
-    kernel is taken: one ciphertext through the fused kernel, a batch through the separate kernels — the oracle's words
-    either way, NTT form and coefficient form."""
-    k, batch = 1, (1 if min_wgs == "1" else 12)
+@pytest.mark.parametrize("batch,log_n", [(1, 16), (2, 16), (4, 16), (12, 16), (3, 13), (40, 13)])
+def test_fused_kernel_threshold(pf, orc, batch, log_n):
+    """The fused block pass + multiply-accumulate kernel is taken once a call offers 160 workgroups (N = 2^16, 3 limbs: from
+    4 ciphertexts; N = 2^13: from 27), the separate kernels below: the oracle's words on either side of the threshold, NTT
+    form and coefficient form."""
+    k = 1
     rng = np.random.default_rng(9090 + log_n + batch)
     otable, glwe, ggsw, exp = make_case(orc, rng, log_n, k, Q61, 30, None, 1, True)
     n = 1 << log_n
     table, base = pf.U64DcrtTable(log_n, Q61), pf.RNSBase(Q61)
     basis = pf.BigUintApproxSignedBasis(base, 30)
-    monkeypatch.setenv("PFHE_FUSED_MIN_WGS", min_wgs)
     ctx = pf.DcrtGlevContext(table, base, basis, k)
     G = ctx.glwe_len()
     full = np.concatenate([glwe, rand_rns(rng, Q61, n, (batch - 1) * (k + 1))]) if batch > 1 else glwe

@@ -412,7 +412,7 @@ def test_slice_spanning_two_registrations_is_not_treated_as_one_pinned_range(pf,
 
 
 def test_idle_contexts_are_capped_and_the_helper_thread_is_reused(pf, orc):
-    """A burst of concurrent callers leaves at most PFHE_STAGE_IDLE_MAX (4) contexts behind; the helper thread of a
+    """A burst of concurrent callers leaves at most four contexts behind; the helper thread of a
     context is started once and parked between calls (no thread per call)."""
     import os
     log_n = 14

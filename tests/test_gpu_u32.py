@@ -198,18 +198,14 @@ def test_u32_and_u64_tables_agree_on_the_gpu(pf, log_n):
 @pytest.mark.parametrize("batch,tiles", [(1400, 0), (1371, 5)])
 def test_u32_pipelined_inverse_equals_plain_passes(pf, orc, batch, tiles, monkeypatch):
     """Round 5: from 1 GiB of u32 data the N = 2^16 transforms take the pipelined form (ntt_pipe_{fwd,inv}_kernel<B32Arith,
-    11>, tiles of 512 MiB); PFHE_NO_PIPE_U32 keeps the forward one on its two plain launches.  Ragged batches and tile
-    counts: bit-identical to the two plain launches in both directions, oracle on the polynomials either side of the tile
-    boundaries."""
+    11>, tiles of 512 MiB).  Ragged batches and tile counts: bit-identical to the two plain launches in both directions,
+    oracle on the polynomials either side of the tile boundaries."""
     import torch
     log_n = 16
     n, L = 1 << log_n, 3
     if tiles:
         monkeypatch.setenv("PFHE_PIPE_TILES", str(tiles))
     t = pf.U32DcrtTable(log_n, Q30)
-    monkeypatch.setenv("PFHE_NO_PIPE_U32", "1")
-    t_fwd = pf.U32DcrtTable(log_n, Q30)          # forward on plain launches, inverse pipelined (the form until round 5)
-    monkeypatch.delenv("PFHE_NO_PIPE_U32")
     monkeypatch.setenv("PFHE_DISABLE_PIPELINED", "1")
     t_plain = pf.U32DcrtTable(log_n, Q30)
     monkeypatch.delenv("PFHE_DISABLE_PIPELINED")
@@ -219,9 +215,7 @@ def test_u32_pipelined_inverse_equals_plain_passes(pf, orc, batch, tiles, monkey
     orig = x.clone()
     y = orig.clone()
     t_plain.transform_dev(y)
-    z = orig.clone()
-    t_fwd.transform_dev(z)                       # forward: plain launches (switch)
-    assert torch.equal(z, y)
+    z = y.clone()
     t.transform_dev(x)                           # forward: pipelined by default
     assert torch.equal(x, y)
     for e in sorted({0, 1, batch // 5, batch // 2 - 1, batch // 2, batch - 1}):

@@ -15,7 +15,6 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 # kernel-name prefix -> scratch bytes per lane tolerated
 ALLOWED = {
-    "ntt_strided_kernel<B32Arith, 4, 1": 12,      # one-column strided pass of the u32 tables (tuning switch PFHE_STRIDED_VEC1)
     "ntt_pipe_mid_kernel<PmArith": 12,            # three roles in 128 registers
     "ntt_pipe_mid_kernel<MontArith": 20,
     "extprod_small_kernel<PmArith": 12,           # small rings, two waves per SIMD by design

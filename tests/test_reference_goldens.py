@@ -20,10 +20,14 @@ import pytest
 
 import pyref
 from golden_inputs import digest, splitmix_rns, splitmix_uniform
+from primes import ntt_primes_below
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REFERENCE_FILE = os.path.join(HERE, "golden", "reference_digests.json")
 Q61 = pyref.Q61
+W9 = ntt_primes_below(9, 61, 4)     # the nine largest primes below 2^61 that are 1 mod 32 (emit_golden: const W9)
+Q60 = ntt_primes_below(3, 60, 4)    # conversion target (const Q60)
+Q30 = [1073479681, 1071513601, 1070727169]
 
 # cases beyond tests/golden/digests.json that integration/emit_golden emits too (keep in step with its main.rs)
 EXTRA_CASES = [
@@ -33,6 +37,12 @@ EXTRA_CASES = [
     dict(kind="gadget_digits", case=0, moduli=[str(q) for q in Q61], log_basis=30, count=4096, seed=0x340),
     dict(kind="rns_compose", case=1, moduli=[str(q) for q in Q61], count=1000, seed=0x341),
     dict(kind="gadget_digits", case=1, moduli=[str(q) for q in Q61], log_basis=13, count=1000, seed=0x341),
+    # round 6: a base of nine moduli (compose, digits, conversion into three 60-bit moduli) and the u32 external product
+    dict(kind="rns_compose", case=2, moduli=[str(q) for q in W9], count=2048, seed=0x342),
+    dict(kind="gadget_digits", case=2, moduli=[str(q) for q in W9], log_basis=30, count=2048, seed=0x342),
+    dict(kind="base_convert", case=0, moduli=[str(q) for q in W9], moduli_out=[str(q) for q in Q60], count=2048, seed=0x342),
+    dict(kind="external_product32", case=0, log_n=10, k=1, moduli=[str(q) for q in Q30], log_basis=15, batch=2,
+         seed_glwe=0x720, seed_ggsw=0x730),
 ]
 
 
@@ -77,6 +87,20 @@ class OracleBackend:
         return np.concatenate([self.o.mul_dcrt_ggsw_to(t, base, basis, k, glwe[e * W:(e + 1) * W].copy(), ggsw)
                                for e in range(glwe.size // W)])
 
+    def base_convert(self, moduli, moduli_out, residues, count):
+        inp = self.o.RNSBase(moduli)
+        fast = self.o.BaseConverter(inp, self.o.RNSBase(moduli_out)).fast_convert_array(residues, count)
+        exact = self.o.BaseConverter(inp, self.o.RNSBase(moduli_out[:1])).exact_convert_array(residues, count)
+        return np.concatenate([fast, exact])
+
+    def external_product32(self, log_n, k, moduli, log_basis, glwe, ggsw_of):
+        t, base = self.o.U32DcrtTable(log_n, moduli), self.o.RNSBase32(moduli)
+        basis = self.o.BigUintApproxSignedBasis32(base, log_basis)
+        ggsw = ggsw_of(basis.decompose_length)
+        W = (k + 1) * t.crt_poly_length
+        return np.concatenate([self.o.mul_dcrt32_ggsw_to(t, base, basis, k, glwe[e * W:(e + 1) * W].copy(), ggsw)
+                               for e in range(glwe.size // W)])
+
     def compose_and_digits(self, moduli, log_basis, residues, count):
         base = self.o.RNSBase(moduli)
         vals = base.compose_multiple_values_to(residues, count)
@@ -119,6 +143,22 @@ class HipBackend:
         t, base = self.p.U64DcrtTable(log_n, moduli), self.p.RNSBase(moduli)
         basis = self.p.BigUintApproxSignedBasis(base, log_basis)
         ctx = self.p.DcrtGlevContext(t, base, basis, k)
+        out = np.empty_like(glwe)
+        self.p.mul_dcrt_ggsw_to(glwe, ggsw_of(basis.decompose_length()), out, ctx)
+        return out
+
+    def base_convert(self, moduli, moduli_out, residues, count):
+        inp = self.p.RNSBase(moduli)
+        fast = np.empty(len(moduli_out) * count, np.uint64)
+        self.p.BaseConverter(inp, self.p.RNSBase(moduli_out)).fast_convert_array(residues, fast, count)
+        exact = np.empty(count, np.uint64)
+        self.p.BaseConverter(inp, self.p.RNSBase(moduli_out[:1])).exact_convert_array(residues, exact, count)
+        return np.concatenate([fast, exact])
+
+    def external_product32(self, log_n, k, moduli, log_basis, glwe, ggsw_of):
+        t, base = self.p.U32DcrtTable(log_n, moduli), self.p.RNSBase32(moduli)
+        basis = self.p.BigUintApproxSignedBasis32(base, log_basis)
+        ctx = self.p.DcrtGlevContext32(t, base, basis, k)
         out = np.empty_like(glwe)
         self.p.mul_dcrt_ggsw_to(glwe, ggsw_of(basis.decompose_length()), out, ctx)
         return out
@@ -168,6 +208,15 @@ def compute(entry, be):
         glwe = splitmix_rns(entry["seed_glwe"], moduli, n, entry["batch"] * (k + 1))
         ggsw_of = lambda ell: splitmix_rns(entry["seed_ggsw"], moduli, n, (k + 1) * ell * (k + 1))  # noqa: E731
         return digest(be.external_product(entry["log_n"], k, moduli, entry["log_basis"], glwe, ggsw_of)), {}
+    if kind == "external_product32":
+        n, k = 1 << entry["log_n"], entry["k"]
+        glwe = splitmix_rns(entry["seed_glwe"], moduli, n, entry["batch"] * (k + 1)).astype(np.uint32)
+        ggsw_of = lambda ell: splitmix_rns(entry["seed_ggsw"], moduli, n, (k + 1) * ell * (k + 1)).astype(np.uint32)  # noqa: E731
+        return digest_u32(be.external_product32(entry["log_n"], k, moduli, entry["log_basis"], glwe, ggsw_of)), {}
+    if kind == "base_convert":
+        count = entry["count"]
+        residues = splitmix_rns(entry["seed"], moduli, count, 1)
+        return digest(be.base_convert(moduli, [int(m) for m in entry["moduli_out"]], residues, count)), {}
     if kind in ("rns_compose", "gadget_digits"):
         count = entry["count"]
         residues = splitmix_rns(entry["seed"], moduli, count, 1)
@@ -237,13 +286,13 @@ def handmade(orc, cases, source):
     return {"source": source, "generator": "tests/test_reference_goldens.py (oracle, NOT the reference)", "digests": out}
 
 
-SMALL = [c for c in all_cases() if c.get("log_n", 0) <= 12 or c["kind"] in ("rns_compose", "gadget_digits")]
+SMALL = [c for c in all_cases() if c.get("log_n", 0) <= 12 or c["kind"] in ("rns_compose", "gadget_digits", "base_convert")]
 
 
 def test_consumer_accepts_a_faithful_file_and_reports_a_tampered_one(orc, tmp_path):
     doc = handmade(orc, SMALL, "hand-made from the oracle (consumer self-test)")
     assert {e["kind"] for e in doc["digests"]} == {"ntt_forward", "dcrt_polymul", "external_product", "ntt32_forward",
-                                                   "rns_compose", "gadget_digits"}
+                                                   "rns_compose", "gadget_digits", "base_convert", "external_product32"}
     good = tmp_path / "reference_digests.json"
     good.write_text(json.dumps(doc, indent=1))
     problems, _ = check_reference_file(str(good), OracleBackend(orc))
@@ -319,8 +368,24 @@ def test_rust_generator_and_python_consumer_list_the_same_cases():
     assert u32 == [(c["log_n"], int(c["q"]), c["batch"]) for c in EXTRA_CASES if c["kind"] == "ntt32_forward"]
     assert "0x810 + cid as u64" in src and all(c["seed"] == 0x810 + c["case"] for c in EXTRA_CASES if c["kind"] == "ntt32_forward")
     gad = tuples(r"for \(cid, &\(log_basis, count\)\) in ")
-    assert gad == [(c["log_basis"], c["count"]) for c in EXTRA_CASES if c["kind"] == "gadget_digits"]
-    assert "0x300 + 0x40 + cid as u64" in src and all(c["seed"] == 0x340 + c["case"] for c in EXTRA_CASES if c["kind"] != "ntt32_forward")
+    assert gad == [(c["log_basis"], c["count"]) for c in EXTRA_CASES if c["kind"] == "gadget_digits" and c["case"] < 2]
+    assert "0x300 + 0x40 + cid as u64" in src
+    assert all(c["seed"] == 0x340 + c["case"] for c in EXTRA_CASES if c["kind"] in ("rns_compose", "gadget_digits"))
+    # round 6: the nine-modulus base (cases 2: `cid = wid + 2`), its conversion, and the u32 external product
+    assert "const W9: [u64; 9] = [%s];" % ", ".join(str(q) for q in W9) in src
+    assert "const Q60: [u64; 3] = [%s];" % ", ".join(str(q) for q in Q60) in src
+    assert "const Q30: [u32; 3] = [%s];" % ", ".join(str(q) for q in Q30) in src
+    wide = tuples(r"for \(wid, &\(log_basis, count\)\) in ")
+    assert "let cid = wid + 2;" in src
+    assert wide == [(c["log_basis"], c["count"]) for c in EXTRA_CASES if c["kind"] == "gadget_digits" and c["case"] >= 2]
+    conv = [c for c in EXTRA_CASES if c["kind"] == "base_convert"]
+    assert len(conv) == 1 and conv[0]["count"] == wide[0][1] and conv[0]["seed"] == 0x342
+    ext32 = tuples(r"for \(cid32, &\(log_n, k, log_basis, batch\)\) in ")
+    assert ext32 == [(c["log_n"], c["k"], c["log_basis"], c["batch"]) for c in EXTRA_CASES if c["kind"] == "external_product32"]
+    assert "(0x720 + cid as u64, 0x730 + cid as u64)" in src
+    assert all((c["seed_glwe"], c["seed_ggsw"]) == (0x720 + c["case"], 0x730 + c["case"])
+               for c in EXTRA_CASES if c["kind"] == "external_product32")
     # every kind the generator writes is one the consumer knows
     kinds = set(re.findall(r'\\"kind\\": \\"([a-z0-9_]+)\\"', src))
-    assert kinds == {"ntt_forward", "dcrt_polymul", "external_product", "ntt32_forward", "rns_compose", "gadget_digits"}
+    assert kinds == {"ntt_forward", "dcrt_polymul", "external_product", "ntt32_forward", "rns_compose", "gadget_digits",
+                     "base_convert", "external_product32"}

@@ -252,3 +252,40 @@ def test_bench_spawner_ends_the_other_ranks_when_one_dies(monkeypatch):
     rc = bench.spawn_ranks(types.SimpleNamespace(gpus=3, one_device=True, master_port=0))
     assert rc == 15 or rc == 3
     assert procs[0].terminated and procs[2].terminated and not procs[1].terminated
+
+
+def test_bench_line_fields_of_round_6():
+    """the line carries config 3 with a per-element multiplicand beside the shared one, a device-copy
+    bandwidth measured in the run (`roofline.peak_measured`, `frac_of_measured`), the prime shape and the generic-prime
+    roofline, roofline objects for the inverse / N = 2^14 / u32 legs, the u32 external product, and `oracle_pin`.  Checked on
+    the helpers (CPU) and on the newest bench line committed under profiles/ (what the GPU box printed)."""
+    import glob
+    import json
+
+    import bench
+    pin = bench.oracle_pin()
+    have = os.path.exists(os.path.join(ROOT, "tests", "golden", "reference_digests.json"))
+    assert pin.startswith("pinned" if have else "unpinned")
+    r = bench.leg_roofline("k<A, 1>", 4, 2.0, 8e9, {"bytes_per_launch": 4e9, "source": "x", "method": "m", "provenance": {}}, 6000.0)
+    assert r["avg_launch_ms"] == 0.5 and r["achieved"] == 4000.0 and r["frac"] == 0.5 and abs(r["frac_of_measured"] - 2 / 3) < 1e-12
+    assert r["algorithmic_bytes_per_launch"] == 2e9 and r["traffic_vs_algorithmic"] == 2.0
+    assert bench.leg_roofline("k", 1, 1.0, 1e9, None)["traffic"] is None
+    t = bench.profile_traffic("ntt_pipe_inv_kernel", {0: "PmArith", 2: "false"})
+    assert t is not None and "profile_matches_build" in t["provenance"]
+    assert bench.profile_traffic("no_such_kernel", {}) is None
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r06_*_bench.json")))
+    if not lines:
+        pytest.skip("no round-6 bench line committed yet")
+    b = json.load(open(lines[-1]))
+    assert b["oracle_pin"].startswith(("pinned", "unpinned"))
+    assert "pseudo-Mersenne" in b["config"]["prime_shape"]
+    assert b["device_copy"]["GBps"] > 3000
+    for obj in (b["roofline"], b["roofline_generic"], b["intt"]["roofline"], b["ntt_2p14"]["forward"]["roofline"],
+                b["ntt_2p14"]["inverse"]["roofline"], b["ntt_u32"]["roofline"], b["ntt_u32"]["inverse"]["roofline"],
+                b["polymul"]["roofline"], b["polymul_per_element"]["roofline"], b["external_product"]["roofline"],
+                b["external_product_u32"]["roofline"]):
+        assert obj["bound"] == "hbm" and 0 < obj["frac"] < 1 and obj["peak_measured"] == b["device_copy"]["GBps"]
+        assert abs(obj["frac_of_measured"] * obj["peak_measured"] - obj["frac"] * obj["peak"]) < 1e-6 * obj["peak"]
+    assert b["polymul_per_element"]["algorithmic_bytes_per_product"] == 72 * 65536
+    assert b["polymul"]["algorithmic_bytes_per_product"] == 48 * 65536
+    assert b["roofline_generic"]["frac"] < b["roofline"]["frac"]

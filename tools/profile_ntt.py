@@ -67,5 +67,28 @@ check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(cin.data_ptr()), cin.numel(), 
 conv = p.BaseConverter(base, p.RNSBase([1152921504606584833, 1152921504598720513]))
 cout = torch.empty(2 * (1 << 26), dtype=torch.int64, device="cuda")
 conv.fast_convert_array_dev(cin, cout, 1 << 26)
+# round 6: the rows bench.py's per-leg roofline objects look up
+# BASELINE config 2 (N = 2^14, one prime, batch 4096: ntt_persist_kernel), forward and inverse
+t14 = p.U64DcrtTable(14, Q61[:1])
+x14 = x[:4096 << 14]
+check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(x14.data_ptr()), x14.numel(), mods.ctypes.data_as(u64p), 1, 1 << 14, 14, None))
+t14.transform_dev(x14)
+t14.inverse_transform_dev(x14)
+# generic-prime arithmetic (Montgomery form) on the headline shape: one forward transform
+check(p.lib().pfhe_fill_uniform_dev(0, C.c_void_p(x.data_ptr()), words, mods.ctypes.data_as(u64p), L, n, 4, None))
+os.environ["PFHE_DISABLE_PM"] = "1"
+t_gen = p.U64DcrtTable(16, Q61)
+del os.environ["PFHE_DISABLE_PM"]
+t_gen.transform_dev(x)
+# the <u32> external product on 64 ciphertexts (three 30-bit primes, log B = 15)
+q30 = [1073479681, 1071513601, 1070727169]
+base32 = p.RNSBase32(q30)
+ctx32 = p.DcrtGlevContext32(t32, base32, p.BigUintApproxSignedBasis32(base32, 15), 1, 8)
+g32 = x32[:ep * 2 * L * n]
+t32.fill_uniform_dev(g32, 8)
+k32 = torch.empty(ctx32.ggsw_len(), dtype=torch.int32, device="cuda")
+t32.fill_uniform_dev(k32, 9)
+o32 = torch.empty_like(g32)
+p.mul_dcrt_ggsw_to_dev(g32, k32, o32, ctx32, into_coeff_form=True)
 torch.cuda.synchronize()
 print("profile workload done")
