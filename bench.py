@@ -907,10 +907,12 @@ def main():
                                                      "coefficient form)",
             "batch": eb32, "ms_per_batch": ms_ep32, "moduli": q30, "gadget": {"log_basis": 15, "ell": basis32.decompose_length(), "k": 1},
             "algorithmic_bytes_per_product": 48 * n, "hbm_roofline_frac": alg32 / (ms_ep32 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "roofline": leg_roofline("gadget_decompose_kernel<u32> + ntt_pipe_fwd_kernel<B32Arith, 11> + gadget_mulacc32_kernel + "
-                                     "inverse transform of the result", 1, ms_ep32, alg32, None, copy_gbs,
-                                     "unfused plan: the 36 lifted digit polynomials (u32) are written, transformed in place "
-                                     "and read back by the multiply-accumulate kernel")}
+            "roofline": leg_roofline("gadget_signed_digits_kernel<u32> + digits_strided32_kernel + gadget_block_mulacc32_kernel "
+                                     "(block pass + multiply-accumulate + inverse block pass) + inverse strided pass", 1, ms_ep32,
+                                     alg32, None, copy_gbs,
+                                     "the 64-bit plan's kernels on B32Arith words (two u32 coefficients per 64-bit word): the "
+                                     "36 half-transformed digit polynomials are written and read once, their transforms stay "
+                                     "on chip")}
         del k32, o32, ctx32
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)

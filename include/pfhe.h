@@ -88,9 +88,11 @@ int pfhe_stream_synchronize(int device, void *stream);
  * buffer (pageable slices, and since round 5 slices the caller merely REGISTERED with hipHostRegister: kernels running on a
  * per-call registration return rare wrong words on this platform with plain HIP alone — tools/microbench12_register_hazard.hip),
  * 2 copy engines on caller-pinned memory (allocated or registered), 3 the runtime's pageable copies, 4 long pageable slices
- * with the copy back on the context's helper thread.
- * Every entry point clears the calling thread's pending HIP error (hipGetLastError is sticky per thread) on the way in, so
- * that an earlier failed HIP call of the caller's own is not reported as a failure of this library's launches.
+ * with the copy back on the context's helper thread, 5 small uploads of the non-transform entry points: a CPU copy into the
+ * pool's pinned buffer + a copy-engine transfer.
+ * Every entry point clears the calling thread's pending HIP error (hipGetLastError is sticky per thread) on the way in — the
+ * outermost one of a call only — so that an earlier failed HIP call of the caller's own is not reported as a failure of
+ * this library's launches: check the return values of your own HIP calls, not hipGetLastError after a pfhe_* call.
  * Streams: since round 4 the host-pointer entry points run on PRIVATE non-blocking streams of the borrowed context, not on
  * the legacy null stream: they are ordered with respect to nothing the caller has queued elsewhere (they block until
  * their own work is done, which is all `&mut [T]` semantics need). */

@@ -60,8 +60,10 @@ struct pfhe_extprod_plan {
 };
 
 // The <u32> instantiation of the same product: CrtGlwe<u32>::mul_dcrt_ggsw_to over a U32DcrtTable (glwe/crt.rs:200-227,
-// dcrt/prime32.rs:11).  Steps (1)-(4) fused (gadget_decompose_kernel on u32 words: the lifted digit polynomials, u32),
-// the table's forward transform over all of them, one multiply-accumulate kernel, chunk after chunk on the caller's stream.
+// dcrt/prime32.rs:11).  N = 2^16, k = 1 (the bench shape) takes the 64-bit plan's kernels on B32Arith: balanced int32
+// digits, lift + strided pass, block pass + multiply-accumulate (+ inverse block pass) with the transformed digits on chip.
+// Every other shape: steps (1)-(4) fused (gadget_decompose_kernel on u32 words), the table's forward transform over the
+// lifted digit polynomials, one multiply-accumulate kernel.  Chunk after chunk on the caller's stream.
 struct pfhe_extprod32_plan {
     const TableSet *table = nullptr;  // borrowed from the pfhe_dcrt32 (must outlive the plan)
     std::atomic<std::uintptr_t> owner{0};  // one holder at a time, as pfhe_extprod_plan
@@ -75,10 +77,13 @@ struct pfhe_extprod32_plan {
     size_t chunk = 1;
     u32 *digits = nullptr;  // chunk * (k+1) * ell * L * N words
     size_t digits_words = 0;
+    int *sdigits = nullptr;  // N = 2^16, k = 1 (the fused kernels): chunk * (k+1) * ell * N balanced digits
+    bool use_fused = true;   // PFHE_DISABLE_FUSED_EXTPROD, read at plan creation
     ~pfhe_extprod32_plan() {
         if (!table) return;
         DeviceGuard g(table->device);
         if (digits) (void)counted_free(digits);
+        if (sdigits) (void)counted_free(sdigits);
         if (last_done) (void)hipEventDestroy(last_done);
     }
 };
@@ -1013,8 +1018,12 @@ int pfhe_extprod_mul_dcrt_ggsw_to(pfhe_extprod_plan *plan, const uint64_t *crt_g
 
 namespace {
 
+// *coeff_passes (when the caller wants coefficient form): 1 = the inverse transform's block pass ran inside the fused
+// kernel (the caller runs the strided pass), 0 = none
 int run_product32(pfhe_extprod32_plan *p, const u32 *polys, u32 rows, const u32 *keys, bool keys_shared, u32 *result,
-                  u64 batch, bool accumulate, hipStream_t s, bool big_input) {
+                  u64 batch, bool accumulate, hipStream_t s, bool big_input, bool into_coeff = false,
+                  int *coeff_passes = nullptr) {
+    if (coeff_passes) *coeff_passes = 0;
     const TableSet &t = *p->table;
     const bool tracked = p->last_done != nullptr && !stream_is_capturing(s);
     if (tracked && p->last_valid) PFHE_HIP(hipStreamWaitEvent(s, p->last_done, 0));
@@ -1024,18 +1033,31 @@ int run_product32(pfhe_extprod32_plan *p, const u32 *polys, u32 rows, const u32 
     const u64 in_words = big_input ? (u64)rns.dev.value_words * t.n : W;
     const u32 ell = p->basis.ell;
     const u64 key_words = (u64)rows * ell * (p->k + 1) * W;
+    // the fused kernels launch one workgroup per (ciphertext, limb, block): they pay once that fills the chip
+    const bool fused = p->sdigits != nullptr && p->use_fused && extprod32_fused_supported(t.log_n, p->k) &&
+                       ((std::min<u64>(batch, p->chunk) * t.L) << (t.log_n - 12)) >= 160;
+    const bool inv_tail = fused && into_coeff && !accumulate && coeff_passes != nullptr;
+    if (inv_tail) *coeff_passes = 1;
     int rc = PFHE_OK;
     for (u64 done = 0; done < batch && rc == PFHE_OK; done += p->chunk) {
         const u64 cur = std::min<u64>(p->chunk, batch - done);
+        const u32 *kp = keys + (keys_shared ? 0 : done * key_words);
+        u32 *rp = result + done * (p->k + 1) * W;
+        if (fused) {
+            rc = gadget_signed_digits_dev<u32>(rns, p->basis_par, t.log_n, polys + done * rows * in_words, p->sdigits, cur * rows, s);
+            if (rc == PFHE_OK) rc = digits_strided32_dev(t.primes_dev, t.L, t.log_n, ell, p->sdigits, p->digits, cur * rows, s);
+            if (rc == PFHE_OK)
+                rc = gadget_block_mulacc32_dev(t.primes_dev, t.L, t.log_n, rows * ell, p->digits, kp, keys_shared, rp, cur,
+                                               accumulate, inv_tail, s);
+            continue;
+        }
         rc = gadget_decompose_dev<u32>(rns, p->basis_par, t.log_n, polys + done * rows * in_words, p->digits, cur * rows, s);
         if (rc == PFHE_OK)
             rc = ntt32_transform_dev(t.primes_dev, t.L, t.log_n, p->digits, cur * rows * ell * t.L, false, false, s, t.tune);
         if (rc == PFHE_OK)
-            rc = gadget_mulacc32_dev(t.primes_dev, t.L, t.log_n, p->k, rows, ell, p->digits,
-                                     keys + (keys_shared ? 0 : done * key_words), keys_shared,
-                                     result + done * (p->k + 1) * W, cur, accumulate, s);
+            rc = gadget_mulacc32_dev(t.primes_dev, t.L, t.log_n, p->k, rows, ell, p->digits, kp, keys_shared, rp, cur, accumulate, s);
     }
-    if (tracked) {  // also after a failed call: whatever it queued still uses the buffer
+    if (tracked) {  // also after a failed call: whatever it queued still uses the buffers
         if (hipEventRecord(p->last_done, s) == hipSuccess) {
             p->last_valid = true;
         } else {
@@ -1113,9 +1135,15 @@ int pfhe_extprod32_plan_create(const pfhe_dcrt32 *table, const pfhe_rns32 *rns, 
     p->digits_words = p->chunk * (p->k + 1) * p->basis.ell * t->L * t->n;
     DeviceGuard g(t->device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
+    p->use_fused = std::getenv("PFHE_DISABLE_FUSED_EXTPROD") == nullptr;
     void *d = nullptr;
     PFHE_HIP(counted_malloc(&d, p->digits_words * sizeof(u32)));
     p->digits = (u32 *)d;
+    if (p->use_fused && extprod32_fused_supported(t->log_n, p->k)) {
+        void *sd = nullptr;
+        PFHE_HIP(counted_malloc(&sd, p->chunk * (p->k + 1) * p->basis.ell * t->n * sizeof(int)));
+        p->sdigits = (int *)sd;
+    }
     PFHE_HIP(hipEventCreateWithFlags(&p->last_done, hipEventDisableTiming));
     *out = p.release();
     return PFHE_OK;
@@ -1126,7 +1154,10 @@ void pfhe_extprod32_plan_destroy(pfhe_extprod32_plan *p) { delete p; }
 int pfhe_extprod32_plan_in_use(const pfhe_extprod32_plan *p) {
     return p && p->owner.load(std::memory_order_acquire) != 0 ? 1 : 0;
 }
-size_t pfhe_extprod32_plan_scratch_bytes(const pfhe_extprod32_plan *p) { return p ? p->digits_words * sizeof(u32) : 0; }
+size_t pfhe_extprod32_plan_scratch_bytes(const pfhe_extprod32_plan *p) {
+    if (!p) return 0;
+    return p->digits_words * sizeof(u32) + (p->sdigits ? p->chunk * (p->k + 1) * p->basis.ell * p->table->n * sizeof(int) : 0);
+}
 
 int pfhe_extprod32_mul_dcrt_ggsw_to_dev(pfhe_extprod32_plan *plan, const uint32_t *crt_glwe_dev, size_t len_glwe,
                                         const uint32_t *dcrt_ggsw_dev, size_t len_ggsw, uint32_t *result_dev,
@@ -1151,11 +1182,15 @@ int pfhe_extprod32_mul_dcrt_ggsw_to_dev(pfhe_extprod32_plan *plan, const uint32_
     DeviceGuard g(t.device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
     // result.set_zero() (glwe/crt.rs:217) is implied: the multiply-accumulate overwrites
+    int coeff_passes = 0;
     PFHE_TRY(run_product32(plan, crt_glwe_dev, plan->k + 1, dcrt_ggsw_dev, len_ggsw == ggsw, result_dev, batch, false,
-                           (hipStream_t)stream, false));
-    if (into_coeff_form)  // DcrtGlwe::into_coeff_form, macros/mod.rs:901-911
+                           (hipStream_t)stream, false, into_coeff_form != 0, &coeff_passes));
+    if (into_coeff_form && coeff_passes == 0)  // DcrtGlwe::into_coeff_form, macros/mod.rs:901-911
         PFHE_TRY(ntt32_transform_dev(t.primes_dev, t.L, t.log_n, result_dev, batch * (plan->k + 1) * t.L, true, false,
                                      (hipStream_t)stream, t.tune));
+    if (into_coeff_form && coeff_passes == 1)  // the block pass ran inside the fused kernel: the strided pass finishes
+        PFHE_TRY(ntt_pass_dev(t.primes_dev, t.L, t.log_n - 1, kArithB32, reinterpret_cast<u64 *>(result_dev),
+                              batch * (plan->k + 1) * t.L, true, 1, false, (hipStream_t)stream, nullptr, 0, t.tune));
     return PFHE_OK;
     PFHE_GUARD_END
 }

@@ -218,27 +218,26 @@ __global__ __launch_bounds__(LOGE == 3 ? 512 : 256, LOGE == 3 ? kMulacc8MinWaves
 // CPT coefficients per thread.  Two adjacent ones for big integers of at most 4 limbs held by value (16-byte loads of
 // the residues, one store of the digit pair: every BASELINE config); one for longer integers and for the device-table
 // form of a wide base (RT = RnsWide, BT = BasisDev or BasisWide), whose residues are fetched as the lift consumes them.
-template <int LEN, class DT, class RT, class BT, int CPT>
+template <int LEN, class DT, class RT, class BT, int CPT, class WT = u64>
 __global__ __launch_bounds__(256) void gadget_signed_digits_kernel(RT R, BT B, u32 log_n,
-                                                                  const u64 *__restrict__ crt, DT *__restrict__ out,
+                                                                  const WT *__restrict__ crt, DT *__restrict__ out,
                                                                   u64 total_threads) {
     const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= total_threads) return;
     const u32 n = 1u << log_n;
     const u64 poly = (gid * CPT) >> log_n;
     const u32 t = (u32)((gid * CPT) & (n - 1));
-    const u32 vl = kByValue<RT> ? (u32)LEN : R.value_len;
     u64 v[CPT][LEN];
     if (R.big_input) {  // BigUintPolynomial input (glwe/dcrt.rs:258-338): already composed
+        const u32 vw = words_of<LEN, WT>(R);
 #pragma unroll
-        for (int e = 0; e < CPT; ++e)
-#pragma unroll
-            for (int j = 0; j < LEN; ++j) v[e][j] = (u32)j < vl ? crt[(poly * n + t + e) * vl + j] : 0;
+        for (int e = 0; e < CPT; ++e) load_limbs<LEN, WT>(crt + (poly * n + t + e) * vw, vw, v[e]);
     } else if constexpr (kByValue<RT>) {
         u64 r[CPT][kMaxLimbs];
         for (u32 i = 0; i < R.L; ++i) {
-            if constexpr (CPT == 2) {
-                const u64x2 w = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(crt + (poly * R.L + i) * n + t));  // read once
+            if constexpr (CPT == 2) {  // two adjacent residues in one load (16 bytes of u64 words, 8 bytes of u32 words), read once
+                typedef WT WT2 __attribute__((ext_vector_type(2)));
+                const WT2 w = __builtin_nontemporal_load(reinterpret_cast<const WT2 *>(crt + (poly * R.L + i) * n + t));
                 r[0][i] = w.x;
                 r[1][i] = w.y;
             } else {
@@ -250,7 +249,7 @@ __global__ __launch_bounds__(256) void gadget_signed_digits_kernel(RT R, BT B, u
     } else {
 #pragma unroll
         for (int e = 0; e < CPT; ++e)
-            compose_general<LEN>(R, [&](u32 i) { return __builtin_nontemporal_load(crt + (poly * R.L + i) * n + t + e); }, v[e]);
+            compose_general<LEN>(R, [&](u32 i) { return (u64)__builtin_nontemporal_load(crt + (poly * R.L + i) * n + t + e); }, v[e]);
     }
     u32 carry[CPT];
 #pragma unroll
@@ -273,23 +272,23 @@ __global__ __launch_bounds__(256) void gadget_signed_digits_kernel(RT R, BT B, u
 }
 
 // steps (1)-(3) for `npolys` polynomials of 2^log_n coefficients (log_n >= 1), any base the handles accept
-template <class DT>
+template <class DT, class WT = u64>
 struct SignedDigitsLaunch {
     template <int LEN>
     struct At {
-        static int run(const RnsParams &r, const BasisParams &b, u32 log_n, const u64 *crt, DT *sdigits, u64 npolys, hipStream_t s) {
+        static int run(const RnsParams &r, const BasisParams &b, u32 log_n, const WT *crt, DT *sdigits, u64 npolys, hipStream_t s) {
             const u64 coeffs = npolys << log_n;
             constexpr int CPT = LEN <= 4 ? 2 : 1;
             if (b.wide()) {
-                hipLaunchKernelGGL((gadget_signed_digits_kernel<LEN, DT, RnsWide, BasisWide, 1>), dim3((u32)((coeffs + 255) / 256)), dim3(256), 0, s,
+                hipLaunchKernelGGL((gadget_signed_digits_kernel<LEN, DT, RnsWide, BasisWide, 1, WT>), dim3((u32)((coeffs + 255) / 256)), dim3(256), 0, s,
                                    r.wide_tab, b.wide_tab, log_n, crt, sdigits, coeffs);
             } else if constexpr (LEN <= kMaxLimbs) {
                 if (r.wide()) {
-                    hipLaunchKernelGGL((gadget_signed_digits_kernel<LEN, DT, RnsWide, BasisDev, 1>), dim3((u32)((coeffs + 255) / 256)), dim3(256), 0, s,
+                    hipLaunchKernelGGL((gadget_signed_digits_kernel<LEN, DT, RnsWide, BasisDev, 1, WT>), dim3((u32)((coeffs + 255) / 256)), dim3(256), 0, s,
                                        r.wide_tab, b.dev, log_n, crt, sdigits, coeffs);
                 } else {
                     const u64 threads = coeffs / CPT;
-                    hipLaunchKernelGGL((gadget_signed_digits_kernel<LEN, DT, RnsDev, BasisDev, CPT>), dim3((u32)((threads + 255) / 256)), dim3(256), 0, s,
+                    hipLaunchKernelGGL((gadget_signed_digits_kernel<LEN, DT, RnsDev, BasisDev, CPT, WT>), dim3((u32)((threads + 255) / 256)), dim3(256), 0, s,
                                        r.dev, b.dev, log_n, crt, sdigits, threads);
                 }
             }
@@ -337,6 +336,179 @@ int launch_digits_strided(const RnsParams &r, const BasisParams &b, const NttPri
                        log_n, (const DT *)sdigits, digits, total);
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// The <u32> product (CrtGlwe<u32> x DcrtGgsw over U32DcrtTable) at N = 2^16, k = 1: the same two fused kernels on
+// B32Arith, where a 64-bit word carries two adjacent u32 coefficients and a polynomial is 2^15 words = 2^4 strided
+// stages x blocks of 2^11 words (+ the intra-word stage inside the block core).
+//   digits_strided32_kernel: a thread owns one word column of one (polynomial, level): reads its 2^K pairs of balanced
+//     int32 digits once and, for every limb, lifts both halves, runs the K strided stages in registers and stores where
+//     the forward transform's strided pass would have stored.
+//   gadget_block_mulacc32_kernel: a workgroup (256 threads x 8 words) owns one 2^11-word block of one limb of one
+//     ciphertext: block pass of every digit polynomial on chip (canonical output), key x digit products accumulated
+//     lazily in one 64-bit register per coefficient — ONE v_mad_u64_u32 per coefficient and term (products below 2^60,
+//     folded by a single-word Barrett step every 8 terms) — then the fold, optionally the inverse transform's block pass,
+//     and the store.  The transformed digits never reach HBM.
+// ------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256, 4) void digits_strided32_kernel(const NttPrime *__restrict__ primes, u32 L, u32 log_nw,
+                                                                 const int *__restrict__ dig, u64 *__restrict__ out,
+                                                                 u64 total_threads) {
+    constexpr int RK = 1 << K;
+    typedef int int2v __attribute__((ext_vector_type(2)));
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total_threads) return;
+    const u32 log_s = log_nw - K;
+    const u32 nw = 1u << log_nw;
+    const u32 col = (u32)(gid & ((1ull << log_s) - 1));
+    const u64 pl = gid >> log_s;  // (input polynomial, level)
+    const int2v *__restrict__ src = reinterpret_cast<const int2v *>(dig) + pl * nw + col;
+    int2v d[RK];
+#pragma unroll
+    for (int k = 0; k < RK; ++k) d[k] = __builtin_nontemporal_load(src + ((u64)k << log_s));  // read once
+#pragma unroll 1
+    for (u32 i = 0; i < L; ++i) {
+        const B32Arith ar(primes + i);
+        u64 x[RK][1];
+        // centred lift (base.rs:279-312) of both halves: d >= 0 -> d, d < 0 -> q_i - |d|
+#pragma unroll
+        for (int k = 0; k < RK; ++k)
+            x[k][0] = B32Arith::pack((u32)d[k].x + (d[k].x < 0 ? ar.q : 0u), (u32)d[k].y + (d[k].y < 0 ? ar.q : 0u));
+        strided_forward_regs<B32Arith, K, 1, true>(ar, x, nw, 0u, log_s);
+        u64 *__restrict__ dst = out + (pl * L + i) * nw + col;
+#pragma unroll
+        for (int k = 0; k < RK; ++k) gstore<true>(dst + ((u64)k << log_s), x[k][0]);
+    }
+}
+
+// x mod q for any 64-bit x, q < 2^30, bar = floor(2^64 / q): the quotient estimate is exact or one short
+__device__ __forceinline__ u32 fold32(u64 x, u32 q, u64 bar) {
+    const u64 r = x - mulhi64(x, bar) * q;
+    return (u32)(r >= q ? r - q : r);
+}
+
+template <int NC>
+__global__ __launch_bounds__(256, 4) void gadget_block_mulacc32_kernel(const u64 *__restrict__ digits,
+                                                                      const u64 *__restrict__ ggsw, u64 ggsw_stride,
+                                                                      u64 *__restrict__ result,
+                                                                      const NttPrime *__restrict__ primes, u32 L, u32 log_nw,
+                                                                      u32 terms, u64 total_blocks, u32 accumulate,
+                                                                      u32 inv_tail) {
+    using A = B32Arith;
+    constexpr int LOGB = 11, LOGE = 3, E = 1 << LOGE, NV = E / 2;
+    extern __shared__ __attribute__((aligned(16))) u64 lds[];
+    const u32 lt = threadIdx.x;
+    const u64 blk = blockIdx.x;
+    if (blk >= total_blocks) return;
+    const u32 log_nb = log_nw - LOGB;
+    const u32 nw = 1u << log_nw;
+    // blk -> (ciphertext e, limb r, block bi), XCD-aware as in gadget_block_mulacc_kernel: XCD x keeps the (limb, block) pairs
+    // whose block index is x (mod 8) and walks all ciphertexts of one pair before it turns to the next
+    const u32 nb = 1u << log_nb;
+    u32 bi, r;
+    u64 e;
+    if (nb >= 8) {
+        const u64 batch = total_blocks / ((u64)L << log_nb);
+        const u32 xcd = (u32)(blk & 7), per = nb >> 3;
+        const u64 i = blk >> 3;
+        const u32 pr = (u32)(i / batch);
+        e = i - (u64)pr * batch;
+        r = pr / per;
+        bi = xcd + 8u * (pr - r * per);
+    } else {
+        bi = (u32)(blk & (nb - 1));
+        const u64 er = blk >> log_nb;
+        r = (u32)(er % L);
+        e = er / L;
+    }
+    const NttPrime *__restrict__ P = primes + r;
+    const A ar(P);
+    const u32 q = ar.q;
+    const u64 bar = P->bar_lo;
+    const u32 eblk = bi << LOGB;
+    const u64 W = (u64)L << log_nw;  // words per RNS polynomial
+    const u64 limb_off = ((u64)r << log_nw) + eblk;
+    const u64 *__restrict__ dg = digits + e * terms * W + limb_off;
+    const u64 *__restrict__ key = ggsw + e * ggsw_stride + limb_off;
+    u64 *__restrict__ out = result + e * NC * W + limb_off;
+
+    u64 acc[NC][2 * E];  // one lazy accumulator per coefficient: coefficient 4j + 2h + half of vector j, word h
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int m = 0; m < 2 * E; ++m) acc[c][m] = 0;
+
+    u32 ij = 0;
+    do {  // terms >= 1 (checked on the host)
+        u64 x[E];
+        u64x2 io[NV];
+        u32 ltl = lt;
+        asm volatile("" : "+v"(ltl));  // per-term addresses are recomputed, not carried around the loop
+#pragma unroll
+        for (int k = 0; k < E; ++k) x[k] = __builtin_nontemporal_load(dg + (u64)ij * W + ((u32)k << (LOGB - LOGE)) + ltl);
+        block_forward_core<A, LOGB, true, LOGE>(ar, x, lds, nw, eblk, ltl, /*lazy=*/false);  // canonical digit_hat
+        lds_put_layout<0, LOGE>(x, lds, ltl);
+        sync_vectors_layout0<LOGB, LOGE>();  // wave-local transposition
+        lds_get_vectors<LOGB, LOGE>(io, lds, ltl);  // natural order: same positions as the key vectors
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            u64x2 kv[NV];
+            load_block_vectors<LOGB, LOGE>(kv, key + ((u64)ij * NC + c) * W, ltl);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                acc[c][4 * j + 0] += (u64)(u32)io[j].x * (u32)kv[j].x;
+                acc[c][4 * j + 1] += (io[j].x >> 32) * (kv[j].x >> 32);
+                acc[c][4 * j + 2] += (u64)(u32)io[j].y * (u32)kv[j].y;
+                acc[c][4 * j + 3] += (io[j].y >> 32) * (kv[j].y >> 32);
+            }
+        }
+        if ((ij & 7u) == 7u) {  // eight products below 2^60 on top of a folded value: below 2^63 + 2^30
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int m = 0; m < 2 * E; ++m) acc[c][m] = fold32(acc[c][m], q, bar);
+        }
+    } while (++ij < terms);
+
+    auto epilogue = [&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        u64 *__restrict__ oc = out + (u64)c * W;
+        u32 lte = lt;
+        asm volatile("" : "+v"(lte));
+        u64x2 v[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            v[j].x = A::pack(fold32(acc[c][4 * j + 0], q, bar), fold32(acc[c][4 * j + 1], q, bar));
+            v[j].y = A::pack(fold32(acc[c][4 * j + 2], q, bar), fold32(acc[c][4 * j + 3], q, bar));
+        }
+        if (accumulate) {  // DcrtGlwe::add_dcrt_glev_mul_crt_poly_assign: acc += previous result (canonical)
+            u64x2 old[NV];
+            load_block_vectors<LOGB, LOGE>(old, oc, lte);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                v[j].x = ar.reduce_2q(v[j].x + old[j].x);  // both halves below 2q < 2^31: no carry between them
+                v[j].y = ar.reduce_2q(v[j].y + old[j].y);
+            }
+        }
+        if (inv_tail) {
+            // DcrtGlwe::into_coeff_form, first pass: the inverse transform's block pass on the accumulators while they
+            // are on chip; what is stored is what the inverse block pass would have left for the strided pass
+            u64 y[E];
+            __syncthreads();  // other threads may still be reading the previous image (last term / previous component)
+            lds_put_vectors<LOGB, LOGE>(v, lds, lte);
+            sync_vectors_layout0<LOGB, LOGE>();
+            lds_get_layout<0, LOGE>(y, lds, lte);
+            block_inverse_core<A, LOGB, false, LOGE>(ar, y, lds, nw, eblk, lte, /*final_block=*/false, /*lazy=*/false);
+#pragma unroll
+            for (int k = 0; k < E; ++k) gstore<true>(oc + ((u32)k << (LOGB - LOGE)) + lte, y[k]);
+        } else {
+            store_block_vectors<LOGB, LOGE>(v, oc, lte);
+        }
+    };
+    epilogue(std::integral_constant<int, 0>{});
+    if constexpr (NC > 1) epilogue(std::integral_constant<int, 1>{});
+    static_assert(NC <= 2, "add an epilogue call per component");
 }
 
 // ------------------------------------------------------------------------------------------
@@ -534,13 +706,16 @@ bool extprod_small_supported(u32 log_n, u32 k, u32 value_len, u32 log_basis) {
 }
 
 // steps (1)-(3) alone: balanced int32 digits of `npolys` CRT polynomials ([poly][level][N])
-int gadget_signed_digits_dev(const RnsParams &r, const BasisParams &b, u32 log_n, const u64 *crt_polys, int *sdigits,
+template <class WT>
+int gadget_signed_digits_dev(const RnsParams &r, const BasisParams &b, u32 log_n, const WT *crt_polys, int *sdigits,
                              u64 npolys, hipStream_t s) {
     if ((npolys << log_n) == 0) return PFHE_OK;
-    PFHE_TRY((dispatch_len<SignedDigitsLaunch<int>::At>(r.dev.value_len, r, b, log_n, crt_polys, sdigits, npolys, s)));
+    PFHE_TRY((dispatch_len<SignedDigitsLaunch<int, WT>::template At>(r.dev.value_len, r, b, log_n, crt_polys, sdigits, npolys, s)));
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
 }
+template int gadget_signed_digits_dev<u64>(const RnsParams &, const BasisParams &, u32, const u64 *, int *, u64, hipStream_t);
+template int gadget_signed_digits_dev<u32>(const RnsParams &, const BasisParams &, u32, const u32 *, int *, u64, hipStream_t);
 
 int extprod_small_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u32 k, u32 rows, u32 ell, const int *sdigits,
                       const u64 *ggsw, bool ggsw_shared, u64 *result, u64 batch, bool accumulate, bool into_coeff,
@@ -554,6 +729,42 @@ int extprod_small_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u32 k
                    : dispatch_extprod_small<ShoupArith, 2>(log_n, sdigits, ggsw, stride, result, primes, L, rows, ell, batch, accumulate, into_coeff, s);
     }
     return PFHE_ERR_UNSUPPORTED;
+}
+
+// ---- the <u32> product's fused kernels: N = 2^16 (2^15 words = 4 strided stages x blocks of 2^11 words), k = 1 ----
+bool extprod32_fused_supported(u32 log_n, u32 k) {
+    if (k != 1 || log_n != 16) return false;
+    const NttPlan plan = make_ntt_plan(log_n - 1, kArithB32);
+    return !plan.tiny && plan.n_strided == 1 && plan.strided[0] == 4 && plan.block_log == 11;
+}
+
+int digits_strided32_dev(const NttPrime *primes, u32 L, u32 log_n, u32 ell, const int *sdigits, u32 *digits, u64 npolys,
+                         hipStream_t s) {
+    if (!extprod32_fused_supported(log_n, 1)) return PFHE_ERR_UNSUPPORTED;
+    const u32 log_nw = log_n - 1;
+    const u64 total = (npolys * ell) << (log_nw - 4);
+    if (total == 0) return PFHE_OK;
+    hipLaunchKernelGGL(digits_strided32_kernel<4>, dim3((u32)((total + 255) / 256)), dim3(256), 0, s, primes, L, log_nw, sdigits,
+                       reinterpret_cast<u64 *>(digits), total);
+    PFHE_HIP(hipGetLastError());
+    return PFHE_OK;
+}
+
+int gadget_block_mulacc32_dev(const NttPrime *primes, u32 L, u32 log_n, u32 terms, const u32 *digits, const u32 *ggsw,
+                              bool ggsw_shared, u32 *result, u64 batch, bool accumulate, bool inv_tail, hipStream_t s) {
+    if (!extprod32_fused_supported(log_n, 1) || terms == 0 || (inv_tail && accumulate)) return PFHE_ERR_UNSUPPORTED;
+    const u32 log_nw = log_n - 1;
+    const u64 total_blocks = (batch * L) << (log_nw - 11);
+    if (total_blocks == 0) return PFHE_OK;
+    if (total_blocks > 0x7fffffffull) return PFHE_ERR_BAD_LENGTH;
+    const u64 ggsw_words = ((u64)terms * 2 * L) << log_nw;  // 64-bit words of one GGSW's rows
+    constexpr size_t lds_bytes = (size_t)BlockCfg<11, 3>::LDS_WORDS * sizeof(u64);
+    hipLaunchKernelGGL((gadget_block_mulacc32_kernel<2>), dim3((u32)total_blocks), dim3(256), lds_bytes, s,
+                       reinterpret_cast<const u64 *>(digits), reinterpret_cast<const u64 *>(ggsw), ggsw_shared ? 0ull : ggsw_words,
+                       reinterpret_cast<u64 *>(result), primes, L, log_nw, terms, total_blocks, accumulate ? 1u : 0u,
+                       inv_tail ? 1u : 0u);
+    PFHE_HIP(hipGetLastError());
+    return PFHE_OK;
 }
 
 // balanced digits are stored as int32 when log_basis <= 31 (|digit| <= 2^(log_basis - 1)), else as int64

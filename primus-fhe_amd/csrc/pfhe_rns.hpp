@@ -192,8 +192,18 @@ int gadget_block_mulacc_dev(const NttPrime *primes, u32 L, u32 log_n, int arith,
 // Small rings (N = 2^10..2^12): digit extraction to int32 + ONE kernel for transforms, multiply-accumulate and
 // (optionally) the inverse transforms (pfhe_extprod.hip, extprod_small_kernel).
 bool extprod_small_supported(u32 log_n, u32 k, u32 value_len, u32 log_basis);
-int gadget_signed_digits_dev(const RnsParams &r, const BasisParams &b, u32 log_n, const u64 *crt_polys, int *sdigits,
+template <class WT>
+int gadget_signed_digits_dev(const RnsParams &r, const BasisParams &b, u32 log_n, const WT *crt_polys, int *sdigits,
                              u64 npolys, hipStream_t s);
+// The <u32> product's fused kernels (pfhe_extprod.hip, B32Arith: two u32 coefficients per 64-bit word) for N = 2^16, k = 1:
+// lift of the balanced digits + the forward transform's strided pass (4 stages) into `digits` ([poly][level][limb][N] u32),
+// then block pass (2^11 words) + multiply-accumulate (+ the inverse transform's block pass when inv_tail) per
+// (ciphertext, limb, block).  The caller finishes a coefficient-form result with the inverse strided pass.
+bool extprod32_fused_supported(u32 log_n, u32 k);
+int digits_strided32_dev(const NttPrime *primes, u32 L, u32 log_n, u32 ell, const int *sdigits, u32 *digits, u64 npolys,
+                         hipStream_t s);
+int gadget_block_mulacc32_dev(const NttPrime *primes, u32 L, u32 log_n, u32 terms, const u32 *digits, const u32 *ggsw,
+                              bool ggsw_shared, u32 *result, u64 batch, bool accumulate, bool inv_tail, hipStream_t s);
 int extprod_small_dev(const NttPrime *primes, u32 L, u32 log_n, int arith, u32 k, u32 rows, u32 ell, const int *sdigits,
                       const u64 *ggsw, bool ggsw_shared, u64 *result, u64 batch, bool accumulate, bool into_coeff,
                       hipStream_t s);

@@ -480,6 +480,7 @@ int HostStage::copy_in(void *dev, const void *host, size_t bytes, hipStream_t s)
         return PFHE_OK;
     }
     if (bytes <= stage_knobs().bounce_max) {
+        stage_path_note(kPathBounceDma);
         void *b = nullptr;
         PFHE_HIP(ctx_->pin.get(bytes, &b));
         std::memcpy(b, host, bytes);

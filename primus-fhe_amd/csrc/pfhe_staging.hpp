@@ -49,7 +49,8 @@ enum StagePath : int {
     kPathDmaCaller = 2,     // copy engines on memory the caller pinned
     kPathPageable = 3,      // the runtime's pageable copies
     kPathHelper = 4,        // long pageable slice, copy back on the context's helper thread
-    kPathCount = 5
+    kPathBounceDma = 5,     // a CPU copy into the pool's pinned buffer + a copy-engine transfer from it (small uploads)
+    kPathCount = 6
 };
 void stage_path_note(StagePath which);
 std::uint64_t stage_path_count(int which);
@@ -86,9 +87,11 @@ class HostStage {
     // a pooled event (timing disabled), the context's until the end of the call
     int take_event(hipEvent_t *out);
 
-    // True when [host, host + bytes) lies in memory the CALLER has pinned: copies from / to it are then true asynchronous
-    // DMA.  Pageable memory is never registered here (see the note on top): it goes through the bounce buffer or the
-    // runtime's pageable path.  copy_in / download call it themselves.
+    // True when [host, host + bytes) lies inside ONE pinned allocation or registration of the CALLER's (hipHostMalloc,
+    // hipHostRegister, a torch pinned tensor): copy engines then read / write it directly (true asynchronous DMA).  KERNELS
+    // are handed such memory only through map(), which accepts driver-allocated memory and refuses registrations.
+    // Pageable memory is never registered here (see the note on top): it goes through the bounce buffer or the runtime's
+    // pageable path.  copy_in / download call it themselves.
     bool pin(const void *host, size_t bytes, bool any_size = false);
     // a region of the pool's pinned, coherent host buffer (valid until the end of the call) and its device-side address
     void *bounce(size_t bytes, void **dev);

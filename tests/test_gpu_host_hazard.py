@@ -62,7 +62,8 @@ def test_registered_slices_are_not_handed_to_kernels():
     merely registered takes the pool's own pinned buffer (short) or the copy engines (long) — path counter 0 must not move
     in a run whose every slice is registered by the caller, counters 1 and 2 must."""
     line = run(["1500", "--register", "--churn-threads", "2", "--seed", "17"])
-    paths = eval(line.split("staging paths ")[1])
+    import ast
+    paths = ast.literal_eval(line.split("staging paths ")[1])
     assert paths[0] == 0 and paths[1] > 500 and paths[2] > 0, line
 
 

@@ -245,3 +245,57 @@ def test_bench_shape_full_batch_every_ciphertext(pf, orc):
     with ThreadPoolExecutor(usable_cores()) as ex:
         ok = list(ex.map(one, range(batch)))
     assert all(ok), [e for e, v in enumerate(ok) if not v][:10]
+
+
+@pytest.mark.parametrize("batch,shared,chunk,log_basis", [(5, True, 0, 15), (7, False, 3, 15), (4, True, 0, 29), (9, True, 4, 7)])
+def test_fused_u32_product_equals_separate_kernels_and_oracle(pf, orc, batch, shared, chunk, log_basis, monkeypatch):
+    """N = 2^16, k = 1, at least four ciphertexts per call: balanced int32 digits, digits_strided32_kernel (lift + strided
+    pass on B32Arith words) and gadget_block_mulacc32_kernel (block pass + multiply-accumulate + inverse block pass) — the
+    same words as the plan created under PFHE_DISABLE_FUSED_EXTPROD (gadget_decompose + the table's transform +
+    gadget_mulacc32) on the whole batch, NTT form and coefficient form, accumulating and overwriting GLev rows on residues
+    and on big integers; the first two ciphertexts against the oracle."""
+    import torch
+    log_n, k = 16, 1
+    n, L = 1 << log_n, 3
+    rng = np.random.default_rng(batch * 31 + log_basis)
+    otable, obase, obasis, glwe2, ggsw2, exp = make_case32(orc, rng, log_n, k, Q30, log_basis, None, 2, shared)
+    table, base = pf.U32DcrtTable(log_n, Q30), pf.RNSBase32(Q30)
+    basis = pf.BigUintApproxSignedBasis32(base, log_basis)
+    ell = basis.decompose_length()
+    ctx = pf.DcrtGlevContext32(table, base, basis, k, chunk)
+    monkeypatch.setenv("PFHE_DISABLE_FUSED_EXTPROD", "1")
+    ctx_sep = pf.DcrtGlevContext32(table, base, basis, k, chunk)
+    monkeypatch.delenv("PFHE_DISABLE_FUSED_EXTPROD")
+    assert ctx.scratch_bytes() > ctx_sep.scratch_bytes()      # the balanced-digit buffer of the fused kernels
+    G, K = ctx.glwe_len(), ctx.ggsw_len()
+    more = batch - 2
+    full_g = np.concatenate([glwe2, rand32(rng, Q30, n, more * (k + 1))])
+    full_k = ggsw2 if shared else np.concatenate([ggsw2, rand32(rng, Q30, n, more * (k + 1) * ell * (k + 1))])
+    dg, dk = to_dev32(full_g), to_dev32(full_k)
+    for coeff in (False, True):
+        fused, sep = torch.zeros_like(dg), torch.zeros_like(dg)
+        pf.mul_dcrt_ggsw_to_dev(dg, dk, fused, ctx, into_coeff_form=coeff)
+        pf.mul_dcrt_ggsw_to_dev(dg, dk, sep, ctx_sep, into_coeff_form=coeff)
+        assert torch.equal(fused, sep), coeff
+        e = exp.copy()
+        if coeff:
+            otable.inverse_transform_slice(e)
+        assert np.array_equal(to_host32(fused[:2 * G]), e), coeff
+    # GLev rows: one row of the GGSW against `batch` polynomials, accumulate and overwrite, residues and big integers
+    W = L * n
+    polys = full_g[:batch * W].copy()
+    glev = full_k[:ell * (k + 1) * W].copy()
+    acc0 = rand32(rng, Q30, n, batch * (k + 1))
+    a1, a2 = to_dev32(acc0), to_dev32(acc0)
+    pf.add_dcrt_glev_mul_crt_poly_assign_dev(a1, to_dev32(glev), to_dev32(polys), ctx)
+    pf.add_dcrt_glev_mul_crt_poly_assign_dev(a2, to_dev32(glev), to_dev32(polys), ctx_sep)
+    assert torch.equal(a1, a2)
+    oacc = acc0[:G].copy()
+    orc.add_dcrt32_glev_mul_crt_poly_assign(otable, obase, obasis, k, oacc, glev, polys[:W].copy())
+    assert np.array_equal(to_host32(a1[:G]), oacc)
+    big = np.empty(batch * n * base.big_uint_value_len(), np.uint32)
+    base.compose_multiple_values_to(np.ascontiguousarray(polys.reshape(batch, L, n).transpose(1, 0, 2)).reshape(-1), big, batch * n)
+    r1, r2 = to_dev32(np.zeros(batch * G, np.uint32)), to_dev32(np.zeros(batch * G, np.uint32))
+    pf.glev_mul_big_uint_poly_to_dev(to_dev32(glev), to_dev32(big), r1, ctx)
+    pf.glev_mul_crt_poly_to_dev(to_dev32(glev), to_dev32(polys), r2, ctx_sep)
+    assert torch.equal(r1, r2)
