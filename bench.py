@@ -333,12 +333,13 @@ def leg_roofline(kernel: str, launches: int, ms_per_batch: float, alg_bytes_per_
     return out
 
 
-def extprod_traffic():
+def extprod_traffic(kind: str = "extprod"):
     """Whole-product HBM bytes per external product from the newest committed counter passes
-    (profiles/*_extprod_traffic.json, written by tools/collect_profiles2.py) — or None when there is none, or when the
-    kernels it was taken on are not the ones in the library being timed (provenance)."""
+    (profiles/*_extprod_traffic.json — kind "extprod32": *_extprod32_traffic.json, the <u32> product — written by
+    tools/collect_profiles2.py) — or None when there is none, or when the kernels it was taken on are not the ones in the
+    library being timed (provenance)."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_extprod_traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_traffic.json" % kind)), reverse=True):
         try:
             d = json.load(open(path))
             prov, ok = provenance(path, {k: (d.get("code_sha256_by_kernel") or {}).get(k)
@@ -913,6 +914,14 @@ def main():
                                      "the 64-bit plan's kernels on B32Arith words (two u32 coefficients per 64-bit word): the "
                                      "36 half-transformed digit polynomials are written and read once, their transforms stay "
                                      "on chip")}
+        tr32 = extprod_traffic("extprod32")   # whole product, every kernel, from the committed counter passes
+        if tr32:
+            rf = result["external_product_u32"]["roofline"]
+            rf["traffic"] = tr32["bytes_per_product"] * eb32 if tr32["bytes_per_product"] else None
+            rf["traffic_unit"] = "bytes per batch of %d products, all kernels of the product (coefficient form)" % eb32
+            rf["traffic_source"] = "from committed profile " + tr32["source"] + ": " + tr32["method"]
+            rf["traffic_provenance"] = tr32["provenance"]
+            rf["traffic_vs_algorithmic"] = tr32["bytes_per_product"] / (48 * n) if tr32["bytes_per_product"] else None
         del k32, o32, ctx32
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_seconds)

@@ -90,25 +90,8 @@ if stf:
         ep.append(f"  {short(r['Name']):58s} calls {int(r['Calls']):5d}  avg {float(r['AverageNs']) / 1e3:9.1f} us  {float(r['Percentage']):6.2f} %")
 ep += counter_table("ep_", "rocprofv3 --pmc <one counter per pass> -- python3 tools/perf_extprod.py (FETCH_SIZE / WRITE_SIZE in KiB as "
                     "reported: reads = 2 x FETCH_SIZE on gfx950)")
-# whole-product HBM traffic: every launch of the COEFF_ONLY counter passes (4 products of batch 1024, coefficient form),
-# 2 x FETCH_SIZE + WRITE_SIZE (KiB as reported; gfx950 correction of MI355X_MICROARCH.md), summed and divided by the products
-ep_vgpr = {}
-
-
-def counter_sum(name):
-    f = newest(f"{src}/ep_{name}/**/*counter_collection.csv")
-    per = collections.defaultdict(float)
-    if f:
-        for r in csv.DictReader(open(f)):
-            k = short(r["Kernel_Name"])
-            if not (k.startswith("__amd") or "fill" in k):
-                per[k] += float(r["Counter_Value"])
-                if r.get("VGPR_Count"):
-                    ep_vgpr[k] = int(r["VGPR_Count"]) + int(r.get("Accum_VGPR_Count") or 0)
-    return per
-
-
-fe, wr = counter_sum("FETCH_SIZE"), counter_sum("WRITE_SIZE")
+# whole-product HBM traffic: every launch of the COEFF_ONLY counter passes (coefficient form), 2 x FETCH_SIZE + WRITE_SIZE
+# (KiB as reported; gfx950 correction of MI355X_MICROARCH.md), summed and divided by the products
 try:  # the code the counters were taken on (bench.py compares it with the library it times)
     sys.path.insert(0, ROOT)
     import primus_fhe_amd as _p
@@ -117,18 +100,53 @@ try:  # the code the counters were taken on (bench.py compares it with the libra
 except Exception as _e:
     print("collect_profiles2: no code hashes:", _e)
     ep_code = {}
-if fe and wr:
-    products = 4 * int(os.environ.get("BATCH", "1024"))
+
+
+def product_traffic(prefix, products, form, alg_bytes):
+    vg = {}
+
+    def counter_sum(name):
+        f = newest(f"{src}/{prefix}{name}/**/*counter_collection.csv")
+        per = collections.defaultdict(float)
+        if f:
+            for r in csv.DictReader(open(f)):
+                k = short(r["Kernel_Name"])
+                if not (k.startswith("__amd") or "fill" in k):
+                    per[k] += float(r["Counter_Value"])
+                    if r.get("VGPR_Count"):
+                        vg[k] = int(r["VGPR_Count"]) + int(r.get("Accum_VGPR_Count") or 0)
+        return per
+
+    fe, wr = counter_sum("FETCH_SIZE"), counter_sum("WRITE_SIZE")
+    if not (fe and wr):
+        return None
     per_kernel = {k: (2 * fe.get(k, 0.0) + wr.get(k, 0.0)) * 1024 / products for k in sorted(set(fe) | set(wr))}
-    traffic = {"products": products, "form": "CrtGlwe x DcrtGgsw -> coefficient form, batch 1024, default chunk",
-               "method": "sum over every kernel launch of 2*FETCH_SIZE + WRITE_SIZE (separate --pmc passes, KiB), / products",
-               "bytes_per_product": sum(per_kernel.values()), "bytes_per_product_by_kernel": per_kernel,
-               "vgpr_count_by_kernel": ep_vgpr,
-               "code_sha256_by_kernel": {k: ep_code.get(k) for k in ep_vgpr},
-               "algorithmic_bytes_per_product": 96 * 65536}
+    return {"products": products, "form": form,
+            "method": "sum over every kernel launch of 2*FETCH_SIZE + WRITE_SIZE (separate --pmc passes, KiB), / products",
+            "bytes_per_product": sum(per_kernel.values()), "bytes_per_product_by_kernel": per_kernel,
+            "vgpr_count_by_kernel": vg, "code_sha256_by_kernel": {k: ep_code.get(k) for k in vg},
+            "algorithmic_bytes_per_product": alg_bytes}
+
+
+traffic = product_traffic("ep_", 4 * int(os.environ.get("BATCH", "1024")),
+                          "CrtGlwe x DcrtGgsw -> coefficient form, batch 1024, default chunk", 96 * 65536)
+if traffic:
     json.dump(traffic, open(f"{dst}/{tag}_extprod_traffic.json", "w"), indent=1)
     ep.append("whole product: %.1f MB moved per product (algorithmic 6.29 MB): " % (traffic["bytes_per_product"] / 1e6) +
-              ", ".join("%s %.1f" % (k, v / 1e6) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1])))
+              ", ".join("%s %.1f" % (k, v / 1e6) for k, v in sorted(traffic["bytes_per_product_by_kernel"].items(), key=lambda kv: -kv[1])))
+# the <u32> product: tools/perf_extprod32.py under COEFF_ONLY runs 1 + 5 products of the batch
+t32 = product_traffic("ep32_", 6 * int(os.environ.get("BATCH", "1024")),
+                      "CrtGlwe<u32> x DcrtGgsw over U32DcrtTable -> coefficient form, batch 1024, fused kernels", 48 * 65536)
+if t32:
+    json.dump(t32, open(f"{dst}/{tag}_extprod32_traffic.json", "w"), indent=1)
+    ep.append("u32 product: %.1f MB moved per product (algorithmic 3.15 MB): " % (t32["bytes_per_product"] / 1e6) +
+              ", ".join("%s %.1f" % (k, v / 1e6) for k, v in sorted(t32["bytes_per_product_by_kernel"].items(), key=lambda kv: -kv[1])))
+    ep += ["tools/perf_extprod32.py: " + " | ".join(l.strip() for l in open(src + "/ep32.log") if "products/s" in l)]
+    stf32 = newest(src + "/ep32_trace/**/*_kernel_stats.csv")
+    if stf32:
+        for r in csv.DictReader(open(stf32)):
+            ep.append(f"  {short(r['Name']):58s} calls {int(r['Calls']):5d}  avg {float(r['AverageNs']) / 1e3:9.1f} us  {float(r['Percentage']):6.2f} %")
+    ep += counter_table("ep32_", "rocprofv3 --pmc <one counter per pass> -- python3 tools/perf_extprod32.py (COEFF_ONLY)")
 open(f"{dst}/{tag}_extprod_pmc.txt", "w").write("\n".join(ep) + "\n")
 print("\n".join(lines[:10]))
 print("\n".join(ep[:14]))

@@ -20,7 +20,9 @@ basis = p.BigUintApproxSignedBasis32(base, int(os.environ.get("LOG_BASIS", "15")
 glwe = torch.empty(batch * 2 * L * n, dtype=torch.int32, device="cuda")
 t.fill_uniform_dev(glwe, 1)
 out = torch.empty_like(glwe)
-for label, env in (("fused", None), ("separate kernels", "PFHE_DISABLE_FUSED_EXTPROD")):
+# COEFF_ONLY=1 (counter passes): the fused plan's coefficient-form product only, 1 + 5 calls of `batch` products
+only = bool(os.environ.get("COEFF_ONLY"))
+for label, env in ((("fused", None),) if only else (("fused", None), ("separate kernels", "PFHE_DISABLE_FUSED_EXTPROD"))):
     if env:
         os.environ[env] = "1"
     try:
@@ -30,7 +32,7 @@ for label, env in (("fused", None), ("separate kernels", "PFHE_DISABLE_FUSED_EXT
             del os.environ[env]
     ggsw = torch.empty(ctx.ggsw_len(), dtype=torch.int32, device="cuda")
     t.fill_uniform_dev(ggsw, 2)
-    for coeff in (False, True):
+    for coeff in ((True,) if only else (False, True)):
         p.mul_dcrt_ggsw_to_dev(glwe, ggsw, out, ctx, into_coeff_form=coeff)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -20,6 +20,13 @@ for c in VALUBusy OccupancyPercent LdsUtil MemUnitStalled FETCH_SIZE WRITE_SIZE;
   rocprofv3 --pmc $c --output-format csv -d $O/ep_$c -- python3 $R/tools/perf_extprod.py > $O/epu_$c.log 2>&1
 done
 unset COEFF_ONLY
+# the <u32> external product at its bench shape: kernel trace, then the HBM counters (coefficient form, fused kernels only)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ep32_trace -- python3 $R/tools/perf_extprod32.py > $O/ep32.log 2>&1
+export COEFF_ONLY=1
+for c in FETCH_SIZE WRITE_SIZE VALUBusy OccupancyPercent; do
+  rocprofv3 --pmc $c --output-format csv -d $O/ep32_$c -- python3 $R/tools/perf_extprod32.py > $O/ep32u_$c.log 2>&1
+done
+unset COEFF_ONLY
 cd $R && python tools/pmc_summary.py $O/trace $O/fetch $O/write $O/rocprof
 python tools/collect_profiles2.py $TAG
 find $O -name "*kernel_trace.csv" -size +2M -delete; find $O -name "*counter_collection.csv" -size +2M -delete; du -sh $O
