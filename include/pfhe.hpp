@@ -3,7 +3,8 @@
 //   U64NttTable   — primus_ntt::NttTable for U64NttTable   (crates/primus_ntt/src/ntt/mod.rs:16-113)
 //   U64DcrtTable  — primus_ntt::DcrtTable for U64DcrtTable (crates/primus_ntt/src/dcrt/mod.rs:19-135)
 //   U32NttTable, U32DcrtTable — the u32 / low-q tables (ntt/prime32/table.rs, dcrt/prime32.rs)
-//   RNSBase, BigUintApproxSignedBasis, DcrtGlevContext, mul_dcrt_ggsw_to
+//   RNSBase, BigUintApproxSignedBasis, DcrtGlevContext, mul_dcrt_ggsw_to (and RNSBase32, BigUintApproxSignedBasis32,
+//   DcrtGlevContext32: the <u32> instantiation, u32 words in memory)
 //                 — primus_rns / primus_decompose / primus_lattice entry points of the RNS
 //                   gadget external product (crates/primus_lattice/src/glwe/crt.rs:200-227)
 // Errors: constructors throw pfhe::Error carrying the pfhe_status (the reference returns
@@ -364,6 +365,11 @@ class BigUintApproxSignedBasis {
                                      uint8_t *carries, size_t count) const {
         check(pfhe_basis_unsigned_decompose_slice_to(h_, level, values, len, digits, carries, count));
     }
+    // decomposer_iter().nth(level).decompose_slice_to (big_integer/common.rs:289-306): signed digit as a residue mod Q
+    void decompose_slice_to(size_t level, const uint64_t *values, size_t len, uint64_t *decomposed_values, size_t len_out,
+                            uint8_t *carries, size_t count) const {
+        check(pfhe_basis_decompose_slice_to(h_, level, values, len, decomposed_values, len_out, carries, count));
+    }
     const pfhe_basis *handle() const { return h_; }
 
   private:
@@ -403,6 +409,117 @@ inline void mul_dcrt_ggsw_to_dev(const uint64_t *crt_glwe_dev, size_t len_glwe, 
                                  bool into_coeff_form = false, void *stream = nullptr) {
     check(pfhe_extprod_mul_dcrt_ggsw_to_dev(context.handle(), crt_glwe_dev, len_glwe, dcrt_ggsw_dev, len_ggsw,
                                             result_dev, len_result, into_coeff_form, stream));
+}
+
+// ---- the <u32> instantiation of the same operators (RNSBase<u32>, BigUintApproxSignedBasis<u32> — the type the
+// reference's tests/big_uint.rs:13 runs — and CrtGlwe<u32>::mul_dcrt_ggsw_to over a U32DcrtTable).  Words are
+// uint32_t in memory (residues, digits, limbs of big integers); moduli below 2^30, log_basis below 32; up to 32 moduli.
+class RNSBase32 {
+  public:
+    explicit RNSBase32(const std::vector<uint32_t> &moduli, int device = 0) {
+        check(pfhe_rns32_create(moduli.data(), moduli.size(), device, &h_));
+    }
+    ~RNSBase32() { pfhe_rns32_destroy(h_); }
+    RNSBase32(const RNSBase32 &) = delete;
+    RNSBase32 &operator=(const RNSBase32 &) = delete;
+    size_t moduli_count() const { return pfhe_rns32_moduli_count(h_); }
+    size_t big_uint_value_len() const { return pfhe_rns32_big_uint_value_len(h_); }
+    std::vector<uint32_t> moduli_product() const {
+        std::vector<uint32_t> q(big_uint_value_len());
+        check(pfhe_rns32_moduli_product(h_, q.data(), q.size()));
+        return q;
+    }
+    void compose_multiple_values_to(const uint32_t *multi_residues, size_t len_in, uint32_t *big_uint_values,
+                                    size_t len_out, size_t value_count) const {
+        check(pfhe_rns32_compose_multiple_values_to(h_, multi_residues, len_in, big_uint_values, len_out, value_count));
+    }
+    void wrapping_decompose_small_values_to(const uint32_t *small_values, size_t value_count, uint32_t *multi_residues,
+                                            size_t len_out, uint32_t small_value_modulus) const {
+        check(pfhe_rns32_wrapping_decompose_small_values_to(h_, small_values, value_count, multi_residues, len_out,
+                                                            small_value_modulus));
+    }
+    void add_wrapping_decompose_small_values_scaled(const uint32_t *small_values, size_t value_count, uint32_t *acc,
+                                                    size_t len_acc, uint32_t small_value_modulus,
+                                                    const std::vector<uint32_t> &factors) const {
+        if (factors.size() != 2 * moduli_count()) throw Error(PFHE_ERR_BAD_LENGTH, "expected one factor per modulus");
+        check(pfhe_rns32_add_wrapping_decompose_small_values_scaled(h_, small_values, value_count, acc, len_acc,
+                                                                    small_value_modulus, factors.data()));
+    }
+    void add_decompose_small_values_scaled(const uint32_t *small_values, size_t value_count, uint32_t *acc, size_t len_acc,
+                                           const std::vector<uint32_t> &factors) const {
+        if (factors.size() != 2 * moduli_count()) throw Error(PFHE_ERR_BAD_LENGTH, "expected one factor per modulus");
+        check(pfhe_rns32_add_decompose_small_values_scaled(h_, small_values, value_count, acc, len_acc, factors.data()));
+    }
+    void decompose_big_uint_values_to(const uint32_t *big_uint_values, size_t len_in, uint32_t *multi_residues,
+                                      size_t len_out, size_t value_count) const {
+        check(pfhe_rns32_decompose_big_uint_values_to(h_, big_uint_values, len_in, multi_residues, len_out, value_count));
+    }
+    const pfhe_rns32 *handle() const { return h_; }
+
+  private:
+    pfhe_rns32 *h_ = nullptr;
+};
+
+class BigUintApproxSignedBasis32 {
+  public:
+    BigUintApproxSignedBasis32(const RNSBase32 &base, uint32_t log_basis, size_t reverse_length = 0) {
+        check(pfhe_basis32_create(base.handle(), log_basis, reverse_length, &h_));
+    }
+    ~BigUintApproxSignedBasis32() { pfhe_basis32_destroy(h_); }
+    BigUintApproxSignedBasis32(const BigUintApproxSignedBasis32 &) = delete;
+    BigUintApproxSignedBasis32 &operator=(const BigUintApproxSignedBasis32 &) = delete;
+    size_t decompose_length() const { return pfhe_basis32_decompose_length(h_); }
+    uint32_t log_basis() const { return pfhe_basis32_log_basis(h_); }
+    uint32_t drop_bits() const { return pfhe_basis32_drop_bits(h_); }
+    uint32_t basis_value() const { return pfhe_basis32_basis_value(h_); }
+    void init_value_carry_slice_inplace(uint32_t *values, size_t len, uint8_t *carries, size_t count) const {
+        check(pfhe_basis32_init_value_carry_slice_inplace(h_, values, len, carries, count));
+    }
+    void unsigned_decompose_slice_to(size_t level, const uint32_t *values, size_t len, uint32_t *digits,
+                                     uint8_t *carries, size_t count) const {
+        check(pfhe_basis32_unsigned_decompose_slice_to(h_, level, values, len, digits, carries, count));
+    }
+    void decompose_slice_to(size_t level, const uint32_t *values, size_t len, uint32_t *decomposed_values, size_t len_out,
+                            uint8_t *carries, size_t count) const {
+        check(pfhe_basis32_decompose_slice_to(h_, level, values, len, decomposed_values, len_out, carries, count));
+    }
+    const pfhe_basis32 *handle() const { return h_; }
+
+  private:
+    pfhe_basis32 *h_ = nullptr;
+};
+
+// DcrtGlevContext over a U32DcrtTable; one holder at a time like DcrtGlevContext
+class DcrtGlevContext32 {
+  public:
+    DcrtGlevContext32(const U32DcrtTable &table, const RNSBase32 &base, const BigUintApproxSignedBasis32 &basis,
+                      size_t glwe_dimension = 1, size_t chunk = 0) {
+        check(pfhe_extprod32_plan_create(table.handle(), base.handle(), basis.handle(), glwe_dimension, chunk, &h_));
+    }
+    ~DcrtGlevContext32() { pfhe_extprod32_plan_destroy(h_); }
+    DcrtGlevContext32(const DcrtGlevContext32 &) = delete;
+    DcrtGlevContext32 &operator=(const DcrtGlevContext32 &) = delete;
+    pfhe_extprod32_plan *handle() const { return h_; }
+    bool in_use() const { return pfhe_extprod32_plan_in_use(h_) != 0; }
+    size_t scratch_bytes() const { return pfhe_extprod32_plan_scratch_bytes(h_); }
+
+  private:
+    pfhe_extprod32_plan *h_ = nullptr;
+};
+
+// CrtGlwe<u32>::mul_dcrt_ggsw_to (crates/primus_lattice/src/glwe/crt.rs:200-227)
+inline void mul_dcrt_ggsw_to(const uint32_t *crt_glwe, size_t len_glwe, const uint32_t *dcrt_ggsw, size_t len_ggsw,
+                             uint32_t *result, size_t len_result, DcrtGlevContext32 &context,
+                             bool into_coeff_form = false) {
+    check(pfhe_extprod32_mul_dcrt_ggsw_to(context.handle(), crt_glwe, len_glwe, dcrt_ggsw, len_ggsw, result, len_result,
+                                          into_coeff_form));
+}
+
+inline void mul_dcrt_ggsw_to_dev(const uint32_t *crt_glwe_dev, size_t len_glwe, const uint32_t *dcrt_ggsw_dev,
+                                 size_t len_ggsw, uint32_t *result_dev, size_t len_result, DcrtGlevContext32 &context,
+                                 bool into_coeff_form = false, void *stream = nullptr) {
+    check(pfhe_extprod32_mul_dcrt_ggsw_to_dev(context.handle(), crt_glwe_dev, len_glwe, dcrt_ggsw_dev, len_ggsw,
+                                              result_dev, len_result, into_coeff_form, stream));
 }
 
 }  // namespace pfhe

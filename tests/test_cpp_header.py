@@ -25,6 +25,23 @@ int main() {
         pfhe::BaseConverter conv(in, out2);
         std::vector<uint64_t> res = {1, 2, 3}, conv_out(2);   // one coefficient, residues (1,2,3)
         conv.fast_convert_array(res.data(), 3, conv_out.data(), 2, 1);
+        // the <u32> operators: compose(decompose(v)) == v over a nine-modulus base (constants in a device table),
+        // and an external product with a zero GGSW is zero
+        pfhe::RNSBase32 wide({1073707009u, 1073698817u, 1073692673u, 1073682433u, 1073668097u, 1073655809u, 1073651713u,
+                              1073643521u, 1073620993u});
+        const size_t wl = wide.big_uint_value_len();
+        std::vector<uint32_t> big(4 * wl, 0), res32(9 * 4), back(4 * wl, 1);
+        for (size_t i = 0; i < 4; ++i) { big[i * wl] = 12345u + (uint32_t)i; big[i * wl + 1] = 99u * (uint32_t)i; }
+        wide.decompose_big_uint_values_to(big.data(), big.size(), res32.data(), res32.size(), 4);
+        wide.compose_multiple_values_to(res32.data(), res32.size(), back.data(), back.size(), 4);
+        pfhe::RNSBase32 base32({1073479681u, 1071513601u});
+        pfhe::BigUintApproxSignedBasis32 basis32(base32, 20);
+        pfhe::DcrtGlevContext32 ctx32(t32, base32, basis32);
+        const size_t ell32 = basis32.decompose_length(), cl = t32.crt_poly_length();
+        std::vector<uint32_t> glwe32(2 * cl, 5), ggsw32(2 * ell32 * 2 * cl, 0), out32(2 * cl, 9);
+        pfhe::mul_dcrt_ggsw_to(glwe32.data(), glwe32.size(), ggsw32.data(), ggsw32.size(), out32.data(), out32.size(), ctx32);
+        bool u32_ok = big == back && wide.moduli_count() == 9 && !ctx32.in_use();
+        for (uint32_t w : out32) u32_ok = u32_ok && w == 0;
         // element-wise family on device buffers: ((a + b) - b) * X^5 * X^(2N-5) == a, and -(-a) == a
         void *da = nullptr, *db = nullptr, *dx = nullptr;
         const size_t bytes = a.size() * sizeof(uint64_t);
@@ -48,7 +65,7 @@ int main() {
         bool ew_ok = true;
         for (size_t i = 0; i < e.size(); ++i) ew_ok = ew_ok && f[i] == 2 * e[i];
         pfhe_device_free(0, da); pfhe_device_free(0, db); pfhe_device_free(0, dx);
-        const bool ok = ew_ok && a == b && c == d && conv.input_moduli_count() == 3 && conv_out[0] < 29 && conv_out[1] < 31;
+        const bool ok = ew_ok && u32_ok && a == b && c == d && conv.input_moduli_count() == 3 && conv_out[0] < 29 && conv_out[1] < 31;
         std::printf(ok ? "roundtrip ok\n" : "roundtrip MISMATCH\n");
         return ok ? 0 : 1;
     } catch (const pfhe::Error &e) {
