@@ -724,6 +724,27 @@ int pfhe_rns32_decompose_big_uint_values_to_dev(const pfhe_rns32 *base,
                                               uint32_t *multi_residues_dev, size_t len_out,
                                               size_t value_count, void *stream);
 
+/* BaseConverter<u32> — primus_rns/src/converter.rs:21 (generic over T: FheUint): the contracts of pfhe_conv_* with
+ * uint32_t residues.  reduce_dot_product folds a 64-bit accumulator every 16 terms there (common/compact/slice.rs:380-405);
+ * the value reduced is the same integer, so every output is the canonical residue the reference produces; the exact form
+ * rounds with `(sum + 0.5) as u32`. */
+typedef struct pfhe_conv32 pfhe_conv32;
+int pfhe_conv32_create(const pfhe_rns32 *input_base, const pfhe_rns32 *output_base, pfhe_conv32 **out);
+void pfhe_conv32_destroy(pfhe_conv32 *conv);
+size_t pfhe_conv32_input_moduli_count(const pfhe_conv32 *conv);
+size_t pfhe_conv32_output_moduli_count(const pfhe_conv32 *conv);
+int pfhe_conv32_base_change_matrix(const pfhe_conv32 *conv, uint32_t *out, size_t len);
+int pfhe_conv32_fast_convert_array(const pfhe_conv32 *conv, const uint32_t *crt_poly_in, size_t len_in,
+                                   uint32_t *crt_poly_out, size_t len_out, size_t poly_length);
+int pfhe_conv32_fast_convert_array_dev(const pfhe_conv32 *conv, const uint32_t *crt_poly_in_dev, size_t len_in,
+                                       uint32_t *crt_poly_out_dev, size_t len_out, size_t poly_length, void *stream);
+int pfhe_conv32_fast_convert_array_to_pairs_dev(const pfhe_conv32 *conv, const uint32_t *crt_poly_in_dev, size_t len_in,
+                                                uint32_t *pairs_out_dev, size_t len_out, size_t poly_length, void *stream);
+int pfhe_conv32_exact_convert_array(const pfhe_conv32 *conv, const uint32_t *crt_poly_in, size_t len_in,
+                                    uint32_t *crt_poly_out, size_t len_out, size_t poly_length);
+int pfhe_conv32_exact_convert_array_dev(const pfhe_conv32 *conv, const uint32_t *crt_poly_in_dev, size_t len_in,
+                                        uint32_t *crt_poly_out_dev, size_t len_out, size_t poly_length, void *stream);
+
 /* The plan of the u32 product: as pfhe_extprod_plan_create (one holder at a time, `table` borrowed, device scratch for
  * `chunk` ciphertexts: chunk*(k+1)*ell*L*N u32 words; 0 = about 1 GiB, at least 128 ciphertexts). */
 int pfhe_extprod32_plan_create(const pfhe_dcrt32 *table, const pfhe_rns32 *base, const pfhe_basis32 *basis,

@@ -3,7 +3,7 @@
 //   U64NttTable   — primus_ntt::NttTable for U64NttTable   (crates/primus_ntt/src/ntt/mod.rs:16-113)
 //   U64DcrtTable  — primus_ntt::DcrtTable for U64DcrtTable (crates/primus_ntt/src/dcrt/mod.rs:19-135)
 //   U32NttTable, U32DcrtTable — the u32 / low-q tables (ntt/prime32/table.rs, dcrt/prime32.rs)
-//   RNSBase, BigUintApproxSignedBasis, DcrtGlevContext, mul_dcrt_ggsw_to (and RNSBase32, BigUintApproxSignedBasis32,
+//   RNSBase, BigUintApproxSignedBasis, DcrtGlevContext, mul_dcrt_ggsw_to (and RNSBase32, BaseConverter32, BigUintApproxSignedBasis32,
 //   DcrtGlevContext32: the <u32> instantiation, u32 words in memory)
 //                 — primus_rns / primus_decompose / primus_lattice entry points of the RNS
 //                   gadget external product (crates/primus_lattice/src/glwe/crt.rs:200-227)
@@ -458,6 +458,38 @@ class RNSBase32 {
 
   private:
     pfhe_rns32 *h_ = nullptr;
+};
+
+// primus_rns::BaseConverter<u32, BarrettModulus<u32>> (converter.rs:21, generic over T: FheUint)
+class BaseConverter32 {
+  public:
+    BaseConverter32(const RNSBase32 &input_base, const RNSBase32 &output_base) {
+        check(pfhe_conv32_create(input_base.handle(), output_base.handle(), &h_));
+    }
+    ~BaseConverter32() { pfhe_conv32_destroy(h_); }
+    BaseConverter32(const BaseConverter32 &) = delete;
+    BaseConverter32 &operator=(const BaseConverter32 &) = delete;
+    size_t input_moduli_count() const { return pfhe_conv32_input_moduli_count(h_); }
+    size_t output_moduli_count() const { return pfhe_conv32_output_moduli_count(h_); }
+    void fast_convert_array(const uint32_t *crt_poly_in, size_t len_in, uint32_t *crt_poly_out, size_t len_out,
+                            size_t poly_length) const {
+        check(pfhe_conv32_fast_convert_array(h_, crt_poly_in, len_in, crt_poly_out, len_out, poly_length));
+    }
+    void exact_convert_array(const uint32_t *crt_poly_in, size_t len_in, uint32_t *crt_poly_out, size_t len_out,
+                             size_t poly_length) const {
+        check(pfhe_conv32_exact_convert_array(h_, crt_poly_in, len_in, crt_poly_out, len_out, poly_length));
+    }
+    void fast_convert_array_dev(const uint32_t *in_dev, size_t len_in, uint32_t *out_dev, size_t len_out,
+                                size_t poly_length, void *stream = nullptr) const {
+        check(pfhe_conv32_fast_convert_array_dev(h_, in_dev, len_in, out_dev, len_out, poly_length, stream));
+    }
+    void exact_convert_array_dev(const uint32_t *in_dev, size_t len_in, uint32_t *out_dev, size_t len_out,
+                                 size_t poly_length, void *stream = nullptr) const {
+        check(pfhe_conv32_exact_convert_array_dev(h_, in_dev, len_in, out_dev, len_out, poly_length, stream));
+    }
+
+  private:
+    pfhe_conv32 *h_ = nullptr;
 };
 
 class BigUintApproxSignedBasis32 {

@@ -185,6 +185,11 @@ def _load(path: str | None = None) -> C.CDLL:
     sig("orc_rns32_compose_multiple_values_to", None, vp, u32p, u32p, sz)
     sig("orc_rns32_decompose_to", None, vp, u32p, u32p)
     sig("orc_rns32_decompose_big_uint_values_to", None, vp, u32p, u32p, sz)
+    sig("orc_conv32_new", ci, vp, vp, C.POINTER(vp))
+    sig("orc_conv32_free", None, vp)
+    sig("orc_conv32_matrix", u32p, vp)
+    sig("orc_conv32_fast_convert_array", None, vp, u32p, u32p, sz, u32p)
+    sig("orc_conv32_exact_convert_array", ci, vp, u32p, u32p, sz)
     sig("orc_rns32_wrapping_decompose_small_values_to", None, vp, u32p, u32p, sz, u32)
     sig("orc_rns32_add_wrapping_decompose_small_values_scaled", None, vp, u32p, u32p, sz, u32, u32p)
     sig("orc_rns32_add_decompose_small_values_scaled", None, vp, u32p, u32p, sz, u32p)
@@ -849,6 +854,37 @@ class RNSBase32:
         f = np.ascontiguousarray(np.array(factors, np.uint32).reshape(-1))
         assert acc.size == self.count * sv.size and f.size == 2 * self.count
         lib().orc_rns32_add_decompose_small_values_scaled(self._h, _p32(sv), _p32(acc), sv.size, _p32(f))
+
+
+class BaseConverter32:
+    """primus_rns::BaseConverter<u32, BarrettModulus<u32>> (converter.rs with T = u32)."""
+
+    def __init__(self, input_base: "RNSBase32", output_base: "RNSBase32"):
+        h = C.c_void_p()
+        rc = lib().orc_conv32_new(input_base._h, output_base._h, C.byref(h))
+        if rc:
+            raise OracleError(rc)
+        self._h = h
+        self.input_base, self.output_base = input_base, output_base  # keep the borrowed bases alive
+        self.base_change_matrix = _arr32(lib().orc_conv32_matrix(h), input_base.count * output_base.count)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_conv32_free(self._h)
+            self._h = None
+
+    def fast_convert_array(self, crt_poly_in, poly_length):
+        out = np.empty(self.output_base.count * poly_length, np.uint32)
+        scratch = np.empty(self.input_base.count * poly_length, np.uint32)
+        lib().orc_conv32_fast_convert_array(self._h, _p32(crt_poly_in), _p32(out), poly_length, _p32(scratch))
+        return out
+
+    def exact_convert_array(self, crt_poly_in, poly_length):
+        out = np.empty(poly_length, np.uint32)
+        rc = lib().orc_conv32_exact_convert_array(self._h, _p32(crt_poly_in), _p32(out), poly_length)
+        if rc:
+            raise OracleError(rc)
+        return out
 
 
 class BigUintApproxSignedBasis32:

@@ -316,6 +316,15 @@ void orc_rns32_add_wrapping_decompose_small_values_scaled(const orc_rns32 *b, co
                                                           const uint32_t *factors);
 void orc_rns32_add_decompose_small_values_scaled(const orc_rns32 *b, const uint32_t *small_values, uint32_t *acc,
                                                  size_t value_count, const uint32_t *factors);
+/* BaseConverter<u32> (converter.rs with T = u32); borrows both bases */
+typedef struct orc_conv32 orc_conv32;
+int orc_conv32_new(const orc_rns32 *in, const orc_rns32 *out, orc_conv32 **res);
+void orc_conv32_free(orc_conv32 *c);
+const uint32_t *orc_conv32_matrix(const orc_conv32 *c);
+void orc_conv32_fast_convert_array(const orc_conv32 *c, const uint32_t *crt_poly_in, uint32_t *crt_poly_out,
+                                   size_t poly_length, uint32_t *scratch);
+int orc_conv32_exact_convert_array(const orc_conv32 *c, const uint32_t *crt_poly_in, uint32_t *crt_poly_out,
+                                   size_t poly_length);
 int orc_basis32_new(const orc_rns32 *rns, uint32_t log_basis, size_t reverse_length, orc_basis32 **out);
 void orc_basis32_free(orc_basis32 *b);
 size_t orc_basis32_decompose_length(const orc_basis32 *b);

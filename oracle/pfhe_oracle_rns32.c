@@ -2,6 +2,7 @@
  * pfhe_oracle_rns32.c — the <u32> instantiations of the reference's RNS / gadget / external-product generics,
  * restated with T = u32 (limbs, residues and digits are 32-bit words, the widening type is u64):
  *   RNSBase<u32, BarrettModulus<u32>>      primus_rns/src/base.rs:26-117 (generic over T: FheUint)
+ *   BaseConverter<u32, BarrettModulus<u32>> primus_rns/src/converter.rs:21-364
  *   BigUintApproxSignedBasis<u32>          primus_decompose/src/big_integer/basis.rs:33 (the type tests/big_uint.rs:13 runs)
  *   CrtGlwe<u32>::mul_dcrt_ggsw_to         primus_lattice/src/glwe/crt.rs:200-227 over U32DcrtTable (dcrt/prime32.rs:11)
  *
@@ -209,6 +210,125 @@ void orc_rns32_add_decompose_small_values_scaled(const orc_rns32 *b, const uint3
         w32 *a = acc + i * value_count;
         for (size_t c = 0; c < value_count; ++c) a[c] = reduce_add32(q, a[c], shoup32_mul(f, small_values[c], q));
     }
+}
+
+/* ========================================================================== */
+/* BaseConverter<u32, BarrettModulus<u32>> — primus_rns/src/converter.rs          */
+/* ========================================================================== */
+/* BarrettModulus<u32> (primus_modulus/src/barrett/mod.rs:25-31): ratio = floor(2^64 / value) as two 32-bit words
+ * (new_unchecked :57-64) */
+typedef struct { w32 value, ratio[2]; } barrett32_t;
+static barrett32_t barrett32_new(w32 value) {
+    /* floor(2^64 / value): 2^64 = value * floor((2^64 - 1) / value) + r, r + 1 <= value; equal only when value | 2^64 */
+    wide q = ~(wide)0 / value;
+    if ((~(wide)0 % value) + 1 == value) ++q;
+    barrett32_t m = {value, {(w32)q, (w32)(q >> 32)}};
+    return m;
+}
+/* lazy_reduce_wide :99-133 + reduce_once (reduce_wide :137-139), every step in 32-bit words */
+static w32 barrett32_reduce_wide(const barrett32_t *m, w32 lo, w32 hi) {
+    const w32 ah = (w32)(((wide)lo * m->ratio[0]) >> 32);     /* widening_mul_hw */
+    const wide b = (wide)lo * m->ratio[1] + ah;               /* carrying_mul(ratio[1], ah) */
+    const wide c = (wide)hi * m->ratio[0];                    /* widening_mul */
+    const w32 d = hi * m->ratio[1];                           /* wrapping_mul */
+    const w32 b0 = (w32)b, b1 = (w32)(b >> 32), c0 = (w32)c, c1 = (w32)(c >> 32);
+    const w32 carry = (w32)(b0 + c0) < b0;                    /* overflowing_add(..).1 */
+    const w32 bch = b1 + c1 + carry;                          /* carrying_add(..).0 */
+    const w32 q = d + bch;
+    const w32 r = lo - q * m->value;
+    return r >= m->value ? r - m->value : r;
+}
+/* reduce_dot_product (primus_modulus/src/common/compact/slice.rs:380-405): a [u32; 2] accumulator per chunk of
+ * DOT_PRODUCT_INNER_CHUNK = 16 terms (multiply_add: widening product added with carry, overflow of the upper word
+ * discarded), reduce, fold with reduce_add; then the remainder */
+static w32 dot_product_mod32(const barrett32_t *m, const w32 *a, const w32 *b, size_t len) {
+    const size_t K = 16;
+    w32 inter = 0;
+    const size_t full = len / K;
+    for (size_t ch = 0; ch < full; ++ch) {
+        wide c = 0;
+        for (size_t t = 0; t < K; ++t) c += (wide)a[ch * K + t] * b[ch * K + t];
+        inter = reduce_add32(m->value, inter, barrett32_reduce_wide(m, (w32)c, (w32)(c >> 32)));
+    }
+    wide c = 0;
+    for (size_t t = full * K; t < len; ++t) c += (wide)a[t] * b[t];
+    return reduce_add32(m->value, barrett32_reduce_wide(m, (w32)c, (w32)(c >> 32)), inter);
+}
+
+struct orc_conv32 {
+    const orc_rns32 *in, *out; /* borrowed */
+    barrett32_t *out_mod;
+    w32 *matrix;               /* out.count rows x in.count columns: (Q/q_i) mod p_j (converter.rs:54-62) */
+    w32 q_mod_p0;              /* Q mod p_0 (converter.rs:345) */
+};
+
+/* converter.rs:43-69 */
+int orc_conv32_new(const orc_rns32 *in, const orc_rns32 *out, orc_conv32 **res) {
+    orc_conv32 *c = (orc_conv32 *)calloc(1, sizeof(*c));
+    c->in = in; c->out = out;
+    c->matrix = (w32 *)malloc(in->count * out->count * sizeof(w32));
+    c->out_mod = (barrett32_t *)malloc(out->count * sizeof(barrett32_t));
+    for (size_t j = 0; j < out->count; ++j) {
+        c->out_mod[j] = barrett32_new(out->moduli[j]);
+        for (size_t i = 0; i < in->count; ++i)
+            c->matrix[j * in->count + i] = big32_mod(in->punctured + i * in->value_len, in->value_len, out->moduli[j]);
+    }
+    c->q_mod_p0 = big32_mod(in->product, in->value_len, out->moduli[0]);
+    *res = c;
+    return ORC_OK;
+}
+void orc_conv32_free(orc_conv32 *c) { if (c) { free(c->matrix); free(c->out_mod); free(c); } }
+const uint32_t *orc_conv32_matrix(const orc_conv32 *c) { return c->matrix; }
+
+/* converter.rs:144-178: coefficient-major scratch; `inv == 1` takes x mod q_i */
+static void fill_scratch32(const orc_conv32 *c, const w32 *crt_poly_in, size_t poly_length, w32 *scratch) {
+    const orc_rns32 *in = c->in;
+    for (size_t i = 0; i < in->count; ++i)
+        for (size_t t = 0; t < poly_length; ++t) {
+            const w32 x = crt_poly_in[i * poly_length + t];
+            scratch[t * in->count + i] = in->inv_punct[i].value == 1 ? x % in->moduli[i]
+                                                                     : shoup32_mul(in->inv_punct[i], x, in->moduli[i]);
+        }
+}
+
+/* converter.rs:192-218 */
+void orc_conv32_fast_convert_array(const orc_conv32 *c, const uint32_t *crt_poly_in, uint32_t *crt_poly_out,
+                                   size_t poly_length, uint32_t *scratch) {
+    const size_t lin = c->in->count;
+    fill_scratch32(c, crt_poly_in, poly_length, scratch);
+    for (size_t j = 0; j < c->out->count; ++j)
+        for (size_t t = 0; t < poly_length; ++t)
+            crt_poly_out[j * poly_length + t] = dot_product_mod32(&c->out_mod[j], scratch + t * lin, c->matrix + j * lin, lin);
+}
+
+/* converter.rs:274-364 with T = u32: v_i = f64(temp_i) / f64(q_i), summed left to right from 0.0, (sum + 0.5) as u32
+ * (truncation, saturating); reduce_mul(v, Q mod p) = reduce(widening_mul) (barrett/ops.rs:280-282) */
+int orc_conv32_exact_convert_array(const orc_conv32 *c, const uint32_t *crt_poly_in, uint32_t *crt_poly_out,
+                                   size_t poly_length) {
+    if (c->out->count != 1) return ORC_ERR_BAD_ARG;
+    const orc_rns32 *in = c->in;
+    const size_t lin = in->count;
+    w32 *temp = (w32 *)malloc(lin * poly_length * sizeof(w32));
+    fill_scratch32(c, crt_poly_in, poly_length, temp);
+    const barrett32_t *p = &c->out_mod[0];
+    for (size_t t = 0; t < poly_length; ++t) {
+        volatile double sum = 0.0;
+        for (size_t i = 0; i < lin; ++i) {
+            const double dividend = (double)temp[t * lin + i];
+            const double divisor = (double)in->moduli[i];
+            sum = sum + dividend / divisor;
+        }
+        const double r = sum + 0.5;
+        w32 v;
+        if (!(r > 0.0)) v = 0; else if (r >= 4294967296.0) v = UINT32_MAX; else v = (w32)r;
+        const w32 dot = dot_product_mod32(p, temp + t * lin, c->matrix, lin);
+        const wide vq_wide = (wide)v * c->q_mod_p0;
+        const w32 vq = barrett32_reduce_wide(p, (w32)vq_wide, (w32)(vq_wide >> 32));
+        const w32 d = dot - vq;                                   /* reduce_sub (compact/primitive.rs) */
+        crt_poly_out[t] = dot >= vq ? d : d + p->value;
+    }
+    free(temp);
+    return ORC_OK;
 }
 
 /* ========================================================================== */

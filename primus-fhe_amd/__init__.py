@@ -11,11 +11,11 @@ from .lattice import (DcrtGlevContext, DcrtGlevContext32, add_dcrt_glev_mul_big_
                       add_dcrt_glev_mul_crt_poly_assign_dev, glev_mul_big_uint_poly_to_dev, glev_mul_crt_poly_to_dev,
                       mul_dcrt_ggsw_to, mul_dcrt_ggsw_to_dev, profile_mul_dcrt_ggsw_to_dev)
 from .ntt import NttError, U32DcrtTable, U32NttTable, U64DcrtTable, U64NttTable  # noqa: F401
-from .rns import (BaseConverter, BigUintApproxSignedBasis, BigUintApproxSignedBasis32, RNSBase, RNSBase32,  # noqa: F401
+from .rns import (BaseConverter, BaseConverter32, BigUintApproxSignedBasis, BigUintApproxSignedBasis32, RNSBase, RNSBase32,  # noqa: F401
                   RNSError)
 
 __all__ = ["PfheError", "NttError", "RNSError", "U64NttTable", "U64DcrtTable", "U32NttTable", "U32DcrtTable", "RNSBase",
-           "BigUintApproxSignedBasis", "BaseConverter", "DcrtGlevContext", "RNSBase32", "BigUintApproxSignedBasis32",
+           "BigUintApproxSignedBasis", "BaseConverter", "BaseConverter32", "DcrtGlevContext", "RNSBase32", "BigUintApproxSignedBasis32",
            "DcrtGlevContext32", "mul_dcrt_ggsw_to", "mul_dcrt_ggsw_to_dev",
            "add_dcrt_glev_mul_crt_poly_assign_dev", "glev_mul_crt_poly_to_dev", "add_dcrt_glev_mul_big_uint_poly_assign_dev",
            "glev_mul_big_uint_poly_to_dev", "build", "lib", "library_path", "status_string"]

@@ -172,15 +172,16 @@ def _declare(lib: C.CDLL) -> None:
         sig(pre + "mul_add_to_dev", ci, vp, vp, sz, vp, sz, vp, vp, vp)
     sig("pfhe_dcrt_add_dcrt_glwe_mul_dcrt_polynomial_assign_dev", ci, vp, vp, vp, sz, vp, sz, sz, vp)
     sig("pfhe_dcrt_glwe_mul_dcrt_polynomial_to_dev", ci, vp, vp, sz, vp, sz, sz, vp, vp)
-    sig("pfhe_conv_create", ci, vp, vp, C.POINTER(vp))
-    sig("pfhe_conv_destroy", None, vp)
-    sig("pfhe_conv_input_moduli_count", sz, vp)
-    sig("pfhe_conv_output_moduli_count", sz, vp)
-    sig("pfhe_conv_base_change_matrix", ci, vp, vp, sz)
-    for g in ("fast_convert_array", "exact_convert_array"):
-        sig("pfhe_conv_" + g, ci, vp, vp, sz, vp, sz, sz)
-        sig("pfhe_conv_" + g + "_dev", ci, vp, vp, sz, vp, sz, sz, vp)
-    sig("pfhe_conv_fast_convert_array_to_pairs_dev", ci, vp, vp, sz, vp, sz, sz, vp)
+    for cv in ("pfhe_conv_", "pfhe_conv32_"):      # BaseConverter<u64> / BaseConverter<u32>
+        sig(cv + "create", ci, vp, vp, C.POINTER(vp))
+        sig(cv + "destroy", None, vp)
+        sig(cv + "input_moduli_count", sz, vp)
+        sig(cv + "output_moduli_count", sz, vp)
+        sig(cv + "base_change_matrix", ci, vp, vp, sz)
+        for g in ("fast_convert_array", "exact_convert_array"):
+            sig(cv + g, ci, vp, vp, sz, vp, sz, sz)
+            sig(cv + g + "_dev", ci, vp, vp, sz, vp, sz, sz, vp)
+        sig(cv + "fast_convert_array_to_pairs_dev", ci, vp, vp, sz, vp, sz, sz, vp)
 
     # u32 tables
     sig("pfhe_ntt32_create", ci, u32, u32, ci, C.POINTER(vp))

@@ -87,8 +87,8 @@ __device__ __forceinline__ u64 dot_mod(const CT &C, u32 j, const u64 (&t)[CT::kS
     return add_mod(barrett_reduce128(lo, hi, C.p_out(j), C.ratio_lo(j), C.ratio_hi(j)), 0, C.p_out(j));
 }
 
-template <class CT>
-__device__ __forceinline__ void load_scaled(const CT &C, const u64 *__restrict__ in, u64 n, u64 c, u64 (&t)[CT::kScaled]) {
+template <class CT, class WT>
+__device__ __forceinline__ void load_scaled(const CT &C, const WT *__restrict__ in, u64 n, u64 c, u64 (&t)[CT::kScaled]) {
     // converter.rs:160-176: x mod q_i when the factor is one, else the Shoup product — both are
     // (factor * x) mod q_i, canonical
 #pragma unroll
@@ -96,31 +96,34 @@ __device__ __forceinline__ void load_scaled(const CT &C, const u64 *__restrict__
         t[i] = (u32)i < C.lin ? mul_shoup(in[(u64)i * n + c], C.inv_in(i), C.inv_in_p(i), C.q_in(i)) : 0;
 }
 
-template <class CT>
-__global__ __launch_bounds__(kThreads) void fast_convert_kernel(CT C, const u64 *__restrict__ in,
-                                                                u64 *__restrict__ out, u64 n) {
+// WT: the word type of the caller's arrays (u64, or u32 for BaseConverter<u32>: the same arithmetic on 32-bit words in
+// memory; every result is canonical, so it is the integer the reference's u32 arithmetic produces)
+template <class CT, class WT>
+__global__ __launch_bounds__(kThreads) void fast_convert_kernel(CT C, const WT *__restrict__ in,
+                                                                WT *__restrict__ out, u64 n) {
     const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     u64 t[CT::kScaled];
     load_scaled(C, in, n, c, t);
-    for (u32 j = 0; j < C.lout; ++j) out[(u64)j * n + c] = dot_mod(C, j, t);
+    for (u32 j = 0; j < C.lout; ++j) out[(u64)j * n + c] = (WT)dot_mod(C, j, t);
 }
 
 // fast_convert_array_to_pair_iter (converter.rs:233-272): two output moduli, one (mod p_0, mod p_1) pair per
-// coefficient, written interleaved — one 16-byte store per thread
-template <class CT>
-__global__ __launch_bounds__(kThreads) void fast_convert_pair_kernel(CT C, const u64 *__restrict__ in,
-                                                                     u64 *__restrict__ out, u64 n) {
+// coefficient, written interleaved — one 16-byte (u32: 8-byte) store per thread
+template <class CT, class WT>
+__global__ __launch_bounds__(kThreads) void fast_convert_pair_kernel(CT C, const WT *__restrict__ in,
+                                                                     WT *__restrict__ out, u64 n) {
     const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     u64 t[CT::kScaled];
     load_scaled(C, in, n, c, t);
-    *reinterpret_cast<ulonglong2 *>(out + 2 * c) = ulonglong2{dot_mod(C, 0, t), dot_mod(C, 1, t)};
+    if constexpr (sizeof(WT) == 8) *reinterpret_cast<ulonglong2 *>(out + 2 * c) = ulonglong2{dot_mod(C, 0, t), dot_mod(C, 1, t)};
+    else *reinterpret_cast<uint2 *>(out + 2 * c) = uint2{(u32)dot_mod(C, 0, t), (u32)dot_mod(C, 1, t)};
 }
 
-template <class CT>
-__global__ __launch_bounds__(kThreads) void exact_convert_kernel(CT C, const u64 *__restrict__ in,
-                                                                 u64 *__restrict__ out, u64 n) {
+template <class CT, class WT>
+__global__ __launch_bounds__(kThreads) void exact_convert_kernel(CT C, const WT *__restrict__ in,
+                                                                 WT *__restrict__ out, u64 n) {
     const u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     u64 t[CT::kScaled];
@@ -130,13 +133,14 @@ __global__ __launch_bounds__(kThreads) void exact_convert_kernel(CT C, const u64
     for (int i = 0; i < CT::kScaled; ++i)
         if ((u32)i < C.lin) sum = __dadd_rn(sum, __ddiv_rn((double)t[i], (double)C.q_in(i)));
     const double r = __dadd_rn(sum, 0.5);
-    u64 v;  // Rust `as u64`: truncation toward zero, saturating, NaN -> 0
+    u64 v;  // Rust `as u64` / `as u32`: truncation toward zero, saturating, NaN -> 0
     if (!(r > 0.0)) v = 0;
+    else if (sizeof(WT) == 4 && r >= 4294967296.0) v = 0xffffffffull;
     else if (r >= 18446744073709551616.0) v = ~0ull;
     else v = (u64)r;
     const u64 dot = dot_mod(C, 0, t);
     const u64 vq = mul_mod_barrett(v, C.q_mod_p0, C.p_out(0), C.ratio_lo(0), C.ratio_hi(0));
-    out[c] = sub_mod(dot, vq, C.p_out(0));
+    out[c] = (WT)sub_mod(dot, vq, C.p_out(0));
 }
 
 void barrett_ratio(u64 q, u64 &lo, u64 &hi) {
@@ -158,7 +162,8 @@ u64 big_mod(const u64 *limbs, u32 len, u64 q) {
 
 using namespace pfhe;
 
-struct pfhe_conv {
+namespace pfhe {
+struct ConvCore {
     int device = 0;
     u32 lin = 0, lout = 0;
     ConvDev dev{};                     // valid when both bases have at most kMaxLimbs moduli
@@ -166,6 +171,14 @@ struct pfhe_conv {
     u64 q_mod_p0 = 0;
     std::vector<u64> matrix;           // host copy, [lout][lin]
     bool wide() const { return blob != nullptr; }
+};
+}  // namespace pfhe
+
+struct pfhe_conv {
+    ConvCore c;
+};
+struct pfhe_conv32 {
+    ConvCore c;
 };
 
 namespace {
@@ -196,7 +209,7 @@ int conv_upload(int device, const RnsHost *in, const RnsHost &out, const std::ve
 
 // runs F<CT>::launch with the constants in the form the converter holds
 template <template <class> class F, class... A>
-int conv_dispatch(const pfhe_conv *c, A &&...a) {
+int conv_dispatch(const ConvCore *c, A &&...a) {
     if (!c->wide()) return F<ConvDev>::launch(c->dev, a...);
     const u64 *tab = (const u64 *)c->blob->ptr;
     if (c->lin <= 8) return F<ConvWide<8>>::launch(ConvWide<8>{c->lin, c->lout, tab, c->q_mod_p0}, a...);
@@ -204,42 +217,37 @@ int conv_dispatch(const pfhe_conv *c, A &&...a) {
     if (c->lin <= 24) return F<ConvWide<24>>::launch(ConvWide<24>{c->lin, c->lout, tab, c->q_mod_p0}, a...);
     return F<ConvWide<32>>::launch(ConvWide<32>{c->lin, c->lout, tab, c->q_mod_p0}, a...);
 }
-template <class CT>
-struct FastLaunch {
-    static int launch(const CT &C, const u64 *in, u64 *out, u64 n, hipStream_t s) {
-        hipLaunchKernelGGL(fast_convert_kernel<CT>, dim3(grid_for(n)), dim3(kThreads), 0, s, C, in, out, n);
-        return PFHE_OK;
-    }
-};
-template <class CT>
-struct PairLaunch {
-    static int launch(const CT &C, const u64 *in, u64 *out, u64 n, hipStream_t s) {
-        hipLaunchKernelGGL(fast_convert_pair_kernel<CT>, dim3(grid_for(n)), dim3(kThreads), 0, s, C, in, out, n);
-        return PFHE_OK;
-    }
-};
-template <class CT>
-struct ExactLaunch {
-    static int launch(const CT &C, const u64 *in, u64 *out, u64 n, hipStream_t s) {
-        hipLaunchKernelGGL(exact_convert_kernel<CT>, dim3(grid_for(n)), dim3(kThreads), 0, s, C, in, out, n);
-        return PFHE_OK;
-    }
+template <class WT>
+struct ConvLaunch {
+    template <class CT>
+    struct Fast {
+        static int launch(const CT &C, const WT *in, WT *out, u64 n, hipStream_t s) {
+            hipLaunchKernelGGL((fast_convert_kernel<CT, WT>), dim3(grid_for(n)), dim3(kThreads), 0, s, C, in, out, n);
+            return PFHE_OK;
+        }
+    };
+    template <class CT>
+    struct Pair {
+        static int launch(const CT &C, const WT *in, WT *out, u64 n, hipStream_t s) {
+            hipLaunchKernelGGL((fast_convert_pair_kernel<CT, WT>), dim3(grid_for(n)), dim3(kThreads), 0, s, C, in, out, n);
+            return PFHE_OK;
+        }
+    };
+    template <class CT>
+    struct Exact {
+        static int launch(const CT &C, const WT *in, WT *out, u64 n, hipStream_t s) {
+            hipLaunchKernelGGL((exact_convert_kernel<CT, WT>), dim3(grid_for(n)), dim3(kThreads), 0, s, C, in, out, n);
+            return PFHE_OK;
+        }
+    };
 };
 
-}  // namespace
-
-extern "C" {
-
-int pfhe_conv_create(const pfhe_rns *input_base, const pfhe_rns *output_base, pfhe_conv **out) {
-    PFHE_GUARD_BEGIN
-    if (!input_base || !output_base || !out) return PFHE_ERR_BAD_ARGUMENT;
-    *out = nullptr;
-    if (input_base->h.device != output_base->h.device) {
+// BaseConverter::new — converter.rs:43-69
+int conv_create(const RnsHost &in, const RnsHost &ob, ConvCore *c) {
+    if (in.device != ob.device) {
         set_last_error("input and output bases live on different devices");
         return PFHE_ERR_BAD_ARGUMENT;
     }
-    auto c = std::make_unique<pfhe_conv>();
-    const RnsHost &in = input_base->h, &ob = output_base->h;
     const u32 lin = (u32)in.moduli.size(), lout = (u32)ob.moduli.size(), len = in.par.dev.value_len;
     c->device = in.device;
     c->lin = lin;
@@ -268,24 +276,19 @@ int pfhe_conv_create(const pfhe_rns *input_base, const pfhe_rns *output_base, pf
         if (!g.ok) return PFHE_ERR_NO_DEVICE;
         PFHE_TRY(conv_upload(c->device, &in, ob, c->matrix, c->blob));
     }
-    *out = c.release();
     return PFHE_OK;
-    PFHE_GUARD_END
 }
 
-void pfhe_conv_destroy(pfhe_conv *c) { delete c; }
-size_t pfhe_conv_input_moduli_count(const pfhe_conv *c) { return c ? c->lin : 0; }
-size_t pfhe_conv_output_moduli_count(const pfhe_conv *c) { return c ? c->lout : 0; }
-
-int pfhe_conv_base_change_matrix(const pfhe_conv *c, uint64_t *out, size_t len) {
+template <class W>
+int conv_matrix(const ConvCore *c, W *out, size_t len) {
     if (!c || !out) return PFHE_ERR_BAD_ARGUMENT;
     if (len != c->matrix.size()) return PFHE_ERR_BAD_LENGTH;
-    std::copy(c->matrix.begin(), c->matrix.end(), out);
+    for (size_t i = 0; i < len; ++i) out[i] = (W)c->matrix[i];
     return PFHE_OK;
 }
 
-static int conv_check(const pfhe_conv *c, const void *in, size_t len_in, const void *out, size_t len_out,
-                      size_t poly_length, bool exact) {
+int conv_check(const ConvCore *c, const void *in, size_t len_in, const void *out, size_t len_out, size_t poly_length,
+               bool exact) {
     if (!c || ((!in || !out) && poly_length)) return PFHE_ERR_BAD_ARGUMENT;
     if (exact && c->lout != 1) {  // converter.rs:284-288 asserts
         set_last_error("output base in exact_convert_array must hold exactly one modulus");
@@ -295,23 +298,26 @@ static int conv_check(const pfhe_conv *c, const void *in, size_t len_in, const v
     return PFHE_OK;
 }
 
-int pfhe_conv_fast_convert_array_dev(const pfhe_conv *c, const uint64_t *crt_poly_in_dev, size_t len_in,
-                                     uint64_t *crt_poly_out_dev, size_t len_out, size_t poly_length, void *stream) {
-    PFHE_GUARD_BEGIN
-    PFHE_TRY(conv_check(c, crt_poly_in_dev, len_in, crt_poly_out_dev, len_out, poly_length, false));
+template <class W>
+int conv_array_dev(const ConvCore *c, const W *in_dev, size_t len_in, W *out_dev, size_t len_out, size_t poly_length,
+                   bool exact, void *stream) {
+    PFHE_TRY(conv_check(c, in_dev, len_in, out_dev, len_out, poly_length, exact));
     if (poly_length == 0) return PFHE_OK;
     DeviceGuard g(c->device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    PFHE_TRY((conv_dispatch<FastLaunch>(c, (const u64 *)crt_poly_in_dev, (u64 *)crt_poly_out_dev, (u64)poly_length, (hipStream_t)stream)));
+    if (exact) {
+        PFHE_TRY((conv_dispatch<ConvLaunch<W>::template Exact>(c, in_dev, out_dev, (u64)poly_length, (hipStream_t)stream)));
+    } else {
+        PFHE_TRY((conv_dispatch<ConvLaunch<W>::template Fast>(c, in_dev, out_dev, (u64)poly_length, (hipStream_t)stream)));
+    }
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
-    PFHE_GUARD_END
 }
 
-int pfhe_conv_fast_convert_array_to_pairs_dev(const pfhe_conv *c, const uint64_t *crt_poly_in_dev, size_t len_in,
-                                              uint64_t *pairs_out_dev, size_t len_out, size_t poly_length, void *stream) {
-    PFHE_GUARD_BEGIN
-    if (!c || ((!crt_poly_in_dev || !pairs_out_dev) && poly_length)) return PFHE_ERR_BAD_ARGUMENT;
+template <class W>
+int conv_pairs_dev(const ConvCore *c, const W *in_dev, size_t len_in, W *pairs_out_dev, size_t len_out, size_t poly_length,
+                   void *stream) {
+    if (!c || ((!in_dev || !pairs_out_dev) && poly_length)) return PFHE_ERR_BAD_ARGUMENT;
     if (c->lout != 2) {  // converter.rs:239-243 asserts
         set_last_error("output base in fast_convert_array_to_pair must contain exactly two moduli");
         return PFHE_ERR_BAD_ARGUMENT;
@@ -321,28 +327,14 @@ int pfhe_conv_fast_convert_array_to_pairs_dev(const pfhe_conv *c, const uint64_t
     if (poly_length == 0) return PFHE_OK;
     DeviceGuard g(c->device);
     if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    PFHE_TRY((conv_dispatch<PairLaunch>(c, (const u64 *)crt_poly_in_dev, (u64 *)pairs_out_dev, (u64)poly_length, (hipStream_t)stream)));
+    PFHE_TRY((conv_dispatch<ConvLaunch<W>::template Pair>(c, in_dev, pairs_out_dev, (u64)poly_length, (hipStream_t)stream)));
     PFHE_HIP(hipGetLastError());
     return PFHE_OK;
-    PFHE_GUARD_END
-}
-
-int pfhe_conv_exact_convert_array_dev(const pfhe_conv *c, const uint64_t *crt_poly_in_dev, size_t len_in,
-                                      uint64_t *crt_poly_out_dev, size_t len_out, size_t poly_length, void *stream) {
-    PFHE_GUARD_BEGIN
-    PFHE_TRY(conv_check(c, crt_poly_in_dev, len_in, crt_poly_out_dev, len_out, poly_length, true));
-    if (poly_length == 0) return PFHE_OK;
-    DeviceGuard g(c->device);
-    if (!g.ok) return PFHE_ERR_NO_DEVICE;
-    PFHE_TRY((conv_dispatch<ExactLaunch>(c, (const u64 *)crt_poly_in_dev, (u64 *)crt_poly_out_dev, (u64)poly_length, (hipStream_t)stream)));
-    PFHE_HIP(hipGetLastError());
-    return PFHE_OK;
-    PFHE_GUARD_END
 }
 
 // host-pointer forms: stage, run, copy back
-static int conv_host(const pfhe_conv *c, const uint64_t *in, size_t len_in, uint64_t *out, size_t len_out,
-                     size_t poly_length, bool exact) {
+template <class W>
+int conv_host(const ConvCore *c, const W *in, size_t len_in, W *out, size_t len_out, size_t poly_length, bool exact) {
     PFHE_TRY(conv_check(c, in, len_in, out, len_out, poly_length, exact));
     if (poly_length == 0) return PFHE_OK;
     DeviceGuard g(c->device);
@@ -350,28 +342,66 @@ static int conv_host(const pfhe_conv *c, const uint64_t *in, size_t len_in, uint
     HostStage st(c->device);  // pooled staging context: no allocation in steady state
     if (!st.ok()) return PFHE_ERR_HIP;
     void *din = nullptr, *dout = nullptr;
-    PFHE_TRY(st.upload(in, len_in * 8, &din));
-    PFHE_TRY(st.alloc(len_out * 8, &dout));
-    PFHE_TRY(exact ? pfhe_conv_exact_convert_array_dev(c, (const uint64_t *)din, len_in, (uint64_t *)dout, len_out,
-                                                       poly_length, st.stream())
-                   : pfhe_conv_fast_convert_array_dev(c, (const uint64_t *)din, len_in, (uint64_t *)dout, len_out,
-                                                      poly_length, st.stream()));
-    PFHE_TRY(st.download(out, dout, len_out * 8));
+    PFHE_TRY(st.upload(in, len_in * sizeof(W), &din));
+    PFHE_TRY(st.alloc(len_out * sizeof(W), &dout));
+    PFHE_TRY(conv_array_dev<W>(c, (const W *)din, len_in, (W *)dout, len_out, poly_length, exact, st.stream()));
+    PFHE_TRY(st.download(out, dout, len_out * sizeof(W)));
     return st.finish();
 }
 
-int pfhe_conv_fast_convert_array(const pfhe_conv *c, const uint64_t *crt_poly_in, size_t len_in, uint64_t *crt_poly_out,
-                                 size_t len_out, size_t poly_length) {
-    PFHE_GUARD_BEGIN
-    return conv_host(c, crt_poly_in, len_in, crt_poly_out, len_out, poly_length, false);
-    PFHE_GUARD_END
-}
+}  // namespace
 
-int pfhe_conv_exact_convert_array(const pfhe_conv *c, const uint64_t *crt_poly_in, size_t len_in,
-                                  uint64_t *crt_poly_out, size_t len_out, size_t poly_length) {
-    PFHE_GUARD_BEGIN
-    return conv_host(c, crt_poly_in, len_in, crt_poly_out, len_out, poly_length, true);
-    PFHE_GUARD_END
-}
+// the C entry points of one word type: CV = pfhe_conv / pfhe_conv32, NS = pfhe_rns / pfhe_rns32
+#define PFHE_CONV_FAMILY(CV, NS, W)                                                                                       \
+    int CV##_create(const NS *input_base, const NS *output_base, CV **out) {                                              \
+        PFHE_GUARD_BEGIN                                                                                                  \
+        if (!input_base || !output_base || !out) return PFHE_ERR_BAD_ARGUMENT;                                            \
+        *out = nullptr;                                                                                                   \
+        auto c = std::make_unique<CV>();                                                                                  \
+        PFHE_TRY(conv_create(input_base->h, output_base->h, &c->c));                                                      \
+        *out = c.release();                                                                                               \
+        return PFHE_OK;                                                                                                   \
+        PFHE_GUARD_END                                                                                                    \
+    }                                                                                                                     \
+    void CV##_destroy(CV *c) { delete c; }                                                                                \
+    size_t CV##_input_moduli_count(const CV *c) { return c ? c->c.lin : 0; }                                              \
+    size_t CV##_output_moduli_count(const CV *c) { return c ? c->c.lout : 0; }                                            \
+    int CV##_base_change_matrix(const CV *c, W *out, size_t len) { return conv_matrix<W>(c ? &c->c : nullptr, out, len); } \
+    int CV##_fast_convert_array_dev(const CV *c, const W *crt_poly_in_dev, size_t len_in, W *crt_poly_out_dev,            \
+                                    size_t len_out, size_t poly_length, void *stream) {                                   \
+        PFHE_GUARD_BEGIN                                                                                                  \
+        return conv_array_dev<W>(c ? &c->c : nullptr, crt_poly_in_dev, len_in, crt_poly_out_dev, len_out, poly_length,    \
+                                 false, stream);                                                                          \
+        PFHE_GUARD_END                                                                                                    \
+    }                                                                                                                     \
+    int CV##_fast_convert_array_to_pairs_dev(const CV *c, const W *crt_poly_in_dev, size_t len_in, W *pairs_out_dev,      \
+                                             size_t len_out, size_t poly_length, void *stream) {                          \
+        PFHE_GUARD_BEGIN                                                                                                  \
+        return conv_pairs_dev<W>(c ? &c->c : nullptr, crt_poly_in_dev, len_in, pairs_out_dev, len_out, poly_length,       \
+                                 stream);                                                                                 \
+        PFHE_GUARD_END                                                                                                    \
+    }                                                                                                                     \
+    int CV##_exact_convert_array_dev(const CV *c, const W *crt_poly_in_dev, size_t len_in, W *crt_poly_out_dev,           \
+                                     size_t len_out, size_t poly_length, void *stream) {                                  \
+        PFHE_GUARD_BEGIN                                                                                                  \
+        return conv_array_dev<W>(c ? &c->c : nullptr, crt_poly_in_dev, len_in, crt_poly_out_dev, len_out, poly_length,    \
+                                 true, stream);                                                                           \
+        PFHE_GUARD_END                                                                                                    \
+    }                                                                                                                     \
+    int CV##_fast_convert_array(const CV *c, const W *crt_poly_in, size_t len_in, W *crt_poly_out, size_t len_out,        \
+                                size_t poly_length) {                                                                     \
+        PFHE_GUARD_BEGIN                                                                                                  \
+        return conv_host<W>(c ? &c->c : nullptr, crt_poly_in, len_in, crt_poly_out, len_out, poly_length, false);         \
+        PFHE_GUARD_END                                                                                                    \
+    }                                                                                                                     \
+    int CV##_exact_convert_array(const CV *c, const W *crt_poly_in, size_t len_in, W *crt_poly_out, size_t len_out,       \
+                                 size_t poly_length) {                                                                    \
+        PFHE_GUARD_BEGIN                                                                                                  \
+        return conv_host<W>(c ? &c->c : nullptr, crt_poly_in, len_in, crt_poly_out, len_out, poly_length, true);          \
+        PFHE_GUARD_END                                                                                                    \
+    }
 
+extern "C" {
+PFHE_CONV_FAMILY(pfhe_conv, pfhe_rns, uint64_t)
+PFHE_CONV_FAMILY(pfhe_conv32, pfhe_rns32, uint32_t)
 }  // extern "C"

@@ -145,49 +145,65 @@ class RNSBase32(RNSBase):
 class BaseConverter:
     """primus_rns::BaseConverter — precomputed converter between two RNS bases (converter.rs:21-69).
 
-    Arrays are modulus-major like the reference's; its `scratch` argument has no counterpart."""
+    Arrays are modulus-major like the reference's; its `scratch` argument has no counterpart.  BaseConverter32 below is
+    the <u32> instantiation (uint32 arrays, RNSBase32 bases)."""
 
-    def __init__(self, input_base: RNSBase, output_base: RNSBase):
+    _pre, _dtype, _base = "pfhe_conv_", np.uint64, RNSBase
+    _host, _dev = staticmethod(_host), staticmethod(_dev)
+
+    def _f(self, name):
+        return getattr(lib(), self._pre + name)
+
+    def __init__(self, input_base, output_base):
+        if not (type(input_base) is self._base and type(output_base) is self._base):
+            raise TypeError(f"{type(self).__name__} converts between two {self._base.__name__} bases")
         h = C.c_void_p()
-        check(lib().pfhe_conv_create(input_base._h, output_base._h, C.byref(h)))
+        check(self._f("create")(input_base._h, output_base._h, C.byref(h)))
         self._h = h
 
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
-            lib().pfhe_conv_destroy(h)
+            self._f("destroy")(h)
             self._h = None
 
-    def input_moduli_count(self) -> int: return int(lib().pfhe_conv_input_moduli_count(self._h))
-    def output_moduli_count(self) -> int: return int(lib().pfhe_conv_output_moduli_count(self._h))
+    def input_moduli_count(self) -> int: return int(self._f("input_moduli_count")(self._h))
+    def output_moduli_count(self) -> int: return int(self._f("output_moduli_count")(self._h))
 
     def base_change_matrix(self) -> np.ndarray:
-        out = np.empty(self.input_moduli_count() * self.output_moduli_count(), np.uint64)
-        check(lib().pfhe_conv_base_change_matrix(self._h, *_host(out)))
+        out = np.empty(self.input_moduli_count() * self.output_moduli_count(), self._dtype)
+        check(self._f("base_change_matrix")(self._h, *self._host(out)))
         return out
 
     def fast_convert_array(self, crt_poly_in, crt_poly_out, poly_length: int):
         """converter.rs:192-218."""
-        (pi, ni), (po, no) = _host(crt_poly_in), _host(crt_poly_out)
-        check(lib().pfhe_conv_fast_convert_array(self._h, pi, ni, po, no, poly_length))
+        (pi, ni), (po, no) = self._host(crt_poly_in), self._host(crt_poly_out)
+        check(self._f("fast_convert_array")(self._h, pi, ni, po, no, poly_length))
 
     def exact_convert_array(self, crt_poly_in, crt_poly_out, poly_length: int):
         """converter.rs:274-364 (single output modulus)."""
-        (pi, ni), (po, no) = _host(crt_poly_in), _host(crt_poly_out)
-        check(lib().pfhe_conv_exact_convert_array(self._h, pi, ni, po, no, poly_length))
+        (pi, ni), (po, no) = self._host(crt_poly_in), self._host(crt_poly_out)
+        check(self._f("exact_convert_array")(self._h, pi, ni, po, no, poly_length))
 
     def fast_convert_array_dev(self, crt_poly_in, crt_poly_out, poly_length: int, stream=None):
-        (pi, ni), (po, no) = _dev(crt_poly_in), _dev(crt_poly_out)
-        check(lib().pfhe_conv_fast_convert_array_dev(self._h, pi, ni, po, no, poly_length, _stream(stream)))
+        (pi, ni), (po, no) = self._dev(crt_poly_in), self._dev(crt_poly_out)
+        check(self._f("fast_convert_array_dev")(self._h, pi, ni, po, no, poly_length, _stream(stream)))
 
     def fast_convert_array_to_pairs_dev(self, crt_poly_in, pairs_out, poly_length: int, stream=None):
         """converter.rs:233-272 (fast_convert_array_to_pair_iter): interleaved (mod p_0, mod p_1) pairs."""
-        (pi, ni), (po, no) = _dev(crt_poly_in), _dev(pairs_out)
-        check(lib().pfhe_conv_fast_convert_array_to_pairs_dev(self._h, pi, ni, po, no, poly_length, _stream(stream)))
+        (pi, ni), (po, no) = self._dev(crt_poly_in), self._dev(pairs_out)
+        check(self._f("fast_convert_array_to_pairs_dev")(self._h, pi, ni, po, no, poly_length, _stream(stream)))
 
     def exact_convert_array_dev(self, crt_poly_in, crt_poly_out, poly_length: int, stream=None):
-        (pi, ni), (po, no) = _dev(crt_poly_in), _dev(crt_poly_out)
-        check(lib().pfhe_conv_exact_convert_array_dev(self._h, pi, ni, po, no, poly_length, _stream(stream)))
+        (pi, ni), (po, no) = self._dev(crt_poly_in), self._dev(crt_poly_out)
+        check(self._f("exact_convert_array_dev")(self._h, pi, ni, po, no, poly_length, _stream(stream)))
+
+
+class BaseConverter32(BaseConverter):
+    """primus_rns::BaseConverter<u32, BarrettModulus<u32>> (converter.rs:21, generic over T: FheUint)."""
+
+    _pre, _dtype, _base = "pfhe_conv32_", np.uint32, RNSBase32
+    _host, _dev = staticmethod(_host32), staticmethod(_dev32)
 
 
 class BigUintApproxSignedBasis:

@@ -34,13 +34,18 @@ int main() {
         for (size_t i = 0; i < 4; ++i) { big[i * wl] = 12345u + (uint32_t)i; big[i * wl + 1] = 99u * (uint32_t)i; }
         wide.decompose_big_uint_values_to(big.data(), big.size(), res32.data(), res32.size(), 4);
         wide.compose_multiple_values_to(res32.data(), res32.size(), back.data(), back.size(), 4);
+        pfhe::RNSBase32 in32({17u, 19u, 23u}), out32b({29u, 31u});
+        pfhe::BaseConverter32 conv32(in32, out32b);
+        std::vector<uint32_t> r32 = {1, 2, 3}, c32(2);
+        conv32.fast_convert_array(r32.data(), 3, c32.data(), 2, 1);
+        const bool conv32_ok = conv32.output_moduli_count() == 2 && c32[0] < 29 && c32[1] < 31;
         pfhe::RNSBase32 base32({1073479681u, 1071513601u});
         pfhe::BigUintApproxSignedBasis32 basis32(base32, 20);
         pfhe::DcrtGlevContext32 ctx32(t32, base32, basis32);
         const size_t ell32 = basis32.decompose_length(), cl = t32.crt_poly_length();
         std::vector<uint32_t> glwe32(2 * cl, 5), ggsw32(2 * ell32 * 2 * cl, 0), out32(2 * cl, 9);
         pfhe::mul_dcrt_ggsw_to(glwe32.data(), glwe32.size(), ggsw32.data(), ggsw32.size(), out32.data(), out32.size(), ctx32);
-        bool u32_ok = big == back && wide.moduli_count() == 9 && !ctx32.in_use();
+        bool u32_ok = conv32_ok && big == back && wide.moduli_count() == 9 && !ctx32.in_use();
         for (uint32_t w : out32) u32_ok = u32_ok && w == 0;
         // element-wise family on device buffers: ((a + b) - b) * X^5 * X^(2N-5) == a, and -(-a) == a
         void *da = nullptr, *db = nullptr, *dx = nullptr;

@@ -299,3 +299,81 @@ def test_fused_u32_product_equals_separate_kernels_and_oracle(pf, orc, batch, sh
     pf.glev_mul_big_uint_poly_to_dev(to_dev32(glev), to_dev32(big), r1, ctx)
     pf.glev_mul_crt_poly_to_dev(to_dev32(glev), to_dev32(polys), r2, ctx_sep)
     assert torch.equal(r1, r2)
+
+
+# ---- BaseConverter<u32> ----
+from test_oracle_rns32 import CONV32  # noqa: E402
+
+
+@pytest.mark.parametrize("mod_in,mod_out", CONV32, ids=lambda m: f"L{len(m)}")
+@pytest.mark.parametrize("n", [1, 5, 4096, 65536 + 3])
+def test_conv32_fast_and_exact_match_the_oracle(pf, orc, mod_in, mod_out, n):
+    rng = np.random.default_rng(n + len(mod_in))
+    conv = pf.BaseConverter32(pf.RNSBase32(mod_in), pf.RNSBase32(mod_out))
+    oin = orc.RNSBase32(mod_in)
+    oconv = orc.BaseConverter32(oin, orc.RNSBase32(mod_out))
+    assert conv.input_moduli_count() == len(mod_in) and conv.output_moduli_count() == len(mod_out)
+    assert np.array_equal(conv.base_change_matrix(), oconv.base_change_matrix)
+    x = rand32(rng, mod_in, n)
+    x[0] = 0
+    x[-1] = 0xFFFFFFFF          # an unreduced word: the reference multiplies whatever it is given (converter.rs:160-176)
+    exp = oconv.fast_convert_array(x, n)
+    out = np.empty(len(mod_out) * n, np.uint32)
+    conv.fast_convert_array(x, out, n)
+    assert np.array_equal(out, exp)
+    dout = to_dev32(np.zeros_like(out))
+    conv.fast_convert_array_dev(to_dev32(x), dout, n)
+    assert np.array_equal(to_host32(dout), exp)
+    e = pf.BaseConverter32(pf.RNSBase32(mod_in), pf.RNSBase32(mod_out[:1]))
+    oe = orc.BaseConverter32(oin, orc.RNSBase32(mod_out[:1]))
+    eo = np.empty(n, np.uint32)
+    e.exact_convert_array(x, eo, n)
+    assert np.array_equal(eo, oe.exact_convert_array(x, n))
+    deo = to_dev32(np.zeros_like(eo))
+    e.exact_convert_array_dev(to_dev32(x), deo, n)
+    assert np.array_equal(to_host32(deo), eo)
+
+
+def test_conv32_exact_rounding_boundary(pf, orc):
+    """Values around Q/2: GPU and oracle take the same branch of (sum + 0.5) as u32 for every input."""
+    mod_in, p = Q30, REF_U32[0]
+    Q = Q30[0] * Q30[1] * Q30[2]
+    rng = np.random.default_rng(99)
+    vals = [Q // 2 + d for d in range(-40, 41)] + [Q // 2 + int(rng.integers(-2 ** 30, 2 ** 30)) for _ in range(200)]
+    n = len(vals)
+    x = np.array([v % q for q in mod_in for v in vals], np.uint32)
+    e = pf.BaseConverter32(pf.RNSBase32(mod_in), pf.RNSBase32([p]))
+    oe = orc.BaseConverter32(orc.RNSBase32(mod_in), orc.RNSBase32([p]))
+    eo = np.empty(n, np.uint32)
+    e.exact_convert_array(x, eo, n)
+    ref = oe.exact_convert_array(x, n)
+    assert np.array_equal(eo, ref)
+    assert {int(r) for r in ref} <= {v % p for v in vals} | {(v - Q) % p for v in vals}
+
+
+def test_conv32_pairs_and_errors(pf, orc):
+    rng = np.random.default_rng(17)
+    n = 5000
+    conv = pf.BaseConverter32(pf.RNSBase32(Q30), pf.RNSBase32(REF_U32))
+    oconv = orc.BaseConverter32(orc.RNSBase32(Q30), orc.RNSBase32(REF_U32))
+    x = rand32(rng, Q30, n)
+    exp = oconv.fast_convert_array(x, n)
+    pairs = to_dev32(np.zeros(2 * n, np.uint32))
+    conv.fast_convert_array_to_pairs_dev(to_dev32(x), pairs, n)
+    got = to_host32(pairs)
+    assert np.array_equal(got[0::2], exp[:n]) and np.array_equal(got[1::2], exp[n:])
+    three = pf.BaseConverter32(pf.RNSBase32(REF_U32), pf.RNSBase32(Q30))
+    with pytest.raises(pf.PfheError) as e:
+        three.fast_convert_array_to_pairs_dev(to_dev32(x[:2 * n]), pairs, n)
+    assert e.value.kind == "BadArgument"
+    with pytest.raises(pf.PfheError) as e:      # exact form: exactly one output modulus (converter.rs:284-288)
+        conv.exact_convert_array(x, np.empty(n, np.uint32), n)
+    assert e.value.kind == "BadArgument"
+    with pytest.raises(pf.PfheError) as e:
+        conv.fast_convert_array(x, np.empty(2 * n - 1, np.uint32), n)
+    assert e.value.kind == "BadLength"
+    with pytest.raises(TypeError):               # a <u64> base is not a <u32> base
+        pf.BaseConverter32(pf.RNSBase(Q30), pf.RNSBase32(REF_U32))
+    with pytest.raises(TypeError):
+        pf.BaseConverter(pf.RNSBase32(Q30), pf.RNSBase(REF_U32))
+    conv.fast_convert_array(x[:0], np.empty(0, np.uint32), 0)   # empty input

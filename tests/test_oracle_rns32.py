@@ -155,3 +155,78 @@ def test_external_product32_equals_schoolbook(orc, moduli, log_n, k, log_basis, 
     orc.add_dcrt32_glev_mul_crt_poly_assign(table, base, basis, k, a1, glev, poly)
     orc.add_dcrt32_glev_mul_big_uint_poly_assign(table, base, basis, k, a2, glev, base.compose_multiple_values_to(poly, n))
     assert np.array_equal(a1, a2)
+
+
+# ---- BaseConverter<u32> (primus_rns/src/converter.rs with T = u32) ----
+CONV32 = [([17, 19, 23], [29, 31]), (Q30, REF_U32), (Q30[:2], Q30[2:] + REF_U32), (REF_U32, Q30),
+          (ntt_primes_below(9, 30, 4), ntt_primes_below(2, 29, 4)), (ntt_primes_below(20, 30, 4), ntt_primes_below(3, 28, 4)),
+          (ntt_primes_below(32, 30, 4), ntt_primes_below(2, 27, 4)), (Q30, ntt_primes_below(12, 29, 4))]
+
+
+@pytest.mark.parametrize("mod_in,mod_out", CONV32, ids=lambda m: f"L{len(m)}")
+def test_conv32_fast_convert_is_the_definition_and_the_64_bit_restatement(orc, mod_in, mod_out):
+    """The reference's case (rns.rs:281-343: (17, 19, 23) -> (29, 31)) and wider bases, incl. more than 16 input moduli
+    (two chunks of the 64-bit accumulator, slice.rs:387-404): sum_i [x_i (Q/q_i)^-1]_{q_i} (Q/q_i) mod p_j."""
+    rng = np.random.default_rng(len(mod_in) * 100 + len(mod_out))
+    n = 40
+    conv = orc.BaseConverter32(orc.RNSBase32(mod_in), orc.RNSBase32(mod_out))
+    conv64 = orc.BaseConverter(orc.RNSBase(mod_in), orc.RNSBase(mod_out))
+    Q = 1
+    for q in mod_in:
+        Q *= q
+    M = conv.base_change_matrix.reshape(len(mod_out), len(mod_in))
+    for j, p in enumerate(mod_out):
+        for i, q in enumerate(mod_in):
+            assert int(M[j, i]) == (Q // q) % p
+    x = rand32(rng, mod_in, n)
+    x[0] = 0
+    for i, q in enumerate(mod_in):
+        x[i * n + n - 1] = q - 1
+    out = conv.fast_convert_array(x, n)
+    for t in range(n):
+        s = sum((int(x[i * n + t]) * pow(Q // q, -1, q) % q) * (Q // q) for i, q in enumerate(mod_in))
+        assert [int(out[j * n + t]) for j in range(len(mod_out))] == [s % p for p in mod_out]
+    assert np.array_equal(out.astype(np.uint64), conv64.fast_convert_array(x.astype(np.uint64), n))
+
+
+def test_conv32_accepts_unreduced_input_words(orc):
+    """fill_fast_convert_array_scratch multiplies whatever word it is given (converter.rs:160-176): any u32, not only
+    residues below q_i."""
+    mod_in, mod_out = Q30, REF_U32
+    conv = orc.BaseConverter32(orc.RNSBase32(mod_in), orc.RNSBase32(mod_out))
+    rng = np.random.default_rng(7)
+    n = 64
+    x = rng.integers(0, 1 << 32, 3 * n, dtype=np.uint64).astype(np.uint32)
+    x[:4] = 0xFFFFFFFF
+    Q = mod_in[0] * mod_in[1] * mod_in[2]
+    out = conv.fast_convert_array(x, n)
+    for t in range(n):
+        s = sum((int(x[i * n + t]) * pow(Q // q, -1, q) % q) * (Q // q) for i, q in enumerate(mod_in))
+        assert [int(out[j * n + t]) for j in range(2)] == [s % p for p in mod_out]
+
+
+@pytest.mark.parametrize("mod_in,p", [([17, 19, 23], 37), (Q30, REF_U32[0]), (Q30[:2], 134215681),
+                                      (ntt_primes_below(9, 30, 4), 134176769), (ntt_primes_below(24, 29, 4), 1073479681)])
+def test_conv32_exact_convert_is_the_centred_value(orc, mod_in, p):
+    rng = np.random.default_rng(p % 1000 + len(mod_in))
+    n = 64
+    conv = orc.BaseConverter32(orc.RNSBase32(mod_in), orc.RNSBase32([p]))
+    conv64 = orc.BaseConverter(orc.RNSBase(mod_in), orc.RNSBase([p]))
+    Q = 1
+    for q in mod_in:
+        Q *= q
+    x = rand32(rng, mod_in, n)
+    x[0::n] = 0
+    out = conv.exact_convert_array(x, n)
+    checked = 0
+    for t in range(n):
+        v = crt_compose([int(x[i * n + t]) for i in range(len(mod_in))], mod_in)
+        frac = v / Q
+        if abs(frac - 0.5) < 1e-9:
+            continue
+        assert int(out[t]) == (v % p if frac < 0.5 else (v - Q) % p)
+        checked += 1
+    assert checked >= n - 2
+    assert np.array_equal(out.astype(np.uint64), conv64.exact_convert_array(x.astype(np.uint64), n))
+    with pytest.raises(orc.OracleError):
+        orc.BaseConverter32(orc.RNSBase32(mod_in), orc.RNSBase32(REF_U32)).exact_convert_array(x, n)
