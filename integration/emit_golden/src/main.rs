@@ -14,7 +14,7 @@
 //!   * `BigUintApproxSignedBasis` balanced digits           crates/primus_decompose/src/big_integer/basis.rs:326-367,
 //!                                                          big_integer/common.rs:275-325
 //!   * `CrtGlwe::mul_dcrt_ggsw_to`                          crates/primus_lattice/src/glwe/crt.rs:200-227 (u64, and u32 over U32DcrtTable)
-//!   * `BaseConverter::fast_convert_array` / `exact_convert_array`   crates/primus_rns/src/converter.rs:192-218, 274-364 (nine -> three moduli)
+//!   * `BaseConverter::fast_convert_array` / `exact_convert_array`   crates/primus_rns/src/converter.rs:192-218, 274-364 (nine -> three moduli; u32: three -> two)
 //! — for every case of tests/golden/digests.json (and the u32 / RNS-gadget digest cases), and writes
 //! tests/golden/reference_digests.json: the same entries (same field names, SHA-256 of the little-endian output words)
 //! plus `"source": "primus-fhe @ <git rev>"`.  tests/test_reference_goldens.py then requires the oracle (CPU suite) and the
@@ -42,6 +42,7 @@ pub const Q61: [u64; 3] = [2305843009211596801, 2305843009210023937, 23058430092
 pub const W9: [u64; 9] = [2305843009213693921, 2305843009213693153, 2305843009213692737, 2305843009213692097, 2305843009213691041, 2305843009213690657, 2305843009213689601, 2305843009213689377, 2305843009213689089];
 pub const Q60: [u64; 3] = [1152921504606845473, 1152921504606844513, 1152921504606844417];
 pub const Q30: [u32; 3] = [1073479681, 1071513601, 1070727169];
+pub const P27: [u32; 2] = [134215681, 134176769]; // the moduli of primus_decompose/tests/big_uint.rs:21
 
 // ---------------------------------------------------------------------------------------------------------------
 // tests/golden_inputs.py restated
@@ -401,6 +402,36 @@ pub fn emit_to(out_path: &str, rev: &str) {
              \"output_sha256\": \"{}\"}}",
             strs(&q30_wide),
             digest_u32(&result)
+        ));
+    }
+
+    // ---- round 6, kind "base_convert32": BaseConverter::<u32, BarrettModulus<u32>> (converter.rs:21, generic over T) from
+    //      the 30-bit triple into the two moduli of the reference's own u32 test (primus_decompose/tests/big_uint.rs:21):
+    //      fast_convert_array, then exact_convert_array into the first of them, of the same residues
+    {
+        let (count, seed) = (2048usize, 0x350u64);
+        let q30_wide: Vec<u64> = Q30.iter().map(|&q| q as u64).collect();
+        let in_moduli: Vec<BarrettModulus<u32>> = Q30.iter().map(|&q| BarrettModulus::new(q)).collect();
+        let out_moduli: Vec<BarrettModulus<u32>> = P27.iter().map(|&q| BarrettModulus::new(q)).collect();
+        let base = RNSBase::<u32, BarrettModulus<u32>>::new(&in_moduli).expect("u32 input base");
+        let out_base = RNSBase::<u32, BarrettModulus<u32>>::new(&out_moduli).expect("u32 output base");
+        let residues: Vec<u32> = splitmix_rns(seed, &q30_wide, count, 1).into_iter().map(|v| v as u32).collect();
+        let conv = BaseConverter::new(&base, &out_base);
+        let mut fast = vec![0u32; count * P27.len()];
+        let mut conv_scratch = vec![0u32; count * Q30.len()];
+        conv.fast_convert_array(&residues, &mut fast, count, &mut conv_scratch);
+        let one_base = RNSBase::<u32, BarrettModulus<u32>>::new(&out_moduli[..1]).expect("one-modulus base");
+        let exact_conv = BaseConverter::new(&base, &one_base);
+        let mut exact = vec![0u32; count];
+        exact_conv.exact_convert_array(&residues, &mut exact, count);
+        fast.extend_from_slice(&exact);
+        let p27_wide: Vec<u64> = P27.iter().map(|&q| q as u64).collect();
+        digests.push(format!(
+            "{{\"kind\": \"base_convert32\", \"case\": 0, \"moduli\": {}, \"moduli_out\": {}, \"count\": {count}, \"seed\": {seed}, \
+             \"output_sha256\": \"{}\"}}",
+            strs(&q30_wide),
+            strs(&p27_wide),
+            digest_u32(&fast)
         ));
     }
 

@@ -305,6 +305,80 @@ impl NttTable for HipU32NttTable {
 }
 
 // ------------------------------------------------------------------------------------------------
+// U32DcrtTable (crates/primus_ntt/src/dcrt/prime32.rs:11-128)
+// ------------------------------------------------------------------------------------------------
+pub struct HipU32DcrtTable {
+    h: *mut ffi::pfhe_dcrt32,
+    limbs: Vec<HipU32NttTable>,
+    poly_length: usize,
+}
+unsafe impl Send for HipU32DcrtTable {}
+unsafe impl Sync for HipU32DcrtTable {}
+impl Drop for HipU32DcrtTable {
+    fn drop(&mut self) {
+        unsafe { ffi::pfhe_dcrt32_destroy(self.h) }
+    }
+}
+impl HipU32DcrtTable {
+    /// Raw handle for the device-resident entry points (`pfhe_dcrt32_*_dev`, `pfhe_extprod32_*`).
+    pub fn handle(&self) -> *const ffi::pfhe_dcrt32 {
+        self.h
+    }
+}
+
+impl DcrtTable for HipU32DcrtTable {
+    type ValueT = u32;
+    type NttTables = HipU32NttTable;
+
+    fn new<M: FieldContext<u32>>(log_n: u32, moduli: &[M]) -> Result<Self, NttError<u32>> {
+        let qs: Vec<u32> = moduli.iter().map(|m| m.value().ok_or(NttError::NttTableErr)).collect::<Result<_, _>>()?;
+        let limbs = moduli.iter().map(|m| HipU32NttTable::new(log_n, *m)).collect::<Result<Vec<_>, _>>()?;
+        let mut h = core::ptr::null_mut();
+        match unsafe { ffi::pfhe_dcrt32_create(log_n, qs.as_ptr(), qs.len(), device(), &mut h) } {
+            ffi::PFHE_OK => Ok(Self { h, limbs, poly_length: 1usize << log_n }),
+            e => Err(status_to_err(e, 1usize << log_n, qs.first().copied().unwrap_or(0), 30)),
+        }
+    }
+    fn ntt_tables(&self) -> &[HipU32NttTable] {
+        &self.limbs
+    }
+    fn iter(&self) -> std::slice::Iter<'_, HipU32NttTable> {
+        self.limbs.iter()
+    }
+    fn poly_length(&self) -> usize {
+        self.poly_length
+    }
+    fn moduli_count(&self) -> usize {
+        self.limbs.len()
+    }
+    fn crt_poly_length(&self) -> usize {
+        self.poly_length * self.limbs.len()
+    }
+    fn transform_inplace<S: RawData<Elem = u32> + DataMut>(&self, mut crt_poly: CrtPolynomial<S>) -> DcrtPolynomial<S> {
+        self.transform_slice(crt_poly.as_mut_slice());
+        DcrtPolynomial::new(crt_poly.0)
+    }
+    fn inverse_transform_inplace<S: RawData<Elem = u32> + DataMut>(&self, mut dcrt_poly: DcrtPolynomial<S>) -> CrtPolynomial<S> {
+        self.inverse_transform_slice(dcrt_poly.as_mut_slice());
+        CrtPolynomial::new(dcrt_poly.0)
+    }
+    fn lazy_transform_slice(&self, poly: &mut [u32]) {
+        expect_ok(unsafe { ffi::pfhe_dcrt32_lazy_transform_slice(self.h, poly.as_mut_ptr(), poly.len()) }, "dcrt32 lazy_transform_slice")
+    }
+    fn transform_slice(&self, poly: &mut [u32]) {
+        expect_ok(unsafe { ffi::pfhe_dcrt32_transform_slice(self.h, poly.as_mut_ptr(), poly.len()) }, "dcrt32 transform_slice")
+    }
+    fn lazy_inverse_transform_slice(&self, poly: &mut [u32]) {
+        expect_ok(unsafe { ffi::pfhe_dcrt32_lazy_inverse_transform_slice(self.h, poly.as_mut_ptr(), poly.len()) },
+                  "dcrt32 lazy_inverse_transform_slice")
+    }
+    fn inverse_transform_slice(&self, poly: &mut [u32]) {
+        expect_ok(unsafe { ffi::pfhe_dcrt32_inverse_transform_slice(self.h, poly.as_mut_ptr(), poly.len()) },
+                  "dcrt32 inverse_transform_slice")
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Batched, device-resident RNS gadget external product:
 //   CrtGlwe::mul_dcrt_ggsw_to (crates/primus_lattice/src/glwe/crt.rs:200-227) for `batch` ciphertexts
 // ------------------------------------------------------------------------------------------------
@@ -346,6 +420,43 @@ impl Drop for HipExternalProduct {
             ffi::pfhe_extprod_plan_destroy(self.plan);
             ffi::pfhe_basis_destroy(self.basis);
             ffi::pfhe_rns_destroy(self.rns);
+        }
+    }
+}
+
+/// The same over `U32DcrtTable`: `CrtGlwe::<u32>::mul_dcrt_ggsw_to` with `RNSBase<u32>` and
+/// `BigUintApproxSignedBasis<u32>` (u32 words on the device; moduli below 2^30, log_basis below 32).
+pub struct HipExternalProduct32 {
+    rns: *mut ffi::pfhe_rns32,
+    basis: *mut ffi::pfhe_basis32,
+    plan: *mut ffi::pfhe_extprod32_plan,
+}
+impl HipExternalProduct32 {
+    pub fn new(table: &HipU32DcrtTable, moduli: &[u32], log_basis: u32, glwe_dimension: usize) -> Result<Self, c_int> {
+        let (mut rns, mut basis, mut plan) = (core::ptr::null_mut(), core::ptr::null_mut(), core::ptr::null_mut());
+        unsafe {
+            let rc = ffi::pfhe_rns32_create(moduli.as_ptr(), moduli.len(), device(), &mut rns);
+            if rc != ffi::PFHE_OK { return Err(rc); }
+            let rc = ffi::pfhe_basis32_create(rns, log_basis, 0, &mut basis);
+            if rc != ffi::PFHE_OK { ffi::pfhe_rns32_destroy(rns); return Err(rc); }
+            let rc = ffi::pfhe_extprod32_plan_create(table.handle(), rns, basis, glwe_dimension, 0, &mut plan);
+            if rc != ffi::PFHE_OK { ffi::pfhe_basis32_destroy(basis); ffi::pfhe_rns32_destroy(rns); return Err(rc); }
+        }
+        Ok(Self { rns, basis, plan })
+    }
+    pub unsafe fn mul_dcrt_ggsw_to_dev(&mut self, crt_glwe_dev: *const u32, len_glwe: usize, dcrt_ggsw_dev: *const u32,
+                                       len_ggsw: usize, result_dev: *mut u32, into_coeff_form: bool,
+                                       stream: *mut core::ffi::c_void) -> Result<(), c_int> {
+        status(unsafe { ffi::pfhe_extprod32_mul_dcrt_ggsw_to_dev(self.plan, crt_glwe_dev, len_glwe, dcrt_ggsw_dev, len_ggsw,
+                                                                 result_dev, len_glwe, into_coeff_form as c_int, stream) })
+    }
+}
+impl Drop for HipExternalProduct32 {
+    fn drop(&mut self) {
+        unsafe {
+            ffi::pfhe_extprod32_plan_destroy(self.plan);
+            ffi::pfhe_basis32_destroy(self.basis);
+            ffi::pfhe_rns32_destroy(self.rns);
         }
     }
 }

@@ -28,6 +28,7 @@ Q61 = pyref.Q61
 W9 = ntt_primes_below(9, 61, 4)     # the nine largest primes below 2^61 that are 1 mod 32 (emit_golden: const W9)
 Q60 = ntt_primes_below(3, 60, 4)    # conversion target (const Q60)
 Q30 = [1073479681, 1071513601, 1070727169]
+P27 = [134215681, 134176769]       # the moduli of primus_decompose/tests/big_uint.rs:21 (const P27)
 
 # cases beyond tests/golden/digests.json that integration/emit_golden emits too (keep in step with its main.rs)
 EXTRA_CASES = [
@@ -43,6 +44,7 @@ EXTRA_CASES = [
     dict(kind="base_convert", case=0, moduli=[str(q) for q in W9], moduli_out=[str(q) for q in Q60], count=2048, seed=0x342),
     dict(kind="external_product32", case=0, log_n=10, k=1, moduli=[str(q) for q in Q30], log_basis=15, batch=2,
          seed_glwe=0x720, seed_ggsw=0x730),
+    dict(kind="base_convert32", case=0, moduli=[str(q) for q in Q30], moduli_out=[str(q) for q in P27], count=2048, seed=0x350),
 ]
 
 
@@ -91,6 +93,12 @@ class OracleBackend:
         inp = self.o.RNSBase(moduli)
         fast = self.o.BaseConverter(inp, self.o.RNSBase(moduli_out)).fast_convert_array(residues, count)
         exact = self.o.BaseConverter(inp, self.o.RNSBase(moduli_out[:1])).exact_convert_array(residues, count)
+        return np.concatenate([fast, exact])
+
+    def base_convert32(self, moduli, moduli_out, residues, count):
+        inp = self.o.RNSBase32(moduli)
+        fast = self.o.BaseConverter32(inp, self.o.RNSBase32(moduli_out)).fast_convert_array(residues, count)
+        exact = self.o.BaseConverter32(inp, self.o.RNSBase32(moduli_out[:1])).exact_convert_array(residues, count)
         return np.concatenate([fast, exact])
 
     def external_product32(self, log_n, k, moduli, log_basis, glwe, ggsw_of):
@@ -155,6 +163,14 @@ class HipBackend:
         self.p.BaseConverter(inp, self.p.RNSBase(moduli_out[:1])).exact_convert_array(residues, exact, count)
         return np.concatenate([fast, exact])
 
+    def base_convert32(self, moduli, moduli_out, residues, count):
+        inp = self.p.RNSBase32(moduli)
+        fast = np.empty(len(moduli_out) * count, np.uint32)
+        self.p.BaseConverter32(inp, self.p.RNSBase32(moduli_out)).fast_convert_array(residues, fast, count)
+        exact = np.empty(count, np.uint32)
+        self.p.BaseConverter32(inp, self.p.RNSBase32(moduli_out[:1])).exact_convert_array(residues, exact, count)
+        return np.concatenate([fast, exact])
+
     def external_product32(self, log_n, k, moduli, log_basis, glwe, ggsw_of):
         t, base = self.p.U32DcrtTable(log_n, moduli), self.p.RNSBase32(moduli)
         basis = self.p.BigUintApproxSignedBasis32(base, log_basis)
@@ -217,6 +233,10 @@ def compute(entry, be):
         count = entry["count"]
         residues = splitmix_rns(entry["seed"], moduli, count, 1)
         return digest(be.base_convert(moduli, [int(m) for m in entry["moduli_out"]], residues, count)), {}
+    if kind == "base_convert32":
+        count = entry["count"]
+        residues = splitmix_rns(entry["seed"], moduli, count, 1).astype(np.uint32)
+        return digest_u32(be.base_convert32(moduli, [int(m) for m in entry["moduli_out"]], residues, count)), {}
     if kind in ("rns_compose", "gadget_digits"):
         count = entry["count"]
         residues = splitmix_rns(entry["seed"], moduli, count, 1)
@@ -286,13 +306,14 @@ def handmade(orc, cases, source):
     return {"source": source, "generator": "tests/test_reference_goldens.py (oracle, NOT the reference)", "digests": out}
 
 
-SMALL = [c for c in all_cases() if c.get("log_n", 0) <= 12 or c["kind"] in ("rns_compose", "gadget_digits", "base_convert")]
+SMALL = [c for c in all_cases() if c.get("log_n", 0) <= 12 or c["kind"] in ("rns_compose", "gadget_digits", "base_convert", "base_convert32")]
 
 
 def test_consumer_accepts_a_faithful_file_and_reports_a_tampered_one(orc, tmp_path):
     doc = handmade(orc, SMALL, "hand-made from the oracle (consumer self-test)")
     assert {e["kind"] for e in doc["digests"]} == {"ntt_forward", "dcrt_polymul", "external_product", "ntt32_forward",
-                                                   "rns_compose", "gadget_digits", "base_convert", "external_product32"}
+                                                   "rns_compose", "gadget_digits", "base_convert", "external_product32",
+                                                   "base_convert32"}
     good = tmp_path / "reference_digests.json"
     good.write_text(json.dumps(doc, indent=1))
     problems, _ = check_reference_file(str(good), OracleBackend(orc))
@@ -385,7 +406,11 @@ def test_rust_generator_and_python_consumer_list_the_same_cases():
     assert "(0x720 + cid as u64, 0x730 + cid as u64)" in src
     assert all((c["seed_glwe"], c["seed_ggsw"]) == (0x720 + c["case"], 0x730 + c["case"])
                for c in EXTRA_CASES if c["kind"] == "external_product32")
+    # BaseConverter<u32>: the 30-bit triple into the two moduli of the reference's u32 test
+    assert "const P27: [u32; 2] = [%s];" % ", ".join(str(q) for q in P27) in src
+    conv32 = [c for c in EXTRA_CASES if c["kind"] == "base_convert32"]
+    assert len(conv32) == 1 and "let (count, seed) = (%dusize, 0x%xu64);" % (conv32[0]["count"], conv32[0]["seed"]) in src
     # every kind the generator writes is one the consumer knows
     kinds = set(re.findall(r'\\"kind\\": \\"([a-z0-9_]+)\\"', src))
     assert kinds == {"ntt_forward", "dcrt_polymul", "external_product", "ntt32_forward", "rns_compose", "gadget_digits",
-                     "base_convert", "external_product32"}
+                     "base_convert", "external_product32", "base_convert32"}
