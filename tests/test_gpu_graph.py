@@ -243,3 +243,39 @@ def test_round3_kernels_first_called_inside_a_capture(pf):
     ref = torch.zeros_like(dg)
     pf.mul_dcrt_ggsw_to_dev(dg, dk, ref, ctx, into_coeff_form=True)
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("log_n,batch", [(11, 3), (16, 4)])   # separate kernels / the fused kernels of N = 2^16
+def test_u32_external_product_in_a_graph(pf, log_n, batch):
+    """The <u32> product (pfhe_extprod32_mul_dcrt_ggsw_to_dev) and the u32 transform, captured and replayed: same words as
+    the eager run, for the shape that takes the separate kernels and for the one that takes the fused ones."""
+    import torch
+    from test_gpu_u32 import to_dev32
+    from test_oracle_rns32 import Q30, rand32
+    k, n = 1, 1 << log_n
+    rng = np.random.default_rng(log_n)
+    t, base = pf.U32DcrtTable(log_n, Q30), pf.RNSBase32(Q30)
+    basis = pf.BigUintApproxSignedBasis32(base, 15)
+    ctx = pf.DcrtGlevContext32(t, base, basis, k)
+    ell = basis.decompose_length()
+    dg = to_dev32(rand32(rng, Q30, n, batch * (k + 1)))
+    dk = to_dev32(rand32(rng, Q30, n, (k + 1) * ell * (k + 1)))
+    out = torch.zeros_like(dg)
+    s = torch.cuda.Stream()
+
+    def work():
+        pf.mul_dcrt_ggsw_to_dev(dg, dk, out, ctx, into_coeff_form=True, stream=s)
+        t.transform_dev(out, stream=s)
+
+    with torch.cuda.stream(s):
+        work()
+    s.synchronize()
+    ref = out.clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        work()
+    for _ in range(2):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)

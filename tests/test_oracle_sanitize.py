@@ -17,7 +17,8 @@ def test_oracle_under_asan_ubsan():
         exe = os.path.join(d, "sanitize")
         cmd = ["gcc", "-O1", "-g", "-std=c11", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
                "-fno-omit-frame-pointer", "-I", ORACLE, os.path.join(ORACLE, "sanitize_main.c"),
-               os.path.join(ORACLE, "pfhe_oracle.c"), os.path.join(ORACLE, "pfhe_oracle_avx512.c"), "-o", exe]
+               os.path.join(ORACLE, "pfhe_oracle.c"), os.path.join(ORACLE, "pfhe_oracle_avx512.c"),
+               os.path.join(ORACLE, "pfhe_oracle_rns32.c"), "-o", exe]
         build = subprocess.run(cmd, capture_output=True, text=True)
         if build.returncode != 0 and "sanitize" in build.stderr.lower() and "cannot find" in build.stderr.lower():
             pytest.skip("sanitizer runtime not installed")
