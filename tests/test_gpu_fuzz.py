@@ -208,3 +208,112 @@ def test_pseudo_mersenne_bounds(pf, orc, K, largest_c):
     d = to_dev(li); t.inverse_transform_dev(d, lazy=True)
     got = to_host(d)
     assert got.max() < 2 * q and np.array_equal(got % np.uint64(q), cani)
+
+
+# ---- round 6: the <u32> RNS / gadget / conversion / product layer and bases of up to 32 moduli, randomized ----
+def random_coprime_moduli(rng, count, max_bits):
+    """`count` pairwise-coprime odd moduli (not necessarily prime) of random sizes in [3, 2^max_bits)."""
+    from math import gcd
+    out = []
+    while len(out) < count:
+        bits = int(rng.integers(max(2, max_bits - 12), max_bits + 1))
+        c = int(rng.integers(1 << (bits - 1), 1 << bits)) | 1
+        if c > 2 and all(gcd(c, m) == 1 for m in out):
+            out.append(c)
+    return out
+
+
+def _family(pf, orc, word_bits):
+    if word_bits == 32:
+        return (pf.RNSBase32, pf.BigUintApproxSignedBasis32, pf.BaseConverter32, orc.RNSBase32, orc.BigUintApproxSignedBasis32,
+                orc.BaseConverter32, np.uint32)
+    return pf.RNSBase, pf.BigUintApproxSignedBasis, pf.BaseConverter, orc.RNSBase, orc.BigUintApproxSignedBasis, orc.BaseConverter, np.uint64
+
+
+@pytest.mark.parametrize("word_bits", [32, 64])
+@pytest.mark.parametrize("case", range(24 * SCALE))
+def test_random_bases_compose_digits_and_conversion(pf, orc, case, word_bits):
+    """Random base width (1..32 moduli, every constants form and limb-count template), random composite moduli, random
+    log_basis and reverse_length: compose, out-of-place carry init, every level's unsigned and signed digits, decompose
+    back, and a conversion into a second random base — each against the oracle on the same words."""
+    rng = np.random.default_rng(7000 + case + 1000 * word_bits)
+    RNS, Basis, Conv, oRNS, oBasis, oConv, dt = _family(pf, orc, word_bits)
+    L = int(rng.integers(1, 33)) if case % 3 else int(rng.integers(1, 9))
+    moduli = random_coprime_moduli(rng, L, word_bits - 2)
+    base, obase = RNS(moduli), oRNS(moduli)
+    vl = base.big_uint_value_len()
+    assert vl == obase.value_len
+    count = int(rng.integers(1, 700))
+    res = np.concatenate([rng.integers(0, q, count, dtype=np.uint64).astype(dt) for q in moduli])
+    big = np.empty(count * vl, dt)
+    base.compose_multiple_values_to(res, big, count)
+    obig = obase.compose_multiple_values_to(res, count)
+    assert np.array_equal(big, obig), (moduli, count)
+    back = np.empty_like(res)
+    base.decompose_big_uint_values_to(big, back, count)
+    assert np.array_equal(back, res)
+    Q = 1
+    for q in moduli:
+        Q *= q
+    log_basis = int(rng.integers(1, min(word_bits, Q.bit_length() + 1)))
+    ell_full = max(1, Q.bit_length() // log_basis)
+    rev = None if case % 2 else int(rng.integers(1, ell_full + 1))
+    try:
+        obasis = oBasis(obase, log_basis, rev)
+    except orc.OracleError:
+        with pytest.raises(pf.PfheError):
+            Basis(base, log_basis, rev)
+        return
+    basis = Basis(base, log_basis, rev)
+    assert (basis.decompose_length(), basis.drop_bits()) == (obasis.decompose_length, obasis.drop_bits), (moduli, log_basis, rev)
+    adj, car = np.empty_like(big), np.zeros(count, np.uint8)
+    basis.init_value_carry_slice_to(big, adj, car)
+    oadj, ocar = obasis.init_value_carry_slice_to(obig.copy(), count)
+    assert np.array_equal(adj, oadj) and np.array_equal(car, ocar), (moduli, log_basis, rev)
+    car2, ocar2 = car.copy(), ocar.copy()
+    for level in range(basis.decompose_length()):
+        dig = np.empty(count, dt)
+        basis.unsigned_decompose_slice_to(level, adj, dig, car)
+        assert np.array_equal(dig, obasis.unsigned_decompose_slice_to(level, oadj, ocar, count)), (moduli, log_basis, rev, level)
+        assert np.array_equal(car, ocar)
+        sig = np.empty_like(adj)
+        basis.decompose_slice_to(level, adj, sig, car2)
+        assert np.array_equal(sig, obasis.decompose_slice_to(level, oadj, ocar2, count)), (moduli, log_basis, rev, level)
+    # conversion into a second random base that is coprime to nothing in particular (BaseConverter::new takes any two bases)
+    Lo = int(rng.integers(1, 9)) if case % 4 else int(rng.integers(9, 33))
+    mod_out = random_coprime_moduli(rng, Lo, word_bits - 2)
+    conv, oconv = Conv(base, RNS(mod_out)), oConv(obase, oRNS(mod_out))
+    out = np.empty(Lo * count, dt)
+    conv.fast_convert_array(res, out, count)
+    assert np.array_equal(out, oconv.fast_convert_array(res, count)), (moduli, mod_out)
+    e, oe = Conv(base, RNS(mod_out[:1])), oConv(obase, oRNS(mod_out[:1]))
+    eo = np.empty(count, dt)
+    e.exact_convert_array(res, eo, count)
+    assert np.array_equal(eo, oe.exact_convert_array(res, count)), (moduli, mod_out[0])
+
+
+@pytest.mark.parametrize("case", range(16 * SCALE))
+def test_random_u32_external_products(pf, orc, case):
+    from test_gpu_rns32 import make_case32
+    rng = np.random.default_rng(8000 + case)
+    log_n = int(rng.integers(3, 13)) if case % 4 else 16
+    L = int(rng.integers(1, 5)) if case % 5 else int(rng.integers(5, 12))
+    bits = int(rng.integers(max(log_n + 12, 20), 31))
+    k = int(rng.integers(1, 3)) if log_n < 16 else 1
+    moduli = random_ntt_primes(rng, L, bits, log_n)
+    Q = 1
+    for q in moduli:
+        Q *= q
+    log_basis = int(rng.integers(4, min(31, min(moduli).bit_length() - 1)))   # the lift needs B below every modulus
+    ell_full = max(1, Q.bit_length() // log_basis)
+    rev = None if case % 3 else int(rng.integers(1, min(ell_full, 8) + 1))
+    if rev is None and ell_full > 10:
+        rev = 6                      # keep the GGSW of a wide base small
+    batch = int(rng.integers(1, 6)) if log_n == 16 else int(rng.integers(1, 4))
+    shared = bool(case % 2)
+    otable, obase, obasis, glwe, ggsw, exp = make_case32(orc, rng, log_n, k, moduli, log_basis, rev, batch, shared)
+    t, base = pf.U32DcrtTable(log_n, moduli), pf.RNSBase32(moduli)
+    ctx = pf.DcrtGlevContext32(t, base, pf.BigUintApproxSignedBasis32(base, log_basis, rev), k, int(rng.integers(0, 3)))
+    out = np.empty_like(glwe)
+    pf.mul_dcrt_ggsw_to(glwe, ggsw, out, ctx)
+    assert np.array_equal(out, exp), (log_n, moduli, k, log_basis, rev, batch, shared)
