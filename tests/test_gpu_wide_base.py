@@ -269,3 +269,69 @@ def test_external_product_equals_schoolbook(pf):
     exp = pyref.external_product_coeff(moduli, n, k, g, glwe.reshape(k + 1, L, n).tolist(),
                                        key_coeff.reshape(k + 1, ell, k + 1, L, n).tolist())
     assert out.reshape(k + 1, L, n).tolist() == exp
+
+
+@pytest.mark.parametrize("word_bits", [64, 32])
+def test_derived_handles_outlive_their_base(pf, orc, word_bits):
+    """A wide base keeps its constants in a device table that the basis, the converter and the plan derived from it share
+    (reference-counted: include/pfhe.h, pfhe_rns_create).  Destroying the pfhe_rns first must leave every derived handle
+    working — the reference's types own clones of the base (converter.rs:64-68) — and destroying the last of them frees
+    the table."""
+    import gc
+    if word_bits == 64:
+        RNS, Basis, Conv, Ctx, Table, dt = pf.RNSBase, pf.BigUintApproxSignedBasis, pf.BaseConverter, pf.DcrtGlevContext, pf.U64DcrtTable, np.uint64
+        oRNS, oBasis, oConv = orc.RNSBase, orc.BigUintApproxSignedBasis, orc.BaseConverter
+        log_n, k, log_basis, rev = 7, 1, 13, 5
+        moduli, mod_out = base_moduli(12, 45, log_n), ntt_primes_below(2, 44, 4)
+    else:
+        RNS, Basis, Conv, Ctx, Table, dt = (pf.RNSBase32, pf.BigUintApproxSignedBasis32, pf.BaseConverter32, pf.DcrtGlevContext32,
+                                            pf.U32DcrtTable, np.uint32)
+        oRNS, oBasis, oConv = orc.RNSBase32, orc.BigUintApproxSignedBasis32, orc.BaseConverter32
+        log_n, k, log_basis, rev = 7, 1, 13, 5
+        moduli, mod_out = ntt_primes_below(12, 30, log_n), ntt_primes_below(2, 29, 4)
+    n, L = 1 << log_n, len(moduli)
+    rng = np.random.default_rng(word_bits)
+    count_of = lambda: int(pf.lib().pfhe_debug_alloc_count())  # noqa: E731
+    base, out_base = RNS(moduli), RNS(mod_out)
+    basis = Basis(base, log_basis, rev)
+    conv = Conv(base, out_base)
+    table = Table(log_n, moduli)
+    ctx = Ctx(table, base, basis, k)
+    ell = basis.decompose_length()
+    # destroy the base (and the narrow output base) at the C level; the Python objects must not destroy them again
+    for b in (base, out_base):
+        b._f("destroy")(b._h)
+        b._h = None
+    gc.collect()
+    before = count_of()
+    obase = oRNS(moduli)
+    obasis = oBasis(obase, log_basis, rev)
+    res = np.concatenate([rng.integers(0, q, n, dtype=np.uint64).astype(dt) for q in moduli])
+    out = np.empty(2 * n, dt)
+    conv.fast_convert_array(res, out, n)
+    assert np.array_equal(out, oConv(obase, oRNS(mod_out)).fast_convert_array(res, n))
+    big = obase.compose_multiple_values_to(res, n)
+    adj, car = np.empty_like(big), np.zeros(n, np.uint8)
+    basis.init_value_carry_slice_to(big, adj, car)
+    oadj, ocar = obasis.init_value_carry_slice_to(big.copy(), n)
+    assert np.array_equal(adj, oadj) and np.array_equal(car, ocar)
+    for level in range(ell):
+        dig = np.empty(n, dt)
+        basis.unsigned_decompose_slice_to(level, adj, dig, car)
+        assert np.array_equal(dig, obasis.unsigned_decompose_slice_to(level, oadj, ocar, n))
+    glwe = np.concatenate([rng.integers(0, q, n, dtype=np.uint64).astype(dt) for _ in range(k + 1) for q in moduli])
+    ggsw = np.concatenate([rng.integers(0, q, n, dtype=np.uint64).astype(dt) for _ in range((k + 1) * ell * (k + 1)) for q in moduli])
+    got = np.empty_like(glwe)
+    pf.mul_dcrt_ggsw_to(glwe, ggsw, got, ctx)
+    if word_bits == 64:
+        exp = orc.mul_dcrt_ggsw_to(orc.U64DcrtTable(log_n, moduli), obase, obasis, k, glwe.copy(), ggsw)
+    else:
+        exp = orc.mul_dcrt32_ggsw_to(orc.U32DcrtTable(log_n, moduli), obase, obasis, k, glwe.copy(), ggsw)
+    assert np.array_equal(got, exp)
+    assert L > 8 and count_of() >= before
+    del conv
+    gc.collect()
+    mid = count_of()
+    del ctx, basis
+    gc.collect()
+    assert count_of() > mid                          # the plan's scratch and, with the last holder, the shared tables
