@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256, 4) void gadget_block_mulacc32_kernel(const u64
 #pragma unroll
         for (int m = 0; m < 2 * E; ++m) acc[c][m] = 0;
 
-    u32 ij = 0;
+    u32 ij = 0, pending = 0;
     do {  // terms >= 1 (checked on the host)
         u64 x[E];
         u64x2 io[NV];
@@ -463,7 +463,8 @@ __global__ __launch_bounds__(256, 4) void gadget_block_mulacc32_kernel(const u64
                 acc[c][4 * j + 3] += (io[j].y >> 32) * (kv[j].y >> 32);
             }
         }
-        if ((ij & 7u) == 7u) {  // eight products below 2^60 on top of a folded value: below 2^63 + 2^30
+        if (++pending == kFold32Every) {  // fifteen products below 2^60 on top of a folded value: below 2^64 (pfhe_rns.hpp)
+            pending = 0;
 #pragma unroll
             for (int c = 0; c < NC; ++c)
 #pragma unroll

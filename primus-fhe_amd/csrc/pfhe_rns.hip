@@ -278,9 +278,13 @@ __global__ __launch_bounds__(kThreads) void gadget_mulacc32_kernel(const NttPrim
     u32 *__restrict__ out = result + (e * (k + 1) + c) * W + (u64)limb * n + t;
     u64 acc = accumulate ? *out : 0u;
     const u32 terms = rows * ell;
+    u32 pending = accumulate ? 1u : 0u;  // the previous result counts as one term (below 2^32 <= 2^60)
     for (u32 ij = 0; ij < terms; ++ij) {
         acc += (u64)dg[(u64)ij * W] * key[(u64)ij * (k + 1) * W];
-        if ((ij & 7u) == 7u) acc = red64_32(acc, q, bar);
+        if (++pending == kFold32Every) {
+            acc = red64_32(acc, q, bar);
+            pending = 0;
+        }
     }
     *out = red64_32(acc, q, bar);
 }

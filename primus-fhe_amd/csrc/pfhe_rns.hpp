@@ -15,6 +15,10 @@ namespace pfhe {
 // accessors, and the device functions (pfhe_rns_device.hpp) and kernels (pfhe_rns.hip) are templates over them.
 constexpr int kMaxLimbs = 8;
 constexpr int kMaxWideLimbs = 32;
+// The <u32> product's lazy 64-bit accumulators (one v_mad_u64_u32 per coefficient and term): digit_hat and key words are
+// canonical (< q < 2^30), a product is at most (2^30 - 1)^2 < 2^60, so fifteen of them on top of a folded value (< 2^30)
+// stay below 2^64; the accumulators are folded once per kFold32Every terms and at the end.
+constexpr unsigned kFold32Every = 15;
 
 // RNSBase<u64, BarrettModulus<u64>> constants (primus_rns/src/base.rs:26-117), passed by value.
 // L and value_len are valid for every base; the arrays only when L <= kMaxLimbs.

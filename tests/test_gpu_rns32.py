@@ -377,3 +377,43 @@ def test_conv32_pairs_and_errors(pf, orc):
     with pytest.raises(TypeError):
         pf.BaseConverter(pf.RNSBase32(Q30), pf.RNSBase(REF_U32))
     conv.fast_convert_array(x[:0], np.empty(0, np.uint32), 0)   # empty input
+
+
+@pytest.mark.parametrize("log_n,batch", [(6, 2), (16, 4)])   # separate kernels / the fused kernels
+def test_u32_product_accumulators_at_their_bound(pf, orc, log_n, batch):
+    """The lazy 64-bit accumulators of the u32 multiply-accumulate kernels are folded every fifteen terms
+    (csrc/pfhe_rns.hpp, kFold32Every): the bound is met exactly when every digit_hat and every key word is q - 1.  Input
+    polynomials whose only coefficient is -sum_j 2^(drop + j log B) have the digit -1 at every level, so every digit
+    polynomial is the constant q - 1 and so is its transform; with a key of q - 1 everywhere each of the (k+1) ell = 36
+    terms adds (q - 1)^2 to every accumulator."""
+    k, log_basis = 1, 5
+    n, L = 1 << log_n, 3
+    g = pyref.Gadget(Q30, log_basis)
+    ell = g.ell
+    assert (k + 1) * ell >= 2 * 15 + 1
+    v = (-sum(1 << (g.drop + j * log_basis) for j in range(ell))) % g.Q
+    assert g.signed_digits(v) == [-1] * ell
+    poly = np.zeros(L * n, np.uint32)
+    for i, q in enumerate(Q30):
+        poly[i * n] = v % q
+    glwe = np.tile(poly, batch * (k + 1))
+    ggsw = np.concatenate([np.full(n, q - 1, np.uint32) for _ in range((k + 1) * ell * (k + 1)) for q in Q30])
+    otable, obase = orc.U32DcrtTable(log_n, Q30), orc.RNSBase32(Q30)
+    obasis = orc.BigUintApproxSignedBasis32(obase, log_basis)
+    assert obasis.decompose_length == ell
+    G = (k + 1) * L * n
+    exp1 = orc.mul_dcrt32_ggsw_to(otable, obase, obasis, k, glwe[:G].copy(), ggsw)
+    # every term is (q - 1)^2 = 1 (mod q) at every position: the sum is the number of terms
+    assert all(int(x) == (k + 1) * ell for x in exp1)
+    table, base = pf.U32DcrtTable(log_n, Q30), pf.RNSBase32(Q30)
+    ctx = pf.DcrtGlevContext32(table, base, pf.BigUintApproxSignedBasis32(base, log_basis), k)
+    out = np.empty_like(glwe)
+    pf.mul_dcrt_ggsw_to(glwe, ggsw, out, ctx)
+    assert np.array_equal(out, np.tile(exp1, batch))
+    # accumulating form on top of a canonical maximum: one GLev row (ell = 18 terms) added to q - 1 everywhere
+    acc = to_dev32(np.concatenate([np.full(n, q - 1, np.uint32) for _ in range(batch * (k + 1)) for q in Q30]))
+    glev = ggsw[:ell * (k + 1) * L * n]
+    pf.add_dcrt_glev_mul_crt_poly_assign_dev(acc, to_dev32(glev), to_dev32(np.tile(poly, batch)), ctx)
+    got = to_host32(acc)
+    assert all(int(x) == (ell - 1) % q for x, q in zip(got[::n], Q30 * (batch * (k + 1))))
+    assert np.array_equal(got, np.tile(np.concatenate([np.full(n, ell - 1, np.uint32)] * L), batch * (k + 1)))
