@@ -1,4 +1,5 @@
 // pfhe_staging.cpp — per-device pool of staging contexts for the host-pointer entry points (pfhe_staging.hpp).
+#include <sys/mman.h>
 #include "pfhe_staging.hpp"
 
 #include <atomic>
@@ -298,20 +299,22 @@ bool HostStage::pin(const void *host, size_t bytes, bool any_size) {
 // apart here and no caller memory is ever mapped.  (2) A second, independent property must hold as well:
 // hipMemGetAddressRange reports a non-null base only for memory the driver allocated (for a registration the base is null,
 // see pin()).  (3) PFHE_STAGE_ZERO_COPY=0 turns the path off altogether.
+// The probe block is two pages of its OWN anonymous mapping, and it stays mapped and registered for the life of the process:
+// pages that have once been registered must never come back as somebody's pageable copy source (the defect located in round
+// 5 lives exactly there — profiles/r05_experiments.txt item 7), which a heap block returned to malloc would.
 static bool host_flags_tell_registrations_apart() {
     static const bool works = [] {
-        void *blk = nullptr;
-        if (posix_memalign(&blk, 4096, 2 * 4096) != 0 || blk == nullptr) return false;
-        bool ok = false;
-        if (hipHostRegister(blk, 2 * 4096, hipHostRegisterDefault) == hipSuccess) {
-            unsigned flags = 0;
-            ok = hipHostGetFlags(&flags, blk) != hipSuccess;  // must be refused for a registration
+        void *blk = mmap(nullptr, 2 * 4096, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (blk == MAP_FAILED) return false;
+        if (hipHostRegister(blk, 2 * 4096, hipHostRegisterDefault) != hipSuccess) {
             (void)hipGetLastError();
-            (void)hipHostUnregister(blk);
+            (void)munmap(blk, 2 * 4096);  // never registered: nothing to keep
+            return false;
         }
+        unsigned flags = 0;
+        const bool ok = hipHostGetFlags(&flags, blk) != hipSuccess;  // must be refused for a registration
         (void)hipGetLastError();
-        std::free(blk);
-        return ok;
+        return ok;  // (the 8 KiB stay registered: see above)
     }();
     return works;
 }

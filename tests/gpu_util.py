@@ -44,3 +44,33 @@ def oracle_map(fn, host: np.ndarray, unit: int, threads: int | None = None):
     chunks = [host[i * unit:min(units, i + per) * unit] for i in range(0, units, per)]
     with ThreadPoolExecutor(threads) as ex:
         list(ex.map(fn, chunks))
+
+
+def isolated(fn):
+    """Run a GPU test in a child pytest process of its own.
+
+    For tests that hipHostRegister heap memory (numpy arrays) on purpose.  The pages of such a block go back to malloc when
+    the array dies and are handed out again — to arrays that torch then copies as PAGEABLE memory — and the runtime / driver
+    defect located in round 5 (profiles/r05_experiments.txt item 7, tools/microbench12_register_hazard.hip: pages that have
+    been both registered and the source of pageable copies) can then surface anywhere later in the same process: once in
+    about twenty full-suite runs a later, unrelated test hung on a device-to-host copy (round 6 soak,
+    profiles/r06_experiments.txt item 7).  In a child process the registrations die with it and the main test process never
+    registers heap memory."""
+    import functools
+    import inspect
+    import os
+    import subprocess
+    import sys
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        if os.environ.get("PFHE_TEST_ISOLATED") == "1":
+            return fn(*args, **kwargs)
+        path = inspect.getsourcefile(fn)
+        env = dict(os.environ, PFHE_TEST_ISOLATED="1")
+        r = subprocess.run([sys.executable, "-m", "pytest", f"{path}::{fn.__name__}", "-q", "-x", "-m", "gpu",
+                            "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(path))))
+        assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-4000:] + r.stderr[-2000:])
+
+    return wrapper

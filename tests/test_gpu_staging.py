@@ -9,7 +9,7 @@ import threading
 import numpy as np
 import pytest
 
-from gpu_util import rand_mod, rand_rns
+from gpu_util import isolated, rand_mod, rand_rns
 from pyref import Q61, Q62
 
 pytestmark = pytest.mark.gpu
@@ -318,6 +318,7 @@ def _default_paths_only():
         pytest.skip("staging path changed by a hazard-probe switch")
 
 
+@isolated
 def test_every_staging_path_is_the_one_meant_and_exact(pf, orc):
     """pfhe_debug_stage_path_count says which way a host-pointer call's bytes travelled: pageable slice up to the bounce
     limit -> kernels on the pool's own pinned buffer; the same slice REGISTERED by the caller -> the pool's buffer too
@@ -371,6 +372,7 @@ def test_every_staging_path_is_the_one_meant_and_exact(pf, orc):
     assert c4[HELPER] == c3[HELPER] + 1
 
 
+@isolated
 def test_slice_spanning_two_registrations_is_not_treated_as_one_pinned_range(pf, orc):
     """pinned first and last bytes do not make a pinned range.  One array whose two halves are registered
     SEPARATELY (two registrations, adjacent): a long slice over both must not be given to the copy engines as one pinned
